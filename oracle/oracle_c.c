@@ -1,0 +1,191 @@
+/* oracle_c.c — plain-C restatement of the reference's symplectic hot path on 64-bit packed rows.
+ *
+ * TEST INFRASTRUCTURE ONLY: linked/loaded by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg as the CHECKER.  The product (symmer_amd/) never loads it.
+ *
+ * Parity status: PINNED — tests/test_oracle_golden.py checks every function here against the golden
+ * fixtures produced by running the reference (oracle/tools/gen_golden.py) and against
+ * oracle/oracle_np.py (itself checked against the imported reference by
+ * oracle/tools/check_oracle_vs_ref.py).  The first-occurrence order of orc_cleanup follows the
+ * published algorithm of qiskit 1.2.4 `unordered_unique` (call site symmer/operators/utils.py:271):
+ * iterate rows in input order, hash-map row -> id, id assigned on first sight.
+ *
+ * Packing (the C-ABI convention): a symplectic row is 2*Wq uint64 words, X words first
+ * then Z words; bit j of word w <-> qubit 64*w + j; padding bits are zero.
+ * Build: gcc -O2 -ffp-contract=off -shared -fPIC   (no FMA contraction: complex products must be the
+ * plain IEEE expression numpy evaluates for exactly representable inputs).
+ * file:line citations are relative to /root/reference/.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+typedef uint64_t u64;
+typedef int64_t i64;
+
+static inline int popc(u64 x) { return __builtin_popcountll(x); }
+
+/* a6 — commutes_termwise (symmer/operators/base.py:938-971, utils.py:63-78):
+ * out[i*M + j] = 1 iff |x_i & z'_j| + |z_i & x'_j| is even. */
+void orc_commutes(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out) {
+    for (i64 i = 0; i < N; ++i) {
+        const u64 *xa = A + i * 2 * Wq, *za = xa + Wq;
+        for (i64 j = 0; j < M; ++j) {
+            const u64 *xb = B + j * 2 * Wq, *zb = xb + Wq;
+            u64 acc = 0;
+            for (int w = 0; w < Wq; ++w) acc ^= (xa[w] & zb[w]) ^ (za[w] & xb[w]);
+            out[i * M + j] = (uint8_t)(!(popc(acc) & 1));
+        }
+    }
+}
+
+/* a2 — Y_count (base.py:604-615) */
+void orc_ycount(const u64 *A, i64 N, int Wq, i64 *out) {
+    for (i64 i = 0; i < N; ++i) {
+        int c = 0;
+        for (int w = 0; w < Wq; ++w) c += popc(A[i * 2 * Wq + w] & A[i * 2 * Wq + Wq + w]);
+        out[i] = c;
+    }
+}
+
+static inline void apply_phase(double re, double im, int e, double *o) {
+    switch (e & 3) {
+        case 0: o[0] = re;  o[1] = im;  break;
+        case 1: o[0] = -im; o[1] = re;  break;
+        case 2: o[0] = -re; o[1] = -im; break;
+        default: o[0] = im; o[1] = -re; break;
+    }
+}
+
+/* a3 — uncleaned all-pairs product (base.py:783-792).
+ * inner op has Ni rows (index i), outer op has No rows (index o); output row o*Ni + i = inner[i]^outer[o].
+ * inner_is_left != 0: the product is inner[i] * outer[o]; else outer[o] * inner[i] (the dagger-swap of
+ * base.py:847-849 folded into one exponent):
+ *   e = (3(Y_i + Y_o) + Y_out + 2 |x_left & z_right|) mod 4 ;  coeff = c_i * c_o * i^e   */
+void orc_mul_allpairs(const u64 *inner, const double *ci, i64 Ni, const u64 *outer, const double *co, i64 No,
+                      int Wq, int inner_is_left, u64 *out_rows, double *out_coeff) {
+    int W = 2 * Wq;
+    i64 *yi = (i64 *)malloc(sizeof(i64) * (size_t)(Ni > 0 ? Ni : 1));
+    i64 *yo = (i64 *)malloc(sizeof(i64) * (size_t)(No > 0 ? No : 1));
+    orc_ycount(inner, Ni, Wq, yi);
+    orc_ycount(outer, No, Wq, yo);
+    for (i64 o = 0; o < No; ++o) {
+        const u64 *ro = outer + o * W;
+        for (i64 i = 0; i < Ni; ++i) {
+            const u64 *ri = inner + i * W;
+            u64 *dst = out_rows + (o * Ni + i) * W;
+            int yout = 0; u64 flip = 0;
+            for (int w = 0; w < Wq; ++w) {
+                u64 x = ri[w] ^ ro[w], z = ri[Wq + w] ^ ro[Wq + w];
+                dst[w] = x; dst[Wq + w] = z;
+                yout += popc(x & z);
+                flip ^= inner_is_left ? (ri[w] & ro[Wq + w]) : (ro[w] & ri[Wq + w]);
+            }
+            int e = (int)((3 * (yi[i] + yo[o]) + yout + 2 * (popc(flip) & 1)) & 3);
+            double ar = ci[2 * i], ai = ci[2 * i + 1], br = co[2 * o], bi = co[2 * o + 1];
+            double re = ar * br - ai * bi, im = ar * bi + ai * br;
+            apply_phase(re, im, e, out_coeff + 2 * (o * Ni + i));
+        }
+    }
+    free(yi); free(yo);
+}
+
+/* a5 — symplectic_cleanup (utils.py:230-279): first-occurrence dedup, sequential sums in input order,
+ * keep |c| > thr (strict) when use_thr.  Returns the number of output rows. */
+static inline u64 mix64(u64 h) { h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ULL; h ^= h >> 33; return h; }
+
+i64 orc_cleanup(const u64 *rows, const double *coeff, i64 T, int W, double thr, int use_thr,
+                u64 *out_rows, double *out_coeff) {
+    if (T == 0) return 0;
+    u64 cap = 16; while (cap < (u64)T * 2) cap <<= 1;
+    i64 *slot = (i64 *)malloc(sizeof(i64) * cap);         /* id of the unique row stored in the slot, -1 = empty */
+    i64 *first = (i64 *)malloc(sizeof(i64) * (size_t)T);  /* first[id] = input index of first occurrence */
+    double *sum = (double *)calloc((size_t)T * 2, sizeof(double));
+    for (u64 s = 0; s < cap; ++s) slot[s] = -1;
+    i64 U = 0;
+    for (i64 t = 0; t < T; ++t) {
+        const u64 *r = rows + t * W;
+        u64 h = 0x9e3779b97f4a7c15ULL;
+        for (int w = 0; w < W; ++w) h = mix64(h ^ r[w]) + 0x9e3779b97f4a7c15ULL * (u64)(w + 1);
+        u64 s = h & (cap - 1);
+        i64 id;
+        for (;;) {
+            id = slot[s];
+            if (id < 0) { id = U++; slot[s] = id; first[id] = t; break; }
+            if (memcmp(rows + first[id] * W, r, sizeof(u64) * (size_t)W) == 0) break;
+            s = (s + 1) & (cap - 1);
+        }
+        sum[2 * id] += coeff[2 * t]; sum[2 * id + 1] += coeff[2 * t + 1];
+    }
+    i64 n_out = 0;
+    for (i64 id = 0; id < U; ++id) {
+        if (use_thr && !(hypot(sum[2 * id], sum[2 * id + 1]) > thr)) continue;
+        memcpy(out_rows + n_out * W, rows + first[id] * W, sizeof(u64) * (size_t)W);
+        out_coeff[2 * n_out] = sum[2 * id]; out_coeff[2 * n_out + 1] = sum[2 * id + 1];
+        ++n_out;
+    }
+    free(slot); free(first); free(sum);
+    return n_out;
+}
+
+/* a8 — _rref_binary (utils.py:292-315) on packed rows: no row swaps, leftmost-set-column pivot,
+ * XOR the pivot row into every other row holding that column.  In place.  Returns the number of
+ * row-XORs performed (sum_i |update_set_i|), the unit of the GF(2) metric.  pivots (may be NULL)
+ * receives the pivot column of each row or -1. */
+i64 orc_rref(u64 *rows, i64 R, i64 Wc, i64 *pivots) {
+    i64 n_xor = 0;
+    for (i64 i = 0; i < R; ++i) {
+        u64 *ri = rows + i * Wc;
+        i64 w0 = 0;
+        while (w0 < Wc && ri[w0] == 0) ++w0;
+        if (pivots) pivots[i] = -1;
+        if (w0 == Wc) continue;
+        int b = __builtin_ctzll(ri[w0]);
+        if (pivots) pivots[i] = w0 * 64 + b;
+        u64 mask = 1ULL << b;
+        for (i64 r = 0; r < R; ++r) {
+            if (r == i) continue;
+            u64 *rr = rows + r * Wc;
+            if (rr[w0] & mask) {
+                for (i64 w = w0; w < Wc; ++w) rr[w] ^= ri[w];   /* words left of the pivot word are zero in row i */
+                ++n_xor;
+            }
+        }
+    }
+    return n_xor;
+}
+
+/* a9 — symmetry generators (independent_op.py:124-126) on packed rows.
+ * Builds the (2n) x (64*Wm + 128*Wq) transposed matrix  [ (H Omega)^T | I ]  with zero padding columns
+ * (they never become pivots, so the reduction equals _cref_binary of the reference's matrix), reduces
+ * it with orc_rref, and writes the identity part of every row whose H part vanished, in row order.
+ * Returns k (number of generators); xor_count (may be NULL) receives the row-XOR count. */
+i64 orc_symmetry_generators(const u64 *H, i64 M, int n, int Wq, u64 *out, i64 *xor_count) {
+    i64 Wm = (M + 63) / 64, Wc = Wm + 2 * Wq, R = 2 * (i64)n;
+    u64 *mat = (u64 *)calloc((size_t)(R * Wc > 0 ? R * Wc : 1), sizeof(u64));
+    for (i64 t = 0; t < M; ++t) {
+        const u64 *row = H + t * 2 * Wq;
+        for (int c = 0; c < n; ++c) {
+            /* column c of [Z|X] is Z[:,c]; column n+c is X[:,c] */
+            if ((row[Wq + c / 64] >> (c % 64)) & 1) mat[(i64)c * Wc + t / 64] |= 1ULL << (t % 64);
+            if ((row[c / 64] >> (c % 64)) & 1) mat[((i64)n + c) * Wc + t / 64] |= 1ULL << (t % 64);
+        }
+    }
+    for (int c = 0; c < n; ++c) {
+        mat[(i64)c * Wc + Wm + c / 64] |= 1ULL << (c % 64);
+        mat[((i64)n + c) * Wc + Wm + Wq + c / 64] |= 1ULL << (c % 64);
+    }
+    i64 nx = orc_rref(mat, R, Wc, NULL);
+    if (xor_count) *xor_count = nx;
+    i64 k = 0;
+    for (i64 r = 0; r < R; ++r) {
+        int zero = 1;
+        for (i64 w = 0; w < Wm; ++w) if (mat[r * Wc + w]) { zero = 0; break; }
+        if (!zero) continue;
+        memcpy(out + k * 2 * Wq, mat + r * Wc + Wm, sizeof(u64) * 2 * (size_t)Wq);
+        ++k;
+    }
+    free(mat);
+    return k;
+}

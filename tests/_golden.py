@@ -1,0 +1,54 @@
+"""Loader for the committed golden fixtures (tests/golden/*.npz; produced by running the reference,
+see oracle/tools/gen_golden.py).  Data only."""
+import os, json
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def family(name):
+    """Yield one dict per case of a fixture family."""
+    z = np.load(os.path.join(GOLDEN, f'{name}.npz'))
+    n = int(z['n_cases'])
+    cases = [dict() for _ in range(n)]
+    for key in z.files:
+        if '/' not in key:
+            continue
+        idx, field = key.split('/', 1)
+        cases[int(idx)][field] = z[key]
+    return cases
+
+
+def known():
+    z = np.load(os.path.join(GOLDEN, 'known.npz'))
+    return {k: z[k] for k in z.files}
+
+
+def known_single_qubit():
+    with open(os.path.join(GOLDEN, 'known_single_qubit.json')) as f:
+        return json.load(f)
+
+
+def as_bool(a):
+    return np.asarray(a).astype(bool)
+
+
+def unpackbits_matrix(packed, shape):
+    R, C = int(shape[0]), int(shape[1])
+    return np.unpackbits(packed, axis=1)[:, :C].astype(bool).reshape(R, C)
+
+
+def assert_op_equal(rows, coeff, exp_rows, exp_coeff, exact=True, tol=1e-12):
+    """Bit-exact rows + row order; coefficients bit-exact (dyadic) or within tol, after dropping on both
+    sides rows with |c| <= tol (the Gaussian 'ghost row' rule of SURVEY §7)."""
+    rows = as_bool(rows); exp_rows = as_bool(exp_rows)
+    coeff = np.asarray(coeff, dtype=complex); exp_coeff = np.asarray(exp_coeff, dtype=complex)
+    if not exact:
+        k1 = np.abs(coeff) > tol; k2 = np.abs(exp_coeff) > tol
+        rows, coeff, exp_rows, exp_coeff = rows[k1], coeff[k1], exp_rows[k2], exp_coeff[k2]
+    assert rows.shape == exp_rows.shape, (rows.shape, exp_rows.shape)
+    assert np.array_equal(rows, exp_rows)
+    if exact:
+        assert np.array_equal(coeff, exp_coeff)
+    else:
+        assert np.allclose(coeff, exp_coeff, rtol=0, atol=tol)
