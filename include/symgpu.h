@@ -1,0 +1,141 @@
+/* symgpu.h — C ABI of libsymgpu.so: the MI355X (gfx950) implementation of Symmer's symplectic hot path.
+ *
+ * The reference (UCL-CCS/symmer) is pure Python and has NO FFI for this path; the seam it offers is the
+ * set of NumPy-level functions below (file:line relative to the reference checkout).  Each entry point
+ * here replaces one of them; `INTEGRATION.md` shows the ctypes stub a Symmer maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every function returns SYMGPU_OK (0) or a negative error code and
+ *    never throws or exits; `symgpu_last_error()` gives the text of the last failure on this thread.
+ *  - host buffers are caller-owned, C-contiguous, and are not retained past the call.
+ *  - packed symplectic row: 2*Wq uint64 words, X words first then Z words, Wq = max(1, ceil(n/64));
+ *    bit j (LSB = 0) of word w <-> qubit 64*w + j; padding bits MUST be zero.
+ *    == np.packbits(block, axis=1, bitorder='little') viewed as '<u8' after zero-padding to 64*Wq columns.
+ *  - GF(2) matrices: R rows of Wc uint64 words, same bit rule; "leftmost column" = lowest set bit of the
+ *    first non-zero word.
+ *  - coefficients: complex128 as interleaved double[2] (re, im).
+ *  - one context per process (one process per GPU); calls are serialised on one HIP stream; a handle is
+ *    single-owner.  Multi-GPU = one process per device + symgpu_comm_* (RCCL over xGMI).
+ */
+#ifndef SYMGPU_H
+#define SYMGPU_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SYMGPU_OK 0
+#define SYMGPU_E_INVALID (-1)   /* bad argument (null pointer, negative size, Wq mismatch, T >= 2^32 for cleanup ...) */
+#define SYMGPU_E_HIP (-2)       /* a HIP runtime call failed; see symgpu_last_error() */
+#define SYMGPU_E_NOMEM (-3)     /* device allocation failed */
+#define SYMGPU_E_CAPACITY (-4)  /* caller-supplied output capacity too small; *n_out holds the required row count */
+#define SYMGPU_E_NODEVICE (-5)  /* no HIP device / symgpu_init not called */
+#define SYMGPU_E_COLLISION (-6) /* row-hash collision survived every reseed (never observed; exactness guard) */
+#define SYMGPU_E_RCCL (-7)      /* RCCL could not be loaded or a collective failed */
+
+typedef struct symgpu_op_s *symgpu_op_t; /* device-resident operator: packed rows (+ optional coefficients) */
+
+/* ---- context -------------------------------------------------------------------------------- */
+int symgpu_init(int device);              /* select device, create stream; idempotent for the same device */
+int symgpu_shutdown(void);
+const char *symgpu_last_error(void);
+int symgpu_device_count(int *n);          /* does not initialise a device */
+int symgpu_sync(void);                    /* wait for the library stream */
+int symgpu_device_name(char *buf, int len);
+int symgpu_mem_info(int64_t *free_bytes, int64_t *total_bytes);
+/* HIP-event timer on the library stream (used by bench.py for per-kernel durations) */
+int symgpu_timer_start(void);
+int symgpu_timer_stop(float *ms);
+
+/* ---- device-resident operators -------------------------------------------------------------- */
+int symgpu_op_upload(const uint64_t *rows, const double *coeff /* may be NULL */, int64_t T, int Wq, symgpu_op_t *out);
+int symgpu_op_alloc(int64_t capacity_rows, int Wq, int with_coeff, symgpu_op_t *out);
+int symgpu_op_download(symgpu_op_t op, uint64_t *rows, double *coeff /* may be NULL */, int64_t capacity_rows);
+int symgpu_op_info(symgpu_op_t op, int64_t *T, int *Wq, int64_t *capacity_rows);
+int symgpu_op_free(symgpu_op_t op);
+int symgpu_op_set_rows(symgpu_op_t op, int64_t T);   /* trim (T <= capacity), e.g. after an all-gather with padding */
+int symgpu_op_random(int64_t T, int n_qubits, double density, uint64_t seed, symgpu_op_t *out); /* synthetic input, generated on device */
+/* XOR-fold of all packed rows (2*Wq words) and plain sum of coefficients: size-independent checksums */
+int symgpu_op_checksum(symgpu_op_t op, uint64_t *xor_words /* [2*Wq] */, double *coeff_sum /* [2] */);
+
+/* ---- a2: PauliwordOp.Y_count  (symmer/operators/base.py:604-615) ----------------------------- */
+int symgpu_ycount(const uint64_t *rows, int64_t T, int Wq, int64_t *out);
+
+/* ---- a6: commutes_termwise / adjacency_matrix (base.py:938-971, 1054-1062; utils.py:9-78) ------
+ * out[i*M + j] = 1 iff A[i] commutes with B[j] (np.bool_ layout of the reference's return value). */
+int symgpu_commutes(const uint64_t *A, int64_t N, const uint64_t *B, int64_t M, int Wq, uint8_t *out);
+/* device-resident; out_dev is a DEVICE pointer obtained from symgpu_dev_alloc (N*M bytes) */
+int symgpu_commutes_dev(symgpu_op_t A, int64_t a_begin, int64_t a_end, symgpu_op_t B, uint8_t *out_dev);
+/* bit-packed variant: out_bits[i*ceil(M/64) + j/64] bit (j%64); 1/8 byte per pair */
+int symgpu_commutes_bits_dev(symgpu_op_t A, int64_t a_begin, int64_t a_end, symgpu_op_t B, uint64_t *out_bits_dev);
+int symgpu_dev_alloc(int64_t bytes, void **ptr);
+int symgpu_dev_free(void *ptr);
+int symgpu_dev_download(const void *dev, void *host, int64_t bytes);
+int symgpu_dev_checksum_u8(const uint8_t *dev, int64_t n, uint64_t *sum); /* sum of bytes (number of commuting pairs) */
+int symgpu_dev_popcount_u64(const uint64_t *dev, int64_t n_words, uint64_t *sum);
+
+/* ---- a3/a4: all-pairs product  (base.py:764-794 `_multiply_by_operator`, :821-859 `__mul__`) ----
+ * Output row o*Ni + i = inner[i] xor outer[o]; coefficient = c_inner[i]*c_outer[o]*i^e with
+ * e = (3(Y_i+Y_o) + Y_out + 2|x_left & z_right|) mod 4, left = inner if inner_is_left else outer
+ * (the reference's dagger-swap for N < M, base.py:847-849, folded into one exponent).  No cleanup. */
+int symgpu_mul_allpairs(const uint64_t *inner, const double *ci, int64_t Ni,
+                        const uint64_t *outer, const double *co, int64_t No, int Wq, int inner_is_left,
+                        uint64_t *out_rows, double *out_coeff);
+/* device-resident slab: outer rows [o_begin, o_end) -> out (capacity >= (o_end-o_begin)*Ni rows) */
+int symgpu_mul_allpairs_dev(symgpu_op_t inner, symgpu_op_t outer, int64_t o_begin, int64_t o_end,
+                            int inner_is_left, symgpu_op_t out);
+
+/* ---- a5: symplectic_cleanup / PauliwordOp.cleanup (utils.py:230-279, base.py:617-638) ------------
+ * Merge duplicate rows (sequential sum in input order), keep |c| > thr (strict) if use_thr, output in
+ * first-occurrence order.  W = words per row (2*Wq).  n_out always receives the row count. */
+int symgpu_cleanup(const uint64_t *rows, const double *coeff, int64_t T, int W, double thr, int use_thr,
+                   uint64_t *out_rows, double *out_coeff, int64_t capacity, int64_t *n_out);
+int symgpu_cleanup_dev(symgpu_op_t in, double thr, int use_thr, symgpu_op_t *out);
+/* product + cleanup fused: product rows are never materialised (linear row hash of pairs) */
+int symgpu_mul_cleanup(const uint64_t *inner, const double *ci, int64_t Ni,
+                       const uint64_t *outer, const double *co, int64_t No, int Wq, int inner_is_left,
+                       double thr, int use_thr,
+                       uint64_t *out_rows, double *out_coeff, int64_t capacity, int64_t *n_out);
+int symgpu_mul_cleanup_dev(symgpu_op_t inner, symgpu_op_t outer, int inner_is_left, double thr, int use_thr,
+                           symgpu_op_t *out);
+
+/* ---- a7: _rotate_by_single_Pword (base.py:1090-1161), one fused pass ------------------------------
+ * clifford_k < 0: non-Clifford: cleanup([commuting, cos*anticommuting, -i*sin*(anticommuting*Q)], thr)
+ * clifford_k >= 0 (= round(2*angle/pi)): [rotated anticommuting rows, commuting rows], no merge;
+ *   odd k: c*i^e*(-i); k in {2,3}: negated (not reduced mod 4, base.py:1148).
+ * *all_commute = 1 (and out untouched / *out = NULL) when every row commutes with Q. */
+int symgpu_rotate_single(const uint64_t *rows, const double *coeff, int64_t N, int Wq, const uint64_t *q_row,
+                         double cos_t, double sin_t, int clifford_k, double thr,
+                         uint64_t *out_rows, double *out_coeff, int64_t capacity, int64_t *n_out, int *all_commute);
+int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double cos_t, double sin_t, int clifford_k,
+                             double thr, symgpu_op_t *out, int *all_commute);
+
+/* ---- a8: _rref_binary (utils.py:292-315): in place, no row swaps, leftmost pivot, eliminate above and
+ * below.  xor_count (may be NULL) = sum_i |update_set_i| as the reference loop performs them.
+ * pivots (may be NULL) = pivot column per row or -1. */
+int symgpu_rref(uint64_t *rows, int64_t R, int64_t Wc, int64_t *xor_count, int64_t *pivots);
+int symgpu_rref_dev(uint64_t *rows_dev, int64_t R, int64_t Wc, int64_t *xor_count, int64_t *pivots_host);
+
+/* ---- a9: IndependentOp.symmetry_generators (independent_op.py:124-126) ----------------------------
+ * H: M packed rows over n qubits.  out: generators as packed rows in the reference's order; *k = count.
+ * capacity in rows (2n always suffices). */
+int symgpu_symmetry_kernel(const uint64_t *H, int64_t M, int n_qubits, int Wq,
+                           uint64_t *out, int64_t capacity, int64_t *k, int64_t *xor_count);
+int symgpu_symmetry_kernel_dev(symgpu_op_t H, int n_qubits, uint64_t *out, int64_t capacity, int64_t *k,
+                               int64_t *xor_count);
+
+/* ---- e: multi-GPU (one process per GPU; RCCL over xGMI) ------------------------------------------- */
+#define SYMGPU_UNIQUE_ID_BYTES 128
+int symgpu_comm_unique_id(uint8_t id[SYMGPU_UNIQUE_ID_BYTES]);                 /* rank 0 */
+int symgpu_comm_init(const uint8_t id[SYMGPU_UNIQUE_ID_BYTES], int rank, int nranks);
+int symgpu_comm_destroy(void);
+/* all-gather equal-sized shards of packed rows (+coefficients if both have them) into `full`
+ * (capacity >= nranks * shard rows); rank r's rows land at [r*T_shard, (r+1)*T_shard). */
+int symgpu_comm_allgather_op(symgpu_op_t shard, symgpu_op_t full);
+int symgpu_comm_barrier(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYMGPU_H */

@@ -1,0 +1,139 @@
+"""ctypes binding of ``libsymgpu.so`` (C ABI declared in ``include/symgpu.h``).
+
+There is NO CPU fallback: if the shared library is missing, or no MI355X is visible, every hot-path
+call raises :class:`SymgpuError`.  The library is built in-tree by ``__graft_entry__.build()``
+(``make -C symmer_amd/csrc``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsymgpu.so')
+
+OK, E_INVALID, E_HIP, E_NOMEM, E_CAPACITY, E_NODEVICE, E_COLLISION, E_RCCL = 0, -1, -2, -3, -4, -5, -6, -7
+_NAMES = {E_INVALID: 'SYMGPU_E_INVALID', E_HIP: 'SYMGPU_E_HIP', E_NOMEM: 'SYMGPU_E_NOMEM',
+          E_CAPACITY: 'SYMGPU_E_CAPACITY', E_NODEVICE: 'SYMGPU_E_NODEVICE', E_COLLISION: 'SYMGPU_E_COLLISION',
+          E_RCCL: 'SYMGPU_E_RCCL'}
+
+
+class SymgpuError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f'{_NAMES.get(code, code)}: {text}')
+        self.code = code
+
+
+c_i64, c_int, c_dbl, c_u64 = ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_uint64
+P = ctypes.c_void_p          # every pointer argument is passed as an address
+PP = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> argument types, exactly the prototypes of include/symgpu.h (all return int unless noted)
+SIGNATURES = {
+    'symgpu_init': [c_int],
+    'symgpu_shutdown': [],
+    'symgpu_device_count': [P],
+    'symgpu_sync': [],
+    'symgpu_device_name': [P, c_int],
+    'symgpu_mem_info': [P, P],
+    'symgpu_timer_start': [],
+    'symgpu_timer_stop': [P],
+    'symgpu_op_upload': [P, P, c_i64, c_int, PP],
+    'symgpu_op_alloc': [c_i64, c_int, c_int, PP],
+    'symgpu_op_download': [P, P, P, c_i64],
+    'symgpu_op_info': [P, P, P, P],
+    'symgpu_op_free': [P],
+    'symgpu_op_set_rows': [P, c_i64],
+    'symgpu_op_random': [c_i64, c_int, c_dbl, c_u64, PP],
+    'symgpu_op_checksum': [P, P, P],
+    'symgpu_ycount': [P, c_i64, c_int, P],
+    'symgpu_commutes': [P, c_i64, P, c_i64, c_int, P],
+    'symgpu_commutes_dev': [P, c_i64, c_i64, P, P],
+    'symgpu_commutes_bits_dev': [P, c_i64, c_i64, P, P],
+    'symgpu_dev_alloc': [c_i64, PP],
+    'symgpu_dev_free': [P],
+    'symgpu_dev_download': [P, P, c_i64],
+    'symgpu_dev_checksum_u8': [P, c_i64, P],
+    'symgpu_dev_popcount_u64': [P, c_i64, P],
+    'symgpu_mul_allpairs': [P, P, c_i64, P, P, c_i64, c_int, c_int, P, P],
+    'symgpu_mul_allpairs_dev': [P, P, c_i64, c_i64, c_int, P],
+    'symgpu_cleanup': [P, P, c_i64, c_int, c_dbl, c_int, P, P, c_i64, P],
+    'symgpu_cleanup_dev': [P, c_dbl, c_int, PP],
+    'symgpu_mul_cleanup': [P, P, c_i64, P, P, c_i64, c_int, c_int, c_dbl, c_int, P, P, c_i64, P],
+    'symgpu_mul_cleanup_dev': [P, P, c_int, c_dbl, c_int, PP],
+    'symgpu_rotate_single': [P, P, c_i64, c_int, P, c_dbl, c_dbl, c_int, c_dbl, P, P, c_i64, P, P],
+    'symgpu_rotate_single_dev': [P, P, c_dbl, c_dbl, c_int, c_dbl, PP, P],
+    'symgpu_rref': [P, c_i64, c_i64, P, P],
+    'symgpu_rref_dev': [P, c_i64, c_i64, P, P],
+    'symgpu_symmetry_kernel': [P, c_i64, c_int, c_int, P, c_i64, P, P],
+    'symgpu_symmetry_kernel_dev': [P, c_int, P, c_i64, P, P],
+    'symgpu_comm_unique_id': [P],
+    'symgpu_comm_init': [P, c_int, c_int],
+    'symgpu_comm_destroy': [],
+    'symgpu_comm_allgather_op': [P, P],
+    'symgpu_comm_barrier': [],
+}
+
+_lib = None
+_initialised_device = None
+
+
+def load():
+    """dlopen libsymgpu.so and attach prototypes (no GPU call)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SymgpuError(E_NODEVICE, f'{LIB_PATH} not found — build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                                      f'or `make -C symmer_amd/csrc` (there is no CPU fallback)')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.symgpu_last_error.restype = ctypes.c_char_p
+    lib.symgpu_last_error.argtypes = []
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().symgpu_last_error().decode('utf-8', 'replace')
+
+
+def check(rc):
+    if rc != OK:
+        raise SymgpuError(rc, last_error())
+
+
+def device_count():
+    n = c_int(0)
+    check(load().symgpu_device_count(ctypes.addressof(n)))
+    return n.value
+
+
+def init(device=None):
+    """Initialise the context on ``device`` (default: $LOCAL_RANK or 0).  Raises if no GPU."""
+    global _initialised_device
+    lib = load()
+    if device is None:
+        device = int(os.environ.get('SYMGPU_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+        if _initialised_device is not None:
+            return _initialised_device
+    if _initialised_device == device:
+        return device
+    n = device_count()
+    if n <= 0:
+        raise SymgpuError(E_NODEVICE, 'no HIP device visible: the symplectic hot path needs an MI355X (no CPU fallback)')
+    check(lib.symgpu_init(device % n))
+    _initialised_device = device % n
+    return _initialised_device
+
+
+def lib():
+    """The loaded library with an initialised context."""
+    init()
+    return _lib
+
+
+def addr(a):
+    """Address of a C-contiguous numpy array (or None)."""
+    return None if a is None else a.ctypes.data

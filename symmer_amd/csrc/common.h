@@ -1,0 +1,111 @@
+// common.h — internal declarations shared by the libsymgpu translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include "../../include/symgpu.h"
+
+typedef uint64_t u64;
+typedef int64_t i64;
+typedef uint32_t u32;
+
+namespace symgpu {
+
+// ---- error handling --------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define HIP_TRY(expr)                                                         \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess) return symgpu::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define SG_TRY(expr)                 \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != SYMGPU_OK) return _rc; \
+    } while (0)
+
+#define SG_REQUIRE(cond, msg)                       \
+    do {                                            \
+        if (!(cond)) {                              \
+            symgpu::set_error("invalid argument: %s (%s)", msg, #cond); \
+            return SYMGPU_E_INVALID;                \
+        }                                           \
+    } while (0)
+
+#define KERNEL_CHECK() HIP_TRY(hipGetLastError())
+
+// ---- context ---------------------------------------------------------------------------------
+struct Context {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int num_cu = 256;
+    // linear-hash tables (cleanup): 8 byte positions x 256 values x {h1,h2}; reseeded on collision
+    u64 *hash_tab = nullptr;       // device, [8][256][2]
+    u64 hash_seed = 0;
+};
+Context &ctx();
+int require_ctx();
+
+// cached device allocator (hipMalloc is slow; rotations chain many small temporaries)
+int dev_alloc(size_t bytes, void **ptr);
+int dev_free(void *ptr);
+void dev_cache_release();
+
+// RAII scratch buffer on the cached allocator
+struct Scratch {
+    void *p = nullptr;
+    Scratch() {}
+    ~Scratch() { if (p) dev_free(p); }
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+    int alloc(size_t bytes) { if (p) { dev_free(p); p = nullptr; } return dev_alloc(bytes ? bytes : 16, &p); }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace symgpu
+
+// ---- device-resident operator ------------------------------------------------------------------
+struct symgpu_op_s {
+    u64 *rows = nullptr;     // [capacity][2*Wq] row-major packed
+    double *coeff = nullptr; // [capacity][2] or null
+    i64 T = 0, capacity = 0;
+    int Wq = 0;
+};
+
+namespace symgpu {
+
+// layout.hip — word-major ("bit-sliced column") copy: out[w][t], t padded to Tpad (zero filled)
+int to_wordmajor(const u64 *rows, i64 T, int W, u64 *out, i64 Tpad);
+// bit-matrix transpose: in R rows x Wc words -> out (64*Wc rows) x ceil(R/64) words, only first C rows written
+int bit_transpose(const u64 *in, i64 R, i64 Wc_in, u64 *out, i64 Wc_out);
+
+// sort.hip
+int exclusive_scan_u32(const u32 *in, u32 *out, i64 n, u32 *total_dev /* may be null: device u32 */);
+int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp, i64 n, int begin_bit, int end_bit,
+                             bool *result_in_tmp);
+
+// commute.hip
+int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits);
+int ycount_dev(const u64 *rows, i64 T, int Wq, int *out);
+
+// product.hip
+int mul_coeff_dev(const u64 *inner, const double *ci, i64 Ni, const u64 *outer, const double *co, i64 o_begin, i64 o_end,
+                  int Wq, int inner_is_left, double *out_coeff);
+int mul_rows_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 o_begin, i64 o_end, int Wq, u64 *out_rows);
+
+// cleanup.hip
+int ensure_hash_tables(u64 seed);
+int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W,          // plain mode (pair mode if inner != null)
+                 const u64 *inner, i64 Ni, const u64 *outer, i64 No,
+                 double thr, int use_thr, symgpu_op_t *out, int Wq_out);
+
+// gf2.hip
+int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host);
+
+}  // namespace symgpu

@@ -1,0 +1,209 @@
+// commute.hip — termwise commutation / adjacency (reference: symmer/operators/base.py:938-971 via
+// matmul_GF2, utils.py:9-78) and Y_count (base.py:604-615).
+//
+//   C[i][j] = NOT parity( |x_i & z'_j| + |z_i & x'_j| )      (True = commute)
+//
+// Roofline: integer-VALU-bound, not HBM-bound.  Per pair and per 64-bit word the kernel issues 4 VALU
+// instructions (two v_bitop3_b32 per 32-bit half: acc ^= xa&zb ; acc ^= za&xb) and one popcount-parity
+// at the very end (parity of a sum of popcounts == parity of the popcount of the XOR).  Operands are
+// tiny (N*16*Wq bytes) and stay in L2/MALL; the only HBM stream is the 1 B/pair (or 1 bit/pair) output.
+//
+// Mapping (64-wide wavefronts): both operands are first re-laid word-major (layout.hip).  One wave owns
+// 8 rows of A x 256 columns of B: the 8 A-words of a word index arrive in SGPRs through a single
+// s_load_dwordx16 (wave-uniform address), the B-words are 4 coalesced 512-byte vector loads, and every
+// lane keeps 8x4 64-bit XOR accumulators in VGPRs.  No LDS is needed: nothing is shared between lanes.
+#include "common.h"
+
+namespace symgpu {
+
+constexpr int CI = 8;    // A rows per wave (SGPR operand)
+constexpr int CJ = 4;    // B columns per lane: j = jbase + 64*b + lane
+constexpr int WAVES = 4; // waves per block, stacked along i
+
+// gfx950 v_bitop3_b32 with truth table 0x78: acc ^ (b & c) in ONE VALU instruction
+__device__ __forceinline__ u32 xor_and(u32 acc, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(acc, b, c, 0x78); }
+
+template <bool BITS>
+__global__ __launch_bounds__(256) void k_commutes(const u64 *__restrict__ At, i64 Npad, i64 N,
+                                                   const u64 *__restrict__ Bt, i64 Mpad, i64 M, int Wq,
+                                                   uint8_t *__restrict__ out, i64 out_stride, u64 *__restrict__ out_bits, i64 bits_stride) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const i64 i0 = ((i64)blockIdx.x * WAVES + wave) * CI;   // wave-uniform
+    const i64 jbase = (i64)blockIdx.y * (64 * CJ);
+    if (i0 >= Npad) return;
+
+    u32 acc_lo[CI][CJ], acc_hi[CI][CJ];
+#pragma unroll
+    for (int a = 0; a < CI; ++a)
+#pragma unroll
+        for (int b = 0; b < CJ; ++b) acc_lo[a][b] = acc_hi[a][b] = 0;
+
+    const u64 *pax = At + i0;                    // x words of A: At[w][i]
+    const u64 *paz = At + (i64)Wq * Npad + i0;   // z words
+    const u64 *pbx = Bt + jbase + lane;
+    const u64 *pbz = Bt + (i64)Wq * Mpad + jbase + lane;
+
+    for (int w = 0; w < Wq; ++w) {
+        u64 xb[CJ], zb[CJ];
+#pragma unroll
+        for (int b = 0; b < CJ; ++b) {
+            xb[b] = pbx[(i64)w * Mpad + 64 * b];
+            zb[b] = pbz[(i64)w * Mpad + 64 * b];
+        }
+        u64 xa[CI], za[CI];
+#pragma unroll
+        for (int a = 0; a < CI; ++a) {
+            xa[a] = pax[(i64)w * Npad + a];   // uniform -> scalar loads
+            za[a] = paz[(i64)w * Npad + a];
+        }
+#pragma unroll
+        for (int a = 0; a < CI; ++a)
+#pragma unroll
+            for (int b = 0; b < CJ; ++b) {
+                // acc ^= (xa & zb) ^ (za & xb): two v_bitop3_b32 (truth table 0x78 = a ^ (b & c)) per 32-bit half
+                acc_lo[a][b] = xor_and(xor_and(acc_lo[a][b], (u32)xa[a], (u32)zb[b]), (u32)za[a], (u32)xb[b]);
+                acc_hi[a][b] = xor_and(xor_and(acc_hi[a][b], (u32)(xa[a] >> 32), (u32)(zb[b] >> 32)), (u32)(za[a] >> 32), (u32)(xb[b] >> 32));
+            }
+    }
+
+#pragma unroll
+    for (int a = 0; a < CI; ++a) {
+        const i64 i = i0 + a;
+#pragma unroll
+        for (int b = 0; b < CJ; ++b) {
+            const i64 j = jbase + 64 * b + lane;
+            const bool commute = !(__popc(acc_lo[a][b] ^ acc_hi[a][b]) & 1);
+            if (BITS) {
+                const u64 m = __ballot(commute && j < M);
+                if (lane == 0 && i < N && jbase + 64 * b < M) out_bits[i * bits_stride + (jbase >> 6) + b] = m;
+            } else {
+                if (i < N && j < M) out[i * out_stride + j] = commute ? 1 : 0;
+            }
+        }
+    }
+}
+
+// Y_count: one lane group per row on row-major packed rows (tiny, O(T*Wq))
+__global__ void k_ycount(const u64 *__restrict__ rows, i64 T, int Wq, int *__restrict__ out) {
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (i64)gridDim.x * blockDim.x) {
+        const u64 *r = rows + t * 2 * Wq;
+        int c = 0;
+        for (int w = 0; w < Wq; ++w) c += __popcll(r[w] & r[Wq + w]);
+        out[t] = c;
+    }
+}
+
+int ycount_dev(const u64 *rows, i64 T, int Wq, int *out) {
+    if (T == 0) return SYMGPU_OK;
+    int grid = (int)((T + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_ycount, dim3(grid), dim3(256), 0, ctx().stream, rows, T, Wq, out);
+    KERNEL_CHECK();
+    return SYMGPU_OK;
+}
+
+static i64 round_up(i64 x, i64 m) { return (x + m - 1) / m * m; }
+
+// A: N rows, B: M rows, row-major packed device pointers.  Exactly one of out / out_bits is non-null.
+int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits) {
+    if (N == 0 || M == 0) return SYMGPU_OK;
+    const int W = 2 * Wq;
+    const i64 Npad = round_up(N, CI * WAVES), Mpad = round_up(M, 64 * CJ);
+    Scratch at, bt;
+    SG_TRY(at.alloc((size_t)Npad * W * sizeof(u64)));
+    SG_TRY(to_wordmajor(A, N, W, at.as<u64>(), Npad));
+    const u64 *Bt = nullptr;
+    if (B == A && M == N && Mpad == Npad) {
+        Bt = at.as<u64>();
+    } else {
+        SG_TRY(bt.alloc((size_t)Mpad * W * sizeof(u64)));
+        SG_TRY(to_wordmajor(B, M, W, bt.as<u64>(), Mpad));
+        Bt = bt.as<u64>();
+    }
+    // blockIdx.x walks along i (fast) so that consecutive blocks reuse the same B column tile from L2
+    const i64 gx = Npad / (CI * WAVES), gy = Mpad / (64 * CJ);
+    // grid.y is limited to 65535: loop over column super-tiles if needed
+    const i64 max_gy = 65535;
+    for (i64 y0 = 0; y0 < gy; y0 += max_gy) {
+        i64 ny = gy - y0 < max_gy ? gy - y0 : max_gy;
+        const i64 joff = y0 * 64 * CJ;
+        dim3 grid((unsigned)gx, (unsigned)ny);
+        if (out_bits) {
+            const i64 stride = (M + 63) / 64;
+            hipLaunchKernelGGL(k_commutes<true>, grid, dim3(256), 0, ctx().stream, at.as<u64>(), Npad, N,
+                               Bt + joff, Mpad, M - joff, Wq, (uint8_t *)nullptr, (i64)0, out_bits + (joff >> 6), stride);
+        } else {
+            // shift the output base so that column j of this launch maps to joff + j of the full row
+            hipLaunchKernelGGL(k_commutes<false>, grid, dim3(256), 0, ctx().stream, at.as<u64>(), Npad, N,
+                               Bt + joff, Mpad, M - joff, Wq, out + joff, M, (u64 *)nullptr, (i64)0);
+        }
+        KERNEL_CHECK();
+    }
+    return SYMGPU_OK;
+}
+
+}  // namespace symgpu
+
+using namespace symgpu;
+
+extern "C" {
+
+int symgpu_ycount(const uint64_t *rows, int64_t T, int Wq, int64_t *out) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(T >= 0 && Wq >= 1 && (T == 0 || (rows && out)), "ycount");
+    if (T == 0) return SYMGPU_OK;
+    Scratch d, o;
+    SG_TRY(d.alloc((size_t)T * 2 * Wq * sizeof(u64)));
+    SG_TRY(o.alloc((size_t)T * sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(d.p, rows, (size_t)T * 2 * Wq * sizeof(u64), hipMemcpyHostToDevice, ctx().stream));
+    SG_TRY(ycount_dev(d.as<u64>(), T, Wq, o.as<int>()));
+    int *h = (int *)malloc((size_t)T * sizeof(int));
+    if (!h) { set_error("host allocation failed"); return SYMGPU_E_NOMEM; }
+    hipError_t e = hipMemcpyAsync(h, o.p, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, ctx().stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
+    if (e != hipSuccess) { free(h); return hip_fail(e, "ycount download", __FILE__, __LINE__); }
+    for (i64 t = 0; t < T; ++t) out[t] = h[t];
+    free(h);
+    return SYMGPU_OK;
+}
+
+int symgpu_commutes_dev(symgpu_op_t A, int64_t a_begin, int64_t a_end, symgpu_op_t B, uint8_t *out_dev) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(A && B && A->Wq == B->Wq, "commutes_dev: operands must share Wq");
+    SG_REQUIRE(0 <= a_begin && a_begin <= a_end && a_end <= A->T, "commutes_dev: bad row range");
+    SG_REQUIRE(out_dev || a_end == a_begin || B->T == 0, "commutes_dev: null output");
+    return commutes_dev(A->rows + a_begin * 2 * A->Wq, a_end - a_begin, B->rows, B->T, A->Wq, out_dev, nullptr);
+}
+
+int symgpu_commutes_bits_dev(symgpu_op_t A, int64_t a_begin, int64_t a_end, symgpu_op_t B, uint64_t *out_bits_dev) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(A && B && A->Wq == B->Wq, "commutes_bits_dev: operands must share Wq");
+    SG_REQUIRE(0 <= a_begin && a_begin <= a_end && a_end <= A->T, "commutes_bits_dev: bad row range");
+    SG_REQUIRE(out_bits_dev || a_end == a_begin || B->T == 0, "commutes_bits_dev: null output");
+    return commutes_dev(A->rows + a_begin * 2 * A->Wq, a_end - a_begin, B->rows, B->T, A->Wq, nullptr, out_bits_dev);
+}
+
+int symgpu_commutes(const uint64_t *A, int64_t N, const uint64_t *B, int64_t M, int Wq, uint8_t *out) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(N >= 0 && M >= 0 && Wq >= 1, "commutes: sizes");
+    if (N == 0 || M == 0) return SYMGPU_OK;
+    SG_REQUIRE(A && B && out, "commutes: null pointer");
+    const size_t rb = (size_t)2 * Wq * sizeof(u64);
+    Scratch da, db, dout;
+    SG_TRY(da.alloc((size_t)N * rb));
+    HIP_TRY(hipMemcpyAsync(da.p, A, (size_t)N * rb, hipMemcpyHostToDevice, ctx().stream));
+    const u64 *pb = da.as<u64>();
+    if (!(B == A && M == N)) {
+        SG_TRY(db.alloc((size_t)M * rb));
+        HIP_TRY(hipMemcpyAsync(db.p, B, (size_t)M * rb, hipMemcpyHostToDevice, ctx().stream));
+        pb = db.as<u64>();
+    }
+    SG_TRY(dout.alloc((size_t)N * (size_t)M));
+    SG_TRY(commutes_dev(da.as<u64>(), N, pb, M, Wq, dout.as<uint8_t>(), nullptr));
+    HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)N * (size_t)M, hipMemcpyDeviceToHost, ctx().stream));
+    HIP_TRY(hipStreamSynchronize(ctx().stream));
+    return SYMGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,466 @@
+// context.hip — context, error text, cached device allocator, operator handles, timers, checksums.
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <vector>
+#include <mutex>
+
+namespace symgpu {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    set_error("HIP error %d (%s) in `%s` at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return e == hipErrorOutOfMemory ? SYMGPU_E_NOMEM : SYMGPU_E_HIP;
+}
+
+static Context g_ctx;
+Context &ctx() { return g_ctx; }
+
+int require_ctx() {
+    if (!g_ctx.ready) {
+        set_error("symgpu_init() has not been called (or no HIP device)");
+        return SYMGPU_E_NODEVICE;
+    }
+    return SYMGPU_OK;
+}
+
+// ---- cached allocator: power-of-two-ish size classes, blocks kept until shutdown/release ----------
+static std::mutex g_alloc_mu;
+static std::multimap<size_t, void *> g_free;      // size class -> block
+static std::map<void *, size_t> g_live;           // block -> size class
+static size_t g_cached_bytes = 0;
+static const size_t kCacheLimit = (size_t)64 << 30;  // keep at most 64 GiB parked
+
+static size_t size_class(size_t b) {
+    if (b < 256) b = 256;
+    if (b <= ((size_t)1 << 20)) {           // <= 1 MiB: next power of two
+        size_t c = 256;
+        while (c < b) c <<= 1;
+        return c;
+    }
+    size_t g = (size_t)1 << 20;             // above: 1 MiB granularity rounded to 1/8 of the leading power
+    size_t p = g;
+    while ((p << 1) <= b) p <<= 1;
+    size_t step = p >> 3;
+    if (step < g) step = g;
+    return (b + step - 1) / step * step;
+}
+
+int dev_alloc(size_t bytes, void **ptr) {
+    SG_TRY(require_ctx());
+    size_t c = size_class(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        auto it = g_free.find(c);
+        if (it != g_free.end()) {
+            *ptr = it->second;
+            g_free.erase(it);
+            g_cached_bytes -= c;
+            g_live[*ptr] = c;
+            return SYMGPU_OK;
+        }
+    }
+    hipError_t e = hipMalloc(ptr, c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        dev_cache_release();
+        e = hipMalloc(ptr, c);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("device allocation of %zu bytes failed: %s", c, hipGetErrorString(e));
+            *ptr = nullptr;
+            return SYMGPU_E_NOMEM;
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    g_live[*ptr] = c;
+    return SYMGPU_OK;
+}
+
+int dev_free(void *ptr) {
+    if (!ptr) return SYMGPU_OK;
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    auto it = g_live.find(ptr);
+    if (it == g_live.end()) {
+        set_error("dev_free: unknown pointer");
+        return SYMGPU_E_INVALID;
+    }
+    size_t c = it->second;
+    g_live.erase(it);
+    if (g_cached_bytes + c > kCacheLimit) {
+        // stream-ordered safety: everything runs on one stream, but hipFree synchronises anyway
+        (void)hipFree(ptr);
+    } else {
+        g_free.insert({c, ptr});
+        g_cached_bytes += c;
+    }
+    return SYMGPU_OK;
+}
+
+void dev_cache_release() {
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
+    for (auto &kv : g_free) (void)hipFree(kv.second);
+    g_free.clear();
+    g_cached_bytes = 0;
+}
+
+// ---- small kernels -----------------------------------------------------------------------------
+__global__ void k_xor_fold(const u64 *__restrict__ rows, i64 T, int W, u64 *__restrict__ out) {
+    // out[w] ^= XOR over rows; one block per grid-stride chunk, lanes over (row, word) pairs
+    extern __shared__ u64 s_fold[];
+    for (int w = threadIdx.x; w < W; w += blockDim.x) s_fold[w] = 0;
+    __syncthreads();
+    i64 total = T * (i64)W;
+    for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (i64)gridDim.x * blockDim.x) {
+        int w = (int)(idx % W);
+        atomicXor((unsigned long long *)&s_fold[w], (unsigned long long)rows[idx]);
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < W; w += blockDim.x)
+        if (s_fold[w]) atomicXor((unsigned long long *)&out[w], (unsigned long long)s_fold[w]);
+}
+
+__global__ void k_sum_f64x2(const double *__restrict__ c, i64 T, double *__restrict__ out) {
+    double re = 0, im = 0;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (i64)gridDim.x * blockDim.x) {
+        re += c[2 * t];
+        im += c[2 * t + 1];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        re += __shfl_down(re, off);
+        im += __shfl_down(im, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], re);
+        atomicAdd(&out[1], im);
+    }
+}
+
+__global__ void k_sum_u8(const uint8_t *__restrict__ p, i64 n, unsigned long long *__restrict__ out) {
+    unsigned long long s = 0;
+    i64 n16 = n / 16;
+    const uint4 *p4 = reinterpret_cast<const uint4 *>(p);
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (i64)gridDim.x * blockDim.x) {
+        uint4 v = p4[i];
+        // bytes are 0/1: popcount counts them
+        s += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (i64 i = n16 * 16; i < n; ++i) s += p[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+__global__ void k_popc_u64(const u64 *__restrict__ p, i64 n, unsigned long long *__restrict__ out) {
+    unsigned long long s = 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) s += __popcll(p[i]);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+__device__ __forceinline__ u64 splitmix64(u64 x) {
+    x += 0x9e3779b97f4a7c15ULL;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    return x ^ (x >> 31);
+}
+
+// synthetic operator: each bit set with probability `density` (compared on 16-bit slices of a counter hash),
+// coefficients from a Box-Muller pair; padding bits zero.
+__global__ void k_random_op(u64 *__restrict__ rows, double *__restrict__ coeff, i64 T, int n, int Wq, u32 thresh16, u64 seed) {
+    i64 total = T * (i64)(2 * Wq);
+    for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (i64)gridDim.x * blockDim.x) {
+        int w = (int)(idx % (2 * Wq));
+        int wq = w % Wq;
+        u64 word = 0;
+        for (int g = 0; g < 16; ++g) {
+            u64 r = splitmix64(seed ^ (u64)idx * 16 + g);
+            for (int k = 0; k < 4; ++k) {
+                int bit = g * 4 + k;
+                if (((r >> (16 * k)) & 0xffff) < thresh16 && wq * 64 + bit < n) word |= 1ULL << bit;
+            }
+        }
+        rows[idx] = word;
+    }
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (i64)gridDim.x * blockDim.x) {
+        u64 a = splitmix64(seed ^ 0xabcdef12345ULL ^ (u64)t * 2), b = splitmix64(seed ^ 0xabcdef12345ULL ^ ((u64)t * 2 + 1));
+        double u1 = ((a >> 11) + 1.0) * (1.0 / 9007199254740993.0), u2 = (b >> 11) * (1.0 / 9007199254740992.0);
+        double r = sqrt(-2.0 * log(u1));
+        coeff[2 * t] = r * cos(6.283185307179586 * u2);
+        coeff[2 * t + 1] = r * sin(6.283185307179586 * u2);
+    }
+}
+
+}  // namespace symgpu
+
+using namespace symgpu;
+
+extern "C" {
+
+const char *symgpu_last_error(void) { return g_err; }
+
+int symgpu_device_count(int *n) {
+    if (!n) return SYMGPU_E_INVALID;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { (void)hipGetLastError(); c = 0; }
+    *n = c;
+    return SYMGPU_OK;
+}
+
+int symgpu_init(int device) {
+    Context &c = ctx();
+    if (c.ready) {
+        if (c.device == device) return SYMGPU_OK;
+        set_error("symgpu_init: already initialised on device %d", c.device);
+        return SYMGPU_E_INVALID;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return SYMGPU_E_NODEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (have %d)", device, n);
+        return SYMGPU_E_INVALID;
+    }
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c.ev0));
+    HIP_TRY(hipEventCreate(&c.ev1));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c.device = device;
+    c.ready = true;
+    return SYMGPU_OK;
+}
+
+int symgpu_shutdown(void) {
+    Context &c = ctx();
+    if (!c.ready) return SYMGPU_OK;
+    (void)hipStreamSynchronize(c.stream);
+    dev_cache_release();
+    if (c.hash_tab) { (void)hipFree(c.hash_tab); c.hash_tab = nullptr; }
+    (void)hipEventDestroy(c.ev0);
+    (void)hipEventDestroy(c.ev1);
+    (void)hipStreamDestroy(c.stream);
+    c.ready = false;
+    c.device = -1;
+    return SYMGPU_OK;
+}
+
+int symgpu_sync(void) {
+    SG_TRY(require_ctx());
+    HIP_TRY(hipStreamSynchronize(ctx().stream));
+    return SYMGPU_OK;
+}
+
+int symgpu_device_name(char *buf, int len) {
+    SG_TRY(require_ctx());
+    if (!buf || len <= 0) return SYMGPU_E_INVALID;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx().device));
+    snprintf(buf, (size_t)len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return SYMGPU_OK;
+}
+
+int symgpu_mem_info(int64_t *free_bytes, int64_t *total_bytes) {
+    SG_TRY(require_ctx());
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return SYMGPU_OK;
+}
+
+int symgpu_timer_start(void) {
+    SG_TRY(require_ctx());
+    HIP_TRY(hipEventRecord(ctx().ev0, ctx().stream));
+    return SYMGPU_OK;
+}
+
+int symgpu_timer_stop(float *ms) {
+    SG_TRY(require_ctx());
+    HIP_TRY(hipEventRecord(ctx().ev1, ctx().stream));
+    HIP_TRY(hipEventSynchronize(ctx().ev1));
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, ctx().ev0, ctx().ev1));
+    if (ms) *ms = t;
+    return SYMGPU_OK;
+}
+
+// ---- raw device buffers ------------------------------------------------------------------------
+int symgpu_dev_alloc(int64_t bytes, void **ptr) {
+    SG_REQUIRE(ptr && bytes >= 0, "dev_alloc");
+    return dev_alloc((size_t)bytes, ptr);
+}
+int symgpu_dev_free(void *ptr) { return dev_free(ptr); }
+
+int symgpu_dev_download(const void *dev, void *host, int64_t bytes) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(dev && host && bytes >= 0, "dev_download");
+    HIP_TRY(hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx().stream));
+    HIP_TRY(hipStreamSynchronize(ctx().stream));
+    return SYMGPU_OK;
+}
+
+static int reduce_to_host_u64(void (*launch)(const void *, i64, unsigned long long *, hipStream_t), const void *p, i64 n, uint64_t *sum) {
+    Scratch acc;
+    SG_TRY(acc.alloc(sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(acc.p, 0, sizeof(unsigned long long), ctx().stream));
+    launch(p, n, acc.as<unsigned long long>(), ctx().stream);
+    KERNEL_CHECK();
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, acc.p, sizeof(h), hipMemcpyDeviceToHost, ctx().stream));
+    HIP_TRY(hipStreamSynchronize(ctx().stream));
+    *sum = h;
+    return SYMGPU_OK;
+}
+
+int symgpu_dev_checksum_u8(const uint8_t *dev, int64_t n, uint64_t *sum) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(dev && sum && n >= 0, "dev_checksum_u8");
+    SG_REQUIRE(((uintptr_t)dev & 15) == 0, "dev_checksum_u8: pointer must be 16-byte aligned");
+    return reduce_to_host_u64([](const void *p, i64 n_, unsigned long long *o, hipStream_t s) {
+        hipLaunchKernelGGL(k_sum_u8, dim3(2048), dim3(256), 0, s, (const uint8_t *)p, n_, o); }, dev, n, sum);
+}
+
+int symgpu_dev_popcount_u64(const uint64_t *dev, int64_t n_words, uint64_t *sum) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(dev && sum && n_words >= 0, "dev_popcount_u64");
+    return reduce_to_host_u64([](const void *p, i64 n_, unsigned long long *o, hipStream_t s) {
+        hipLaunchKernelGGL(k_popc_u64, dim3(2048), dim3(256), 0, s, (const u64 *)p, n_, o); }, dev, n_words, sum);
+}
+
+// ---- operator handles ----------------------------------------------------------------------------
+int symgpu_op_alloc(int64_t capacity_rows, int Wq, int with_coeff, symgpu_op_t *out) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(out && capacity_rows >= 0 && Wq >= 1, "op_alloc");
+    symgpu_op_s *op = new symgpu_op_s();
+    op->Wq = Wq;
+    op->capacity = capacity_rows;
+    op->T = 0;
+    int rc = dev_alloc((size_t)capacity_rows * 2 * Wq * sizeof(u64), (void **)&op->rows);
+    if (rc == SYMGPU_OK && with_coeff) rc = dev_alloc((size_t)capacity_rows * 2 * sizeof(double), (void **)&op->coeff);
+    if (rc != SYMGPU_OK) {
+        if (op->rows) dev_free(op->rows);
+        delete op;
+        return rc;
+    }
+    *out = op;
+    return SYMGPU_OK;
+}
+
+int symgpu_op_free(symgpu_op_t op) {
+    if (!op) return SYMGPU_OK;
+    if (op->rows) dev_free(op->rows);
+    if (op->coeff) dev_free(op->coeff);
+    delete op;
+    return SYMGPU_OK;
+}
+
+int symgpu_op_set_rows(symgpu_op_t op, int64_t T) {
+    SG_REQUIRE(op && T >= 0 && T <= op->capacity, "op_set_rows");
+    op->T = T;
+    return SYMGPU_OK;
+}
+
+int symgpu_op_upload(const uint64_t *rows, const double *coeff, int64_t T, int Wq, symgpu_op_t *out) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(out && T >= 0 && Wq >= 1 && (rows || T == 0), "op_upload");
+    symgpu_op_t op = nullptr;
+    SG_TRY(symgpu_op_alloc(T, Wq, coeff != nullptr, &op));
+    op->T = T;
+    if (T > 0) {
+        hipError_t e = hipMemcpyAsync(op->rows, rows, (size_t)T * 2 * Wq * sizeof(u64), hipMemcpyHostToDevice, ctx().stream);
+        if (e == hipSuccess && coeff) e = hipMemcpyAsync(op->coeff, coeff, (size_t)T * 2 * sizeof(double), hipMemcpyHostToDevice, ctx().stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);   // host buffers are not retained past the call
+        if (e != hipSuccess) { symgpu_op_free(op); return hip_fail(e, "op_upload memcpy", __FILE__, __LINE__); }
+    }
+    *out = op;
+    return SYMGPU_OK;
+}
+
+int symgpu_op_download(symgpu_op_t op, uint64_t *rows, double *coeff, int64_t capacity_rows) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(op, "op_download: null handle");
+    if (capacity_rows < op->T) {
+        set_error("op_download: capacity %lld < %lld rows", (long long)capacity_rows, (long long)op->T);
+        return SYMGPU_E_CAPACITY;
+    }
+    if (op->T > 0) {
+        if (rows) HIP_TRY(hipMemcpyAsync(rows, op->rows, (size_t)op->T * 2 * op->Wq * sizeof(u64), hipMemcpyDeviceToHost, ctx().stream));
+        if (coeff) {
+            SG_REQUIRE(op->coeff, "op_download: operator has no coefficients");
+            HIP_TRY(hipMemcpyAsync(coeff, op->coeff, (size_t)op->T * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(ctx().stream));
+    return SYMGPU_OK;
+}
+
+int symgpu_op_info(symgpu_op_t op, int64_t *T, int *Wq, int64_t *capacity_rows) {
+    SG_REQUIRE(op, "op_info: null handle");
+    if (T) *T = op->T;
+    if (Wq) *Wq = op->Wq;
+    if (capacity_rows) *capacity_rows = op->capacity;
+    return SYMGPU_OK;
+}
+
+int symgpu_op_random(int64_t T, int n_qubits, double density, uint64_t seed, symgpu_op_t *out) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(out && T >= 0 && n_qubits >= 1 && density >= 0.0 && density <= 1.0, "op_random");
+    int Wq = (n_qubits + 63) / 64;
+    symgpu_op_t op = nullptr;
+    SG_TRY(symgpu_op_alloc(T, Wq, 1, &op));
+    op->T = T;
+    if (T > 0) {
+        u32 th = (u32)(density * 65536.0 + 0.5);
+        hipLaunchKernelGGL(k_random_op, dim3(4096), dim3(256), 0, ctx().stream, op->rows, op->coeff, T, n_qubits, Wq, th, seed);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { symgpu_op_free(op); return hip_fail(e, "k_random_op", __FILE__, __LINE__); }
+    }
+    *out = op;
+    return SYMGPU_OK;
+}
+
+int symgpu_op_checksum(symgpu_op_t op, uint64_t *xor_words, double *coeff_sum) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(op, "op_checksum: null handle");
+    int W = 2 * op->Wq;
+    Scratch acc;
+    SG_TRY(acc.alloc((size_t)W * sizeof(u64) + 2 * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(acc.p, 0, (size_t)W * sizeof(u64) + 2 * sizeof(double), ctx().stream));
+    u64 *dx = acc.as<u64>();
+    double *dc = reinterpret_cast<double *>(dx + W);
+    if (op->T > 0) {
+        if (xor_words) {
+            hipLaunchKernelGGL(k_xor_fold, dim3(1024), dim3(256), (size_t)W * sizeof(u64), ctx().stream, op->rows, op->T, W, dx);
+            KERNEL_CHECK();
+        }
+        if (coeff_sum && op->coeff) {
+            hipLaunchKernelGGL(k_sum_f64x2, dim3(1024), dim3(256), 0, ctx().stream, op->coeff, op->T, dc);
+            KERNEL_CHECK();
+        }
+    }
+    if (xor_words) HIP_TRY(hipMemcpyAsync(xor_words, dx, (size_t)W * sizeof(u64), hipMemcpyDeviceToHost, ctx().stream));
+    if (coeff_sum) HIP_TRY(hipMemcpyAsync(coeff_sum, dc, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+    HIP_TRY(hipStreamSynchronize(ctx().stream));
+    return SYMGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+// sort.hip — device-wide exclusive scan and stable LSD radix sort of (u64 key, u32 value) pairs.
+//
+// Used by term cleanup (reference: symplectic_cleanup, symmer/operators/utils.py:230-279) to group equal
+// rows: keys are 64-bit GF(2)-linear row hashes, values are input indices.  The sort is STABLE, so inside
+// a run of equal keys the values stay in ascending input order — which is exactly the order in which the
+// reference's `np.add.at` accumulates duplicate coefficients (utils.py:273-274).
+//
+// HBM-bound: per 8-bit pass each element is read twice (histogram + scatter: 8 B + 12 B) and written once
+// (12 B).  Tiles of 4096 elements are ranked with 64-wide wavefront ballots (one match mask per lane from 8
+// __ballot calls), staged through LDS in digit order and written out as contiguous per-digit runs.
+#include "common.h"
+
+namespace symgpu {
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan (u32), 2048 elements per block, recursive over block sums
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;
+
+__device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        u32 n = __shfl_up(v, off);
+        if (lane >= off) v += n;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix, *total = block sum
+__device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32 *s_wave /* [4] */, u32 *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 incl = wave_incl_scan(v, lane);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    u32 off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        u32 s = s_wave[k];
+        if (k < wave) off += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return off + incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_block(const u32 *__restrict__ in, u32 *__restrict__ out, i64 n, u32 *__restrict__ block_sums) {
+    __shared__ u32 s_wave[4];
+    const i64 base = (i64)blockIdx.x * SCAN_BLOCK + (i64)threadIdx.x * SCAN_ITEMS;
+    u32 v[SCAN_ITEMS];
+    u32 sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        sum += v[k];
+    }
+    u32 total;
+    u32 excl = block_excl_scan_256(sum, s_wave, &total);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = excl;
+        excl += v[k];
+    }
+    if (threadIdx.x == 0 && block_sums) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(u32 *__restrict__ out, i64 n, const u32 *__restrict__ block_offsets) {
+    const i64 base = (i64)blockIdx.x * SCAN_BLOCK + (i64)threadIdx.x * SCAN_ITEMS;
+    const u32 off = block_offsets[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) out[base + k] += off;
+}
+
+__global__ void k_store_total(const u32 *__restrict__ last_in, const u32 *__restrict__ last_out, u32 *__restrict__ total) {
+    *total = *last_in + *last_out;
+}
+
+// out may alias in.  total_dev (optional, device) receives the sum of all n inputs.
+int exclusive_scan_u32(const u32 *in, u32 *out, i64 n, u32 *total_dev) {
+    hipStream_t st = ctx().stream;
+    if (n <= 0) {
+        if (total_dev) HIP_TRY(hipMemsetAsync(total_dev, 0, sizeof(u32), st));
+        return SYMGPU_OK;
+    }
+    const i64 nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    Scratch last;   // keep in[n-1] before it is overwritten (aliasing) to form the total
+    if (total_dev) {
+        SG_TRY(last.alloc(sizeof(u32)));
+        HIP_TRY(hipMemcpyAsync(last.p, in + (n - 1), sizeof(u32), hipMemcpyDeviceToDevice, st));
+    }
+    if (nb == 1) {
+        hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(256), 0, st, in, out, n, (u32 *)nullptr);
+        KERNEL_CHECK();
+    } else {
+        Scratch sums;
+        SG_TRY(sums.alloc((size_t)nb * sizeof(u32)));
+        hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(256), 0, st, in, out, n, sums.as<u32>());
+        KERNEL_CHECK();
+        SG_TRY(exclusive_scan_u32(sums.as<u32>(), sums.as<u32>(), nb, nullptr));
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(256), 0, st, out, n, sums.as<u32>());
+        KERNEL_CHECK();
+    }
+    if (total_dev) {
+        hipLaunchKernelGGL(k_store_total, dim3(1), dim3(1), 0, st, last.as<u32>(), out + (n - 1), total_dev);
+        KERNEL_CHECK();
+    }
+    return SYMGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// radix sort
+// ------------------------------------------------------------------------------------------------
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = 256 * RS_ITEMS;   // 4096
+constexpr int RS_WSEG = 64 * RS_ITEMS;    // keys per wave segment
+
+__global__ __launch_bounds__(256) void k_rs_hist(const u64 *__restrict__ keys, i64 n, int shift, i64 n_tiles, u32 *__restrict__ tile_hist) {
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const i64 base = (i64)blockIdx.x * RS_TILE;
+#pragma unroll 4
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const i64 idx = base + k * 256 + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    tile_hist[(i64)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];   // digit-major
+}
+
+__global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ keys, const u32 *__restrict__ vals, i64 n, int shift,
+                                                     i64 n_tiles, const u32 *__restrict__ tile_off /* scanned, digit-major */,
+                                                     u64 *__restrict__ out_keys, u32 *__restrict__ out_vals) {
+    __shared__ u64 s_key[RS_TILE];
+    __shared__ u32 s_val[RS_TILE];
+    __shared__ u32 s_cnt[4][256];      // per-wave running digit counters, then per-wave exclusive offsets
+    __shared__ u32 s_dig_off[256];     // exclusive offset of each digit inside the tile
+    __shared__ u32 s_gbase[256];       // global base of each digit for this tile
+    __shared__ u32 s_wave[4];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 tile_base = (i64)blockIdx.x * RS_TILE;
+    volatile u32 *cnt = s_cnt[wave];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
+    s_gbase[threadIdx.x] = tile_off[(i64)threadIdx.x * n_tiles + blockIdx.x];
+    __syncthreads();
+
+    u64 key[RS_ITEMS];
+    u32 val[RS_ITEMS];
+    u32 pos[RS_ITEMS];
+    const u64 lt_mask = (1ULL << lane) - 1ULL;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const i64 idx = tile_base + (i64)wave * RS_WSEG + r * 64 + lane;
+        const bool valid = idx < n;
+        key[r] = valid ? keys[idx] : ~0ULL;
+        val[r] = valid ? vals[idx] : 0u;
+        const u32 d = (u32)(key[r] >> shift) & 255u;
+        u64 m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        const u32 rank = __popcll(m & lt_mask);
+        const u32 count = __popcll(m);
+        u32 base = 0;
+        if (valid) base = cnt[d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) cnt[d] = base + count;
+        __builtin_amdgcn_wave_barrier();
+        pos[r] = base + rank;
+    }
+    __syncthreads();
+    // per-digit: exclusive offsets over waves, tile digit counts, exclusive scan over digits
+    {
+        const int d = threadIdx.x;
+        u32 run = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            u32 c = s_cnt[k][d];
+            s_cnt[k][d] = run;
+            run += c;
+        }
+        u32 total;
+        u32 excl = block_excl_scan_256(run, s_wave, &total);
+        s_dig_off[d] = excl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const i64 idx = tile_base + (i64)wave * RS_WSEG + r * 64 + lane;
+        if (idx < n) {
+            const u32 d = (u32)(key[r] >> shift) & 255u;
+            const u32 slot = s_dig_off[d] + s_cnt[wave][d] + pos[r];
+            s_key[slot] = key[r];
+            s_val[slot] = val[r];
+        }
+    }
+    __syncthreads();
+    const i64 n_valid = (n - tile_base < RS_TILE) ? (n - tile_base) : RS_TILE;
+#pragma unroll 4
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const int s = k * 256 + threadIdx.x;
+        if (s < n_valid) {
+            const u64 kk = s_key[s];
+            const u32 d = (u32)(kk >> shift) & 255u;
+            const i64 g = (i64)s_gbase[d] + (s - (int)s_dig_off[d]);
+            out_keys[g] = kk;
+            out_vals[g] = s_val[s];
+        }
+    }
+}
+
+// Sort n pairs by key bits [begin_bit, end_bit) (multiple of 8 wide), stable.  Ping-pongs between the
+// given buffers; *result_in_tmp tells where the sorted data ended up.
+int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp, i64 n, int begin_bit, int end_bit,
+                             bool *result_in_tmp) {
+    *result_in_tmp = false;
+    if (n <= 1) return SYMGPU_OK;
+    if (n >= ((i64)1 << 32)) {
+        set_error("radix sort: n = %lld exceeds 2^32 - 1", (long long)n);
+        return SYMGPU_E_INVALID;
+    }
+    hipStream_t st = ctx().stream;
+    const i64 n_tiles = (n + RS_TILE - 1) / RS_TILE;
+    Scratch hist;
+    SG_TRY(hist.alloc((size_t)n_tiles * 256 * sizeof(u32)));
+    u64 *ksrc = keys, *kdst = keys_tmp;
+    u32 *vsrc = vals, *vdst = vals_tmp;
+    bool in_tmp = false;
+    for (int shift = begin_bit; shift < end_bit; shift += 8) {
+        hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)n_tiles), dim3(256), 0, st, ksrc, n, shift, n_tiles, hist.as<u32>());
+        KERNEL_CHECK();
+        SG_TRY(exclusive_scan_u32(hist.as<u32>(), hist.as<u32>(), n_tiles * 256, nullptr));
+        hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)n_tiles), dim3(256), 0, st, ksrc, vsrc, n, shift, n_tiles, hist.as<u32>(), kdst, vdst);
+        KERNEL_CHECK();
+        u64 *tk = ksrc; ksrc = kdst; kdst = tk;
+        u32 *tv = vsrc; vsrc = vdst; vdst = tv;
+        in_tmp = !in_tmp;
+    }
+    *result_in_tmp = in_tmp;
+    return SYMGPU_OK;
+}
+
+}  // namespace symgpu

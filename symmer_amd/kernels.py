@@ -1,0 +1,218 @@
+"""NumPy-facing wrappers of the C-ABI: packed ``uint64`` rows + ``complex128`` coefficients in, same out.
+
+Every function here runs on the GPU through ``libsymgpu.so``; there is no CPU path (a missing library or
+GPU raises :class:`symmer_amd._lib.SymgpuError`).  Reference seams replaced (file:line in /root/reference):
+``symplectic_cleanup`` utils.py:230, ``matmul_GF2``/``commutes_termwise`` utils.py:9 / base.py:938,
+``_multiply_by_operator`` base.py:764, ``_rotate_by_single_Pword`` base.py:1090, ``_rref_binary`` utils.py:292,
+``IndependentOp.symmetry_generators`` independent_op.py:90.
+"""
+import ctypes
+import numpy as np
+from . import _lib
+from ._lib import addr, check
+
+c_i64, c_int = ctypes.c_int64, ctypes.c_int
+
+
+def _rows(a):
+    a = np.ascontiguousarray(a, dtype='<u8')
+    assert a.ndim == 2 and a.shape[1] % 2 == 0 and a.shape[1] >= 2, 'packed rows must be uint64[T, 2*Wq]'
+    return a
+
+
+def _coeff(c):
+    return np.ascontiguousarray(c, dtype=np.complex128)
+
+
+class DeviceOp:
+    """Owner of a device-resident operator handle (``symgpu_op_t``)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    @classmethod
+    def upload(cls, rows, coeff=None):
+        rows = _rows(rows)
+        coeff = None if coeff is None else _coeff(coeff)
+        if coeff is not None:
+            assert coeff.shape[0] == rows.shape[0]
+        h = ctypes.c_void_p()
+        check(_lib.lib().symgpu_op_upload(addr(rows), addr(coeff), rows.shape[0], rows.shape[1] // 2, ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def alloc(cls, capacity, wq, with_coeff=True):
+        h = ctypes.c_void_p()
+        check(_lib.lib().symgpu_op_alloc(int(capacity), int(wq), 1 if with_coeff else 0, ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def random(cls, n_terms, n_qubits, density=0.3, seed=1234):
+        h = ctypes.c_void_p()
+        check(_lib.lib().symgpu_op_random(int(n_terms), int(n_qubits), float(density), int(seed), ctypes.byref(h)))
+        return cls(h)
+
+    def info(self):
+        t, wq, cap = c_i64(0), c_int(0), c_i64(0)
+        check(_lib.lib().symgpu_op_info(self.handle, ctypes.addressof(t), ctypes.addressof(wq), ctypes.addressof(cap)))
+        return t.value, wq.value, cap.value
+
+    @property
+    def n_terms(self):
+        return self.info()[0]
+
+    def set_rows(self, t):
+        check(_lib.lib().symgpu_op_set_rows(self.handle, int(t)))
+
+    def download(self, with_coeff=True):
+        t, wq, _ = self.info()
+        rows = np.empty((t, 2 * wq), dtype='<u8')
+        coeff = np.empty(t, dtype=np.complex128) if with_coeff else None
+        check(_lib.lib().symgpu_op_download(self.handle, addr(rows), addr(coeff), t))
+        return (rows, coeff) if with_coeff else rows
+
+    def checksum(self, with_coeff=True):
+        _, wq, _ = self.info()
+        x = np.zeros(2 * wq, dtype='<u8')
+        c = np.zeros(1, dtype=np.complex128)
+        check(_lib.lib().symgpu_op_checksum(self.handle, addr(x), addr(c) if with_coeff else None))
+        return x, complex(c[0])
+
+    def free(self):
+        if self.handle is not None and self.handle.value:
+            _lib.load().symgpu_op_free(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sync():
+    check(_lib.lib().symgpu_sync())
+
+
+def ycount(rows):
+    rows = _rows(rows)
+    out = np.zeros(rows.shape[0], dtype=np.int64)
+    check(_lib.lib().symgpu_ycount(addr(rows), rows.shape[0], rows.shape[1] // 2, addr(out)))
+    return out
+
+
+def commutes(a_rows, b_rows):
+    """bool[N, M]: True where a_rows[i] commutes with b_rows[j]."""
+    a_rows, b_rows = _rows(a_rows), _rows(b_rows)
+    assert a_rows.shape[1] == b_rows.shape[1], 'operands packed with different Wq'
+    n, m = a_rows.shape[0], b_rows.shape[0]
+    out = np.empty((n, m), dtype=np.uint8)
+    if n and m:
+        same = a_rows is b_rows
+        check(_lib.lib().symgpu_commutes(addr(a_rows), n, addr(a_rows if same else b_rows), m, a_rows.shape[1] // 2, addr(out)))
+    return out.view(np.bool_)
+
+
+def mul_allpairs(inner, ci, outer, co, inner_is_left=True):
+    """Uncleaned product: row ``o*Ni + i`` = ``inner[i] ^ outer[o]`` with its phase-corrected coefficient."""
+    inner, outer, ci, co = _rows(inner), _rows(outer), _coeff(ci), _coeff(co)
+    assert inner.shape[1] == outer.shape[1]
+    ni, no = inner.shape[0], outer.shape[0]
+    rows = np.empty((ni * no, inner.shape[1]), dtype='<u8')
+    coeff = np.empty(ni * no, dtype=np.complex128)
+    if ni and no:
+        check(_lib.lib().symgpu_mul_allpairs(addr(inner), addr(ci), ni, addr(outer), addr(co), no, inner.shape[1] // 2,
+                                             1 if inner_is_left else 0, addr(rows), addr(coeff)))
+    return rows, coeff
+
+
+def _thr_args(zero_threshold):
+    return (0.0, 0) if zero_threshold is None else (float(zero_threshold), 1)
+
+
+def cleanup(rows, coeff, zero_threshold=1e-15):
+    """First-occurrence dedup + sequential coefficient sums + strict threshold (None keeps everything)."""
+    rows, coeff = _rows(rows), _coeff(coeff)
+    assert rows.shape[0] == coeff.shape[0]
+    if rows.shape[0] == 0:
+        return rows.copy(), coeff.copy()
+    thr, use = _thr_args(zero_threshold)
+    op = DeviceOp.upload(rows, coeff)
+    out = ctypes.c_void_p()
+    try:
+        check(_lib.lib().symgpu_cleanup_dev(op.handle, thr, use, ctypes.byref(out)))
+        return DeviceOp(out).download()
+    finally:
+        op.free()
+
+
+def mul_cleanup(inner, ci, outer, co, inner_is_left=True, zero_threshold=1e-15):
+    """Fused product + cleanup; the product rows are never materialised."""
+    inner, outer, ci, co = _rows(inner), _rows(outer), _coeff(ci), _coeff(co)
+    assert inner.shape[1] == outer.shape[1]
+    if inner.shape[0] == 0 or outer.shape[0] == 0:
+        return np.empty((0, inner.shape[1]), dtype='<u8'), np.empty(0, dtype=np.complex128)
+    thr, use = _thr_args(zero_threshold)
+    a, b = DeviceOp.upload(inner, ci), DeviceOp.upload(outer, co)
+    out = ctypes.c_void_p()
+    try:
+        check(_lib.lib().symgpu_mul_cleanup_dev(a.handle, b.handle, 1 if inner_is_left else 0, thr, use, ctypes.byref(out)))
+        return DeviceOp(out).download()
+    finally:
+        a.free(); b.free()
+
+
+def rotation_args(angle, threshold=1e-18):
+    """(cos, sin, clifford_k) for ``_rotate_by_single_Pword`` (base.py:1146-1156): clifford_k = round(2*angle/pi) if the
+    angle is a multiple of pi/2 to within ``threshold``, else -1.  Negative multiples keep the reference's behaviour
+    (``int_part in [2,3]`` is not reduced mod 4): only the parity and membership in {2,3} matter, so a negative k is
+    mapped to k & 1 (parity preserved, never 2 or 3)."""
+    multiple = angle * 2 / np.pi
+    k = round(multiple)
+    if abs(k - multiple) <= threshold:
+        ck = k if k in (2, 3) else (k % 2)
+        return float(np.cos(angle)), float(np.sin(angle)), int(ck)
+    return float(np.cos(angle)), float(np.sin(angle)), -1
+
+
+def rotate_single_dev(op, q_row, angle, zero_threshold=1e-15):
+    """Device-resident rotation: returns (DeviceOp or None, all_commute)."""
+    q_row = np.ascontiguousarray(q_row, dtype='<u8').reshape(-1)
+    cos_t, sin_t, k = rotation_args(angle)
+    out = ctypes.c_void_p()
+    allc = c_int(0)
+    check(_lib.lib().symgpu_rotate_single_dev(op.handle, addr(q_row), cos_t, sin_t, k, float(zero_threshold), ctypes.byref(out),
+                                              ctypes.addressof(allc)))
+    if allc.value:
+        return None, True
+    return DeviceOp(out), False
+
+
+def cleanup_dev(op, zero_threshold=1e-15):
+    thr, use = _thr_args(zero_threshold)
+    out = ctypes.c_void_p()
+    check(_lib.lib().symgpu_cleanup_dev(op.handle, thr, use, ctypes.byref(out)))
+    return DeviceOp(out)
+
+
+def rref(matrix_words, want_pivots=False):
+    """``_rref_binary`` on uint64[R, Wc] packed rows -> (reduced, xor_count[, pivot column per row or -1])."""
+    m = np.array(matrix_words, dtype='<u8', order='C', copy=True)
+    assert m.ndim == 2
+    R, wc = m.shape
+    count = c_i64(0)
+    piv = np.full(R, -1, dtype=np.int64)
+    if R and wc:
+        check(_lib.lib().symgpu_rref(addr(m), R, wc, ctypes.addressof(count), addr(piv)))
+    return (m, count.value, piv) if want_pivots else (m, count.value)
+
+
+def symmetry_kernel(h_rows, n_qubits):
+    """Packed generators of the Z2 symmetries of the operator with packed rows ``h_rows`` -> (rows, xor_count)."""
+    h_rows = _rows(h_rows)
+    wq = h_rows.shape[1] // 2
+    out = np.zeros((2 * n_qubits, 2 * wq), dtype='<u8')
+    k, count = c_i64(0), c_i64(0)
+    check(_lib.lib().symgpu_symmetry_kernel(addr(h_rows), h_rows.shape[0], int(n_qubits), wq, addr(out), 2 * n_qubits,
+                                            ctypes.addressof(k), ctypes.addressof(count)))
+    return out[:k.value].copy(), count.value

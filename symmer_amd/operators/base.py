@@ -1,0 +1,378 @@
+"""``PauliwordOp`` — drop-in for the reference class on the symplectic hot path
+(``symmer/operators/base.py:33-1561``): same constructor, attributes, methods, exceptions and results for
+construction, ``+ - *``, ``cleanup``, commutation/adjacency, single-Pauli rotations and GF(2) generator
+routines.  The data-parallel work runs in hand-written HIP kernels (``libsymgpu.so``); host code is NumPy
+glue only.  Out of scope (not on the path): ``from_matrix``, ``to_sparse_matrix``, graph colouring,
+openfermion/qiskit converters, ``QuantumState``.
+"""
+import warnings
+from copy import deepcopy
+from functools import reduce, cached_property
+from numbers import Number
+from typing import Dict, List, Tuple, Union
+
+import numpy as np
+
+from .. import kernels, packing
+from .utils import (string_to_symplectic, symplectic_to_string, random_symplectic_matrix, check_independent,
+                    cref_binary, _rref_binary)
+
+warnings.simplefilter('always', UserWarning)
+
+
+class PauliwordOp:
+    """Weighted sum of n-qubit Pauli strings in the symplectic representation
+    (``symp_matrix`` bool ``[T, 2n]`` = ``[X | Z]``, ``coeff_vec`` complex128 ``[T]``)."""
+    sigfig = 3
+
+    def __init__(self, symp_matrix, coeff_vec) -> None:
+        # validation mirrors base.py:56-72 (AssertionError on bad input; TypeError for a scalar coefficient via len())
+        symp_matrix = np.asarray(symp_matrix)
+        if symp_matrix.dtype == int:
+            assert set(np.unique(symp_matrix)).issubset({0, 1}), 'symplectic matrix not defined with 0 and 1 only'
+            symp_matrix = symp_matrix.astype(bool)
+        assert symp_matrix.dtype == bool, 'Symplectic matrix must be defined over bools'
+        if len(symp_matrix.shape) == 1:
+            symp_matrix = symp_matrix.reshape([1, len(symp_matrix)])
+        self.symp_matrix = symp_matrix
+        assert self.symp_matrix.shape[-1] % 2 == 0, 'symplectic matrix must have even number of columns'
+        assert len(self.symp_matrix.shape) == 2, 'symplectic matrix must be 2 dimensional only'
+        self.n_qubits = self.symp_matrix.shape[1] // 2
+        self.coeff_vec = np.asarray(coeff_vec, dtype=complex)
+        self.n_terms = self.symp_matrix.shape[0]
+        assert self.n_terms == len(self.coeff_vec), 'coeff list and Pauliwords not same length'
+        self.X_block = self.symp_matrix[:, :self.n_qubits]
+        self.Z_block = self.symp_matrix[:, self.n_qubits:]
+        self._packed_cache = None
+
+    # ---- packed view (the C-ABI operand) ----------------------------------------------------------
+    @property
+    def packed(self) -> np.ndarray:
+        """uint64[T, 2*Wq] rows of the C-ABI; cached (``symp_matrix`` is treated as immutable, as in the reference)."""
+        if self._packed_cache is None:
+            self._packed_cache = packing.pack_rows(self.symp_matrix)
+        return self._packed_cache
+
+    @classmethod
+    def _from_packed(cls, packed: np.ndarray, n_qubits: int, coeff_vec) -> "PauliwordOp":
+        op = cls.__new__(cls)
+        PauliwordOp.__init__(op, packing.unpack_rows(packed, n_qubits), coeff_vec)
+        op._packed_cache = np.ascontiguousarray(packed, dtype='<u8')
+        return op
+
+    # ---- constructors --------------------------------------------------------------------------------
+    @classmethod
+    def random(cls, n_qubits: int, n_terms: int, diagonal: bool = False, complex_coeffs: bool = True,
+               density: float = 0.3) -> "PauliwordOp":
+        symp_matrix = random_symplectic_matrix(n_qubits, n_terms, diagonal, density=density)
+        coeff_vec = np.random.randn(n_terms).astype(complex)
+        if complex_coeffs:
+            coeff_vec += 1j * np.random.randn(n_terms)
+        return cls(symp_matrix, coeff_vec)
+
+    @classmethod
+    def from_list(cls, pauli_terms: List[str], coeff_vec: List[complex] = None) -> "PauliwordOp":
+        n_rows = len(pauli_terms)
+        if coeff_vec is None:
+            coeff_vec = np.ones(n_rows)
+        else:
+            coeff_vec = np.array(coeff_vec)
+            if len(coeff_vec.shape) == 2:
+                assert coeff_vec.shape[1] == 2, 'Only tuples of size two allowed (real and imaginary components)'
+                coeff_vec = coeff_vec[:, 0] + 1j * coeff_vec[:, 1]
+        if pauli_terms:
+            n_qubits = len(pauli_terms[0])
+            symp_matrix = np.zeros((n_rows, 2 * n_qubits), dtype=int)
+            for row_ind, pauli_str in enumerate(pauli_terms):
+                symp_matrix[row_ind] = string_to_symplectic(pauli_str, n_qubits)
+        else:
+            symp_matrix = np.array([[]], dtype=bool)
+        return cls(symp_matrix, coeff_vec)
+
+    @classmethod
+    def from_dictionary(cls, operator_dict: Dict[str, complex]) -> "PauliwordOp":
+        pauli_terms, coeff_vec = zip(*operator_dict.items())
+        return cls.from_list(list(pauli_terms), coeff_vec)
+
+    @classmethod
+    def empty(cls, n_qubits: int) -> "PauliwordOp":
+        return cls.from_dictionary({'I' * n_qubits: 0})
+
+    # ---- printing / copying / ordering ---------------------------------------------------------------
+    def __str__(self) -> str:
+        if self.symp_matrix.shape[1]:
+            out_string = ''
+            for pauli_vec, coeff in zip(self.symp_matrix, self.coeff_vec):
+                out_string += f'{coeff: .{self.sigfig}f} {symplectic_to_string(pauli_vec)} +\n'
+            return out_string[:-3]
+        return f'{self.coeff_vec[0]: .{self.sigfig}f}'
+
+    def __repr__(self) -> str:
+        return str(self)
+
+    def copy(self) -> "PauliwordOp":
+        return deepcopy(self)
+
+    def sort(self, by: str = 'magnitude', key: str = 'decreasing') -> "PauliwordOp":
+        """base.py:455-492; ``'lex'`` is ``np.lexsort(symp_matrix.T)`` (last column = primary key)."""
+        if by == 'magnitude':
+            sort_order = np.argsort(-abs(self.coeff_vec))
+        elif by == 'lex':
+            sort_order = np.lexsort(self.symp_matrix.T) if self.n_terms else np.zeros(0, dtype=int)
+        elif by == 'weight':
+            sort_order = np.argsort(-np.sum(self.symp_matrix.astype(int), axis=1))
+        elif by == 'support':
+            occ = np.logical_or(self.X_block, self.Z_block)
+            view = np.ascontiguousarray(occ).view(np.dtype((np.void, occ.dtype.itemsize * occ.shape[1])))
+            sort_order = np.argsort(view.ravel())[::-1]
+        elif by == 'Z':
+            sort_order = np.argsort(np.sum((self.n_qubits + 1) * self.X_block.astype(int) + self.Z_block.astype(int), axis=1))
+        elif by == 'X':
+            sort_order = np.argsort(np.sum(self.X_block.astype(int) + (self.n_qubits + 1) * self.Z_block.astype(int), axis=1))
+        elif by == 'Y':
+            sort_order = np.argsort(np.sum(abs(self.X_block.astype(int) - self.Z_block.astype(int)), axis=1))
+        else:
+            raise ValueError('Only permitted sort by values are magnitude, weight, X, Y or Z')
+        if key == 'increasing':
+            sort_order = sort_order[::-1]
+        elif key != 'decreasing':
+            raise ValueError('Only permitted sort by values are increasing or decreasing')
+        return PauliwordOp(self.symp_matrix[sort_order], self.coeff_vec[sort_order])
+
+    # ---- a2 ----------------------------------------------------------------------------------------------
+    @cached_property
+    def Y_count(self) -> np.ndarray:
+        """base.py:604-615: per-term count of Pauli Y (popcount of X & Z on the packed rows, on device)."""
+        if self.n_terms == 0 or self.n_qubits == 0:
+            return np.zeros(self.n_terms, dtype=np.int64)
+        return kernels.ycount(self.packed)
+
+    # ---- a5 ----------------------------------------------------------------------------------------------
+    def cleanup(self, zero_threshold: float = 1e-15) -> "PauliwordOp":
+        """base.py:617-638.  Edge cases as the reference: no terms -> one identity row with coefficient 0;
+        0 qubits -> the scalar term (the reference raises there, SURVEY §8a'; we return the sum)."""
+        if self.n_qubits == 0:
+            return PauliwordOp(np.zeros((1, 0), dtype=bool), [np.sum(self.coeff_vec)])
+        if self.n_terms == 0:
+            return PauliwordOp(np.zeros((1, self.symp_matrix.shape[1]), dtype=bool), [0])
+        rows, coeff = kernels.cleanup(self.packed, self.coeff_vec, zero_threshold)
+        return PauliwordOp._from_packed(rows, self.n_qubits, coeff)
+
+    def __eq__(self, Pword: "PauliwordOp") -> bool:
+        """base.py:640-662: cleanup + lexicographic sort on both sides, exact rows, ``np.allclose`` coefficients."""
+        check_1 = self.cleanup().sort('lex')
+        check_2 = Pword.cleanup().sort('lex')
+        if check_1.n_qubits != check_2.n_qubits:
+            raise ValueError('Operators defined over differing numbers of qubits.')
+        if check_1.n_terms != check_2.n_terms:
+            return False
+        return bool(not np.sum(np.logical_xor(check_1.symp_matrix, check_2.symp_matrix)) and
+                    np.allclose(check_1.coeff_vec, check_2.coeff_vec))
+
+    def __hash__(self) -> int:
+        return hash(tuple(self.to_dictionary.items()))
+
+    def append(self, PwordOp: "PauliwordOp") -> "PauliwordOp":
+        assert self.n_qubits == PwordOp.n_qubits, 'Pauliwords defined for different number of qubits'
+        return PauliwordOp(np.vstack((self.symp_matrix, PwordOp.symp_matrix)),
+                           np.hstack((self.coeff_vec, PwordOp.coeff_vec)))
+
+    def __add__(self, PwordOp: "PauliwordOp") -> "PauliwordOp":
+        return self.append(PwordOp).cleanup()
+
+    def __radd__(self, add_obj) -> "PauliwordOp":
+        if isinstance(add_obj, Number) and add_obj == 0:
+            return self
+        return self + add_obj
+
+    def __sub__(self, PwordOp: "PauliwordOp") -> "PauliwordOp":
+        op_copy = PwordOp.copy()
+        op_copy.coeff_vec *= -1
+        return self + op_copy
+
+    def multiply_by_constant(self, const: complex) -> "PauliwordOp":
+        return PauliwordOp(self.symp_matrix, self.coeff_vec * const)
+
+    # ---- a3 / a4 -----------------------------------------------------------------------------------------
+    def _multiply_by_operator(self, PwordOp: "PauliwordOp", zero_threshold: float = 1e-15) -> "PauliwordOp":
+        """base.py:764-794: ``self`` is the inner (fast) index and the LEFT factor; fused product + cleanup on device."""
+        assert self.n_qubits == PwordOp.n_qubits, 'PauliwordOps defined for different number of qubits'
+        rows, coeff = kernels.mul_cleanup(self.packed, self.coeff_vec, PwordOp.packed, PwordOp.coeff_vec, True, zero_threshold)
+        return PauliwordOp._from_packed(rows, self.n_qubits, coeff)
+
+    def __mul__(self, mul_obj, zero_threshold: float = 1e-15) -> "PauliwordOp":
+        """base.py:821-859.  The operand with fewer terms is the outer index; the reference does that through
+        ``(B^+ A^+)^+`` (base.py:847-849), which equals the direct phase with the roles swapped."""
+        if isinstance(mul_obj, Number):
+            return self.multiply_by_constant(mul_obj)
+        assert isinstance(mul_obj, PauliwordOp), f'cannot multiply PauliwordOp by {type(mul_obj)} (QuantumState is out of scope)'
+        assert self.n_qubits == mul_obj.n_qubits, 'PauliwordOps defined for different number of qubits'
+        if self.n_terms < mul_obj.n_terms:
+            rows, coeff = kernels.mul_cleanup(mul_obj.packed, mul_obj.coeff_vec, self.packed, self.coeff_vec, False, zero_threshold)
+        else:
+            rows, coeff = kernels.mul_cleanup(self.packed, self.coeff_vec, mul_obj.packed, mul_obj.coeff_vec, True, zero_threshold)
+        return PauliwordOp._from_packed(rows, self.n_qubits, coeff)
+
+    def __rmul__(self, const):
+        if isinstance(const, Number):
+            return self.multiply_by_constant(const)
+        return NotImplemented
+
+    def __imul__(self, PwordOp: "PauliwordOp") -> "PauliwordOp":
+        return self.__mul__(PwordOp)
+
+    def __pow__(self, exponent: int) -> "PauliwordOp":
+        assert isinstance(exponent, int), 'the exponent is not an integer'
+        if exponent == 0:
+            return PauliwordOp.from_list(['I' * self.n_qubits], [1])
+        return reduce(lambda x, y: x * y, [self.copy()] * exponent)
+
+    def __getitem__(self, key) -> "PauliwordOp":
+        if isinstance(key, (int, np.integer)):
+            key = int(key)
+            if key < 0:
+                key += self.n_terms
+            assert key < self.n_terms, 'Index out of range'
+            mask = [key]
+        elif isinstance(key, slice):
+            start, stop = key.start, key.stop
+            if start is None:
+                start = 0
+            if stop is None:
+                stop = self.n_terms
+            mask = np.arange(start, stop, key.step)
+        elif isinstance(key, (list, np.ndarray)):
+            mask = np.asarray(key)
+        else:
+            raise ValueError(f'Unrecognised input {type(key)}, must be an integer, slice, list or np.array')
+        return PauliwordOp(self.symp_matrix[mask], self.coeff_vec[mask])
+
+    def __iter__(self):
+        return iter([self[i] for i in range(self.n_terms)])
+
+    # ---- a6 ----------------------------------------------------------------------------------------------
+    def commutes_termwise(self, PwordOp: "PauliwordOp") -> np.ndarray:
+        """base.py:938-971: bool ``[N, M]``, True where terms commute."""
+        assert self.n_qubits == PwordOp.n_qubits, 'Pauliwords defined for different number of qubits'
+        if self.n_qubits == 0:
+            return np.ones((self.n_terms, PwordOp.n_terms), dtype=bool)
+        return kernels.commutes(self.packed, self.packed if PwordOp is self else PwordOp.packed)
+
+    def anticommutes_termwise(self, PwordOp: "PauliwordOp") -> np.ndarray:
+        return ~self.commutes_termwise(PwordOp)
+
+    @cached_property
+    def adjacency_matrix(self) -> np.ndarray:
+        return self.commutes_termwise(self)
+
+    def commutator(self, PwordOp: "PauliwordOp") -> "PauliwordOp":
+        return self * PwordOp - PwordOp * self
+
+    def anticommutator(self, PwordOp: "PauliwordOp") -> "PauliwordOp":
+        return self * PwordOp + PwordOp * self
+
+    def commutes(self, PwordOp: "PauliwordOp") -> bool:
+        commutator = self.commutator(PwordOp).cleanup()
+        return bool(commutator.n_terms == 0 or np.all(commutator.coeff_vec[0] == 0))
+
+    # ---- a7 ----------------------------------------------------------------------------------------------
+    def _rotate_by_single_Pword(self, Pword: "PauliwordOp", angle: float = None, threshold: float = 1e-18
+                                ) -> "PauliwordOp":
+        """base.py:1090-1161 as one fused device pass (valid for operators without duplicate rows, i.e. anything
+        that has been through ``cleanup``; see ``csrc/rotate.hip``)."""
+        if angle is None:
+            angle = np.pi / 2
+        if angle.imag != 0:
+            warnings.warn('Complex component in angle: this will be ignored.')
+        angle = angle.real
+        assert Pword.n_terms == 1, 'Only rotation by single Pauliword allowed here'
+        assert Pword.n_qubits == self.n_qubits, 'Pauliwords defined for different number of qubits'
+        if Pword.coeff_vec[0] != 1:
+            warnings.warn(f'Pword coefficient {Pword.coeff_vec[0]: .8f} has been set to 1')
+        if self.n_terms == 0:
+            return self
+        multiple = angle * 2 / np.pi
+        if abs(round(multiple) - multiple) > threshold and abs(angle) > 1e6:
+            warnings.warn('Large angle can lead to precision errors: recommend using high-precision math library '
+                          'such as mpmath or redefine angle in range [-pi, pi]')
+        op = kernels.DeviceOp.upload(self.packed, self.coeff_vec)
+        try:
+            res, all_commute = kernels.rotate_single_dev(op, Pword.packed[0], angle)
+            if all_commute:
+                return self                                     # identity action: the SAME object (base.py:1131-1133)
+            rows, coeff = res.download()
+            res.free()
+        finally:
+            op.free()
+        return PauliwordOp._from_packed(rows, self.n_qubits, coeff)
+
+    def perform_rotations(self, rotations: List[Tuple["PauliwordOp", float]]) -> "PauliwordOp":
+        """base.py:1163-1186: rotations applied left to right, each followed by ``cleanup()``; the operator stays
+        device-resident across the whole chain (one upload, one download)."""
+        if rotations == []:
+            return self.copy().cleanup()
+        wq = packing.words_per_block(self.n_qubits)
+        dev = kernels.DeviceOp.upload(self.packed, self.coeff_vec)
+        try:
+            for pauli_rotation, angle in rotations:
+                assert pauli_rotation.n_terms == 1, 'Only rotation by single Pauliword allowed here'
+                assert pauli_rotation.n_qubits == self.n_qubits, 'Pauliwords defined for different number of qubits'
+                if angle is None:
+                    angle = np.pi / 2
+                if pauli_rotation.coeff_vec[0] != 1:
+                    warnings.warn(f'Pword coefficient {pauli_rotation.coeff_vec[0]: .8f} has been set to 1')
+                if dev.n_terms > 0:
+                    res, all_commute = kernels.rotate_single_dev(dev, pauli_rotation.packed[0], float(np.real(angle)))
+                    if not all_commute:
+                        dev.free()
+                        dev = res
+                # `.cleanup()` after every rotation (base.py:1185); an operator without terms becomes 0*I (base.py:631-632)
+                if dev.n_terms == 0:
+                    cleaned = kernels.DeviceOp.upload(np.zeros((1, 2 * wq), dtype='<u8'), np.zeros(1, dtype=complex))
+                else:
+                    cleaned = kernels.cleanup_dev(dev)
+                dev.free()
+                dev = cleaned
+            rows, coeff = dev.download()
+        finally:
+            dev.free()
+        if rows.shape[0] == 0:
+            # cleanup() of an operator whose terms all cancelled has shape (0, 2n) (test_base.py:124-130)
+            return PauliwordOp(np.zeros((0, 2 * self.n_qubits), dtype=bool), [])
+        return PauliwordOp._from_packed(rows, self.n_qubits, coeff)
+
+    def tensor(self, right_op: "PauliwordOp") -> "PauliwordOp":
+        id_r = np.zeros([right_op.n_terms, self.n_qubits], dtype=bool)
+        id_l = np.zeros([self.n_terms, right_op.n_qubits], dtype=bool)
+        left = PauliwordOp(np.hstack([self.X_block, id_l, self.Z_block, id_l]), self.coeff_vec)
+        right = PauliwordOp(np.hstack([id_r, right_op.X_block, id_r, right_op.Z_block]), right_op.coeff_vec)
+        return left * right
+
+    @cached_property
+    def dagger(self) -> "PauliwordOp":
+        return PauliwordOp(self.symp_matrix, self.coeff_vec.conjugate())
+
+    @cached_property
+    def to_dictionary(self) -> Dict[str, complex]:
+        op = self.cleanup()
+        return {symplectic_to_string(v): c for v, c in zip(op.symp_matrix, op.coeff_vec)}
+
+    # ---- a10 / f2: GF(2) generator routines (same device kernel as a8) ----------------------------------------
+    @cached_property
+    def generators(self) -> "PauliwordOp":
+        """base.py:1436-1456: non-zero rows of ``_rref_binary(symp_matrix)``."""
+        row_red = _rref_binary(self.symp_matrix)
+        non_zero_rows = row_red[np.sum(row_red, axis=1).astype(bool)]
+        gens = PauliwordOp(non_zero_rows, np.ones(non_zero_rows.shape[0], dtype=complex))
+        assert check_independent(gens), 'generators are not independent'
+        assert gens.n_terms <= 2 * self.n_qubits, 'cannot have an independent generating set of size greaterthan 2 time num qubits'
+        return gens
+
+    def generator_reconstruction(self, generators: "PauliwordOp", override_independence_check: bool = False):
+        """base.py:523-560: ``cref_binary(vstack([G, M]))`` -> (R int[T, g], mask bool[T])."""
+        if not override_independence_check:
+            assert check_independent(generators), 'Supplied generators are algebraically dependent'
+        dim = generators.n_terms
+        reduced = cref_binary(np.vstack([generators.symp_matrix, self.symp_matrix]))
+        mask = np.all(~reduced[dim:, dim:], axis=1)
+        return reduced[dim:, :dim].astype(int), mask

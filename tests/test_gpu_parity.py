@@ -1,0 +1,287 @@
+"""GPU parity tests: the HIP path (through the C-ABI and the drop-in classes) against
+(1) the committed golden fixtures produced by running the reference, and
+(2) the C / NumPy oracles on the same seeded inputs at sizes the oracle finishes in seconds.
+Bar: bit-exact rows, row order, commutation tables and GF(2) matrices; coefficients bit-exact for dyadic inputs
+and within 1e-12 for Gaussian inputs (rows with |c| <= 1e-12 discarded on both sides — SURVEY.md §7)."""
+import numpy as np
+import pytest
+from symmer_amd import PauliwordOp, IndependentOp, kernels, packing
+from symmer_amd.operators import (symplectic_cleanup, _rref_binary, rref_binary, _cref_binary, cref_binary, matmul_GF2,
+                                  mul_symplectic)
+from oracle import oracle_np as onp
+from oracle import oracle_c as oc
+from _golden import family, known, known_single_qubit, as_bool, unpackbits_matrix, assert_op_equal
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def dyadic(rng, t):
+    return (rng.integers(-8, 9, t) + 1j * rng.integers(-8, 9, t)) / 16.0
+
+
+# ---------------------------------------------------------------- known answers (reference's own tests) ----
+def test_known_answers():
+    k = known()
+    P = PauliwordOp(as_bool(k['ycount_symp']), np.ones(4))
+    assert np.all(P.Y_count == np.array([0, 0, 3, 0]))                                   # test_base.py:510-515
+    P = PauliwordOp.from_list(['XXX', 'YYY', 'XXX', 'YYY'], [1, 1, -1, 1])
+    assert P == PauliwordOp.from_list(['YYY'], [2])                                       # :537-544
+    c = P.cleanup()
+    assert_op_equal(c.symp_matrix, c.coeff_vec, k['cleanup_out_symp'], k['cleanup_out_coeff'])
+    Z = PauliwordOp(as_bool(k['pl1_symp']), np.zeros(4))
+    assert Z.cleanup().n_terms == 0 and Z.cleanup().symp_matrix.shape == (0, 6)           # :531-535, :124-130
+    P1 = PauliwordOp.from_list(['III', 'XXX', 'YYY', 'ZZZ']); P2 = PauliwordOp.from_list(['ZXZ', 'XZX', 'XYZ', 'ZIX'])
+    assert np.array_equal(P1.commutes_termwise(P2), as_bool(k['pl1_commutes_pl2']))       # :554-566
+    assert np.array_equal(P2.adjacency_matrix, as_bool(k['pl2_adjacency']))               # :568-579
+    assert np.array_equal(P1.anticommutes_termwise(P2), ~as_bool(k['pl1_commutes_pl2']))
+    op1 = PauliwordOp.from_list(['XYXZ', 'YYII']); op2 = PauliwordOp.from_list(['YYZZ', 'XIXZ', 'XZZI'])
+    assert np.array_equal(op1.commutes_termwise(op2), as_bool(k['doc_commutes']))         # base.py:944-951
+    A = PauliwordOp(as_bool(k['small_A_symp']), k['small_A_coeff']); B = PauliwordOp(as_bool(k['small_B_symp']), k['small_B_coeff'])
+    for nm, R in (('AB', A * B), ('BA', B * A)):
+        assert_op_equal(R.symp_matrix, R.coeff_vec, k[f'small_{nm}_symp'], k[f'small_{nm}_coeff'])
+    P = PauliwordOp.from_list(['XZ', 'ZX', 'XZ', 'II', 'ZX'], [1, 2, 3, 4, -2]).cleanup()
+    assert P.to_dictionary == {'XZ': 4, 'II': 4} and list(P.to_dictionary) == ['XZ', 'II']
+
+
+def test_single_qubit_multiplication_table():
+    for pair, (res, (re, im)) in known_single_qubit().items():                            # test_base.py:596-613
+        P1, P2 = PauliwordOp.from_dictionary({pair[0]: 1}), PauliwordOp.from_dictionary({pair[1]: 1})
+        assert P1 * P2 == PauliwordOp.from_dictionary({res: complex(re, im)})
+        row, c = mul_symplectic(P1.symp_matrix[0], 1, P2.symp_matrix[0], 1)
+        assert c == complex(re, im)
+
+
+def test_add_sub_random():
+    np.random.seed(7)
+    P = PauliwordOp.random(3, 10)
+    assert P + P == P * 2                                                                 # :546-548
+    assert (P - P).n_terms == 0                                                           # :550-552
+    assert sum([P, P, P]) == P * 3
+    E = PauliwordOp(np.zeros((0, 6), dtype=bool), [])
+    assert (P * E).symp_matrix.shape == (0, 6) and (E * P).symp_matrix.shape == (0, 6)    # SURVEY §8a'
+    assert P.commutes_termwise(E).shape == (10, 0) and E.commutes_termwise(P).shape == (0, 10)
+    ee = E + E
+    assert ee.n_terms == 1 and ee.coeff_vec[0] == 0 and not ee.symp_matrix.any()
+    assert (P ** 2) == P * P and (P ** 0) == PauliwordOp.from_list(['III'], [1])
+    assert P.commutes(P) and hash(P) == hash(P.copy())
+
+
+# ---------------------------------------------------------------- golden families --------------------------
+@pytest.mark.parametrize('case', family('mul'))
+def test_mul_golden(case):
+    A = PauliwordOp(as_bool(case['a_symp']), case['a_coeff']); B = PauliwordOp(as_bool(case['b_symp']), case['b_coeff'])
+    R = A * B
+    assert_op_equal(R.symp_matrix, R.coeff_vec, case['out_symp'], case['out_coeff'], exact=bool(case['exact']), tol=TOL)
+    if A.n_terms and B.n_terms:
+        # unfused path (materialised product + separate cleanup) must agree with the fused one
+        inner, outer, left = (B, A, False) if A.n_terms < B.n_terms else (A, B, True)
+        rows, coeff = kernels.mul_allpairs(inner.packed, inner.coeff_vec, outer.packed, outer.coeff_vec, left)
+        rows2, coeff2 = kernels.cleanup(rows, coeff, 1e-15)
+        assert_op_equal(packing.unpack_rows(rows2, A.n_qubits), coeff2, case['out_symp'], case['out_coeff'],
+                        exact=bool(case['exact']), tol=TOL)
+
+
+@pytest.mark.parametrize('case', family('cleanup'))
+def test_cleanup_golden(case):
+    s = as_bool(case['in_symp']); thr = float(case['thr'])
+    exact = bool(np.all(np.asarray(case['in_coeff']) * 16 == np.round(np.asarray(case['in_coeff']) * 16)))
+    if thr < 0:
+        rows, coeff = symplectic_cleanup(s, case['in_coeff'], None)
+    else:
+        P = PauliwordOp(s, case['in_coeff']).cleanup(thr)
+        rows, coeff = P.symp_matrix, P.coeff_vec
+    assert_op_equal(rows, coeff, case['out_symp'], case['out_coeff'], exact=exact, tol=TOL)
+
+
+@pytest.mark.parametrize('case', family('commute'))
+def test_commute_golden(case):
+    A = PauliwordOp(as_bool(case['a_symp']), np.ones(case['a_symp'].shape[0]))
+    B = PauliwordOp(as_bool(case['b_symp']), np.ones(case['b_symp'].shape[0]))
+    assert np.array_equal(A.commutes_termwise(B), as_bool(case['out']))
+    assert np.array_equal(A.adjacency_matrix, as_bool(case['adj']))
+
+
+@pytest.mark.parametrize('case', family('rotate'))
+def test_rotate_golden(case):
+    P = PauliwordOp(as_bool(case['in_symp']), case['in_coeff'])
+    n = P.n_qubits
+    if int(case['chain']):
+        rots = [(PauliwordOp(as_bool(q).reshape(1, -1), [1]), float(a)) for q, a in zip(case['q'], case['angle'])]
+        R = P.perform_rotations(rots)
+        assert_op_equal(R.symp_matrix, R.coeff_vec, case['out_symp'], case['out_coeff'], exact=False, tol=TOL)
+    else:
+        ang = float(case['angle'])
+        Q = PauliwordOp(as_bool(case['q']).reshape(1, -1), [1])
+        R = P._rotate_by_single_Pword(Q, ang)
+        clifford = abs(round(2 * ang / np.pi) - 2 * ang / np.pi) <= 1e-18
+        assert_op_equal(R.symp_matrix, R.coeff_vec, case['out_symp'], case['out_coeff'], exact=clifford, tol=TOL)
+        if np.all(onp.commutes_termwise(P.symp_matrix, Q.symp_matrix)):
+            assert R is P                                                                  # base.py:1131-1133
+    assert n == case['in_symp'].shape[1] // 2
+
+
+@pytest.mark.parametrize('case', family('gf2'))
+def test_gf2_golden(case):
+    m = unpackbits_matrix(case['m'], case['shape'])
+    R, C = m.shape
+    assert np.array_equal(_rref_binary(m), unpackbits_matrix(case['rref_noswap'], (R, C)))
+    assert np.array_equal(rref_binary(m), unpackbits_matrix(case['rref'], (R, C)))
+    assert np.array_equal(_cref_binary(m), unpackbits_matrix(case['cref_noswap'], (R, C)))
+    assert np.array_equal(cref_binary(m), unpackbits_matrix(case['cref'], (R, C)))
+    _, n_xor = kernels.rref(packing.pack_bits(m))
+    assert n_xor == onp.rref_noswap(m, count_xors=True)[1]                                 # reference-order XOR count
+
+
+@pytest.mark.parametrize('case', family('symgen'))
+def test_symgen_golden(case):
+    H = PauliwordOp(as_bool(case['h_symp']), np.ones(case['h_symp'].shape[0]))
+    S = IndependentOp.symmetry_generators(H, commuting_override=True)
+    assert np.array_equal(S.symp_matrix, as_bool(case['symgen'])) and S.coeff_vec.dtype.kind == 'i'
+    G = H.generators
+    assert np.array_equal(G.symp_matrix, as_bool(case['gens']))
+    Rm, mask = H.generator_reconstruction(G)
+    assert np.array_equal(Rm, case['recon']) and np.array_equal(mask, as_bool(case['recon_mask']))
+
+
+def test_independent_op_known():
+    k = known()
+    H2 = PauliwordOp(as_bool(k['H2_symp']), k['H2_coeff'])
+    G1 = IndependentOp.symmetry_generators(H2)                                             # test_independent_op.py:97-104
+    assert np.array_equal(G1.symp_matrix, as_bool(k['H2_symgen']))
+    G2 = IndependentOp.from_list(['ZIZI', 'IZIZ', 'IIZZ'])
+    assert np.all(G1.generator_reconstruction(G2)[1]) and np.all(G2.generator_reconstruction(G1)[1])
+    with pytest.warns(UserWarning):
+        assert IndependentOp.symmetry_generators(PauliwordOp.from_list(['X', 'Y', 'Z'])).n_terms == 0   # :50-53
+    op = PauliwordOp.from_list(['IZZ', 'ZZI', 'IXX', 'XXI', 'IYY', 'YYI'])
+    assert IndependentOp.symmetry_generators(op, commuting_override=True) == IndependentOp.from_list(['XXX', 'ZZZ'])  # :56-66
+    with pytest.raises(ValueError):
+        IndependentOp.from_list(['X', 'Y', 'Z'])                                           # :73-75
+    with pytest.raises(ValueError):
+        IndependentOp([[0, 1]], [1], target_sqp='x')                                       # :27-29
+    with pytest.raises(ValueError):
+        IndependentOp.from_list(['XZ'], [2])                                               # :117-119
+    assert IndependentOp.from_list(['X', 'Z']) == IndependentOp([[0, 1], [1, 0]], [1, 1])
+    G = IndependentOp.from_list(['IZ', 'ZI', 'XX'])
+    assert G[2] == IndependentOp.from_list(['XX'])
+
+
+# ---------------------------------------------------------------- oracle parity on seeded inputs -----------
+@pytest.mark.parametrize('n,N,M', [(1000, 3000, 2500), (2000, 700, 1100), (100, 513, 257), (1, 70, 300), (64, 1, 1000), (4097, 40, 33)])
+def test_commutes_vs_oracle(n, N, M):
+    rng = np.random.default_rng(100 + n)
+    a = packing.pack_rows(rng.random((N, 2 * n)) < 0.3); b = packing.pack_rows(rng.random((M, 2 * n)) < 0.3)
+    assert np.array_equal(kernels.commutes(a, b), oc.commutes(a, b))
+    assert np.array_equal(kernels.commutes(a, a), oc.commutes(a, a))
+
+
+def test_matmul_gf2_vs_oracle():
+    rng = np.random.default_rng(5)
+    A = rng.random((70, 130)) < 0.5; B = rng.random((130, 45)) < 0.5
+    assert np.array_equal(matmul_GF2(A, B), onp.matmul_gf2(A, B))
+
+
+@pytest.mark.parametrize('n,Ni,No,left', [(1000, 700, 300, True), (1000, 300, 700, False), (100, 500, 500, True), (130, 1, 77, True),
+                                           (2000, 257, 9, False), (63, 1000, 3, True)])
+def test_mul_allpairs_vs_oracle(n, Ni, No, left):
+    rng = np.random.default_rng(200 + n + Ni)
+    a = packing.pack_rows(rng.random((Ni, 2 * n)) < 0.3); b = packing.pack_rows(rng.random((No, 2 * n)) < 0.3)
+    ca, cb = dyadic(rng, Ni), dyadic(rng, No)
+    rows, coeff = kernels.mul_allpairs(a, ca, b, cb, left)
+    erows, ecoeff = oc.mul_allpairs(a, ca, b, cb, left)
+    assert np.array_equal(rows, erows) and np.array_equal(coeff, ecoeff)
+    cg, cbg = rng.standard_normal(Ni) + 1j * rng.standard_normal(Ni), rng.standard_normal(No) + 1j * rng.standard_normal(No)
+    _, coeff = kernels.mul_allpairs(a, cg, b, cbg, left)
+    _, ecoeff = oc.mul_allpairs(a, cg, b, cbg, left)
+    assert np.array_equal(coeff, ecoeff)        # both sides are the un-fused IEEE expression: bit-exact even for Gaussian input
+
+
+@pytest.mark.parametrize('n,N,M', [(100, 500, 500), (1000, 300, 200), (3, 700, 700), (65, 64, 900)])
+def test_mul_cleanup_vs_oracle(n, N, M):
+    """cfg 1 (100 qubits, 500 terms squared: 250k pairs -> 124,751 unique) plus wider/narrower cases, bit-exact."""
+    rng = np.random.default_rng(300 + n)
+    A = PauliwordOp(rng.random((N, 2 * n)) < 0.3, dyadic(rng, N))
+    B = A if N == M else PauliwordOp(rng.random((M, 2 * n)) < 0.3, dyadic(rng, M))
+    R = A * B
+    erows, ecoeff = oc.mul(A.packed, A.coeff_vec, B.packed, B.coeff_vec)
+    assert np.array_equal(R.packed, erows) and np.array_equal(R.coeff_vec, ecoeff)
+    if n == 100:
+        rows_nothr, _ = kernels.mul_cleanup(A.packed, A.coeff_vec, A.packed, A.coeff_vec, True, None)
+        assert rows_nothr.shape[0] == 1 + N * (N - 1) // 2                                # 124,751
+
+
+def test_mul_cleanup_gaussian_tolerance():
+    rng = np.random.default_rng(11)
+    n, N = 100, 300
+    A = PauliwordOp(rng.random((N, 2 * n)) < 0.3, rng.standard_normal(N) + 1j * rng.standard_normal(N))
+    R = A * A
+    erows, ecoeff = onp.mul(A.symp_matrix, A.coeff_vec, A.symp_matrix, A.coeff_vec)
+    assert_op_equal(R.symp_matrix, R.coeff_vec, erows, ecoeff, exact=False, tol=TOL)
+
+
+@pytest.mark.parametrize('T,n,dup', [(200000, 1000, 0.5), (50000, 100, 0.9), (100000, 3, 1.0), (4097, 2000, 0.2)])
+def test_cleanup_vs_oracle(T, n, dup):
+    rng = np.random.default_rng(400 + n)
+    base = packing.pack_rows(rng.random((max(1, int(T * (1 - dup)) + 1), 2 * n)) < 0.3)
+    rows = base[rng.integers(0, base.shape[0], T)]
+    coeff = dyadic(rng, T)
+    for thr in (1e-15, None):
+        r, c = kernels.cleanup(rows, coeff, thr)
+        er, ec = oc.cleanup(rows, coeff, thr)
+        assert np.array_equal(r, er) and np.array_equal(c, ec)
+
+
+@pytest.mark.parametrize('R,C,dens', [(1000, 3000, 0.5), (300, 20000, 0.01), (2000, 500, 0.5), (33, 64, 0.5), (700, 700, 0.003)])
+def test_rref_vs_oracle(R, C, dens):
+    rng = np.random.default_rng(500 + R)
+    m = rng.random((R, C)) < dens
+    m[R // 3] = False
+    m[R - 1] = m[0]
+    p = packing.pack_bits(m)
+    red, n_xor, piv = kernels.rref(p, want_pivots=True)
+    ered, en_xor, epiv = oc.rref(p, want_pivots=True)
+    assert np.array_equal(red, ered) and n_xor == en_xor and np.array_equal(piv, epiv)
+
+
+def test_rref_wide_rows_global_panel():
+    """rows wider than the LDS budget take the global-memory panel path"""
+    rng = np.random.default_rng(9)
+    m = rng.random((40, 64 * 20000)) < 0.001
+    p = packing.pack_bits(m)
+    red, n_xor = kernels.rref(p)
+    ered, en_xor = oc.rref(p)
+    assert np.array_equal(red, ered) and n_xor == en_xor
+
+
+@pytest.mark.parametrize('n,M,k', [(300, 2000, 12), (1000, 5000, 20), (64, 64, 3)])
+def test_symmetry_kernel_vs_oracle(n, M, k):
+    rng = np.random.default_rng(600 + n)
+    symp = rng.random((M, 2 * n)) < 0.3
+    symp[:, :k] = False                                   # planted: Z_0..Z_{k-1} commute with every term
+    H = PauliwordOp(symp, np.ones(M))
+    for _ in range(4):                                    # scramble with Clifford rotations (symmer/utils.py:141-149)
+        H = H._rotate_by_single_Pword(PauliwordOp((rng.random(2 * n) < 0.3).reshape(1, -1), [1]), np.pi / 2)
+    rows, n_xor = kernels.symmetry_kernel(H.packed, n)
+    erows, en_xor = oc.symmetry_generators(H.packed, n)
+    assert np.array_equal(rows, erows) and n_xor == en_xor and rows.shape[0] == k
+    S = IndependentOp.symmetry_generators(H, commuting_override=True)
+    assert np.all(S.commutes_termwise(H))
+
+
+@pytest.mark.parametrize('n,T', [(1000, 20000), (130, 5000)])
+def test_rotation_vs_oracle(n, T):
+    rng = np.random.default_rng(700 + n)
+    symp, c = onp.cleanup_op(rng.random((T, 2 * n)) < 0.3, dyadic(rng, T))
+    q = rng.random(2 * n) < 0.3
+    half = symp.shape[0] // 2
+    symp, c = onp.cleanup_op(np.vstack([symp, symp[:half] ^ q]), np.hstack([c, dyadic(rng, half)]))   # force P / P*Q merges
+    P = PauliwordOp(symp, c); Q = PauliwordOp(q.reshape(1, -1), [1])
+    for ang in (0.3, np.pi / 2, np.pi, -np.pi / 2, 3 * np.pi / 2):
+        R = P._rotate_by_single_Pword(Q, ang)
+        er, ec = onp.rotate_by_single_pword(symp, c, q, ang)
+        clifford = abs(round(2 * ang / np.pi) - 2 * ang / np.pi) <= 1e-18
+        assert_op_equal(R.symp_matrix, R.coeff_vec, er, ec, exact=clifford, tol=TOL)
+    rots = [(PauliwordOp((rng.random(2 * n) < 0.3).reshape(1, -1), [1]), a) for a in (np.pi / 2, 0.4, np.pi / 2, -1.3)]
+    R = P.perform_rotations(rots)
+    er, ec = onp.perform_rotations(symp, c, [(r.symp_matrix[0], a) for r, a in rots])
+    assert_op_equal(R.symp_matrix, R.coeff_vec, er, ec, exact=False, tol=TOL)

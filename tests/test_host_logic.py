@@ -1,0 +1,158 @@
+"""CPU: host-side logic of the drop-in classes (no kernel is launched), the packing convention, and the C-ABI
+library: it must load here and export every symbol ``include/symgpu.h`` declares; compute calls must fail
+loudly without a GPU (there is no CPU fallback)."""
+import os, re, ctypes
+import numpy as np
+import pytest
+import symmer_amd
+from symmer_amd import PauliwordOp, IndependentOp, SymgpuError, _lib, packing
+from symmer_amd.operators.utils import string_to_symplectic, symplectic_to_string
+from oracle import oracle_np as onp
+from _golden import known, as_bool
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAVE_GPU = _lib.device_count() > 0 if os.path.exists(_lib.LIB_PATH) else False
+
+
+# ---- constructor validation: mirrors tests/test_operators/test_base.py:26-110 of the reference -------------
+def test_init_symplectic_float_type():
+    with pytest.raises(AssertionError):
+        PauliwordOp([[0., 1., 0., 1., 0., 1.]], [1])
+
+
+def test_init_symplectic_nonbinary_ints_type():
+    with pytest.raises(AssertionError):
+        PauliwordOp([[0, 1, 2, 3, 4, 5]], [1])
+
+
+def test_init_symplectic_str_type():
+    with pytest.raises(AssertionError):
+        PauliwordOp([['0', '1', '1', '0', '1', '1']], [1])
+
+
+def test_incompatible_length_of_symp_matrix_and_coeff_vec():
+    with pytest.raises(AssertionError):
+        PauliwordOp([[0, 1, 0, 1, 0, 1], [1, 0, 1, 0, 1, 0]], [1])
+
+
+def test_init_symplectic_incorrect_dimension():
+    with pytest.raises(AssertionError):
+        PauliwordOp([[[[0, 1, 1, 0, 1, 1]]]], [1])
+
+
+def test_init_symplectic_2D_but_odd_columns():
+    with pytest.raises(AssertionError):
+        PauliwordOp([[0, 0, 1], [1, 0, 1]], [1, 1])
+
+
+def test_init_symplectic_int_coeff():
+    with pytest.raises(TypeError):
+        PauliwordOp([[0, 0, 1, 1]], 1)
+
+
+def test_from_list_incorrect_str():
+    with pytest.raises(AssertionError):
+        PauliwordOp.from_list(['ixi', 'zzi'], [0, 1])
+
+
+def test_empty_and_constructors():
+    P = PauliwordOp.empty(3)
+    assert P.n_terms == 1 and P.n_qubits == 3 and np.array_equal(P.coeff_vec, [0])
+    k = known()
+    P1 = PauliwordOp.from_list(['III', 'XXX', 'YYY', 'ZZZ'])
+    assert np.array_equal(P1.symp_matrix, as_bool(k['pl1_symp']))
+    D = PauliwordOp.from_dictionary({'XZ': 1 + 2j, 'YI': 3})
+    assert D.n_terms == 2 and D.coeff_vec[0] == 1 + 2j
+    T = PauliwordOp.from_list(['XZ', 'YI'], [(1, 2), (3, 0)])
+    assert np.array_equal(T.coeff_vec, [1 + 2j, 3])
+    R = PauliwordOp.random(7, 5)
+    assert R.symp_matrix.shape == (5, 14) and R.coeff_vec.dtype == complex
+    assert str(PauliwordOp.from_list(['XY'], [1])) == ' 1.000+0.000j XY'
+
+
+def test_strings_roundtrip():
+    for s in ('IXYZ', 'YYII', 'Z'):
+        assert symplectic_to_string(string_to_symplectic(s, len(s)).astype(bool)) == s
+
+
+def test_getitem_iter_sort_dagger_append():
+    P = PauliwordOp.from_list(['ZXZ', 'XZX', 'XYZ', 'ZIX'], [1, 2j, -3, 4])
+    assert all(np.array_equal(P[i].symp_matrix[0], P.symp_matrix[i]) for i in range(-4, 4))
+    assert [q.coeff_vec[0] for q in P] == list(P.coeff_vec)
+    assert P[1:3].n_terms == 2 and P[[0, 3]].n_terms == 2 and P[np.array([True, False, True, False])].n_terms == 2
+    with pytest.raises(ValueError):
+        P['a']
+    lex = P.sort('lex')
+    assert np.array_equal(lex.symp_matrix, P.symp_matrix[onp.lex_order(P.symp_matrix)])
+    assert np.array_equal(P.sort('magnitude').coeff_vec, [4, -3, 2j, 1])
+    with pytest.raises(ValueError):
+        P.sort('nope')
+    assert np.array_equal(P.dagger.coeff_vec, np.conj(P.coeff_vec))
+    A = P.append(P)
+    assert A.n_terms == 8
+    with pytest.raises(AssertionError):
+        P.append(PauliwordOp.from_list(['XX']))
+    assert np.array_equal(P.multiply_by_constant(2).coeff_vec, 2 * P.coeff_vec)
+    assert np.array_equal((P * 2).coeff_vec, 2 * P.coeff_vec) and np.array_equal((2 * P).coeff_vec, 2 * P.coeff_vec)
+    C = P.copy(); C.coeff_vec[:] = 0
+    assert P.coeff_vec[0] == 1
+
+
+def test_qubit_mismatch_asserts_before_any_kernel():
+    P, Q = PauliwordOp.from_list(['XX']), PauliwordOp.from_list(['XXX'])
+    with pytest.raises(AssertionError):
+        P * Q
+    with pytest.raises(AssertionError):
+        P.commutes_termwise(Q)
+    with pytest.raises(AssertionError):
+        P._multiply_by_operator(Q)
+    with pytest.raises(AssertionError):
+        P._rotate_by_single_Pword(Q, 0.3)
+
+
+def test_packing_convention():
+    rng = np.random.default_rng(3)
+    for n in (1, 5, 63, 64, 65, 130, 1000):
+        s = rng.random((6, 2 * n)) < 0.4
+        p = packing.pack_rows(s)
+        wq = packing.words_per_block(n)
+        assert p.shape == (6, 2 * wq) and p.dtype == np.dtype('<u8')
+        assert np.array_equal(p, onp.pack_rows(s))
+        assert np.array_equal(packing.unpack_rows(p, n), s)
+        q = 64 * (wq - 1) + (n - 1) % 64                           # bit j of word w <-> qubit 64 w + j
+        assert bool((p[0, (n - 1) // 64] >> np.uint64((n - 1) % 64)) & np.uint64(1)) == bool(s[0, n - 1])
+        if n % 64:
+            assert not np.any(p[:, wq - 1] >> np.uint64(n % 64))    # padding bits zero
+    m = rng.random((5, 70)) < 0.5
+    assert np.array_equal(packing.unpack_bits(packing.pack_bits(m), 70), m)
+
+
+# ---- the C-ABI library ---------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'symgpu.h')).read()
+    declared = set(re.findall(r'\b(symgpu_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 40
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/symgpu.h but not exported by libsymgpu.so'
+    assert declared == set(_lib.SIGNATURES) | {'symgpu_last_error'}, 'ctypes prototypes out of sync with the header'
+
+
+@pytest.mark.skipif(HAVE_GPU, reason='this container has a GPU')
+def test_compute_fails_loudly_without_gpu():
+    P = PauliwordOp.from_list(['XX', 'ZZ'], [1, 2])
+    for call in (lambda: P * P, lambda: P.cleanup(), lambda: P.commutes_termwise(P),
+                 lambda: IndependentOp.symmetry_generators(P), lambda: P + P):
+        with pytest.raises(SymgpuError):
+            call()
+    n = ctypes.c_int(-1)
+    assert _lib.load().symgpu_device_count(ctypes.addressof(n)) == 0 and n.value == 0
+    assert _lib.load().symgpu_sync() == _lib.E_NODEVICE
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'symmer_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('ORACLE', ''), f'{f} mentions the oracle'
