@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the symplectic hot path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W     (N>1: launched by torch.distributed.run,
+one rank per GPU).  Prints ONE JSON line on rank 0.
+
+Workload (config.workload = "allpairs_product"): the north-star all-pairs symplectic product of
+BASELINE.json — a 1,000-qubit operator, 10^5 left terms per GPU x 10^5 right terms, product rows + phase-
+corrected coefficients streamed through a ring of output slabs in HBM (10^10 pairs, 2.72 TB written per step and
+GPU).  One "step" = (N>1: RCCL all-gather of the packed right operand over xGMI, each rank contributes 1/N) + the
+full product of this rank's left block against the whole right operand.  Inputs are resident in HBM before the
+timed region.  Weak scaling: per-GPU work is fixed, value = all ranks' pairs / max-over-ranks time.
+
+roofline     — dominant kernel k_mul_rows (HBM-write stream): algorithmic bytes 16*Wq per pair (256 B at n=1000)
+               x pairs per launch / average launch duration from HIP events recorded around every launch in the
+               timed region (library stream).  peak = 8 TB/s (MI355X_MICROARCH.md).
+cpu_baseline — the NumPy restatement of the reference algorithm (oracle/oracle_np.py: broadcast XOR on
+               1-byte-per-bit matrices, per-bit popcount sums, complex outer product; base.py:783-792) timed on a
+               bounded sample of the same workload on the host cores.
+extras       — the other BASELINE configs measured on the same GPU (cfg3 product+cleanup, cfg2 rotation chain,
+               cfg4 GF(2) symmetry kernel in row-XORs/s, cfg5 commutation slice).  N=1, rank 0 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--qubits', type=int, default=1000)
+    ap.add_argument('--left-terms', type=int, default=100000, help='left terms PER GPU')
+    ap.add_argument('--right-terms', type=int, default=100000)
+    ap.add_argument('--slab-rows', type=int, default=256, help='outer rows per output slab')
+    ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--no-cpu', action='store_true')
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+    from symmer_amd import _lib, kernels
+    from symmer_amd.kernels import DeviceOp
+    from symmer_amd import parallel
+
+    _lib.init(local_rank)
+    lib = _lib.lib()
+    comm = parallel.Communicator.from_env()       # gloo control plane + RCCL data plane when world > 1
+
+    n, Ni, M = args.qubits, args.left_terms, args.right_terms
+    wq = (n + 63) // 64
+    left = DeviceOp.random(Ni, n, 0.3, seed=1234 + 7919 * rank)
+    # right operand: every rank owns a 1/world shard; the step all-gathers it
+    Ts = (M + world - 1) // world
+    my_rows = max(0, min(Ts, M - rank * Ts))
+    shard = DeviceOp.random(my_rows, n, 0.3, seed=99991 + rank) if world == 1 else parallel.padded_random_shard(my_rows, Ts, n, 99991 + rank)
+    right = shard if world == 1 else DeviceOp.alloc(Ts * world, wq, with_coeff=True)
+    slab = max(1, min(args.slab_rows, M))
+    ring = [DeviceOp.alloc(slab * Ni, wq, with_coeff=True) for _ in range(2)]
+
+    def step():
+        if world > 1:
+            comm.allgather_op(shard, right, M)
+        k = 0
+        for o0 in range(0, M, slab):
+            o1 = min(M, o0 + slab)
+            _lib.check(lib.symgpu_mul_allpairs_dev(left.handle, right.handle, o0, o1, 1, ring[k & 1].handle))
+            k += 1
+
+    def full_sync():
+        kernels.sync()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+
+    for _ in range(args.warmup):
+        step()
+    full_sync(); comm.barrier()
+    _lib.check(lib.symgpu_prof_enable(0, 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    full_sync(); comm.barrier()
+    dt = time.perf_counter() - t0
+    _lib.check(lib.symgpu_prof_enable(0, 0))
+    n_launch, tot_ms = ctypes.c_int64(0), ctypes.c_double(0)
+    _lib.check(lib.symgpu_prof_read(0, ctypes.addressof(n_launch), ctypes.addressof(tot_ms)))
+    dt = comm.max_over_ranks(dt)
+
+    pairs_per_step_rank = Ni * M
+    value = world * pairs_per_step_rank * args.steps / dt
+    launch_pairs = pairs_per_step_rank * args.steps / max(1, n_launch.value)
+    launch_ms = tot_ms.value / max(1, n_launch.value)
+    algo_bytes_launch = launch_pairs * 16 * wq
+    achieved = algo_bytes_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+
+    out = {
+        'metric': 'pauli_term_pairs_per_sec', 'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'u64', 'data': 'synthetic',
+        'config': {'workload': 'allpairs_product', 'n_qubits': n, 'left_terms_per_gpu': Ni, 'right_terms': M,
+                   'pairs_per_step': world * pairs_per_step_rank, 'bytes_per_pair': 16 * wq + 16, 'slab_rows': slab,
+                   'parallelism': f'left-axis shard x{world}, RCCL all-gather of right rows' if world > 1 else 'single GPU'},
+        'roofline': {'bound': 'hbm', 'kernel': 'k_mul_rows', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'launches': n_launch.value, 'avg_launch_ms': launch_ms,
+                     'algorithmic_bytes_per_launch': algo_bytes_launch,
+                     'whole_step_GBps': pairs_per_step_rank * (16 * wq + 16) / (dt / args.steps) / 1e9},
+    }
+    for r in ring:
+        r.free()
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        out['extras'] = extras(_lib, kernels, DeviceOp)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out['cpu_baseline'] = cpu_baseline(n)
+    comm.close()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def timed(fn, reps):
+    from symmer_amd import kernels
+    fn()
+    kernels.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    kernels.sync()
+    return (time.perf_counter() - t0) / reps
+
+
+def extras(_lib, kernels, DeviceOp):
+    """Other BASELINE.json configs on one GPU (device-resident inputs, C-ABI level)."""
+    lib = _lib.lib()
+    ex = {}
+    # cfg3: 1,000 qubits, 10,000 terms squared (1e8 pairs) + cleanup
+    A = DeviceOp.random(10000, 1000, 0.3, seed=1237)
+
+    def cfg3():
+        h = ctypes.c_void_p()
+        _lib.check(lib.symgpu_mul_cleanup_dev(A.handle, A.handle, 1, 1e-15, 1, ctypes.byref(h)))
+        r = DeviceOp(h); cfg3.n_out = r.n_terms; r.free()
+    t = timed(cfg3, 2)
+    ex['cfg3_mul_cleanup'] = {'pairs': 10**8, 'seconds': t, 'pairs_per_s': 1e8 / t, 'terms_out': cfg3.n_out}
+    A.free()
+    # cfg2: 1,000 qubits, 100,000 terms, chain of non-Clifford single-Pauli rotations, device resident
+    rng = np.random.default_rng(1236)
+    from symmer_amd import packing
+    P = DeviceOp.random(100000, 1000, 0.3, seed=1236)
+    qs = [packing.pack_rows((rng.random((1, 2000)) < 0.3))[0] for _ in range(8)]
+    t0 = time.perf_counter(); terms = []
+    cur = P
+    for q in qs[:4]:
+        res, allc = kernels.rotate_single_dev(cur, q, 0.3)
+        if cur is not P:
+            cur.free()
+        cur = res
+        terms.append(cur.n_terms)
+    kernels.sync(); t_chain = time.perf_counter() - t0
+    cur.free()
+    t1 = timed(lambda: kernels.rotate_single_dev(P, qs[0], 0.3)[0].free(), 5)
+    ex['cfg2_rotation'] = {'terms_in': 100000, 'first_rotation_seconds': t1, 'term_pairs_per_s': 1e5 / t1,
+                           'chain4_seconds': t_chain, 'chain_terms': terms}
+    P.free()
+    # cfg5 slice: 2,000 qubits, 25,000 x 200,000 commutation block (one rank's share of the 8-GPU adjacency)
+    C = DeviceOp.random(200000, 2000, 0.3, seed=1239)
+    nrow = 25000
+    buf = ctypes.c_void_p()
+    _lib.check(lib.symgpu_dev_alloc(nrow * 200000, ctypes.byref(buf)))
+    _lib.check(lib.symgpu_prof_enable(1, 1))
+    t = timed(lambda: _lib.check(lib.symgpu_commutes_dev(C.handle, 0, nrow, C.handle, buf)), 2)
+    nl, ms = ctypes.c_int64(0), ctypes.c_double(0)
+    _lib.check(lib.symgpu_prof_enable(1, 0)); _lib.check(lib.symgpu_prof_read(1, ctypes.addressof(nl), ctypes.addressof(ms)))
+    kt = ms.value / max(1, nl.value) * 1e-3
+    pairs = nrow * 200000
+    ex['cfg5_commutation_slice'] = {'pairs': pairs, 'seconds': t, 'pairs_per_s': pairs / t, 'kernel_seconds': kt,
+                                    'kernel_pairs_per_s': pairs / kt if kt else None,
+                                    'valu_frac': (pairs / kt * 4 * 32) / (256 * 4 * 32 * 2.4e9) if kt else None,
+                                    'hbm_GBps_at_1B_per_pair': pairs / kt / 1e9 if kt else None}
+    _lib.check(lib.symgpu_dev_free(buf)); C.free()
+    # cfg4: GF(2) symmetry kernel, 2,000 qubits x 50,000 terms, 32 planted symmetries, Clifford-scrambled
+    symp = rng.random((50000, 4000)) < 0.3
+    symp[:, :32] = False
+    H = DeviceOp.upload(packing.pack_rows(symp), np.ones(50000, dtype=complex))
+    del symp
+    for _ in range(16):
+        q = packing.pack_rows((rng.random((1, 4000)) < 0.3))[0]
+        res, allc = kernels.rotate_single_dev(H, q, np.pi / 2)
+        if not allc:
+            H.free(); H = res
+    outg = np.zeros((4000, 64), dtype='<u8')
+    k, nx = ctypes.c_int64(0), ctypes.c_int64(0)
+
+    def cfg4():
+        _lib.check(lib.symgpu_symmetry_kernel_dev(H.handle, 2000, outg.ctypes.data, 4000, ctypes.addressof(k), ctypes.addressof(nx)))
+    t = timed(cfg4, 2)
+    wc = (50000 + 63) // 64 + 64
+    ex['cfg4_symmetry_kernel'] = {'rows': 4000, 'cols': 54000, 'generators_found': k.value, 'row_xors': nx.value, 'seconds': t,
+                                  'row_xors_per_s': nx.value / t, 'algorithmic_GBps': nx.value * 16 * wc / t / 1e9}
+    H.free()
+    return ex
+
+
+def cpu_baseline(n):
+    """NumPy port of the reference's product (no cleanup), bounded sample of the same 1,000-qubit workload."""
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(1234)
+    Ns, Ms = 1000, 250
+    A = rng.random((Ns, 2 * n)) < 0.3; B = rng.random((Ms, 2 * n)) < 0.3
+    a = rng.standard_normal(Ns) + 1j * rng.standard_normal(Ns); b = rng.standard_normal(Ms) + 1j * rng.standard_normal(Ms)
+    onp.product_rows_and_coeffs(A[:50], a[:50], B[:20], b[:20])
+    reps, t_total = 0, 0.0
+    while t_total < 10.0 and reps < 20:
+        t0 = time.perf_counter()
+        onp.product_rows_and_coeffs(A, a, B, b)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    v = Ns * Ms * reps / t_total
+    return {'value': v, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{reps} x ({Ns} x {Ms} terms, {n} qubits) all-pairs product, NumPy restatement of base.py:783-792 '
+                      f'(1 byte per bit, single thread; host has {os.cpu_count()} cores)'}
+
+
+if __name__ == '__main__':
+    main()

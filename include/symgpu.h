@@ -47,6 +47,10 @@ int symgpu_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 /* HIP-event timer on the library stream (used by bench.py for per-kernel durations) */
 int symgpu_timer_start(void);
 int symgpu_timer_stop(float *ms);
+/* per-launch HIP-event timing of the dominant kernel of a class (0 = product row stream k_mul_rows,
+ * 1 = commutation k_commutes, 2 = GF(2) sweep k_sweep): enable, run, then read {launch count, total ms}. */
+int symgpu_prof_enable(int kernel_class, int on);
+int symgpu_prof_read(int kernel_class, int64_t *n_launches, double *total_ms);
 
 /* ---- device-resident operators -------------------------------------------------------------- */
 int symgpu_op_upload(const uint64_t *rows, const double *coeff /* may be NULL */, int64_t T, int Wq, symgpu_op_t *out);

@@ -52,6 +52,14 @@ struct Context {
 Context &ctx();
 int require_ctx();
 
+// per-launch event timing of one kernel class (bench.py roofline leg)
+struct ProfScope {
+    int cls; bool on;
+    hipEvent_t a = nullptr, b = nullptr;
+    explicit ProfScope(int kernel_class);
+    ~ProfScope();
+};
+
 // cached device allocator (hipMalloc is slow; rotations chain many small temporaries)
 int dev_alloc(size_t bytes, void **ptr);
 int dev_free(void *ptr);

@@ -129,6 +129,7 @@ int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out,
         i64 ny = gy - y0 < max_gy ? gy - y0 : max_gy;
         const i64 joff = y0 * 64 * CJ;
         dim3 grid((unsigned)gx, (unsigned)ny);
+        ProfScope prof(1);
         if (out_bits) {
             const i64 stride = (M + 63) / 64;
             hipLaunchKernelGGL(k_commutes<true>, grid, dim3(256), 0, ctx().stream, at.as<u64>(), Npad, N,

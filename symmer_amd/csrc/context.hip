@@ -115,6 +115,22 @@ void dev_cache_release() {
     g_cached_bytes = 0;
 }
 
+// ---- per-launch profiling ---------------------------------------------------------------------------
+struct ProfClass { bool on = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
+static ProfClass g_prof[3];
+
+ProfScope::ProfScope(int kernel_class) : cls(kernel_class), on(false) {
+    if (cls < 0 || cls >= 3 || !g_prof[cls].on) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { (void)hipGetLastError(); return; }
+    on = true;
+    (void)hipEventRecord(a, g_ctx.stream);
+}
+ProfScope::~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(b, g_ctx.stream);
+    g_prof[cls].ev.push_back({a, b});
+}
+
 // ---- small kernels -----------------------------------------------------------------------------
 __global__ void k_xor_fold(const u64 *__restrict__ rows, i64 T, int W, u64 *__restrict__ out) {
     // out[w] ^= XOR over rows; one block per grid-stride chunk, lanes over (row, word) pairs
@@ -300,6 +316,29 @@ int symgpu_timer_stop(float *ms) {
     float t = 0;
     HIP_TRY(hipEventElapsedTime(&t, ctx().ev0, ctx().ev1));
     if (ms) *ms = t;
+    return SYMGPU_OK;
+}
+
+int symgpu_prof_enable(int kernel_class, int on) {
+    SG_REQUIRE(kernel_class >= 0 && kernel_class < 3, "prof_enable: class");
+    g_prof[kernel_class].on = on != 0;
+    return SYMGPU_OK;
+}
+
+int symgpu_prof_read(int kernel_class, int64_t *n_launches, double *total_ms) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(kernel_class >= 0 && kernel_class < 3, "prof_read: class");
+    HIP_TRY(hipStreamSynchronize(ctx().stream));
+    double tot = 0;
+    for (auto &p : g_prof[kernel_class].ev) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) tot += ms;
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    if (n_launches) *n_launches = (int64_t)g_prof[kernel_class].ev.size();
+    if (total_ms) *total_ms = tot;
+    g_prof[kernel_class].ev.clear();
     return SYMGPU_OK;
 }
 

@@ -179,6 +179,7 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
             hipLaunchKernelGGL(k_select, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, rows, R, Wc, i0, kk, info.as<PanelInfo>(),
                                sel.as<u32>(), count.as<unsigned long long>());
             KERNEL_CHECK();
+            ProfScope prof(2);
             hipLaunchKernelGGL(k_sweep, dim3(gx, gy), dim3(256), 0, st, rows, R, Wc, i0, kk, sel.as<u32>());
             KERNEL_CHECK();
         }

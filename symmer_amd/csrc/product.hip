@@ -193,6 +193,7 @@ int mul_rows_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 o_begin, i64 o_
         const i64 ny = gy_total - y0 < max_gy ? gy_total - y0 : max_gy;
         const i64 ooff = y0 * RTO;
         dim3 grid((unsigned)gx, (unsigned)ny);
+        ProfScope prof(0);
         hipLaunchKernelGGL(k_mul_rows, grid, dim3(256), 0, ctx().stream, reinterpret_cast<const u32x4 *>(inner), n_chunks,
                            reinterpret_cast<const u32x4 *>(outer + (o_begin + ooff) * 2 * Wq), Wq, No - ooff,
                            reinterpret_cast<u32x4 *>(out_rows) + ooff * n_chunks);

@@ -1,0 +1,139 @@
+"""Multi-GPU sharding of the all-pairs kernels — one process per GPU.
+
+The LEFT term axis is split into contiguous blocks, one per rank; every rank owns a 1/G shard of the packed RIGHT
+operand, and ONE all-gather assembles the full right operand on every rank (RCCL ``ncclAllGather`` over xGMI through
+``symgpu_comm_allgather_op``); each rank then computes its ``[N/G, M]`` block locally.  There is no reduction
+collective anywhere on the path.  The reference has nothing comparable (its only parallelism is a CPU fork pool,
+``symmer/process_handler.py``, off this path).
+
+Control plane (unique-id exchange, barriers, max-over-ranks timing) uses ``torch.distributed`` with the gloo backend
+— plumbing only; the data plane never touches torch.  With ``backend='gloo-host'`` the all-gather itself runs over
+gloo on host arrays, which is what the CPU tests (world_size 2) exercise.
+"""
+import os
+import ctypes
+import numpy as np
+
+
+def shard_bounds(n_rows, world):
+    """Contiguous equal blocks of ``ceil(n_rows/world)`` rows; tail ranks may be short or empty.
+    Returns (Ts, [(begin, end)] per rank)."""
+    ts = (n_rows + world - 1) // world if world > 0 else n_rows
+    return ts, [(min(n_rows, r * ts), min(n_rows, (r + 1) * ts)) for r in range(world)]
+
+
+class Communicator:
+    def __init__(self, rank=0, world=1, data_plane='none'):
+        self.rank, self.world, self.data_plane = rank, world, data_plane
+        self._dist = None
+
+    # ---- construction ------------------------------------------------------------------------------------
+    @classmethod
+    def from_env(cls, data_plane='rccl'):
+        """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as set by ``torch.distributed.run``."""
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        rank = int(os.environ.get('RANK', '0'))
+        if world == 1:
+            return cls(0, 1, 'none')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        self = cls(rank, world, data_plane)
+        self._dist = dist
+        if data_plane == 'rccl':
+            self._init_rccl()
+        return self
+
+    def _init_rccl(self):
+        import torch
+        from . import _lib
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (ctypes.c_uint8 * 128)()
+            _lib.check(_lib.lib().symgpu_comm_unique_id(ctypes.addressof(buf)))
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        self._dist.broadcast(ident, src=0)
+        raw = (ctypes.c_uint8 * 128)(*ident.tolist())
+        _lib.check(_lib.lib().symgpu_comm_init(ctypes.addressof(raw), self.rank, self.world))
+
+    # ---- control plane -----------------------------------------------------------------------------------
+    def barrier(self):
+        if self._dist is not None:
+            self._dist.barrier()
+
+    def max_over_ranks(self, x):
+        if self._dist is None:
+            return x
+        import torch
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t[0])
+
+    # ---- data plane ----------------------------------------------------------------------------------------
+    def allgather_op(self, shard, full, n_rows_total):
+        """Device-resident: gather every rank's shard (capacity Ts) into ``full`` and trim it to ``n_rows_total``."""
+        from . import _lib
+        if self.world == 1:
+            raise ValueError('allgather_op on a single rank: use the shard directly')
+        _lib.check(_lib.lib().symgpu_comm_allgather_op(shard.handle, full.handle))
+        full.set_rows(n_rows_total)
+
+    def allgather_rows_host(self, local_rows, n_rows_total):
+        """Host arrays over gloo (CPU tests / PCIe staging): returns the full ``uint64[n_rows_total, W]`` array."""
+        local_rows = np.ascontiguousarray(local_rows, dtype='<u8')
+        if self.world == 1:
+            return local_rows
+        import torch
+        ts, _ = shard_bounds(n_rows_total, self.world)
+        W = local_rows.shape[1]
+        pad = np.zeros((ts, W), dtype=np.int64)
+        pad[:local_rows.shape[0]] = local_rows.view(np.int64)
+        parts = [torch.zeros((ts, W), dtype=torch.int64) for _ in range(self.world)]
+        self._dist.all_gather(parts, torch.from_numpy(pad))
+        return np.concatenate([p.numpy() for p in parts], axis=0)[:n_rows_total].view('<u8')
+
+    def close(self):
+        if self.data_plane == 'rccl' and self.world > 1:
+            from . import _lib
+            _lib.load().symgpu_comm_destroy()
+        if self._dist is not None and self._dist.is_initialized():
+            self._dist.barrier()
+            self._dist.destroy_process_group()
+            self._dist = None
+
+
+def padded_random_shard(my_rows, ts, n_qubits, seed):
+    """Synthetic right-operand shard with capacity ``ts`` (the all-gather pads the unused tail with zeros)."""
+    from .kernels import DeviceOp
+    op = DeviceOp.random(ts, n_qubits, 0.3, seed)
+    op.set_rows(my_rows)
+    return op
+
+
+def sharded_commutes(a_rows_global, b_rows_local, n_b_total, comm, kernel=None):
+    """This rank's block of ``commutes_termwise``: rows ``[begin, end)`` of the left operand against the WHOLE right
+    operand (gathered from the per-rank shards).  ``kernel(a_block, b_full) -> bool[rows, M]`` defaults to the HIP
+    commutation kernel; the CPU tests inject a checker to exercise the sharding/gather logic without a GPU."""
+    if kernel is None:
+        from . import kernels
+        kernel = kernels.commutes
+    _, bounds = shard_bounds(a_rows_global.shape[0], comm.world)
+    b0, b1 = bounds[comm.rank]
+    b_full = comm.allgather_rows_host(b_rows_local, n_b_total)
+    return (b0, b1), kernel(np.ascontiguousarray(a_rows_global[b0:b1]), b_full)
+
+
+def sharded_product(a_rows_global, a_coeff_global, b_rows_local, b_coeff_local, n_b_total, comm, kernel=None):
+    """This rank's slab of the uncleaned product ``A * B`` with A (left factor) sharded along its term axis and B
+    gathered: returns ((begin, end), rows, coeff) where row ``o*(end-begin) + i`` = ``A[begin+i] ^ B[o]``."""
+    if kernel is None:
+        from . import kernels
+        kernel = kernels.mul_allpairs
+    _, bounds = shard_bounds(a_rows_global.shape[0], comm.world)
+    b0, b1 = bounds[comm.rank]
+    b_full = comm.allgather_rows_host(b_rows_local, n_b_total)
+    c = np.ascontiguousarray(b_coeff_local, dtype=np.complex128).view(np.float64).reshape(-1, 2)
+    c_full = comm.allgather_rows_host(c.view('<u8'), n_b_total).view(np.float64).reshape(-1, 2).copy().view(np.complex128).reshape(-1)
+    rows, coeff = kernel(np.ascontiguousarray(a_rows_global[b0:b1]), a_coeff_global[b0:b1], b_full, c_full, True)
+    return (b0, b1), rows, coeff

@@ -1,0 +1,68 @@
+"""CPU, world_size 2 over gloo: the left-axis sharding + right-operand all-gather logic of symmer_amd/parallel.py.
+The per-rank kernel is injected (the C oracle stands in for the HIP kernel, which needs a GPU), so this checks
+exactly the multi-rank plumbing: shard bounds, padded gather, block placement."""
+import os, socket, sys
+import multiprocessing as mp
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        from symmer_amd import parallel
+        from oracle import oracle_c as oc, oracle_np as onp
+        comm = parallel.Communicator.from_env(data_plane='gloo-host')
+        rng = np.random.default_rng(77)                       # same global operands on every rank
+        n, N, M = 130, 37, 51
+        A = onp.pack_rows(rng.random((N, 2 * n)) < 0.3); B = onp.pack_rows(rng.random((M, 2 * n)) < 0.3)
+        a = (rng.integers(-8, 9, N) + 1j * rng.integers(-8, 9, N)) / 16.0; b = (rng.integers(-8, 9, M) + 1j * rng.integers(-8, 9, M)) / 16.0
+        ts, bounds = parallel.shard_bounds(M, world)
+        m0, m1 = bounds[rank]
+        (r0, r1), blk = parallel.sharded_commutes(A, B[m0:m1], M, comm, kernel=oc.commutes)
+        full = oc.commutes(A, B)
+        ok = np.array_equal(blk, full[r0:r1]) and (r0, r1) == parallel.shard_bounds(N, world)[1][rank]
+        (r0, r1), rows, coeff = parallel.sharded_product(A, a, B[m0:m1], b[m0:m1], M, comm, kernel=oc.mul_allpairs)
+        erows, ecoeff = oc.mul_allpairs(A[r0:r1], a[r0:r1], B, b, True)
+        ok = ok and np.array_equal(rows, erows) and np.array_equal(coeff, ecoeff)
+        t = comm.max_over_ranks(float(rank + 1))
+        ok = ok and t == float(world)
+        comm.close()
+        q.put((rank, bool(ok), ''))
+    except Exception as e:                                    # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+def test_shard_bounds():
+    from symmer_amd.parallel import shard_bounds
+    assert shard_bounds(10, 4) == (3, [(0, 3), (3, 6), (6, 9), (9, 10)])
+    assert shard_bounds(2, 4) == (1, [(0, 1), (1, 2), (2, 2), (2, 2)])
+    assert shard_bounds(200000, 8)[0] == 25000
+    for n in (0, 1, 7, 64, 1001):
+        for w in (1, 2, 3, 8):
+            ts, b = shard_bounds(n, w)
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert all(e - s <= ts for s, e in b)
+
+
+@pytest.mark.timeout(300)
+def test_world_size_2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, err in res:
+        assert ok, f'rank {rank} failed: {err}'
