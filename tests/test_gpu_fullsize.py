@@ -1,0 +1,142 @@
+"""GPU: BASELINE.json's full sizes, checked through size-independent properties (round trips, linearity checksums,
+cross-kernel consistency) plus exact oracle comparison on sub-blocks the C oracle finishes in seconds."""
+import ctypes
+import numpy as np
+import pytest
+from symmer_amd import PauliwordOp, IndependentOp, kernels, packing, _lib
+from symmer_amd.kernels import DeviceOp
+from oracle import oracle_c as oc
+
+pytestmark = pytest.mark.gpu
+
+
+def dyadic(rng, t):
+    return (rng.integers(-8, 9, t) + 1j * rng.integers(-8, 9, t)) / 16.0
+
+
+def sort_rows(rows, coeff):
+    order = np.lexsort(rows.T[::-1])
+    return rows[order], coeff[order]
+
+
+def test_northstar_product_slab_checksums():
+    """1,000 qubits, 10^5 x 10^5 terms: one 256-row output slab (2.56e7 pairs, 6.5 GB) — XOR-fold linearity,
+    coefficient-sum vs the oracle on the slab's coefficients, exact rows/coefficients on a 3-row sub-slab."""
+    n, Ni, No = 1000, 100000, 100000
+    A = DeviceOp.random(Ni, n, 0.3, seed=1234); B = DeviceOp.random(No, n, 0.3, seed=99991)
+    a_rows, a_c = A.download(); b_rows, b_c = B.download()
+    out = DeviceOp.alloc(256 * Ni, 16, with_coeff=True)
+    lib = _lib.lib()
+    for (o0, o1) in ((0, 256), (99872, 100000), (5000, 5003)):
+        _lib.check(lib.symgpu_mul_allpairs_dev(A.handle, B.handle, o0, o1, 1, out.handle))
+        assert out.n_terms == (o1 - o0) * Ni
+        x, csum = out.checksum()
+        expect = np.zeros(32, dtype='<u8')
+        if (o1 - o0) % 2:
+            expect ^= np.bitwise_xor.reduce(a_rows, axis=0)
+        if Ni % 2:
+            expect ^= np.bitwise_xor.reduce(b_rows[o0:o1], axis=0)
+        assert np.array_equal(x, expect)
+        if o1 - o0 == 3:
+            rows, coeff = out.download()
+            er, ec = oc.mul_allpairs(a_rows, a_c, b_rows[o0:o1], b_c[o0:o1], True)
+            assert np.array_equal(rows, er) and np.array_equal(coeff, ec)
+            assert abs(csum - ec.sum()) <= 1e-9 * np.abs(ec).sum()
+    for h in (A, B, out):
+        h.free()
+
+
+def test_cfg3_square_with_cleanup_consistency():
+    """1,000 qubits, 10^4 terms squared (10^8 pairs) + cleanup, dyadic coefficients: the number of surviving terms must be
+    1 + #commuting pairs with non-zero doubled coefficient (anticommuting pairs cancel EXACTLY), the coefficient sum is
+    conserved exactly, and every surviving row is a product of two input rows."""
+    rng = np.random.default_rng(1237)
+    n, N = 1000, 10000
+    symp = rng.random((N, 2 * n)) < 0.3
+    c = dyadic(rng, N); c[c == 0] = 0.5
+    A = PauliwordOp(symp, c)
+    R = A * A
+    adj = A.adjacency_matrix
+    n_comm_pairs = (int(adj.sum()) - N) // 2
+    assert R.n_terms == 1 + n_comm_pairs
+    assert not R.symp_matrix[0].any()                                    # identity first (first occurrence: pair (0,0))
+    # conservation: sum of output coefficients == sum over all pairs, computed slab-wise from the uncleaned product
+    dA = DeviceOp.upload(A.packed, A.coeff_vec)
+    out = DeviceOp.alloc(1000 * N, 16, with_coeff=True)
+    total = 0j
+    for o0 in range(0, N, 1000):
+        _lib.check(_lib.lib().symgpu_mul_allpairs_dev(dA.handle, dA.handle, o0, o0 + 1000, 1, out.handle))
+        total += out.checksum()[1]
+    assert total == R.coeff_vec.sum()                                    # dyadic: exact
+    assert R.coeff_vec[0] == np.sum(c * c)                               # P_i * P_i = I with coefficient c_i^2
+    dA.free(); out.free()
+
+
+def test_cfg2_rotation_roundtrip():
+    """1,000 qubits, 10^5 terms: R(-t) R(t) P == P (rows as a set, coefficients 1e-12); Clifford pi/2 then 3pi/2 == P exactly."""
+    rng = np.random.default_rng(1236)
+    n, N = 1000, 100000
+    P = PauliwordOp(rng.random((N, 2 * n)) < 0.3, dyadic(rng, N)).cleanup()
+    Q = PauliwordOp((rng.random(2 * n) < 0.3).reshape(1, -1), [1])
+    fwd = P._rotate_by_single_Pword(Q, 0.3)
+    assert P.n_terms < fwd.n_terms <= 2 * P.n_terms
+    n_anti = int((~P.commutes_termwise(Q)).sum())
+    assert fwd.n_terms == P.n_terms + n_anti                              # no accidental merges at n=1000
+    back = fwd._rotate_by_single_Pword(Q, -0.3)
+    r1, c1 = sort_rows(back.packed, back.coeff_vec); r0, c0 = sort_rows(P.packed, P.coeff_vec)
+    assert np.array_equal(r1, r0) and np.allclose(c1, c0, rtol=0, atol=1e-12)
+    cl = P._rotate_by_single_Pword(Q, np.pi / 2)._rotate_by_single_Pword(Q, 3 * np.pi / 2)
+    r1, c1 = sort_rows(cl.packed, cl.coeff_vec)
+    assert np.array_equal(r1, r0) and np.array_equal(c1, c0)
+    chain = P.perform_rotations([(Q, 0.3), (Q, -0.3)])
+    r1, c1 = sort_rows(chain.packed, chain.coeff_vec)
+    assert np.array_equal(r1, r0) and np.allclose(c1, c0, rtol=0, atol=1e-12)
+
+
+def test_cfg4_symmetry_generators_full_size():
+    """2,000 qubits x 50,000 terms with 32 planted symmetries, scrambled by 16 Clifford rotations: exactly 32 generators,
+    each commuting with every term, mutually independent; [4000 x 54000] elimination, ~8e6 reference row-XORs."""
+    rng = np.random.default_rng(1238)
+    n, M, k = 2000, 50000, 32
+    symp = rng.random((M, 2 * n)) < 0.3
+    symp[:, :k] = False
+    H = PauliwordOp(symp, np.ones(M))
+    rots = [(PauliwordOp((rng.random(2 * n) < 0.3).reshape(1, -1), [1]), np.pi / 2) for _ in range(16)]
+    H = H.perform_rotations(rots)
+    assert H.n_terms == M
+    rows, n_xor = kernels.symmetry_kernel(H.packed, n)
+    assert rows.shape[0] == k
+    assert 7_000_000 < n_xor < 9_000_000
+    S = IndependentOp.symmetry_generators(H, commuting_override=True)     # constructor re-checks independence on device
+    assert S.n_terms == k and np.all(S.commutes_termwise(H)) and np.all(S.adjacency_matrix)
+    # the planted generators Z_0..Z_31, pushed through the same rotations, span the same space
+    planted = np.zeros((k, 2 * n), dtype=bool); planted[np.arange(k), n + np.arange(k)] = True
+    Z = PauliwordOp(planted, np.ones(k)).perform_rotations(rots)
+    _, mask = Z.generator_reconstruction(S)
+    assert np.all(mask)
+
+
+def test_cfg5_adjacency_slice_full_width():
+    """2,000 qubits, 200,000 terms: a 4096-row block of the adjacency matrix against all terms — symmetric on the square
+    sub-block, True on the diagonal, exact vs the C oracle on a 64 x 8192 corner, and byte count == bit-packed popcount."""
+    n, N, rows = 2000, 200000, 4096
+    A = DeviceOp.random(N, n, 0.3, seed=1239)
+    lib = _lib.lib()
+    buf = ctypes.c_void_p(); bits = ctypes.c_void_p()
+    _lib.check(lib.symgpu_dev_alloc(rows * N, ctypes.byref(buf)))
+    _lib.check(lib.symgpu_dev_alloc(rows * ((N + 63) // 64) * 8, ctypes.byref(bits)))
+    _lib.check(lib.symgpu_commutes_dev(A.handle, 0, rows, A.handle, buf))
+    _lib.check(lib.symgpu_commutes_bits_dev(A.handle, 0, rows, A.handle, bits))
+    out = np.empty((rows, N), dtype=np.uint8)
+    _lib.check(lib.symgpu_dev_download(buf, out.ctypes.data, out.nbytes))
+    assert set(np.unique(out)) <= {0, 1}
+    sq = out[:, :rows]
+    assert np.array_equal(sq, sq.T) and np.all(np.diag(sq) == 1)
+    a_rows = A.download(with_coeff=False)
+    assert np.array_equal(out[:64, :8192].astype(bool), oc.commutes(a_rows[:64], a_rows[:8192]))
+    s_bytes, s_bits = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    _lib.check(lib.symgpu_dev_checksum_u8(buf, rows * N, ctypes.addressof(s_bytes)))
+    _lib.check(lib.symgpu_dev_popcount_u64(bits, rows * ((N + 63) // 64), ctypes.addressof(s_bits)))
+    assert s_bytes.value == int(out.sum()) == s_bits.value
+    assert 0.45 < s_bytes.value / (rows * N) < 0.55
+    _lib.check(lib.symgpu_dev_free(buf)); _lib.check(lib.symgpu_dev_free(bits)); A.free()
