@@ -71,13 +71,13 @@ def main():
     # right operand: every rank owns a 1/world shard; the step all-gathers it
     Ts = (M + world - 1) // world
     my_rows = max(0, min(Ts, M - rank * Ts))
-    shard = DeviceOp.random(my_rows, n, 0.3, seed=99991 + rank) if world == 1 else parallel.padded_random_shard(my_rows, Ts, n, 99991 + rank)
-    right = shard if world == 1 else DeviceOp.alloc(Ts * world, wq, with_coeff=True)
+    shard = parallel.padded_random_shard(my_rows, Ts, n, 99991 + rank) if comm.gathers else DeviceOp.random(my_rows, n, 0.3, seed=99991 + rank)
+    right = DeviceOp.alloc(Ts * world, wq, with_coeff=True) if comm.gathers else shard
     slab = max(1, min(args.slab_rows, M))
     ring = [DeviceOp.alloc(slab * Ni, wq, with_coeff=True) for _ in range(2)]
 
     def step():
-        if world > 1:
+        if comm.gathers:
             comm.allgather_op(shard, right, M)
         k = 0
         for o0 in range(0, M, slab):
@@ -86,13 +86,9 @@ def main():
             k += 1
 
     def full_sync():
-        kernels.sync()
-        try:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-        except Exception:
-            pass
+        # device-wide synchronisation == torch.cuda.synchronize(); torch's CUDA runtime is deliberately NOT initialised in
+        # this process (PyTorch wheels bundle their own HIP runtime; the product uses the system one)
+        _lib.check(lib.symgpu_device_sync())
 
     for _ in range(args.warmup):
         step()

@@ -42,6 +42,7 @@ int symgpu_shutdown(void);
 const char *symgpu_last_error(void);
 int symgpu_device_count(int *n);          /* does not initialise a device */
 int symgpu_sync(void);                    /* wait for the library stream */
+int symgpu_device_sync(void);             /* hipDeviceSynchronize on the library's device (all streams) */
 int symgpu_device_name(char *buf, int len);
 int symgpu_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 /* HIP-event timer on the library stream (used by bench.py for per-kernel durations) */

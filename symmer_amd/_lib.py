@@ -32,6 +32,7 @@ SIGNATURES = {
     'symgpu_shutdown': [],
     'symgpu_device_count': [P],
     'symgpu_sync': [],
+    'symgpu_device_sync': [],
     'symgpu_device_name': [P, c_int],
     'symgpu_mem_info': [P, P],
     'symgpu_timer_start': [],
@@ -86,7 +87,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise SymgpuError(E_NODEVICE, f'{LIB_PATH} not found — build it with `python -c "import __graft_entry__ as g; g.build()"` '
                                       f'or `make -C symmer_amd/csrc` (there is no CPU fallback)')
-    lib = ctypes.CDLL(LIB_PATH)
+    # RTLD_DEEPBIND: bind HIP symbols to the runtime this library was linked against (/opt/rocm), even if another HIP
+    # runtime (e.g. the one bundled in a PyTorch wheel) is already loaded in the process' global scope.
+    lib = ctypes.CDLL(LIB_PATH, mode=os.RTLD_NOW | os.RTLD_LOCAL | getattr(os, 'RTLD_DEEPBIND', 0))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes

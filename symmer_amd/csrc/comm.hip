@@ -8,6 +8,8 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <string.h>
+#include <stdlib.h>
+#include <string>
 
 namespace symgpu {
 
@@ -26,10 +28,15 @@ static Rccl g_rccl;
 
 static int load_rccl() {
     if (g_rccl.handle) return SYMGPU_OK;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // absolute paths first: a dlopen by SONAME would hand back a *different* librccl that is already in the process
+    // (PyTorch wheels bundle one, built against their own HIP runtime)
+    std::string env_path = getenv("ROCM_PATH") ? std::string(getenv("ROCM_PATH")) + "/lib/librccl.so.1" : std::string("/opt/rocm/lib/librccl.so.1");
+    const char *names[] = {env_path.c_str(), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
     void *h = nullptr;
     for (const char *n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        // DEEPBIND: librccl must resolve HIP against ITS OWN dependency (the /opt/rocm libamdhip64 this library is linked
+        // to), not against another HIP runtime that may sit in the global scope (PyTorch wheels bundle one).
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
         if (h) break;
     }
     if (!h) {

@@ -285,6 +285,12 @@ int symgpu_sync(void) {
     return SYMGPU_OK;
 }
 
+int symgpu_device_sync(void) {
+    SG_TRY(require_ctx());
+    HIP_TRY(hipDeviceSynchronize());
+    return SYMGPU_OK;
+}
+
 int symgpu_device_name(char *buf, int len) {
     SG_TRY(require_ctx());
     if (!buf || len <= 0) return SYMGPU_E_INVALID;

@@ -91,6 +91,110 @@ __global__ __launch_bounds__(PANEL_THREADS) void k_panel(u64 *__restrict__ rows,
     if (tid == 0 && cnt) atomicAdd(xor_count, cnt);
 }
 
+// ---- register-resident panel ------------------------------------------------------------------------
+// 256 threads (one wave per SIMD); thread t holds words t, t+256, ... (WPT of them) of all KB block rows in VGPRs
+// (KB*WPT*2 registers, up to 256).  Per pivot: the pivot row is picked with a wave-uniform if-chain, its leftmost
+// non-zero word is found with WPT ballots + one 4-entry LDS exchange, the owner lane of that word extracts the pivot
+// bit of every block row into a KB-bit mask (second LDS exchange), and every thread XORs the pivot row into the
+// flagged rows in registers under scalar branches.  Two barriers per pivot, no LDS atomics, no LDS read-modify-write.
+template <int WPT, int KB>
+__global__ __launch_bounds__(256) void k_panel_reg(u64 *__restrict__ rows, i64 Wc, i64 i0, int kk, PanelInfo *__restrict__ info,
+                                                    i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count) {
+    __shared__ int s_cand[2][4];
+    __shared__ u32 s_mask[2];
+    __shared__ u32 s_allmask[GK];
+    __shared__ int s_pw[GK], s_pb[GK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 Rl[KB][WPT], Rh[KB][WPT];      // 32-bit halves: no register-pair constraints across the loop back-edge
+#pragma unroll
+    for (int r = 0; r < KB; ++r)
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            const i64 w = tid + 256 * k;
+            const u64 v = (r < kk && w < Wc) ? rows[(i0 + r) * Wc + w] : 0ULL;
+            Rl[r][k] = (u32)v;
+            Rh[r][k] = (u32)(v >> 32);
+        }
+    u32 cnt = 0;
+#pragma unroll 1
+    for (int j = 0; j < kk; ++j) {
+        const int slot = j & 1;
+        u32 pl[WPT], ph[WPT];
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) pl[k] = ph[k] = 0;
+#pragma unroll
+        for (int r = 0; r < KB; ++r)
+            if (r == j) {                       // wave-uniform: scalar branch, one copy executed
+#pragma unroll
+                for (int k = 0; k < WPT; ++k) { pl[k] = Rl[r][k]; ph[k] = Rh[r][k]; }
+            }
+        // leftmost non-zero word of row j: word index = 256*k + tid, increasing in k first
+        int cand = 0x7fffffff;
+#pragma unroll
+        for (int k = WPT - 1; k >= 0; --k) {
+            const u64 b = __ballot((pl[k] | ph[k]) != 0);
+            if (b) cand = 256 * k + 64 * wave + (int)__builtin_ctzll(b);
+        }
+        if (lane == 0) s_cand[slot][wave] = cand;
+        __syncthreads();
+        int w0 = s_cand[slot][0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) w0 = min(w0, s_cand[slot][q]);
+        if (w0 == 0x7fffffff) {                 // zero row: no pivot (uniform)
+            if (tid == 0) { s_pw[j] = -1; s_pb[j] = 0; s_allmask[j] = 0; }
+            continue;
+        }
+        const int k0 = w0 >> 8, t0 = w0 & 255;
+        if (tid == t0) {                        // owner of the pivot word: pivot bit + flags of all block rows
+            u32 mask = 0;
+            int b = 0;
+#pragma unroll
+            for (int k = 0; k < WPT; ++k)
+                if (k == k0) {
+                    const bool in_lo = pl[k] != 0;
+                    const int bb = in_lo ? __builtin_ctz(pl[k]) : __builtin_ctz(ph[k]);
+                    b = in_lo ? bb : 32 + bb;
+#pragma unroll
+                    for (int r = 0; r < KB; ++r) mask |= (((in_lo ? Rl[r][k] : Rh[r][k]) >> bb) & 1u) << r;
+                }
+            mask &= ~(1u << j);
+            s_mask[slot] = mask;
+            s_pw[j] = w0; s_pb[j] = b; s_allmask[j] = mask;
+            cnt += __popc(mask);
+        }
+        __syncthreads();
+        const u32 mask = __builtin_amdgcn_readfirstlane(s_mask[slot]);
+#pragma unroll
+        for (int r = 0; r < KB; ++r) {
+            // branch-free: sel is a wave-uniform all-ones/zero word (SGPR); R ^= p & sel is one v_bitop3_b32 per half
+            const u32 sel = ((mask >> r) & 1u) ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int k = 0; k < WPT; ++k) {
+                Rl[r][k] = __builtin_amdgcn_bitop3_b32(Rl[r][k], pl[k], sel, 0x78);
+                Rh[r][k] = __builtin_amdgcn_bitop3_b32(Rh[r][k], ph[k], sel, 0x78);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < KB; ++r)
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            const i64 w = tid + 256 * k;
+            if (r < kk && w < Wc) rows[(i0 + r) * Wc + w] = ((u64)Rh[r][k] << 32) | Rl[r][k];
+        }
+    if (tid < GK) {
+        const bool live = tid < kk;
+        info->pivw[tid] = live ? s_pw[tid] : -1;
+        info->pivb[tid] = live ? s_pb[tid] : 0;
+        info->mask[tid] = live ? s_allmask[tid] : 0u;
+        if (live && pivots) pivots[i0 + tid] = s_pw[tid] < 0 ? -1 : (i64)s_pw[tid] * 64 + s_pb[tid];
+    }
+    // the owner lane differs per pivot: reduce the per-thread counts
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if (lane == 0 && cnt) atomicAdd(xor_count, (unsigned long long)cnt);
+}
+
 // selector of every row outside the block + reference-order XOR count
 __global__ __launch_bounds__(256) void k_select(const u64 *__restrict__ rows, i64 R, i64 Wc, i64 i0, int kk, const PanelInfo *__restrict__ info,
                                                  u32 *__restrict__ sel, unsigned long long *__restrict__ xor_count) {
@@ -156,24 +260,36 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     SG_TRY(count.alloc(16));
     SG_TRY(piv.alloc((size_t)R * 8));
     HIP_TRY(hipMemsetAsync(count.p, 0, 16, st));
-    // rows per panel: as many as fit in LDS (<= 32); rows wider than the LDS budget run the panel in global memory
+    // Panel variant: rows up to 2048 words stay in VGPRs (k_panel_reg); wider rows use the LDS panel (as many rows as fit
+    // in LDS, <= 32), and rows wider than the LDS budget run the same code on global memory.
     const size_t lds_budget = 144 * 1024;
-    int K = (int)(lds_budget / ((size_t)Wc * 8));
-    bool in_lds = true;
-    if (K < 1) { K = 8; in_lds = false; }
-    if (K > GK) K = GK;
-    if (in_lds) {
+    int K = GK, variant = 0;        // 0: registers, 1: LDS, 2: global
+    if (Wc <= 1024) K = 32;
+    else if (Wc <= 2048) K = 16;
+    else {
+        K = (int)(lds_budget / ((size_t)Wc * 8));
+        variant = 1;
+        if (K < 1) { K = 8; variant = 2; }
+        if (K > GK) K = GK;
+    }
+    if (variant == 1) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
     }
     const unsigned gx = (unsigned)((Wc + 255) / 256), gy = (unsigned)((R + SW_ROWS - 1) / SW_ROWS);
+    PanelInfo *pinfo = info.as<PanelInfo>();
+    i64 *ppiv = piv.as<i64>();
+    unsigned long long *pcount = count.as<unsigned long long>();
     for (i64 i0 = 0; i0 < R; i0 += K) {
         const int kk = (int)((R - i0 < K) ? (R - i0) : K);
-        if (in_lds)
-            hipLaunchKernelGGL(k_panel<true>, dim3(1), dim3(PANEL_THREADS), (size_t)kk * Wc * 8, st, rows, Wc, i0, kk,
-                               info.as<PanelInfo>(), piv.as<i64>(), count.as<unsigned long long>());
+        if (variant == 0) {
+            if (Wc <= 256) hipLaunchKernelGGL((k_panel_reg<1, 32>), dim3(1), dim3(256), 0, st, rows, Wc, i0, kk, pinfo, ppiv, pcount);
+            else if (Wc <= 512) hipLaunchKernelGGL((k_panel_reg<2, 32>), dim3(1), dim3(256), 0, st, rows, Wc, i0, kk, pinfo, ppiv, pcount);
+            else if (Wc <= 1024) hipLaunchKernelGGL((k_panel_reg<4, 32>), dim3(1), dim3(256), 0, st, rows, Wc, i0, kk, pinfo, ppiv, pcount);
+            else hipLaunchKernelGGL((k_panel_reg<8, 16>), dim3(1), dim3(256), 0, st, rows, Wc, i0, kk, pinfo, ppiv, pcount);
+        } else if (variant == 1)
+            hipLaunchKernelGGL(k_panel<true>, dim3(1), dim3(PANEL_THREADS), (size_t)kk * Wc * 8, st, rows, Wc, i0, kk, pinfo, ppiv, pcount);
         else
-            hipLaunchKernelGGL(k_panel<false>, dim3(1), dim3(PANEL_THREADS), 0, st, rows, Wc, i0, kk, info.as<PanelInfo>(), piv.as<i64>(),
-                               count.as<unsigned long long>());
+            hipLaunchKernelGGL(k_panel<false>, dim3(1), dim3(PANEL_THREADS), 0, st, rows, Wc, i0, kk, pinfo, ppiv, pcount);
         KERNEL_CHECK();
         if (R > kk) {
             hipLaunchKernelGGL(k_select, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, rows, R, Wc, i0, kk, info.as<PanelInfo>(),

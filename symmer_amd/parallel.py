@@ -6,9 +6,11 @@ operand, and ONE all-gather assembles the full right operand on every rank (RCCL
 collective anywhere on the path.  The reference has nothing comparable (its only parallelism is a CPU fork pool,
 ``symmer/process_handler.py``, off this path).
 
-Control plane (unique-id exchange, barriers, max-over-ranks timing) uses ``torch.distributed`` with the gloo backend
-— plumbing only; the data plane never touches torch.  With ``backend='gloo-host'`` the all-gather itself runs over
-gloo on host arrays, which is what the CPU tests (world_size 2) exercise.
+Control plane (unique-id exchange, barriers, max-over-ranks timing): either a few lines of plain TCP
+(``control='tcp'``, default of ``bench.py``: no PyTorch in the GPU processes at all — PyTorch wheels bundle their own HIP
+runtime and RCCL, which must not be mixed with the system ones this library links to) or ``torch.distributed`` with
+the gloo backend (``control='gloo'``).  With ``data_plane='gloo-host'`` the all-gather itself runs over gloo on host
+arrays, which is what the CPU tests (world_size 2) exercise.
 """
 import os
 import ctypes
@@ -22,47 +24,139 @@ def shard_bounds(n_rows, world):
     return ts, [(min(n_rows, r * ts), min(n_rows, (r + 1) * ts)) for r in range(world)]
 
 
+class _TcpControl:
+    """Minimal rank-0-rooted control plane over TCP: broadcast of bytes, max-reduce of a float, barrier."""
+
+    def __init__(self, rank, world, addr, port, timeout=300.0):
+        import socket, struct, time
+        self.rank, self.world, self._struct = rank, world, struct
+        self.peers = []
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr if addr not in ('localhost',) else '127.0.0.1', port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            conns = {}
+            while len(conns) < world - 1:
+                c, _ = srv.accept()
+                c.settimeout(timeout)
+                r = struct.unpack('<i', self._recv(c, 4))[0]
+                conns[r] = c
+            self.peers = [conns[r] for r in sorted(conns)]
+            srv.close()
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    c = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.2)
+            c.settimeout(timeout)
+            c.sendall(struct.pack('<i', rank))
+            self.peers = [c]
+
+    @staticmethod
+    def _recv(c, n):
+        buf = b''
+        while len(buf) < n:
+            chunk = c.recv(n - len(buf))
+            if not chunk:
+                raise ConnectionError('control-plane peer closed the connection')
+            buf += chunk
+        return buf
+
+    def bcast(self, payload, nbytes):
+        if self.rank == 0:
+            for c in self.peers:
+                c.sendall(payload)
+            return payload
+        return self._recv(self.peers[0], nbytes)
+
+    def max(self, x):
+        s = self._struct
+        if self.rank == 0:
+            vals = [float(x)] + [s.unpack('<d', self._recv(c, 8))[0] for c in self.peers]
+            m = max(vals)
+            for c in self.peers:
+                c.sendall(s.pack('<d', m))
+            return m
+        self.peers[0].sendall(s.pack('<d', float(x)))
+        return s.unpack('<d', self._recv(self.peers[0], 8))[0]
+
+    def close(self):
+        for c in self.peers:
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.peers = []
+
+
 class Communicator:
     def __init__(self, rank=0, world=1, data_plane='none'):
         self.rank, self.world, self.data_plane = rank, world, data_plane
         self._dist = None
+        self._tcp = None
+        self.gathers = False      # True when the right operand must be assembled with the all-gather
 
     # ---- construction ------------------------------------------------------------------------------------
     @classmethod
-    def from_env(cls, data_plane='rccl'):
+    def from_env(cls, data_plane='rccl', control='tcp'):
         """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as set by ``torch.distributed.run``."""
         world = int(os.environ.get('WORLD_SIZE', '1'))
         rank = int(os.environ.get('RANK', '0'))
-        if world == 1:
+        # SYMGPU_FORCE_COMM=1 exercises the whole multi-rank path (control plane, RCCL init, all-gather) with ONE rank
+        forced = os.environ.get('SYMGPU_FORCE_COMM', '0') == '1'
+        if world == 1 and not forced:
             return cls(0, 1, 'none')
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        addr = os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        mport = int(os.environ.setdefault('MASTER_PORT', '29531'))
         self = cls(rank, world, data_plane)
-        self._dist = dist
+        self.gathers = True
+        if control == 'gloo':
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+            self._dist = dist
+        else:
+            # MASTER_PORT itself belongs to the launcher's store; use a derived port for our own socket
+            port = int(os.environ.get('SYMGPU_CONTROL_PORT', 1024 + (mport + 7919) % 60000))
+            self._tcp = _TcpControl(rank, world, addr, port)
         if data_plane == 'rccl':
             self._init_rccl()
         return self
 
-    def _init_rccl(self):
+    def _bcast_bytes(self, payload, nbytes):
+        if self._tcp is not None:
+            return self._tcp.bcast(payload, nbytes)
         import torch
+        t = torch.tensor(list(payload), dtype=torch.uint8) if self.rank == 0 else torch.zeros(nbytes, dtype=torch.uint8)
+        self._dist.broadcast(t, src=0)
+        return bytes(t.tolist())
+
+    def _init_rccl(self):
         from . import _lib
-        ident = torch.zeros(128, dtype=torch.uint8)
+        raw = (ctypes.c_uint8 * 128)()
         if self.rank == 0:
-            buf = (ctypes.c_uint8 * 128)()
-            _lib.check(_lib.lib().symgpu_comm_unique_id(ctypes.addressof(buf)))
-            ident = torch.tensor(list(buf), dtype=torch.uint8)
-        self._dist.broadcast(ident, src=0)
-        raw = (ctypes.c_uint8 * 128)(*ident.tolist())
+            _lib.check(_lib.lib().symgpu_comm_unique_id(ctypes.addressof(raw)))
+        ident = self._bcast_bytes(bytes(raw), 128)
+        raw = (ctypes.c_uint8 * 128)(*ident)
         _lib.check(_lib.lib().symgpu_comm_init(ctypes.addressof(raw), self.rank, self.world))
 
     # ---- control plane -----------------------------------------------------------------------------------
     def barrier(self):
-        if self._dist is not None:
+        if self._tcp is not None:
+            self._tcp.max(0.0)
+        elif self._dist is not None:
             self._dist.barrier()
 
     def max_over_ranks(self, x):
+        if self._tcp is not None:
+            return self._tcp.max(x)
         if self._dist is None:
             return x
         import torch
@@ -74,8 +168,8 @@ class Communicator:
     def allgather_op(self, shard, full, n_rows_total):
         """Device-resident: gather every rank's shard (capacity Ts) into ``full`` and trim it to ``n_rows_total``."""
         from . import _lib
-        if self.world == 1:
-            raise ValueError('allgather_op on a single rank: use the shard directly')
+        if not self.gathers:
+            raise ValueError('allgather_op without a communicator: use the shard directly')
         _lib.check(_lib.lib().symgpu_comm_allgather_op(shard.handle, full.handle))
         full.set_rows(n_rows_total)
 
@@ -84,6 +178,7 @@ class Communicator:
         local_rows = np.ascontiguousarray(local_rows, dtype='<u8')
         if self.world == 1:
             return local_rows
+        assert self._dist is not None, 'host all-gather needs the gloo control plane'
         import torch
         ts, _ = shard_bounds(n_rows_total, self.world)
         W = local_rows.shape[1]
@@ -94,9 +189,13 @@ class Communicator:
         return np.concatenate([p.numpy() for p in parts], axis=0)[:n_rows_total].view('<u8')
 
     def close(self):
-        if self.data_plane == 'rccl' and self.world > 1:
+        if self.data_plane == 'rccl' and self.gathers:
             from . import _lib
             _lib.load().symgpu_comm_destroy()
+        if self._tcp is not None:
+            self._tcp.max(0.0)
+            self._tcp.close()
+            self._tcp = None
         if self._dist is not None and self._dist.is_initialized():
             self._dist.barrier()
             self._dist.destroy_process_group()

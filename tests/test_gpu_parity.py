@@ -286,3 +286,29 @@ def test_rotation_vs_oracle(n, T):
     R = P.perform_rotations(rots)
     er, ec = onp.perform_rotations(symp, c, [(r.symp_matrix[0], a) for r, a in rots])
     assert_op_equal(R.symp_matrix, R.coeff_vec, er, ec, exact=False, tol=TOL)
+
+
+def test_rccl_allgather_single_rank():
+    """The RCCL data plane with ONE rank (the GPU box has one device): unique id, communicator, all-gather of packed
+    rows + coefficients into a larger operator, barrier, destroy — everything but the peer traffic."""
+    import ctypes
+    from symmer_amd import _lib
+    from symmer_amd.kernels import DeviceOp
+    lib = _lib.lib()
+    ident = (ctypes.c_uint8 * 128)()
+    _lib.check(lib.symgpu_comm_unique_id(ctypes.addressof(ident)))
+    _lib.check(lib.symgpu_comm_init(ctypes.addressof(ident), 0, 1))
+    try:
+        rng = np.random.default_rng(3)
+        rows = packing.pack_rows(rng.random((1000, 260)) < 0.3); coeff = dyadic(rng, 1000)
+        shard = DeviceOp.upload(rows, coeff)
+        shard.set_rows(777)                                    # tail of the shard is padding: must come out zeroed
+        full = DeviceOp.alloc(1000, rows.shape[1] // 2, with_coeff=True)
+        _lib.check(lib.symgpu_comm_allgather_op(shard.handle, full.handle))
+        assert full.n_terms == 1000
+        r, c = full.download()
+        assert np.array_equal(r[:777], rows[:777]) and np.array_equal(c[:777], coeff[:777])
+        assert not r[777:].any() and not c[777:].any()
+        _lib.check(lib.symgpu_comm_barrier())
+    finally:
+        _lib.check(lib.symgpu_comm_destroy())

@@ -19,7 +19,7 @@ def _worker(rank, world, port, q):
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         from symmer_amd import parallel
         from oracle import oracle_c as oc, oracle_np as onp
-        comm = parallel.Communicator.from_env(data_plane='gloo-host')
+        comm = parallel.Communicator.from_env(data_plane='gloo-host', control='gloo')
         rng = np.random.default_rng(77)                       # same global operands on every rank
         n, N, M = 130, 37, 51
         A = onp.pack_rows(rng.random((N, 2 * n)) < 0.3); B = onp.pack_rows(rng.random((M, 2 * n)) < 0.3)
@@ -64,5 +64,36 @@ def test_world_size_2_gloo():
     res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    for rank, ok, err in res:
+        assert ok, f'rank {rank} failed: {err}'
+
+
+def _tcp_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        from symmer_amd import parallel
+        comm = parallel.Communicator.from_env(data_plane='none', control='tcp')     # bench.py's control plane, no torch
+        payload = comm._bcast_bytes(bytes(range(128)), 128)
+        ok = payload == bytes(range(128)) and comm.max_over_ranks(10.0 * (rank + 1)) == 10.0 * world
+        comm.barrier()
+        comm.close()
+        q.put((rank, bool(ok) and 'torch' not in sys.modules, ''))
+    except Exception:                                         # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+@pytest.mark.timeout(120)
+def test_world_size_3_tcp_control_plane():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tcp_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
     for rank, ok, err in res:
         assert ok, f'rank {rank} failed: {err}'
