@@ -3,247 +3,218 @@
 // symmer/operators/independent_op.py:124-126).
 //
 // Reference loop: for i = 0..R-1: if row i != 0: pivot = leftmost set column of row i; XOR row i into every
-// OTHER row that has that column set.  Sequential in i.  Blocked form used here (bit-exact by construction):
-//   panel   — ONE workgroup holds K <= 32 consecutive rows in LDS and runs the reference loop restricted to
-//             those rows (Gauss-Jordan inside the block): 3 barriers per pivot, no HBM/L2 round trip.
-//             Afterwards the block is the identity on its own pivot columns.
-//   select  — for every row r outside the block: f(r) = its bits at the block's pivot columns (taken BEFORE
-//             the block is applied).  Because the reduced block is the identity there, the unique combination
-//             of block rows that clears those bits is exactly f(r) — the same row the sequential loop yields.
-//   sweep   — r ^= XOR_{j in f(r)} block_row_j for all rows, one pass over the matrix per K pivots
-//             (pivot rows broadcast from registers; wave-uniform selector -> scalar branches).
-// Row-XORs are COUNTED as the reference performs them: with mask_j = set of block rows that held pivot j's
-// column at time j, the sequential-time selector of an outside row is t_j = f_j ^ parity(f & mask_j & (2^j-1)),
-// so the count is sum_j |mask_j| + sum_r |t(r)|  (derivation in DESIGN.md).
+// OTHER row that has that column set.  Sequential in i.  Blocked form used here (bit-exact by construction), up to
+// 64 consecutive rows per block:
+//   lead    — first non-zero word of each block row (one wave per row, coalesced, early exit).
+//   panel   — ONE wavefront, lane = block row.  It holds a WINDOW of 4 words (256 columns) of every block row,
+//             starting at the leading word of the block's first non-zero row, runs the reference loop on the window
+//             (pivot row broadcast with v_readlane, pivot-column flags of all 64 rows with ONE __ballot, row updates
+//             lane-predicated: ~50 instructions per pivot) and records, besides the pivots, the transformation
+//             T (new_row_r = XOR_{i in T_r} old_row_i).  The window is exact as long as every processed row has its
+//             leading word inside it and does not cancel to zero inside it; the first row that violates this ENDS the
+//             block (it opens the next one, whose window starts at its own leading word), so any matrix is handled.
+//   select  — for every row r outside the block: f(r) = its bits at the block's pivot columns BEFORE the block is
+//             applied.  The reduced block is the identity on its pivot columns, so the unique combination of reduced
+//             block rows that clears those bits is f(r) itself — exactly the row the sequential loop produces; in terms
+//             of the OLD block rows the selector is g = f*T.  Block rows use g = T_r (minus themselves).
+//   sweep   — row ^= XOR_{i in g(row)} old_block_row_i for ALL rows, one pass over the matrix per block (old block
+//             rows snapshotted first; 64 of them live in VGPRs; wave-uniform selector -> scalar branches).
+// Row-XORs are COUNTED as the reference performs them: with mask_j = set of block rows that held pivot j's column at
+// time j, the sequential-time selector of an outside row is t_j = f_j ^ parity(f & mask_j & (2^j-1)), so the count is
+// sum_j |mask_j| + sum_r |t(r)|  (derivation in DESIGN.md §3.5).
 #include "common.h"
 
 namespace symgpu {
 
-constexpr int GK = 32;           // max pivots per block
-constexpr int PANEL_THREADS = 1024;
+constexpr int WK = 64;        // max rows per block = lanes of the panel wave
+constexpr int WN = 4;         // window width in 64-bit words
+constexpr int NOLEAD = 0x7fffffff;
 
-struct PanelInfo {
-    int pivw[GK];     // pivot word index or -1
-    int pivb[GK];     // pivot bit
-    u32 mask[GK];     // block rows (bit r) that held the pivot column at time j, r != j
+struct BlockInfo {
+    i64 i0;                   // first row of the block
+    int kk;                   // rows in the block (0: nothing left)
+    int pivw[WK];             // absolute pivot word per block row, -1 = no pivot (zero row)
+    int pivb[WK];
+    u64 mask[WK];             // block rows (bit r < kk, r != j) holding pivot j's column at time j
+    u64 T[WK];                // new_row_r = XOR_{i in T[r]} old_row_i
 };
 
-template <bool IN_LDS>
-__global__ __launch_bounds__(PANEL_THREADS) void k_panel(u64 *__restrict__ rows, i64 Wc, i64 i0, int kk, PanelInfo *__restrict__ info,
-                                                          i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count) {
-    extern __shared__ __attribute__((aligned(16))) u64 smem[];
-    __shared__ int s_min[2];
-    __shared__ u32 s_mask[GK];
-    __shared__ int s_pw[GK], s_pb[GK];
-    const int tid = threadIdx.x;
-    u64 *blk = IN_LDS ? smem : rows + i0 * Wc;
-    if (IN_LDS) {
-        for (i64 k = tid; k < (i64)kk * Wc; k += PANEL_THREADS) blk[k] = rows[i0 * Wc + k];
+struct SweepState {
+    i64 next_i0;              // first row not yet processed
+};
+
+// lead[r] = index of the first non-zero word of row next_i0 + r (NOLEAD if the row is zero, -1 if beyond the matrix)
+__global__ __launch_bounds__(256) void k_lead(const u64 *__restrict__ rows, i64 R, i64 Wc, const SweepState *__restrict__ st, int *__restrict__ lead) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const i64 row = st->next_i0 + r;
+    if (r >= WK) return;
+    if (row >= R) { if (lane == 0) lead[r] = -1; return; }
+    const u64 *p = rows + row * Wc;
+    int found = NOLEAD;
+    for (i64 w0 = 0; w0 < Wc; w0 += 64) {
+        const i64 w = w0 + lane;
+        const u64 nz = __ballot(w < Wc && p[w] != 0);
+        if (nz) { found = (int)(w0 + __builtin_ctzll(nz)); break; }
     }
-    if (tid < 2) s_min[tid] = 0x7fffffff;
-    __syncthreads();
-    unsigned long long cnt = 0;
-    for (int j = 0; j < kk; ++j) {
-        u64 *rj = blk + (i64)j * Wc;
-        // leftmost non-zero word of row j
-        for (i64 w = tid; w < Wc; w += PANEL_THREADS) {
-            if (rj[w] != 0) { atomicMin(&s_min[j & 1], (int)w); break; }
-        }
-        __syncthreads();
-        const int w0 = s_min[j & 1];
-        if (tid == 0) s_min[(j + 1) & 1] = 0x7fffffff;   // reset the other slot for the next pivot
-        if (w0 == 0x7fffffff) {                           // zero row: no pivot
-            if (tid == 0) { s_pw[j] = -1; s_pb[j] = 0; s_mask[j] = 0; }
-            __syncthreads();
-            continue;
-        }
-        const int b = __builtin_ctzll(rj[w0]);
-        u32 mask = 0;
-        for (int r = 0; r < kk; ++r)
-            if (r != j && ((blk[(i64)r * Wc + w0] >> b) & 1ULL)) mask |= 1u << r;
-        if (tid == 0) { s_pw[j] = w0; s_pb[j] = b; s_mask[j] = mask; cnt += __popc(mask); }
-        __syncthreads();   // every thread has read the flags before any row changes
-        if (mask) {
-            for (i64 w = w0 + tid; w < Wc; w += PANEL_THREADS) {   // words left of the pivot word are zero in row j
-                const u64 x = rj[w];
-                if (x) {
-                    u32 m = mask;
-                    while (m) {
-                        const int r = __builtin_ctz(m);
-                        m &= m - 1;
-                        blk[(i64)r * Wc + w] ^= x;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (IN_LDS) {
-        for (i64 k = tid; k < (i64)kk * Wc; k += PANEL_THREADS) rows[i0 * Wc + k] = blk[k];
-    }
-    if (tid < GK) {
-        const bool live = tid < kk;
-        info->pivw[tid] = live ? s_pw[tid] : -1;
-        info->pivb[tid] = live ? s_pb[tid] : 0;
-        info->mask[tid] = live ? s_mask[tid] : 0u;
-        if (live && pivots) pivots[i0 + tid] = s_pw[tid] < 0 ? -1 : (i64)s_pw[tid] * 64 + s_pb[tid];
-    }
-    if (tid == 0 && cnt) atomicAdd(xor_count, cnt);
+    if (lane == 0) lead[r] = found;
 }
 
-// ---- register-resident panel ------------------------------------------------------------------------
-// 256 threads (one wave per SIMD); thread t holds words t, t+256, ... (WPT of them) of all KB block rows in VGPRs
-// (KB*WPT*2 registers, up to 256).  Per pivot: the pivot row is picked with a wave-uniform if-chain, its leftmost
-// non-zero word is found with WPT ballots + one 4-entry LDS exchange, the owner lane of that word extracts the pivot
-// bit of every block row into a KB-bit mask (second LDS exchange), and every thread XORs the pivot row into the
-// flagged rows in registers under scalar branches.  Two barriers per pivot, no LDS atomics, no LDS read-modify-write.
-template <int WPT, int KB>
-__global__ __launch_bounds__(256) void k_panel_reg(u64 *__restrict__ rows, i64 Wc, i64 i0, int kk, PanelInfo *__restrict__ info,
-                                                    i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count) {
-    __shared__ int s_cand[2][4];
-    __shared__ u32 s_mask[2];
-    __shared__ u32 s_allmask[GK];
-    __shared__ int s_pw[GK], s_pb[GK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32 Rl[KB][WPT], Rh[KB][WPT];      // 32-bit halves: no register-pair constraints across the loop back-edge
-#pragma unroll
-    for (int r = 0; r < KB; ++r)
-#pragma unroll
-        for (int k = 0; k < WPT; ++k) {
-            const i64 w = tid + 256 * k;
-            const u64 v = (r < kk && w < Wc) ? rows[(i0 + r) * Wc + w] : 0ULL;
-            Rl[r][k] = (u32)v;
-            Rh[r][k] = (u32)(v >> 32);
-        }
-    u32 cnt = 0;
-#pragma unroll 1
-    for (int j = 0; j < kk; ++j) {
-        const int slot = j & 1;
-        u32 pl[WPT], ph[WPT];
-#pragma unroll
-        for (int k = 0; k < WPT; ++k) pl[k] = ph[k] = 0;
-#pragma unroll
-        for (int r = 0; r < KB; ++r)
-            if (r == j) {                       // wave-uniform: scalar branch, one copy executed
-#pragma unroll
-                for (int k = 0; k < WPT; ++k) { pl[k] = Rl[r][k]; ph[k] = Rh[r][k]; }
-            }
-        // leftmost non-zero word of row j: word index = 256*k + tid, increasing in k first
-        int cand = 0x7fffffff;
-#pragma unroll
-        for (int k = WPT - 1; k >= 0; --k) {
-            const u64 b = __ballot((pl[k] | ph[k]) != 0);
-            if (b) cand = 256 * k + 64 * wave + (int)__builtin_ctzll(b);
-        }
-        if (lane == 0) s_cand[slot][wave] = cand;
-        __syncthreads();
-        int w0 = s_cand[slot][0];
-#pragma unroll
-        for (int q = 1; q < 4; ++q) w0 = min(w0, s_cand[slot][q]);
-        if (w0 == 0x7fffffff) {                 // zero row: no pivot (uniform)
-            if (tid == 0) { s_pw[j] = -1; s_pb[j] = 0; s_allmask[j] = 0; }
-            continue;
-        }
-        const int k0 = w0 >> 8, t0 = w0 & 255;
-        if (tid == t0) {                        // owner of the pivot word: pivot bit + flags of all block rows
-            u32 mask = 0;
-            int b = 0;
-#pragma unroll
-            for (int k = 0; k < WPT; ++k)
-                if (k == k0) {
-                    const bool in_lo = pl[k] != 0;
-                    const int bb = in_lo ? __builtin_ctz(pl[k]) : __builtin_ctz(ph[k]);
-                    b = in_lo ? bb : 32 + bb;
-#pragma unroll
-                    for (int r = 0; r < KB; ++r) mask |= (((in_lo ? Rl[r][k] : Rh[r][k]) >> bb) & 1u) << r;
-                }
-            mask &= ~(1u << j);
-            s_mask[slot] = mask;
-            s_pw[j] = w0; s_pb[j] = b; s_allmask[j] = mask;
-            cnt += __popc(mask);
-        }
-        __syncthreads();
-        const u32 mask = __builtin_amdgcn_readfirstlane(s_mask[slot]);
-#pragma unroll
-        for (int r = 0; r < KB; ++r) {
-            // branch-free: sel is a wave-uniform all-ones/zero word (SGPR); R ^= p & sel is one v_bitop3_b32 per half
-            const u32 sel = ((mask >> r) & 1u) ? 0xffffffffu : 0u;
-#pragma unroll
-            for (int k = 0; k < WPT; ++k) {
-                Rl[r][k] = __builtin_amdgcn_bitop3_b32(Rl[r][k], pl[k], sel, 0x78);
-                Rh[r][k] = __builtin_amdgcn_bitop3_b32(Rh[r][k], ph[k], sel, 0x78);
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < KB; ++r)
-#pragma unroll
-        for (int k = 0; k < WPT; ++k) {
-            const i64 w = tid + 256 * k;
-            if (r < kk && w < Wc) rows[(i0 + r) * Wc + w] = ((u64)Rh[r][k] << 32) | Rl[r][k];
-        }
-    if (tid < GK) {
-        const bool live = tid < kk;
-        info->pivw[tid] = live ? s_pw[tid] : -1;
-        info->pivb[tid] = live ? s_pb[tid] : 0;
-        info->mask[tid] = live ? s_allmask[tid] : 0u;
-        if (live && pivots) pivots[i0 + tid] = s_pw[tid] < 0 ? -1 : (i64)s_pw[tid] * 64 + s_pb[tid];
-    }
-    // the owner lane differs per pivot: reduce the per-thread counts
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
-    if (lane == 0 && cnt) atomicAdd(xor_count, (unsigned long long)cnt);
+__global__ void k_sum_u32(const u32 *__restrict__ p, i64 n, unsigned long long *__restrict__ out) {
+    unsigned long long s = 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) s += p[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
 
-// selector of every row outside the block + reference-order XOR count
-__global__ __launch_bounds__(256) void k_select(const u64 *__restrict__ rows, i64 R, i64 Wc, i64 i0, int kk, const PanelInfo *__restrict__ info,
-                                                 u32 *__restrict__ sel, unsigned long long *__restrict__ xor_count) {
-    __shared__ PanelInfo s_info;
-    if (threadIdx.x < GK) {
-        s_info.pivw[threadIdx.x] = info->pivw[threadIdx.x];
-        s_info.pivb[threadIdx.x] = info->pivb[threadIdx.x];
-        s_info.mask[threadIdx.x] = info->mask[threadIdx.x];
-    }
-    __syncthreads();
-    const i64 r = (i64)blockIdx.x * 256 + threadIdx.x;
-    u32 f = 0;
-    int c = 0;
-    if (r < R && (r < i0 || r >= i0 + kk)) {
-        const u64 *row = rows + r * Wc;
-        for (int j = 0; j < kk; ++j) {
-            const int pw = s_info.pivw[j];
-            if (pw >= 0) f |= (u32)((row[pw] >> s_info.pivb[j]) & 1ULL) << j;
+__device__ __forceinline__ u64 readlane64(u64 v, int l) {
+    const u32 lo = __builtin_amdgcn_readlane((u32)v, l), hi = __builtin_amdgcn_readlane((u32)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(64) void k_wpanel(const u64 *__restrict__ rows, i64 R, i64 Wc, SweepState *__restrict__ st, const int *__restrict__ lead,
+                                                BlockInfo *__restrict__ info, i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count) {
+    const int lane = threadIdx.x;
+    const i64 i0 = st->next_i0;
+    if (i0 >= R) { if (lane == 0) { info->i0 = i0; info->kk = 0; } return; }
+    const int a = lead[lane];
+    const bool valid = a >= 0;
+    const int n_valid = __popcll(__ballot(valid));                 // rows i0 .. i0+n_valid-1 exist
+    const u64 zero_m = __ballot(valid && a == NOLEAD);
+    const u64 fin_m = __ballot(valid && a != NOLEAD);
+    int kk = n_valid;
+    int pw = -1, pb = 0;                                            // this lane's (= block row's) pivot
+    u64 my_mask = 0;                                                // mask_j for j = lane
+    u64 tv = 1ULL << lane;                                          // T row of this lane
+    if (fin_m != 0) {
+        const int jf = __builtin_ctzll(fin_m);
+        const int w_lo = __builtin_amdgcn_readlane(a, jf);
+        const u64 in_m = __ballot(valid && a != NOLEAD && a >= w_lo && a < w_lo + WN);
+        u64 C[WN];
+#pragma unroll
+        for (int k = 0; k < WN; ++k) C[k] = (valid && (i64)w_lo + k < Wc) ? rows[(i0 + lane) * Wc + w_lo + k] : 0ULL;
+        for (int j = 0; j < n_valid; ++j) {
+            if ((zero_m >> j) & 1ULL) continue;                     // genuinely zero row: no pivot, never modified
+            if (!((in_m >> j) & 1ULL)) { kk = j; break; }           // leading word outside the window: it opens the next block
+            u64 p[WN];
+#pragma unroll
+            for (int k = 0; k < WN; ++k) p[k] = readlane64(C[k], j);
+            int k0 = -1;
+#pragma unroll
+            for (int k = WN - 1; k >= 0; --k) if (p[k] != 0) k0 = k;
+            if (k0 < 0) { kk = j; break; }                          // cancelled to zero inside the window: re-window
+            u64 pk = p[0], ck = C[0];
+#pragma unroll
+            for (int k = 1; k < WN; ++k) if (k == k0) { pk = p[k]; ck = C[k]; }
+            const int b = __builtin_ctzll(pk);
+            const u64 mk = __ballot((ck >> b) & 1ULL) & ~(1ULL << j);
+            if (lane == j) { pw = w_lo + k0; pb = b; my_mask = mk; }
+            const u64 tj = readlane64(tv, j);
+            if ((mk >> lane) & 1ULL) {
+#pragma unroll
+                for (int k = 0; k < WN; ++k) C[k] ^= p[k];
+                tv ^= tj;
+            }
         }
-        for (int j = 0; j < kk; ++j) {
-            const u32 tj = ((f >> j) & 1u) ^ (__popc(f & s_info.mask[j] & ((1u << j) - 1u)) & 1u);
-            c += (int)tj;
-        }
     }
-    if (r < R) sel[r] = f;
+    // publish: only rows < kk belong to the block
+    const u64 low = (kk >= 64) ? ~0ULL : ((1ULL << kk) - 1ULL);
+    const bool mine = lane < kk;
+    info->pivw[lane] = mine ? pw : -1;
+    info->pivb[lane] = mine ? pb : 0;
+    info->mask[lane] = mine ? (my_mask & low) : 0ULL;
+    info->T[lane] = mine ? tv : 0ULL;
+    if (mine && pivots) pivots[i0 + lane] = pw < 0 ? -1 : (i64)pw * 64 + pb;
+    unsigned long long c = mine ? (unsigned long long)__popcll(my_mask & low) : 0ULL;
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(xor_count, (unsigned long long)c);
+    if (lane == 0) {
+        info->i0 = i0;
+        info->kk = kk;
+        st->next_i0 = i0 + kk;
+        if (c) atomicAdd(xor_count, c);
+    }
 }
 
-constexpr int SW_ROWS = 16;   // rows per sweep block
+// selectors of all rows (in terms of the OLD block rows), reference-order XOR count, snapshot of the old block rows.
+// One wavefront per row, lane j <-> pivot j: the 64 pivot-column bits are fetched in parallel and f is ONE __ballot.
+__global__ __launch_bounds__(256) void k_select(const u64 *__restrict__ rows, i64 R, i64 Wc, const BlockInfo *__restrict__ info,
+                                                 u64 *__restrict__ sel, u64 *__restrict__ snap, u32 *__restrict__ rowcnt) {
+    const int kk = info->kk;
+    if (kk == 0) return;
+    const int lane = threadIdx.x & 63;
+    const i64 i0 = info->i0;
+    const int pw = info->pivw[lane], pb = info->pivb[lane];
+    const u64 mj = info->mask[lane] & ((1ULL << lane) - 1ULL);      // earlier block rows that held pivot `lane`'s column
+    const u64 Tj = info->T[lane];
+    const i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r < R) {
+        u64 g;
+        if (r >= i0 && r < i0 + kk) {
+            // new_r = XOR_{i in T_r} old_i = old_r ^ XOR_{i in T_r xor {r}} old_i
+            g = readlane64(Tj, (int)(r - i0)) ^ (1ULL << (r - i0));
+        } else {
+            const bool bit = (lane < kk && pw >= 0) ? ((rows[r * Wc + pw] >> pb) & 1ULL) : false;
+            const u64 f = __ballot(bit);
+            // sequential-time selector t_j = f_j ^ parity(f & mask_j & (2^j-1)): |t| row-XORs in the reference loop
+            const bool tj = bit ^ (bool)(__popcll(f & mj) & 1);
+            const u64 t = __ballot(tj);
+            if (lane == 0) rowcnt[r] += (u32)__popcll(t);             // one wave per row: no atomics, summed at the end
+            u64 x = bit ? Tj : 0ULL;                                  // g = XOR_{j in f} T_j
+            for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off);
+            g = x;
+        }
+        if (lane == 0) sel[r] = g;
+    }
+    // snapshot of the old block rows (the sweep overwrites them while other workgroups still read them)
+    const i64 total = (i64)kk * Wc;
+    for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < total; k += (i64)gridDim.x * 256) snap[k] = rows[i0 * Wc + k];
+}
 
-__global__ __launch_bounds__(256) void k_sweep(u64 *__restrict__ rows, i64 R, i64 Wc, i64 i0, int kk, const u32 *__restrict__ sel) {
+constexpr int SW_ROWS = 16;   // rows per sweep workgroup, held in VGPRs
+
+// Each lane owns one word column of SW_ROWS rows (kept in registers); the old block rows stream past once
+// (independent loads, no dependent load->xor->store chain per row) and are XORed in under wave-uniform selector bits.
+__global__ __launch_bounds__(256) void k_sweep(u64 *__restrict__ rows, i64 R, i64 Wc, const BlockInfo *__restrict__ info,
+                                                const u64 *__restrict__ sel, const u64 *__restrict__ snap) {
+    const int kk = info->kk;
+    if (kk == 0) return;
     const i64 w = (i64)blockIdx.x * 256 + threadIdx.x;
     const bool live = w < Wc;
-    u64 bw[GK];
-#pragma unroll
-    for (int j = 0; j < GK; ++j) bw[j] = (live && j < kk) ? rows[(i0 + j) * Wc + w] : 0ULL;
     const i64 rb = (i64)blockIdx.y * SW_ROWS;
+    u32 slo[SW_ROWS], shi[SW_ROWS];
+    u64 x[SW_ROWS];
+    u32 any = 0;
+#pragma unroll
     for (int k = 0; k < SW_ROWS; ++k) {
         const i64 r = rb + k;
-        if (r >= R) break;
-        const u32 s = __builtin_amdgcn_readfirstlane(sel[r]);   // uniform
-        if (s == 0) continue;
-        if (live) {
-            u64 x = rows[r * Wc + w];
+        const u64 sv = (r < R) ? sel[r] : 0ULL;
+        slo[k] = __builtin_amdgcn_readfirstlane((u32)sv);
+        shi[k] = __builtin_amdgcn_readfirstlane((u32)(sv >> 32));
+        any |= slo[k] | shi[k];
+        x[k] = (live && r < R) ? rows[r * Wc + w] : 0ULL;
+    }
+    if (any == 0) return;                                            // uniform
+    const u64 *sp = snap + w;
+#pragma unroll 4
+    for (int j = 0; j < kk; ++j) {
+        const u64 b = live ? sp[(i64)j * Wc] : 0ULL;
+        const u32 blo = (u32)b, bhi = (u32)(b >> 32);
 #pragma unroll
-            for (int j = 0; j < GK; ++j)
-                if ((s >> j) & 1u) x ^= bw[j];
-            rows[r * Wc + w] = x;
+        for (int k = 0; k < SW_ROWS; ++k) {
+            // all-ones / zero from selector bit j in ONE VALU op (v_bfe_i32): the CU's single scalar unit would otherwise
+            // be the bottleneck (3 SALU per (j, row))
+            const u32 sbits = (j < 32) ? slo[k] : shi[k];
+            const u32 m = (u32)__builtin_amdgcn_sbfe((int)sbits, j & 31, 1);
+            const u32 lo = __builtin_amdgcn_bitop3_b32((u32)x[k], blo, m, 0x78);
+            const u32 hi = __builtin_amdgcn_bitop3_b32((u32)(x[k] >> 32), bhi, m, 0x78);
+            x[k] = ((u64)hi << 32) | lo;
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < SW_ROWS; ++k) {
+            const i64 r = rb + k;
+            if (r < R && (slo[k] | shi[k])) rows[r * Wc + w] = x[k];
         }
     }
 }
@@ -253,53 +224,44 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     hipStream_t st = ctx().stream;
     if (xor_count) *xor_count = 0;
     if (R <= 0 || Wc <= 0) return SYMGPU_OK;
-    if (Wc >= ((i64)1 << 31)) { set_error("rref: Wc too large"); return SYMGPU_E_INVALID; }
-    Scratch info, sel, count, piv;
-    SG_TRY(info.alloc(sizeof(PanelInfo)));
-    SG_TRY(sel.alloc((size_t)R * 4));
+    if (Wc >= ((i64)1 << 31) - 64) { set_error("rref: Wc too large"); return SYMGPU_E_INVALID; }
+    Scratch info, state, lead, sel, snap, count, piv, rowcnt;
+    SG_TRY(info.alloc(sizeof(BlockInfo)));
+    SG_TRY(state.alloc(sizeof(SweepState)));
+    SG_TRY(lead.alloc(WK * sizeof(int)));
+    SG_TRY(sel.alloc((size_t)R * 8));
+    SG_TRY(snap.alloc((size_t)WK * Wc * 8));
     SG_TRY(count.alloc(16));
     SG_TRY(piv.alloc((size_t)R * 8));
+    SG_TRY(rowcnt.alloc((size_t)R * 4));
+    HIP_TRY(hipMemsetAsync(rowcnt.p, 0, (size_t)R * 4, st));
     HIP_TRY(hipMemsetAsync(count.p, 0, 16, st));
-    // Panel variant: rows up to 2048 words stay in VGPRs (k_panel_reg); wider rows use the LDS panel (as many rows as fit
-    // in LDS, <= 32), and rows wider than the LDS budget run the same code on global memory.
-    const size_t lds_budget = 144 * 1024;
-    int K = GK, variant = 0;        // 0: registers, 1: LDS, 2: global
-    if (Wc <= 1024) K = 32;
-    else if (Wc <= 2048) K = 16;
-    else {
-        K = (int)(lds_budget / ((size_t)Wc * 8));
-        variant = 1;
-        if (K < 1) { K = 8; variant = 2; }
-        if (K > GK) K = GK;
-    }
-    if (variant == 1) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
-    }
+    HIP_TRY(hipMemsetAsync(state.p, 0, sizeof(SweepState), st));
     const unsigned gx = (unsigned)((Wc + 255) / 256), gy = (unsigned)((R + SW_ROWS - 1) / SW_ROWS);
-    PanelInfo *pinfo = info.as<PanelInfo>();
-    i64 *ppiv = piv.as<i64>();
-    unsigned long long *pcount = count.as<unsigned long long>();
-    for (i64 i0 = 0; i0 < R; i0 += K) {
-        const int kk = (int)((R - i0 < K) ? (R - i0) : K);
-        if (variant == 0) {
-            if (Wc <= 256) hipLaunchKernelGGL((k_panel_reg<1, 32>), dim3(1), dim3(256), 0, st, rows, Wc, i0, kk, pinfo, ppiv, pcount);
-            else if (Wc <= 512) hipLaunchKernelGGL((k_panel_reg<2, 32>), dim3(1), dim3(256), 0, st, rows, Wc, i0, kk, pinfo, ppiv, pcount);
-            else if (Wc <= 1024) hipLaunchKernelGGL((k_panel_reg<4, 32>), dim3(1), dim3(256), 0, st, rows, Wc, i0, kk, pinfo, ppiv, pcount);
-            else hipLaunchKernelGGL((k_panel_reg<8, 16>), dim3(1), dim3(256), 0, st, rows, Wc, i0, kk, pinfo, ppiv, pcount);
-        } else if (variant == 1)
-            hipLaunchKernelGGL(k_panel<true>, dim3(1), dim3(PANEL_THREADS), (size_t)kk * Wc * 8, st, rows, Wc, i0, kk, pinfo, ppiv, pcount);
-        else
-            hipLaunchKernelGGL(k_panel<false>, dim3(1), dim3(PANEL_THREADS), 0, st, rows, Wc, i0, kk, pinfo, ppiv, pcount);
-        KERNEL_CHECK();
-        if (R > kk) {
-            hipLaunchKernelGGL(k_select, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, rows, R, Wc, i0, kk, info.as<PanelInfo>(),
-                               sel.as<u32>(), count.as<unsigned long long>());
-            KERNEL_CHECK();
+    const unsigned gsel = (unsigned)((R + 3) / 4);
+    i64 done = 0;
+    while (done < R) {
+        // optimistic batch: every block consumes up to 64 rows; blocks that end early are caught by the read-back
+        i64 n_iter = (R - done + WK - 1) / WK;
+        if (n_iter > 4096) n_iter = 4096;
+        for (i64 it = 0; it < n_iter; ++it) {
+            hipLaunchKernelGGL(k_lead, dim3(WK / 4), dim3(256), 0, st, rows, R, Wc, state.as<SweepState>(), lead.as<int>());
+            hipLaunchKernelGGL(k_wpanel, dim3(1), dim3(64), 0, st, rows, R, Wc, state.as<SweepState>(), lead.as<int>(), info.as<BlockInfo>(),
+                               piv.as<i64>(), count.as<unsigned long long>());
+            hipLaunchKernelGGL(k_select, dim3(gsel), dim3(256), 0, st, rows, R, Wc, info.as<BlockInfo>(), sel.as<u64>(), snap.as<u64>(),
+                               rowcnt.as<u32>());
             ProfScope prof(2);
-            hipLaunchKernelGGL(k_sweep, dim3(gx, gy), dim3(256), 0, st, rows, R, Wc, i0, kk, sel.as<u32>());
+            hipLaunchKernelGGL(k_sweep, dim3(gx, gy), dim3(256), 0, st, rows, R, Wc, info.as<BlockInfo>(), sel.as<u64>(), snap.as<u64>());
             KERNEL_CHECK();
         }
+        SweepState hs;
+        HIP_TRY(hipMemcpyAsync(&hs, state.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (hs.next_i0 <= done) { set_error("rref: no progress (internal error)"); return SYMGPU_E_INVALID; }
+        done = hs.next_i0;
     }
+    hipLaunchKernelGGL(k_sum_u32, dim3(256), dim3(256), 0, st, rowcnt.as<u32>(), R, count.as<unsigned long long>());
+    KERNEL_CHECK();
     unsigned long long h = 0;
     HIP_TRY(hipMemcpyAsync(&h, count.p, 8, hipMemcpyDeviceToHost, st));
     if (pivots_host) HIP_TRY(hipMemcpyAsync(pivots_host, piv.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
