@@ -22,6 +22,8 @@ constexpr int WAVES = 4; // waves per block, stacked along i
 
 // gfx950 v_bitop3_b32 with truth table 0x78: acc ^ (b & c) in ONE VALU instruction
 __device__ __forceinline__ u32 xor_and(u32 acc, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(acc, b, c, 0x78); }
+// force a wave-uniform value into a VGPR (the compiler would otherwise fold the SGPR into every consumer)
+__device__ __forceinline__ u32 to_vgpr(u32 s) { u32 v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
 
 template <bool BITS>
 __global__ __launch_bounds__(256) void k_commutes(const u64 *__restrict__ At, i64 Npad, i64 N,
@@ -58,13 +60,21 @@ __global__ __launch_bounds__(256) void k_commutes(const u64 *__restrict__ At, i6
             za[a] = paz[(i64)w * Npad + a];
         }
 #pragma unroll
-        for (int a = 0; a < CI; ++a)
+        for (int a = 0; a < CI; ++a) {
+            // Measured on gfx950 (tools/ubench_bitop.hip): a VALU instruction with an SGPR source issues at ~60 % of the
+            // all-VGPR rate, so the wave-uniform A words are copied into VGPRs once (4 v_mov) and reused by 4*CJ bitop3.
+            // Tried and rejected (slower on MI355X): per-lane broadcast vector loads (34.8 ms), A tile in LDS (19.7 ms),
+            // A+B tiles in LDS with barriers (25.3 ms), CI=4/CJ=8 with explicit prefetch (35.4 ms) vs 19.0 ms for this form
+            // on the 25,000 x 200,000 block at n=2000.
+            const u32 xal = to_vgpr((u32)xa[a]), xah = to_vgpr((u32)(xa[a] >> 32));
+            const u32 zal = to_vgpr((u32)za[a]), zah = to_vgpr((u32)(za[a] >> 32));
 #pragma unroll
             for (int b = 0; b < CJ; ++b) {
                 // acc ^= (xa & zb) ^ (za & xb): two v_bitop3_b32 (truth table 0x78 = a ^ (b & c)) per 32-bit half
-                acc_lo[a][b] = xor_and(xor_and(acc_lo[a][b], (u32)xa[a], (u32)zb[b]), (u32)za[a], (u32)xb[b]);
-                acc_hi[a][b] = xor_and(xor_and(acc_hi[a][b], (u32)(xa[a] >> 32), (u32)(zb[b] >> 32)), (u32)(za[a] >> 32), (u32)(xb[b] >> 32));
+                acc_lo[a][b] = xor_and(xor_and(acc_lo[a][b], xal, (u32)zb[b]), zal, (u32)xb[b]);
+                acc_hi[a][b] = xor_and(xor_and(acc_hi[a][b], xah, (u32)(zb[b] >> 32)), zah, (u32)(xb[b] >> 32));
             }
+        }
     }
 
 #pragma unroll

@@ -19,6 +19,7 @@ namespace symgpu {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ u32 xor_and(u32 acc, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(acc, b, c, 0x78); }   // a ^ (b & c)
+__device__ __forceinline__ u32 to_vgpr(u32 s) { u32 v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
 __device__ __forceinline__ u32 and_xor(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x60); }     // a & (b ^ c)
 
 constexpr int PO = 8;   // outer terms per wave (SGPR operand)
@@ -75,11 +76,13 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
             yo[a] += __popcll(xo[a] & zo[a]);
         }
 #pragma unroll
-        for (int a = 0; a < PO; ++a)
+        for (int a = 0; a < PO; ++a) {
+            // SGPR sources cost ~40 % VALU issue rate on gfx950 (tools/ubench_bitop.hip): copy the uniform words to VGPRs once
+            const u32 xol = to_vgpr((u32)xo[a]), xoh = to_vgpr((u32)(xo[a] >> 32));
+            const u32 zol = to_vgpr((u32)zo[a]), zoh = to_vgpr((u32)(zo[a] >> 32));
 #pragma unroll
             for (int b = 0; b < PJ; ++b) {
                 const u32 xil = (u32)xi[b], xih = (u32)(xi[b] >> 32), zil = (u32)zi[b], zih = (u32)(zi[b] >> 32);
-                const u32 xol = (u32)xo[a], xoh = (u32)(xo[a] >> 32), zol = (u32)zo[a], zoh = (u32)(zo[a] >> 32);
                 // Y_out += |(xi^xo) & (zi^zo)|
                 cnt[a][b] += __popc(and_xor(xil ^ xol, zil, zol));
                 cnt[a][b] += __popc(and_xor(xih ^ xoh, zih, zoh));
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
                     fhi[a][b] = xor_and(fhi[a][b], zih, xoh);
                 }
             }
+        }
     }
 
 #pragma unroll
