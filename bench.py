@@ -11,9 +11,10 @@ GPU).  One "step" = (N>1: RCCL all-gather of the packed right operand over xGMI,
 full product of this rank's left block against the whole right operand.  Inputs are resident in HBM before the
 timed region.  Weak scaling: per-GPU work is fixed, value = all ranks' pairs / max-over-ranks time.
 
-roofline     — dominant kernel k_mul_rows (HBM-write stream): algorithmic bytes 16*Wq per pair (256 B at n=1000)
-               x pairs per launch / average launch duration from HIP events recorded around every launch in the
-               timed region (library stream).  peak = 8 TB/s (MI355X_MICROARCH.md).
+roofline     — dominant kernel k_mul_rows (HBM-write stream): algorithmic bytes 16*Wq per pair (256 B at n=1000) x pairs
+               per launch / average launch duration from HIP events recorded around every launch in the timed region
+               (library stream).  The VALU-bound coefficient kernel (16 B/pair) overlaps it on a side stream, so the
+               whole step moves 16*Wq+16 B/pair (`whole_step_GBps`).  peak = 8 TB/s (MI355X_MICROARCH.md).
 cpu_baseline — the NumPy restatement of the reference algorithm (oracle/oracle_np.py: broadcast XOR on
                1-byte-per-bit matrices, per-bit popcount sums, complex outer product; base.py:783-792) timed on a
                bounded sample of the same workload on the host cores.
@@ -108,7 +109,9 @@ def main():
     value = world * pairs_per_step_rank * args.steps / dt
     launch_pairs = pairs_per_step_rank * args.steps / max(1, n_launch.value)
     launch_ms = tot_ms.value / max(1, n_launch.value)
-    algo_bytes_launch = launch_pairs * 16 * wq
+    fused = os.environ.get('SYMGPU_PRODUCT_MODE', '').startswith('f')
+    per_pair = (16 * wq + 16) if fused else 16 * wq      # fused launch writes rows + coefficients; two-kernel mode: rows only
+    algo_bytes_launch = launch_pairs * per_pair
     achieved = algo_bytes_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
 
     out = {
@@ -118,7 +121,8 @@ def main():
         'config': {'workload': 'allpairs_product', 'n_qubits': n, 'left_terms_per_gpu': Ni, 'right_terms': M,
                    'pairs_per_step': world * pairs_per_step_rank, 'bytes_per_pair': 16 * wq + 16, 'slab_rows': slab,
                    'parallelism': f'left-axis shard x{world}, RCCL all-gather of right rows' if world > 1 else 'single GPU'},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_mul_rows', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'roofline': {'bound': 'hbm', 'kernel': 'k_mul_coeff<*,FUSED> (coefficients + row stream)' if fused else 'k_mul_rows', 'bytes_per_pair': per_pair,
+                     'note': None if fused else 'k_mul_coeff (16 B/pair) runs concurrently on a side stream; incl. its bytes: %.0f GB/s' % (achieved * (16 * wq + 16) / (16 * wq)), 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'launches': n_launch.value, 'avg_launch_ms': launch_ms,
                      'algorithmic_bytes_per_launch': algo_bytes_launch,
                      'whole_step_GBps': pairs_per_step_rank * (16 * wq + 16) / (dt / args.steps) / 1e9},

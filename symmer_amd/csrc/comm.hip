@@ -125,6 +125,7 @@ int symgpu_comm_allgather_op(symgpu_op_t shard, symgpu_op_t full) {
         r = g_rccl.AllGather(shard->coeff, full->coeff, (size_t)Ts * 2, ncclFloat64, g_rccl.comm, st);
         if (r != ncclSuccess) return rccl_fail(r, "ncclAllGather(coeff)");
     }
+    op_invalidate(full);
     full->T = Ts * g_rccl.nranks;
     return SYMGPU_OK;
 }

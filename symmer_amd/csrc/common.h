@@ -43,6 +43,8 @@ struct Context {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;           // side stream: VALU-bound coefficient kernel overlaps the HBM-bound row stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cu = 256;
     // linear-hash tables (cleanup): 8 byte positions x 256 values x {h1,h2}; reseeded on collision
@@ -84,12 +86,18 @@ struct symgpu_op_s {
     double *coeff = nullptr; // [capacity][2] or null
     i64 T = 0, capacity = 0;
     int Wq = 0;
+    // cached word-major copy of rows[0..T) (layout.hip), padded to wm_pad terms; dropped whenever rows/T change
+    u64 *wm = nullptr;
+    i64 wm_pad = 0, wm_T = -1;
 };
 
 namespace symgpu {
 
 // layout.hip — word-major ("bit-sliced column") copy: out[w][t], t padded to Tpad (zero filled)
-int to_wordmajor(const u64 *rows, i64 T, int W, u64 *out, i64 Tpad);
+int to_wordmajor(const u64 *rows, i64 T, int W, u64 *out, i64 Tpad, hipStream_t st = nullptr);
+// cached word-major copy of a whole operator (padded to a multiple of `mult` terms); built on the main stream
+int op_wordmajor(symgpu_op_s *op, i64 mult, const u64 **out, i64 *pad);
+void op_invalidate(symgpu_op_s *op);
 // bit-matrix transpose: in R rows x Wc words -> out (64*Wc rows) x ceil(R/64) words, only first C rows written
 int bit_transpose(const u64 *in, i64 R, i64 Wc_in, u64 *out, i64 Wc_out);
 

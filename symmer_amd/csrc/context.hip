@@ -255,6 +255,9 @@ int symgpu_init(int device) {
     }
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&c.ev0));
     HIP_TRY(hipEventCreate(&c.ev1));
     hipDeviceProp_t prop;
@@ -273,6 +276,10 @@ int symgpu_shutdown(void) {
     if (c.hash_tab) { (void)hipFree(c.hash_tab); c.hash_tab = nullptr; }
     (void)hipEventDestroy(c.ev0);
     (void)hipEventDestroy(c.ev1);
+    (void)hipStreamSynchronize(c.stream2);
+    (void)hipEventDestroy(c.ev_fork);
+    (void)hipEventDestroy(c.ev_join);
+    (void)hipStreamDestroy(c.stream2);
     (void)hipStreamDestroy(c.stream);
     c.ready = false;
     c.device = -1;
@@ -412,6 +419,7 @@ int symgpu_op_alloc(int64_t capacity_rows, int Wq, int with_coeff, symgpu_op_t *
 
 int symgpu_op_free(symgpu_op_t op) {
     if (!op) return SYMGPU_OK;
+    op_invalidate(op);
     if (op->rows) dev_free(op->rows);
     if (op->coeff) dev_free(op->coeff);
     delete op;
@@ -420,6 +428,7 @@ int symgpu_op_free(symgpu_op_t op) {
 
 int symgpu_op_set_rows(symgpu_op_t op, int64_t T) {
     SG_REQUIRE(op && T >= 0 && T <= op->capacity, "op_set_rows");
+    if (T != op->T) op_invalidate(op);
     op->T = T;
     return SYMGPU_OK;
 }

@@ -30,11 +30,34 @@ __global__ __launch_bounds__(256) void k_to_wordmajor(const u64 *__restrict__ ro
     }
 }
 
-int to_wordmajor(const u64 *rows, i64 T, int W, u64 *out, i64 Tpad) {
+int to_wordmajor(const u64 *rows, i64 T, int W, u64 *out, i64 Tpad, hipStream_t st) {
     if (Tpad <= 0) return SYMGPU_OK;
     dim3 grid((unsigned)((Tpad + TT - 1) / TT), (unsigned)((W + TW - 1) / TW));
-    hipLaunchKernelGGL(k_to_wordmajor, grid, dim3(256), 0, ctx().stream, rows, T, W, out, Tpad);
+    hipLaunchKernelGGL(k_to_wordmajor, grid, dim3(256), 0, st ? st : ctx().stream, rows, T, W, out, Tpad);
     KERNEL_CHECK();
+    return SYMGPU_OK;
+}
+
+void op_invalidate(symgpu_op_s *op) {
+    if (op && op->wm) { dev_free(op->wm); op->wm = nullptr; }
+    if (op) { op->wm_pad = 0; op->wm_T = -1; }
+}
+
+int op_wordmajor(symgpu_op_s *op, i64 mult, const u64 **out, i64 *pad) {
+    const i64 need = (op->T + mult - 1) / mult * mult;
+    if (!op->wm || op->wm_T != op->T || op->wm_pad % mult != 0 || op->wm_pad < need) {
+        op_invalidate(op);
+        // pad to a multiple of 256 as well so that every all-pairs kernel can share the copy
+        i64 m = mult;
+        while (m % 256) m *= 2;
+        const i64 p = (op->T + m - 1) / m * m;
+        SG_TRY(dev_alloc((size_t)(p > 0 ? p : m) * 2 * op->Wq * sizeof(u64), (void **)&op->wm));
+        SG_TRY(to_wordmajor(op->rows, op->T, 2 * op->Wq, op->wm, p));
+        op->wm_pad = p;
+        op->wm_T = op->T;
+    }
+    *out = op->wm;
+    *pad = op->wm_pad;
     return SYMGPU_OK;
 }
 

@@ -13,6 +13,8 @@
 //    stores, 1 KiB per wave instruction, perfectly coalesced.  Inputs stay in L2; algorithmic bytes == HBM
 //    bytes.  This is the kernel the north-star roofline is quoted on.
 #include "common.h"
+#include <stdlib.h>
+#include <stdio.h>
 
 namespace symgpu {
 
@@ -36,10 +38,15 @@ __device__ __forceinline__ void apply_phase(double re, double im, int e, double 
     oim = neg_b ? -b : b;
 }
 
-template <bool INNER_LEFT>
+// FUSED: after the coefficients of its (256 inner x 32 outer) tile the block also streams the tile's product ROWS
+// (k_mul_rows' store pattern: 16 B per lane, 4 KiB contiguous per outer row, non-temporal), so ONE launch writes the
+// full 16*Wq + 16 bytes per pair; while some waves of a CU sit in the VALU phase others keep the HBM write stream busy.
+template <bool INNER_LEFT, bool FUSED>
 __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i64 Ipad, i64 Ni, const double *__restrict__ ci,
                                                     const u64 *__restrict__ Ot, i64 Opad, i64 No, const double *__restrict__ co,
-                                                    int Wq, double *__restrict__ out /* [(o)*Ni + i][2], o relative to slab */) {
+                                                    int Wq, double *__restrict__ out /* [(o)*Ni + i][2], o relative to slab */,
+                                                    const u32x4 *__restrict__ inner_rm, const u32x4 *__restrict__ outer_rm,
+                                                    u32x4 *__restrict__ out_rows) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const i64 o0 = ((i64)blockIdx.y * PW + wave) * PO;   // wave-uniform, relative to the slab
@@ -119,70 +126,116 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
             reinterpret_cast<double2 *>(out)[o * Ni + i] = v;
         }
     }
-}
-
-// ---- the HBM-write stream ------------------------------------------------------------------------
-constexpr int RC = 4;    // 16-byte chunks per lane
-constexpr int RTO = 32;  // outer rows per block
-
-__global__ __launch_bounds__(256) void k_mul_rows(const u32x4 *__restrict__ inner, i64 n_chunks, const u32x4 *__restrict__ outer,
-                                                   int Wq, i64 o_count, u32x4 *__restrict__ out) {
-    const i64 c0 = (i64)blockIdx.x * (256 * RC) + threadIdx.x;
-    u32x4 v[RC];
-    int wq[RC];
-    bool ok[RC];
-#pragma unroll
-    for (int k = 0; k < RC; ++k) {
-        const i64 c = c0 + 256 * k;
-        ok[k] = c < n_chunks;
-        v[k] = ok[k] ? inner[c] : (u32x4)(0u);
-        wq[k] = ok[k] ? (int)(c % Wq) : 0;
-    }
-    const i64 ob = (i64)blockIdx.y * RTO;
-    const i64 oe = ob + RTO < o_count ? ob + RTO : o_count;
-    for (i64 o = ob; o < oe; ++o) {
-        const u32x4 *orow = outer + o * Wq;
-        u32x4 *dst = out + o * n_chunks + c0;
-#pragma unroll
-        for (int k = 0; k < RC; ++k) {
-            if (ok[k]) {
-                u32x4 r = v[k] ^ orow[wq[k]];
-                __builtin_nontemporal_store(r, dst + 256 * k);
+    if (FUSED) {
+        const i64 n_chunks = Ni * Wq;
+        const i64 rows_here = (Ni - ibase < 64 * PJ) ? (Ni - ibase) : (i64)(64 * PJ);
+        const i64 ctile = rows_here > 0 ? rows_here * Wq : 0;
+        const i64 cbase = ibase * Wq;
+        const i64 ob = (i64)blockIdx.y * (PO * PW);
+        const i64 oe = (ob + PO * PW < No) ? ob + PO * PW : No;
+        for (i64 cc = threadIdx.x; cc < ctile; cc += 256) {
+            const u32x4 v = inner_rm[cbase + cc];
+            const int wqi = (int)(cc % Wq);
+            u32x4 *dst = out_rows + cbase + cc;
+            for (i64 o = ob; o < oe; ++o) {
+                const u32x4 r = v ^ outer_rm[o * Wq + wqi];
+                __builtin_nontemporal_store(r, dst + o * n_chunks);
             }
         }
     }
 }
 
+// ---- the HBM-write stream ------------------------------------------------------------------------
+// RCT = 16-byte chunks per lane, NT = non-temporal stores, rto = outer rows per block (runtime).
+template <int RCT, bool NT>
+__global__ __launch_bounds__(256) void k_mul_rows(const u32x4 *__restrict__ inner, i64 n_chunks, const u32x4 *__restrict__ outer,
+                                                   int Wq, i64 o_count, u32x4 *__restrict__ out, int rto) {
+    const i64 c0 = (i64)blockIdx.x * (256 * RCT) + threadIdx.x;
+    u32x4 v[RCT];
+    int wq[RCT];
+    bool ok[RCT];
+#pragma unroll
+    for (int k = 0; k < RCT; ++k) {
+        const i64 c = c0 + 256 * k;
+        ok[k] = c < n_chunks;
+        v[k] = ok[k] ? inner[c] : (u32x4)(0u);
+        wq[k] = ok[k] ? (int)(c % Wq) : 0;
+    }
+    const i64 ob = (i64)blockIdx.y * rto;
+    const i64 oe = ob + rto < o_count ? ob + rto : o_count;
+    for (i64 o = ob; o < oe; ++o) {
+        const u32x4 *orow = outer + o * Wq;
+        u32x4 *dst = out + o * n_chunks + c0;
+#pragma unroll
+        for (int k = 0; k < RCT; ++k) {
+            if (ok[k]) {
+                u32x4 r = v[k] ^ orow[wq[k]];
+                if (NT) __builtin_nontemporal_store(r, dst + 256 * k);
+                else dst[256 * k] = r;
+            }
+        }
+    }
+}
+
+// tuning knobs (defaults are the measured best on MI355X; SYMGPU_ROWS_VARIANT="rc,rto,nt" overrides for experiments)
+struct RowsVariant { int rc = 1, rto = 32, nt = 1; bool parsed = false; };
+static RowsVariant g_rv;
+static const RowsVariant &rows_variant() {
+    if (!g_rv.parsed) {
+        g_rv.parsed = true;
+        const char *e = getenv("SYMGPU_ROWS_VARIANT");
+        if (e) {
+            int a = 0, b2 = 0, c = 0;
+            if (sscanf(e, "%d,%d,%d", &a, &b2, &c) == 3 && (a == 1 || a == 2 || a == 4 || a == 8) && b2 >= 1) { g_rv.rc = a; g_rv.rto = b2; g_rv.nt = c != 0; }
+        }
+    }
+    return g_rv;
+}
+
 static i64 round_up(i64 x, i64 m) { return (x + m - 1) / m * m; }
 
-// coefficients of the slab of outer rows [o_begin, o_end): out_coeff[(o-o_begin)*Ni + i]
-int mul_coeff_dev(const u64 *inner, const double *ci, i64 Ni, const u64 *outer, const double *co, i64 o_begin, i64 o_end,
-                  int Wq, int inner_is_left, double *out_coeff) {
+// coefficients of the slab of outer rows [o_begin, o_end): out_coeff[(o-o_begin)*Ni + i].
+// It = word-major inner operand (padded to Ipad, a multiple of 64*PJ); kernels go to stream `st`.
+static int mul_coeff_launch(const u64 *It, i64 Ipad, const double *ci, i64 Ni, const u64 *outer, const double *co, i64 o_begin, i64 o_end,
+                            int Wq, int inner_is_left, double *out_coeff, hipStream_t st, Scratch &ot,
+                            const u64 *inner_rm = nullptr, u64 *out_rows = nullptr) {
     const i64 No = o_end - o_begin;
-    if (Ni == 0 || No <= 0) return SYMGPU_OK;
     const int W = 2 * Wq;
-    const i64 Ipad = round_up(Ni, 64 * PJ), Opad = round_up(No, PO * PW);
-    Scratch it, ot;
-    SG_TRY(it.alloc((size_t)Ipad * W * sizeof(u64)));
+    const i64 Opad = round_up(No, PO * PW);
     SG_TRY(ot.alloc((size_t)Opad * W * sizeof(u64)));
-    SG_TRY(to_wordmajor(inner, Ni, W, it.as<u64>(), Ipad));
-    SG_TRY(to_wordmajor(outer + o_begin * W, No, W, ot.as<u64>(), Opad));
-    const i64 gx = Ipad / (64 * PJ);
+    SG_TRY(to_wordmajor(outer + o_begin * W, No, W, ot.as<u64>(), Opad, st));
+    const i64 gx = (Ni + 64 * PJ - 1) / (64 * PJ);
     const i64 gy_total = Opad / (PO * PW);
     const i64 max_gy = 65535;
     for (i64 y0 = 0; y0 < gy_total; y0 += max_gy) {
         const i64 ny = gy_total - y0 < max_gy ? gy_total - y0 : max_gy;
         const i64 ooff = y0 * PO * PW;
         dim3 grid((unsigned)gx, (unsigned)ny);
-        if (inner_is_left)
-            hipLaunchKernelGGL(k_mul_coeff<true>, grid, dim3(256), 0, ctx().stream, it.as<u64>(), Ipad, Ni, ci,
-                               ot.as<u64>() + ooff, Opad, No - ooff, co + 2 * (o_begin + ooff), Wq, out_coeff + 2 * ooff * Ni);
-        else
-            hipLaunchKernelGGL(k_mul_coeff<false>, grid, dim3(256), 0, ctx().stream, it.as<u64>(), Ipad, Ni, ci,
-                               ot.as<u64>() + ooff, Opad, No - ooff, co + 2 * (o_begin + ooff), Wq, out_coeff + 2 * ooff * Ni);
+        const u32x4 *irm = reinterpret_cast<const u32x4 *>(inner_rm);
+        const u32x4 *orm = reinterpret_cast<const u32x4 *>(outer + (o_begin + ooff) * W);
+        u32x4 *drows = out_rows ? reinterpret_cast<u32x4 *>(out_rows) + ooff * Ni * Wq : nullptr;
+#define LAUNCH_COEFF(L, F) hipLaunchKernelGGL((k_mul_coeff<L, F>), grid, dim3(256), 0, st, It, Ipad, Ni, ci, ot.as<u64>() + ooff, Opad, \
+                                              No - ooff, co + 2 * (o_begin + ooff), Wq, out_coeff + 2 * ooff * Ni, irm, orm, drows)
+        if (out_rows) {
+            ProfScope prof(0);
+            if (inner_is_left) LAUNCH_COEFF(true, true); else LAUNCH_COEFF(false, true);
+        } else {
+            if (inner_is_left) LAUNCH_COEFF(true, false); else LAUNCH_COEFF(false, false);
+        }
+#undef LAUNCH_COEFF
         KERNEL_CHECK();
     }
     return SYMGPU_OK;
+}
+
+int mul_coeff_dev(const u64 *inner, const double *ci, i64 Ni, const u64 *outer, const double *co, i64 o_begin, i64 o_end,
+                  int Wq, int inner_is_left, double *out_coeff) {
+    if (Ni == 0 || o_end - o_begin <= 0) return SYMGPU_OK;
+    const i64 Ipad = round_up(Ni, 64 * PJ);
+    Scratch it, ot;
+    SG_TRY(it.alloc((size_t)Ipad * 2 * Wq * sizeof(u64)));
+    SG_TRY(to_wordmajor(inner, Ni, 2 * Wq, it.as<u64>(), Ipad));
+    return mul_coeff_launch(it.as<u64>(), Ipad, ci, Ni, outer, co, o_begin, o_end, Wq, inner_is_left, out_coeff, ctx().stream, ot);
 }
 
 // rows of the slab: out_rows[((o-o_begin)*Ni + i)*W + w]
@@ -190,17 +243,25 @@ int mul_rows_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 o_begin, i64 o_
     const i64 No = o_end - o_begin;
     if (Ni == 0 || No <= 0) return SYMGPU_OK;
     const i64 n_chunks = Ni * Wq;
-    const i64 gx = (n_chunks + 256 * RC - 1) / (256 * RC);
+    const RowsVariant &rv = rows_variant();
+    const i64 gx = (n_chunks + 256 * rv.rc - 1) / (256 * rv.rc);
     const i64 max_gy = 65535;
-    const i64 gy_total = (No + RTO - 1) / RTO;
+    const i64 gy_total = (No + rv.rto - 1) / rv.rto;
     for (i64 y0 = 0; y0 < gy_total; y0 += max_gy) {
         const i64 ny = gy_total - y0 < max_gy ? gy_total - y0 : max_gy;
-        const i64 ooff = y0 * RTO;
+        const i64 ooff = y0 * rv.rto;
         dim3 grid((unsigned)gx, (unsigned)ny);
+        const u32x4 *pi = reinterpret_cast<const u32x4 *>(inner);
+        const u32x4 *po = reinterpret_cast<const u32x4 *>(outer + (o_begin + ooff) * 2 * Wq);
+        u32x4 *pd = reinterpret_cast<u32x4 *>(out_rows) + ooff * n_chunks;
         ProfScope prof(0);
-        hipLaunchKernelGGL(k_mul_rows, grid, dim3(256), 0, ctx().stream, reinterpret_cast<const u32x4 *>(inner), n_chunks,
-                           reinterpret_cast<const u32x4 *>(outer + (o_begin + ooff) * 2 * Wq), Wq, No - ooff,
-                           reinterpret_cast<u32x4 *>(out_rows) + ooff * n_chunks);
+#define LAUNCH_ROWS(RCV, NTV) hipLaunchKernelGGL((k_mul_rows<RCV, NTV>), grid, dim3(256), 0, ctx().stream, pi, n_chunks, po, Wq, No - ooff, pd, rv.rto)
+        if (rv.nt) {
+            if (rv.rc == 1) LAUNCH_ROWS(1, true); else if (rv.rc == 2) LAUNCH_ROWS(2, true); else if (rv.rc == 8) LAUNCH_ROWS(8, true); else LAUNCH_ROWS(4, true);
+        } else {
+            if (rv.rc == 1) LAUNCH_ROWS(1, false); else if (rv.rc == 2) LAUNCH_ROWS(2, false); else if (rv.rc == 8) LAUNCH_ROWS(8, false); else LAUNCH_ROWS(4, false);
+        }
+#undef LAUNCH_ROWS
         KERNEL_CHECK();
     }
     return SYMGPU_OK;
@@ -223,12 +284,37 @@ int symgpu_mul_allpairs_dev(symgpu_op_t inner, symgpu_op_t outer, int64_t o_begi
         set_error("mul_allpairs_dev: output capacity %lld < %lld rows", (long long)out->capacity, (long long)rows);
         return SYMGPU_E_CAPACITY;
     }
-    if (out->coeff) {
+    op_invalidate(out);
+    if (out->coeff && rows > 0) {
         SG_REQUIRE(inner->coeff && outer->coeff, "mul_allpairs_dev: operands have no coefficients");
-        SG_TRY(mul_coeff_dev(inner->rows, inner->coeff, inner->T, outer->rows, outer->coeff, o_begin, o_end, inner->Wq,
-                             inner_is_left, out->coeff));
+        // Default ("streams"): the VALU-bound coefficient kernel runs on a side stream and overlaps the HBM-bound row stream
+        // (measured on MI355X, 1e5 x 1e5 terms, n=1000: 2.05e10 pairs/s).  SYMGPU_PRODUCT_MODE=fused runs ONE launch per
+        // slab that does both (1.86e10 pairs/s: the long VALU prologue of every block delays its stores).
+        Context &c = ctx();
+        const u64 *It = nullptr;
+        i64 Ipad = 0;
+        SG_TRY(op_wordmajor(inner, 64 * PJ, &It, &Ipad));          // cached across slabs of the same inner operand
+        Scratch ot;
+        static const int mode = [] { const char *e = getenv("SYMGPU_PRODUCT_MODE"); return (e && e[0] == 'f') ? 0 : 1; }();
+        if (mode == 0) {
+            SG_TRY(mul_coeff_launch(It, Ipad, inner->coeff, inner->T, outer->rows, outer->coeff, o_begin, o_end, inner->Wq, inner_is_left,
+                                    out->coeff, c.stream, ot, inner->rows, out->rows));
+        } else {
+            HIP_TRY(hipEventRecord(c.ev_fork, c.stream));
+            HIP_TRY(hipStreamWaitEvent(c.stream2, c.ev_fork, 0));
+            int rc = mul_coeff_launch(It, Ipad, inner->coeff, inner->T, outer->rows, outer->coeff, o_begin, o_end, inner->Wq,
+                                      inner_is_left, out->coeff, c.stream2, ot);
+            hipError_t e1 = hipEventRecord(c.ev_join, c.stream2);
+            int rc2 = mul_rows_dev(inner->rows, inner->T, outer->rows, o_begin, o_end, inner->Wq, out->rows);
+            hipError_t e2 = hipStreamWaitEvent(c.stream, c.ev_join, 0);
+            if (rc != SYMGPU_OK) return rc;
+            if (rc2 != SYMGPU_OK) return rc2;
+            if (e1 != hipSuccess) return hip_fail(e1, "event record (join)", __FILE__, __LINE__);
+            if (e2 != hipSuccess) return hip_fail(e2, "stream wait (join)", __FILE__, __LINE__);
+        }
+    } else {
+        SG_TRY(mul_rows_dev(inner->rows, inner->T, outer->rows, o_begin, o_end, inner->Wq, out->rows));
     }
-    SG_TRY(mul_rows_dev(inner->rows, inner->T, outer->rows, o_begin, o_end, inner->Wq, out->rows));
     out->T = rows;
     return SYMGPU_OK;
 }
