@@ -106,40 +106,98 @@ __global__ void k_pair_keys(const u64 *__restrict__ hI, i64 Ni, const u64 *__res
     }
 }
 
-// head flags + exact verification of equal-key neighbours.  PAIR: row(t) = inner[t % Ni] ^ outer[t / Ni].
+// head flags + exact verification of equal-key neighbours + coefficient gather into sorted order.
+// PAIR: row(t) = inner[t % Ni] ^ outer[t / Ni].  One wavefront owns 64 consecutive sorted positions; the positions whose
+// key equals their predecessor's (ballot) are verified COOPERATIVELY: G = pow2 >= W lanes (<= 64) read the words of the
+// two rows with coalesced loads, 64/G comparisons in flight per step.  A mismatch (two different rows with one 64-bit
+// hash) only raises the collision flag: the caller reseeds the hash and redoes the pass, so exactness never rests on the
+// hash.  cg[s] = coeff[idx[s]] turns the segment sums into sequential reads.
 template <bool PAIR>
-__global__ void k_heads(const u64 *__restrict__ keys, const u32 *__restrict__ idx, i64 T, const u64 *__restrict__ rows, int W,
-                        const u64 *__restrict__ inner, i64 Ni, const u64 *__restrict__ outer, u32 *__restrict__ heads, u32 *__restrict__ collision) {
-    for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
-        u32 head = 1;
-        if (s > 0 && keys[s] == keys[s - 1]) {
-            const i64 t1 = idx[s], t0 = idx[s - 1];
-            bool same = true;
-            if (PAIR) {
-                const i64 o1 = t1 / Ni, i1 = t1 - o1 * Ni, o0 = t0 / Ni, i0 = t0 - o0 * Ni;
-                const u64 *a1 = inner + i1 * W, *b1 = outer + o1 * W, *a0 = inner + i0 * W, *b0 = outer + o0 * W;
-                for (int w = 0; w < W; ++w) same &= ((a1[w] ^ b1[w]) == (a0[w] ^ b0[w]));
-            } else {
-                const u64 *r1 = rows + t1 * W, *r0 = rows + t0 * W;
-                for (int w = 0; w < W; ++w) same &= (r1[w] == r0[w]);
-            }
-            if (same) head = 0;
-            else atomicOr(collision, 1u);
+__global__ __launch_bounds__(256) void k_heads(const u64 *__restrict__ keys, const u32 *__restrict__ idx, i64 T, const u64 *__restrict__ rows, int W,
+                                                const u64 *__restrict__ inner, i64 Ni, const u64 *__restrict__ outer, int G,
+                                                const double *__restrict__ coeff, double *__restrict__ cg,
+                                                u32 *__restrict__ heads, u32 *__restrict__ collision) {
+    const int lane = threadIdx.x & 63;
+    const int per = 64 / G, gi = lane / G, gl = lane % G;
+    const i64 n_chunks = (T + 63) / 64;
+    for (i64 chunk = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += (i64)gridDim.x * 4) {
+        const i64 s = chunk * 64 + lane;
+        const bool valid = s < T;
+        const u64 k = valid ? keys[s] : 0ULL;
+        const u64 kp = (valid && s > 0) ? keys[s - 1] : ~k;
+        const u32 t1 = valid ? idx[s] : 0u;
+        const u32 t0 = (valid && s > 0) ? idx[s - 1] : 0u;
+        const bool eq = valid && s > 0 && k == kp;
+        if (valid) {
+            heads[s] = eq ? 0u : 1u;
+            reinterpret_cast<double2 *>(cg)[s] = reinterpret_cast<const double2 *>(coeff)[t1];
         }
-        heads[s] = head;
+        u64 m = __ballot(eq);
+        bool mism = false;
+        while (m) {                                                  // wave-uniform
+            u64 mm = m;
+            for (int q = 0; q < gi; ++q) mm &= mm - 1;               // this group's candidate: the gi-th lowest set bit
+            const bool act = mm != 0;
+            const int p = act ? __builtin_ctzll(mm) : 0;
+            const i64 a1 = __shfl(t1, p), a0 = __shfl(t0, p);
+            if (act) {
+                if (PAIR) {
+                    const i64 o1 = a1 / Ni, i1 = a1 - o1 * Ni, o0 = a0 / Ni, i0 = a0 - o0 * Ni;
+                    const u64 *r1 = inner + i1 * W, *q1 = outer + o1 * W, *r0 = inner + i0 * W, *q0 = outer + o0 * W;
+                    for (int w = gl; w < W; w += G) mism |= ((r1[w] ^ q1[w]) != (r0[w] ^ q0[w]));
+                } else {
+                    const u64 *r1 = rows + a1 * W, *r0 = rows + a0 * W;
+                    for (int w = gl; w < W; w += G) mism |= (r1[w] != r0[w]);
+                }
+            }
+            for (int q = 0; q < per && m; ++q) m &= m - 1;           // retire the `per` candidates just handled
+        }
+        if (__ballot(mism) && lane == 0) atomicOr(collision, 1u);
     }
 }
 
-// one thread per segment: sequential sum in ascending input order (the sort is stable), threshold, mark
-__global__ void k_segsum(const u32 *__restrict__ idx, const u32 *__restrict__ seg_start, i64 U, i64 T, const double *__restrict__ coeff,
+// Truncated sort fix-up.  The radix sort only orders the top `nb` key bits (random hash bits: ~log2(T)+5..12 of them already
+// separate almost all distinct keys).  Inside a run of equal prefixes the elements are still in input order; if such a
+// run holds more than one distinct key it is re-ordered here by (full key, input order) with a stable insertion sort.
+// Runs longer than FIX_MAX that are not uniform raise `fallback`: the caller then redoes a full 64-bit sort.
+constexpr int FIX_MAX = 48;
+__global__ void k_fixup_runs(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 T, int shift, u32 *__restrict__ fallback) {
+    for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
+        const u64 k0 = keys[s];
+        if (s > 0 && (keys[s - 1] >> shift) == (k0 >> shift)) continue;      // not a run start
+        i64 e = s + 1;
+        bool uniform = true;
+        while (e < T) {
+            const u64 k = keys[e];
+            if ((k >> shift) != (k0 >> shift)) break;
+            uniform &= (k == k0);
+            ++e;
+        }
+        if (uniform) continue;
+        const i64 len = e - s;
+        if (len > FIX_MAX) { atomicOr(fallback, 1u); continue; }
+        for (i64 a = s + 1; a < e; ++a) {                                     // stable insertion sort by full key
+            const u64 ka = keys[a];
+            const u32 ia = idx[a];
+            i64 b = a - 1;
+            while (b >= s && keys[b] > ka) { keys[b + 1] = keys[b]; idx[b + 1] = idx[b]; --b; }
+            keys[b + 1] = ka;
+            idx[b + 1] = ia;
+        }
+    }
+}
+
+// one thread per segment: sequential sum in ascending input order (the sort is stable), threshold, mark.
+// cg holds the coefficients already gathered into sorted order (k_heads): the reads are sequential.
+__global__ void k_segsum(const u32 *__restrict__ idx, const u32 *__restrict__ seg_start, i64 U, i64 T, const double *__restrict__ cg,
                          double thr, int use_thr, double *__restrict__ seg_sum, u32 *__restrict__ seg_first, u32 *__restrict__ mark) {
     for (i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (i64)gridDim.x * blockDim.x) {
         const i64 b = seg_start[u], e = (u + 1 < U) ? (i64)seg_start[u + 1] : T;
         double re = 0.0, im = 0.0;
         for (i64 s = b; s < e; ++s) {
-            const i64 t = idx[s];
-            re = __dadd_rn(re, coeff[2 * t]);
-            im = __dadd_rn(im, coeff[2 * t + 1]);
+            const double2 c = reinterpret_cast<const double2 *>(cg)[s];
+            re = __dadd_rn(re, c.x);
+            im = __dadd_rn(im, c.y);
         }
         const u32 first = idx[b];
         const bool keep = use_thr ? (hypot(re, im) > thr) : true;
@@ -273,18 +331,27 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         *out = res;
         return SYMGPU_OK;
     }
-    Scratch keys, keys2, idx, idx2, heads, collision;
+    Scratch keys, keys2, idx, idx2, heads, collision, cg;
     SG_TRY(keys.alloc((size_t)T * 8));
     SG_TRY(keys2.alloc((size_t)T * 8));
     SG_TRY(idx.alloc((size_t)T * 4));
     SG_TRY(idx2.alloc((size_t)T * 4));
     SG_TRY(heads.alloc((size_t)T * 4));
     SG_TRY(collision.alloc(16));
+    SG_TRY(cg.alloc((size_t)T * 16));
     u64 *ks = nullptr;
     u32 *is = nullptr;
     u64 seed = ctx().hash_tab ? ctx().hash_seed : 1;
     bool ok = false;
-    for (int attempt = 0; attempt < 4 && !ok; ++attempt, ++seed) {
+    // number of (top) key bits the radix sort orders; the rest is handled by k_fixup_runs
+    int nb = 64;
+    {
+        int lg = 0;
+        while (((i64)1 << lg) < T) ++lg;
+        const int want = (lg + 5 + 7) / 8 * 8;   // ~1-3 % of the keys then share a prefix with another key: cheap local fix-up
+        if (want < 64) nb = want;
+    }
+    for (int attempt = 0; attempt < 6 && !ok; ++attempt) {
         SG_TRY(ensure_hash_tables(seed));
         if (pair) {
             Scratch hI, hO;
@@ -300,21 +367,33 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             KERNEL_CHECK();
         }
         bool in_tmp = false;
-        SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), T, 0, 64, &in_tmp));
+        SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), T, 64 - nb, 64, &in_tmp));
         ks = in_tmp ? keys2.as<u64>() : keys.as<u64>();
         is = in_tmp ? idx2.as<u32>() : idx.as<u32>();
         HIP_TRY(hipMemsetAsync(collision.p, 0, 16, st));
-        if (pair)
-            hipLaunchKernelGGL(k_heads<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, is, T, (const u64 *)nullptr, W, inner, Ni, outer,
-                               heads.as<u32>(), collision.as<u32>());
-        else
-            hipLaunchKernelGGL(k_heads<false>, dim3(grid_for(T)), dim3(256), 0, st, ks, is, T, rows, W, (const u64 *)nullptr, (i64)1,
-                               (const u64 *)nullptr, heads.as<u32>(), collision.as<u32>());
+        if (nb < 64) {
+            hipLaunchKernelGGL(k_fixup_runs, dim3(grid_for(T)), dim3(256), 0, st, ks, is, T, 64 - nb, collision.as<u32>() + 1);
+            KERNEL_CHECK();
+        }
+        {
+            int G = 8;
+            while (G < W && G < 64) G <<= 1;
+            i64 gh = ((T + 63) / 64 + 3) / 4;
+            if (gh > 16384) gh = 16384;
+            if (pair)
+                hipLaunchKernelGGL(k_heads<true>, dim3((unsigned)gh), dim3(256), 0, st, ks, is, T, (const u64 *)nullptr, W, inner, Ni, outer, G,
+                                   coeff, cg.as<double>(), heads.as<u32>(), collision.as<u32>());
+            else
+                hipLaunchKernelGGL(k_heads<false>, dim3((unsigned)gh), dim3(256), 0, st, ks, is, T, rows, W, (const u64 *)nullptr, (i64)1,
+                                   (const u64 *)nullptr, G, coeff, cg.as<double>(), heads.as<u32>(), collision.as<u32>());
+        }
         KERNEL_CHECK();
-        u32 hcol = 0;
-        HIP_TRY(hipMemcpyAsync(&hcol, collision.p, 4, hipMemcpyDeviceToHost, st));
+        u32 hflags[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(hflags, collision.p, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        ok = (hcol == 0);
+        if (hflags[1]) { nb = 64; continue; }       // a long mixed prefix run: redo with a full 64-bit sort, same seed
+        ok = (hflags[0] == 0);
+        if (!ok) ++seed;                            // genuine 64-bit hash collision: reseed and retry
     }
     if (!ok) {
         set_error("cleanup: 64-bit row-hash collision survived 4 reseeds");
@@ -335,7 +414,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
     SG_TRY(seg_first.alloc((size_t)U * 4));
     SG_TRY(mark.alloc((size_t)T * 4));
     HIP_TRY(hipMemsetAsync(mark.p, 0, (size_t)T * 4, st));
-    return cleanup_finish(heads.as<u32>(), is, T, U, coeff, thr, use_thr, seg_start.as<u32>(), seg_sum.as<double>(),
+    return cleanup_finish(heads.as<u32>(), is, T, U, cg.as<double>(), thr, use_thr, seg_start.as<u32>(), seg_sum.as<double>(),
                           seg_first.as<u32>(), mark.as<u32>(), pair, rows, W, inner, Ni, outer, out, Wq_out);
 }
 
