@@ -127,6 +127,23 @@ def main():
                      'algorithmic_bytes_per_launch': algo_bytes_launch,
                      'whole_step_GBps': pairs_per_step_rank * (16 * wq + 16) / (dt / args.steps) / 1e9},
     }
+    # the same kernel WITHOUT the concurrent coefficient kernel (rows-only output slab), outside the timed region
+    if rank == 0:
+        rows_only = DeviceOp.alloc(slab * Ni, wq, with_coeff=False)
+        o1 = min(M, slab)
+        for _ in range(2):
+            _lib.check(lib.symgpu_mul_allpairs_dev(left.handle, right.handle, 0, o1, 1, rows_only.handle))
+        kernels.sync()
+        _lib.check(lib.symgpu_prof_enable(0, 1))
+        for _ in range(10):
+            _lib.check(lib.symgpu_mul_allpairs_dev(left.handle, right.handle, 0, o1, 1, rows_only.handle))
+        _lib.check(lib.symgpu_prof_enable(0, 0))
+        n2, ms2 = ctypes.c_int64(0), ctypes.c_double(0)
+        _lib.check(lib.symgpu_prof_read(0, ctypes.addressof(n2), ctypes.addressof(ms2)))
+        iso = (o1 * Ni * 16 * wq) / (ms2.value / max(1, n2.value) * 1e-3) / 1e9 if ms2.value > 0 else 0.0
+        out['roofline']['isolated_GBps'] = iso
+        out['roofline']['isolated_frac'] = iso / HBM_PEAK_GBS
+        rows_only.free()
     for r in ring:
         r.free()
 
