@@ -27,6 +27,8 @@ static u64 host_splitmix64(u64 &s) {
     return z ^ (z >> 31);
 }
 
+static std::vector<u64> g_host_tab;   // host copy of the device tables (to hash single rows, e.g. a rotation's Q)
+
 int ensure_hash_tables(u64 seed) {
     Context &c = ctx();
     if (c.hash_tab && c.hash_seed == seed) return SYMGPU_OK;
@@ -47,7 +49,30 @@ int ensure_hash_tables(u64 seed) {
     HIP_TRY(hipMemcpyAsync(c.hash_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, c.stream));
     HIP_TRY(hipStreamSynchronize(c.stream));   // tab is a host temporary
     c.hash_seed = seed;
+    g_host_tab = tab;
     return SYMGPU_OK;
+}
+
+// host evaluation of the same linear hash h1 as k_hash_rows (per-lane Horner over 64-word blocks, XOR over lanes)
+u64 host_row_hash(const u64 *row, int W) {
+    const int n_blk = (W + 63) / 64;
+    u64 h = 0;
+    for (int g = 0; g < 64; ++g) {
+        u64 hg = 0;
+        for (int b = 0; b < n_blk; ++b) {
+            const int w = b * 64 + g;
+            u64 a1 = 0;
+            if (w < W) {
+                const u64 x = row[w];
+                for (int k = 0; k < 8; ++k) a1 ^= g_host_tab[((size_t)k * 256 + ((x >> (8 * k)) & 255)) * 2];
+            }
+            hg ^= hg << 13; hg ^= hg >> 7; hg ^= hg << 17;
+            const int r = g & 63;
+            hg ^= r ? ((a1 << r) | (a1 >> (64 - r))) : a1;
+        }
+        h ^= hg;
+    }
+    return h;
 }
 
 __device__ __forceinline__ u64 rotl64(u64 x, int r) { r &= 63; return r ? ((x << r) | (x >> (64 - r))) : x; }
@@ -254,7 +279,7 @@ static int pow2_group(int W) {
     return g;
 }
 
-static int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
+int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
     if (T == 0) return SYMGPU_OK;
     const int G = pow2_group(W);
     const int rpb = 256 / G;

@@ -117,6 +117,8 @@ int mul_rows_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 o_begin, i64 o_
 
 // cleanup.hip
 int ensure_hash_tables(u64 seed);
+int hash_rows(const u64 *rows, i64 T, int W, u64 *out1);       // h1 of every row (current tables)
+u64 host_row_hash(const u64 *row, int W);                       // the same hash on the host
 int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W,          // plain mode (pair mode if inner != null)
                  const u64 *inner, i64 Ni, const u64 *outer, i64 No,
                  double thr, int use_thr, symgpu_op_t *out, int Wq_out);

@@ -14,23 +14,36 @@
 // Equivalent to the reference's three intermediate cleanups when the input has no duplicate rows
 // (every operator that left cleanup() qualifies).
 #include "common.h"
+#include <stdlib.h>
 
 namespace symgpu {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// flags[t] = 1 iff row t anticommutes with q;  ph[t] = phase exponent e of (row_t * q)
+// flags[t] = 1 iff row t anticommutes with q;  ph[t] = phase exponent e of (row_t * q).
+// HASH: also the linear row hash h1 of cleanup.hip (same tables, same per-lane Horner) for the hash-join fast path.
+__device__ __forceinline__ u64 rot_rotl64(u64 x, int r) { r &= 63; return r ? ((x << r) | (x >> (64 - r))) : x; }
+
+template <bool HASH>
 __global__ __launch_bounds__(256) void k_rot_analyze(const u64 *__restrict__ rows, i64 T, int Wq, int G, const u64 *__restrict__ q,
-                                                      u32 *__restrict__ flags, uint8_t *__restrict__ ph) {
+                                                      u32 *__restrict__ flags, uint8_t *__restrict__ ph, const u64 *__restrict__ tab_g,
+                                                      u64 *__restrict__ hout) {
+    __shared__ u64 tab[HASH ? 8 * 256 : 1];
+    if (HASH) {
+        for (int k = threadIdx.x; k < 8 * 256; k += 256) tab[k] = tab_g[2 * k];      // h1 entries only
+        __syncthreads();
+    }
     const int rows_per_block = 256 / G;
     const int g = threadIdx.x % G, rsub = threadIdx.x / G;
     // Y count of q (every lane redundantly; Wq is small)
     int yq = 0;
     for (int w = 0; w < Wq; ++w) yq += __popcll(q[w] & q[Wq + w]);
+    const int W = 2 * Wq;
     for (i64 t0 = (i64)blockIdx.x * rows_per_block; t0 < T; t0 += (i64)gridDim.x * rows_per_block) {
         const i64 t = t0 + rsub;
         u64 par = 0, flip = 0;
         int yp = 0, yout = 0;
+        u64 h1 = 0;
         if (t < T) {
             const u64 *r = rows + t * 2 * Wq;
             for (int w = g; w < Wq; w += G) {
@@ -40,6 +53,26 @@ __global__ __launch_bounds__(256) void k_rot_analyze(const u64 *__restrict__ row
                 yp += __popcll(x & z);
                 yout += __popcll((x ^ xq) & (z ^ zq));
             }
+            if (HASH) {
+                // lane g of a 64-lane virtual row owns words g, g+64, ...; here G <= 64 lanes cover the row, so every
+                // lane loops over the virtual lanes vg = g, g+G, ... < 64 it stands for
+                const int n_blk = (W + 63) / 64;
+                for (int vg = g; vg < 64; vg += G) {
+                    u64 hv = 0;
+                    for (int b = 0; b < n_blk; ++b) {
+                        const int w = b * 64 + vg;
+                        u64 a1 = 0;
+                        if (w < W) {
+                            const u64 x = r[w];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) a1 ^= tab[k * 256 + (int)((x >> (8 * k)) & 255)];
+                        }
+                        hv ^= hv << 13; hv ^= hv >> 7; hv ^= hv << 17;
+                        hv ^= rot_rotl64(a1, vg);
+                    }
+                    h1 ^= hv;
+                }
+            }
         }
         int pp = __popcll(par) & 1, fp = __popcll(flip) & 1;
         for (int off = G >> 1; off > 0; off >>= 1) {
@@ -47,10 +80,12 @@ __global__ __launch_bounds__(256) void k_rot_analyze(const u64 *__restrict__ row
             fp ^= __shfl_xor(fp, off);
             yp += __shfl_xor(yp, off);
             yout += __shfl_xor(yout, off);
+            if (HASH) h1 ^= __shfl_xor(h1, off);
         }
         if (g == 0 && t < T) {
             flags[t] = (u32)pp;
             ph[t] = (uint8_t)((3 * (yp + yq) + yout + 2 * fp) & 3);
+            if (HASH) hout[t] = h1;
         }
     }
 }
@@ -146,6 +181,238 @@ static int grid_for(i64 n, int block = 256, int cap = 8192) {
     return (int)g;
 }
 
+// ---- fast non-Clifford path: hash-table join instead of the sort-based cleanup ---------------------------------------
+// For an operator WITHOUT duplicate rows (anything that left cleanup()) the only possible merge is between a product row
+// P_k ^ Q and the existing row R_j = P_k ^ Q, which is anticommuting too and whose own product row is P_k: partners come
+// in pairs.  So: hash every row (linear hash: h(P^Q) = h(P) ^ h(Q)), insert the rows in an open-addressing table, look
+// up h(P_k) ^ h(Q) for every anticommuting row and verify the candidate word by word.  A duplicate row in the input
+// (same hash AND same words) raises `dup`; the caller then takes the general sort-based path, which handles it.
+// Output order and sums are those of the reference (base.py:1158-1161 + cleanup): kept commuting rows, kept
+// anticommuting rows with  cos*c_t + (-i sin) i^{e_p} c_p  (first-occurrence entry first), then the kept unmatched product
+// rows; strict |c| > thr everywhere.
+struct RotCounts { u32 nC, nA, nN, dup, nAnti; };
+
+__device__ __forceinline__ u64 mix64(u64 h) { h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 29; return h; }
+
+__global__ void k_rotf_insert(const u64 *__restrict__ rows, const u64 *__restrict__ h, i64 T, int W, u32 *__restrict__ table, u32 mask,
+                              RotCounts *__restrict__ cnt) {
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (i64)gridDim.x * blockDim.x) {
+        const u64 ht = h[t];
+        u32 pos = (u32)mix64(ht) & mask;
+        for (;;) {
+            const u32 old = atomicCAS(&table[pos], 0u, (u32)t + 1u);
+            if (old == 0u) break;
+            const i64 o = (i64)old - 1;
+            if (h[o] == ht) {                                   // same hash: duplicate row (or a 64-bit collision)
+                bool same = true;
+                for (int w = 0; w < W; ++w) same &= (rows[o * W + w] == rows[t * W + w]);
+                if (same) { atomicOr(&cnt->dup, 1u); break; }
+            }
+            pos = (pos + 1) & mask;
+        }
+    }
+}
+
+// G lanes per row.  cls: bit0 kept commuting, bit1 kept anticommuting, bit2 kept new (unmatched product) row.
+__global__ __launch_bounds__(256) void k_rotf_match(const u64 *__restrict__ rows, const double *__restrict__ coeff, const u64 *__restrict__ h, i64 T,
+                                                     int Wq, int G, const u64 *__restrict__ q, u64 hq, const u32 *__restrict__ anti,
+                                                     const uint8_t *__restrict__ ph, const u32 *__restrict__ table, u32 mask, double cos_t,
+                                                     double sin_t, double thr, double *__restrict__ selfc, double *__restrict__ prodc,
+                                                     uint8_t *__restrict__ cls) {
+    const int W = 2 * Wq;
+    const int rows_per_block = 256 / G;
+    const int g = threadIdx.x % G, rsub = threadIdx.x / G;
+    const int lane = threadIdx.x & 63;
+    const u64 gmask = (G == 64) ? ~0ULL : (((1ULL << G) - 1ULL) << (lane - g));
+    for (i64 t0 = (i64)blockIdx.x * rows_per_block; t0 < T; t0 += (i64)gridDim.x * rows_per_block) {
+        const i64 t = t0 + rsub;
+        const bool valid = t < T;
+        const bool is_anti = valid && anti[t];
+        i64 partner = -1;
+        if (__ballot(is_anti) & gmask) {                        // group-uniform
+            const u64 key = h[t] ^ hq;
+            u32 pos = (u32)mix64(key) & mask;
+            for (;;) {
+                const u32 v = table[pos];
+                if (v == 0u) break;
+                const i64 o = (i64)v - 1;
+                if (h[o] == key) {
+                    bool mism = false;
+                    for (int w = g; w < W; w += G) mism |= (rows[o * W + w] != (rows[t * W + w] ^ q[w]));
+                    if (!(__ballot(mism) & gmask)) { partner = o; break; }
+                }
+                pos = (pos + 1) & mask;
+            }
+        }
+        if (g == 0 && valid) {
+            const double re = coeff[2 * t], im = coeff[2 * t + 1];
+            uint8_t c = 0;
+            if (!is_anti) {
+                selfc[2 * t] = re; selfc[2 * t + 1] = im;
+                if (hypot(re, im) > thr) c = 1;
+            } else {
+                double sr = __dmul_rn(re, cos_t), si = __dmul_rn(im, cos_t);
+                if (partner >= 0) {                              // merge: (0 + cos*c_t) + (-i sin) i^{e_p} c_p, in that order
+                    double pr, pi;
+                    phase_mul(coeff[2 * partner], coeff[2 * partner + 1], ph[partner], pr, pi);
+                    sr = __dadd_rn(sr, __dmul_rn(pi, sin_t));
+                    si = __dadd_rn(si, -__dmul_rn(pr, sin_t));
+                } else {                                         // its product row is new
+                    double pr, pi;
+                    phase_mul(re, im, ph[t], pr, pi);
+                    const double nr = __dmul_rn(pi, sin_t), ni = -__dmul_rn(pr, sin_t);
+                    prodc[2 * t] = nr; prodc[2 * t + 1] = ni;
+                    if (hypot(nr, ni) > thr) c |= 4;
+                }
+                selfc[2 * t] = sr; selfc[2 * t + 1] = si;
+                if (hypot(sr, si) > thr) c |= 2;
+            }
+            cls[t] = c;
+        }
+    }
+}
+
+// three exclusive scans (kept-commuting, kept-anticommuting, kept-new) + the anticommuting count, two small launches:
+// per-1024-element block counts, then every block adds the counts of the blocks before it (<= 4096 blocks) to its local ranks.
+__global__ __launch_bounds__(1024) void k_rotf_count(const uint8_t *__restrict__ cls, const u32 *__restrict__ anti, i64 T, u32 *__restrict__ blk) {
+    __shared__ u32 s_c[4];
+    if (threadIdx.x < 4) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    const i64 t = (i64)blockIdx.x * 1024 + threadIdx.x;
+    const uint8_t c = (t < T) ? cls[t] : 0;
+    const bool a = t < T && anti[t];
+    const int lane = threadIdx.x & 63;
+    const u64 b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4), b3 = __ballot(a);
+    if (lane == 0) {
+        atomicAdd(&s_c[0], (u32)__popcll(b0)); atomicAdd(&s_c[1], (u32)__popcll(b1));
+        atomicAdd(&s_c[2], (u32)__popcll(b2)); atomicAdd(&s_c[3], (u32)__popcll(b3));
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) blk[blockIdx.x * 4 + threadIdx.x] = s_c[threadIdx.x];
+}
+
+__global__ __launch_bounds__(1024) void k_rotf_scan3(const uint8_t *__restrict__ cls, i64 T, const u32 *__restrict__ blk, int n_blk,
+                                                      u32 *__restrict__ pos_self, u32 *__restrict__ pos_new, RotCounts *__restrict__ cnt) {
+    __shared__ u32 s_w[3][16];
+    __shared__ u32 s_base[4], s_all[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 4) { s_base[threadIdx.x] = 0; s_all[threadIdx.x] = 0; }
+    __syncthreads();
+    {   // counts of the blocks before this one (and, for the last block, of all blocks)
+        u32 before[4] = {0, 0, 0, 0}, all[4] = {0, 0, 0, 0};
+        for (int b = threadIdx.x; b < n_blk; b += 1024)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const u32 x = blk[b * 4 + k]; all[k] += x; if (b < (int)blockIdx.x) before[k] += x; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            for (int off = 32; off > 0; off >>= 1) { before[k] += __shfl_down(before[k], off); all[k] += __shfl_down(all[k], off); }
+            if (lane == 0) { if (before[k]) atomicAdd(&s_base[k], before[k]); if (all[k]) atomicAdd(&s_all[k], all[k]); }
+        }
+    }
+    const i64 t = (i64)blockIdx.x * 1024 + threadIdx.x;
+    const uint8_t c = (t < T) ? cls[t] : 0;
+    u32 ex[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const u64 b = __ballot((c >> k) & 1);
+        ex[k] = __popcll(b & ((1ULL << lane) - 1ULL));
+        if (lane == 0) s_w[k][wave] = __popcll(b);
+    }
+    __syncthreads();
+    u32 off[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int w2 = 0; w2 < wave; ++w2) off[k] += s_w[k][w2];
+    if (t < T) {
+        pos_self[t] = (c & 1) ? s_base[0] + off[0] + ex[0] : s_base[1] + off[1] + ex[1];
+        pos_new[t] = s_base[2] + off[2] + ex[2];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { cnt->nC = s_all[0]; cnt->nA = s_all[1]; cnt->nN = s_all[2]; cnt->nAnti = s_all[3]; }
+}
+
+__global__ void k_rotf_write(const u32x4 *__restrict__ rows, const u32x4 *__restrict__ q, i64 T, int Wq, const uint8_t *__restrict__ cls,
+                             const u32 *__restrict__ pos_self, const u32 *__restrict__ pos_new, const RotCounts *__restrict__ cnt,
+                             const double *__restrict__ selfc, const double *__restrict__ prodc, u32x4 *__restrict__ out_rows,
+                             double *__restrict__ out_coeff) {
+    const i64 total = T * Wq;
+    const u32 nC = cnt->nC, nA = cnt->nA;
+    for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (i64)gridDim.x * blockDim.x) {
+        const i64 t = idx / Wq;
+        const int c = (int)(idx - t * Wq);
+        const uint8_t k = cls[t];
+        if (!k) continue;
+        const u32x4 v = rows[idx];
+        if (k & 3) {
+            const i64 d = (k & 1) ? (i64)pos_self[t] : (i64)nC + pos_self[t];
+            out_rows[d * Wq + c] = v;
+            if (c == 0) { out_coeff[2 * d] = selfc[2 * t]; out_coeff[2 * d + 1] = selfc[2 * t + 1]; }
+        }
+        if (k & 4) {
+            const i64 d = (i64)nC + nA + pos_new[t];
+            out_rows[d * Wq + c] = v ^ q[c];
+            if (c == 0) { out_coeff[2 * d] = prodc[2 * t]; out_coeff[2 * d + 1] = prodc[2 * t + 1]; }
+        }
+    }
+}
+
+// returns SYMGPU_OK with *done = 1 (result in *out / *all_commute) or *done = 0 (duplicate rows: use the general path)
+static int rotate_fast_nonclifford(symgpu_op_t in, const u64 *q_dev, const u64 *q_host, const u32 *anti, const uint8_t *ph, const u64 *hrows, double cos_t,
+                                   double sin_t, double thr, symgpu_op_t *out, int *all_commute, int *done) {
+    hipStream_t st = ctx().stream;
+    const i64 T = in->T;
+    const int Wq = in->Wq, W = 2 * Wq;
+    *done = 0;
+    if (T > ((i64)1 << 22)) return SYMGPU_OK;                  // block-count array of the 2-launch scan: <= 4096 blocks
+    const u64 hq = host_row_hash(q_host, W);
+    u32 cap = 1024;
+    while ((i64)cap < 4 * T) cap <<= 1;
+    Scratch table, selfc, prodc, cls, pself, pnew, cnt, blk;
+    const int n_blk = (int)((T + 1023) / 1024);
+    SG_TRY(blk.alloc((size_t)n_blk * 16));
+    SG_TRY(table.alloc((size_t)cap * 4));
+    SG_TRY(selfc.alloc((size_t)T * 16));
+    SG_TRY(prodc.alloc((size_t)T * 16));
+    SG_TRY(cls.alloc((size_t)T));
+    SG_TRY(pself.alloc((size_t)T * 4));
+    SG_TRY(pnew.alloc((size_t)T * 4));
+    SG_TRY(cnt.alloc(sizeof(RotCounts)));
+    HIP_TRY(hipMemsetAsync(table.p, 0, (size_t)cap * 4, st));
+    HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(RotCounts), st));
+    hipLaunchKernelGGL(k_rotf_insert, dim3(grid_for(T)), dim3(256), 0, st, in->rows, hrows, T, W, table.as<u32>(), cap - 1, cnt.as<RotCounts>());
+    KERNEL_CHECK();
+    int G = 8;
+    while (G < W && G < 64) G <<= 1;
+    {
+        const int rpb = 256 / G;
+        i64 gr = (T + rpb - 1) / rpb;
+        if (gr > 8192) gr = 8192;
+        hipLaunchKernelGGL(k_rotf_match, dim3((unsigned)gr), dim3(256), 0, st, in->rows, in->coeff, hrows, T, Wq, G, q_dev, hq, anti, ph,
+                           table.as<u32>(), cap - 1, cos_t, sin_t, thr, selfc.as<double>(), prodc.as<double>(), cls.as<uint8_t>());
+        KERNEL_CHECK();
+    }
+    hipLaunchKernelGGL(k_rotf_count, dim3(n_blk), dim3(1024), 0, st, cls.as<uint8_t>(), anti, T, blk.as<u32>());
+    hipLaunchKernelGGL(k_rotf_scan3, dim3(n_blk), dim3(1024), 0, st, cls.as<uint8_t>(), T, blk.as<u32>(), n_blk, pself.as<u32>(), pnew.as<u32>(),
+                       cnt.as<RotCounts>());
+    KERNEL_CHECK();
+    symgpu_op_t res = nullptr;
+    SG_TRY(symgpu_op_alloc(2 * T, Wq, 1, &res));               // upper bound: no host round trip before the write kernel
+    hipLaunchKernelGGL(k_rotf_write, dim3(grid_for(T * Wq)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(in->rows),
+                       reinterpret_cast<const u32x4 *>(q_dev), T, Wq, cls.as<uint8_t>(), pself.as<u32>(), pnew.as<u32>(), cnt.as<RotCounts>(),
+                       selfc.as<double>(), prodc.as<double>(), reinterpret_cast<u32x4 *>(res->rows), res->coeff);
+    RotCounts hc;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&hc, cnt.p, sizeof(hc), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { symgpu_op_free(res); return hip_fail(e, "rotate fast path", __FILE__, __LINE__); }
+    if (hc.nAnti == 0) { symgpu_op_free(res); *all_commute = 1; *done = 1; return SYMGPU_OK; }   // identity action (base.py:1131-1133)
+    if (hc.dup) { symgpu_op_free(res); return SYMGPU_OK; }     // duplicates in the input: general path
+    res->T = (i64)hc.nC + hc.nA + hc.nN;
+    *out = res;
+    *all_commute = 0;
+    *done = 1;
+    return SYMGPU_OK;
+}
+
 }  // namespace symgpu
 
 using namespace symgpu;
@@ -175,16 +442,33 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
     SG_TRY(dmain.alloc((size_t)T * 4));
     SG_TRY(dprod.alloc((size_t)T * 4));
     HIP_TRY(hipMemcpyAsync(q.p, q_row_host, (size_t)W * 8, hipMemcpyHostToDevice, st));
+    const bool clifford = clifford_k >= 0;
+    const bool try_fast = !clifford && !getenv("SYMGPU_ROTATE_GENERAL");
+    Scratch hrows;
     int G = 1;
     while (G < Wq && G < 64) G <<= 1;
     {
         const int rpb = 256 / G;
         i64 g = (T + rpb - 1) / rpb;
-        if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(k_rot_analyze, dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>());
+        if (g > 1024) g = 1024;
+        if (try_fast) {
+            SG_TRY(ensure_hash_tables(ctx().hash_tab ? ctx().hash_seed : 1));
+            SG_TRY(hrows.alloc((size_t)T * 8));
+            hipLaunchKernelGGL(k_rot_analyze<true>, dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(),
+                               ctx().hash_tab, hrows.as<u64>());
+        } else {
+            hipLaunchKernelGGL(k_rot_analyze<false>, dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(),
+                               (const u64 *)nullptr, (u64 *)nullptr);
+        }
         KERNEL_CHECK();
     }
-    const bool clifford = clifford_k >= 0;
+    if (try_fast) {
+        int done = 0;
+        SG_TRY(rotate_fast_nonclifford(in, q.as<u64>(), q_row_host, anti.as<u32>(), ph.as<uint8_t>(), hrows.as<u64>(), cos_t, sin_t, thr, out, all_commute, &done));
+        if (done) return SYMGPU_OK;
+        *out = nullptr;
+        *all_commute = 1;
+    }
     const int drop_small = clifford && (clifford_k & 1);
     hipLaunchKernelGGL(k_rot_keepflags, dim3(grid_for(T)), dim3(256), 0, st, anti.as<u32>(), in->coeff, T, thr, drop_small, sel.as<u32>());
     KERNEL_CHECK();

@@ -312,3 +312,19 @@ def test_rccl_allgather_single_rank():
         _lib.check(lib.symgpu_comm_barrier())
     finally:
         _lib.check(lib.symgpu_comm_destroy())
+
+
+def test_rotation_input_with_duplicate_rows_takes_general_path():
+    """The hash-join fast path assumes distinct rows; duplicates are detected on the device and routed to the sort-based path.
+    Result must still equal the reference's step-by-step evaluation (dyadic coefficients, cos/sin irrational -> 1e-12)."""
+    rng = np.random.default_rng(77)
+    n, T = 70, 300
+    symp = rng.random((T, 2 * n)) < 0.3
+    q = rng.random(2 * n) < 0.4
+    symp = np.vstack([symp, symp[:50], symp[:30] ^ q, symp[10:20]])          # duplicates and P*Q partners
+    c = dyadic(rng, symp.shape[0])
+    P = PauliwordOp(symp, c); Q = PauliwordOp(q.reshape(1, -1), [1])
+    for ang in (0.3, -2.2):
+        R = P._rotate_by_single_Pword(Q, ang)
+        er, ec = onp.rotate_by_single_pword(symp, c, q, ang)
+        assert_op_equal(R.symp_matrix, R.coeff_vec, er, ec, exact=False, tol=TOL)
