@@ -222,3 +222,50 @@ G = P.generators
 Rm, mask = P.generator_reconstruction(G)
 fam.add(h_symp=P.symp_matrix, symgen=S.symp_matrix, planted=-1, gens=G.symp_matrix, recon=Rm, recon_mask=mask)
 fam.save()
+
+
+# ---------------------------------------------------------------- taper --------
+from symmer.projection import QubitTapering
+from symmer.operators.utils import check_adjmat_noncontextual
+fam = Family('taper')
+HAM = '/root/reference/tests/hamiltonian_data/'
+def load_ham(name):
+    with open(HAM + name) as f:
+        d = json.load(f)
+    H = PauliwordOp.from_dictionary({k: complex(*v) for k, v in d['hamiltonian'].items()})
+    return H, np.array(d['data']['hf_array'])
+for name in ('H3+_STO-3G_SINGLET_JW.json', 'H3+_STO-3G_SINGLET_BK.json', 'H4_STO-3G_SINGLET_JW.json', 'H4_STO-3G_SINGLET_BK.json',
+             'O_STO-3G_TRIPLET_JW.json'):
+    H, hf = load_ham(name)
+    for target in ('Z', 'X'):
+        T = QubitTapering(H, target_sqp=target)
+        out = T.taper_it(ref_state=hf)
+        rots = np.vstack([r.symp_matrix for r, _ in T.stabilizers.stabilizer_rotations]) if T.stabilizers.stabilizer_rotations else np.zeros((0, 2 * H.n_qubits), dtype=bool)
+        fam.add(h_symp=H.symp_matrix, h_coeff=H.coeff_vec, hf=hf, target=np.array(ord(target)), stab_symp=T.stabilizers.symp_matrix,
+                stab_coeff=np.asarray(T.stabilizers.coeff_vec), rotations=rots, rotated_stab=T.rotated_stabilizers.symp_matrix,
+                rotated_stab_coeff=np.asarray(T.rotated_stabilizers.coeff_vec), free=T.free_qubit_indices,
+                **op_arrays(out, 'out'))
+        sector = -np.asarray(T.stabilizers.coeff_vec)
+        T2 = QubitTapering(H, target_sqp=target)
+        out2 = T2.taper_it(sector=sector)
+        fam.add(h_symp=H.symp_matrix, h_coeff=H.coeff_vec, hf=np.zeros(0, dtype=int), target=np.array(ord(target)), stab_symp=T2.stabilizers.symp_matrix,
+                stab_coeff=np.asarray(T2.stabilizers.coeff_vec), rotations=rots, rotated_stab=T2.rotated_stabilizers.symp_matrix,
+                rotated_stab_coeff=np.asarray(T2.rotated_stabilizers.coeff_vec), free=T2.free_qubit_indices,
+                **op_arrays(out2, 'out'))
+fam.save()
+
+# noncontextuality known answers (tests/test_operators/test_base.py:581-595) + random adjacency checks
+nc = {}
+cases = [(['XZ', 'ZX', 'ZI', 'IZ'], False), (['XZ', 'ZX', 'XX', 'YY'], True), (['XX', 'YY', 'ZZ', 'II'], True),
+         (['II', 'ZZ', 'ZX', 'ZY', 'XZ', 'YZ', 'XX', 'XY', 'YX', 'YY'], False), (['III', 'IIZ', 'ZII', 'IXZ', 'IYZ', 'YYZ'], False),
+         (['IZI', 'ZII', 'IIY', 'ZZY', 'XXZ', 'XYZ', 'YXZ', 'YYZ', 'XXX', 'XYX', 'YXX', 'YYX'], True)]
+out_nc = []
+for plist, expect in cases:
+    P = PauliwordOp.from_list(plist)
+    assert bool(P.is_noncontextual) == expect
+    out_nc.append([plist, bool(P.is_noncontextual)])
+for trial in range(20):
+    P = PauliwordOp(rand_symp(int(rng.integers(2, 6)), int(rng.integers(4, 12)), 0.4), np.ones(1)).cleanup() if False else None
+with open(os.path.join(OUT, 'known_noncontextual.json'), 'w') as f:
+    json.dump(out_nc, f)
+print('noncontextual:', len(out_nc), 'cases')

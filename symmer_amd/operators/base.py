@@ -15,7 +15,7 @@ import numpy as np
 
 from .. import kernels, packing
 from .utils import (string_to_symplectic, symplectic_to_string, random_symplectic_matrix, check_independent,
-                    cref_binary, _rref_binary)
+                    cref_binary, _rref_binary, check_adjmat_noncontextual)
 
 warnings.simplefilter('always', UserWarning)
 
@@ -264,6 +264,13 @@ class PauliwordOp:
     @cached_property
     def adjacency_matrix(self) -> np.ndarray:
         return self.commutes_termwise(self)
+
+    @cached_property
+    def is_noncontextual(self) -> bool:
+        """base.py:1074-1088: O(M^2) test on the adjacency matrix (computed on the device)."""
+        if self.n_terms < 4:
+            return True
+        return check_adjmat_noncontextual(self.adjacency_matrix)
 
     def commutator(self, PwordOp: "PauliwordOp") -> "PauliwordOp":
         return self * PwordOp - PwordOp * self

@@ -1,10 +1,12 @@
-"""``IndependentOp`` — drop-in for the reference class on the hot path
-(``symmer/operators/independent_op.py:9-159``): algebraically independent +/-1 stabiliser sets and the
-symmetry-generator kernel, with the GF(2) elimination on the MI355X (``csrc/gf2.hip``).
-Out of scope: stabiliser rotations, sector assignment, clique selection (networkx) — SURVEY.md §2 #4.
+"""``IndependentOp`` — drop-in for the reference class (``symmer/operators/independent_op.py:9-383``): algebraically
+independent +/-1 stabiliser sets, the symmetry-generator kernel with the GF(2) elimination on the MI355X
+(``csrc/gf2.hip``), and — SURVEY.md §8f row f4 — the Clifford rotations onto single-qubit Paulis and the sector
+assignment that the tapering workflow needs (host control flow over the device kernels).
+Out of scope: clique selection for non-commuting generators (networkx) and ``QuantumState`` reference states.
 """
 import warnings
-from typing import Dict, List, Union
+from functools import reduce
+from typing import Dict, List, Tuple, Union
 import numpy as np
 from .. import kernels, packing
 from .base import PauliwordOp
@@ -71,10 +73,94 @@ class IndependentOp(PauliwordOp):
             raise ValueError('The supplied stabilizers are not independent')
 
     def __str__(self) -> str:
-        if self.n_terms == 0:
-            return ''
-        return super().__str__()
+        from .utils import symplectic_to_string
+        out_string = ''
+        for pauli_vec, coeff in zip(self.symp_matrix, self.coeff_vec):
+            out_string += f'{coeff} {symplectic_to_string(pauli_vec)} \n'
+        return out_string[:-2]
+
+    def __repr__(self) -> str:
+        return str(self)
+
+    def __add__(self, Pword: "IndependentOp") -> "IndependentOp":
+        return self.from_PauliwordOp(super().__add__(Pword))
+
+    def _rotate_by_single_Pword(self, Pword: PauliwordOp, angle: float = None) -> "IndependentOp":
+        return self.from_PauliwordOp(super()._rotate_by_single_Pword(Pword, angle))
+
+    def perform_rotations(self, rotations: List[Tuple[PauliwordOp, float]]) -> "IndependentOp":
+        return self.from_PauliwordOp(super().perform_rotations(rotations))
+
+    # ---- f4: rotation onto single-qubit Paulis (independent_op.py:204-273) --------------------------------------
+    def _recursive_rotations(self, basis: "IndependentOp") -> None:
+        """independent_op.py:204-241: repeatedly pick the lowest-weight non-single-qubit stabiliser, its least-supported
+        qubit, and the pi/2 rotation that maps it onto that qubit; every rotation is one device pass."""
+        non_sqp = np.where(np.sum(basis.symp_matrix, axis=1) != 1)
+        basis_non_sqp = IndependentOp(basis.symp_matrix[non_sqp], basis.coeff_vec[non_sqp])
+        # the reference takes them from (basis - basis_non_sqp), i.e. after a cleanup: zero-coefficient terms drop out
+        sqp_rows = basis.symp_matrix[(np.sum(basis.symp_matrix, axis=1) == 1) & (np.abs(basis.coeff_vec) > 1e-15)]
+        sqp_indices = np.where(sqp_rows)[1] % self.n_qubits
+        self.used_indices += np.append(sqp_indices, sqp_indices + self.n_qubits).tolist()
+        if basis_non_sqp.n_terms == 0:
+            return None
+        row_sum = np.sum(basis_non_sqp.symp_matrix, axis=1)
+        pivot_row = basis_non_sqp.symp_matrix[np.argsort(row_sum)][0]
+        non_I = np.setdiff1d(np.where(pivot_row)[0], np.array(self.used_indices))
+        col_sum = np.sum(basis_non_sqp.symp_matrix, axis=0)
+        support = pivot_row * col_sum
+        pivot_point = non_I[np.argmin(support[non_I])]
+        target = np.zeros(2 * self.n_qubits, dtype=int)
+        target[pivot_point + self.n_qubits * (-1) ** (pivot_point // self.n_qubits)] = 1
+        pivot_rotation = PauliwordOp(np.bitwise_xor(target, pivot_row.astype(int)), [1])
+        self.stabilizer_rotations.append((pivot_rotation, None))
+        rotated_basis = basis_non_sqp._rotate_by_single_Pword(pivot_rotation)
+        return self._recursive_rotations(rotated_basis)
+
+    def generate_stabilizer_rotations(self) -> None:
+        """independent_op.py:243-273."""
+        assert self.n_terms <= self.n_qubits, 'Too many terms in basis to reduce to single-qubit Paulis'
+        assert np.all(self.adjacency_matrix), 'The basis is not commuting, hence the rotation is not possible'
+        self.stabilizer_rotations = []
+        self.used_indices = []
+        basis = self.copy()
+        self._recursive_rotations(basis)
+        rotated_basis = basis.perform_rotations(self.stabilizer_rotations)
+        for P in rotated_basis:
+            sqp_index = np.where(P.symp_matrix[0])[0][0] % self.n_qubits
+            target = np.zeros(2 * self.n_qubits, dtype=int)
+            if self.target_sqp in ['X', 'Y']:
+                target[sqp_index] = 1
+            if self.target_sqp in ['Y', 'Z']:
+                target[sqp_index + self.n_qubits] = 1
+            R_symp = np.bitwise_xor(target, P.symp_matrix[0].astype(int))
+            if np.any(R_symp):
+                self.stabilizer_rotations.append((PauliwordOp(R_symp, [1]), None))
+
+    def update_sector(self, ref_state: Union[List[int], np.ndarray], threshold: float = 0.5) -> None:
+        """independent_op.py:275-301 for a computational-basis reference state given as a bit array: the expectation
+        value of a stabiliser is (-1)^{|z & b|} if it is diagonal (no X/Y) and 0 otherwise (then the assignment is 0,
+        with the reference's warning).  ``QuantumState`` superpositions are outside the accelerated path."""
+        b = np.asarray(ref_state).reshape(-1)
+        assert b.shape[0] == self.n_qubits and set(np.unique(b)).issubset({0, 1}), 'reference state must be a bit array over all qubits'
+        diagonal = ~np.any(self.X_block, axis=1)
+        signs = (-1) ** np.sum(np.bitwise_and(self.Z_block, b.astype(bool)), axis=1)
+        self.coeff_vec = np.where(diagonal, signs, 0).astype(int)
+        if np.any(self.coeff_vec == 0):
+            from .utils import symplectic_to_string
+            S_zero = [symplectic_to_string(r) for r in self.symp_matrix[self.coeff_vec == 0]]
+            warnings.warn(f'The stabilizers {S_zero} were assigned zero values - bad reference state.')
+
+    def rotate_onto_single_qubit_paulis(self) -> "IndependentOp":
+        """independent_op.py:303-319."""
+        self.generate_stabilizer_rotations()
+        if self.stabilizer_rotations != []:
+            return IndependentOp.from_PauliwordOp(
+                reduce(lambda x, y: x.append(y), [s.perform_rotations(self.stabilizer_rotations) for s in self]))
+        return self
 
     def __getitem__(self, key) -> "IndependentOp":
-        P = super().__getitem__(key)
-        return IndependentOp(P.symp_matrix, P.coeff_vec, target_sqp=self.target_sqp)
+        P = PauliwordOp.__getitem__(self, key)
+        return IndependentOp(P.symp_matrix, P.coeff_vec)
+
+    def __iter__(self):
+        return iter([self[i] for i in range(self.n_terms)])

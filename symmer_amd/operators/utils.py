@@ -109,3 +109,13 @@ def check_independent(operators) -> bool:
         return True
     red = _rref_binary(operators.symp_matrix)
     return bool(~np.any(np.all(~red, axis=1)))
+
+
+# ---- f4: noncontextuality test on the device-computed adjacency matrix (reference utils.py:567-589) --------------
+def check_adjmat_noncontextual(adjmat) -> bool:
+    """Terms that do not commute universally must split into cliques: the unique rows of the masked adjacency matrix
+    have to be disjoint (https://doi.org/10.1103/PhysRevLett.123.200501)."""
+    adjmat = np.asarray(adjmat, dtype=bool)
+    mask_non_universal = np.where(~np.all(adjmat, axis=1))[0]
+    unique_character = np.unique(adjmat[mask_non_universal, :][:, mask_non_universal], axis=0)
+    return bool(np.all(np.count_nonzero(unique_character, axis=0) == 1))
