@@ -269,3 +269,32 @@ for trial in range(20):
 with open(os.path.join(OUT, 'known_noncontextual.json'), 'w') as f:
     json.dump(out_nc, f)
 print('noncontextual:', len(out_nc), 'cases')
+
+
+# ---------------------------------------------------------------- circuit --------
+from symmer.evolution.circuit_symmerlator import CircuitSymmerlator
+fam = Family('circuit')
+G1 = ['x', 'y', 'z', 'h', 's', 'sdg', 'sx', 'sy', 'sz']; G2 = ['cx', 'cy', 'cz', 'swap']; GR = ['rx', 'ry', 'rz']
+for trial in range(12):
+    n = int((2, 3, 5, 8, 20, 70)[trial % 6]); depth = int(rng.integers(5, 60))
+    cs = CircuitSymmerlator(n)
+    names, qa, qb, ang = [], [], [], []
+    for d in range(depth):
+        r = rng.random()
+        if r < 0.55 or n < 2:
+            g = G1[int(rng.integers(len(G1)))]; a = int(rng.integers(n)); cs.gate_map[g](a); names.append(g); qa.append(a); qb.append(-1); ang.append(0.0)
+        elif r < 0.9:
+            g = G2[int(rng.integers(len(G2)))]; a, b = (int(v) for v in rng.choice(n, 2, replace=False)); cs.gate_map[g](a, b)
+            names.append(g); qa.append(a); qb.append(b); ang.append(0.0)
+        elif trial % 2 == 0:
+            g = GR[int(rng.integers(len(GR)))]; a = int(rng.integers(n)); t = float(rng.normal()); cs.gate_map[g](a, t)
+            names.append(g); qa.append(a); qb.append(-1); ang.append(t)
+    O = PauliwordOp(rand_symp(n, int(rng.integers(1, 30))), dyadic(1)[0] * np.ones(1) if False else dyadic(1)).cleanup() if False else None
+    t_op = int(rng.integers(1, 30))
+    O = PauliwordOp(rand_symp(n, t_op, 0.4), dyadic(t_op)).cleanup()
+    if O.n_terms == 0:
+        continue
+    R = cs.apply_sequence(O)
+    fam.add(n=n, gates=np.array(names), qa=np.array(qa), qb=np.array(qb), angle=np.array(ang), **op_arrays(O, 'in'), **op_arrays(R, 'out'),
+            expval=np.array(complex(cs.evaluate(O))))
+fam.save()

@@ -272,6 +272,68 @@ class PauliwordOp:
             return True
         return check_adjmat_noncontextual(self.adjacency_matrix)
 
+    # ---- graph glue on the device-computed adjacency matrix (reference base.py:985-1364; networkx, host) ------------
+    def qubitwise_commutes_termwise(self, PwordOp: "PauliwordOp") -> np.ndarray:
+        """base.py:985-1009: True where terms commute qubit by qubit (host NumPy; not a hot-path kernel)."""
+        assert self.n_qubits == PwordOp.n_qubits, 'Pauliwords defined for different number of qubits'
+        xa, za = self.X_block[:, None, :], self.Z_block[:, None, :]
+        xb, zb = PwordOp.X_block[None, :, :], PwordOp.Z_block[None, :, :]
+        both = (xa | za) & (xb | zb)
+        return np.all(~both | ((xa == xb) & (za == zb)), axis=2)
+
+    @cached_property
+    def adjacency_matrix_qwc(self) -> np.ndarray:
+        return self.qubitwise_commutes_termwise(self)
+
+    def get_graph(self, edge_relation: str = 'C', label_nodes: bool = False):
+        import networkx as nx
+        if edge_relation == 'AC':
+            adjmat = ~self.adjacency_matrix.copy()
+        elif edge_relation == 'C':
+            adjmat = self.adjacency_matrix.copy()
+        elif edge_relation == 'QWC':
+            adjmat = self.adjacency_matrix_qwc.copy()
+        else:
+            raise TypeError('Unrecognised edge relation, must be one of C (commuting), AC (anticommuting) or QWC (qubitwise commuting).')
+        np.fill_diagonal(adjmat, False)
+        graph = nx.from_numpy_array(adjmat)
+        if label_nodes:
+            nodes = [symplectic_to_string(r) for r in self.symp_matrix]
+            graph = nx.relabel_nodes(graph, dict(zip(range(len(nodes)), nodes)))
+        return graph
+
+    def largest_clique(self, edge_relation: str = 'C') -> "PauliwordOp":
+        import networkx as nx
+        graph = self.get_graph(edge_relation=edge_relation)
+        pauli_indices = sorted(nx.find_cliques(graph), key=lambda x: -len(x))[0]
+        return sum([self[i] for i in pauli_indices])
+
+    def clique_cover(self, edge_relation: str = 'C', strategy: str = 'largest_first', colouring_interchange: bool = False
+                     ) -> Dict[int, "PauliwordOp"]:
+        """base.py:1266-1364: clique partition by greedy colouring of the complement graph, or 'sorted_insertion'."""
+        if strategy == 'sorted_insertion':
+            if colouring_interchange is not False:
+                warnings.warn(f'{strategy} is not a graph colouring method, so colouring_interchange flag is ignored')
+            ops = list(self.sort(by='magnitude', key='decreasing'))
+            check = {'C': lambda x, y: np.all(x.commutes_termwise(y)), 'AC': lambda x, y: np.all(~x.commutes_termwise(y)),
+                     'QWC': lambda x, y: np.all(x.qubitwise_commutes_termwise(y))}[edge_relation]
+            cliques = {0: ops[0]}
+            for op in ops[1:]:
+                for key in cliques:
+                    if check(op, cliques[key]):
+                        cliques[key] += op
+                        break
+                else:
+                    cliques[len(cliques)] = op
+            return cliques
+        import networkx as nx
+        graph = self.get_graph(edge_relation=edge_relation)
+        col_map = nx.greedy_color(nx.complement(graph), strategy=strategy, interchange=colouring_interchange)
+        cliques = {}
+        for p_index, colour in col_map.items():
+            cliques[colour] = cliques.get(colour, PauliwordOp.from_list(['I' * self.n_qubits], [0])) + self[p_index]
+        return cliques
+
     def commutator(self, PwordOp: "PauliwordOp") -> "PauliwordOp":
         return self * PwordOp - PwordOp * self
 

@@ -59,10 +59,14 @@ class IndependentOp(PauliwordOp):
             return S
         if commuting_override or np.all(S.adjacency_matrix):
             return S
-        # The reference now picks a commuting subset with networkx clique routines (independent_op.py:132-144),
-        # which are graph glue outside the accelerated path.
-        raise NotImplementedError('non-commuting symmetry generators: clique selection is outside the hot path; '
-                                  'pass commuting_override=True to obtain the full generating set')
+        # non-commuting generators: take a commuting subset (independent_op.py:132-144; networkx graph glue on the
+        # device-computed adjacency matrix)
+        if S.n_terms < 10 or largest_clique:
+            S_commuting = S.largest_clique(edge_relation='C')
+        else:
+            S_commuting = S.clique_cover(edge_relation='C', strategy='independent_set')[0]
+            warnings.warn('Greedy method may identify non-optimal commuting symmetry terms; might be able to taper again.')
+        return cls(S_commuting.symp_matrix, np.ones(S_commuting.n_terms, dtype=complex))
 
     def _check_stab(self) -> None:
         if not set(self.coeff_vec).issubset({0, +1, -1}):

@@ -154,7 +154,12 @@ def test_independent_op_known():
     with pytest.warns(UserWarning):
         assert IndependentOp.symmetry_generators(PauliwordOp.from_list(['X', 'Y', 'Z'])).n_terms == 0   # :50-53
     op = PauliwordOp.from_list(['IZZ', 'ZZI', 'IXX', 'XXI', 'IYY', 'YYI'])
-    assert IndependentOp.symmetry_generators(op, commuting_override=True) == IndependentOp.from_list(['XXX', 'ZZZ'])  # :56-66
+    with_override = IndependentOp.symmetry_generators(op, commuting_override=True)
+    without = IndependentOp.symmetry_generators(op, commuting_override=False)                 # :56-66
+    assert with_override == IndependentOp.from_list(['XXX', 'ZZZ']) and with_override != without
+    assert without in [IndependentOp.from_list(['XXX']), IndependentOp.from_list(['ZZZ'])]
+    with pytest.warns():
+        IndependentOp.symmetry_generators(PauliwordOp.from_list(['Z' * 20]))               # :68-71 (greedy clique cover)
     with pytest.raises(ValueError):
         IndependentOp.from_list(['X', 'Y', 'Z'])                                           # :73-75
     with pytest.raises(ValueError):
@@ -381,3 +386,23 @@ def test_independent_op_rotations_and_sector():
         X = IndependentOp.from_list(['XX', 'ZZ'])
         X.update_sector([0, 0])
     assert X.coeff_vec.tolist() == [0, 1]
+
+
+@pytest.mark.parametrize('case', family('circuit'))
+def test_circuit_symmerlator_golden(case):
+    """random Clifford(+rotation) circuits through CircuitSymmerlator, rotated observable and <0|..|0>
+    expectation value equal to the reference's (generated by oracle/tools/gen_golden.py)."""
+    from symmer_amd.evolution import CircuitSymmerlator
+    cs = CircuitSymmerlator(int(case['n']))
+    for g, a, b, t in zip(case['gates'], case['qa'], case['qb'], case['angle']):
+        g = str(g)
+        if g in ('rx', 'ry', 'rz'):
+            cs.gate_map[g](int(a), float(t))
+        elif int(b) >= 0:
+            cs.gate_map[g](int(a), int(b))
+        else:
+            cs.gate_map[g](int(a))
+    O = PauliwordOp(as_bool(case['in_symp']), case['in_coeff'])
+    R = cs.apply_sequence(O)
+    assert_op_equal(R.symp_matrix, R.coeff_vec, case['out_symp'], case['out_coeff'], exact=False, tol=TOL)
+    assert abs(complex(cs.evaluate(O)) - complex(case['expval'])) < 1e-10
