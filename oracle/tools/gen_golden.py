@@ -298,3 +298,20 @@ for trial in range(12):
     fam.add(n=n, gates=np.array(names), qa=np.array(qa), qb=np.array(qb), angle=np.array(ang), **op_arrays(O, 'in'), **op_arrays(R, 'out'),
             expval=np.array(complex(cs.evaluate(O))))
 fam.save()
+
+
+# ---------------------------------------------------------------- state --------
+from symmer.operators import QuantumState
+from symmer.operators.base import single_term_expval
+fam = Family('state')
+np.random.seed(4321)
+for n, t_op, t_psi in ((1, 2, 2), (3, 6, 4), (5, 40, 12), (8, 30, 60), (20, 50, 30), (70, 25, 15), (70, 8, 40)):
+    P = PauliwordOp(rand_symp(n, t_op, 0.4), dyadic(t_op)).cleanup()
+    psi = QuantumState.random(n, t_psi); phi = QuantumState.random(n, t_psi + 3)
+    out = P * psi
+    bra = psi.dagger * P
+    fam.add(n=n, **op_arrays(P, 'p'), psi_m=psi.state_matrix, psi_c=psi.state_op.coeff_vec, phi_m=phi.state_matrix, phi_c=phi.state_op.coeff_vec,
+            out_m=out.state_matrix, out_c=out.state_op.coeff_vec, bra_m=bra.state_matrix, bra_c=bra.state_op.coeff_vec,
+            inner=np.array(complex(psi.dagger * phi)), expval=np.array(complex(P.expval(psi))),
+            term_expvals=np.array([single_term_expval(Pk, psi) for Pk in P]))
+fam.save()

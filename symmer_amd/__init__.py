@@ -5,6 +5,6 @@ functions in ``symmer_amd.operators``.  All data-parallel work runs in hand-writ
 (``symmer_amd/csrc``) behind the C ABI of ``include/symgpu.h``; there is no CPU fallback.
 """
 from ._lib import SymgpuError
-from .operators import PauliwordOp, IndependentOp
+from .operators import PauliwordOp, IndependentOp, QuantumState
 
-__all__ = ['PauliwordOp', 'IndependentOp', 'SymgpuError']
+__all__ = ['PauliwordOp', 'IndependentOp', 'QuantumState', 'SymgpuError']

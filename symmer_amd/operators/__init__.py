@@ -3,3 +3,4 @@ from .utils import (symplectic_cleanup, matmul_GF2, mul_symplectic, _rref_binary
                     random_symplectic_matrix, check_adjmat_noncontextual)
 from .base import PauliwordOp
 from .independent_op import IndependentOp
+from .quantum_state import QuantumState, single_term_expval

@@ -205,13 +205,33 @@ class PauliwordOp:
         ``(B^+ A^+)^+`` (base.py:847-849), which equals the direct phase with the roles swapped."""
         if isinstance(mul_obj, Number):
             return self.multiply_by_constant(mul_obj)
-        assert isinstance(mul_obj, PauliwordOp), f'cannot multiply PauliwordOp by {type(mul_obj)} (QuantumState is out of scope)'
-        assert self.n_qubits == mul_obj.n_qubits, 'PauliwordOps defined for different number of qubits'
-        if self.n_terms < mul_obj.n_terms:
-            rows, coeff = kernels.mul_cleanup(mul_obj.packed, mul_obj.coeff_vec, self.packed, self.coeff_vec, False, zero_threshold)
+        from .quantum_state import QuantumState
+        is_state = isinstance(mul_obj, QuantumState)
+        if is_state:
+            # applying an operator to a ket == multiplying by its state_op (|0> -> Z, |1> -> X), base.py:838-842
+            assert mul_obj.vec_type == 'ket', 'cannot multiply a bra from the left'
+            other = mul_obj.state_op
         else:
-            rows, coeff = kernels.mul_cleanup(self.packed, self.coeff_vec, mul_obj.packed, mul_obj.coeff_vec, True, zero_threshold)
-        return PauliwordOp._from_packed(rows, self.n_qubits, coeff)
+            other = mul_obj
+        assert isinstance(other, PauliwordOp), f'cannot multiply PauliwordOp by {type(mul_obj)}'
+        assert self.n_qubits == other.n_qubits, 'PauliwordOps defined for different number of qubits'
+        if self.n_terms < other.n_terms:
+            rows, coeff = kernels.mul_cleanup(other.packed, other.coeff_vec, self.packed, self.coeff_vec, False, zero_threshold)
+        else:
+            rows, coeff = kernels.mul_cleanup(self.packed, self.coeff_vec, other.packed, other.coeff_vec, True, zero_threshold)
+        out = PauliwordOp._from_packed(rows, self.n_qubits, coeff)
+        if is_state:
+            # identities were mapped to Z: II == ZZ as states, so fold i^Y into the coefficients and merge again (base.py:854-857)
+            return QuantumState(out.X_block.astype(int), out.coeff_vec * (1j ** out.Y_count)).cleanup()
+        return out
+
+    def expval(self, psi) -> complex:
+        """base.py:796-819: <psi|H|psi>; many-term operators use one bra x op x ket product, otherwise term by term."""
+        from .quantum_state import single_term_expval
+        if self.n_terms > psi.n_terms and psi.n_terms > 10:
+            return (psi.dagger * self * psi).real
+        expvals = np.array([single_term_expval(P, psi) for P in self]) if self.n_terms > 1 else np.array(single_term_expval(self, psi))
+        return np.sum(expvals * self.coeff_vec).real
 
     def __rmul__(self, const):
         if isinstance(const, Number):

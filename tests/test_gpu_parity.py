@@ -406,3 +406,23 @@ def test_circuit_symmerlator_golden(case):
     R = cs.apply_sequence(O)
     assert_op_equal(R.symp_matrix, R.coeff_vec, case['out_symp'], case['out_coeff'], exact=False, tol=TOL)
     assert abs(complex(cs.evaluate(O)) - complex(case['expval'])) < 1e-10
+
+
+@pytest.mark.parametrize('case', family('state'))
+def test_quantum_state_golden(case):
+    """operator x ket, bra x operator, inner products and expectation values against the reference."""
+    from symmer_amd import QuantumState
+    from symmer_amd.operators import single_term_expval
+    P = PauliwordOp(as_bool(case['p_symp']), case['p_coeff'])
+    psi = QuantumState(case['psi_m'], case['psi_c']); phi = QuantumState(case['phi_m'], case['phi_c'])
+    assert psi._is_normalized()
+    out = P * psi
+    assert np.array_equal(out.state_matrix, case['out_m']) and np.allclose(out.state_op.coeff_vec, case['out_c'], rtol=0, atol=TOL)
+    bra = psi.dagger * P
+    assert bra.vec_type == 'bra'
+    assert np.array_equal(bra.state_matrix, case['bra_m']) and np.allclose(bra.state_op.coeff_vec, case['bra_c'], rtol=0, atol=TOL)
+    assert abs(complex(psi.dagger * phi) - complex(case['inner'])) < 1e-12
+    assert abs(P.expval(psi) - complex(case['expval']).real) < 1e-10
+    got = np.array([single_term_expval(Pk, psi) for Pk in P])
+    assert np.allclose(got, case['term_expvals'], rtol=0, atol=1e-10)
+    assert psi + psi == psi * 2 and (psi - psi).n_terms == 0
