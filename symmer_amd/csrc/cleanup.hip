@@ -186,62 +186,69 @@ __global__ __launch_bounds__(256) void k_heads(const u64 *__restrict__ keys, con
 // run holds more than one distinct key it is re-ordered here by (full key, input order) with a stable insertion sort.
 // Runs longer than FIX_MAX that are not uniform raise `fallback`: the caller then redoes a full 64-bit sort.
 constexpr int FIX_MAX = 48;
-__global__ void k_fixup_runs(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 T, int shift, u32 *__restrict__ fallback) {
+// phase 1 (read-only): a position whose key differs from its predecessor's INSIDE a prefix run marks the run's start
+__global__ void k_fixup_mark(const u64 *__restrict__ keys, i64 T, int shift, u32 *__restrict__ need) {
     for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
-        const u64 k0 = keys[s];
-        if (s > 0 && (keys[s - 1] >> shift) == (k0 >> shift)) continue;      // not a run start
-        i64 e = s + 1;
-        bool uniform = true;
-        while (e < T) {
-            const u64 k = keys[e];
-            if ((k >> shift) != (k0 >> shift)) break;
-            uniform &= (k == k0);
-            ++e;
-        }
-        if (uniform) continue;
-        const i64 len = e - s;
-        if (len > FIX_MAX) { atomicOr(fallback, 1u); continue; }
-        for (i64 a = s + 1; a < e; ++a) {                                     // stable insertion sort by full key
+        if (s == 0) continue;
+        const u64 k = keys[s], kp = keys[s - 1];
+        if ((k >> shift) != (kp >> shift) || k == kp) continue;
+        i64 b = s - 1;
+        while (b > 0 && (keys[b - 1] >> shift) == (kp >> shift)) --b;
+        need[b] = 1u;
+    }
+}
+// phase 2: the marked run starts (one thread per mixed run) sort their run
+__global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 T, int shift, const u32 *__restrict__ need, u32 *__restrict__ fallback) {
+    for (i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x; b < T; b += (i64)gridDim.x * blockDim.x) {
+        if (!need[b]) continue;
+        const u64 pfx = keys[b] >> shift;
+        i64 e = b + 1;
+        while (e < T && (keys[e] >> shift) == pfx) ++e;
+        if (e - b > FIX_MAX) { atomicOr(fallback, 1u); continue; }
+        for (i64 a = b + 1; a < e; ++a) {                                     // stable insertion sort by full key
             const u64 ka = keys[a];
             const u32 ia = idx[a];
-            i64 b = a - 1;
-            while (b >= s && keys[b] > ka) { keys[b + 1] = keys[b]; idx[b + 1] = idx[b]; --b; }
-            keys[b + 1] = ka;
-            idx[b + 1] = ia;
+            i64 c = a - 1;
+            while (c >= b && keys[c] > ka) { keys[c + 1] = keys[c]; idx[c + 1] = idx[c]; --c; }
+            keys[c + 1] = ka;
+            idx[c + 1] = ia;
         }
     }
 }
 
-// one thread per segment: sequential sum in ascending input order (the sort is stable), threshold, mark.
-// cg holds the coefficients already gathered into sorted order (k_heads): the reads are sequential.
-__global__ void k_segsum(const u32 *__restrict__ idx, const u32 *__restrict__ seg_start, i64 U, i64 T, const double *__restrict__ cg,
-                         double thr, int use_thr, double *__restrict__ seg_sum, u32 *__restrict__ seg_first, u32 *__restrict__ mark) {
-    for (i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (i64)gridDim.x * blockDim.x) {
-        const i64 b = seg_start[u], e = (u + 1 < U) ? (i64)seg_start[u + 1] : T;
-        double re = 0.0, im = 0.0;
-        for (i64 s = b; s < e; ++s) {
-            const double2 c = reinterpret_cast<const double2 *>(cg)[s];
+// Segment sums without segment ids: the thread at a head position walks its segment (the following non-head positions),
+// summing SEQUENTIALLY in ascending input order (the sort is stable) — exactly np.add.at's order (utils.py:273-274).
+// The sum replaces cg[s] at the head; heads[s] becomes 2 if the term survives the strict |c| > thr test (1 otherwise) and
+// the first-occurrence index of a surviving term is marked for the output-order scan.
+__global__ void k_segsum_heads(u32 *__restrict__ heads, const u32 *__restrict__ idx, i64 T, double *__restrict__ cg, double thr, int use_thr,
+                               u32 *__restrict__ mark) {
+    for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
+        if (heads[s] == 0u) continue;
+        double2 c = reinterpret_cast<const double2 *>(cg)[s];
+        double re = __dadd_rn(0.0, c.x), im = __dadd_rn(0.0, c.y);
+        for (i64 e = s + 1; e < T && heads[e] == 0u; ++e) {
+            c = reinterpret_cast<const double2 *>(cg)[e];
             re = __dadd_rn(re, c.x);
             im = __dadd_rn(im, c.y);
         }
-        const u32 first = idx[b];
         const bool keep = use_thr ? (hypot(re, im) > thr) : true;
-        seg_sum[2 * u] = re;
-        seg_sum[2 * u + 1] = im;
-        seg_first[u] = keep ? first : 0xffffffffu;
-        if (keep) mark[first] = 1u;
+        if (keep) {
+            double2 o; o.x = re; o.y = im;
+            reinterpret_cast<double2 *>(cg)[s] = o;
+            heads[s] = 2u;
+            mark[idx[s]] = 1u;
+        }
     }
 }
 
-// out position of a kept segment = exclusive scan of mark at its first index
-__global__ void k_emit(const u32 *__restrict__ seg_first, const double *__restrict__ seg_sum, i64 U, const u32 *__restrict__ outpos,
-                       double *__restrict__ out_coeff, u32 *__restrict__ out_src) {
-    for (i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (i64)gridDim.x * blockDim.x) {
-        const u32 first = seg_first[u];
-        if (first == 0xffffffffu) continue;
+// out position of a kept segment = exclusive scan of mark at its first index (= idx at the head: the sort is stable)
+__global__ void k_emit_heads(const u32 *__restrict__ heads, const u32 *__restrict__ idx, i64 T, const double *__restrict__ cg,
+                             const u32 *__restrict__ outpos, double *__restrict__ out_coeff, u32 *__restrict__ out_src) {
+    for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
+        if (heads[s] != 2u) continue;
+        const u32 first = idx[s];
         const u32 p = outpos[first];
-        out_coeff[2 * (i64)p] = seg_sum[2 * u];
-        out_coeff[2 * (i64)p + 1] = seg_sum[2 * u + 1];
+        reinterpret_cast<double2 *>(out_coeff)[p] = reinterpret_cast<const double2 *>(cg)[s];
         out_src[p] = first;
     }
 }
@@ -290,22 +297,10 @@ int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
     return SYMGPU_OK;
 }
 
-// head(s) <=> scan[s+1] == scan[s] + 1  (scan = exclusive scan of the 0/1 head flags; scan[T] := U)
-__global__ void k_seg_starts2(const u32 *__restrict__ scan, i64 T, u32 U, u32 *__restrict__ seg_start) {
-    for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
-        const u32 cur = scan[s];
-        const u32 nxt = (s + 1 < T) ? scan[s + 1] : U;
-        if (nxt == cur + 1) seg_start[cur] = (u32)s;
-    }
-}
-
-int cleanup_finish(const u32 *scan, const u32 *is, i64 T, i64 U, const double *coeff, double thr, int use_thr, u32 *seg_start,
-                   double *seg_sum, u32 *seg_first, u32 *mark, bool pair, const u64 *rows, int W, const u64 *inner, i64 Ni,
-                   const u64 *outer, symgpu_op_t *out, int Wq_out) {
+int cleanup_finish(u32 *heads, const u32 *is, i64 T, double *cg, double thr, int use_thr, u32 *mark, bool pair, const u64 *rows, int W,
+                   const u64 *inner, i64 Ni, const u64 *outer, symgpu_op_t *out, int Wq_out) {
     hipStream_t st = ctx().stream;
-    hipLaunchKernelGGL(k_seg_starts2, dim3(grid_for(T)), dim3(256), 0, st, scan, T, (u32)U, seg_start);
-    KERNEL_CHECK();
-    hipLaunchKernelGGL(k_segsum, dim3(grid_for(U)), dim3(256), 0, st, is, seg_start, U, T, coeff, thr, use_thr, seg_sum, seg_first, mark);
+    hipLaunchKernelGGL(k_segsum_heads, dim3(grid_for(T)), dim3(256), 0, st, heads, is, T, cg, thr, use_thr, mark);
     KERNEL_CHECK();
     Scratch total;
     SG_TRY(total.alloc(16));
@@ -321,7 +316,7 @@ int cleanup_finish(const u32 *scan, const u32 *is, i64 T, i64 U, const double *c
         Scratch src;
         int rc = src.alloc((size_t)n_out * 4);
         if (rc != SYMGPU_OK) { symgpu_op_free(res); return rc; }
-        hipLaunchKernelGGL(k_emit, dim3(grid_for(U)), dim3(256), 0, st, seg_first, seg_sum, U, mark, res->coeff, src.as<u32>());
+        hipLaunchKernelGGL(k_emit_heads, dim3(grid_for(T)), dim3(256), 0, st, heads, is, T, cg, mark, res->coeff, src.as<u32>());
         const int Wq = W / 2;
         if (pair)
             hipLaunchKernelGGL(k_gather_rows<true>, dim3(grid_for(n_out * Wq)), dim3(256), 0, st, src.as<u32>(), n_out, Wq,
@@ -368,7 +363,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
     u32 *is = nullptr;
     u64 seed = ctx().hash_tab ? ctx().hash_seed : 1;
     bool ok = false;
-    // number of (top) key bits the radix sort orders; the rest is handled by k_fixup_runs
+    // number of (top) key bits the radix sort orders; the rest is handled by k_fixup_mark / k_fixup_sort
     int nb = 64;
     {
         int lg = 0;
@@ -397,7 +392,10 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         is = in_tmp ? idx2.as<u32>() : idx.as<u32>();
         HIP_TRY(hipMemsetAsync(collision.p, 0, 16, st));
         if (nb < 64) {
-            hipLaunchKernelGGL(k_fixup_runs, dim3(grid_for(T)), dim3(256), 0, st, ks, is, T, 64 - nb, collision.as<u32>() + 1);
+            // `heads` doubles as the run-start marker array here (it is overwritten by k_heads afterwards)
+            HIP_TRY(hipMemsetAsync(heads.p, 0, (size_t)T * 4, st));
+            hipLaunchKernelGGL(k_fixup_mark, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nb, heads.as<u32>());
+            hipLaunchKernelGGL(k_fixup_sort, dim3(grid_for(T)), dim3(256), 0, st, ks, is, T, 64 - nb, heads.as<u32>(), collision.as<u32>() + 1);
             KERNEL_CHECK();
         }
         {
@@ -424,23 +422,10 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         set_error("cleanup: 64-bit row-hash collision survived 4 reseeds");
         return SYMGPU_E_COLLISION;
     }
-    // segment ids
-    Scratch total;
-    SG_TRY(total.alloc(16));
-    SG_TRY(exclusive_scan_u32(heads.as<u32>(), heads.as<u32>(), T, total.as<u32>()));
-    // heads[] now holds the exclusive scan of the 0/1 head flags; a position s is a head iff scan[s+1] == scan[s]+1
-    u32 U32 = 0;
-    HIP_TRY(hipMemcpyAsync(&U32, total.p, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const i64 U = U32;
-    Scratch seg_start, seg_sum, seg_first, mark;
-    SG_TRY(seg_start.alloc((size_t)(U + 1) * 4));
-    SG_TRY(seg_sum.alloc((size_t)U * 16));
-    SG_TRY(seg_first.alloc((size_t)U * 4));
+    Scratch mark;
     SG_TRY(mark.alloc((size_t)T * 4));
     HIP_TRY(hipMemsetAsync(mark.p, 0, (size_t)T * 4, st));
-    return cleanup_finish(heads.as<u32>(), is, T, U, cg.as<double>(), thr, use_thr, seg_start.as<u32>(), seg_sum.as<double>(),
-                          seg_first.as<u32>(), mark.as<u32>(), pair, rows, W, inner, Ni, outer, out, Wq_out);
+    return cleanup_finish(heads.as<u32>(), is, T, cg.as<double>(), thr, use_thr, mark.as<u32>(), pair, rows, W, inner, Ni, outer, out, Wq_out);
 }
 
 }  // namespace symgpu
