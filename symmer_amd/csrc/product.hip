@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_mul_rows(const u32x4 *__restrict__ inne
 }
 
 // tuning knobs (defaults are the measured best on MI355X; SYMGPU_ROWS_VARIANT="rc,rto,nt" overrides for experiments)
-struct RowsVariant { int rc = 1, rto = 32, nt = 1; bool parsed = false; };
+struct RowsVariant { int rc = 1, rto = 12, nt = 1; bool parsed = false; };
 static RowsVariant g_rv;
 static const RowsVariant &rows_variant() {
     if (!g_rv.parsed) {
