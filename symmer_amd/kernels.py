@@ -146,20 +146,45 @@ def cleanup(rows, coeff, zero_threshold=1e-15):
         op.free()
 
 
-def mul_cleanup(inner, ci, outer, co, inner_is_left=True, zero_threshold=1e-15):
-    """Fused product + cleanup; the product rows are never materialised."""
+MAX_PAIRS_PER_CALL = 1 << 31      # one device call sorts 32-bit pair indices; larger products are tiled over the outer operand
+
+
+def mul_cleanup(inner, ci, outer, co, inner_is_left=True, zero_threshold=1e-15, max_pairs=None):
+    """Fused product + cleanup; the product rows are never materialised.  Products with more than ``max_pairs`` pairs are
+    tiled over the outer (slow) index: every slab is cleaned on the device, the concatenation of the cleaned slabs is
+    cleaned once more (same first-occurrence order; coefficient sums associate per slab, i.e. within 1e-16 relative)."""
     inner, outer, ci, co = _rows(inner), _rows(outer), _coeff(ci), _coeff(co)
     assert inner.shape[1] == outer.shape[1]
-    if inner.shape[0] == 0 or outer.shape[0] == 0:
+    ni, no = inner.shape[0], outer.shape[0]
+    if ni == 0 or no == 0:
         return np.empty((0, inner.shape[1]), dtype='<u8'), np.empty(0, dtype=np.complex128)
     thr, use = _thr_args(zero_threshold)
-    a, b = DeviceOp.upload(inner, ci), DeviceOp.upload(outer, co)
-    out = ctypes.c_void_p()
+    max_pairs = MAX_PAIRS_PER_CALL if max_pairs is None else int(max_pairs)
+    a = DeviceOp.upload(inner, ci)
     try:
-        check(_lib.lib().symgpu_mul_cleanup_dev(a.handle, b.handle, 1 if inner_is_left else 0, thr, use, ctypes.byref(out)))
-        return DeviceOp(out).download()
+        if ni * no <= max_pairs:
+            b = DeviceOp.upload(outer, co)
+            out = ctypes.c_void_p()
+            try:
+                check(_lib.lib().symgpu_mul_cleanup_dev(a.handle, b.handle, 1 if inner_is_left else 0, thr, use, ctypes.byref(out)))
+                return DeviceOp(out).download()
+            finally:
+                b.free()
+        slab = max(1, max_pairs // ni)
+        parts_r, parts_c = [], []
+        for o0 in range(0, no, slab):
+            b = DeviceOp.upload(outer[o0:o0 + slab], co[o0:o0 + slab])
+            out = ctypes.c_void_p()
+            try:
+                # partial sums must not be thresholded: a term may only cancel across slabs
+                check(_lib.lib().symgpu_mul_cleanup_dev(a.handle, b.handle, 1 if inner_is_left else 0, 0.0, 0, ctypes.byref(out)))
+                r, c = DeviceOp(out).download()
+            finally:
+                b.free()
+            parts_r.append(r); parts_c.append(c)
+        return cleanup(np.vstack(parts_r), np.hstack(parts_c), zero_threshold)
     finally:
-        a.free(); b.free()
+        a.free()
 
 
 def rotation_args(angle, threshold=1e-18):

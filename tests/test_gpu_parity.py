@@ -426,3 +426,13 @@ def test_quantum_state_golden(case):
     got = np.array([single_term_expval(Pk, psi) for Pk in P])
     assert np.allclose(got, case['term_expvals'], rtol=0, atol=1e-10)
     assert psi + psi == psi * 2 and (psi - psi).n_terms == 0
+
+
+def test_mul_cleanup_tiled_over_outer_operand():
+    """Products beyond the 32-bit pair-index limit are tiled over the outer operand; forced here with a tiny tile."""
+    rng = np.random.default_rng(8)
+    n, N, M = 100, 300, 290
+    A = PauliwordOp(rng.random((N, 2 * n)) < 0.3, dyadic(rng, N))
+    rows, coeff = kernels.mul_cleanup(A.packed, A.coeff_vec, A.packed[:M], A.coeff_vec[:M], True, 1e-15, max_pairs=7000)
+    erows, ecoeff = oc.mul(A.packed, A.coeff_vec, A.packed[:M], A.coeff_vec[:M])
+    assert np.array_equal(rows, erows) and np.array_equal(coeff, ecoeff)
