@@ -27,36 +27,72 @@ def shard_bounds(n_rows, world):
 class _TcpControl:
     """Minimal rank-0-rooted control plane over TCP: broadcast of bytes, max-reduce of a float, barrier."""
 
+    N_CANDIDATE_PORTS = 8
+
     def __init__(self, rank, world, addr, port, timeout=300.0):
+        """``port`` is the first of N_CANDIDATE_PORTS candidates (stride 101): rank 0 listens on the first one it can bind, the
+        other ranks probe the candidates until one answers the handshake (magic derived from port and world size), so a port
+        that happens to be taken by an unrelated service on the node does not break the job."""
         import socket, struct, time
         self.rank, self.world, self._struct = rank, world, struct
         self.peers = []
+        host = addr if addr not in ('localhost',) else '127.0.0.1'
+        ports = [1024 + (port - 1024 + 101 * k) % 64000 for k in range(self.N_CANDIDATE_PORTS)]
+        magic = struct.pack('<4sHH', b'SYMG', port & 0xFFFF, world & 0xFFFF)
         if rank == 0:
-            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr if addr not in ('localhost',) else '127.0.0.1', port))
-            srv.listen(world)
+            srv = None
+            for p in ports:
+                try:
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind((host, p))
+                    break
+                except OSError:
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise OSError(f'control plane: none of the ports {ports} could be bound on {host}')
+            srv.listen(world + 8)
             srv.settimeout(timeout)
             conns = {}
             while len(conns) < world - 1:
                 c, _ = srv.accept()
-                c.settimeout(timeout)
-                r = struct.unpack('<i', self._recv(c, 4))[0]
-                conns[r] = c
+                try:
+                    c.settimeout(10.0)
+                    hello = self._recv(c, len(magic) + 4)
+                    r = struct.unpack('<i', hello[len(magic):])[0]
+                    if hello[:len(magic)] != magic or not (0 < r < world) or r in conns:
+                        raise ConnectionError('not a peer of this job')
+                    c.sendall(magic)
+                    c.settimeout(timeout)
+                    conns[r] = c
+                except (OSError, ConnectionError):
+                    c.close()
             self.peers = [conns[r] for r in sorted(conns)]
             srv.close()
         else:
             deadline = time.time() + timeout
-            while True:
-                try:
-                    c = socket.create_connection((addr, port), timeout=5.0)
-                    break
-                except OSError:
+            c = None
+            while c is None:
+                for p in ports:
+                    try:
+                        s = socket.create_connection((host, p), timeout=5.0)
+                    except OSError:
+                        continue
+                    try:
+                        s.settimeout(10.0)
+                        s.sendall(magic + struct.pack('<i', rank))
+                        if self._recv(s, len(magic)) == magic:
+                            c = s
+                            break
+                        s.close()
+                    except (OSError, ConnectionError):
+                        s.close()
+                if c is None:
                     if time.time() > deadline:
-                        raise
+                        raise TimeoutError(f'control plane: rank 0 did not answer on any of {ports} at {host}')
                     time.sleep(0.2)
             c.settimeout(timeout)
-            c.sendall(struct.pack('<i', rank))
             self.peers = [c]
 
     @staticmethod

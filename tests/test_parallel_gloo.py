@@ -97,3 +97,30 @@ def test_world_size_3_tcp_control_plane():
         p.join(timeout=30)
     for rank, ok, err in res:
         assert ok, f'rank {rank} failed: {err}'
+
+
+@pytest.mark.timeout(120)
+def test_tcp_control_plane_survives_an_occupied_port():
+    """The first candidate port is held by an unrelated (silent) listener: rank 0 must move on, the peers must find it."""
+    import socket
+    port = _free_port()
+    first = 1024 + (port + 7919) % 60000                      # Communicator.from_env's derived control port
+    blocker = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    try:
+        blocker.bind(('127.0.0.1', first))
+    except OSError:
+        pytest.skip('derived port already in use by something else')
+    blocker.listen(4)
+    try:
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_tcp_worker, args=(r, 2, port, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=100) for _ in procs]
+        for p in procs:
+            p.join(timeout=30)
+        for rank, ok, err in res:
+            assert ok, f'rank {rank} failed: {err}'
+    finally:
+        blocker.close()
