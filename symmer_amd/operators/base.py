@@ -34,30 +34,62 @@ class PauliwordOp:
         assert symp_matrix.dtype == bool, 'Symplectic matrix must be defined over bools'
         if len(symp_matrix.shape) == 1:
             symp_matrix = symp_matrix.reshape([1, len(symp_matrix)])
-        self.symp_matrix = symp_matrix
-        assert self.symp_matrix.shape[-1] % 2 == 0, 'symplectic matrix must have even number of columns'
-        assert len(self.symp_matrix.shape) == 2, 'symplectic matrix must be 2 dimensional only'
-        self.n_qubits = self.symp_matrix.shape[1] // 2
+        assert symp_matrix.shape[-1] % 2 == 0, 'symplectic matrix must have even number of columns'
+        assert len(symp_matrix.shape) == 2, 'symplectic matrix must be 2 dimensional only'
+        self._symp = symp_matrix
+        self.n_qubits = symp_matrix.shape[1] // 2
         self.coeff_vec = np.asarray(coeff_vec, dtype=complex)
-        self.n_terms = self.symp_matrix.shape[0]
+        self.n_terms = symp_matrix.shape[0]
         assert self.n_terms == len(self.coeff_vec), 'coeff list and Pauliwords not same length'
-        self.X_block = self.symp_matrix[:, :self.n_qubits]
-        self.Z_block = self.symp_matrix[:, self.n_qubits:]
         self._packed_cache = None
 
-    # ---- packed view (the C-ABI operand) ----------------------------------------------------------
+    # ---- the two layouts: reference bool matrix (host glue) and packed rows (the C-ABI operand) -----------
+    @property
+    def symp_matrix(self) -> np.ndarray:
+        """bool[T, 2n] = [X | Z] as in the reference.  Results of device kernels arrive packed and are only expanded
+        to one byte per bit when somebody asks (a 2.5e7-term, 1000-qubit product is 6 GB packed but 50 GB as bools)."""
+        if self._symp is None:
+            self._symp = packing.unpack_rows(self._packed_cache, self.n_qubits)
+        return self._symp
+
+    @property
+    def X_block(self) -> np.ndarray:
+        return self.symp_matrix[:, :self.n_qubits]
+
+    @property
+    def Z_block(self) -> np.ndarray:
+        return self.symp_matrix[:, self.n_qubits:]
+
     @property
     def packed(self) -> np.ndarray:
         """uint64[T, 2*Wq] rows of the C-ABI; cached (``symp_matrix`` is treated as immutable, as in the reference)."""
         if self._packed_cache is None:
-            self._packed_cache = packing.pack_rows(self.symp_matrix)
+            self._packed_cache = packing.pack_rows(self._symp)
         return self._packed_cache
 
     @classmethod
     def _from_packed(cls, packed: np.ndarray, n_qubits: int, coeff_vec) -> "PauliwordOp":
         op = cls.__new__(cls)
-        PauliwordOp.__init__(op, packing.unpack_rows(packed, n_qubits), coeff_vec)
-        op._packed_cache = np.ascontiguousarray(packed, dtype='<u8')
+        packed = np.ascontiguousarray(packed, dtype='<u8')
+        assert packed.ndim == 2 and packed.shape[1] == 2 * packing.words_per_block(n_qubits)
+        op._symp = None
+        op._packed_cache = packed
+        op.n_qubits = n_qubits
+        op.n_terms = packed.shape[0]
+        op.coeff_vec = np.asarray(coeff_vec, dtype=complex)
+        assert op.n_terms == len(op.coeff_vec), 'coeff list and Pauliwords not same length'
+        return op
+
+    def _derive(self, index=None, coeff_vec=None) -> "PauliwordOp":
+        """Row selection / new coefficients without touching layouts that have not been materialised."""
+        op = PauliwordOp.__new__(PauliwordOp)
+        op._symp = None if self._symp is None else (self._symp if index is None else self._symp[index])
+        op._packed_cache = None if self._packed_cache is None else (self._packed_cache if index is None else
+                                                                    np.ascontiguousarray(self._packed_cache[index]))
+        op.n_qubits = self.n_qubits
+        coeff = self.coeff_vec if coeff_vec is None else coeff_vec
+        op.coeff_vec = np.asarray(coeff if index is None or coeff_vec is not None else coeff[index], dtype=complex)
+        op.n_terms = len(op.coeff_vec)
         return op
 
     # ---- constructors --------------------------------------------------------------------------------
@@ -137,7 +169,7 @@ class PauliwordOp:
             sort_order = sort_order[::-1]
         elif key != 'decreasing':
             raise ValueError('Only permitted sort by values are increasing or decreasing')
-        return PauliwordOp(self.symp_matrix[sort_order], self.coeff_vec[sort_order])
+        return self._derive(index=sort_order)
 
     # ---- a2 ----------------------------------------------------------------------------------------------
     @cached_property
@@ -174,8 +206,10 @@ class PauliwordOp:
 
     def append(self, PwordOp: "PauliwordOp") -> "PauliwordOp":
         assert self.n_qubits == PwordOp.n_qubits, 'Pauliwords defined for different number of qubits'
-        return PauliwordOp(np.vstack((self.symp_matrix, PwordOp.symp_matrix)),
-                           np.hstack((self.coeff_vec, PwordOp.coeff_vec)))
+        coeff = np.hstack((self.coeff_vec, PwordOp.coeff_vec))
+        if (self._symp is None or PwordOp._symp is None) and self.n_qubits:
+            return PauliwordOp._from_packed(np.vstack((self.packed, PwordOp.packed)), self.n_qubits, coeff)
+        return PauliwordOp(np.vstack((self.symp_matrix, PwordOp.symp_matrix)), coeff)
 
     def __add__(self, PwordOp: "PauliwordOp") -> "PauliwordOp":
         return self.append(PwordOp).cleanup()
@@ -191,7 +225,7 @@ class PauliwordOp:
         return self + op_copy
 
     def multiply_by_constant(self, const: complex) -> "PauliwordOp":
-        return PauliwordOp(self.symp_matrix, self.coeff_vec * const)
+        return self._derive(coeff_vec=self.coeff_vec * const)
 
     # ---- a3 / a4 -----------------------------------------------------------------------------------------
     def _multiply_by_operator(self, PwordOp: "PauliwordOp", zero_threshold: float = 1e-15) -> "PauliwordOp":
@@ -265,7 +299,7 @@ class PauliwordOp:
             mask = np.asarray(key)
         else:
             raise ValueError(f'Unrecognised input {type(key)}, must be an integer, slice, list or np.array')
-        return PauliwordOp(self.symp_matrix[mask], self.coeff_vec[mask])
+        return self._derive(index=mask)
 
     def __iter__(self):
         return iter([self[i] for i in range(self.n_terms)])
@@ -439,7 +473,7 @@ class PauliwordOp:
 
     @cached_property
     def dagger(self) -> "PauliwordOp":
-        return PauliwordOp(self.symp_matrix, self.coeff_vec.conjugate())
+        return self._derive(coeff_vec=self.coeff_vec.conjugate())
 
     @cached_property
     def to_dictionary(self) -> Dict[str, complex]:

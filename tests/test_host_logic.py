@@ -156,3 +156,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in src.replace('ORACLE', ''), f'{f} mentions the oracle'
+
+
+def test_packed_results_are_not_expanded_until_asked():
+    """Kernel results arrive packed; the one-byte-per-bit matrix is only built on access, and row selection / scaling /
+    appending keep working on the packed layout alone."""
+    from symmer_amd.operators import PauliwordOp
+    from symmer_amd import packing
+    rng = np.random.default_rng(0)
+    symp = rng.random((7, 2 * 70)) < 0.4
+    coeff = rng.standard_normal(7) + 0j
+    op = PauliwordOp._from_packed(packing.pack_rows(symp), 70, coeff)
+    assert op._symp is None and op.n_terms == 7 and op.n_qubits == 70
+    sub = (op[[4, 1]] * 2.0).append(op[2:5])
+    assert sub._symp is None and op._symp is None
+    assert np.array_equal(sub.symp_matrix, symp[[4, 1, 2, 3, 4]]) and np.array_equal(sub.coeff_vec, np.hstack([2 * coeff[[4, 1]], coeff[2:5]]))
+    assert np.array_equal(op.symp_matrix, symp) and np.array_equal(op.X_block, symp[:, :70]) and np.array_equal(op.Z_block, symp[:, 70:])
+    assert np.array_equal(op.dagger.coeff_vec, coeff.conjugate())
