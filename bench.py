@@ -144,6 +144,13 @@ def main():
         out['roofline']['isolated_GBps'] = iso
         out['roofline']['isolated_frac'] = iso / HBM_PEAK_GBS
         rows_only.free()
+    # on-box ceilings measured by the library itself (one-shot 16-B fill / copy over 4 GiB buffers)
+    if rank == 0:
+        fill, cp = ctypes.c_double(0), ctypes.c_double(0)
+        _lib.check(lib.symgpu_membw_probe(4 << 30, ctypes.addressof(fill), ctypes.addressof(cp)))
+        out['roofline']['measured_fill_ceiling_GBps'] = fill.value
+        out['roofline']['measured_copy_ceiling_GBps'] = cp.value
+        out['roofline']['frac_of_measured_fill_ceiling'] = achieved / fill.value if fill.value else None
     # HBM traffic of the dominant kernel from the committed PMC profile (counters cannot be read from inside this process)
     try:
         with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
@@ -179,9 +186,21 @@ def timed(fn, reps):
 
 
 def extras(_lib, kernels, DeviceOp):
-    """Other BASELINE.json configs on one GPU (device-resident inputs, C-ABI level)."""
+    """Other BASELINE.json configs on one GPU (device-resident inputs, C-ABI level; cfg1 through the Python classes)."""
     lib = _lib.lib()
     ex = {}
+    # cfg1: the reference's own CPU-runnable case through the drop-in API, host buffers in / host result out
+    from symmer_amd.operators import PauliwordOp
+    rng1 = np.random.default_rng(1235)
+    P1 = PauliwordOp(rng1.random((500, 200)) < 0.3, rng1.standard_normal(500) + 1j * rng1.standard_normal(500))
+    (P1 * P1)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        P1._packed_cache = None
+        R1 = P1 * P1
+    t = (time.perf_counter() - t0) / 5
+    ex['cfg1_api_mul'] = {'call': 'PauliwordOp * PauliwordOp (pack + upload + fused product/cleanup + download)', 'pairs': 250000,
+                          'seconds': t, 'pairs_per_s': 250000 / t, 'terms_out': R1.n_terms}
     # cfg3: 1,000 qubits, 10,000 terms squared (1e8 pairs) + cleanup
     A = DeviceOp.random(10000, 1000, 0.3, seed=1237)
 
@@ -208,8 +227,23 @@ def extras(_lib, kernels, DeviceOp):
     kernels.sync(); t_chain = time.perf_counter() - t0
     cur.free()
     t1 = timed(lambda: kernels.rotate_single_dev(P, qs[0], 0.3)[0].free(), 5)
+    # chain of 128 Clifford (pi/2) rotations with the operator device resident (term count stays 1e5)
+    cur = P
+    kernels.sync(); t0 = time.perf_counter()
+    n_rot = 0
+    for k in range(128):
+        res, allc = kernels.rotate_single_dev(cur, qs[k % 8], np.pi / 2)
+        if allc:
+            continue
+        if cur is not P:
+            cur.free()
+        cur = res; n_rot += 1
+    kernels.sync(); t_cl = (time.perf_counter() - t0) / max(1, n_rot)
+    if cur is not P:
+        cur.free()
     ex['cfg2_rotation'] = {'terms_in': 100000, 'first_rotation_seconds': t1, 'term_pairs_per_s': 1e5 / t1,
-                           'chain4_seconds': t_chain, 'chain_terms': terms}
+                           'chain4_seconds': t_chain, 'chain_terms': terms,
+                           'clifford_chain': {'rotations': n_rot, 'seconds_per_rotation': t_cl, 'term_pairs_per_s': 1e5 / t_cl}}
     P.free()
     # cfg5 slice: 2,000 qubits, 25,000 x 200,000 commutation block (one rank's share of the 8-GPU adjacency)
     C = DeviceOp.random(200000, 2000, 0.3, seed=1239)
@@ -265,7 +299,30 @@ def cpu_baseline(n):
         t_total += time.perf_counter() - t0
         reps += 1
     v = Ns * Ms * reps / t_total
-    return {'value': v, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port',
+    other = {}
+    # cfg1 at full size: product + cleanup of 500 x 500 terms on 100 qubits
+    A1 = rng.random((500, 200)) < 0.3; a1 = rng.standard_normal(500) + 1j * rng.standard_normal(500)
+    t0 = time.perf_counter(); onp.multiply_by_operator(A1, a1, A1, a1); t = time.perf_counter() - t0
+    other['cfg1_mul_cleanup'] = {'pairs': 250000, 'seconds': t, 'pairs_per_s': 250000 / t}
+    # cfg3 cannot be materialised by the reference algorithm (200 GB temporaries): 500 x 500 terms on 1,000 qubits
+    # (the port's first-occurrence unique is a NumPy sort of 2,000-byte rows; the reference uses qiskit's Rust hash map there)
+    t0 = time.perf_counter(); onp.multiply_by_operator(A[:500], a[:500], A[:500], a[:500]); t = time.perf_counter() - t0
+    other['cfg3_sample_mul_cleanup'] = {'pairs': 250000, 'seconds': t, 'pairs_per_s': 250000 / t}
+    # cfg2 at full size: one non-Clifford rotation of 1e5 terms on 1,000 qubits
+    P2 = rng.random((100000, 2 * n)) < 0.3; c2 = rng.standard_normal(100000) + 0j; q2 = rng.random(2 * n) < 0.3
+    t0 = time.perf_counter(); onp.rotate_by_single_pword(P2, c2, q2, 0.3); t = time.perf_counter() - t0
+    other['cfg2_rotation'] = {'terms_in': 100000, 'seconds': t, 'term_pairs_per_s': 1e5 / t}
+    del P2
+    # cfg5 sample: 1,000 x 10,000 block of the 2,000-qubit commutation matrix (f64 dot % 2 as the reference)
+    C5 = rng.random((10000, 4000)) < 0.3
+    t0 = time.perf_counter(); onp.commutes_termwise(C5[:1000], C5); t = time.perf_counter() - t0
+    other['cfg5_sample_commutation'] = {'pairs': 10**7, 'seconds': t, 'pairs_per_s': 1e7 / t}
+    del C5
+    # cfg4 sample: row-XOR rate depends on the row length, so keep cfg4's 54,000 columns and reduce the row count
+    M4 = rng.random((256, 54000)) < 0.5
+    t0 = time.perf_counter(); _, nx = onp.rref_noswap(M4, count_xors=True); t = time.perf_counter() - t0
+    other['cfg4_sample_rref'] = {'rows': 256, 'cols': 54000, 'row_xors': int(nx), 'seconds': t, 'row_xors_per_s': nx / t}
+    return {'other_configs': other, 'value': v, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port',
             'sample': f'{reps} x ({Ns} x {Ms} terms, {n} qubits) all-pairs product, NumPy restatement of base.py:783-792 '
                       f'(1 byte per bit, single thread; host has {os.cpu_count()} cores)'}
 

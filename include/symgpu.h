@@ -53,6 +53,10 @@ int symgpu_timer_stop(float *ms);
 int symgpu_prof_enable(int kernel_class, int on);
 int symgpu_prof_read(int kernel_class, int64_t *n_launches, double *total_ms);
 
+/* measured on-box HBM ceilings for the roofline: one-shot 16-byte-per-thread fill (GB/s written) and copy (GB/s read+written)
+ * over scratch buffers of `bytes` each (best of 3). */
+int symgpu_membw_probe(int64_t bytes, double *fill_GBps, double *copy_GBps);
+
 /* ---- device-resident operators -------------------------------------------------------------- */
 int symgpu_op_upload(const uint64_t *rows, const double *coeff /* may be NULL */, int64_t T, int Wq, symgpu_op_t *out);
 int symgpu_op_alloc(int64_t capacity_rows, int Wq, int with_coeff, symgpu_op_t *out);

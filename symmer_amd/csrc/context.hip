@@ -218,6 +218,17 @@ __global__ void k_random_op(u64 *__restrict__ rows, double *__restrict__ coeff, 
     }
 }
 
+// on-box bandwidth ceilings for the roofline (one 16-byte store / load+store per thread, one-shot grid)
+typedef unsigned int u32x4p __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_probe_fill(u32x4p *out, i64 n, u32 v) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (u32x4p)(v);
+}
+__global__ __launch_bounds__(256) void k_probe_copy(const u32x4p *in, u32x4p *out, i64 n) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
 }  // namespace symgpu
 
 using namespace symgpu;
@@ -329,6 +340,37 @@ int symgpu_timer_stop(float *ms) {
     float t = 0;
     HIP_TRY(hipEventElapsedTime(&t, ctx().ev0, ctx().ev1));
     if (ms) *ms = t;
+    return SYMGPU_OK;
+}
+
+int symgpu_membw_probe(int64_t bytes, double *fill_GBps, double *copy_GBps) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(bytes >= (1 << 20), "membw_probe: at least 1 MiB");
+    const i64 n = bytes / 16;
+    Scratch a, b;
+    SG_TRY(a.alloc((size_t)n * 16));
+    SG_TRY(b.alloc((size_t)n * 16));
+    Context &c = ctx();
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    float best_fill = 1e30f, best_copy = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        float ms = 0;
+        HIP_TRY(hipEventRecord(c.ev0, c.stream));
+        hipLaunchKernelGGL(k_probe_fill, dim3(grid), dim3(256), 0, c.stream, a.as<u32x4p>(), n, 7u + rep);
+        HIP_TRY(hipEventRecord(c.ev1, c.stream));
+        HIP_TRY(hipEventSynchronize(c.ev1));
+        HIP_TRY(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+        if (rep && ms < best_fill) best_fill = ms;
+        HIP_TRY(hipEventRecord(c.ev0, c.stream));
+        hipLaunchKernelGGL(k_probe_copy, dim3(grid), dim3(256), 0, c.stream, a.as<u32x4p>(), b.as<u32x4p>(), n);
+        HIP_TRY(hipEventRecord(c.ev1, c.stream));
+        HIP_TRY(hipEventSynchronize(c.ev1));
+        HIP_TRY(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+        if (rep && ms < best_copy) best_copy = ms;
+    }
+    KERNEL_CHECK();
+    if (fill_GBps) *fill_GBps = (double)n * 16 / (best_fill * 1e-3) / 1e9;
+    if (copy_GBps) *copy_GBps = 2.0 * (double)n * 16 / (best_copy * 1e-3) / 1e9;
     return SYMGPU_OK;
 }
 
