@@ -131,51 +131,99 @@ __global__ void k_pair_keys(const u64 *__restrict__ hI, i64 Ni, const u64 *__res
     }
 }
 
+// PACKED pair keys: one u64 per pair = (top 32 hash bits << 32) | (o << bi) | i   (bi = bits of Ni-1; needs bi + bits of
+// No-1 <= 32).  The radix sort then moves 8 instead of 12 bytes per element and pass, nothing on the path divides by Ni,
+// and the full 64-bit key of a sorted element is recomputed from its (i, o) fields with two lookups in the cache-resident
+// per-operand hash tables whenever it is needed.  The LSD sort only touches the hash bits and is stable, so equal keys stay
+// in ascending pair-index order exactly as with separate index values.
+__device__ __forceinline__ u64 packed_full_key(const u64 *__restrict__ hI, const u64 *__restrict__ hO, u32 w, int bi) {
+    return hI[w & ((1u << bi) - 1u)] ^ hO[w >> bi];
+}
+__device__ __forceinline__ u32 packed_index(u32 w, int bi, u32 Ni) { return (w >> bi) * Ni + (w & ((1u << bi) - 1u)); }
+
+__global__ __launch_bounds__(256) void k_pair_keys_packed(const u64 *__restrict__ hI, u32 Ni, const u64 *__restrict__ hO, u32 No, int bi,
+                                                           u64 *__restrict__ keys) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= Ni) return;
+    const u64 hi = hI[i];
+    for (u32 o = blockIdx.y; o < No; o += gridDim.y)
+        keys[(u64)o * Ni + i] = ((hi ^ hO[o]) & 0xFFFFFFFF00000000ULL) | (u64)((o << bi) | i);
+}
+
 // head flags + exact verification of equal-key neighbours + coefficient gather into sorted order.
 // PAIR: row(t) = inner[t % Ni] ^ outer[t / Ni].  One wavefront owns 64 consecutive sorted positions; the positions whose
-// key equals their predecessor's (ballot) are verified COOPERATIVELY: G = pow2 >= W lanes (<= 64) read the words of the
-// two rows with coalesced loads, 64/G comparisons in flight per step.  A mismatch (two different rows with one 64-bit
+// key equals their predecessor's are verified COOPERATIVELY with 16-byte loads: G = pow2 >= W/2 lanes (<= 64) cover the
+// 16-byte chunks of the two rows, the 64/G lane groups each walk the candidates of their own lane range, so 64/G
+// comparisons (4 row reads each in PAIR mode) are in flight per step.  A mismatch (two different rows with one 64-bit
 // hash) only raises the collision flag: the caller reseeds the hash and redoes the pass, so exactness never rests on the
 // hash.  cg[s] = coeff[idx[s]] turns the segment sums into sequential reads.
-template <bool PAIR>
+__device__ __forceinline__ bool differs(u32x4 a, u32x4 b) {
+    const u32x4 d = a ^ b;
+    return (d.x | d.y | d.z | d.w) != 0u;
+}
+// PACKED (implies PAIR): keys are k_pair_keys_packed values; idx is unused, full keys come from hI / hO.
+template <bool PAIR, bool PACKED>
 __global__ __launch_bounds__(256) void k_heads(const u64 *__restrict__ keys, const u32 *__restrict__ idx, i64 T, const u64 *__restrict__ rows, int W,
-                                                const u64 *__restrict__ inner, i64 Ni, const u64 *__restrict__ outer, int G,
+                                                const u64 *__restrict__ inner, u32 Ni, const u64 *__restrict__ outer, int G,
                                                 const double *__restrict__ coeff, double *__restrict__ cg,
-                                                u32 *__restrict__ heads, u32 *__restrict__ collision) {
+                                                u32 *__restrict__ heads, u32 *__restrict__ collision,
+                                                const u64 *__restrict__ hI, const u64 *__restrict__ hO, int bi) {
     const int lane = threadIdx.x & 63;
-    const int per = 64 / G, gi = lane / G, gl = lane % G;
+    const int gi = lane / G, gl = lane % G;
+    const int C = W / 2;                                             // 16-byte chunks per row
+    const u64 gmask = G == 64 ? ~0ULL : (((1ULL << G) - 1ULL) << (gi * G));
     const i64 n_chunks = (T + 63) / 64;
     for (i64 chunk = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += (i64)gridDim.x * 4) {
         const i64 s = chunk * 64 + lane;
         const bool valid = s < T;
-        const u64 k = valid ? keys[s] : 0ULL;
-        const u64 kp = (valid && s > 0) ? keys[s - 1] : ~k;
-        const u32 t1 = valid ? idx[s] : 0u;
-        const u32 t0 = (valid && s > 0) ? idx[s - 1] : 0u;
-        const bool eq = valid && s > 0 && k == kp;
+        // this position: input index t1 (PAIR: as (i1, o1)), full key f1
+        u64 f1 = 0;
+        u32 t1 = 0, i1 = 0, o1 = 0;
+        auto decode = [&](i64 pos, u64 &f, u32 &t, u32 &ii, u32 &oo) {
+            const u64 k = keys[pos];
+            if (PACKED) {
+                const u32 w = (u32)k;
+                ii = w & ((1u << bi) - 1u); oo = w >> bi;
+                t = oo * Ni + ii;
+                f = hI[ii] ^ hO[oo];
+            } else {
+                t = idx[pos];
+                f = k;
+                if (PAIR) { oo = t / Ni; ii = t - oo * Ni; }
+            }
+        };
+        if (valid) decode(s, f1, t1, i1, o1);
+        // predecessor: neighbour lane, lane 0 decodes position s-1 itself
+        u64 f0 = __shfl_up(f1, 1);
+        u32 t0 = __shfl_up(t1, 1), i0 = __shfl_up(i1, 1), o0 = __shfl_up(o1, 1);
+        if (lane == 0 && valid && s > 0) decode(s - 1, f0, t0, i0, o0);
+        const bool eq = valid && s > 0 && f1 == f0;
         if (valid) {
             heads[s] = eq ? 0u : 1u;
             reinterpret_cast<double2 *>(cg)[s] = reinterpret_cast<const double2 *>(coeff)[t1];
         }
-        u64 m = __ballot(eq);
+        // P * P: row(i, o) == row(o, i) by commutativity of XOR when both operands are the same array — nothing to read
+        const bool trivially_equal = PAIR && inner == outer && i1 == o0 && o1 == i0;
+        u64 sub = __ballot(eq && !trivially_equal) & gmask;          // this group's candidates
         bool mism = false;
-        while (m) {                                                  // wave-uniform
-            u64 mm = m;
-            for (int q = 0; q < gi; ++q) mm &= mm - 1;               // this group's candidate: the gi-th lowest set bit
-            const bool act = mm != 0;
-            const int p = act ? __builtin_ctzll(mm) : 0;
-            const i64 a1 = __shfl(t1, p), a0 = __shfl(t0, p);
-            if (act) {
-                if (PAIR) {
-                    const i64 o1 = a1 / Ni, i1 = a1 - o1 * Ni, o0 = a0 / Ni, i0 = a0 - o0 * Ni;
-                    const u64 *r1 = inner + i1 * W, *q1 = outer + o1 * W, *r0 = inner + i0 * W, *q0 = outer + o0 * W;
-                    for (int w = gl; w < W; w += G) mism |= ((r1[w] ^ q1[w]) != (r0[w] ^ q0[w]));
-                } else {
-                    const u64 *r1 = rows + a1 * W, *r0 = rows + a0 * W;
-                    for (int w = gl; w < W; w += G) mism |= (r1[w] != r0[w]);
+        while (__ballot(sub != 0ULL)) {                              // wave-uniform
+            const bool act = sub != 0ULL;
+            const int p = act ? __builtin_ctzll(sub) : 0;
+            sub &= sub - 1;
+            if (PAIR) {
+                const i64 ci1 = __shfl(i1, p), co1 = __shfl(o1, p), ci0 = __shfl(i0, p), co0 = __shfl(o0, p);
+                if (act) {
+                    const u32x4 *r1 = reinterpret_cast<const u32x4 *>(inner + ci1 * W), *q1 = reinterpret_cast<const u32x4 *>(outer + co1 * W);
+                    const u32x4 *r0 = reinterpret_cast<const u32x4 *>(inner + ci0 * W), *q0 = reinterpret_cast<const u32x4 *>(outer + co0 * W);
+                    for (int c = gl; c < C; c += G) mism |= differs(r1[c] ^ q1[c], r0[c] ^ q0[c]);
+                }
+            } else {
+                const i64 a1 = __shfl(t1, p), a0 = __shfl(t0, p);
+                if (act) {
+                    const u32x4 *r1 = reinterpret_cast<const u32x4 *>(rows + a1 * W), *r0 = reinterpret_cast<const u32x4 *>(rows + a0 * W);
+                    for (int c = gl; c < C; c += G) mism |= differs(r1[c], r0[c]);
                 }
             }
-            for (int q = 0; q < per && m; ++q) m &= m - 1;           // retire the `per` candidates just handled
         }
         if (__ballot(mism) && lane == 0) atomicOr(collision, 1u);
     }
@@ -186,19 +234,25 @@ __global__ __launch_bounds__(256) void k_heads(const u64 *__restrict__ keys, con
 // run holds more than one distinct key it is re-ordered here by (full key, input order) with a stable insertion sort.
 // Runs longer than FIX_MAX that are not uniform raise `fallback`: the caller then redoes a full 64-bit sort.
 constexpr int FIX_MAX = 48;
-// phase 1 (read-only): a position whose key differs from its predecessor's INSIDE a prefix run marks the run's start
-__global__ void k_fixup_mark(const u64 *__restrict__ keys, i64 T, int shift, u32 *__restrict__ need) {
+// phase 1 (read-only): a position whose key differs from its predecessor's INSIDE a prefix run marks the run's start.
+// PACKED: keys are k_pair_keys_packed values (full key recomputed from the pair index), there is no separate idx array.
+template <bool PACKED>
+__global__ void k_fixup_mark(const u64 *__restrict__ keys, i64 T, int shift, u32 *__restrict__ need,
+                             const u64 *__restrict__ hI, const u64 *__restrict__ hO, int bi) {
     for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
         if (s == 0) continue;
         const u64 k = keys[s], kp = keys[s - 1];
-        if ((k >> shift) != (kp >> shift) || k == kp) continue;
+        if ((k >> shift) != (kp >> shift)) continue;
+        if (PACKED ? (packed_full_key(hI, hO, (u32)k, bi) == packed_full_key(hI, hO, (u32)kp, bi)) : (k == kp)) continue;
         i64 b = s - 1;
         while (b > 0 && (keys[b - 1] >> shift) == (kp >> shift)) --b;
         need[b] = 1u;
     }
 }
 // phase 2: the marked run starts (one thread per mixed run) sort their run
-__global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 T, int shift, const u32 *__restrict__ need, u32 *__restrict__ fallback) {
+template <bool PACKED>
+__global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 T, int shift, const u32 *__restrict__ need, u32 *__restrict__ fallback,
+                             const u64 *__restrict__ hI, const u64 *__restrict__ hO, int bi) {
     for (i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x; b < T; b += (i64)gridDim.x * blockDim.x) {
         if (!need[b]) continue;
         const u64 pfx = keys[b] >> shift;
@@ -207,70 +261,145 @@ __global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 
         if (e - b > FIX_MAX) { atomicOr(fallback, 1u); continue; }
         for (i64 a = b + 1; a < e; ++a) {                                     // stable insertion sort by full key
             const u64 ka = keys[a];
-            const u32 ia = idx[a];
-            i64 c = a - 1;
-            while (c >= b && keys[c] > ka) { keys[c + 1] = keys[c]; idx[c + 1] = idx[c]; --c; }
-            keys[c + 1] = ka;
-            idx[c + 1] = ia;
+            if (PACKED) {
+                const u64 fa = packed_full_key(hI, hO, (u32)ka, bi);
+                i64 c = a - 1;
+                while (c >= b && packed_full_key(hI, hO, (u32)keys[c], bi) > fa) { keys[c + 1] = keys[c]; --c; }
+                keys[c + 1] = ka;
+            } else {
+                const u32 ia = idx[a];
+                i64 c = a - 1;
+                while (c >= b && keys[c] > ka) { keys[c + 1] = keys[c]; idx[c + 1] = idx[c]; --c; }
+                keys[c + 1] = ka;
+                idx[c + 1] = ia;
+            }
         }
     }
 }
 
-// Segment sums without segment ids: the thread at a head position walks its segment (the following non-head positions),
-// summing SEQUENTIALLY in ascending input order (the sort is stable) — exactly np.add.at's order (utils.py:273-274).
-// The sum replaces cg[s] at the head; heads[s] becomes 2 if the term survives the strict |c| > thr test (1 otherwise) and
-// the first-occurrence index of a surviving term is marked for the output-order scan.
-__global__ void k_segsum_heads(u32 *__restrict__ heads, const u32 *__restrict__ idx, i64 T, double *__restrict__ cg, double thr, int use_thr,
-                               u32 *__restrict__ mark) {
-    for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
-        if (heads[s] == 0u) continue;
-        double2 c = reinterpret_cast<const double2 *>(cg)[s];
+// Segment sums without segment ids, wave-cooperative.  Every wavefront owns a contiguous range of 64-position chunks; the
+// heads / coefficients of a chunk are loaded coalesced, the head lanes add the coefficients of the non-head lanes that follow
+// them one shuffle at a time — SEQUENTIALLY in ascending input order (the sort is stable), exactly np.add.at's order
+// (utils.py:273-274) — and a segment that runs past the end of a chunk is carried (wave-uniform accumulator) into the next
+// chunks, past the end of the wave's own range if necessary; the leading non-head positions of a range therefore belong to
+// the previous wave and are skipped.  The sum replaces cg[s] at the head; heads[s] becomes 2 if the term survives the strict
+// |c| > thr test (1 otherwise) and the first-occurrence index of a surviving term sets its bit in `markbits` (T bits:
+// 12.5 MB for 1e8 terms, cache resident, instead of a 4-byte flag per input index scattered over 400 MB).
+// PACKED: idx points at the packed pair keys (u64 per position, low word = (o << bi) | i).
+template <bool PACKED>
+__device__ __forceinline__ void segment_close(i64 pos, double re, double im, u32 *__restrict__ heads, const u32 *__restrict__ idx,
+                                              double *__restrict__ cg, double thr, int use_thr, u32 *__restrict__ markbits, int bi, u32 Ni) {
+    const bool keep = use_thr ? (hypot(re, im) > thr) : true;
+    if (!keep) return;
+    double2 o; o.x = re; o.y = im;
+    reinterpret_cast<double2 *>(cg)[pos] = o;
+    heads[pos] = 2u;
+    const u32 first = PACKED ? packed_index(idx[2 * pos], bi, Ni) : idx[pos];
+    atomicOr(&markbits[first >> 5], 1u << (first & 31u));
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_segsum_heads(u32 *__restrict__ heads, const u32 *__restrict__ idx, i64 T, double *__restrict__ cg, double thr,
+                                                       int use_thr, u32 *__restrict__ markbits, int bi, u32 Ni, i64 chunks_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const i64 n_chunks = (T + 63) / 64;
+    const i64 c0 = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * chunks_per_wave;
+    if (c0 >= n_chunks) return;
+    const i64 c1 = c0 + chunks_per_wave < n_chunks ? c0 + chunks_per_wave : n_chunks;
+    bool open = false;                  // wave-uniform: a segment is carried across chunk boundaries
+    double are = 0.0, aim = 0.0;        // its running sum
+    i64 apos = 0;                       // position of its head
+    for (i64 chunk = c0;; ++chunk) {
+        if (chunk >= c1 && !open) break;
+        if (chunk >= n_chunks) {        // the carried segment ends with the data
+            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, cg, thr, use_thr, markbits, bi, Ni);
+            break;
+        }
+        const i64 s = chunk * 64 + lane;
+        const bool valid = s < T;
+        const u32 h = valid ? heads[s] : 1u;                      // positions past the end act as heads: they end every run
+        double2 c; c.x = 0.0; c.y = 0.0;
+        if (valid) c = reinterpret_cast<const double2 *>(cg)[s];
+        const u64 m = __ballot(h != 0u);
+        const int lead = m ? __builtin_ctzll(m) : 64;             // leading non-head lanes continue the carried segment
+        if (open) {
+            for (int k = 0; k < lead; ++k) {
+                are = __dadd_rn(are, __shfl(c.x, k));
+                aim = __dadd_rn(aim, __shfl(c.y, k));
+            }
+        }
+        if (m == 0ULL) continue;                                  // no head in this chunk
+        if (open) {
+            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, cg, thr, use_thr, markbits, bi, Ni);
+            open = false;
+        }
+        if (chunk >= c1) break;                                   // beyond the own range only the carry had to be closed
+        const bool is_head = valid && h != 0u;
+        const u64 above = lane == 63 ? 0ULL : (m >> (lane + 1));
+        const int run = above ? __builtin_ctzll(above) : 63 - lane;   // non-head lanes that follow this lane in the chunk
         double re = __dadd_rn(0.0, c.x), im = __dadd_rn(0.0, c.y);
-        for (i64 e = s + 1; e < T && heads[e] == 0u; ++e) {
-            c = reinterpret_cast<const double2 *>(cg)[e];
-            re = __dadd_rn(re, c.x);
-            im = __dadd_rn(im, c.y);
+        for (int k = 1; __ballot(is_head && k <= run); ++k) {
+            const double vx = __shfl_down(c.x, k), vy = __shfl_down(c.y, k);
+            if (is_head && k <= run) {
+                re = __dadd_rn(re, vx);
+                im = __dadd_rn(im, vy);
+            }
         }
-        const bool keep = use_thr ? (hypot(re, im) > thr) : true;
-        if (keep) {
-            double2 o; o.x = re; o.y = im;
-            reinterpret_cast<double2 *>(cg)[s] = o;
-            heads[s] = 2u;
-            mark[idx[s]] = 1u;
+        // the last head of a full chunk may continue in the next chunk: carry it; everything else closes here
+        const int last = 63 - __builtin_clzll(m);
+        const bool carry = (chunk * 64 + 64 <= T) && true;       // a full chunk: lane `last` is a real head whose run reaches lane 63
+        if (is_head && !(carry && lane == last)) segment_close<PACKED>(s, re, im, heads, idx, cg, thr, use_thr, markbits, bi, Ni);
+        if (carry) {
+            open = true;
+            are = __shfl(re, last);
+            aim = __shfl(im, last);
+            apos = chunk * 64 + last;
         }
     }
 }
 
-// out position of a kept segment = exclusive scan of mark at its first index (= idx at the head: the sort is stable)
+__global__ void k_popc_words(const u32 *__restrict__ bits, i64 n_words, u32 *__restrict__ counts) {
+    for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (i64)gridDim.x * blockDim.x) counts[w] = (u32)__popc(bits[w]);
+}
+
+// out position of a kept segment = number of marked first indices below its own (= idx at the head: the sort is stable):
+// word prefix + popcount of the lower bits of its word
+// out_src[p]: input index of the row, PACKED: its (o << bi) | i fields (k_gather_rows then needs no division)
+template <bool PACKED>
 __global__ void k_emit_heads(const u32 *__restrict__ heads, const u32 *__restrict__ idx, i64 T, const double *__restrict__ cg,
-                             const u32 *__restrict__ outpos, double *__restrict__ out_coeff, u32 *__restrict__ out_src) {
+                             const u32 *__restrict__ markbits, const u32 *__restrict__ wordprefix, double *__restrict__ out_coeff,
+                             u32 *__restrict__ out_src, int bi, u32 Ni) {
     for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
         if (heads[s] != 2u) continue;
-        const u32 first = idx[s];
-        const u32 p = outpos[first];
+        const u32 w = PACKED ? idx[2 * s] : idx[s];
+        const u32 first = PACKED ? packed_index(w, bi, Ni) : w;
+        const u32 p = wordprefix[first >> 5] + (u32)__popc(markbits[first >> 5] & ((1u << (first & 31u)) - 1u));
         reinterpret_cast<double2 *>(out_coeff)[p] = reinterpret_cast<const double2 *>(cg)[s];
-        out_src[p] = first;
+        out_src[p] = w;
     }
 }
 
-// gather surviving rows as 16-byte chunks: out[p][c] = row(out_src[p])[c]
-template <bool PAIR>
-__global__ void k_gather_rows(const u32 *__restrict__ out_src, i64 n_out, int Wq, const u32x4 *__restrict__ rows,
-                              const u32x4 *__restrict__ inner, i64 Ni, const u32x4 *__restrict__ outer, u32x4 *__restrict__ out) {
-    const i64 total = n_out * Wq;
-    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (i64)gridDim.x * blockDim.x) {
-        const i64 p = k / Wq;
-        const int c = (int)(k - p * Wq);
-        const i64 t = out_src[p];
-        u32x4 v;
-        if (PAIR) {
-            const i64 o = t / Ni, i = t - o * Ni;
-            v = inner[i * Wq + c] ^ outer[o * Wq + c];
-        } else {
-            v = rows[t * Wq + c];
-        }
-        out[k] = v;
+// gather surviving rows as 16-byte chunks: out[p][c] = row(out_src[p])[c].  One chunk per thread, one-shot grid,
+// non-temporal stores (the k_mul_rows store pattern: consecutive lanes -> consecutive 16-byte chunks).
+template <bool PAIR, bool PACKED>
+__global__ __launch_bounds__(256) void k_gather_rows(const u32 *__restrict__ out_src, i64 n_out, int Wq, const u32x4 *__restrict__ rows,
+                                                      const u32x4 *__restrict__ inner, u32 Ni, const u32x4 *__restrict__ outer,
+                                                      u32x4 *__restrict__ out, int bi) {
+    const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_out * Wq) return;
+    const i64 p = k / Wq;
+    const int c = (int)(k - p * Wq);
+    const u32 t = out_src[p];
+    u32x4 v;
+    if (PAIR) {
+        u32 o, i;
+        if (PACKED) { o = t >> bi; i = t & ((1u << bi) - 1u); }
+        else { o = t / Ni; i = t - o * Ni; }
+        v = inner[(i64)i * Wq + c] ^ outer[(i64)o * Wq + c];
+    } else {
+        v = rows[(i64)t * Wq + c];
     }
+    __builtin_nontemporal_store(v, out + k);
 }
 
 static int grid_for(i64 n, int block = 256, int cap = 8192) {
@@ -297,14 +426,29 @@ int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
     return SYMGPU_OK;
 }
 
-int cleanup_finish(u32 *heads, const u32 *is, i64 T, double *cg, double thr, int use_thr, u32 *mark, bool pair, const u64 *rows, int W,
+int cleanup_finish(u32 *heads, const u32 *is, bool packed, int bi, i64 T, double *cg, double thr, int use_thr, bool pair, const u64 *rows, int W,
                    const u64 *inner, i64 Ni, const u64 *outer, symgpu_op_t *out, int Wq_out) {
     hipStream_t st = ctx().stream;
-    hipLaunchKernelGGL(k_segsum_heads, dim3(grid_for(T)), dim3(256), 0, st, heads, is, T, cg, thr, use_thr, mark);
+    const i64 n_words = (T + 31) / 32;
+    Scratch markbits, wordprefix;
+    SG_TRY(markbits.alloc((size_t)n_words * 4));
+    SG_TRY(wordprefix.alloc((size_t)n_words * 4));
+    HIP_TRY(hipMemsetAsync(markbits.p, 0, (size_t)n_words * 4, st));
+    {
+        const i64 n_chunks = (T + 63) / 64;
+        const i64 cpw = (n_chunks + 32767) / 32768;               // ~32k wavefronts, each on a contiguous range of chunks
+        const i64 n_waves = (n_chunks + cpw - 1) / cpw;
+        const dim3 gs((unsigned)((n_waves + 3) / 4));
+        if (packed)
+            hipLaunchKernelGGL(k_segsum_heads<true>, gs, dim3(256), 0, st, heads, is, T, cg, thr, use_thr, markbits.as<u32>(), bi, (u32)Ni, cpw);
+        else
+            hipLaunchKernelGGL(k_segsum_heads<false>, gs, dim3(256), 0, st, heads, is, T, cg, thr, use_thr, markbits.as<u32>(), 0, 1u, cpw);
+    }
+    hipLaunchKernelGGL(k_popc_words, dim3(grid_for(n_words)), dim3(256), 0, st, markbits.as<u32>(), n_words, wordprefix.as<u32>());
     KERNEL_CHECK();
     Scratch total;
     SG_TRY(total.alloc(16));
-    SG_TRY(exclusive_scan_u32(mark, mark, T, total.as<u32>()));
+    SG_TRY(exclusive_scan_u32(wordprefix.as<u32>(), wordprefix.as<u32>(), n_words, total.as<u32>()));
     u32 n_out32 = 0;
     HIP_TRY(hipMemcpyAsync(&n_out32, total.p, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -316,16 +460,23 @@ int cleanup_finish(u32 *heads, const u32 *is, i64 T, double *cg, double thr, int
         Scratch src;
         int rc = src.alloc((size_t)n_out * 4);
         if (rc != SYMGPU_OK) { symgpu_op_free(res); return rc; }
-        hipLaunchKernelGGL(k_emit_heads, dim3(grid_for(T)), dim3(256), 0, st, heads, is, T, cg, mark, res->coeff, src.as<u32>());
-        const int Wq = W / 2;
-        if (pair)
-            hipLaunchKernelGGL(k_gather_rows<true>, dim3(grid_for(n_out * Wq)), dim3(256), 0, st, src.as<u32>(), n_out, Wq,
-                               (const u32x4 *)nullptr, reinterpret_cast<const u32x4 *>(inner), Ni, reinterpret_cast<const u32x4 *>(outer),
-                               reinterpret_cast<u32x4 *>(res->rows));
+        if (packed)
+            hipLaunchKernelGGL(k_emit_heads<true>, dim3(grid_for(T)), dim3(256), 0, st, heads, is, T, cg, markbits.as<u32>(), wordprefix.as<u32>(),
+                               res->coeff, src.as<u32>(), bi, (u32)Ni);
         else
-            hipLaunchKernelGGL(k_gather_rows<false>, dim3(grid_for(n_out * Wq)), dim3(256), 0, st, src.as<u32>(), n_out, Wq,
-                               reinterpret_cast<const u32x4 *>(rows), (const u32x4 *)nullptr, (i64)1, (const u32x4 *)nullptr,
-                               reinterpret_cast<u32x4 *>(res->rows));
+            hipLaunchKernelGGL(k_emit_heads<false>, dim3(grid_for(T)), dim3(256), 0, st, heads, is, T, cg, markbits.as<u32>(), wordprefix.as<u32>(),
+                               res->coeff, src.as<u32>(), 0, 1u);
+        const int Wq = W / 2;
+        const dim3 gg((unsigned)((n_out * Wq + 255) / 256));
+        const u32x4 *pin = reinterpret_cast<const u32x4 *>(inner), *pout = reinterpret_cast<const u32x4 *>(outer);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(res->rows);
+        if (packed)
+            hipLaunchKernelGGL((k_gather_rows<true, true>), gg, dim3(256), 0, st, src.as<u32>(), n_out, Wq, (const u32x4 *)nullptr, pin, (u32)Ni, pout, dst, bi);
+        else if (pair)
+            hipLaunchKernelGGL((k_gather_rows<true, false>), gg, dim3(256), 0, st, src.as<u32>(), n_out, Wq, (const u32x4 *)nullptr, pin, (u32)Ni, pout, dst, 0);
+        else
+            hipLaunchKernelGGL((k_gather_rows<false, false>), gg, dim3(256), 0, st, src.as<u32>(), n_out, Wq, reinterpret_cast<const u32x4 *>(rows),
+                               (const u32x4 *)nullptr, 1u, (const u32x4 *)nullptr, dst, 0);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);   // src is freed on return; keep ordering simple
         if (e != hipSuccess) { symgpu_op_free(res); return hip_fail(e, "cleanup emit/gather", __FILE__, __LINE__); }
@@ -351,14 +502,25 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         *out = res;
         return SYMGPU_OK;
     }
-    Scratch keys, keys2, idx, idx2, heads, collision, cg;
+    // pair mode sorts PACKED keys (top 32 hash bits | o | i) unless the index fields need more than 32 bits or a long mixed
+    // prefix run forced the 64-bit fallback
+    int bi = 0, bo = 0;
+    while (pair && ((i64)1 << bi) < Ni) ++bi;
+    while (pair && ((i64)1 << bo) < No) ++bo;
+    bool packed = pair && bi + bo <= 32 && bi < 32;
+    Scratch keys, keys2, idx, idx2, heads, collision, cg, hI, hO;
     SG_TRY(keys.alloc((size_t)T * 8));
     SG_TRY(keys2.alloc((size_t)T * 8));
-    SG_TRY(idx.alloc((size_t)T * 4));
-    SG_TRY(idx2.alloc((size_t)T * 4));
     SG_TRY(heads.alloc((size_t)T * 4));
     SG_TRY(collision.alloc(16));
     SG_TRY(cg.alloc((size_t)T * 16));
+    if (pair) {
+        SG_TRY(hI.alloc((size_t)Ni * 8));
+        SG_TRY(hO.alloc((size_t)No * 8));
+    } else {
+        SG_TRY(idx.alloc((size_t)T * 4));
+        SG_TRY(idx2.alloc((size_t)T * 4));
+    }
     u64 *ks = nullptr;
     u32 *is = nullptr;
     u64 seed = ctx().hash_tab ? ctx().hash_seed : 1;
@@ -373,48 +535,69 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
     }
     for (int attempt = 0; attempt < 6 && !ok; ++attempt) {
         SG_TRY(ensure_hash_tables(seed));
+        const int nbits = (packed && nb > 32) ? 32 : nb;      // a packed key carries 32 hash bits
+        bool in_tmp = false;
         if (pair) {
-            Scratch hI, hO;
-            SG_TRY(hI.alloc((size_t)Ni * 8));
-            SG_TRY(hO.alloc((size_t)No * 8));
             SG_TRY(hash_rows(inner, Ni, W, hI.as<u64>()));
             SG_TRY(hash_rows(outer, No, W, hO.as<u64>()));
-            hipLaunchKernelGGL(k_pair_keys, dim3(grid_for(T)), dim3(256), 0, st, hI.as<u64>(), Ni, hO.as<u64>(), T, keys.as<u64>(), idx.as<u32>());
-            KERNEL_CHECK();
+            if (packed) {
+                hipLaunchKernelGGL(k_pair_keys_packed, dim3((unsigned)((Ni + 255) / 256), (unsigned)(No < 65535 ? No : 65535)), dim3(256), 0, st,
+                                   hI.as<u64>(), (u32)Ni, hO.as<u64>(), (u32)No, bi, keys.as<u64>());
+                KERNEL_CHECK();
+                SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), T, 64 - nbits, 64, &in_tmp));
+            } else {
+                if (!idx.p) {
+                    SG_TRY(idx.alloc((size_t)T * 4));
+                    SG_TRY(idx2.alloc((size_t)T * 4));
+                }
+                hipLaunchKernelGGL(k_pair_keys, dim3(grid_for(T)), dim3(256), 0, st, hI.as<u64>(), Ni, hO.as<u64>(), T, keys.as<u64>(), idx.as<u32>());
+                KERNEL_CHECK();
+            }
         } else {
             SG_TRY(hash_rows(rows, T, W, keys.as<u64>()));
             hipLaunchKernelGGL(k_iota_keys_plain, dim3(grid_for(T)), dim3(256), 0, st, idx.as<u32>(), T);
             KERNEL_CHECK();
         }
-        bool in_tmp = false;
-        SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), T, 64 - nb, 64, &in_tmp));
+        if (!packed) SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), T, 64 - nbits, 64, &in_tmp));
         ks = in_tmp ? keys2.as<u64>() : keys.as<u64>();
-        is = in_tmp ? idx2.as<u32>() : idx.as<u32>();
+        is = packed ? reinterpret_cast<u32 *>(ks) : (in_tmp ? idx2.as<u32>() : idx.as<u32>());
         HIP_TRY(hipMemsetAsync(collision.p, 0, 16, st));
-        if (nb < 64) {
+        if (nbits < 64) {
             // `heads` doubles as the run-start marker array here (it is overwritten by k_heads afterwards)
             HIP_TRY(hipMemsetAsync(heads.p, 0, (size_t)T * 4, st));
-            hipLaunchKernelGGL(k_fixup_mark, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nb, heads.as<u32>());
-            hipLaunchKernelGGL(k_fixup_sort, dim3(grid_for(T)), dim3(256), 0, st, ks, is, T, 64 - nb, heads.as<u32>(), collision.as<u32>() + 1);
+            if (packed) {
+                hipLaunchKernelGGL(k_fixup_mark<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<u32>(), hI.as<u64>(), hO.as<u64>(), bi);
+                hipLaunchKernelGGL(k_fixup_sort<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, (u32 *)nullptr, T, 64 - nbits, heads.as<u32>(),
+                                   collision.as<u32>() + 1, hI.as<u64>(), hO.as<u64>(), bi);
+            } else {
+                hipLaunchKernelGGL(k_fixup_mark<false>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<u32>(), (const u64 *)nullptr,
+                                   (const u64 *)nullptr, 0);
+                hipLaunchKernelGGL(k_fixup_sort<false>, dim3(grid_for(T)), dim3(256), 0, st, ks, is, T, 64 - nbits, heads.as<u32>(),
+                                   collision.as<u32>() + 1, (const u64 *)nullptr, (const u64 *)nullptr, 0);
+            }
             KERNEL_CHECK();
         }
         {
-            int G = 8;
-            while (G < W && G < 64) G <<= 1;
+            int G = 1;                                   // lanes per verified candidate: one 16-byte chunk each
+            while (G < W / 2 && G < 64) G <<= 1;
             i64 gh = ((T + 63) / 64 + 3) / 4;
             if (gh > 16384) gh = 16384;
-            if (pair)
-                hipLaunchKernelGGL(k_heads<true>, dim3((unsigned)gh), dim3(256), 0, st, ks, is, T, (const u64 *)nullptr, W, inner, Ni, outer, G,
-                                   coeff, cg.as<double>(), heads.as<u32>(), collision.as<u32>());
+            if (packed)
+                hipLaunchKernelGGL((k_heads<true, true>), dim3((unsigned)gh), dim3(256), 0, st, ks, (const u32 *)nullptr, T, (const u64 *)nullptr, W,
+                                   inner, (u32)Ni, outer, G, coeff, cg.as<double>(), heads.as<u32>(), collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), bi);
+            else if (pair)
+                hipLaunchKernelGGL((k_heads<true, false>), dim3((unsigned)gh), dim3(256), 0, st, ks, is, T, (const u64 *)nullptr, W, inner, (u32)Ni, outer, G,
+                                   coeff, cg.as<double>(), heads.as<u32>(), collision.as<u32>(), (const u64 *)nullptr, (const u64 *)nullptr, 0);
             else
-                hipLaunchKernelGGL(k_heads<false>, dim3((unsigned)gh), dim3(256), 0, st, ks, is, T, rows, W, (const u64 *)nullptr, (i64)1,
-                                   (const u64 *)nullptr, G, coeff, cg.as<double>(), heads.as<u32>(), collision.as<u32>());
+                hipLaunchKernelGGL((k_heads<false, false>), dim3((unsigned)gh), dim3(256), 0, st, ks, is, T, rows, W, (const u64 *)nullptr, 1u,
+                                   (const u64 *)nullptr, G, coeff, cg.as<double>(), heads.as<u32>(), collision.as<u32>(), (const u64 *)nullptr,
+                                   (const u64 *)nullptr, 0);
         }
         KERNEL_CHECK();
         u32 hflags[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(hflags, collision.p, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (hflags[1]) { nb = 64; continue; }       // a long mixed prefix run: redo with a full 64-bit sort, same seed
+        if (hflags[1]) { nb = 64; packed = false; continue; }   // a long mixed prefix run: redo with a full 64-bit sort, same seed
         ok = (hflags[0] == 0);
         if (!ok) ++seed;                            // genuine 64-bit hash collision: reseed and retry
     }
@@ -422,10 +605,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         set_error("cleanup: 64-bit row-hash collision survived 4 reseeds");
         return SYMGPU_E_COLLISION;
     }
-    Scratch mark;
-    SG_TRY(mark.alloc((size_t)T * 4));
-    HIP_TRY(hipMemsetAsync(mark.p, 0, (size_t)T * 4, st));
-    return cleanup_finish(heads.as<u32>(), is, T, cg.as<double>(), thr, use_thr, mark.as<u32>(), pair, rows, W, inner, Ni, outer, out, Wq_out);
+    return cleanup_finish(heads.as<u32>(), is, packed, bi, T, cg.as<double>(), thr, use_thr, pair, rows, W, inner, Ni, outer, out, Wq_out);
 }
 
 }  // namespace symgpu

@@ -105,6 +105,7 @@ int bit_transpose(const u64 *in, i64 R, i64 Wc_in, u64 *out, i64 Wc_out);
 int exclusive_scan_u32(const u32 *in, u32 *out, i64 n, u32 *total_dev /* may be null: device u32 */);
 int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp, i64 n, int begin_bit, int end_bit,
                              bool *result_in_tmp);
+int radix_sort_keys_u64(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp);
 
 // commute.hip
 int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits);

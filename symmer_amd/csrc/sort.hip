@@ -1,4 +1,4 @@
-// sort.hip — device-wide exclusive scan and stable LSD radix sort of (u64 key, u32 value) pairs.
+// sort.hip — device-wide exclusive scan and stable LSD radix sort of (u64 key, u32 value) pairs or bare u64 keys.
 //
 // Used by term cleanup (reference: symplectic_cleanup, symmer/operators/utils.py:230-279) to group equal
 // rows: keys are 64-bit GF(2)-linear row hashes, values are input indices.  The sort is STABLE, so inside
@@ -130,11 +130,12 @@ __global__ __launch_bounds__(256) void k_rs_hist(const u64 *__restrict__ keys, i
     tile_hist[(i64)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];   // digit-major
 }
 
+template <bool HAS_VALS>
 __global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ keys, const u32 *__restrict__ vals, i64 n, int shift,
                                                      i64 n_tiles, const u32 *__restrict__ tile_off /* scanned, digit-major */,
                                                      u64 *__restrict__ out_keys, u32 *__restrict__ out_vals) {
     __shared__ u64 s_key[RS_TILE];
-    __shared__ u32 s_val[RS_TILE];
+    __shared__ u32 s_val[HAS_VALS ? RS_TILE : 1];
     __shared__ u32 s_cnt[4][256];      // per-wave running digit counters, then per-wave exclusive offsets
     __shared__ u32 s_dig_off[256];     // exclusive offset of each digit inside the tile
     __shared__ u32 s_gbase[256];       // global base of each digit for this tile
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ keys
         const i64 idx = tile_base + (i64)wave * RS_WSEG + r * 64 + lane;
         const bool valid = idx < n;
         key[r] = valid ? keys[idx] : ~0ULL;
-        val[r] = valid ? vals[idx] : 0u;
+        val[r] = (HAS_VALS && valid) ? vals[idx] : 0u;
         const u32 d = (u32)(key[r] >> shift) & 255u;
         u64 m = __ballot(valid);
 #pragma unroll
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ keys
             const u32 d = (u32)(key[r] >> shift) & 255u;
             const u32 slot = s_dig_off[d] + s_cnt[wave][d] + pos[r];
             s_key[slot] = key[r];
-            s_val[slot] = val[r];
+            if (HAS_VALS) s_val[slot] = val[r];
         }
     }
     __syncthreads();
@@ -211,13 +212,13 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ keys
             const u32 d = (u32)(kk >> shift) & 255u;
             const i64 g = (i64)s_gbase[d] + (s - (int)s_dig_off[d]);
             out_keys[g] = kk;
-            out_vals[g] = s_val[s];
+            if (HAS_VALS) out_vals[g] = s_val[s];
         }
     }
 }
 
 // Sort n pairs by key bits [begin_bit, end_bit) (multiple of 8 wide), stable.  Ping-pongs between the
-// given buffers; *result_in_tmp tells where the sorted data ended up.
+// given buffers; *result_in_tmp tells where the sorted data ended up.  vals == nullptr: keys only.
 int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp, i64 n, int begin_bit, int end_bit,
                              bool *result_in_tmp) {
     *result_in_tmp = false;
@@ -237,7 +238,11 @@ int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp,
         hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)n_tiles), dim3(256), 0, st, ksrc, n, shift, n_tiles, hist.as<u32>());
         KERNEL_CHECK();
         SG_TRY(exclusive_scan_u32(hist.as<u32>(), hist.as<u32>(), n_tiles * 256, nullptr));
-        hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)n_tiles), dim3(256), 0, st, ksrc, vsrc, n, shift, n_tiles, hist.as<u32>(), kdst, vdst);
+        if (vals)
+            hipLaunchKernelGGL(k_rs_scatter<true>, dim3((unsigned)n_tiles), dim3(256), 0, st, ksrc, vsrc, n, shift, n_tiles, hist.as<u32>(), kdst, vdst);
+        else
+            hipLaunchKernelGGL(k_rs_scatter<false>, dim3((unsigned)n_tiles), dim3(256), 0, st, ksrc, (const u32 *)nullptr, n, shift, n_tiles,
+                               hist.as<u32>(), kdst, (u32 *)nullptr);
         KERNEL_CHECK();
         u64 *tk = ksrc; ksrc = kdst; kdst = tk;
         u32 *tv = vsrc; vsrc = vdst; vdst = tv;
@@ -245,6 +250,10 @@ int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp,
     }
     *result_in_tmp = in_tmp;
     return SYMGPU_OK;
+}
+
+int radix_sort_keys_u64(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp) {
+    return radix_sort_pairs_u64_u32(keys, nullptr, keys_tmp, nullptr, n, begin_bit, end_bit, result_in_tmp);
 }
 
 }  // namespace symgpu

@@ -33,6 +33,12 @@ if 'cfg3' in what:
         h = ctypes.c_void_p(); _lib.check(lib.symgpu_mul_cleanup_dev(A.handle, A.handle, 1, 1e-15, 1, ctypes.byref(h))); DeviceOp(h).free()
     t = timed(cfg3, 3); print(f'cfg3 mul+cleanup 1e8 pairs: {t*1e3:.2f} ms  {1e8/t:.3e} pairs/s', flush=True)
     A.free()
+if 'cfg3x' in what:
+    A = DeviceOp.random(10000, 1000, 0.3, seed=1237)
+    def cfg3x():
+        h = ctypes.c_void_p(); _lib.check(lib.symgpu_mul_cleanup_dev(A.handle, A.handle, 1, -1.0, 1, ctypes.byref(h))); DeviceOp(h).free()
+    t = timed(cfg3x, 3); print(f'cfg3x (no atomics experiment) {t*1e3:.2f} ms', flush=True)
+    A.free()
 if 'rotate' in what:
     from symmer_amd import packing
     rng = np.random.default_rng(5)
