@@ -436,3 +436,16 @@ def test_mul_cleanup_tiled_over_outer_operand():
     rows, coeff = kernels.mul_cleanup(A.packed, A.coeff_vec, A.packed[:M], A.coeff_vec[:M], True, 1e-15, max_pairs=7000)
     erows, ecoeff = oc.mul(A.packed, A.coeff_vec, A.packed[:M], A.coeff_vec[:M])
     assert np.array_equal(rows, erows) and np.array_equal(coeff, ecoeff)
+
+
+@pytest.mark.parametrize('T,n', [(3_000_000, 2), (2_500_001, 1), (1_000_000, 40)])
+def test_cleanup_long_segments_sum_in_input_order(T, n):
+    """Segments of 1e5+ equal rows span many 64-position chunks and the chunk ranges of several wavefronts; with Gaussian
+    coefficients the result only matches bit for bit if every segment is summed sequentially in ascending input order."""
+    rng = np.random.default_rng(77 + n)
+    base = packing.pack_rows(rng.random((16, 2 * n)) < 0.5)
+    rows = base[rng.integers(0, 16, T)]
+    coeff = rng.standard_normal(T) + 1j * rng.standard_normal(T)
+    r, c = kernels.cleanup(rows, coeff, 1e-15)
+    er, ec = oc.cleanup(rows, coeff, 1e-15)
+    assert np.array_equal(r, er) and np.array_equal(c, ec)
