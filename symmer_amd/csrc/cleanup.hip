@@ -131,24 +131,22 @@ __global__ void k_pair_keys(const u64 *__restrict__ hI, i64 Ni, const u64 *__res
     }
 }
 
-// PACKED pair keys: one u64 per pair = (top 32 hash bits << 32) | (o << bi) | i   (bi = bits of Ni-1; needs bi + bits of
-// No-1 <= 32).  The radix sort then moves 8 instead of 12 bytes per element and pass, nothing on the path divides by Ni,
-// and the full 64-bit key of a sorted element is recomputed from its (i, o) fields with two lookups in the cache-resident
-// per-operand hash tables whenever it is needed.  The LSD sort only touches the hash bits and is stable, so equal keys stay
-// in ascending pair-index order exactly as with separate index values.
-__device__ __forceinline__ u64 packed_full_key(const u64 *__restrict__ hI, const u64 *__restrict__ hO, u32 w, int bi) {
-    return hI[w & ((1u << bi) - 1u)] ^ hO[w >> bi];
-}
-__device__ __forceinline__ u32 packed_index(u32 w, int bi, u32 Ni) { return (w >> bi) * Ni + (w & ((1u << bi) - 1u)); }
-
-__global__ __launch_bounds__(256) void k_pair_keys_packed(const u64 *__restrict__ hI, u32 Ni, const u64 *__restrict__ hO, u32 No, int bi,
-                                                           u64 *__restrict__ keys) {
-    const u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= Ni) return;
-    const u64 hi = hI[i];
-    for (u32 o = blockIdx.y; o < No; o += gridDim.y)
-        keys[(u64)o * Ni + i] = ((hi ^ hO[o]) & 0xFFFFFFFF00000000ULL) | (u64)((o << bi) | i);
-}
+// PACKED pair keys (written by product.hip's k_mul_coeff<.., KEYS>): one u64 per pair
+//     [hash: 64-F bits][e: 2 bits][o: bo bits][i: bi bits],   F = bi + bo + 2,  bi/bo = bits of Ni-1 / No-1  (bi + bo <= 32)
+// The radix sort then moves 8 instead of 12 bytes per element and pass, nothing on the path divides by Ni, the 16-byte pair
+// coefficient is never materialised (c_i * c_o * i^e is rebuilt from e and the two cache-resident operand tables when the
+// sorted order is known), and the full 64-bit key of a sorted element is recomputed from its (i, o) fields with two lookups
+// in the per-operand hash tables whenever it is needed.  The LSD sort only touches hash bits and is stable, so equal keys
+// stay in ascending pair-index order exactly as with separate index values.
+struct PackedLayout {
+    int bi, bo;
+    __host__ __device__ int F() const { return bi + bo + 2; }
+    __device__ __forceinline__ u32 i(u64 k) const { return (u32)(k & ((1ULL << bi) - 1ULL)); }
+    __device__ __forceinline__ u32 o(u64 k) const { return (u32)((k >> bi) & ((1ULL << bo) - 1ULL)); }
+    __device__ __forceinline__ int e(u64 k) const { return (int)((k >> (bi + bo)) & 3ULL); }
+    __device__ __forceinline__ u32 fields(u64 k) const { return (u32)(k & ((1ULL << (bi + bo)) - 1ULL)); }   // (o << bi) | i
+    __device__ __forceinline__ u64 full_key(const u64 *__restrict__ hI, const u64 *__restrict__ hO, u64 k) const { return hI[i(k)] ^ hO[o(k)]; }
+};
 
 // head flags + exact verification of equal-key neighbours + coefficient gather into sorted order.
 // PAIR: row(t) = inner[t % Ni] ^ outer[t / Ni].  One wavefront owns 64 consecutive sorted positions; the positions whose
@@ -161,13 +159,15 @@ __device__ __forceinline__ bool differs(u32x4 a, u32x4 b) {
     const u32x4 d = a ^ b;
     return (d.x | d.y | d.z | d.w) != 0u;
 }
-// PACKED (implies PAIR): keys are k_pair_keys_packed values; idx is unused, full keys come from hI / hO.
+// PACKED (implies PAIR): keys are packed pair keys; idx and coeff are unused: the input index, the full key and the pair
+// coefficient c_i * c_o * i^e come from the key's fields and the operand tables hI / hO / ci / co.
 template <bool PAIR, bool PACKED>
 __global__ __launch_bounds__(256) void k_heads(const u64 *__restrict__ keys, const u32 *__restrict__ idx, i64 T, const u64 *__restrict__ rows, int W,
                                                 const u64 *__restrict__ inner, u32 Ni, const u64 *__restrict__ outer, int G,
                                                 const double *__restrict__ coeff, double *__restrict__ cg,
                                                 u32 *__restrict__ heads, u32 *__restrict__ collision,
-                                                const u64 *__restrict__ hI, const u64 *__restrict__ hO, int bi) {
+                                                const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L,
+                                                const double *__restrict__ ci, const double *__restrict__ co) {
     const int lane = threadIdx.x & 63;
     const int gi = lane / G, gl = lane % G;
     const int C = W / 2;                                             // 16-byte chunks per row
@@ -177,14 +177,12 @@ __global__ __launch_bounds__(256) void k_heads(const u64 *__restrict__ keys, con
         const i64 s = chunk * 64 + lane;
         const bool valid = s < T;
         // this position: input index t1 (PAIR: as (i1, o1)), full key f1
-        u64 f1 = 0;
+        u64 f1 = 0, k1 = 0;
         u32 t1 = 0, i1 = 0, o1 = 0;
-        auto decode = [&](i64 pos, u64 &f, u32 &t, u32 &ii, u32 &oo) {
-            const u64 k = keys[pos];
+        auto decode = [&](i64 pos, u64 &k, u64 &f, u32 &t, u32 &ii, u32 &oo) {
+            k = keys[pos];
             if (PACKED) {
-                const u32 w = (u32)k;
-                ii = w & ((1u << bi) - 1u); oo = w >> bi;
-                t = oo * Ni + ii;
+                ii = L.i(k); oo = L.o(k);
                 f = hI[ii] ^ hO[oo];
             } else {
                 t = idx[pos];
@@ -192,15 +190,18 @@ __global__ __launch_bounds__(256) void k_heads(const u64 *__restrict__ keys, con
                 if (PAIR) { oo = t / Ni; ii = t - oo * Ni; }
             }
         };
-        if (valid) decode(s, f1, t1, i1, o1);
+        if (valid) decode(s, k1, f1, t1, i1, o1);
         // predecessor: neighbour lane, lane 0 decodes position s-1 itself
         u64 f0 = __shfl_up(f1, 1);
         u32 t0 = __shfl_up(t1, 1), i0 = __shfl_up(i1, 1), o0 = __shfl_up(o1, 1);
-        if (lane == 0 && valid && s > 0) decode(s - 1, f0, t0, i0, o0);
+        if (lane == 0 && valid && s > 0) { u64 k0; decode(s - 1, k0, f0, t0, i0, o0); }
         const bool eq = valid && s > 0 && f1 == f0;
         if (valid) {
             heads[s] = eq ? 0u : 1u;
-            reinterpret_cast<double2 *>(cg)[s] = reinterpret_cast<const double2 *>(coeff)[t1];
+            double2 c;
+            if (PACKED) pair_coefficient(ci[2 * i1], ci[2 * i1 + 1], co[2 * o1], co[2 * o1 + 1], L.e(k1), c.x, c.y);
+            else c = reinterpret_cast<const double2 *>(coeff)[t1];
+            reinterpret_cast<double2 *>(cg)[s] = c;
         }
         // P * P: row(i, o) == row(o, i) by commutativity of XOR when both operands are the same array — nothing to read
         const bool trivially_equal = PAIR && inner == outer && i1 == o0 && o1 == i0;
@@ -235,15 +236,15 @@ __global__ __launch_bounds__(256) void k_heads(const u64 *__restrict__ keys, con
 // Runs longer than FIX_MAX that are not uniform raise `fallback`: the caller then redoes a full 64-bit sort.
 constexpr int FIX_MAX = 48;
 // phase 1 (read-only): a position whose key differs from its predecessor's INSIDE a prefix run marks the run's start.
-// PACKED: keys are k_pair_keys_packed values (full key recomputed from the pair index), there is no separate idx array.
+// PACKED: keys are packed pair keys (full key recomputed from the (i, o) fields), there is no separate idx array.
 template <bool PACKED>
 __global__ void k_fixup_mark(const u64 *__restrict__ keys, i64 T, int shift, u32 *__restrict__ need,
-                             const u64 *__restrict__ hI, const u64 *__restrict__ hO, int bi) {
+                             const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L) {
     for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
         if (s == 0) continue;
         const u64 k = keys[s], kp = keys[s - 1];
         if ((k >> shift) != (kp >> shift)) continue;
-        if (PACKED ? (packed_full_key(hI, hO, (u32)k, bi) == packed_full_key(hI, hO, (u32)kp, bi)) : (k == kp)) continue;
+        if (PACKED ? (L.full_key(hI, hO, k) == L.full_key(hI, hO, kp)) : (k == kp)) continue;
         i64 b = s - 1;
         while (b > 0 && (keys[b - 1] >> shift) == (kp >> shift)) --b;
         need[b] = 1u;
@@ -252,7 +253,7 @@ __global__ void k_fixup_mark(const u64 *__restrict__ keys, i64 T, int shift, u32
 // phase 2: the marked run starts (one thread per mixed run) sort their run
 template <bool PACKED>
 __global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 T, int shift, const u32 *__restrict__ need, u32 *__restrict__ fallback,
-                             const u64 *__restrict__ hI, const u64 *__restrict__ hO, int bi) {
+                             const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L) {
     for (i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x; b < T; b += (i64)gridDim.x * blockDim.x) {
         if (!need[b]) continue;
         const u64 pfx = keys[b] >> shift;
@@ -262,9 +263,9 @@ __global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 
         for (i64 a = b + 1; a < e; ++a) {                                     // stable insertion sort by full key
             const u64 ka = keys[a];
             if (PACKED) {
-                const u64 fa = packed_full_key(hI, hO, (u32)ka, bi);
+                const u64 fa = L.full_key(hI, hO, ka);
                 i64 c = a - 1;
-                while (c >= b && packed_full_key(hI, hO, (u32)keys[c], bi) > fa) { keys[c + 1] = keys[c]; --c; }
+                while (c >= b && L.full_key(hI, hO, keys[c]) > fa) { keys[c + 1] = keys[c]; --c; }
                 keys[c + 1] = ka;
             } else {
                 const u32 ia = idx[a];
@@ -285,22 +286,26 @@ __global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 
 // the previous wave and are skipped.  The sum replaces cg[s] at the head; heads[s] becomes 2 if the term survives the strict
 // |c| > thr test (1 otherwise) and the first-occurrence index of a surviving term sets its bit in `markbits` (T bits:
 // 12.5 MB for 1e8 terms, cache resident, instead of a 4-byte flag per input index scattered over 400 MB).
-// PACKED: idx points at the packed pair keys (u64 per position, low word = (o << bi) | i).
+// PACKED: idx is unused, the input index comes from the (o, i) fields of the packed pair keys pk.
 template <bool PACKED>
 __device__ __forceinline__ void segment_close(i64 pos, double re, double im, u32 *__restrict__ heads, const u32 *__restrict__ idx,
-                                              double *__restrict__ cg, double thr, int use_thr, u32 *__restrict__ markbits, int bi, u32 Ni) {
+                                              const u64 *__restrict__ pk, double *__restrict__ cg, double thr, int use_thr,
+                                              u32 *__restrict__ markbits, PackedLayout L, u32 Ni) {
     const bool keep = use_thr ? (hypot(re, im) > thr) : true;
     if (!keep) return;
     double2 o; o.x = re; o.y = im;
     reinterpret_cast<double2 *>(cg)[pos] = o;
     heads[pos] = 2u;
-    const u32 first = PACKED ? packed_index(idx[2 * pos], bi, Ni) : idx[pos];
+    u32 first;
+    if (PACKED) { const u64 k = pk[pos]; first = L.o(k) * Ni + L.i(k); }
+    else first = idx[pos];
     atomicOr(&markbits[first >> 5], 1u << (first & 31u));
 }
 
 template <bool PACKED>
-__global__ __launch_bounds__(256) void k_segsum_heads(u32 *__restrict__ heads, const u32 *__restrict__ idx, i64 T, double *__restrict__ cg, double thr,
-                                                       int use_thr, u32 *__restrict__ markbits, int bi, u32 Ni, i64 chunks_per_wave) {
+__global__ __launch_bounds__(256) void k_segsum_heads(u32 *__restrict__ heads, const u32 *__restrict__ idx, const u64 *__restrict__ pk, i64 T,
+                                                       double *__restrict__ cg, double thr, int use_thr, u32 *__restrict__ markbits, PackedLayout L,
+                                                       u32 Ni, i64 chunks_per_wave) {
     const int lane = threadIdx.x & 63;
     const i64 n_chunks = (T + 63) / 64;
     const i64 c0 = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * chunks_per_wave;
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(256) void k_segsum_heads(u32 *__restrict__ heads, c
     for (i64 chunk = c0;; ++chunk) {
         if (chunk >= c1 && !open) break;
         if (chunk >= n_chunks) {        // the carried segment ends with the data
-            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, cg, thr, use_thr, markbits, bi, Ni);
+            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni);
             break;
         }
         const i64 s = chunk * 64 + lane;
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(256) void k_segsum_heads(u32 *__restrict__ heads, c
         }
         if (m == 0ULL) continue;                                  // no head in this chunk
         if (open) {
-            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, cg, thr, use_thr, markbits, bi, Ni);
+            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni);
             open = false;
         }
         if (chunk >= c1) break;                                   // beyond the own range only the carry had to be closed
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256) void k_segsum_heads(u32 *__restrict__ heads, c
         // the last head of a full chunk may continue in the next chunk: carry it; everything else closes here
         const int last = 63 - __builtin_clzll(m);
         const bool carry = (chunk * 64 + 64 <= T) && true;       // a full chunk: lane `last` is a real head whose run reaches lane 63
-        if (is_head && !(carry && lane == last)) segment_close<PACKED>(s, re, im, heads, idx, cg, thr, use_thr, markbits, bi, Ni);
+        if (is_head && !(carry && lane == last)) segment_close<PACKED>(s, re, im, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni);
         if (carry) {
             open = true;
             are = __shfl(re, last);
@@ -366,13 +371,14 @@ __global__ void k_popc_words(const u32 *__restrict__ bits, i64 n_words, u32 *__r
 // word prefix + popcount of the lower bits of its word
 // out_src[p]: input index of the row, PACKED: its (o << bi) | i fields (k_gather_rows then needs no division)
 template <bool PACKED>
-__global__ void k_emit_heads(const u32 *__restrict__ heads, const u32 *__restrict__ idx, i64 T, const double *__restrict__ cg,
-                             const u32 *__restrict__ markbits, const u32 *__restrict__ wordprefix, double *__restrict__ out_coeff,
-                             u32 *__restrict__ out_src, int bi, u32 Ni) {
+__global__ void k_emit_heads(const u32 *__restrict__ heads, const u32 *__restrict__ idx, const u64 *__restrict__ pk, i64 T,
+                             const double *__restrict__ cg, const u32 *__restrict__ markbits, const u32 *__restrict__ wordprefix,
+                             double *__restrict__ out_coeff, u32 *__restrict__ out_src, PackedLayout L, u32 Ni) {
     for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
         if (heads[s] != 2u) continue;
-        const u32 w = PACKED ? idx[2 * s] : idx[s];
-        const u32 first = PACKED ? packed_index(w, bi, Ni) : w;
+        u32 w, first;
+        if (PACKED) { const u64 k = pk[s]; w = L.fields(k); first = L.o(k) * Ni + L.i(k); }
+        else { w = idx[s]; first = w; }
         const u32 p = wordprefix[first >> 5] + (u32)__popc(markbits[first >> 5] & ((1u << (first & 31u)) - 1u));
         reinterpret_cast<double2 *>(out_coeff)[p] = reinterpret_cast<const double2 *>(cg)[s];
         out_src[p] = w;
@@ -426,8 +432,8 @@ int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
     return SYMGPU_OK;
 }
 
-int cleanup_finish(u32 *heads, const u32 *is, bool packed, int bi, i64 T, double *cg, double thr, int use_thr, bool pair, const u64 *rows, int W,
-                   const u64 *inner, i64 Ni, const u64 *outer, symgpu_op_t *out, int Wq_out) {
+int cleanup_finish(u32 *heads, const u32 *is, const u64 *pk, bool packed, PackedLayout L, i64 T, double *cg, double thr, int use_thr, bool pair,
+                   const u64 *rows, int W, const u64 *inner, i64 Ni, const u64 *outer, symgpu_op_t *out, int Wq_out) {
     hipStream_t st = ctx().stream;
     const i64 n_words = (T + 31) / 32;
     Scratch markbits, wordprefix;
@@ -440,9 +446,9 @@ int cleanup_finish(u32 *heads, const u32 *is, bool packed, int bi, i64 T, double
         const i64 n_waves = (n_chunks + cpw - 1) / cpw;
         const dim3 gs((unsigned)((n_waves + 3) / 4));
         if (packed)
-            hipLaunchKernelGGL(k_segsum_heads<true>, gs, dim3(256), 0, st, heads, is, T, cg, thr, use_thr, markbits.as<u32>(), bi, (u32)Ni, cpw);
+            hipLaunchKernelGGL(k_segsum_heads<true>, gs, dim3(256), 0, st, heads, is, pk, T, cg, thr, use_thr, markbits.as<u32>(), L, (u32)Ni, cpw);
         else
-            hipLaunchKernelGGL(k_segsum_heads<false>, gs, dim3(256), 0, st, heads, is, T, cg, thr, use_thr, markbits.as<u32>(), 0, 1u, cpw);
+            hipLaunchKernelGGL(k_segsum_heads<false>, gs, dim3(256), 0, st, heads, is, pk, T, cg, thr, use_thr, markbits.as<u32>(), L, 1u, cpw);
     }
     hipLaunchKernelGGL(k_popc_words, dim3(grid_for(n_words)), dim3(256), 0, st, markbits.as<u32>(), n_words, wordprefix.as<u32>());
     KERNEL_CHECK();
@@ -461,17 +467,17 @@ int cleanup_finish(u32 *heads, const u32 *is, bool packed, int bi, i64 T, double
         int rc = src.alloc((size_t)n_out * 4);
         if (rc != SYMGPU_OK) { symgpu_op_free(res); return rc; }
         if (packed)
-            hipLaunchKernelGGL(k_emit_heads<true>, dim3(grid_for(T)), dim3(256), 0, st, heads, is, T, cg, markbits.as<u32>(), wordprefix.as<u32>(),
-                               res->coeff, src.as<u32>(), bi, (u32)Ni);
+            hipLaunchKernelGGL(k_emit_heads<true>, dim3(grid_for(T)), dim3(256), 0, st, heads, is, pk, T, cg, markbits.as<u32>(), wordprefix.as<u32>(),
+                               res->coeff, src.as<u32>(), L, (u32)Ni);
         else
-            hipLaunchKernelGGL(k_emit_heads<false>, dim3(grid_for(T)), dim3(256), 0, st, heads, is, T, cg, markbits.as<u32>(), wordprefix.as<u32>(),
-                               res->coeff, src.as<u32>(), 0, 1u);
+            hipLaunchKernelGGL(k_emit_heads<false>, dim3(grid_for(T)), dim3(256), 0, st, heads, is, pk, T, cg, markbits.as<u32>(), wordprefix.as<u32>(),
+                               res->coeff, src.as<u32>(), L, 1u);
         const int Wq = W / 2;
         const dim3 gg((unsigned)((n_out * Wq + 255) / 256));
         const u32x4 *pin = reinterpret_cast<const u32x4 *>(inner), *pout = reinterpret_cast<const u32x4 *>(outer);
         u32x4 *dst = reinterpret_cast<u32x4 *>(res->rows);
         if (packed)
-            hipLaunchKernelGGL((k_gather_rows<true, true>), gg, dim3(256), 0, st, src.as<u32>(), n_out, Wq, (const u32x4 *)nullptr, pin, (u32)Ni, pout, dst, bi);
+            hipLaunchKernelGGL((k_gather_rows<true, true>), gg, dim3(256), 0, st, src.as<u32>(), n_out, Wq, (const u32x4 *)nullptr, pin, (u32)Ni, pout, dst, L.bi);
         else if (pair)
             hipLaunchKernelGGL((k_gather_rows<true, false>), gg, dim3(256), 0, st, src.as<u32>(), n_out, Wq, (const u32x4 *)nullptr, pin, (u32)Ni, pout, dst, 0);
         else
@@ -485,10 +491,10 @@ int cleanup_finish(u32 *heads, const u32 *is, bool packed, int bi, i64 T, double
     return SYMGPU_OK;
 }
 
-// plain mode: rows/coeff of T terms.  pair mode (inner != null): T = Ni*No, coeff holds the pair coefficients
-// in index order t = o*Ni + i.  *out is a fresh operator with the cleaned result.
+// plain mode: rows/coeff of T terms.  pair mode (inner != null): T = Ni*No, term t = o*Ni + i is inner[i] ^ outer[o] with
+// coefficient ci[i] * co[o] * i^e (product.hip); coeff is unused.  *out is a fresh operator with the cleaned result.
 int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *inner, i64 Ni, const u64 *outer, i64 No,
-                 double thr, int use_thr, symgpu_op_t *out, int Wq_out) {
+                 double thr, int use_thr, symgpu_op_t *out, int Wq_out, const double *ci, const double *co, int inner_is_left) {
     hipStream_t st = ctx().stream;
     const bool pair = inner != nullptr;
     if (T >= ((i64)1 << 32) - 1) {
@@ -502,13 +508,14 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         *out = res;
         return SYMGPU_OK;
     }
-    // pair mode sorts PACKED keys (top 32 hash bits | o | i) unless the index fields need more than 32 bits or a long mixed
-    // prefix run forced the 64-bit fallback
-    int bi = 0, bo = 0;
-    while (pair && ((i64)1 << bi) < Ni) ++bi;
-    while (pair && ((i64)1 << bo) < No) ++bo;
-    bool packed = pair && bi + bo <= 32 && bi < 32;
-    Scratch keys, keys2, idx, idx2, heads, collision, cg, hI, hO;
+    // pair mode sorts PACKED keys (hash | e | o | i) unless the index fields need more than 32 bits or a long mixed prefix
+    // run forced the 64-bit fallback (then the pair coefficients are materialised and sorted by separate index values)
+    PackedLayout L;
+    L.bi = 0; L.bo = 0;
+    while (pair && ((i64)1 << L.bi) < Ni) ++L.bi;
+    while (pair && ((i64)1 << L.bo) < No) ++L.bo;
+    bool packed = pair && L.bi + L.bo <= 32 && L.bi < 32;
+    Scratch keys, keys2, idx, idx2, heads, collision, cg, hI, hO, pair_coeff;
     SG_TRY(keys.alloc((size_t)T * 8));
     SG_TRY(keys2.alloc((size_t)T * 8));
     SG_TRY(heads.alloc((size_t)T * 4));
@@ -535,20 +542,26 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
     }
     for (int attempt = 0; attempt < 6 && !ok; ++attempt) {
         SG_TRY(ensure_hash_tables(seed));
-        const int nbits = (packed && nb > 32) ? 32 : nb;      // a packed key carries 32 hash bits
+        const int hash_bits = packed ? 64 - L.F() : 64;       // a packed key carries 64 - F >= 30 hash bits
+        const int nbits = nb > hash_bits ? hash_bits : nb;
         bool in_tmp = false;
         if (pair) {
             SG_TRY(hash_rows(inner, Ni, W, hI.as<u64>()));
             SG_TRY(hash_rows(outer, No, W, hO.as<u64>()));
             if (packed) {
-                hipLaunchKernelGGL(k_pair_keys_packed, dim3((unsigned)((Ni + 255) / 256), (unsigned)(No < 65535 ? No : 65535)), dim3(256), 0, st,
-                                   hI.as<u64>(), (u32)Ni, hO.as<u64>(), (u32)No, bi, keys.as<u64>());
-                KERNEL_CHECK();
+                PairKeyArgs ka;
+                ka.hI = hI.as<u64>(); ka.hO = hO.as<u64>(); ka.keys = keys.as<u64>(); ka.bi = L.bi; ka.bo = L.bo; ka.o_base = 0;
+                SG_TRY(mul_keys_dev(inner, Ni, outer, No, W / 2, inner_is_left, ka));
                 SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), T, 64 - nbits, 64, &in_tmp));
             } else {
                 if (!idx.p) {
                     SG_TRY(idx.alloc((size_t)T * 4));
                     SG_TRY(idx2.alloc((size_t)T * 4));
+                }
+                if (!pair_coeff.p) {
+                    SG_TRY(pair_coeff.alloc((size_t)T * 16));
+                    SG_TRY(mul_coeff_dev(inner, ci, Ni, outer, co, 0, No, W / 2, inner_is_left, pair_coeff.as<double>()));
+                    coeff = pair_coeff.as<double>();
                 }
                 hipLaunchKernelGGL(k_pair_keys, dim3(grid_for(T)), dim3(256), 0, st, hI.as<u64>(), Ni, hO.as<u64>(), T, keys.as<u64>(), idx.as<u32>());
                 KERNEL_CHECK();
@@ -560,20 +573,20 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         }
         if (!packed) SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), T, 64 - nbits, 64, &in_tmp));
         ks = in_tmp ? keys2.as<u64>() : keys.as<u64>();
-        is = packed ? reinterpret_cast<u32 *>(ks) : (in_tmp ? idx2.as<u32>() : idx.as<u32>());
+        is = packed ? nullptr : (in_tmp ? idx2.as<u32>() : idx.as<u32>());
         HIP_TRY(hipMemsetAsync(collision.p, 0, 16, st));
         if (nbits < 64) {
             // `heads` doubles as the run-start marker array here (it is overwritten by k_heads afterwards)
             HIP_TRY(hipMemsetAsync(heads.p, 0, (size_t)T * 4, st));
             if (packed) {
-                hipLaunchKernelGGL(k_fixup_mark<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<u32>(), hI.as<u64>(), hO.as<u64>(), bi);
+                hipLaunchKernelGGL(k_fixup_mark<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<u32>(), hI.as<u64>(), hO.as<u64>(), L);
                 hipLaunchKernelGGL(k_fixup_sort<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, (u32 *)nullptr, T, 64 - nbits, heads.as<u32>(),
-                                   collision.as<u32>() + 1, hI.as<u64>(), hO.as<u64>(), bi);
+                                   collision.as<u32>() + 1, hI.as<u64>(), hO.as<u64>(), L);
             } else {
                 hipLaunchKernelGGL(k_fixup_mark<false>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<u32>(), (const u64 *)nullptr,
-                                   (const u64 *)nullptr, 0);
+                                   (const u64 *)nullptr, L);
                 hipLaunchKernelGGL(k_fixup_sort<false>, dim3(grid_for(T)), dim3(256), 0, st, ks, is, T, 64 - nbits, heads.as<u32>(),
-                                   collision.as<u32>() + 1, (const u64 *)nullptr, (const u64 *)nullptr, 0);
+                                   collision.as<u32>() + 1, (const u64 *)nullptr, (const u64 *)nullptr, L);
             }
             KERNEL_CHECK();
         }
@@ -582,16 +595,17 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             while (G < W / 2 && G < 64) G <<= 1;
             i64 gh = ((T + 63) / 64 + 3) / 4;
             if (gh > 16384) gh = 16384;
+            const u64 *nul = nullptr;
+            const double *nud = nullptr;
             if (packed)
-                hipLaunchKernelGGL((k_heads<true, true>), dim3((unsigned)gh), dim3(256), 0, st, ks, (const u32 *)nullptr, T, (const u64 *)nullptr, W,
-                                   inner, (u32)Ni, outer, G, coeff, cg.as<double>(), heads.as<u32>(), collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), bi);
+                hipLaunchKernelGGL((k_heads<true, true>), dim3((unsigned)gh), dim3(256), 0, st, ks, (const u32 *)nullptr, T, nul, W, inner, (u32)Ni, outer, G,
+                                   nud, cg.as<double>(), heads.as<u32>(), collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), L, ci, co);
             else if (pair)
-                hipLaunchKernelGGL((k_heads<true, false>), dim3((unsigned)gh), dim3(256), 0, st, ks, is, T, (const u64 *)nullptr, W, inner, (u32)Ni, outer, G,
-                                   coeff, cg.as<double>(), heads.as<u32>(), collision.as<u32>(), (const u64 *)nullptr, (const u64 *)nullptr, 0);
+                hipLaunchKernelGGL((k_heads<true, false>), dim3((unsigned)gh), dim3(256), 0, st, ks, is, T, nul, W, inner, (u32)Ni, outer, G,
+                                   coeff, cg.as<double>(), heads.as<u32>(), collision.as<u32>(), nul, nul, L, nud, nud);
             else
-                hipLaunchKernelGGL((k_heads<false, false>), dim3((unsigned)gh), dim3(256), 0, st, ks, is, T, rows, W, (const u64 *)nullptr, 1u,
-                                   (const u64 *)nullptr, G, coeff, cg.as<double>(), heads.as<u32>(), collision.as<u32>(), (const u64 *)nullptr,
-                                   (const u64 *)nullptr, 0);
+                hipLaunchKernelGGL((k_heads<false, false>), dim3((unsigned)gh), dim3(256), 0, st, ks, is, T, rows, W, nul, 1u, nul, G,
+                                   coeff, cg.as<double>(), heads.as<u32>(), collision.as<u32>(), nul, nul, L, nud, nud);
         }
         KERNEL_CHECK();
         u32 hflags[2] = {0, 0};
@@ -605,7 +619,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         set_error("cleanup: 64-bit row-hash collision survived 4 reseeds");
         return SYMGPU_E_COLLISION;
     }
-    return cleanup_finish(heads.as<u32>(), is, packed, bi, T, cg.as<double>(), thr, use_thr, pair, rows, W, inner, Ni, outer, out, Wq_out);
+    return cleanup_finish(heads.as<u32>(), is, ks, packed, L, T, cg.as<double>(), thr, use_thr, pair, rows, W, inner, Ni, outer, out, Wq_out);
 }
 
 }  // namespace symgpu
@@ -618,7 +632,7 @@ int symgpu_cleanup_dev(symgpu_op_t in, double thr, int use_thr, symgpu_op_t *out
     SG_TRY(require_ctx());
     SG_REQUIRE(in && out, "cleanup_dev: null handle");
     SG_REQUIRE(in->coeff || in->T == 0, "cleanup_dev: operator has no coefficients");
-    return cleanup_core(in->rows, in->coeff, in->T, 2 * in->Wq, nullptr, 0, nullptr, 0, thr, use_thr, out, in->Wq);
+    return cleanup_core(in->rows, in->coeff, in->T, 2 * in->Wq, nullptr, 0, nullptr, 0, thr, use_thr, out, in->Wq, nullptr, nullptr, 1);
 }
 
 int symgpu_mul_cleanup_dev(symgpu_op_t inner, symgpu_op_t outer, int inner_is_left, double thr, int use_thr, symgpu_op_t *out) {
@@ -627,13 +641,11 @@ int symgpu_mul_cleanup_dev(symgpu_op_t inner, symgpu_op_t outer, int inner_is_le
     SG_REQUIRE(inner->Wq == outer->Wq, "mul_cleanup_dev: operands must share Wq");
     const i64 Ni = inner->T, No = outer->T;
     const i64 T = Ni * No;
-    if (T == 0) return cleanup_core(nullptr, nullptr, 0, 2 * inner->Wq, nullptr, 0, nullptr, 0, thr, use_thr, out, inner->Wq);
+    if (T == 0) return cleanup_core(nullptr, nullptr, 0, 2 * inner->Wq, nullptr, 0, nullptr, 0, thr, use_thr, out, inner->Wq, nullptr, nullptr, 1);
     SG_REQUIRE(inner->coeff && outer->coeff, "mul_cleanup_dev: operands have no coefficients");
     SG_REQUIRE(No == 0 || Ni < ((i64)1 << 32) / No, "mul_cleanup_dev: Ni*No must stay below 2^32 (tile the outer operand)");
-    Scratch coeff;
-    SG_TRY(coeff.alloc((size_t)T * 16));
-    SG_TRY(mul_coeff_dev(inner->rows, inner->coeff, Ni, outer->rows, outer->coeff, 0, No, inner->Wq, inner_is_left, coeff.as<double>()));
-    return cleanup_core(nullptr, coeff.as<double>(), T, 2 * inner->Wq, inner->rows, Ni, outer->rows, No, thr, use_thr, out, inner->Wq);
+    return cleanup_core(nullptr, nullptr, T, 2 * inner->Wq, inner->rows, Ni, outer->rows, No, thr, use_thr, out, inner->Wq, inner->coeff, outer->coeff,
+                        inner_is_left);
 }
 
 static int finish_to_host(symgpu_op_t res, uint64_t *out_rows, double *out_coeff, int64_t capacity, int64_t *n_out) {
@@ -657,7 +669,7 @@ int symgpu_cleanup(const uint64_t *rows, const double *coeff, int64_t T, int W, 
     symgpu_op_t in = nullptr, res = nullptr;
     SG_TRY(symgpu_op_upload(rows, coeff, T, W / 2, &in));
     if (T == 0 && !in->coeff) { /* empty upload has no coeff buffer; cleanup_core handles T == 0 first */ }
-    int rc = cleanup_core(in->rows, in->coeff, T, W, nullptr, 0, nullptr, 0, thr, use_thr, &res, W / 2);
+    int rc = cleanup_core(in->rows, in->coeff, T, W, nullptr, 0, nullptr, 0, thr, use_thr, &res, W / 2, nullptr, nullptr, 1);
     symgpu_op_free(in);
     if (rc != SYMGPU_OK) return rc;
     return finish_to_host(res, out_rows, out_coeff, capacity, n_out);

@@ -112,9 +112,36 @@ int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out,
 int ycount_dev(const u64 *rows, i64 T, int Wq, int *out);
 
 // product.hip
+// ---- shared device helpers ----------------------------------------------------------------------
+// exact phase application: multiply (re, im) by i^e
+__device__ __forceinline__ void apply_phase(double re, double im, int e, double &ore, double &oim) {
+    const bool swap = e & 1;
+    double a = swap ? im : re, b = swap ? re : im;
+    // e=0: ( re,  im)  e=1: (-im,  re)  e=2: (-re, -im)  e=3: ( im, -re)
+    const bool neg_a = (e == 1) || (e == 2), neg_b = (e == 2) || (e == 3);
+    ore = neg_a ? -a : a;
+    oim = neg_b ? -b : b;
+}
+// plain IEEE complex product (no FMA contraction: matches numpy for exactly representable inputs) times i^e
+__device__ __forceinline__ void pair_coefficient(double ar, double ai, double br, double bi, int e, double &ore, double &oim) {
+    const double re = __dsub_rn(__dmul_rn(ar, br), __dmul_rn(ai, bi));
+    const double im = __dadd_rn(__dmul_rn(ar, bi), __dmul_rn(ai, br));
+    apply_phase(re, im, e, ore, oim);
+}
+
+// packed pair key of the fused product + cleanup: [hash: 64-F bits][e: 2][o: bo][i: bi], F = bi + bo + 2 (cleanup.hip)
+struct PairKeyArgs {
+    const u64 *hI, *hO;     // per-operand row hashes
+    u64 *keys;              // [No*Ni] out, index o*Ni + i
+    int bi, bo;
+    i64 o_base;             // absolute index of the launch's first outer row
+};
+
 int mul_coeff_dev(const u64 *inner, const double *ci, i64 Ni, const u64 *outer, const double *co, i64 o_begin, i64 o_end,
                   int Wq, int inner_is_left, double *out_coeff);
 int mul_rows_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 o_begin, i64 o_end, int Wq, u64 *out_rows);
+// packed (hash | phase exponent | o | i) keys of all pairs, for the fused product + cleanup
+int mul_keys_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 No, int Wq, int inner_is_left, PairKeyArgs ka);
 
 // cleanup.hip
 int ensure_hash_tables(u64 seed);
@@ -122,7 +149,8 @@ int hash_rows(const u64 *rows, i64 T, int W, u64 *out1);       // h1 of every ro
 u64 host_row_hash(const u64 *row, int W);                       // the same hash on the host
 int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W,          // plain mode (pair mode if inner != null)
                  const u64 *inner, i64 Ni, const u64 *outer, i64 No,
-                 double thr, int use_thr, symgpu_op_t *out, int Wq_out);
+                 double thr, int use_thr, symgpu_op_t *out, int Wq_out,
+                 const double *ci = nullptr, const double *co = nullptr, int inner_is_left = 1);   // pair mode: operand coefficients
 
 // gf2.hip
 int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host);

@@ -28,25 +28,17 @@ constexpr int PO = 8;   // outer terms per wave (SGPR operand)
 constexpr int PJ = 4;   // inner terms per lane: i = ibase + 64*b + lane
 constexpr int PW = 4;   // waves per block, stacked along o
 
-// exact phase application: multiply (re, im) by i^e
-__device__ __forceinline__ void apply_phase(double re, double im, int e, double &ore, double &oim) {
-    const bool swap = e & 1;
-    double a = swap ? im : re, b = swap ? re : im;
-    // e=0: ( re,  im)  e=1: (-im,  re)  e=2: (-re, -im)  e=3: ( im, -re)
-    const bool neg_a = (e == 1) || (e == 2), neg_b = (e == 2) || (e == 3);
-    ore = neg_a ? -a : a;
-    oim = neg_b ? -b : b;
-}
-
 // FUSED: after the coefficients of its (256 inner x 32 outer) tile the block also streams the tile's product ROWS
 // (k_mul_rows' store pattern: 16 B per lane, 4 KiB contiguous per outer row, non-temporal), so ONE launch writes the
 // full 16*Wq + 16 bytes per pair; while some waves of a CU sit in the VALU phase others keep the HBM write stream busy.
-template <bool INNER_LEFT, bool FUSED>
+// KEYS: instead of the coefficient the kernel emits the packed cleanup key of every pair (hash | phase exponent e | o | i):
+// the 16-byte coefficient is never materialised, the cleanup rebuilds c_i * c_o * i^e from e and the two operand tables.
+template <bool INNER_LEFT, bool FUSED, bool KEYS>
 __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i64 Ipad, i64 Ni, const double *__restrict__ ci,
                                                     const u64 *__restrict__ Ot, i64 Opad, i64 No, const double *__restrict__ co,
                                                     int Wq, double *__restrict__ out /* [(o)*Ni + i][2], o relative to slab */,
                                                     const u32x4 *__restrict__ inner_rm, const u32x4 *__restrict__ outer_rm,
-                                                    u32x4 *__restrict__ out_rows) {
+                                                    u32x4 *__restrict__ out_rows, PairKeyArgs ka) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const i64 o0 = ((i64)blockIdx.y * PW + wave) * PO;   // wave-uniform, relative to the slab
@@ -109,20 +101,27 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
     for (int b = 0; b < PJ; ++b) {
         const i64 i = ibase + 64 * b + lane;
         if (i >= Ni) continue;
+        if (KEYS) {
+            const u64 hi = ka.hI[i];
+            const int F = ka.bi + ka.bo + 2;
+            const u64 hmask = ~((1ULL << F) - 1ULL);
+#pragma unroll
+            for (int a = 0; a < PO; ++a) {
+                const i64 o = o0 + a;
+                if (o >= No) continue;
+                const u64 e = (3u * (yi[b] + (u32)yo[a]) + cnt[a][b] + 2u * (__popc(flo[a][b] ^ fhi[a][b]) & 1u)) & 3u;
+                ka.keys[o * Ni + i] = ((hi ^ ka.hO[o]) & hmask) | (e << (ka.bi + ka.bo)) | ((u64)(o + ka.o_base) << ka.bi) | (u64)i;
+            }
+            continue;
+        }
         const double ar = ci[2 * i], ai = ci[2 * i + 1];
 #pragma unroll
         for (int a = 0; a < PO; ++a) {
             const i64 o = o0 + a;
             if (o >= No) continue;
-            const double br = co[2 * o], bi = co[2 * o + 1];
-            // plain IEEE complex product (no FMA contraction): matches numpy for exactly representable inputs
-            const double re = __dsub_rn(__dmul_rn(ar, br), __dmul_rn(ai, bi));
-            const double im = __dadd_rn(__dmul_rn(ar, bi), __dmul_rn(ai, br));
             const int e = (int)((3u * (yi[b] + (u32)yo[a]) + cnt[a][b] + 2u * (__popc(flo[a][b] ^ fhi[a][b]) & 1u)) & 3u);
-            double ore, oim;
-            apply_phase(re, im, e, ore, oim);
             double2 v;
-            v.x = ore; v.y = oim;
+            pair_coefficient(ar, ai, co[2 * o], co[2 * o + 1], e, v.x, v.y);
             reinterpret_cast<double2 *>(out)[o * Ni + i] = v;
         }
     }
@@ -198,7 +197,7 @@ static i64 round_up(i64 x, i64 m) { return (x + m - 1) / m * m; }
 // It = word-major inner operand (padded to Ipad, a multiple of 64*PJ); kernels go to stream `st`.
 static int mul_coeff_launch(const u64 *It, i64 Ipad, const double *ci, i64 Ni, const u64 *outer, const double *co, i64 o_begin, i64 o_end,
                             int Wq, int inner_is_left, double *out_coeff, hipStream_t st, Scratch &ot,
-                            const u64 *inner_rm = nullptr, u64 *out_rows = nullptr) {
+                            const u64 *inner_rm = nullptr, u64 *out_rows = nullptr, const PairKeyArgs *keys = nullptr) {
     const i64 No = o_end - o_begin;
     const int W = 2 * Wq;
     const i64 Opad = round_up(No, PO * PW);
@@ -214,9 +213,21 @@ static int mul_coeff_launch(const u64 *It, i64 Ipad, const double *ci, i64 Ni, c
         const u32x4 *irm = reinterpret_cast<const u32x4 *>(inner_rm);
         const u32x4 *orm = reinterpret_cast<const u32x4 *>(outer + (o_begin + ooff) * W);
         u32x4 *drows = out_rows ? reinterpret_cast<u32x4 *>(out_rows) + ooff * Ni * Wq : nullptr;
-#define LAUNCH_COEFF(L, F) hipLaunchKernelGGL((k_mul_coeff<L, F>), grid, dim3(256), 0, st, It, Ipad, Ni, ci, ot.as<u64>() + ooff, Opad, \
-                                              No - ooff, co + 2 * (o_begin + ooff), Wq, out_coeff + 2 * ooff * Ni, irm, orm, drows)
-        if (out_rows) {
+#define LAUNCH_COEFF(L, F) hipLaunchKernelGGL((k_mul_coeff<L, F, false>), grid, dim3(256), 0, st, It, Ipad, Ni, ci, ot.as<u64>() + ooff, Opad, \
+                                              No - ooff, co + 2 * (o_begin + ooff), Wq, out_coeff + 2 * ooff * Ni, irm, orm, drows, PairKeyArgs())
+        if (keys) {
+            // key mode runs over the whole outer operand (o_begin == 0); the o field stays absolute through o_base
+            PairKeyArgs ka = *keys;
+            ka.hO += ooff;
+            ka.keys += ooff * Ni;
+            ka.o_base = ooff;
+            if (inner_is_left)
+                hipLaunchKernelGGL((k_mul_coeff<true, false, true>), grid, dim3(256), 0, st, It, Ipad, Ni, (const double *)nullptr, ot.as<u64>() + ooff, Opad, No - ooff,
+                                   (const double *)nullptr, Wq, (double *)nullptr, irm, orm, drows, ka);
+            else
+                hipLaunchKernelGGL((k_mul_coeff<false, false, true>), grid, dim3(256), 0, st, It, Ipad, Ni, (const double *)nullptr, ot.as<u64>() + ooff, Opad, No - ooff,
+                                   (const double *)nullptr, Wq, (double *)nullptr, irm, orm, drows, ka);
+        } else if (out_rows) {
             ProfScope prof(0);
             if (inner_is_left) LAUNCH_COEFF(true, true); else LAUNCH_COEFF(false, true);
         } else {
@@ -236,6 +247,15 @@ int mul_coeff_dev(const u64 *inner, const double *ci, i64 Ni, const u64 *outer, 
     SG_TRY(it.alloc((size_t)Ipad * 2 * Wq * sizeof(u64)));
     SG_TRY(to_wordmajor(inner, Ni, 2 * Wq, it.as<u64>(), Ipad));
     return mul_coeff_launch(it.as<u64>(), Ipad, ci, Ni, outer, co, o_begin, o_end, Wq, inner_is_left, out_coeff, ctx().stream, ot);
+}
+
+int mul_keys_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 No, int Wq, int inner_is_left, PairKeyArgs ka) {
+    if (Ni == 0 || No <= 0) return SYMGPU_OK;
+    const i64 Ipad = round_up(Ni, 64 * PJ);
+    Scratch it, ot;
+    SG_TRY(it.alloc((size_t)Ipad * 2 * Wq * sizeof(u64)));
+    SG_TRY(to_wordmajor(inner, Ni, 2 * Wq, it.as<u64>(), Ipad));
+    return mul_coeff_launch(it.as<u64>(), Ipad, nullptr, Ni, outer, nullptr, 0, No, Wq, inner_is_left, nullptr, ctx().stream, ot, nullptr, nullptr, &ka);
 }
 
 // rows of the slab: out_rows[((o-o_begin)*Ni + i)*W + w]
