@@ -14,6 +14,7 @@
 //           -> threshold |c| > thr (strict, utils.py:275-278) -> first-occurrence order via mark+scan over
 //           input positions (qiskit `unordered_unique` order, utils.py:271) -> gather surviving rows.
 #include "common.h"
+#include <stdlib.h>
 #include <vector>
 
 namespace symgpu {
@@ -515,6 +516,10 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
     while (pair && ((i64)1 << L.bi) < Ni) ++L.bi;
     while (pair && ((i64)1 << L.bo) < No) ++L.bo;
     bool packed = pair && L.bi + L.bo <= 32 && L.bi < 32;
+    {   // SYMGPU_CLEANUP_UNPACKED=1 forces the fallback path (tests)
+        const char *e = getenv("SYMGPU_CLEANUP_UNPACKED");
+        if (e && e[0] == '1') packed = false;
+    }
     Scratch keys, keys2, idx, idx2, heads, collision, cg, hI, hO, pair_coeff;
     SG_TRY(keys.alloc((size_t)T * 8));
     SG_TRY(keys2.alloc((size_t)T * 8));

@@ -449,3 +449,21 @@ def test_cleanup_long_segments_sum_in_input_order(T, n):
     r, c = kernels.cleanup(rows, coeff, 1e-15)
     er, ec = oc.cleanup(rows, coeff, 1e-15)
     assert np.array_equal(r, er) and np.array_equal(c, ec)
+
+
+def test_mul_cleanup_unpacked_fallback_path(monkeypatch):
+    """The fused product + cleanup normally sorts packed (hash | e | o | i) keys; operands whose index fields need more than
+    32 bits, or a long mixed prefix run, use separate 64-bit keys + index values with materialised pair coefficients."""
+    import os
+    rng = np.random.default_rng(9)
+    n, N, M = 70, 400, 150
+    A = PauliwordOp(rng.random((N, 2 * n)) < 0.15, dyadic(rng, N))
+    B = PauliwordOp(rng.random((M, 2 * n)) < 0.15, dyadic(rng, M))
+    erows, ecoeff = oc.mul(A.packed, A.coeff_vec, B.packed, B.coeff_vec)
+    monkeypatch.setenv('SYMGPU_CLEANUP_UNPACKED', '1')
+    rows, coeff = kernels.mul_cleanup(A.packed, A.coeff_vec, B.packed, B.coeff_vec, True, 1e-15)
+    assert np.array_equal(rows, erows) and np.array_equal(coeff, ecoeff)
+    rows2, coeff2 = kernels.mul_cleanup(A.packed, A.coeff_vec, A.packed, A.coeff_vec, True, 1e-15)
+    monkeypatch.delenv('SYMGPU_CLEANUP_UNPACKED')
+    rows3, coeff3 = kernels.mul_cleanup(A.packed, A.coeff_vec, A.packed, A.coeff_vec, True, 1e-15)
+    assert np.array_equal(rows2, rows3) and np.array_equal(coeff2, coeff3)
