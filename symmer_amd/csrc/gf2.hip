@@ -23,6 +23,7 @@
 // time j, the sequential-time selector of an outside row is t_j = f_j ^ parity(f & mask_j & (2^j-1)), so the count is
 // sum_j |mask_j| + sum_r |t(r)|  (derivation in DESIGN.md §3.5).
 #include "common.h"
+#include <stdlib.h>
 
 namespace symgpu {
 
@@ -170,34 +171,36 @@ __global__ __launch_bounds__(256) void k_select(const u64 *__restrict__ rows, i6
     for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < total; k += (i64)gridDim.x * 256) snap[k] = rows[i0 * Wc + k];
 }
 
-constexpr int SW_ROWS = 16;   // rows per sweep workgroup, held in VGPRs
 
 // Each lane owns one word column of SW_ROWS rows (kept in registers); the old block rows stream past once
 // (independent loads, no dependent load->xor->store chain per row) and are XORed in under wave-uniform selector bits.
+template <int SW_ROWS, int UNR>
 __global__ __launch_bounds__(256) void k_sweep(u64 *__restrict__ rows, i64 R, i64 Wc, const BlockInfo *__restrict__ info,
                                                 const u64 *__restrict__ sel, const u64 *__restrict__ snap) {
     const int kk = info->kk;
     if (kk == 0) return;
     const i64 w = (i64)blockIdx.x * 256 + threadIdx.x;
     const bool live = w < Wc;
+    const i64 wl = live ? w : Wc - 1;                               // dead lanes load a valid column and never store
     const i64 rb = (i64)blockIdx.y * SW_ROWS;
+    const bool full = rb + SW_ROWS <= R;                             // uniform: branch-free loads and stores for full tiles
     u32 slo[SW_ROWS], shi[SW_ROWS];
     u64 x[SW_ROWS];
     u32 any = 0;
 #pragma unroll
     for (int k = 0; k < SW_ROWS; ++k) {
-        const i64 r = rb + k;
-        const u64 sv = (r < R) ? sel[r] : 0ULL;
+        const i64 r = (full || rb + k < R) ? rb + k : R - 1;          // clamped: rows past the end are loaded but never stored
+        const u64 sv = (rb + k < R) ? sel[r] : 0ULL;
         slo[k] = __builtin_amdgcn_readfirstlane((u32)sv);
         shi[k] = __builtin_amdgcn_readfirstlane((u32)(sv >> 32));
         any |= slo[k] | shi[k];
-        x[k] = (live && r < R) ? rows[r * Wc + w] : 0ULL;
+        x[k] = rows[r * Wc + wl];
     }
     if (any == 0) return;                                            // uniform
-    const u64 *sp = snap + w;
-#pragma unroll 4
+    const u64 *sp = snap + wl;
+#pragma unroll UNR
     for (int j = 0; j < kk; ++j) {
-        const u64 b = live ? sp[(i64)j * Wc] : 0ULL;
+        const u64 b = sp[(i64)j * Wc];
         const u32 blo = (u32)b, bhi = (u32)(b >> 32);
 #pragma unroll
         for (int k = 0; k < SW_ROWS; ++k) {
@@ -210,12 +213,17 @@ __global__ __launch_bounds__(256) void k_sweep(u64 *__restrict__ rows, i64 R, i6
             x[k] = ((u64)hi << 32) | lo;
         }
     }
-    if (live) {
+    if (!live) return;
+    if (full) {
+        // unconditional back-to-back stores (a conditional store per row made the compiler wait for the previous store:
+        // s_waitcnt vmcnt(0) before each of the 16 stores serialised them)
+        u64 *dst = rows + rb * Wc + w;
 #pragma unroll
-        for (int k = 0; k < SW_ROWS; ++k) {
-            const i64 r = rb + k;
-            if (r < R && (slo[k] | shi[k])) rows[r * Wc + w] = x[k];
-        }
+        for (int k = 0; k < SW_ROWS; ++k) dst[(i64)k * Wc] = x[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < SW_ROWS; ++k)
+            if (rb + k < R) rows[(rb + k) * Wc + w] = x[k];
     }
 }
 
@@ -237,6 +245,7 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     HIP_TRY(hipMemsetAsync(rowcnt.p, 0, (size_t)R * 4, st));
     HIP_TRY(hipMemsetAsync(count.p, 0, 16, st));
     HIP_TRY(hipMemsetAsync(state.p, 0, sizeof(SweepState), st));
+    constexpr int SW_ROWS = 16;                                     // rows per sweep workgroup, held in VGPRs
     const unsigned gx = (unsigned)((Wc + 255) / 256), gy = (unsigned)((R + SW_ROWS - 1) / SW_ROWS);
     const unsigned gsel = (unsigned)((R + 3) / 4);
     i64 done = 0;
@@ -251,7 +260,7 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
             hipLaunchKernelGGL(k_select, dim3(gsel), dim3(256), 0, st, rows, R, Wc, info.as<BlockInfo>(), sel.as<u64>(), snap.as<u64>(),
                                rowcnt.as<u32>());
             ProfScope prof(2);
-            hipLaunchKernelGGL(k_sweep, dim3(gx, gy), dim3(256), 0, st, rows, R, Wc, info.as<BlockInfo>(), sel.as<u64>(), snap.as<u64>());
+hipLaunchKernelGGL((k_sweep<SW_ROWS, 4>), dim3(gx, gy), dim3(256), 0, st, rows, R, Wc, info.as<BlockInfo>(), sel.as<u64>(), snap.as<u64>());
             KERNEL_CHECK();
         }
         SweepState hs;
