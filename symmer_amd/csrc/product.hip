@@ -97,6 +97,17 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
         }
     }
 
+    // Epilogue.  The stores of a full 8-outer-term tile are issued unconditionally back to back: a conditional store per
+    // pair made the compiler drain the memory counter (s_waitcnt vmcnt(0)) before every single store.
+    const bool full_o = o0 + PO <= No;                                   // wave-uniform
+    u64 ho[PO];
+    double cor[PO], coi[PO];
+#pragma unroll
+    for (int a = 0; a < PO; ++a) {
+        const i64 o = (o0 + a < No) ? o0 + a : (No > 0 ? No - 1 : 0);    // clamped: rows past the end are computed, never stored
+        if (KEYS) ho[a] = ka.hO[o];
+        else { cor[a] = co[2 * o]; coi[a] = co[2 * o + 1]; }
+    }
 #pragma unroll
     for (int b = 0; b < PJ; ++b) {
         const i64 i = ibase + 64 * b + lane;
@@ -105,24 +116,38 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
             const u64 hi = ka.hI[i];
             const int F = ka.bi + ka.bo + 2;
             const u64 hmask = ~((1ULL << F) - 1ULL);
+            u64 key[PO];
 #pragma unroll
             for (int a = 0; a < PO; ++a) {
-                const i64 o = o0 + a;
-                if (o >= No) continue;
                 const u64 e = (3u * (yi[b] + (u32)yo[a]) + cnt[a][b] + 2u * (__popc(flo[a][b] ^ fhi[a][b]) & 1u)) & 3u;
-                ka.keys[o * Ni + i] = ((hi ^ ka.hO[o]) & hmask) | (e << (ka.bi + ka.bo)) | ((u64)(o + ka.o_base) << ka.bi) | (u64)i;
+                key[a] = ((hi ^ ho[a]) & hmask) | (e << (ka.bi + ka.bo)) | ((u64)(o0 + a + ka.o_base) << ka.bi) | (u64)i;
+            }
+            u64 *dst = ka.keys + o0 * Ni + i;
+            if (full_o) {
+#pragma unroll
+                for (int a = 0; a < PO; ++a) dst[(i64)a * Ni] = key[a];
+            } else {
+#pragma unroll
+                for (int a = 0; a < PO; ++a)
+                    if (o0 + a < No) dst[(i64)a * Ni] = key[a];
             }
             continue;
         }
         const double ar = ci[2 * i], ai = ci[2 * i + 1];
+        double2 v[PO];
 #pragma unroll
         for (int a = 0; a < PO; ++a) {
-            const i64 o = o0 + a;
-            if (o >= No) continue;
             const int e = (int)((3u * (yi[b] + (u32)yo[a]) + cnt[a][b] + 2u * (__popc(flo[a][b] ^ fhi[a][b]) & 1u)) & 3u);
-            double2 v;
-            pair_coefficient(ar, ai, co[2 * o], co[2 * o + 1], e, v.x, v.y);
-            reinterpret_cast<double2 *>(out)[o * Ni + i] = v;
+            pair_coefficient(ar, ai, cor[a], coi[a], e, v[a].x, v[a].y);
+        }
+        double2 *dst = reinterpret_cast<double2 *>(out) + o0 * Ni + i;
+        if (full_o) {
+#pragma unroll
+            for (int a = 0; a < PO; ++a) dst[(i64)a * Ni] = v[a];
+        } else {
+#pragma unroll
+            for (int a = 0; a < PO; ++a)
+                if (o0 + a < No) dst[(i64)a * Ni] = v[a];
         }
     }
     if (FUSED) {
