@@ -153,12 +153,12 @@ def main():
         out['roofline']['frac_of_measured_fill_ceiling'] = achieved / fill.value if fill.value else None
     # HBM traffic of the dominant kernel from the committed PMC profile (counters cannot be read from inside this process)
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r01e_traffic.json')) as f:
             tr = json.load(f)
         cfg = tr['config']
         if (cfg['n_qubits'], cfg['left_terms_per_gpu'], cfg['right_terms'], cfg['slab_rows']) == (n, Ni, M, slab):
             out['roofline']['traffic'] = tr['write_bytes_per_launch'] + tr['fetch_bytes_per_launch_corrected_x2']
-            out['roofline']['traffic_source'] = 'profiles/r01_traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes)'
+            out['roofline']['traffic_source'] = 'profiles/r01e_traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes)'
     except Exception:
         pass
     for r in ring:
