@@ -81,6 +81,7 @@ int symgpu_commutes_bits_dev(symgpu_op_t A, int64_t a_begin, int64_t a_end, symg
 int symgpu_dev_alloc(int64_t bytes, void **ptr);
 int symgpu_dev_free(void *ptr);
 int symgpu_dev_download(const void *dev, void *host, int64_t bytes);
+int symgpu_dev_upload(void *dev, const void *host, int64_t bytes);
 int symgpu_dev_checksum_u8(const uint8_t *dev, int64_t n, uint64_t *sum); /* sum of bytes (number of commuting pairs) */
 int symgpu_dev_popcount_u64(const uint64_t *dev, int64_t n_words, uint64_t *sum);
 

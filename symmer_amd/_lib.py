@@ -55,6 +55,7 @@ SIGNATURES = {
     'symgpu_dev_alloc': [c_i64, PP],
     'symgpu_dev_free': [P],
     'symgpu_dev_download': [P, P, c_i64],
+    'symgpu_dev_upload': [P, P, c_i64],
     'symgpu_dev_checksum_u8': [P, c_i64, P],
     'symgpu_dev_popcount_u64': [P, c_i64, P],
     'symgpu_mul_allpairs': [P, P, c_i64, P, P, c_i64, c_int, c_int, P, P],

@@ -9,15 +9,17 @@
 // tiny (N*16*Wq bytes) and stay in L2/MALL; the only HBM stream is the 1 B/pair (or 1 bit/pair) output.
 //
 // Mapping (64-wide wavefronts): both operands are first re-laid word-major (layout.hip).  One wave owns
-// 8 rows of A x 256 columns of B: the 8 A-words of a word index arrive in SGPRs through a single
-// s_load_dwordx16 (wave-uniform address), the B-words are 4 coalesced 512-byte vector loads, and every
-// lane keeps 8x4 64-bit XOR accumulators in VGPRs.  No LDS is needed: nothing is shared between lanes.
+// 8 rows of A x 512 columns of B: the 8 A-words of a word index arrive in SGPRs through a single
+// s_load_dwordx16 (wave-uniform address) and are copied to VGPRs, every lane owns 8 ADJACENT columns of B
+// (64 contiguous bytes per word) and keeps 8x8 32-bit XOR accumulators in VGPRs.  No LDS is needed:
+// nothing is shared between lanes.
 #include "common.h"
+#include <stdlib.h>
+#include <stdint.h>
 
 namespace symgpu {
 
 constexpr int CI = 8;    // A rows per wave (SGPR operand)
-constexpr int CJ = 4;    // B columns per lane: j = jbase + 64*b + lane
 constexpr int WAVES = 4; // waves per block, stacked along i
 
 // gfx950 v_bitop3_b32 with truth table 0x78: acc ^ (b & c) in ONE VALU instruction
@@ -25,33 +27,41 @@ __device__ __forceinline__ u32 xor_and(u32 acc, u32 b, u32 c) { return __builtin
 // force a wave-uniform value into a VGPR (the compiler would otherwise fold the SGPR into every consumer)
 __device__ __forceinline__ u32 to_vgpr(u32 s) { u32 v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
 
-template <bool BITS>
+// ---- 8 x 8 register tile ---------------------------------------------------------------------------------------------
+// Wave = 8 rows of A x 512 columns of B, lane = 8 ADJACENT columns (j = jbase + 8*lane + b): the B words of a lane are 64
+// contiguous bytes (4 dwordx4 loads per block), the 8 result bytes of a row leave as ONE 8-byte store (512 B per wave
+// store instead of 64 B), and the 4 v_mov that bring an A word into VGPRs are shared by 32 bitop3 instead of 16
+// (VALU mix 256 bitop3 : 32 mov per word step = 89 % useful issue slots instead of 80 %).  The low and high halves of a
+// word feed ONE 32-bit accumulator (only the parity of the total popcount matters): 64 accumulator VGPRs for 64 pairs.
+constexpr int DJ = 8;    // adjacent B columns per lane
+
+template <bool BITS, bool VEC>
 __global__ __launch_bounds__(256) void k_commutes(const u64 *__restrict__ At, i64 Npad, i64 N,
-                                                   const u64 *__restrict__ Bt, i64 Mpad, i64 M, int Wq,
-                                                   uint8_t *__restrict__ out, i64 out_stride, u64 *__restrict__ out_bits, i64 bits_stride) {
+                                                    const u64 *__restrict__ Bt, i64 Mpad, i64 M, int Wq,
+                                                    uint8_t *__restrict__ out, i64 out_stride, uint8_t *__restrict__ out_bits, i64 bits_stride_bytes) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const i64 i0 = ((i64)blockIdx.x * WAVES + wave) * CI;   // wave-uniform
-    const i64 jbase = (i64)blockIdx.y * (64 * CJ);
+    const i64 jbase = (i64)blockIdx.y * (64 * DJ);
     if (i0 >= Npad) return;
 
-    u32 acc_lo[CI][CJ], acc_hi[CI][CJ];
+    u32 acc[CI][DJ];
 #pragma unroll
     for (int a = 0; a < CI; ++a)
 #pragma unroll
-        for (int b = 0; b < CJ; ++b) acc_lo[a][b] = acc_hi[a][b] = 0;
+        for (int b = 0; b < DJ; ++b) acc[a][b] = 0;
 
-    const u64 *pax = At + i0;                    // x words of A: At[w][i]
-    const u64 *paz = At + (i64)Wq * Npad + i0;   // z words
-    const u64 *pbx = Bt + jbase + lane;
-    const u64 *pbz = Bt + (i64)Wq * Mpad + jbase + lane;
+    const u64 *pax = At + i0;
+    const u64 *paz = At + (i64)Wq * Npad + i0;
+    const u64 *pbx = Bt + jbase + DJ * lane;
+    const u64 *pbz = Bt + (i64)Wq * Mpad + jbase + DJ * lane;
 
     for (int w = 0; w < Wq; ++w) {
-        u64 xb[CJ], zb[CJ];
+        u64 xb[DJ], zb[DJ];
 #pragma unroll
-        for (int b = 0; b < CJ; ++b) {
-            xb[b] = pbx[(i64)w * Mpad + 64 * b];
-            zb[b] = pbz[(i64)w * Mpad + 64 * b];
+        for (int b = 0; b < DJ; ++b) {
+            xb[b] = pbx[(i64)w * Mpad + b];
+            zb[b] = pbz[(i64)w * Mpad + b];
         }
         u64 xa[CI], za[CI];
 #pragma unroll
@@ -62,33 +72,50 @@ __global__ __launch_bounds__(256) void k_commutes(const u64 *__restrict__ At, i6
 #pragma unroll
         for (int a = 0; a < CI; ++a) {
             // Measured on gfx950 (tools/ubench_bitop.hip): a VALU instruction with an SGPR source issues at ~60 % of the
-            // all-VGPR rate, so the wave-uniform A words are copied into VGPRs once (4 v_mov) and reused by 4*CJ bitop3.
-            // Tried and rejected (slower on MI355X): per-lane broadcast vector loads (34.8 ms), A tile in LDS (19.7 ms),
-            // A+B tiles in LDS with barriers (25.3 ms), CI=4/CJ=8 with explicit prefetch (35.4 ms) vs 19.0 ms for this form
-            // on the 25,000 x 200,000 block at n=2000.
+            // all-VGPR rate, so the wave-uniform A words are copied into VGPRs once (4 v_mov) and reused by 4*DJ bitop3.
+            // Tried and rejected (slower on MI355X, 25,000 x 200,000 block at n=2000; this form: 17.4 ms): 8x4 tile with
+            // strided columns and two accumulators per pair (19.0 ms), per-lane broadcast vector loads (34.8 ms), A tile
+            // in LDS (19.7 ms), A+B tiles in LDS with barriers (25.3 ms), 4x8 tile with explicit prefetch (35.4 ms),
+            // 8x16 tile (36.0 ms: register pressure).
             const u32 xal = to_vgpr((u32)xa[a]), xah = to_vgpr((u32)(xa[a] >> 32));
             const u32 zal = to_vgpr((u32)za[a]), zah = to_vgpr((u32)(za[a] >> 32));
 #pragma unroll
-            for (int b = 0; b < CJ; ++b) {
-                // acc ^= (xa & zb) ^ (za & xb): two v_bitop3_b32 (truth table 0x78 = a ^ (b & c)) per 32-bit half
-                acc_lo[a][b] = xor_and(xor_and(acc_lo[a][b], xal, (u32)zb[b]), zal, (u32)xb[b]);
-                acc_hi[a][b] = xor_and(xor_and(acc_hi[a][b], xah, (u32)(zb[b] >> 32)), zah, (u32)(xb[b] >> 32));
+            for (int b = 0; b < DJ; ++b) {
+                u32 t = xor_and(xor_and(acc[a][b], xal, (u32)zb[b]), zal, (u32)xb[b]);
+                acc[a][b] = xor_and(xor_and(t, xah, (u32)(zb[b] >> 32)), zah, (u32)(xb[b] >> 32));
             }
         }
     }
 
+    const i64 j0 = jbase + DJ * lane;
 #pragma unroll
     for (int a = 0; a < CI; ++a) {
         const i64 i = i0 + a;
+        if (i >= N) break;                                      // wave-uniform
+        if (BITS) {
 #pragma unroll
-        for (int b = 0; b < CJ; ++b) {
-            const i64 j = jbase + 64 * b + lane;
-            const bool commute = !(__popc(acc_lo[a][b] ^ acc_hi[a][b]) & 1);
-            if (BITS) {
-                const u64 m = __ballot(commute && j < M);
-                if (lane == 0 && i < N && jbase + 64 * b < M) out_bits[i * bits_stride + (jbase >> 6) + b] = m;
+            for (int q = 0; q < DJ / 8; ++q) {
+                u32 byte = 0;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) byte |= ((!(__popc(acc[a][8 * q + b]) & 1) && j0 + 8 * q + b < M) ? 1u : 0u) << b;
+                if (j0 + 8 * q < ((M + 63) & ~(i64)63)) out_bits[i * bits_stride_bytes + (j0 >> 3) + q] = (uint8_t)byte;   // zero padding up to the word end
+            }
+        } else {
+            u64 v[DJ / 8];
+#pragma unroll
+            for (int q = 0; q < DJ / 8; ++q) {
+                v[q] = 0;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) v[q] |= (u64)(!(__popc(acc[a][8 * q + b]) & 1)) << (8 * b);
+            }
+            uint8_t *dst = out + i * out_stride + j0;
+            if (VEC && j0 + DJ <= M) {
+#pragma unroll
+                for (int q = 0; q < DJ / 8; ++q) __builtin_nontemporal_store(v[q], reinterpret_cast<u64 *>(dst) + q);
             } else {
-                if (i < N && j < M) out[i * out_stride + j] = commute ? 1 : 0;
+#pragma unroll
+                for (int b = 0; b < DJ; ++b)
+                    if (j0 + b < M) dst[b] = (uint8_t)(v[b / 8] >> (8 * (b % 8)));
             }
         }
     }
@@ -119,7 +146,9 @@ static i64 round_up(i64 x, i64 m) { return (x + m - 1) / m * m; }
 int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits) {
     if (N == 0 || M == 0) return SYMGPU_OK;
     const int W = 2 * Wq;
-    const i64 Npad = round_up(N, CI * WAVES), Mpad = round_up(M, 64 * CJ);
+    const int cj = DJ;
+    const bool same = (B == A && M == N);                 // adjacency: one word-major copy serves both sides
+    const i64 Mpad = round_up(M, 64 * cj), Npad = same ? Mpad : round_up(N, CI * WAVES);
     Scratch at, bt;
     SG_TRY(at.alloc((size_t)Npad * W * sizeof(u64)));
     SG_TRY(to_wordmajor(A, N, W, at.as<u64>(), Npad));
@@ -132,22 +161,28 @@ int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out,
         Bt = bt.as<u64>();
     }
     // blockIdx.x walks along i (fast) so that consecutive blocks reuse the same B column tile from L2
-    const i64 gx = Npad / (CI * WAVES), gy = Mpad / (64 * CJ);
+    const i64 gx = Npad / (CI * WAVES), gy = Mpad / (64 * cj);
     // grid.y is limited to 65535: loop over column super-tiles if needed
     const i64 max_gy = 65535;
     for (i64 y0 = 0; y0 < gy; y0 += max_gy) {
         i64 ny = gy - y0 < max_gy ? gy - y0 : max_gy;
-        const i64 joff = y0 * 64 * CJ;
+        const i64 joff = y0 * 64 * cj;
         dim3 grid((unsigned)gx, (unsigned)ny);
         ProfScope prof(1);
         if (out_bits) {
-            const i64 stride = (M + 63) / 64;
-            hipLaunchKernelGGL(k_commutes<true>, grid, dim3(256), 0, ctx().stream, at.as<u64>(), Npad, N,
-                               Bt + joff, Mpad, M - joff, Wq, (uint8_t *)nullptr, (i64)0, out_bits + (joff >> 6), stride);
+            const i64 stride_bytes = (M + 63) / 64 * 8;
+            hipLaunchKernelGGL((k_commutes<true, false>), grid, dim3(256), 0, ctx().stream, at.as<u64>(), Npad, N, Bt + joff, Mpad, M - joff, Wq,
+                               (uint8_t *)nullptr, (i64)0, reinterpret_cast<uint8_t *>(out_bits) + (joff >> 3), stride_bytes);
         } else {
-            // shift the output base so that column j of this launch maps to joff + j of the full row
-            hipLaunchKernelGGL(k_commutes<false>, grid, dim3(256), 0, ctx().stream, at.as<u64>(), Npad, N,
-                               Bt + joff, Mpad, M - joff, Wq, out + joff, M, (u64 *)nullptr, (i64)0);
+            // 8-byte result stores need 8-byte aligned rows: row stride (= M) and base address multiples of 8.
+            // The output base is shifted so that column j of this launch maps to joff + j of the full row.
+            const bool vec = (M % 8 == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
+            if (vec)
+                hipLaunchKernelGGL((k_commutes<false, true>), grid, dim3(256), 0, ctx().stream, at.as<u64>(), Npad, N, Bt + joff, Mpad, M - joff, Wq,
+                                   out + joff, M, (uint8_t *)nullptr, (i64)0);
+            else
+                hipLaunchKernelGGL((k_commutes<false, false>), grid, dim3(256), 0, ctx().stream, at.as<u64>(), Npad, N, Bt + joff, Mpad, M - joff, Wq,
+                                   out + joff, M, (uint8_t *)nullptr, (i64)0);
         }
         KERNEL_CHECK();
     }

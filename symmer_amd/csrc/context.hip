@@ -412,6 +412,14 @@ int symgpu_dev_download(const void *dev, void *host, int64_t bytes) {
     return SYMGPU_OK;
 }
 
+int symgpu_dev_upload(void *dev, const void *host, int64_t bytes) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(dev && host && bytes >= 0, "dev_upload");
+    HIP_TRY(hipMemcpyAsync(dev, host, (size_t)bytes, hipMemcpyHostToDevice, ctx().stream));
+    HIP_TRY(hipStreamSynchronize(ctx().stream));
+    return SYMGPU_OK;
+}
+
 static int reduce_to_host_u64(void (*launch)(const void *, i64, unsigned long long *, hipStream_t), const void *p, i64 n, uint64_t *sum) {
     Scratch acc;
     SG_TRY(acc.alloc(sizeof(unsigned long long)));

@@ -467,3 +467,26 @@ def test_mul_cleanup_unpacked_fallback_path(monkeypatch):
     monkeypatch.delenv('SYMGPU_CLEANUP_UNPACKED')
     rows3, coeff3 = kernels.mul_cleanup(A.packed, A.coeff_vec, A.packed, A.coeff_vec, True, 1e-15)
     assert np.array_equal(rows2, rows3) and np.array_equal(coeff2, coeff3)
+
+
+@pytest.mark.parametrize('n,N,M', [(100, 37, 1000), (1000, 129, 517), (64, 5, 64)])
+def test_commutes_bit_packed_output(n, N, M):
+    """symgpu_commutes_bits_dev: bit j of row i (little-endian u64 words, zero padding up to the word end) == C[i, j]."""
+    import ctypes
+    from symmer_amd import _lib
+    from symmer_amd.kernels import DeviceOp
+    rng = np.random.default_rng(200 + n)
+    a = packing.pack_rows(rng.random((N, 2 * n)) < 0.3); b = packing.pack_rows(rng.random((M, 2 * n)) < 0.3)
+    A, B = DeviceOp.upload(a), DeviceOp.upload(b)
+    words = (M + 63) // 64
+    lib = _lib.lib()
+    bits = ctypes.c_void_p()
+    _lib.check(lib.symgpu_dev_alloc(N * words * 8, ctypes.byref(bits)))
+    junk = np.full(N * words, 0xFFFFFFFFFFFFFFFF, dtype='<u8')              # the kernel must overwrite every word completely
+    _lib.check(lib.symgpu_dev_upload(bits, junk.ctypes.data, junk.nbytes))
+    _lib.check(lib.symgpu_commutes_bits_dev(A.handle, 0, N, B.handle, bits))
+    out = np.empty((N, words), dtype='<u8')
+    _lib.check(lib.symgpu_dev_download(bits, out.ctypes.data, out.nbytes))
+    expect = packing.pack_bits(oc.commutes(a, b), words)
+    assert np.array_equal(out, expect)
+    _lib.check(lib.symgpu_dev_free(bits)); A.free(); B.free()
