@@ -230,6 +230,32 @@ def check_independent(symp):
     return not np.any(np.all(~red, axis=1))
 
 
+def check_jordan_independent(symp):
+    """utils.py:521-566: at most 3n terms; the globally commuting terms are independent; no dependency among the rows
+    [X-only | Z-only | Y] (Y as a third symbol)."""
+    symp = np.asarray(symp, dtype=bool)
+    t, n = symp.shape[0], symp.shape[1] // 2
+    if t > 3 * n:
+        return False
+    universal = np.all(commutes_termwise(symp, symp), axis=1)
+    if not check_independent(symp[universal]):
+        return False
+    x, z = symp[:, :n], symp[:, n:]
+    y = x & z
+    red = rref_noswap(np.hstack([x ^ y, z ^ y, y]))
+    return not np.any(np.all(~red, axis=1))
+
+
+def reindex(symp, old_indices, new_indices):
+    """base.py:493-521: column ``old`` of the result is column ``new`` of the input, in both blocks."""
+    symp = np.asarray(symp, dtype=bool)
+    n = symp.shape[1] // 2
+    x, z = symp[:, :n].copy(), symp[:, n:].copy()
+    x[:, list(old_indices)] = symp[:, :n][:, list(new_indices)]
+    z[:, list(old_indices)] = symp[:, n:][:, list(new_indices)]
+    return np.hstack([x, z])
+
+
 def generators(symp):
     """base.py:1436-1456: non-zero rows of ``_rref_binary(symp)``."""
     red = rref_noswap(symp)

@@ -315,3 +315,55 @@ for n, t_op, t_psi in ((1, 2, 2), (3, 6, 4), (5, 40, 12), (8, 30, 60), (20, 50, 
             inner=np.array(complex(psi.dagger * phi)), expval=np.array(complex(P.expval(psi))),
             term_expvals=np.array([single_term_expval(Pk, psi) for Pk in P]))
 fam.save()
+
+
+# ---------------------------------------------------------------- jordan / reindex (host glue on the GF(2) + commutation kernels) --------
+from symmer.operators.utils import check_jordan_independent
+rj = np.random.default_rng(4242)
+fam = Family('jordan')
+# (1) known answers of tests/test_operators/test_operator_utils.py:4-75
+for plist, expect in [(['XXX', 'XII', 'IIX', 'IXI', 'ZZI', 'IYY'], False), (['IX', 'IY', 'IZ', 'ZI', 'YI', 'XI'], True),
+                      (['IX', 'IY', 'IZ', 'ZI', 'YI', 'XI', 'XX'], False), (['XX', 'YY', 'ZZ'], False),
+                      (['XZXIIIZI', 'IZZIZZZX', 'IXXXZXZI', 'IIZIIXZX', 'XIXIIIIZ', 'ZYIIZZIY', 'IIIXIIII', 'ZIZIIYZZ', 'IIZIIIXY'], True)]:
+    P = PauliwordOp.from_list(plist)
+    assert bool(check_jordan_independent(P)) == expect
+    fam.add(kind=np.array(0), symp=P.symp_matrix, expect=np.array(expect))
+# (2) random operators judged by the reference
+for trial in range(30):
+    n = int(rj.integers(1, 7)); t = int(rj.integers(1, 3 * n + 2))
+    P = PauliwordOp((rj.random((t, 2 * n)) < 0.4), np.ones(t))
+    fam.add(kind=np.array(0), symp=P.symp_matrix, expect=np.array(bool(check_jordan_independent(P))))
+# (3) reindex: list and dictionary forms
+for trial in range(10):
+    n = int(rj.integers(2, 9)); t = int(rj.integers(1, 8))
+    P = PauliwordOp((rj.random((t, 2 * n)) < 0.5), rj.integers(-8, 9, t) / 16)
+    k = int(rj.integers(2, n + 1))
+    chosen = rj.choice(n, k, replace=False)
+    shuffled = rj.permutation(chosen)
+    if trial % 2 == 0:
+        Q = P.reindex([int(v) for v in shuffled])
+        fam.add(kind=np.array(1), symp=P.symp_matrix, coeff=P.coeff_vec, keys=np.sort(chosen), vals=shuffled, as_list=np.array(1), out=Q.symp_matrix)
+    else:
+        Q = P.reindex({int(a): int(b) for a, b in zip(chosen, shuffled)})
+        fam.add(kind=np.array(1), symp=P.symp_matrix, coeff=P.coeff_vec, keys=chosen, vals=shuffled, as_list=np.array(0), out=Q.symp_matrix)
+# (4) jordan_generator_reconstruction: symmetry generators + one anticommuting clique (docstring example of utils.py:533-541 and random)
+def jordan_case(G, n_terms):
+    sym = np.all(G.commutes_termwise(G), axis=1)
+    S, A = G[sym], G[~sym]
+    rows = []
+    for _ in range(n_terms):
+        term = PauliwordOp.from_list(['I' * G.n_qubits])
+        for s in S:
+            if rj.random() < 0.5:
+                term = term * s
+        if A.n_terms and rj.random() < 0.7:
+            term = term * A[int(rj.integers(A.n_terms))]
+        rows.append(term.symp_matrix[0])
+    extra = (rj.random((2, 2 * G.n_qubits)) < 0.5)                  # most likely not reconstructable
+    H = PauliwordOp(np.vstack(rows + [extra]), np.ones(n_terms + 2))
+    R, mask = H.jordan_generator_reconstruction(G)
+    fam.add(kind=np.array(2), g_symp=G.symp_matrix, h_symp=H.symp_matrix, R=np.asarray(R), mask=np.asarray(mask))
+jordan_case(PauliwordOp.from_list(['IIZI', 'ZIIZ', 'IXII', 'IIIZ', 'XIIX']), 12)
+jordan_case(PauliwordOp.from_list(['ZII', 'IZI', 'IIZ']), 6)
+jordan_case(PauliwordOp.from_list(['ZIIII', 'IZIII', 'IIXII', 'IIZXX', 'IIYXX', 'IIIZI']), 15) if check_jordan_independent(PauliwordOp.from_list(['ZIIII', 'IZIII', 'IIXII', 'IIZXX', 'IIYXX', 'IIIZI'])) else None
+fam.save()

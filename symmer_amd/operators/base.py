@@ -15,7 +15,7 @@ import numpy as np
 
 from .. import kernels, packing
 from .utils import (string_to_symplectic, symplectic_to_string, random_symplectic_matrix, check_independent,
-                    cref_binary, _rref_binary, check_adjmat_noncontextual)
+                    cref_binary, _rref_binary, check_adjmat_noncontextual, check_jordan_independent)
 
 warnings.simplefilter('always', UserWarning)
 
@@ -170,6 +170,58 @@ class PauliwordOp:
         elif key != 'decreasing':
             raise ValueError('Only permitted sort by values are increasing or decreasing')
         return self._derive(index=sort_order)
+
+    def reindex(self, qubit_map) -> "PauliwordOp":
+        """base.py:493-521: relabel qubits; ``{0: 2, 2: 3, 3: 0}`` or the list ``[2, 3, 0]`` (sorted values -> listed values):
+        column ``old`` of the result is column ``new`` of this operator."""
+        if isinstance(qubit_map, list):
+            old_indices, new_indices = sorted(qubit_map), qubit_map
+        elif isinstance(qubit_map, dict):
+            old_indices, new_indices = zip(*qubit_map.items())
+        else:
+            raise TypeError('qubit_map must be a list or a dictionary')
+        unmapped = set(old_indices).difference(new_indices)
+        assert len(new_indices) == len(set(new_indices)), 'Duplicated index'
+        assert len(unmapped) == 0, f'Assignment conflict: indices {unmapped} cannot be mapped.'
+        perm = np.arange(self.n_qubits)
+        perm[list(old_indices)] = list(new_indices)
+        return PauliwordOp(np.hstack([self.X_block[:, perm], self.Z_block[:, perm]]), self.coeff_vec)
+
+    def set_processing_method(self, method):
+        """base.py:76-80 selects mp / ray / single_thread for the reference's host fan-out; the device path has no such pool."""
+        if method not in ('mp', 'ray', 'single_thread'):
+            raise ValueError('Invalid processing method, must be one of mp, single_thread or ray.')
+
+    def to_dataframe(self):
+        """base.py:1419-1434."""
+        import pandas as pd
+        frame = pd.DataFrame.from_dict({'Pauli terms': list(self.to_dictionary.keys()), 'Coefficients (real)': self.coeff_vec.real})
+        if np.any(self.coeff_vec.imag):
+            frame['Coefficients (imaginary)'] = self.coeff_vec.imag
+        return frame
+
+    def conjugate_op(self, R: "PauliwordOp") -> "PauliwordOp":
+        """base.py:1512-1561 is a stub in the reference as well."""
+        raise NotImplementedError('not done yet. Full function at: from symmer.operators.anticommuting_op.conjugate_Pop_with_R')
+
+    def jordan_generator_reconstruction(self, generators: "PauliwordOp"):
+        """base.py:562-602: reconstruction under the Jordan product — the symmetry generators plus ONE clique of the
+        pairwise anticommuting generators at a time, each through ``generator_reconstruction`` (device GF(2) kernel)."""
+        assert check_jordan_independent(generators), 'The non-symmetry elements do not pairwise anticommute.'
+        symmetry_mask = np.all(generators.commutes_termwise(generators), axis=1)
+        if np.all(symmetry_mask):
+            return self.generator_reconstruction(generators)
+        reconstruction = np.zeros([self.n_terms, generators.n_terms])
+        reconstructed = np.zeros(self.n_terms, dtype=bool)
+        for clique in generators[~symmetry_mask].clique_cover(edge_relation='C').values():
+            member = [int(np.where(np.all(generators.symp_matrix == row, axis=1))[0][0]) for row in clique.symp_matrix]
+            use = symmetry_mask.copy()
+            use[member] = True
+            part, ok = self.generator_reconstruction(generators[use])
+            rows, cols = np.ix_(ok, use)
+            reconstruction[rows, cols] = part[ok]
+            reconstructed |= ok
+        return reconstruction.astype(int), reconstructed
 
     # ---- a2 ----------------------------------------------------------------------------------------------
     @cached_property

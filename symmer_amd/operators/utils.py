@@ -119,3 +119,19 @@ def check_adjmat_noncontextual(adjmat) -> bool:
     mask_non_universal = np.where(~np.all(adjmat, axis=1))[0]
     unique_character = np.unique(adjmat[mask_non_universal, :][:, mask_non_universal], axis=0)
     return bool(np.all(np.count_nonzero(unique_character, axis=0) == 1))
+
+
+def check_jordan_independent(operators) -> bool:
+    """Reference utils.py:521-566: independence under the Jordan product PQ = {P,Q}/2.  At most 3n terms; the globally
+    commuting terms must be independent as ordinary generators; then the rows [X-only | Z-only | Y] (Y treated as its own
+    symbol) must have no dependency — all three tests on the device GF(2) / commutation kernels."""
+    if operators.n_terms > 3 * operators.n_qubits:
+        return False
+    commute = operators.commutes_termwise(operators)
+    universal = operators[np.all(commute, axis=1)]
+    if not check_independent(universal):
+        return False
+    y = operators.X_block & operators.Z_block
+    three_symbol = np.hstack([operators.X_block ^ y, operators.Z_block ^ y, y])
+    reduced = _rref_binary(three_symbol)
+    return bool(~np.any(np.all(~reduced, axis=1)))

@@ -490,3 +490,24 @@ def test_commutes_bit_packed_output(n, N, M):
     expect = packing.pack_bits(oc.commutes(a, b), words)
     assert np.array_equal(out, expect)
     _lib.check(lib.symgpu_dev_free(bits)); A.free(); B.free()
+
+
+@pytest.mark.parametrize('case', family('jordan'))
+def test_jordan_and_reindex_golden(case):
+    """check_jordan_independent / reindex / jordan_generator_reconstruction against outputs of the reference."""
+    from symmer_amd.operators import check_jordan_independent
+    kind = int(case['kind'])
+    if kind == 0:
+        P = PauliwordOp(case['symp'].astype(bool), np.ones(case['symp'].shape[0]))
+        assert bool(check_jordan_independent(P)) == bool(case['expect'])
+    elif kind == 1:
+        P = PauliwordOp(case['symp'].astype(bool), case['coeff'])
+        vals = [int(v) for v in case['vals']]
+        Q = P.reindex(vals) if int(case['as_list']) else P.reindex({int(a): int(b) for a, b in zip(case['keys'], vals)})
+        assert np.array_equal(Q.symp_matrix, case['out'].astype(bool)) and np.array_equal(Q.coeff_vec, P.coeff_vec)
+    else:
+        G = PauliwordOp(case['g_symp'].astype(bool), np.ones(case['g_symp'].shape[0]))
+        H = PauliwordOp(case['h_symp'].astype(bool), np.ones(case['h_symp'].shape[0]))
+        R, mask = H.jordan_generator_reconstruction(G)
+        assert np.array_equal(mask, case['mask'].astype(bool))
+        assert np.array_equal(np.asarray(R)[mask], case['R'][mask])

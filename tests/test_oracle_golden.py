@@ -122,3 +122,13 @@ def test_symgen(case):
     assert np.array_equal(onp.generators(h), as_bool(case['gens']))
     r, mask = onp.generator_reconstruction(h, as_bool(case['gens']))
     assert np.array_equal(r, case['recon']) and np.array_equal(mask, as_bool(case['recon_mask']))
+
+
+@pytest.mark.parametrize('case', [c for c in family('jordan') if int(c['kind']) in (0, 1)])
+def test_jordan_independence_and_reindex_golden(case):
+    if int(case['kind']) == 0:
+        assert onp.check_jordan_independent(case['symp'].astype(bool)) == bool(case['expect'])
+    else:
+        keys, vals = case['keys'].tolist(), case['vals'].tolist()
+        old, new = (sorted(vals), vals) if int(case['as_list']) else (keys, vals)
+        assert np.array_equal(onp.reindex(case['symp'].astype(bool), old, new), case['out'].astype(bool))
