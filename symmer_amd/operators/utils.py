@@ -63,6 +63,16 @@ def matmul_GF2(A: np.ndarray, B: np.ndarray) -> np.ndarray:
     return ~kernels.commutes(a, b)
 
 
+def numba_binary_matmal_GF2(A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """Reference utils.py:28-61 (AND/XOR loops under numba): the same boolean ``(A @ B) % 2`` on the device kernel."""
+    return matmul_GF2(A, B)
+
+
+def numba_dot_matmal_GF2(A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """Reference utils.py:63-78 (``np.dot`` in float64, ``% 2``): the same boolean ``(A @ B) % 2`` on the device kernel."""
+    return matmul_GF2(A, B)
+
+
 def mul_symplectic(symp_vec1, coeff1, symp_vec2, coeff2):
     """Reference utils.py:429-470 (scalar twin of the all-pairs product): one pair through the device kernel."""
     s1 = np.asarray(symp_vec1, dtype=bool).reshape(1, -1); s2 = np.asarray(symp_vec2, dtype=bool).reshape(1, -1)

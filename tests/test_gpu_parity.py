@@ -184,6 +184,8 @@ def test_matmul_gf2_vs_oracle():
     rng = np.random.default_rng(5)
     A = rng.random((70, 130)) < 0.5; B = rng.random((130, 45)) < 0.5
     assert np.array_equal(matmul_GF2(A, B), onp.matmul_gf2(A, B))
+    from symmer_amd.operators import numba_binary_matmal_GF2, numba_dot_matmal_GF2
+    assert np.array_equal(numba_binary_matmal_GF2(A, B), onp.matmul_gf2(A, B)) and np.array_equal(numba_dot_matmal_GF2(A, B), onp.matmul_gf2(A, B))
 
 
 @pytest.mark.parametrize('n,Ni,No,left', [(1000, 700, 300, True), (1000, 300, 700, False), (100, 500, 500, True), (130, 1, 77, True),
