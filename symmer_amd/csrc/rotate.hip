@@ -333,9 +333,12 @@ __global__ __launch_bounds__(1024) void k_rotf_scan3(const uint8_t *__restrict__
 __global__ void k_rotf_write(const u32x4 *__restrict__ rows, const u32x4 *__restrict__ q, i64 T, int Wq, const uint8_t *__restrict__ cls,
                              const u32 *__restrict__ pos_self, const u32 *__restrict__ pos_new, const RotCounts *__restrict__ cnt,
                              const double *__restrict__ selfc, const double *__restrict__ prodc, u32x4 *__restrict__ out_rows,
-                             double *__restrict__ out_coeff) {
+                             double *__restrict__ out_coeff, int clifford) {
     const i64 total = T * Wq;
-    const u32 nC = cnt->nC, nA = cnt->nA;
+    // output order: non-Clifford [commuting | cos * anticommuting | new rows]; Clifford [rotated anticommuting | commuting]
+    const i64 baseC = clifford ? (i64)cnt->nA + cnt->nN : 0;
+    const i64 baseA = clifford ? 0 : (i64)cnt->nC;
+    const i64 baseN = clifford ? 0 : (i64)cnt->nC + cnt->nA;
     for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (i64)gridDim.x * blockDim.x) {
         const i64 t = idx / Wq;
         const int c = (int)(idx - t * Wq);
@@ -343,16 +346,103 @@ __global__ void k_rotf_write(const u32x4 *__restrict__ rows, const u32x4 *__rest
         if (!k) continue;
         const u32x4 v = rows[idx];
         if (k & 3) {
-            const i64 d = (k & 1) ? (i64)pos_self[t] : (i64)nC + pos_self[t];
+            const i64 d = (k & 1) ? baseC + pos_self[t] : baseA + pos_self[t];
             out_rows[d * Wq + c] = v;
             if (c == 0) { out_coeff[2 * d] = selfc[2 * t]; out_coeff[2 * d + 1] = selfc[2 * t + 1]; }
         }
         if (k & 4) {
-            const i64 d = (i64)nC + nA + pos_new[t];
+            const i64 d = baseN + pos_new[t];
             out_rows[d * Wq + c] = v ^ q[c];
             if (c == 0) { out_coeff[2 * d] = prodc[2 * t]; out_coeff[2 * d + 1] = prodc[2 * t + 1]; }
         }
     }
+}
+
+// Clifford rotation (angle = k * pi/2), classes + per-1024-row block counts in one launch:
+//   commuting row            -> class 1, coefficient unchanged
+//   anticommuting, even k    -> class 2 (the row itself), coefficient c (k = 0) or -c (k = 2)
+//   anticommuting, odd k     -> class 4 (row ^ Q), coefficient c * i^e * (-i), negated for k = 3; rows with |c| <= thr are
+//                               dropped as the reference's `*` does (cleanup inside _multiply_by_operator, base.py:789-793)
+// `k` arrives already mapped by rotation_args (negative multiples are not reduced mod 4, base.py:1148).
+__global__ __launch_bounds__(1024) void k_rotc_classify(const u32 *__restrict__ anti, const uint8_t *__restrict__ ph, const double *__restrict__ coeff,
+                                                         i64 T, int k, double thr, uint8_t *__restrict__ cls, double *__restrict__ selfc,
+                                                         double *__restrict__ prodc, u32 *__restrict__ blk) {
+    __shared__ u32 s_c[4];
+    if (threadIdx.x < 4) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    const i64 t = (i64)blockIdx.x * 1024 + threadIdx.x;
+    uint8_t c = 0;
+    bool a = false;
+    if (t < T) {
+        const double re = coeff[2 * t], im = coeff[2 * t + 1];
+        a = anti[t] != 0;
+        if (!a) {
+            c = 1;
+            selfc[2 * t] = re; selfc[2 * t + 1] = im;
+        } else if (k & 1) {
+            if (hypot(re, im) > thr) {
+                double x, y;
+                phase_mul(re, im, ph[t], x, y);
+                double pr = y, pi = -x;
+                if (k == 3) { pr = -pr; pi = -pi; }
+                prodc[2 * t] = pr; prodc[2 * t + 1] = pi;
+                c = 4;
+            }
+        } else {
+            const bool neg = (k == 2);
+            selfc[2 * t] = neg ? -re : re; selfc[2 * t + 1] = neg ? -im : im;
+            c = 2;
+        }
+        cls[t] = c;
+    }
+    const int lane = threadIdx.x & 63;
+    const u64 b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4), b3 = __ballot(a);
+    if (lane == 0) {
+        atomicAdd(&s_c[0], (u32)__popcll(b0)); atomicAdd(&s_c[1], (u32)__popcll(b1));
+        atomicAdd(&s_c[2], (u32)__popcll(b2)); atomicAdd(&s_c[3], (u32)__popcll(b3));
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) blk[blockIdx.x * 4 + threadIdx.x] = s_c[threadIdx.x];
+}
+
+// Clifford fast path: analyze (done by the caller) -> classify+count -> scan -> write, one host round trip at the very end.
+static int rotate_fast_clifford(symgpu_op_t in, const u64 *q_dev, const u32 *anti, const uint8_t *ph, int k, double thr, symgpu_op_t *out,
+                                int *all_commute, int *done) {
+    hipStream_t st = ctx().stream;
+    const i64 T = in->T;
+    const int Wq = in->Wq;
+    *done = 0;
+    if (T > ((i64)1 << 22)) return SYMGPU_OK;                  // block-count array of the 2-launch scan: <= 4096 blocks
+    Scratch selfc, prodc, cls, pself, pnew, cnt, blk;
+    const int n_blk = (int)((T + 1023) / 1024);
+    SG_TRY(blk.alloc((size_t)n_blk * 16));
+    SG_TRY(selfc.alloc((size_t)T * 16));
+    SG_TRY(prodc.alloc((size_t)T * 16));
+    SG_TRY(cls.alloc((size_t)T));
+    SG_TRY(pself.alloc((size_t)T * 4));
+    SG_TRY(pnew.alloc((size_t)T * 4));
+    SG_TRY(cnt.alloc(sizeof(RotCounts)));
+    hipLaunchKernelGGL(k_rotc_classify, dim3(n_blk), dim3(1024), 0, st, anti, ph, in->coeff, T, k, thr, cls.as<uint8_t>(), selfc.as<double>(),
+                       prodc.as<double>(), blk.as<u32>());
+    hipLaunchKernelGGL(k_rotf_scan3, dim3(n_blk), dim3(1024), 0, st, cls.as<uint8_t>(), T, blk.as<u32>(), n_blk, pself.as<u32>(), pnew.as<u32>(),
+                       cnt.as<RotCounts>());
+    KERNEL_CHECK();
+    symgpu_op_t res = nullptr;
+    SG_TRY(symgpu_op_alloc(T, Wq, 1, &res));                   // a Clifford rotation never adds rows
+    hipLaunchKernelGGL(k_rotf_write, dim3(grid_for(T * Wq)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(in->rows),
+                       reinterpret_cast<const u32x4 *>(q_dev), T, Wq, cls.as<uint8_t>(), pself.as<u32>(), pnew.as<u32>(), cnt.as<RotCounts>(),
+                       selfc.as<double>(), prodc.as<double>(), reinterpret_cast<u32x4 *>(res->rows), res->coeff, 1);
+    RotCounts hc;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&hc, cnt.p, sizeof(hc), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { symgpu_op_free(res); return hip_fail(e, "rotate Clifford fast path", __FILE__, __LINE__); }
+    *done = 1;
+    if (hc.nAnti == 0) { symgpu_op_free(res); *all_commute = 1; return SYMGPU_OK; }   // identity action (base.py:1131-1133)
+    res->T = (i64)hc.nC + hc.nA + hc.nN;
+    *out = res;
+    *all_commute = 0;
+    return SYMGPU_OK;
 }
 
 // returns SYMGPU_OK with *done = 1 (result in *out / *all_commute) or *done = 0 (duplicate rows: use the general path)
@@ -398,7 +488,7 @@ static int rotate_fast_nonclifford(symgpu_op_t in, const u64 *q_dev, const u64 *
     SG_TRY(symgpu_op_alloc(2 * T, Wq, 1, &res));               // upper bound: no host round trip before the write kernel
     hipLaunchKernelGGL(k_rotf_write, dim3(grid_for(T * Wq)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(in->rows),
                        reinterpret_cast<const u32x4 *>(q_dev), T, Wq, cls.as<uint8_t>(), pself.as<u32>(), pnew.as<u32>(), cnt.as<RotCounts>(),
-                       selfc.as<double>(), prodc.as<double>(), reinterpret_cast<u32x4 *>(res->rows), res->coeff);
+                       selfc.as<double>(), prodc.as<double>(), reinterpret_cast<u32x4 *>(res->rows), res->coeff, 0);
     RotCounts hc;
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&hc, cnt.p, sizeof(hc), hipMemcpyDeviceToHost, st);
@@ -465,6 +555,13 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
     if (try_fast) {
         int done = 0;
         SG_TRY(rotate_fast_nonclifford(in, q.as<u64>(), q_row_host, anti.as<u32>(), ph.as<uint8_t>(), hrows.as<u64>(), cos_t, sin_t, thr, out, all_commute, &done));
+        if (done) return SYMGPU_OK;
+        *out = nullptr;
+        *all_commute = 1;
+    }
+    if (clifford && !getenv("SYMGPU_ROTATE_GENERAL")) {
+        int done = 0;
+        SG_TRY(rotate_fast_clifford(in, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(), clifford_k, thr, out, all_commute, &done));
         if (done) return SYMGPU_OK;
         *out = nullptr;
         *all_commute = 1;

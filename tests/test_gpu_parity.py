@@ -513,3 +513,11 @@ def test_jordan_and_reindex_golden(case):
         R, mask = H.jordan_generator_reconstruction(G)
         assert np.array_equal(mask, case['mask'].astype(bool))
         assert np.array_equal(np.asarray(R)[mask], case['R'][mask])
+
+
+@pytest.mark.parametrize('case', family('rotate')[::3])
+def test_rotate_golden_general_path(case, monkeypatch):
+    """SYMGPU_ROTATE_GENERAL=1 disables the hash-join (non-Clifford) and fused (Clifford) fast paths: the stacked-operator +
+    cleanup path that serves inputs with duplicate rows and very large operators must give the same answers."""
+    monkeypatch.setenv('SYMGPU_ROTATE_GENERAL', '1')
+    test_rotate_golden(case)
