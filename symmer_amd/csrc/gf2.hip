@@ -73,12 +73,10 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l) {
     return ((u64)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(64) void k_wpanel(const u64 *__restrict__ rows, i64 R, i64 Wc, SweepState *__restrict__ st, const int *__restrict__ lead,
-                                                BlockInfo *__restrict__ info, i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count) {
-    const int lane = threadIdx.x;
-    const i64 i0 = st->next_i0;
+// the panel proper: ONE wavefront (lane = block row), `a` = this lane's leading word (lead[] semantics), block starts at i0
+__device__ __forceinline__ void panel_wave(const u64 *__restrict__ rows, i64 R, i64 Wc, i64 i0, int a, int lane, SweepState *__restrict__ st,
+                                           BlockInfo *__restrict__ info, i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count) {
     if (i0 >= R) { if (lane == 0) { info->i0 = i0; info->kk = 0; } return; }
-    const int a = lead[lane];
     const bool valid = a >= 0;
     const int n_valid = __popcll(__ballot(valid));                 // rows i0 .. i0+n_valid-1 exist
     const u64 zero_m = __ballot(valid && a == NOLEAD);
@@ -136,6 +134,12 @@ __global__ __launch_bounds__(64) void k_wpanel(const u64 *__restrict__ rows, i64
     }
 }
 
+__global__ __launch_bounds__(64) void k_wpanel(const u64 *__restrict__ rows, i64 R, i64 Wc, SweepState *__restrict__ st, const int *__restrict__ lead,
+                                                BlockInfo *__restrict__ info, i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count) {
+    const i64 i0 = st->next_i0;
+    panel_wave(rows, R, Wc, i0, i0 < R ? lead[threadIdx.x] : -1, threadIdx.x, st, info, pivots, xor_count);
+}
+
 // selectors of all rows (in terms of the OLD block rows), reference-order XOR count, snapshot of the old block rows.
 // One wavefront per row, lane j <-> pivot j: the 64 pivot-column bits are fetched in parallel and f is ONE __ballot.
 __global__ __launch_bounds__(256) void k_select(const u64 *__restrict__ rows, i64 R, i64 Wc, const BlockInfo *__restrict__ info,
@@ -175,14 +179,13 @@ __global__ __launch_bounds__(256) void k_select(const u64 *__restrict__ rows, i6
 // Each lane owns one word column of SW_ROWS rows (kept in registers); the old block rows stream past once
 // (independent loads, no dependent load->xor->store chain per row) and are XORed in under wave-uniform selector bits.
 template <int SW_ROWS, int UNR>
-__global__ __launch_bounds__(256) void k_sweep(u64 *__restrict__ rows, i64 R, i64 Wc, const BlockInfo *__restrict__ info,
-                                                const u64 *__restrict__ sel, const u64 *__restrict__ snap) {
-    const int kk = info->kk;
+__device__ __forceinline__ void sweep_tile(u64 *__restrict__ rows, i64 R, i64 Wc, int kk, const u64 *__restrict__ sel, const u64 *__restrict__ snap,
+                                           i64 col_block, i64 row_group) {
     if (kk == 0) return;
-    const i64 w = (i64)blockIdx.x * 256 + threadIdx.x;
+    const i64 w = col_block * 256 + threadIdx.x;
     const bool live = w < Wc;
     const i64 wl = live ? w : Wc - 1;                               // dead lanes load a valid column and never store
-    const i64 rb = (i64)blockIdx.y * SW_ROWS;
+    const i64 rb = row_group * SW_ROWS;
     const bool full = rb + SW_ROWS <= R;                             // uniform: branch-free loads and stores for full tiles
     u32 slo[SW_ROWS], shi[SW_ROWS];
     u64 x[SW_ROWS];
@@ -227,6 +230,111 @@ __global__ __launch_bounds__(256) void k_sweep(u64 *__restrict__ rows, i64 R, i6
     }
 }
 
+template <int SW_ROWS, int UNR>
+__global__ __launch_bounds__(256) void k_sweep(u64 *__restrict__ rows, i64 R, i64 Wc, const BlockInfo *__restrict__ info,
+                                                const u64 *__restrict__ sel, const u64 *__restrict__ snap) {
+    sweep_tile<SW_ROWS, UNR>(rows, R, Wc, info->kk, sel, snap, blockIdx.x, blockIdx.y);
+}
+
+// ---- Method-of-Four-Russians sweep ------------------------------------------------------------------------------
+// The flag-per-block-row sweep above costs 3 VALU instructions per (block row, matrix row, word): ~200 per word of a matrix
+// row for a 64-row block, which makes the sweep VALU-bound.  Here a workgroup owns a 64-word column tile and FIRST tabulates,
+// in LDS, all 16 XOR combinations of every group of 4 old block rows (16 groups x 16 entries x 64 words x 8 B = 128 KiB of the
+// CU's 160 KiB).  A matrix row then needs 16 table look-ups (ds_read_b64, wave-uniform entry index taken from 4 selector bits,
+// consecutive lanes -> consecutive words: conflict free) and 16 XORs per word instead of 64 conditional ones.
+// PHASE as in k_sweep_lookahead: 0 = only the rows of the next block, 1 = workgroup 0 runs the panel of the next block and the
+// others sweep all remaining rows.
+constexpr int M4_TW = 64;                       // words per column tile = lanes
+constexpr int M4_NT = 1024;                     // threads per workgroup (16 waves; one workgroup per CU because of the table)
+constexpr int M4_U = 4;                         // rows in flight per wave
+constexpr size_t M4_LDS = (size_t)16 * 16 * M4_TW * sizeof(u64);
+
+template <int PHASE>
+__global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64 R, i64 Wc, const BlockInfo *__restrict__ info,
+                                                      const u64 *__restrict__ sel, const u64 *__restrict__ snap, int n_tiles, int n_chunks,
+                                                      BlockInfo *__restrict__ info_next, SweepState *__restrict__ st, i64 *__restrict__ pivots,
+                                                      unsigned long long *__restrict__ xor_count, int *__restrict__ lead) {
+    extern __shared__ u64 tab[];                                    // [16 groups][16 entries][64 words]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = info->kk;
+    const i64 i0n = info->i0 + kk;                                  // first row of the next block
+    // rows of the next block: [nb, ne)   (PHASE 2: plain sweep of all rows, no lookahead)
+    const i64 nb = PHASE == 2 ? 0 : (i0n < R ? i0n : R), ne = PHASE == 2 ? 0 : (i0n + WK < R ? i0n + WK : R);
+    int k = blockIdx.x;
+    if (PHASE == 1) {
+        if (k == 0) {
+            // ---- panel workgroup: one wavefront; the leading words were collected by phase 0 (reset for the next block) ----
+            if (wave == 0) {
+                int a = -1;
+                if (i0n + lane < R) { a = lead[lane]; lead[lane] = NOLEAD; }
+                panel_wave(rows, R, Wc, i0n, a, lane, st, info_next, pivots, xor_count);
+            }
+            return;
+        }
+        --k;
+    }
+    if (kk == 0 && PHASE != 0) return;
+    const int tile = k % n_tiles, chunk = k / n_tiles;
+    // rows of this chunk: PHASE 0 the next block's rows, PHASE 1 / 2 the virtual index space of all OTHER rows
+    const i64 n_rows = PHASE == 0 ? ne - nb : R - (ne - nb);
+    const i64 per = (n_rows + n_chunks - 1) / n_chunks;
+    const i64 v_lo = (i64)chunk * per, v_hi = v_lo + per < n_rows ? v_lo + per : n_rows;
+    if (v_lo >= v_hi) return;
+    const i64 w = (i64)tile * M4_TW + lane;
+    const bool live = w < Wc;
+    const i64 wl = live ? w : Wc - 1;
+    // ---- tabulate the XOR combinations of the old block rows ----
+    if (kk != 0) {
+        for (int g = wave; g < 16; g += M4_NT / 64) {
+            u64 sv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv[i] = (4 * g + i < kk) ? snap[(i64)(4 * g + i) * Wc + wl] : 0ULL;
+            u64 t[16];
+            t[0] = 0; t[1] = sv[0]; t[2] = sv[1]; t[3] = sv[0] ^ sv[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[4 + e] = t[e] ^ sv[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[8 + e] = t[e] ^ sv[3];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tab[(g * 16 + e) * M4_TW + lane] = t[e];
+        }
+    }
+    __syncthreads();
+    // ---- stream the rows: M4_U per wave and step so that their loads overlap ----
+    const i64 shift = ne - nb;
+    for (i64 v0 = v_lo + M4_U * wave; v0 < v_hi; v0 += M4_U * (M4_NT / 64)) {
+        i64 r[M4_U];
+        u64 x[M4_U];
+        u32 slo[M4_U], shi[M4_U];
+#pragma unroll
+        for (int u = 0; u < M4_U; ++u) {
+            const i64 v = v0 + u < v_hi ? v0 + u : v0;               // tail: surplus slots repeat the first row and are not stored
+            r[u] = PHASE == 0 ? nb + v : (v < nb ? v : v + shift);
+            const u64 s1 = kk != 0 ? sel[r[u]] : 0ULL;
+            slo[u] = __builtin_amdgcn_readfirstlane((u32)s1);
+            shi[u] = __builtin_amdgcn_readfirstlane((u32)(s1 >> 32));
+            x[u] = rows[r[u] * Wc + wl];
+        }
+#pragma unroll
+        for (int u = 0; u < M4_U; ++u) {
+            const bool mine = (u == 0 || v0 + u < v_hi);
+            if ((slo[u] | shi[u]) != 0u) {                           // uniform; untouched rows are not rewritten
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const u32 e = ((g < 8 ? slo[u] : shi[u]) >> (4 * (g & 7))) & 15u;
+                    x[u] ^= tab[(g * 16 + (int)e) * M4_TW + lane];
+                }
+                if (live && mine) rows[r[u] * Wc + w] = x[u];
+            }
+            if (PHASE == 0 && mine) {
+                // leading word of the next block's rows for its panel: minimum over the column tiles
+                const u64 nz = __ballot(live && x[u] != 0);
+                if (nz && lane == 0) atomicMin(&lead[r[u] - nb], tile * M4_TW + (int)__builtin_ctzll(nz));
+            }
+        }
+    }
+}
+
 // ---- in-place reduction of a device matrix -------------------------------------------------------
 int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     hipStream_t st = ctx().stream;
@@ -234,7 +342,7 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     if (R <= 0 || Wc <= 0) return SYMGPU_OK;
     if (Wc >= ((i64)1 << 31) - 64) { set_error("rref: Wc too large"); return SYMGPU_E_INVALID; }
     Scratch info, state, lead, sel, snap, count, piv, rowcnt;
-    SG_TRY(info.alloc(sizeof(BlockInfo)));
+    SG_TRY(info.alloc(2 * sizeof(BlockInfo)));
     SG_TRY(state.alloc(sizeof(SweepState)));
     SG_TRY(lead.alloc(WK * sizeof(int)));
     SG_TRY(sel.alloc((size_t)R * 8));
@@ -245,9 +353,63 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     HIP_TRY(hipMemsetAsync(rowcnt.p, 0, (size_t)R * 4, st));
     HIP_TRY(hipMemsetAsync(count.p, 0, 16, st));
     HIP_TRY(hipMemsetAsync(state.p, 0, sizeof(SweepState), st));
+    HIP_TRY(hipMemsetAsync(info.p, 0, 2 * sizeof(BlockInfo), st));   // {i0 = 0, kk = 0}: "nothing swept yet, next block starts at row 0"
     constexpr int SW_ROWS = 16;                                     // rows per sweep workgroup, held in VGPRs
     const unsigned gx = (unsigned)((Wc + 255) / 256), gy = (unsigned)((R + SW_ROWS - 1) / SW_ROWS);
     const unsigned gsel = (unsigned)((R + 3) / 4);
+    BlockInfo *binfo = info.as<BlockInfo>();
+    // Four-Russians sweep (128 KiB of LDS per workgroup) unless disabled or refused by the runtime
+    static const bool m4r_ok = [] {
+        const char *e = getenv("SYMGPU_GF2_M4R");
+        if (e && e[0] == '0') return false;
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess;
+    }();
+    const bool m4r = m4r_ok, m4r_plain = m4r_ok;
+    const int m4_tiles = (int)((Wc + M4_TW - 1) / M4_TW);
+    int m4_chunks = 256 / m4_tiles;                              // one workgroup per CU: about one round of workgroups
+    if ((i64)m4_chunks > (R + 127) / 128) m4_chunks = (int)((R + 127) / 128);   // the table costs about 100 rows of work
+    if (m4_chunks < 1) m4_chunks = 1;
+    static const bool lookahead = [] { const char *e = getenv("SYMGPU_GF2_LOOKAHEAD"); return !(e && e[0] == '0'); }();
+    if (lookahead && m4r && (i64)m4_tiles * m4_chunks + 1 < ((i64)1 << 31)) {
+        // Pipeline, three launches per block: select(b) -> phase 0: sweep of the rows of block b+1 + their leading words ->
+        // phase 1: panel of block b+1 (-> the other info buffer) inside the sweep of all remaining rows.  The very first
+        // iteration has nothing to sweep (zeroed info): it only collects the leading words of rows 0..63 and panels block 0.
+        // `it` keeps counting across batches.
+        {
+            int h_lead[WK];
+            for (int k = 0; k < WK; ++k) h_lead[k] = NOLEAD;
+            HIP_TRY(hipMemcpyAsync(lead.p, h_lead, sizeof(h_lead), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));                      // h_lead is a stack buffer
+        }
+        i64 it = 0, done = 0, prev = -1;
+        bool finished = false;
+        while (!finished) {
+            i64 n_iter = (R - done + WK - 1) / WK + 1;
+            if (n_iter > 4096) n_iter = 4096;
+            for (i64 k = 0; k < n_iter; ++k, ++it) {
+                BlockInfo *cur = binfo + ((it + 1) & 1), *next = binfo + (it & 1);      // cur: block it-1 (to sweep), next: block it (to panel)
+                if (it > 0)
+                    hipLaunchKernelGGL(k_select, dim3(gsel), dim3(256), 0, st, rows, R, Wc, cur, sel.as<u64>(), snap.as<u64>(), rowcnt.as<u32>());
+                hipLaunchKernelGGL(k_sweep_m4r<0>, dim3(m4_tiles), dim3(M4_NT), M4_LDS, st, rows, R, Wc, cur, sel.as<u64>(), snap.as<u64>(),
+                                   m4_tiles, 1, next, state.as<SweepState>(), piv.as<i64>(), count.as<unsigned long long>(), lead.as<int>());
+                ProfScope prof(2);
+                hipLaunchKernelGGL(k_sweep_m4r<1>, dim3(m4_tiles * m4_chunks + 1), dim3(M4_NT), M4_LDS, st, rows, R, Wc, cur, sel.as<u64>(),
+                                   snap.as<u64>(), m4_tiles, m4_chunks, next, state.as<SweepState>(), piv.as<i64>(), count.as<unsigned long long>(),
+                                   lead.as<int>());
+                KERNEL_CHECK();
+            }
+            // the block that has been panelled but not swept yet: kk == 0 means the matrix is exhausted
+            struct { i64 i0; int kk; } pending;
+            HIP_TRY(hipMemcpyAsync(&pending, binfo + ((it + 1) & 1), sizeof(pending), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (pending.kk == 0) finished = true;
+            else if (pending.i0 <= prev) { set_error("rref: no progress (internal error)"); return SYMGPU_E_INVALID; }
+            prev = pending.i0;
+            done = pending.i0;
+        }
+    } else {
     i64 done = 0;
     while (done < R) {
         // optimistic batch: every block consumes up to 64 rows; blocks that end early are caught by the read-back
@@ -255,12 +417,16 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
         if (n_iter > 4096) n_iter = 4096;
         for (i64 it = 0; it < n_iter; ++it) {
             hipLaunchKernelGGL(k_lead, dim3(WK / 4), dim3(256), 0, st, rows, R, Wc, state.as<SweepState>(), lead.as<int>());
-            hipLaunchKernelGGL(k_wpanel, dim3(1), dim3(64), 0, st, rows, R, Wc, state.as<SweepState>(), lead.as<int>(), info.as<BlockInfo>(),
+            hipLaunchKernelGGL(k_wpanel, dim3(1), dim3(64), 0, st, rows, R, Wc, state.as<SweepState>(), lead.as<int>(), binfo,
                                piv.as<i64>(), count.as<unsigned long long>());
-            hipLaunchKernelGGL(k_select, dim3(gsel), dim3(256), 0, st, rows, R, Wc, info.as<BlockInfo>(), sel.as<u64>(), snap.as<u64>(),
+            hipLaunchKernelGGL(k_select, dim3(gsel), dim3(256), 0, st, rows, R, Wc, binfo, sel.as<u64>(), snap.as<u64>(),
                                rowcnt.as<u32>());
             ProfScope prof(2);
-hipLaunchKernelGGL((k_sweep<SW_ROWS, 4>), dim3(gx, gy), dim3(256), 0, st, rows, R, Wc, info.as<BlockInfo>(), sel.as<u64>(), snap.as<u64>());
+            if (m4r_plain)
+                hipLaunchKernelGGL(k_sweep_m4r<2>, dim3(m4_tiles * m4_chunks), dim3(M4_NT), M4_LDS, st, rows, R, Wc, binfo, sel.as<u64>(), snap.as<u64>(),
+                                   m4_tiles, m4_chunks, binfo, state.as<SweepState>(), piv.as<i64>(), count.as<unsigned long long>(), lead.as<int>());
+            else
+            hipLaunchKernelGGL((k_sweep<SW_ROWS, 4>), dim3(gx, gy), dim3(256), 0, st, rows, R, Wc, binfo, sel.as<u64>(), snap.as<u64>());
             KERNEL_CHECK();
         }
         SweepState hs;
@@ -268,6 +434,7 @@ hipLaunchKernelGGL((k_sweep<SW_ROWS, 4>), dim3(gx, gy), dim3(256), 0, st, rows, 
         HIP_TRY(hipStreamSynchronize(st));
         if (hs.next_i0 <= done) { set_error("rref: no progress (internal error)"); return SYMGPU_E_INVALID; }
         done = hs.next_i0;
+    }
     }
     hipLaunchKernelGGL(k_sum_u32, dim3(256), dim3(256), 0, st, rowcnt.as<u32>(), R, count.as<unsigned long long>());
     KERNEL_CHECK();
