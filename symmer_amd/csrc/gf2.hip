@@ -359,19 +359,18 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     const unsigned gsel = (unsigned)((R + 3) / 4);
     BlockInfo *binfo = info.as<BlockInfo>();
     // Four-Russians sweep (128 KiB of LDS per workgroup) unless disabled or refused by the runtime
-    static const bool m4r_ok = [] {
-        const char *e = getenv("SYMGPU_GF2_M4R");
-        if (e && e[0] == '0') return false;
+    static const bool m4r_attr = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess &&
                hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess &&
                hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess;
     }();
-    const bool m4r = m4r_ok, m4r_plain = m4r_ok;
+    const char *env_m4r = getenv("SYMGPU_GF2_M4R"), *env_la = getenv("SYMGPU_GF2_LOOKAHEAD");   // read per call: the tests switch paths
+    const bool m4r = m4r_attr && !(env_m4r && env_m4r[0] == '0'), m4r_plain = m4r;
     const int m4_tiles = (int)((Wc + M4_TW - 1) / M4_TW);
     int m4_chunks = 256 / m4_tiles;                              // one workgroup per CU: about one round of workgroups
     if ((i64)m4_chunks > (R + 127) / 128) m4_chunks = (int)((R + 127) / 128);   // the table costs about 100 rows of work
     if (m4_chunks < 1) m4_chunks = 1;
-    static const bool lookahead = [] { const char *e = getenv("SYMGPU_GF2_LOOKAHEAD"); return !(e && e[0] == '0'); }();
+    const bool lookahead = !(env_la && env_la[0] == '0');
     if (lookahead && m4r && (i64)m4_tiles * m4_chunks + 1 < ((i64)1 << 31)) {
         // Pipeline, three launches per block: select(b) -> phase 0: sweep of the rows of block b+1 + their leading words ->
         // phase 1: panel of block b+1 (-> the other info buffer) inside the sweep of all remaining rows.  The very first

@@ -521,3 +521,13 @@ def test_rotate_golden_general_path(case, monkeypatch):
     cleanup path that serves inputs with duplicate rows and very large operators must give the same answers."""
     monkeypatch.setenv('SYMGPU_ROTATE_GENERAL', '1')
     test_rotate_golden(case)
+
+
+@pytest.mark.parametrize('env', [{'SYMGPU_GF2_LOOKAHEAD': '0'}, {'SYMGPU_GF2_M4R': '0'}])
+@pytest.mark.parametrize('case', family('gf2')[::4])
+def test_gf2_golden_other_sweep_paths(case, env, monkeypatch):
+    """The GF(2) elimination has three schedules: lookahead + Four-Russians sweep (default), Four-Russians sweep without
+    lookahead, and the flag-per-block-row sweep; all must reproduce the reference's matrices."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    test_gf2_golden(case)
