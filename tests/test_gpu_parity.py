@@ -203,7 +203,8 @@ def test_mul_allpairs_vs_oracle(n, Ni, No, left):
     assert np.array_equal(coeff, ecoeff)        # both sides are the un-fused IEEE expression: bit-exact even for Gaussian input
 
 
-@pytest.mark.parametrize('n,N,M', [(100, 500, 500), (1000, 300, 200), (3, 700, 700), (65, 64, 900)])
+@pytest.mark.parametrize('n,N,M', [(100, 500, 500), (1000, 300, 200), (3, 700, 700), (65, 64, 900), (5000, 90, 60), (10, 70000, 3),
+                                   (40, 1, 5000), (40, 5000, 1), (2, 9, 9)])
 def test_mul_cleanup_vs_oracle(n, N, M):
     """cfg 1 (100 qubits, 500 terms squared: 250k pairs -> 124,751 unique) plus wider/narrower cases, bit-exact."""
     rng = np.random.default_rng(300 + n)
@@ -226,7 +227,8 @@ def test_mul_cleanup_gaussian_tolerance():
     assert_op_equal(R.symp_matrix, R.coeff_vec, erows, ecoeff, exact=False, tol=TOL)
 
 
-@pytest.mark.parametrize('T,n,dup', [(200000, 1000, 0.5), (50000, 100, 0.9), (100000, 3, 1.0), (4097, 2000, 0.2)])
+@pytest.mark.parametrize('T,n,dup', [(200000, 1000, 0.5), (50000, 100, 0.9), (100000, 3, 1.0), (4097, 2000, 0.2), (3000, 5000, 0.6), (1, 70, 0.0),
+                                     (65, 64, 0.5)])
 def test_cleanup_vs_oracle(T, n, dup):
     rng = np.random.default_rng(400 + n)
     base = packing.pack_rows(rng.random((max(1, int(T * (1 - dup)) + 1), 2 * n)) < 0.3)
