@@ -92,16 +92,20 @@ __device__ __forceinline__ void panel_wave(const u64 *__restrict__ rows, i64 R, 
         u64 C[WN];
 #pragma unroll
         for (int k = 0; k < WN; ++k) C[k] = (valid && (i64)w_lo + k < Wc) ? rows[(i0 + lane) * Wc + w_lo + k] : 0ULL;
-        for (int j = 0; j < n_valid; ++j) {
-            if ((zero_m >> j) & 1ULL) continue;                     // genuinely zero row: no pivot, never modified
-            if (!((in_m >> j) & 1ULL)) { kk = j; break; }           // leading word outside the window: it opens the next block
+        // rows still to process, in order (genuinely zero rows have no pivot and are never modified: skipped).  ONE exit test
+        // per pivot: the row's leading word lies outside the window, or the row cancelled to zero inside it -> it opens the
+        // next block (re-windowed at its own leading word).
+        u64 todo = (n_valid >= 64 ? ~0ULL : ((1ULL << n_valid) - 1ULL)) & ~zero_m;
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
             u64 p[WN];
 #pragma unroll
             for (int k = 0; k < WN; ++k) p[k] = readlane64(C[k], j);
             int k0 = -1;
 #pragma unroll
             for (int k = WN - 1; k >= 0; --k) if (p[k] != 0) k0 = k;
-            if (k0 < 0) { kk = j; break; }                          // cancelled to zero inside the window: re-window
+            if (!((in_m >> j) & 1ULL) || k0 < 0) { kk = j; break; }
+            todo &= todo - 1;
             u64 pk = p[0], ck = C[0];
 #pragma unroll
             for (int k = 1; k < WN; ++k) if (k == k0) { pk = p[k]; ck = C[k]; }
