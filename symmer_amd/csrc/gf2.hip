@@ -101,16 +101,25 @@ __device__ __forceinline__ void panel_wave(const u64 *__restrict__ rows, i64 R, 
             u64 p[WN];
 #pragma unroll
             for (int k = 0; k < WN; ++k) p[k] = readlane64(C[k], j);
-            int k0 = -1;
+            if (!((in_m >> j) & 1ULL)) { kk = j; break; }
+            int k0 = 0, b;
+            u64 mk;
+            if (p[0] != 0) {                                        // common case: the pivot sits in the first window word
+                b = __builtin_ctzll(p[0]);
+                mk = __ballot((C[0] >> b) & 1ULL);
+            } else {
+                k0 = -1;
 #pragma unroll
-            for (int k = WN - 1; k >= 0; --k) if (p[k] != 0) k0 = k;
-            if (!((in_m >> j) & 1ULL) || k0 < 0) { kk = j; break; }
+                for (int k = WN - 1; k >= 1; --k) if (p[k] != 0) k0 = k;
+                if (k0 < 0) { kk = j; break; }
+                u64 pk = p[1], ck = C[1];
+#pragma unroll
+                for (int k = 2; k < WN; ++k) if (k == k0) { pk = p[k]; ck = C[k]; }
+                b = __builtin_ctzll(pk);
+                mk = __ballot((ck >> b) & 1ULL);
+            }
+            mk &= ~(1ULL << j);
             todo &= todo - 1;
-            u64 pk = p[0], ck = C[0];
-#pragma unroll
-            for (int k = 1; k < WN; ++k) if (k == k0) { pk = p[k]; ck = C[k]; }
-            const int b = __builtin_ctzll(pk);
-            const u64 mk = __ballot((ck >> b) & 1ULL) & ~(1ULL << j);
             if (lane == j) { pw = w_lo + k0; pb = b; my_mask = mk; }
             const u64 tj = readlane64(tv, j);
             if ((mk >> lane) & 1ULL) {
@@ -304,21 +313,34 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
         }
     }
     __syncthreads();
-    // ---- stream the rows: M4_U per wave and step so that their loads overlap ----
+    // ---- stream the rows: M4_U per wave and step, software pipelined (the loads of step i+1 are in flight while step i
+    //      does its table look-ups: a wave only runs a handful of steps, so nothing else would hide the load latency) ----
     const i64 shift = ne - nb;
-    for (i64 v0 = v_lo + M4_U * wave; v0 < v_hi; v0 += M4_U * (M4_NT / 64)) {
+    const i64 step = M4_U * (M4_NT / 64);
+    i64 rn[M4_U];
+    u64 xn[M4_U], sn[M4_U];
+    auto fetch = [&](i64 v0) {
+#pragma unroll
+        for (int u = 0; u < M4_U; ++u) {
+            const i64 v = v0 + u < v_hi ? v0 + u : (v0 < v_hi ? v0 : v_lo);   // tail: surplus slots repeat a valid row, never stored
+            rn[u] = PHASE == 0 ? nb + v : (v < nb ? v : v + shift);
+            sn[u] = kk != 0 ? sel[rn[u]] : 0ULL;
+            xn[u] = rows[rn[u] * Wc + wl];
+        }
+    };
+    i64 v0 = v_lo + M4_U * wave;
+    if (v0 < v_hi) fetch(v0);
+    for (; v0 < v_hi; v0 += step) {
         i64 r[M4_U];
         u64 x[M4_U];
         u32 slo[M4_U], shi[M4_U];
 #pragma unroll
         for (int u = 0; u < M4_U; ++u) {
-            const i64 v = v0 + u < v_hi ? v0 + u : v0;               // tail: surplus slots repeat the first row and are not stored
-            r[u] = PHASE == 0 ? nb + v : (v < nb ? v : v + shift);
-            const u64 s1 = kk != 0 ? sel[r[u]] : 0ULL;
-            slo[u] = __builtin_amdgcn_readfirstlane((u32)s1);
-            shi[u] = __builtin_amdgcn_readfirstlane((u32)(s1 >> 32));
-            x[u] = rows[r[u] * Wc + wl];
+            r[u] = rn[u]; x[u] = xn[u];
+            slo[u] = __builtin_amdgcn_readfirstlane((u32)sn[u]);
+            shi[u] = __builtin_amdgcn_readfirstlane((u32)(sn[u] >> 32));
         }
+        if (v0 + step < v_hi) fetch(v0 + step);                      // uniform
 #pragma unroll
         for (int u = 0; u < M4_U; ++u) {
             const bool mine = (u == 0 || v0 + u < v_hi);
