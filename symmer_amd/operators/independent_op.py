@@ -5,7 +5,6 @@ assignment that the tapering workflow needs (host control flow over the device k
 Out of scope: clique selection for non-commuting generators (networkx) and ``QuantumState`` reference states.
 """
 import warnings
-from functools import reduce
 from typing import Dict, List, Tuple, Union
 import numpy as np
 from .. import kernels, packing
@@ -13,22 +12,30 @@ from .base import PauliwordOp
 from .utils import check_independent
 
 
+_SINGLE_QUBIT_TARGETS = ('X', 'Y', 'Z')
+
+
+def _weights(symp: np.ndarray) -> np.ndarray:
+    """number of set symplectic bits per row (1 <=> a single-qubit X or Z)"""
+    return np.count_nonzero(symp, axis=1)
+
+
 class IndependentOp(PauliwordOp):
+    """Algebraically independent stabilisers with eigenvalue assignments in {0, +1, -1} (kept as ``int``)."""
+
     def __init__(self, symp_matrix: np.ndarray, coeff_vec: Union[List[complex], np.ndarray] = None, target_sqp: str = 'Z'):
-        symp_matrix = np.asarray(symp_matrix)
-        if coeff_vec is None:
-            coeff_vec = np.ones(symp_matrix.shape[0], dtype=complex)
-        super().__init__(symp_matrix, coeff_vec)
+        rows = np.asarray(symp_matrix)
+        PauliwordOp.__init__(self, rows, np.ones(rows.shape[0], dtype=complex) if coeff_vec is None else coeff_vec)
+        # independent_op.py:33-43: eigenvalues first, then independence, then the rotation target
         self._check_stab()
         self.coeff_vec = self.coeff_vec.real.astype(int)
         self._check_independent()
-        if target_sqp in ['X', 'Z', 'Y']:
-            self.target_sqp = target_sqp
-        else:
+        if target_sqp not in _SINGLE_QUBIT_TARGETS:
             raise ValueError('Target single-qubit Pauli not recognised - must be X or Z')
-        self.stabilizer_rotations = None
-        self.used_indices = None
+        self.target_sqp = target_sqp
+        self.stabilizer_rotations, self.used_indices = None, None
 
+    # ---- constructors ------------------------------------------------------------------------------------
     @classmethod
     def from_PauliwordOp(cls, PwordOp: PauliwordOp) -> "IndependentOp":
         return cls(PwordOp.symp_matrix, PwordOp.coeff_vec)
@@ -46,45 +53,46 @@ class IndependentOp(PauliwordOp):
                             ) -> "IndependentOp":
         """independent_op.py:90-144: kernel of ``H Omega`` over GF(2).  The reference column-reduces
         ``vstack([hstack([Z, X]), eye(2n)])`` (:124-125) and reads the identity part of the columns whose top part
-        vanished (:126); the device builds the transposed matrix bit-packed, row-reduces it with the blocked
-        pivot-broadcast sweep and reads the same rows out, in the same order."""
-        if PwordOp.n_terms == 0 or PwordOp.n_qubits == 0:
-            S_symp = np.eye(2 * PwordOp.n_qubits, dtype=bool)     # nothing constrains the kernel
+        vanished (:126); the device builds the transposed matrix bit-packed, row-reduces it (blocked panel + Four-Russians
+        sweep, ``csrc/gf2.hip``) and reads the same rows out, in the same order."""
+        n = PwordOp.n_qubits
+        if PwordOp.n_terms and n:
+            packed_generators, _ = kernels.symmetry_kernel(PwordOp.packed, n)
+            found = packing.unpack_rows(packed_generators, n)
         else:
-            rows, _ = kernels.symmetry_kernel(PwordOp.packed, PwordOp.n_qubits)
-            S_symp = packing.unpack_rows(rows, PwordOp.n_qubits)
-        S = cls(S_symp, np.ones(S_symp.shape[0]))
-        if S.n_terms == 0:
+            found = np.eye(2 * n, dtype=bool)                     # nothing constrains the kernel
+        generators = cls(found, np.ones(found.shape[0]))
+        if generators.n_terms == 0:
             warnings.warn('The input PauliwordOp has no Z2 symmetries.')
-            return S
-        if commuting_override or np.all(S.adjacency_matrix):
-            return S
-        # non-commuting generators: take a commuting subset (independent_op.py:132-144; networkx graph glue on the
-        # device-computed adjacency matrix)
-        if S.n_terms < 10 or largest_clique:
-            S_commuting = S.largest_clique(edge_relation='C')
+        if generators.n_terms == 0 or commuting_override or bool(np.all(generators.adjacency_matrix)):
+            return generators
+        # the generators do not all commute: keep a commuting subset (independent_op.py:132-144 — networkx graph glue on
+        # the device-computed adjacency matrix; exact for small sets or on request, greedy colouring otherwise)
+        if largest_clique or generators.n_terms < 10:
+            subset = generators.largest_clique(edge_relation='C')
         else:
-            S_commuting = S.clique_cover(edge_relation='C', strategy='independent_set')[0]
+            subset = generators.clique_cover(edge_relation='C', strategy='independent_set')[0]
             warnings.warn('Greedy method may identify non-optimal commuting symmetry terms; might be able to taper again.')
-        return cls(S_commuting.symp_matrix, np.ones(S_commuting.n_terms, dtype=complex))
+        return cls(subset.symp_matrix, np.ones(subset.n_terms, dtype=complex))
 
+    # ---- validation --------------------------------------------------------------------------------------
     def _check_stab(self) -> None:
-        if not set(self.coeff_vec).issubset({0, +1, -1}):
+        allowed = {0, 1, -1}
+        if any(c not in allowed for c in self.coeff_vec):
             raise ValueError(f'Stabilizer coefficients not +/-1: {self.coeff_vec}')
 
     def _check_independent(self) -> None:
-        if not check_independent(self):
-            raise ValueError('The supplied stabilizers are not independent')
+        if check_independent(self):
+            return
+        raise ValueError('The supplied stabilizers are not independent')
 
+    # ---- printing / closure of the PauliwordOp operations ------------------------------------------------------
     def __str__(self) -> str:
         from .utils import symplectic_to_string
-        out_string = ''
-        for pauli_vec, coeff in zip(self.symp_matrix, self.coeff_vec):
-            out_string += f'{coeff} {symplectic_to_string(pauli_vec)} \n'
-        return out_string[:-2]
+        return ' \n'.join(f'{c} {symplectic_to_string(row)}' for row, c in zip(self.symp_matrix, self.coeff_vec))
 
     def __repr__(self) -> str:
-        return str(self)
+        return self.__str__()
 
     def __add__(self, Pword: "IndependentOp") -> "IndependentOp":
         return self.from_PauliwordOp(super().__add__(Pword))
@@ -95,50 +103,58 @@ class IndependentOp(PauliwordOp):
     def perform_rotations(self, rotations: List[Tuple[PauliwordOp, float]]) -> "IndependentOp":
         return self.from_PauliwordOp(super().perform_rotations(rotations))
 
+    def __getitem__(self, key) -> "IndependentOp":
+        picked = PauliwordOp.__getitem__(self, key)
+        return IndependentOp(picked.symp_matrix, picked.coeff_vec)
+
+    def __iter__(self):
+        return iter([self[k] for k in range(self.n_terms)])
+
     # ---- f4: rotation onto single-qubit Paulis (independent_op.py:204-273) --------------------------------------
     def _recursive_rotations(self, basis: "IndependentOp") -> None:
-        """independent_op.py:204-241: repeatedly pick the lowest-weight non-single-qubit stabiliser, its least-supported
-        qubit, and the pi/2 rotation that maps it onto that qubit; every rotation is one device pass."""
-        non_sqp = np.where(np.sum(basis.symp_matrix, axis=1) != 1)
-        basis_non_sqp = IndependentOp(basis.symp_matrix[non_sqp], basis.coeff_vec[non_sqp])
-        # the reference takes them from (basis - basis_non_sqp), i.e. after a cleanup: zero-coefficient terms drop out
-        sqp_rows = basis.symp_matrix[(np.sum(basis.symp_matrix, axis=1) == 1) & (np.abs(basis.coeff_vec) > 1e-15)]
-        sqp_indices = np.where(sqp_rows)[1] % self.n_qubits
-        self.used_indices += np.append(sqp_indices, sqp_indices + self.n_qubits).tolist()
-        if basis_non_sqp.n_terms == 0:
-            return None
-        row_sum = np.sum(basis_non_sqp.symp_matrix, axis=1)
-        pivot_row = basis_non_sqp.symp_matrix[np.argsort(row_sum)][0]
-        non_I = np.setdiff1d(np.where(pivot_row)[0], np.array(self.used_indices))
-        col_sum = np.sum(basis_non_sqp.symp_matrix, axis=0)
-        support = pivot_row * col_sum
-        pivot_point = non_I[np.argmin(support[non_I])]
-        target = np.zeros(2 * self.n_qubits, dtype=int)
-        target[pivot_point + self.n_qubits * (-1) ** (pivot_point // self.n_qubits)] = 1
-        pivot_rotation = PauliwordOp(np.bitwise_xor(target, pivot_row.astype(int)), [1])
-        self.stabilizer_rotations.append((pivot_rotation, None))
-        rotated_basis = basis_non_sqp._rotate_by_single_Pword(pivot_rotation)
-        return self._recursive_rotations(rotated_basis)
+        """independent_op.py:204-241, written as a loop: while a stabiliser of weight != 1 is left, take the lightest one,
+        choose among its not-yet-used positions the one supported by the fewest other stabilisers, and rotate (pi/2, one
+        device pass) by the Pauli that maps the stabiliser onto the conjugate single-qubit Pauli at that position."""
+        n = self.n_qubits
+        current = basis
+        while True:
+            weight = _weights(current.symp_matrix)
+            single = (weight == 1) & (np.abs(current.coeff_vec) > 1e-15)          # the reference sees them after a cleanup
+            qubits = np.where(current.symp_matrix[single])[1] % n
+            self.used_indices += np.concatenate([qubits, qubits + n]).tolist()
+            heavy = weight != 1
+            if not np.any(heavy):
+                return None
+            rest = IndependentOp(current.symp_matrix[heavy], current.coeff_vec[heavy])
+            lightest = rest.symp_matrix[np.argsort(_weights(rest.symp_matrix))[0]]
+            candidates = np.setdiff1d(np.flatnonzero(lightest), np.array(self.used_indices))
+            crowding = lightest * np.count_nonzero(rest.symp_matrix, axis=0)
+            position = candidates[np.argmin(crowding[candidates])]
+            conjugate = position + n if position < n else position - n            # X position <-> Z position of the same qubit
+            generator = lightest.astype(int)
+            generator[conjugate] ^= 1
+            rotation = PauliwordOp(generator, [1])
+            self.stabilizer_rotations.append((rotation, None))
+            current = rest._rotate_by_single_Pword(rotation)
 
     def generate_stabilizer_rotations(self) -> None:
-        """independent_op.py:243-273."""
+        """independent_op.py:243-273: the pi/2 rotations onto single-qubit Paulis, then one more per stabiliser whose
+        single-qubit image is not of the requested kind (X, Y or Z)."""
         assert self.n_terms <= self.n_qubits, 'Too many terms in basis to reduce to single-qubit Paulis'
         assert np.all(self.adjacency_matrix), 'The basis is not commuting, hence the rotation is not possible'
-        self.stabilizer_rotations = []
-        self.used_indices = []
-        basis = self.copy()
-        self._recursive_rotations(basis)
-        rotated_basis = basis.perform_rotations(self.stabilizer_rotations)
-        for P in rotated_basis:
-            sqp_index = np.where(P.symp_matrix[0])[0][0] % self.n_qubits
-            target = np.zeros(2 * self.n_qubits, dtype=int)
-            if self.target_sqp in ['X', 'Y']:
-                target[sqp_index] = 1
-            if self.target_sqp in ['Y', 'Z']:
-                target[sqp_index + self.n_qubits] = 1
-            R_symp = np.bitwise_xor(target, P.symp_matrix[0].astype(int))
-            if np.any(R_symp):
-                self.stabilizer_rotations.append((PauliwordOp(R_symp, [1]), None))
+        self.stabilizer_rotations, self.used_indices = [], []
+        start = self.copy()
+        self._recursive_rotations(start)
+        n = self.n_qubits
+        want_x, want_z = self.target_sqp in ('X', 'Y'), self.target_sqp in ('Y', 'Z')
+        for image in start.perform_rotations(self.stabilizer_rotations):
+            row = image.symp_matrix[0].astype(int)
+            qubit = int(np.flatnonzero(row)[0]) % n
+            fix = row.copy()
+            fix[qubit] ^= int(want_x)
+            fix[qubit + n] ^= int(want_z)
+            if fix.any():
+                self.stabilizer_rotations.append((PauliwordOp(fix, [1]), None))
 
     def update_sector(self, ref_state: Union[List[int], np.ndarray], threshold: float = 0.5) -> None:
         """independent_op.py:275-301 for a computational-basis reference state given as a bit array: the expectation
@@ -155,16 +171,12 @@ class IndependentOp(PauliwordOp):
             warnings.warn(f'The stabilizers {S_zero} were assigned zero values - bad reference state.')
 
     def rotate_onto_single_qubit_paulis(self) -> "IndependentOp":
-        """independent_op.py:303-319."""
+        """independent_op.py:303-319: every stabiliser through the rotation chain, stacked again in the original order."""
         self.generate_stabilizer_rotations()
-        if self.stabilizer_rotations != []:
-            return IndependentOp.from_PauliwordOp(
-                reduce(lambda x, y: x.append(y), [s.perform_rotations(self.stabilizer_rotations) for s in self]))
-        return self
-
-    def __getitem__(self, key) -> "IndependentOp":
-        P = PauliwordOp.__getitem__(self, key)
-        return IndependentOp(P.symp_matrix, P.coeff_vec)
-
-    def __iter__(self):
-        return iter([self[i] for i in range(self.n_terms)])
+        if not self.stabilizer_rotations:
+            return self
+        images = [stabilizer.perform_rotations(self.stabilizer_rotations) for stabilizer in self]
+        stacked = images[0]
+        for image in images[1:]:
+            stacked = stacked.append(image)
+        return IndependentOp.from_PauliwordOp(stacked)
