@@ -96,30 +96,30 @@ class PauliwordOp:
     @classmethod
     def random(cls, n_qubits: int, n_terms: int, diagonal: bool = False, complex_coeffs: bool = True,
                density: float = 0.3) -> "PauliwordOp":
-        symp_matrix = random_symplectic_matrix(n_qubits, n_terms, diagonal, density=density)
-        coeff_vec = np.random.randn(n_terms).astype(complex)
+        """base.py:82-107: Bernoulli(density) bits, standard-normal coefficients (same draws, same order, from NumPy's
+        global generator as the reference, so seeded scripts see the same operators)."""
+        bits = random_symplectic_matrix(n_qubits, n_terms, diagonal, density=density)
+        coeffs = np.random.randn(n_terms) + 0j
         if complex_coeffs:
-            coeff_vec += 1j * np.random.randn(n_terms)
-        return cls(symp_matrix, coeff_vec)
+            coeffs = coeffs + 1j * np.random.randn(n_terms)
+        return cls(bits, coeffs)
 
     @classmethod
     def from_list(cls, pauli_terms: List[str], coeff_vec: List[complex] = None) -> "PauliwordOp":
-        n_rows = len(pauli_terms)
+        """base.py:199-232: strings over I/X/Y/Z, all of one length; coefficients default to 1, may be (re, im) pairs."""
+        count = len(pauli_terms)
         if coeff_vec is None:
-            coeff_vec = np.ones(n_rows)
+            weights = np.ones(count)
         else:
-            coeff_vec = np.array(coeff_vec)
-            if len(coeff_vec.shape) == 2:
-                assert coeff_vec.shape[1] == 2, 'Only tuples of size two allowed (real and imaginary components)'
-                coeff_vec = coeff_vec[:, 0] + 1j * coeff_vec[:, 1]
-        if pauli_terms:
-            n_qubits = len(pauli_terms[0])
-            symp_matrix = np.zeros((n_rows, 2 * n_qubits), dtype=int)
-            for row_ind, pauli_str in enumerate(pauli_terms):
-                symp_matrix[row_ind] = string_to_symplectic(pauli_str, n_qubits)
-        else:
-            symp_matrix = np.array([[]], dtype=bool)
-        return cls(symp_matrix, coeff_vec)
+            weights = np.array(coeff_vec)
+            if weights.ndim == 2:
+                assert weights.shape[1] == 2, 'Only tuples of size two allowed (real and imaginary components)'
+                weights = weights[:, 0] + 1j * weights[:, 1]
+        if count == 0:
+            return cls(np.array([[]], dtype=bool), weights)
+        width = len(pauli_terms[0])
+        table = np.stack([string_to_symplectic(term, width) for term in pauli_terms]) if count else None
+        return cls(table.astype(int), weights)
 
     @classmethod
     def from_dictionary(cls, operator_dict: Dict[str, complex]) -> "PauliwordOp":
@@ -132,12 +132,10 @@ class PauliwordOp:
 
     # ---- printing / copying / ordering ---------------------------------------------------------------
     def __str__(self) -> str:
-        if self.symp_matrix.shape[1]:
-            out_string = ''
-            for pauli_vec, coeff in zip(self.symp_matrix, self.coeff_vec):
-                out_string += f'{coeff: .{self.sigfig}f} {symplectic_to_string(pauli_vec)} +\n'
-            return out_string[:-3]
-        return f'{self.coeff_vec[0]: .{self.sigfig}f}'
+        fmt = f' .{self.sigfig}f'
+        if self.n_qubits == 0:
+            return format(self.coeff_vec[0], fmt)                 # a bare scalar
+        return ' +\n'.join(f'{format(c, fmt)} {symplectic_to_string(row)}' for row, c in zip(self.symp_matrix, self.coeff_vec))
 
     def __repr__(self) -> str:
         return str(self)
@@ -392,20 +390,17 @@ class PauliwordOp:
         return self.qubitwise_commutes_termwise(self)
 
     def get_graph(self, edge_relation: str = 'C', label_nodes: bool = False):
+        """base.py:1192-1230: networkx graph whose edges join terms that commute ('C'), anticommute ('AC') or commute
+        qubit-wise ('QWC'); the relation matrices come from the device kernel."""
         import networkx as nx
-        if edge_relation == 'AC':
-            adjmat = ~self.adjacency_matrix.copy()
-        elif edge_relation == 'C':
-            adjmat = self.adjacency_matrix.copy()
-        elif edge_relation == 'QWC':
-            adjmat = self.adjacency_matrix_qwc.copy()
-        else:
+        relations = {'C': lambda: self.adjacency_matrix, 'AC': lambda: ~self.adjacency_matrix, 'QWC': lambda: self.adjacency_matrix_qwc}
+        if edge_relation not in relations:
             raise TypeError('Unrecognised edge relation, must be one of C (commuting), AC (anticommuting) or QWC (qubitwise commuting).')
-        np.fill_diagonal(adjmat, False)
-        graph = nx.from_numpy_array(adjmat)
+        edges = np.array(relations[edge_relation](), dtype=bool, copy=True)
+        np.fill_diagonal(edges, False)                            # no self loops
+        graph = nx.from_numpy_array(edges)
         if label_nodes:
-            nodes = [symplectic_to_string(r) for r in self.symp_matrix]
-            graph = nx.relabel_nodes(graph, dict(zip(range(len(nodes)), nodes)))
+            graph = nx.relabel_nodes(graph, {k: symplectic_to_string(row) for k, row in enumerate(self.symp_matrix)})
         return graph
 
     def largest_clique(self, edge_relation: str = 'C') -> "PauliwordOp":
