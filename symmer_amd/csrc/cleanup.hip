@@ -80,42 +80,43 @@ __device__ __forceinline__ u64 rotl64(u64 x, int r) { r &= 63; return r ? ((x <<
 __device__ __forceinline__ u64 xorshift_step(u64 h) { h ^= h << 13; h ^= h >> 7; h ^= h << 17; return h; }
 
 // Row hash on row-major rows.  G (power of two, <= 64) lanes cooperate on one row; lane g handles words
-// g, g+64, g+128, ... (only G == 64 has more than one).  h1 -> out1[t], h2 -> out2[t] (out2 may be null).
+// g, g+64, g+128, ... (only G == 64 has more than one).  Only the first of the two table columns is used (16 KiB of LDS).
 __global__ __launch_bounds__(256) void k_hash_rows(const u64 *__restrict__ rows, i64 T, int W, int G, const u64 *__restrict__ tab_g,
-                                                    u64 *__restrict__ out1, u64 *__restrict__ out2) {
-    __shared__ u64 tab[8 * 256 * 2];
-    for (int k = threadIdx.x; k < 8 * 256 * 2; k += 256) tab[k] = tab_g[k];
+                                                    u64 *__restrict__ out1) {
+    __shared__ u64 tab[8 * 256];
+    for (int k = threadIdx.x; k < 8 * 256; k += 256) tab[k] = tab_g[2 * k];
     __syncthreads();
     const int rows_per_block = 256 / G;
     const int g = threadIdx.x % G, rsub = threadIdx.x / G;
     const int n_blk = (W + 63) / 64;
-    for (i64 t0 = (i64)blockIdx.x * rows_per_block; t0 < T; t0 += (i64)gridDim.x * rows_per_block) {
-        const i64 t = t0 + rsub;
-        u64 h1 = 0, h2 = 0;
-        if (t < T) {
-            for (int b = 0; b < n_blk; ++b) {
-                const int w = b * 64 + g;
-                u64 a1 = 0, a2 = 0;
-                if (w < W && g < 64) {
-                    const u64 x = rows[t * W + w];
+    constexpr int HU = 4;                                           // row groups in flight per step (the loop is latency bound)
+    for (i64 t0 = (i64)blockIdx.x * rows_per_block * HU; t0 < T; t0 += (i64)gridDim.x * rows_per_block * HU) {
+        u64 h1[HU];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int v = (int)((x >> (8 * k)) & 255);
-                        a1 ^= tab[(k * 256 + v) * 2];
-                        a2 ^= tab[(k * 256 + v) * 2 + 1];
-                    }
+        for (int u = 0; u < HU; ++u) h1[u] = 0;
+        for (int b = 0; b < n_blk; ++b) {
+            const int w = b * 64 + g;
+            u64 x[HU];
+#pragma unroll
+            for (int u = 0; u < HU; ++u) {
+                const i64 t = t0 + (i64)u * rows_per_block + rsub;
+                x[u] = (t < T && w < W && g < 64) ? rows[t * W + w] : 0ULL;
+            }
+#pragma unroll
+            for (int u = 0; u < HU; ++u) {
+                u64 a1 = 0;
+                if (w < W && g < 64) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a1 ^= tab[k * 256 + (int)((x[u] >> (8 * k)) & 255)];
                 }
-                h1 = xorshift_step(h1) ^ rotl64(a1, g);
-                h2 = xorshift_step(h2) ^ rotl64(a2, g * 29 + 7);
+                h1[u] = xorshift_step(h1[u]) ^ rotl64(a1, g);
             }
         }
-        for (int off = G >> 1; off > 0; off >>= 1) {
-            h1 ^= __shfl_xor(h1, off);
-            h2 ^= __shfl_xor(h2, off);
-        }
-        if (g == 0 && t < T) {
-            out1[t] = h1;
-            if (out2) out2[t] = h2;
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            for (int off = G >> 1; off > 0; off >>= 1) h1[u] ^= __shfl_xor(h1[u], off);
+            const i64 t = t0 + (i64)u * rows_per_block + rsub;
+            if (g == 0 && t < T) out1[t] = h1[u];
         }
     }
 }
@@ -425,10 +426,10 @@ static int pow2_group(int W) {
 int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
     if (T == 0) return SYMGPU_OK;
     const int G = pow2_group(W);
-    const int rpb = 256 / G;
+    const int rpb = 4 * (256 / G);                                  // k_hash_rows: HU = 4 row groups per step
     i64 g = (T + rpb - 1) / rpb;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(k_hash_rows, dim3((unsigned)g), dim3(256), 0, ctx().stream, rows, T, W, G, ctx().hash_tab, out1, (u64 *)nullptr);
+    hipLaunchKernelGGL(k_hash_rows, dim3((unsigned)g), dim3(256), 0, ctx().stream, rows, T, W, G, ctx().hash_tab, out1);
     KERNEL_CHECK();
     return SYMGPU_OK;
 }
