@@ -64,6 +64,7 @@ struct ProfScope {
 
 // cached device allocator (hipMalloc is slow; rotations chain many small temporaries)
 int dev_alloc(size_t bytes, void **ptr);
+void prefault_host(void *dst, size_t bytes);                      // touch the pages of a large D2H destination first
 int dev_free(void *ptr);
 void dev_cache_release();
 

@@ -247,6 +247,7 @@ int symgpu_commutes(const uint64_t *A, int64_t N, const uint64_t *B, int64_t M, 
     }
     SG_TRY(dout.alloc((size_t)N * (size_t)M));
     SG_TRY(commutes_dev(da.as<u64>(), N, pb, M, Wq, dout.as<uint8_t>(), nullptr));
+    prefault_host(out, (size_t)N * (size_t)M);
     HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)N * (size_t)M, hipMemcpyDeviceToHost, ctx().stream));
     HIP_TRY(hipStreamSynchronize(ctx().stream));
     return SYMGPU_OK;

@@ -1,5 +1,9 @@
 // context.hip — context, error text, cached device allocator, operator handles, timers, checksums.
 #include "common.h"
+#include <thread>
+#include <sys/mman.h>
+#include <stdint.h>
+#include <vector>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -229,6 +233,33 @@ __global__ __launch_bounds__(256) void k_probe_copy(const u32x4p *in, u32x4p *ou
     if (i < n) out[i] = in[i];
 }
 
+// Large device -> host copies into FRESH pageable memory (np.empty) are bound by first-touch page faults taken inside the
+// runtime's pinning path: 9-18 GB/s, against 43-55 GB/s once the pages exist (tools/ubench_d2h.hip, MI355X box).  Touch the
+// destination pages first, from a few threads; the copy overwrites the whole range anyway.
+void prefault_host(void *dst, size_t bytes) {
+    if (!dst || bytes < ((size_t)64 << 20)) return;
+    const size_t page = 4096;
+    {   // ask for transparent huge pages on the page-aligned interior (honoured where THP is 'always' or 'madvise'): 512x fewer faults
+        const uintptr_t a = (reinterpret_cast<uintptr_t>(dst) + page - 1) & ~(uintptr_t)(page - 1);
+        const uintptr_t b = (reinterpret_cast<uintptr_t>(dst) + bytes) & ~(uintptr_t)(page - 1);
+        if (b > a) (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_HUGEPAGE);
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    const int n_threads = hw >= 16 ? 8 : (hw >= 4 ? 4 : 1);
+    char *base = static_cast<char *>(dst);
+    const size_t chunk = (bytes / n_threads + page - 1) / page * page;
+    std::vector<std::thread> workers;
+    for (int k = 0; k < n_threads; ++k) {
+        const size_t lo = (size_t)k * chunk, hi = lo + chunk < bytes ? lo + chunk : bytes;
+        if (lo >= hi) break;
+        workers.emplace_back([base, lo, hi] {
+            for (size_t o = lo; o < hi; o += 4096) reinterpret_cast<volatile char *>(base)[o] = 0;
+            reinterpret_cast<volatile char *>(base)[hi - 1] = 0;
+        });
+    }
+    for (auto &w : workers) w.join();
+}
+
 }  // namespace symgpu
 
 using namespace symgpu;
@@ -407,6 +438,7 @@ int symgpu_dev_free(void *ptr) { return dev_free(ptr); }
 int symgpu_dev_download(const void *dev, void *host, int64_t bytes) {
     SG_TRY(require_ctx());
     SG_REQUIRE(dev && host && bytes >= 0, "dev_download");
+    prefault_host(host, (size_t)bytes);
     HIP_TRY(hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx().stream));
     HIP_TRY(hipStreamSynchronize(ctx().stream));
     return SYMGPU_OK;
@@ -507,9 +539,13 @@ int symgpu_op_download(symgpu_op_t op, uint64_t *rows, double *coeff, int64_t ca
         return SYMGPU_E_CAPACITY;
     }
     if (op->T > 0) {
-        if (rows) HIP_TRY(hipMemcpyAsync(rows, op->rows, (size_t)op->T * 2 * op->Wq * sizeof(u64), hipMemcpyDeviceToHost, ctx().stream));
+        if (rows) {
+            prefault_host(rows, (size_t)op->T * 2 * op->Wq * sizeof(u64));
+            HIP_TRY(hipMemcpyAsync(rows, op->rows, (size_t)op->T * 2 * op->Wq * sizeof(u64), hipMemcpyDeviceToHost, ctx().stream));
+        }
         if (coeff) {
             SG_REQUIRE(op->coeff, "op_download: operator has no coefficients");
+            prefault_host(coeff, (size_t)op->T * 2 * sizeof(double));
             HIP_TRY(hipMemcpyAsync(coeff, op->coeff, (size_t)op->T * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
         }
     }
