@@ -72,8 +72,15 @@ def main():
     # right operand: every rank owns a 1/world shard; the step all-gathers it
     Ts = (M + world - 1) // world
     my_rows = max(0, min(Ts, M - rank * Ts))
-    shard = parallel.padded_random_shard(my_rows, Ts, n, 99991 + rank) if comm.gathers else DeviceOp.random(my_rows, n, 0.3, seed=99991 + rank)
-    right = DeviceOp.alloc(Ts * world, wq, with_coeff=True) if comm.gathers else shard
+    if comm.gathers:
+        shard = parallel.padded_random_shard(my_rows, Ts, n, 99991 + rank)
+        right = DeviceOp.alloc(Ts * world, wq, with_coeff=True)
+    elif world > 1:
+        # RCCL could not be initialised (comm.rccl_error): every rank generates the whole right operand itself, so the
+        # per-GPU work is unchanged but the step has no all-gather; reported in config.parallelism
+        shard = right = DeviceOp.random(M, n, 0.3, seed=99991)
+    else:
+        shard = right = DeviceOp.random(my_rows, n, 0.3, seed=99991 + rank)
     slab = max(1, min(args.slab_rows, M))
     ring = [DeviceOp.alloc(slab * Ni, wq, with_coeff=True) for _ in range(2)]
 
@@ -120,7 +127,8 @@ def main():
         'vs_baseline': None, 'dtype': 'u64', 'data': 'synthetic',
         'config': {'workload': 'allpairs_product', 'n_qubits': n, 'left_terms_per_gpu': Ni, 'right_terms': M,
                    'pairs_per_step': world * pairs_per_step_rank, 'bytes_per_pair': 16 * wq + 16, 'slab_rows': slab,
-                   'parallelism': f'left-axis shard x{world}, RCCL all-gather of right rows' if world > 1 else 'single GPU'},
+                   'parallelism': (f'left-axis shard x{world}, RCCL all-gather of right rows' if comm.gathers else
+                                   f'left-axis shard x{world}, right operand replicated (RCCL unavailable: {comm.rccl_error})') if world > 1 else 'single GPU'},
         'roofline': {'bound': 'hbm', 'kernel': 'k_mul_coeff<*,FUSED> (coefficients + row stream)' if fused else 'k_mul_rows', 'bytes_per_pair': per_pair,
                      'note': None if fused else 'k_mul_coeff (16 B/pair) runs concurrently on a side stream; incl. its bytes: %.0f GB/s' % (achieved * (16 * wq + 16) / (16 * wq)), 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'launches': n_launch.value, 'avg_launch_ms': launch_ms,

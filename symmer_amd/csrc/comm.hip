@@ -28,6 +28,10 @@ static Rccl g_rccl;
 
 static int load_rccl() {
     if (g_rccl.handle) return SYMGPU_OK;
+    if (getenv("SYMGPU_RCCL_DISABLE")) {                           // test knob: exercise the callers' no-RCCL fallback
+        set_error("RCCL disabled by SYMGPU_RCCL_DISABLE");
+        return SYMGPU_E_RCCL;
+    }
     // absolute paths first: a dlopen by SONAME would hand back a *different* librccl that is already in the process
     // (PyTorch wheels bundle one, built against their own HIP runtime)
     std::string env_path = getenv("ROCM_PATH") ? std::string(getenv("ROCM_PATH")) + "/lib/librccl.so.1" : std::string("/opt/rocm/lib/librccl.so.1");

@@ -137,6 +137,7 @@ class Communicator:
         self.rank, self.world, self.data_plane = rank, world, data_plane
         self._dist = None
         self._tcp = None
+        self.rccl_error = None
         self.gathers = False      # True when the right operand must be assembled with the all-gather
 
     # ---- construction ------------------------------------------------------------------------------------
@@ -175,13 +176,33 @@ class Communicator:
         return bytes(t.tolist())
 
     def _init_rccl(self):
+        """RCCL communicator over the control plane.  Every step that can fail locally is followed by an agreement over the
+        control plane, so that either ALL ranks end up with a communicator or all of them fall back to ``rccl_error`` set
+        (callers such as bench.py then replicate the right operand instead of gathering it)."""
         from . import _lib
+        self.rccl_error = None
         raw = (ctypes.c_uint8 * 128)()
         if self.rank == 0:
-            _lib.check(_lib.lib().symgpu_comm_unique_id(ctypes.addressof(raw)))
+            try:
+                _lib.check(_lib.lib().symgpu_comm_unique_id(ctypes.addressof(raw)))
+            except Exception as exc:                              # librccl missing / not loadable: broadcast an all-zero id
+                self.rccl_error = str(exc)
+                raw = (ctypes.c_uint8 * 128)()
         ident = self._bcast_bytes(bytes(raw), 128)
-        raw = (ctypes.c_uint8 * 128)(*ident)
-        _lib.check(_lib.lib().symgpu_comm_init(ctypes.addressof(raw), self.rank, self.world))
+        if not any(ident):
+            self.rccl_error = self.rccl_error or 'rank 0 could not create an RCCL unique id'
+        else:
+            try:
+                raw = (ctypes.c_uint8 * 128)(*ident)
+                _lib.check(_lib.lib().symgpu_comm_init(ctypes.addressof(raw), self.rank, self.world))
+            except Exception as exc:
+                self.rccl_error = str(exc)
+        if self.max_over_ranks(1.0 if self.rccl_error else 0.0) > 0.0:
+            if self.rccl_error is None:
+                self.rccl_error = 'RCCL initialisation failed on another rank'
+                _lib.load().symgpu_comm_destroy()
+            self.gathers = False
+            self.data_plane = 'none'
 
     # ---- control plane -----------------------------------------------------------------------------------
     def barrier(self):
