@@ -124,3 +124,34 @@ def test_tcp_control_plane_survives_an_occupied_port():
             assert ok, f'rank {rank} failed: {err}'
     finally:
         blocker.close()
+
+
+def _rccl_fallback_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        from symmer_amd import parallel
+        # no GPU here: rank 0 cannot create an RCCL unique id -> every rank must agree on the fallback instead of hanging
+        comm = parallel.Communicator.from_env(data_plane='rccl', control='tcp')
+        ok = (not comm.gathers) and bool(comm.rccl_error) and comm.data_plane == 'none'
+        comm.barrier()
+        comm.close()
+        q.put((rank, ok, '' if ok else f'gathers={comm.gathers} error={comm.rccl_error}'))
+    except Exception:                                         # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+@pytest.mark.timeout(120)
+def test_rccl_failure_is_agreed_across_ranks():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    for rank, ok, err in res:
+        assert ok, f'rank {rank} failed: {err}'
