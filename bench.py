@@ -301,7 +301,7 @@ def cpu_baseline(n):
     a = rng.standard_normal(Ns) + 1j * rng.standard_normal(Ns); b = rng.standard_normal(Ms) + 1j * rng.standard_normal(Ms)
     onp.product_rows_and_coeffs(A[:50], a[:50], B[:20], b[:20])
     reps, t_total = 0, 0.0
-    while t_total < 10.0 and reps < 20:
+    while t_total < 10.0 and reps < 100:
         t0 = time.perf_counter()
         onp.product_rows_and_coeffs(A, a, B, b)
         t_total += time.perf_counter() - t0
