@@ -116,8 +116,7 @@ def main():
     value = world * pairs_per_step_rank * args.steps / dt
     launch_pairs = pairs_per_step_rank * args.steps / max(1, n_launch.value)
     launch_ms = tot_ms.value / max(1, n_launch.value)
-    fused = os.environ.get('SYMGPU_PRODUCT_MODE', '').startswith('f')
-    per_pair = (16 * wq + 16) if fused else 16 * wq      # fused launch writes rows + coefficients; two-kernel mode: rows only
+    per_pair = 16 * wq                                   # the dominant kernel streams the rows; coefficients: side stream
     algo_bytes_launch = launch_pairs * per_pair
     achieved = algo_bytes_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
 
@@ -129,8 +128,8 @@ def main():
                    'pairs_per_step': world * pairs_per_step_rank, 'bytes_per_pair': 16 * wq + 16, 'slab_rows': slab,
                    'parallelism': (f'left-axis shard x{world}, RCCL all-gather of right rows' if comm.gathers else
                                    f'left-axis shard x{world}, right operand replicated (RCCL unavailable: {comm.rccl_error})') if world > 1 else 'single GPU'},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_mul_coeff<*,FUSED> (coefficients + row stream)' if fused else 'k_mul_rows', 'bytes_per_pair': per_pair,
-                     'note': None if fused else 'k_mul_coeff (16 B/pair) runs concurrently on a side stream; incl. its bytes: %.0f GB/s' % (achieved * (16 * wq + 16) / (16 * wq)), 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'roofline': {'bound': 'hbm', 'kernel': 'k_mul_rows', 'bytes_per_pair': per_pair,
+                     'note': 'k_mul_coeff (16 B/pair) runs concurrently on a side stream; incl. its bytes: %.0f GB/s' % (achieved * (16 * wq + 16) / (16 * wq)), 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'launches': n_launch.value, 'avg_launch_ms': launch_ms,
                      'algorithmic_bytes_per_launch': algo_bytes_launch,
                      'whole_step_GBps': pairs_per_step_rank * (16 * wq + 16) / (dt / args.steps) / 1e9},

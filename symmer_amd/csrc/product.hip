@@ -28,17 +28,13 @@ constexpr int PO = 8;   // outer terms per wave (SGPR operand)
 constexpr int PJ = 4;   // inner terms per lane: i = ibase + 64*b + lane
 constexpr int PW = 4;   // waves per block, stacked along o
 
-// FUSED: after the coefficients of its (256 inner x 32 outer) tile the block also streams the tile's product ROWS
-// (k_mul_rows' store pattern: 16 B per lane, 4 KiB contiguous per outer row, non-temporal), so ONE launch writes the
-// full 16*Wq + 16 bytes per pair; while some waves of a CU sit in the VALU phase others keep the HBM write stream busy.
 // KEYS: instead of the coefficient the kernel emits the packed cleanup key of every pair (hash | phase exponent e | o | i):
 // the 16-byte coefficient is never materialised, the cleanup rebuilds c_i * c_o * i^e from e and the two operand tables.
-template <bool INNER_LEFT, bool FUSED, bool KEYS>
+template <bool INNER_LEFT, bool KEYS>
 __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i64 Ipad, i64 Ni, const double *__restrict__ ci,
                                                     const u64 *__restrict__ Ot, i64 Opad, i64 No, const double *__restrict__ co,
                                                     int Wq, double *__restrict__ out /* [(o)*Ni + i][2], o relative to slab */,
-                                                    const u32x4 *__restrict__ inner_rm, const u32x4 *__restrict__ outer_rm,
-                                                    u32x4 *__restrict__ out_rows, PairKeyArgs ka) {
+                                                    PairKeyArgs ka) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const i64 o0 = ((i64)blockIdx.y * PW + wave) * PO;   // wave-uniform, relative to the slab
@@ -150,23 +146,6 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
                 if (o0 + a < No) dst[(i64)a * Ni] = v[a];
         }
     }
-    if (FUSED) {
-        const i64 n_chunks = Ni * Wq;
-        const i64 rows_here = (Ni - ibase < 64 * PJ) ? (Ni - ibase) : (i64)(64 * PJ);
-        const i64 ctile = rows_here > 0 ? rows_here * Wq : 0;
-        const i64 cbase = ibase * Wq;
-        const i64 ob = (i64)blockIdx.y * (PO * PW);
-        const i64 oe = (ob + PO * PW < No) ? ob + PO * PW : No;
-        for (i64 cc = threadIdx.x; cc < ctile; cc += 256) {
-            const u32x4 v = inner_rm[cbase + cc];
-            const int wqi = (int)(cc % Wq);
-            u32x4 *dst = out_rows + cbase + cc;
-            for (i64 o = ob; o < oe; ++o) {
-                const u32x4 r = v ^ outer_rm[o * Wq + wqi];
-                __builtin_nontemporal_store(r, dst + o * n_chunks);
-            }
-        }
-    }
 }
 
 // ---- the HBM-write stream ------------------------------------------------------------------------
@@ -222,7 +201,7 @@ static i64 round_up(i64 x, i64 m) { return (x + m - 1) / m * m; }
 // It = word-major inner operand (padded to Ipad, a multiple of 64*PJ); kernels go to stream `st`.
 static int mul_coeff_launch(const u64 *It, i64 Ipad, const double *ci, i64 Ni, const u64 *outer, const double *co, i64 o_begin, i64 o_end,
                             int Wq, int inner_is_left, double *out_coeff, hipStream_t st, Scratch &ot,
-                            const u64 *inner_rm = nullptr, u64 *out_rows = nullptr, const PairKeyArgs *keys = nullptr) {
+                            const PairKeyArgs *keys = nullptr) {
     const i64 No = o_end - o_begin;
     const int W = 2 * Wq;
     const i64 Opad = round_up(No, PO * PW);
@@ -235,11 +214,8 @@ static int mul_coeff_launch(const u64 *It, i64 Ipad, const double *ci, i64 Ni, c
         const i64 ny = gy_total - y0 < max_gy ? gy_total - y0 : max_gy;
         const i64 ooff = y0 * PO * PW;
         dim3 grid((unsigned)gx, (unsigned)ny);
-        const u32x4 *irm = reinterpret_cast<const u32x4 *>(inner_rm);
-        const u32x4 *orm = reinterpret_cast<const u32x4 *>(outer + (o_begin + ooff) * W);
-        u32x4 *drows = out_rows ? reinterpret_cast<u32x4 *>(out_rows) + ooff * Ni * Wq : nullptr;
-#define LAUNCH_COEFF(L, F) hipLaunchKernelGGL((k_mul_coeff<L, F, false>), grid, dim3(256), 0, st, It, Ipad, Ni, ci, ot.as<u64>() + ooff, Opad, \
-                                              No - ooff, co + 2 * (o_begin + ooff), Wq, out_coeff + 2 * ooff * Ni, irm, orm, drows, PairKeyArgs())
+#define LAUNCH_COEFF(L) hipLaunchKernelGGL((k_mul_coeff<L, false>), grid, dim3(256), 0, st, It, Ipad, Ni, ci, ot.as<u64>() + ooff, Opad, \
+                                              No - ooff, co + 2 * (o_begin + ooff), Wq, out_coeff + 2 * ooff * Ni, PairKeyArgs())
         if (keys) {
             // key mode runs over the whole outer operand (o_begin == 0); the o field stays absolute through o_base
             PairKeyArgs ka = *keys;
@@ -247,16 +223,13 @@ static int mul_coeff_launch(const u64 *It, i64 Ipad, const double *ci, i64 Ni, c
             ka.keys += ooff * Ni;
             ka.o_base = ooff;
             if (inner_is_left)
-                hipLaunchKernelGGL((k_mul_coeff<true, false, true>), grid, dim3(256), 0, st, It, Ipad, Ni, (const double *)nullptr, ot.as<u64>() + ooff, Opad, No - ooff,
-                                   (const double *)nullptr, Wq, (double *)nullptr, irm, orm, drows, ka);
+                hipLaunchKernelGGL((k_mul_coeff<true, true>), grid, dim3(256), 0, st, It, Ipad, Ni, (const double *)nullptr, ot.as<u64>() + ooff, Opad, No - ooff,
+                                   (const double *)nullptr, Wq, (double *)nullptr, ka);
             else
-                hipLaunchKernelGGL((k_mul_coeff<false, false, true>), grid, dim3(256), 0, st, It, Ipad, Ni, (const double *)nullptr, ot.as<u64>() + ooff, Opad, No - ooff,
-                                   (const double *)nullptr, Wq, (double *)nullptr, irm, orm, drows, ka);
-        } else if (out_rows) {
-            ProfScope prof(0);
-            if (inner_is_left) LAUNCH_COEFF(true, true); else LAUNCH_COEFF(false, true);
+                hipLaunchKernelGGL((k_mul_coeff<false, true>), grid, dim3(256), 0, st, It, Ipad, Ni, (const double *)nullptr, ot.as<u64>() + ooff, Opad, No - ooff,
+                                   (const double *)nullptr, Wq, (double *)nullptr, ka);
         } else {
-            if (inner_is_left) LAUNCH_COEFF(true, false); else LAUNCH_COEFF(false, false);
+            if (inner_is_left) LAUNCH_COEFF(true); else LAUNCH_COEFF(false);
         }
 #undef LAUNCH_COEFF
         KERNEL_CHECK();
@@ -280,7 +253,7 @@ int mul_keys_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 No, int Wq, int
     Scratch it, ot;
     SG_TRY(it.alloc((size_t)Ipad * 2 * Wq * sizeof(u64)));
     SG_TRY(to_wordmajor(inner, Ni, 2 * Wq, it.as<u64>(), Ipad));
-    return mul_coeff_launch(it.as<u64>(), Ipad, nullptr, Ni, outer, nullptr, 0, No, Wq, inner_is_left, nullptr, ctx().stream, ot, nullptr, nullptr, &ka);
+    return mul_coeff_launch(it.as<u64>(), Ipad, nullptr, Ni, outer, nullptr, 0, No, Wq, inner_is_left, nullptr, ctx().stream, ot, &ka);
 }
 
 // rows of the slab: out_rows[((o-o_begin)*Ni + i)*W + w]
@@ -332,31 +305,25 @@ int symgpu_mul_allpairs_dev(symgpu_op_t inner, symgpu_op_t outer, int64_t o_begi
     op_invalidate(out);
     if (out->coeff && rows > 0) {
         SG_REQUIRE(inner->coeff && outer->coeff, "mul_allpairs_dev: operands have no coefficients");
-        // Default ("streams"): the VALU-bound coefficient kernel runs on a side stream and overlaps the HBM-bound row stream
-        // (measured on MI355X, 1e5 x 1e5 terms, n=1000: 2.05e10 pairs/s).  SYMGPU_PRODUCT_MODE=fused runs ONE launch per
-        // slab that does both (1.86e10 pairs/s: the long VALU prologue of every block delays its stores).
+        // The VALU-bound coefficient kernel runs on a side stream and overlaps the HBM-bound row stream (measured on MI355X,
+        // 1e5 x 1e5 terms, n=1000: 2.2e10 pairs/s; ONE launch doing both was slower, 1.86e10: the long VALU prologue of every
+        // block delays its stores).
         Context &c = ctx();
         const u64 *It = nullptr;
         i64 Ipad = 0;
         SG_TRY(op_wordmajor(inner, 64 * PJ, &It, &Ipad));          // cached across slabs of the same inner operand
         Scratch ot;
-        static const int mode = [] { const char *e = getenv("SYMGPU_PRODUCT_MODE"); return (e && e[0] == 'f') ? 0 : 1; }();
-        if (mode == 0) {
-            SG_TRY(mul_coeff_launch(It, Ipad, inner->coeff, inner->T, outer->rows, outer->coeff, o_begin, o_end, inner->Wq, inner_is_left,
-                                    out->coeff, c.stream, ot, inner->rows, out->rows));
-        } else {
-            HIP_TRY(hipEventRecord(c.ev_fork, c.stream));
-            HIP_TRY(hipStreamWaitEvent(c.stream2, c.ev_fork, 0));
-            int rc = mul_coeff_launch(It, Ipad, inner->coeff, inner->T, outer->rows, outer->coeff, o_begin, o_end, inner->Wq,
-                                      inner_is_left, out->coeff, c.stream2, ot);
-            hipError_t e1 = hipEventRecord(c.ev_join, c.stream2);
-            int rc2 = mul_rows_dev(inner->rows, inner->T, outer->rows, o_begin, o_end, inner->Wq, out->rows);
-            hipError_t e2 = hipStreamWaitEvent(c.stream, c.ev_join, 0);
-            if (rc != SYMGPU_OK) return rc;
-            if (rc2 != SYMGPU_OK) return rc2;
-            if (e1 != hipSuccess) return hip_fail(e1, "event record (join)", __FILE__, __LINE__);
-            if (e2 != hipSuccess) return hip_fail(e2, "stream wait (join)", __FILE__, __LINE__);
-        }
+        HIP_TRY(hipEventRecord(c.ev_fork, c.stream));
+        HIP_TRY(hipStreamWaitEvent(c.stream2, c.ev_fork, 0));
+        int rc = mul_coeff_launch(It, Ipad, inner->coeff, inner->T, outer->rows, outer->coeff, o_begin, o_end, inner->Wq,
+                                  inner_is_left, out->coeff, c.stream2, ot);
+        hipError_t e1 = hipEventRecord(c.ev_join, c.stream2);
+        int rc2 = mul_rows_dev(inner->rows, inner->T, outer->rows, o_begin, o_end, inner->Wq, out->rows);
+        hipError_t e2 = hipStreamWaitEvent(c.stream, c.ev_join, 0);
+        if (rc != SYMGPU_OK) return rc;
+        if (rc2 != SYMGPU_OK) return rc2;
+        if (e1 != hipSuccess) return hip_fail(e1, "event record (join)", __FILE__, __LINE__);
+        if (e2 != hipSuccess) return hip_fail(e2, "stream wait (join)", __FILE__, __LINE__);
     } else {
         SG_TRY(mul_rows_dev(inner->rows, inner->T, outer->rows, o_begin, o_end, inner->Wq, out->rows));
     }
