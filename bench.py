@@ -285,8 +285,19 @@ def extras(_lib, kernels, DeviceOp):
         _lib.check(lib.symgpu_symmetry_kernel_dev(H.handle, 2000, outg.ctypes.data, 4000, ctypes.addressof(k), ctypes.addressof(nx)))
     t = timed(cfg4, 2)
     wc = (50000 + 63) // 64 + 64
+    # physical traffic of the sweep launches (HIP events around every launch of the main sweep kernel): each pass reads and
+    # writes the whole 4000 x 846-word matrix once
+    _lib.check(lib.symgpu_prof_enable(2, 1))
+    cfg4(); kernels.sync()
+    _lib.check(lib.symgpu_prof_enable(2, 0))
+    nl4, ms4 = ctypes.c_int64(0), ctypes.c_double(0)
+    _lib.check(lib.symgpu_prof_read(2, ctypes.addressof(nl4), ctypes.addressof(ms4)))
+    sweep_s = ms4.value / max(1, nl4.value) * 1e-3
     ex['cfg4_symmetry_kernel'] = {'rows': 4000, 'cols': 54000, 'generators_found': k.value, 'row_xors': nx.value, 'seconds': t,
-                                  'row_xors_per_s': nx.value / t, 'algorithmic_GBps': nx.value * 16 * wc / t / 1e9}
+                                  'row_xors_per_s': nx.value / t, 'algorithmic_GBps': nx.value * 16 * wc / t / 1e9,
+                                  'sweep_launches': nl4.value, 'sweep_avg_launch_us': sweep_s * 1e6,
+                                  'sweep_physical_GBps': 2 * 4000 * wc * 8 / sweep_s / 1e9 if sweep_s else None,
+                                  'sweep_frac_of_hbm_peak': 2 * 4000 * wc * 8 / sweep_s / 1e9 / HBM_PEAK_GBS if sweep_s else None}
     H.free()
     return ex
 
