@@ -340,7 +340,16 @@ def cpu_baseline(n):
     M4 = rng.random((256, 54000)) < 0.5
     t0 = time.perf_counter(); _, nx = onp.rref_noswap(M4, count_xors=True); t = time.perf_counter() - t0
     other['cfg4_sample_rref'] = {'rows': 256, 'cols': 54000, 'row_xors': int(nx), 'seconds': t, 'row_xors_per_s': nx / t}
-    return {'other_configs': other, 'value': v, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port',
+    model = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {'cpu_model': model, 'host_cores': os.cpu_count(), 'other_configs': other, 'value': v, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port',
             'sample': f'{reps} x ({Ns} x {Ms} terms, {n} qubits) all-pairs product, NumPy restatement of base.py:783-792 '
                       f'(1 byte per bit, single thread; host has {os.cpu_count()} cores)'}
 
