@@ -483,6 +483,12 @@ class PauliwordOp:
             return self.copy().cleanup()
         wq = packing.words_per_block(self.n_qubits)
         dev = kernels.DeviceOp.upload(self.packed, self.coeff_vec)
+        # The reference calls ``.cleanup()`` after every rotation (base.py:1185).  On an operator that has no duplicate rows and
+        # no coefficient with |c| <= 1e-15 that cleanup is the identity, and the rotation kernels preserve both properties
+        # (a rotated row P*Q can only coincide with an input row, which the kernels merge themselves; they also apply the
+        # strict threshold).  So the device cleanup runs until the operator is known to be in that state — i.e. once, after
+        # the first rotation of a user-supplied operator — and is skipped for the rest of the chain.
+        clean = False
         try:
             for pauli_rotation, angle in rotations:
                 assert pauli_rotation.n_terms == 1, 'Only rotation by single Pauliword allowed here'
@@ -496,11 +502,16 @@ class PauliwordOp:
                     if not all_commute:
                         dev.free()
                         dev = res
-                # `.cleanup()` after every rotation (base.py:1185); an operator without terms becomes 0*I (base.py:631-632)
                 if dev.n_terms == 0:
+                    # an operator without terms becomes 0*I under cleanup(), and 0*I loses its only term again under the
+                    # next one (base.py:631-632): the reference alternates between the two states
                     cleaned = kernels.DeviceOp.upload(np.zeros((1, 2 * wq), dtype='<u8'), np.zeros(1, dtype=complex))
-                else:
+                    clean = False
+                elif not clean:
                     cleaned = kernels.cleanup_dev(dev)
+                    clean = True
+                else:
+                    continue
                 dev.free()
                 dev = cleaned
             rows, coeff = dev.download()

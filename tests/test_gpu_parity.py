@@ -533,3 +533,24 @@ def test_gf2_golden_other_sweep_paths(case, env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     test_gf2_golden(case)
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_rotation_chain_with_duplicates_and_tiny_terms(seed):
+    """perform_rotations runs the per-rotation cleanup only until the operator is known to be duplicate-free and above the
+    threshold; the result must equal the reference's cleanup-after-every-rotation on inputs that need the first one."""
+    rng = np.random.default_rng(600 + seed)
+    n, T = int(rng.choice([3, 20, 70])), 60
+    base = rng.random((12, 2 * n)) < 0.4
+    symp = base[rng.integers(0, 12, T)]                                  # heavy duplication
+    coeff = dyadic(rng, T)
+    coeff[::7] = 1e-17                                                   # below the cleanup threshold
+    rots = [(rng.random(2 * n) < 0.5, float(a)) for a in rng.choice([np.pi / 2, np.pi, -np.pi / 2, 3 * np.pi / 2], 9)]
+    P = PauliwordOp(symp, coeff)
+    R = P.perform_rotations([(PauliwordOp(q.reshape(1, -1), [1]), a) for q, a in rots])
+    er, ec = onp.perform_rotations(symp, coeff, rots)
+    assert_op_equal(R.symp_matrix, R.coeff_vec, er, ec, exact=False, tol=TOL)
+    mixed = rots[:3] + [(rots[3][0], 0.37), (rots[4][0], -1.1)] + rots[5:]
+    R2 = P.perform_rotations([(PauliwordOp(q.reshape(1, -1), [1]), a) for q, a in mixed])
+    er2, ec2 = onp.perform_rotations(symp, coeff, mixed)
+    assert_op_equal(R2.symp_matrix, R2.coeff_vec, er2, ec2, exact=False, tol=TOL)
