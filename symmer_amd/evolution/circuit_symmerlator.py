@@ -84,7 +84,8 @@ class CircuitSymmerlator:
         return operator.perform_rotations(self.sequence[::-1])
 
     def evaluate(self, operator: PauliwordOp) -> complex:
-        """<0|U^+ O U|0>: only I/Z strings (no X bit) contribute; duplicates are merged by perform_rotations' cleanup."""
-        rotated = self.apply_sequence(operator).cleanup()
+        """<0|U^+ O U|0>: only I/Z strings (no X bit) contribute.  ``perform_rotations`` always returns a cleaned operator
+        (also for an empty sequence), so the reference's extra ``cleanup()`` (circuit_symmerlator.py:163) is the identity here."""
+        rotated = self.apply_sequence(operator)
         diagonal = ~np.any(rotated.X_block, axis=1)
         return np.sum(rotated.coeff_vec[diagonal]) if rotated.n_terms else 0
