@@ -167,7 +167,7 @@ template <bool PAIR, bool PACKED>
 __global__ __launch_bounds__(256) void k_heads(const u64 *__restrict__ keys, const u32 *__restrict__ idx, i64 T, const u64 *__restrict__ rows, int W,
                                                 const u64 *__restrict__ inner, u32 Ni, const u64 *__restrict__ outer, int G,
                                                 const double *__restrict__ coeff, double *__restrict__ cg,
-                                                u32 *__restrict__ heads, u32 *__restrict__ collision,
+                                                uint8_t *__restrict__ heads, u32 *__restrict__ collision,
                                                 const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L,
                                                 const double *__restrict__ ci, const double *__restrict__ co) {
     const int lane = threadIdx.x & 63;
@@ -240,7 +240,7 @@ constexpr int FIX_MAX = 48;
 // phase 1 (read-only): a position whose key differs from its predecessor's INSIDE a prefix run marks the run's start.
 // PACKED: keys are packed pair keys (full key recomputed from the (i, o) fields), there is no separate idx array.
 template <bool PACKED>
-__global__ void k_fixup_mark(const u64 *__restrict__ keys, i64 T, int shift, u32 *__restrict__ need,
+__global__ void k_fixup_mark(const u64 *__restrict__ keys, i64 T, int shift, uint8_t *__restrict__ need,
                              const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L) {
     for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
         if (s == 0) continue;
@@ -254,7 +254,7 @@ __global__ void k_fixup_mark(const u64 *__restrict__ keys, i64 T, int shift, u32
 }
 // phase 2: the marked run starts (one thread per mixed run) sort their run
 template <bool PACKED>
-__global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 T, int shift, const u32 *__restrict__ need, u32 *__restrict__ fallback,
+__global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 T, int shift, const uint8_t *__restrict__ need, u32 *__restrict__ fallback,
                              const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L) {
     for (i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x; b < T; b += (i64)gridDim.x * blockDim.x) {
         if (!need[b]) continue;
@@ -290,7 +290,7 @@ __global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 
 // 12.5 MB for 1e8 terms, cache resident, instead of a 4-byte flag per input index scattered over 400 MB).
 // PACKED: idx is unused, the input index comes from the (o, i) fields of the packed pair keys pk.
 template <bool PACKED>
-__device__ __forceinline__ void segment_close(i64 pos, double re, double im, u32 *__restrict__ heads, const u32 *__restrict__ idx,
+__device__ __forceinline__ void segment_close(i64 pos, double re, double im, uint8_t *__restrict__ heads, const u32 *__restrict__ idx,
                                               const u64 *__restrict__ pk, double *__restrict__ cg, double thr, int use_thr,
                                               u32 *__restrict__ markbits, PackedLayout L, u32 Ni) {
     const bool keep = use_thr ? (hypot(re, im) > thr) : true;
@@ -305,7 +305,7 @@ __device__ __forceinline__ void segment_close(i64 pos, double re, double im, u32
 }
 
 template <bool PACKED>
-__global__ __launch_bounds__(256) void k_segsum_heads(u32 *__restrict__ heads, const u32 *__restrict__ idx, const u64 *__restrict__ pk, i64 T,
+__global__ __launch_bounds__(256) void k_segsum_heads(uint8_t *__restrict__ heads, const u32 *__restrict__ idx, const u64 *__restrict__ pk, i64 T,
                                                        double *__restrict__ cg, double thr, int use_thr, u32 *__restrict__ markbits, PackedLayout L,
                                                        u32 Ni, i64 chunks_per_wave) {
     const int lane = threadIdx.x & 63;
@@ -373,7 +373,7 @@ __global__ void k_popc_words(const u32 *__restrict__ bits, i64 n_words, u32 *__r
 // word prefix + popcount of the lower bits of its word
 // out_src[p]: input index of the row, PACKED: its (o << bi) | i fields (k_gather_rows then needs no division)
 template <bool PACKED>
-__global__ void k_emit_heads(const u32 *__restrict__ heads, const u32 *__restrict__ idx, const u64 *__restrict__ pk, i64 T,
+__global__ void k_emit_heads(const uint8_t *__restrict__ heads, const u32 *__restrict__ idx, const u64 *__restrict__ pk, i64 T,
                              const double *__restrict__ cg, const u32 *__restrict__ markbits, const u32 *__restrict__ wordprefix,
                              double *__restrict__ out_coeff, u32 *__restrict__ out_src, PackedLayout L, u32 Ni) {
     for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
@@ -434,7 +434,7 @@ int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
     return SYMGPU_OK;
 }
 
-int cleanup_finish(u32 *heads, const u32 *is, const u64 *pk, bool packed, PackedLayout L, i64 T, double *cg, double thr, int use_thr, bool pair,
+int cleanup_finish(uint8_t *heads, const u32 *is, const u64 *pk, bool packed, PackedLayout L, i64 T, double *cg, double thr, int use_thr, bool pair,
                    const u64 *rows, int W, const u64 *inner, i64 Ni, const u64 *outer, symgpu_op_t *out, int Wq_out) {
     hipStream_t st = ctx().stream;
     const i64 n_words = (T + 31) / 32;
@@ -524,7 +524,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
     Scratch keys, keys2, idx, idx2, heads, collision, cg, hI, hO, pair_coeff;
     SG_TRY(keys.alloc((size_t)T * 8));
     SG_TRY(keys2.alloc((size_t)T * 8));
-    SG_TRY(heads.alloc((size_t)T * 4));
+    SG_TRY(heads.alloc((size_t)T));                                 // one byte per sorted position: 0 continuation, 1 head, 2 kept head
     SG_TRY(collision.alloc(16));
     SG_TRY(cg.alloc((size_t)T * 16));
     if (pair) {
@@ -583,15 +583,15 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         HIP_TRY(hipMemsetAsync(collision.p, 0, 16, st));
         if (nbits < 64) {
             // `heads` doubles as the run-start marker array here (it is overwritten by k_heads afterwards)
-            HIP_TRY(hipMemsetAsync(heads.p, 0, (size_t)T * 4, st));
+            HIP_TRY(hipMemsetAsync(heads.p, 0, (size_t)T, st));
             if (packed) {
-                hipLaunchKernelGGL(k_fixup_mark<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<u32>(), hI.as<u64>(), hO.as<u64>(), L);
-                hipLaunchKernelGGL(k_fixup_sort<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, (u32 *)nullptr, T, 64 - nbits, heads.as<u32>(),
+                hipLaunchKernelGGL(k_fixup_mark<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<uint8_t>(), hI.as<u64>(), hO.as<u64>(), L);
+                hipLaunchKernelGGL(k_fixup_sort<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, (u32 *)nullptr, T, 64 - nbits, heads.as<uint8_t>(),
                                    collision.as<u32>() + 1, hI.as<u64>(), hO.as<u64>(), L);
             } else {
-                hipLaunchKernelGGL(k_fixup_mark<false>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<u32>(), (const u64 *)nullptr,
+                hipLaunchKernelGGL(k_fixup_mark<false>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<uint8_t>(), (const u64 *)nullptr,
                                    (const u64 *)nullptr, L);
-                hipLaunchKernelGGL(k_fixup_sort<false>, dim3(grid_for(T)), dim3(256), 0, st, ks, is, T, 64 - nbits, heads.as<u32>(),
+                hipLaunchKernelGGL(k_fixup_sort<false>, dim3(grid_for(T)), dim3(256), 0, st, ks, is, T, 64 - nbits, heads.as<uint8_t>(),
                                    collision.as<u32>() + 1, (const u64 *)nullptr, (const u64 *)nullptr, L);
             }
             KERNEL_CHECK();
@@ -605,13 +605,13 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             const double *nud = nullptr;
             if (packed)
                 hipLaunchKernelGGL((k_heads<true, true>), dim3((unsigned)gh), dim3(256), 0, st, ks, (const u32 *)nullptr, T, nul, W, inner, (u32)Ni, outer, G,
-                                   nud, cg.as<double>(), heads.as<u32>(), collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), L, ci, co);
+                                   nud, cg.as<double>(), heads.as<uint8_t>(), collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), L, ci, co);
             else if (pair)
                 hipLaunchKernelGGL((k_heads<true, false>), dim3((unsigned)gh), dim3(256), 0, st, ks, is, T, nul, W, inner, (u32)Ni, outer, G,
-                                   coeff, cg.as<double>(), heads.as<u32>(), collision.as<u32>(), nul, nul, L, nud, nud);
+                                   coeff, cg.as<double>(), heads.as<uint8_t>(), collision.as<u32>(), nul, nul, L, nud, nud);
             else
                 hipLaunchKernelGGL((k_heads<false, false>), dim3((unsigned)gh), dim3(256), 0, st, ks, is, T, rows, W, nul, 1u, nul, G,
-                                   coeff, cg.as<double>(), heads.as<u32>(), collision.as<u32>(), nul, nul, L, nud, nud);
+                                   coeff, cg.as<double>(), heads.as<uint8_t>(), collision.as<u32>(), nul, nul, L, nud, nud);
         }
         KERNEL_CHECK();
         u32 hflags[2] = {0, 0};
@@ -625,7 +625,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         set_error("cleanup: 64-bit row-hash collision survived 4 reseeds");
         return SYMGPU_E_COLLISION;
     }
-    return cleanup_finish(heads.as<u32>(), is, ks, packed, L, T, cg.as<double>(), thr, use_thr, pair, rows, W, inner, Ni, outer, out, Wq_out);
+    return cleanup_finish(heads.as<uint8_t>(), is, ks, packed, L, T, cg.as<double>(), thr, use_thr, pair, rows, W, inner, Ni, outer, out, Wq_out);
 }
 
 }  // namespace symgpu
