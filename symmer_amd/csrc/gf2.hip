@@ -361,12 +361,84 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
     }
 }
 
+// ---- small matrices: the whole reduction in ONE workgroup -------------------------------------------------------------
+// R <= 64 rows and Wc <= 64 words (32 KiB of LDS): the reference loop verbatim — for every row in order: leftmost set column,
+// flags of the rows holding it (one ballot), XOR — without the 3 launches per block of the blocked path.  Stabiliser sets,
+// generator reconstructions and the symmetry matrices of molecules with <= 32 qubits land here (their rows are sparse and lead
+// at scattered columns, which the windowed panel handles poorly).
+constexpr int SMALL_R = 64, SMALL_WC = 64;     // wider dense matrices are faster on the blocked path (measured)
+
+__global__ __launch_bounds__(256) void k_rref_small(u64 *__restrict__ rows, int R, int Wc, i64 *__restrict__ pivots,
+                                                    unsigned long long *__restrict__ xor_count) {
+    extern __shared__ u64 m[];                                      // [R][Wc]
+    __shared__ u64 s_mask;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int total = R * Wc;
+    for (int k = threadIdx.x; k < total; k += 256) m[k] = rows[k];
+    __syncthreads();
+    unsigned long long count = 0;                                   // kept by thread 0
+    for (int j = 0; j < R; ++j) {
+        if (wave == 0) {
+            int pw = -1, pb = 0;
+            for (int w0 = 0; w0 < Wc; w0 += 64) {
+                const int w = w0 + lane;
+                const u64 v = w < Wc ? m[j * Wc + w] : 0ULL;
+                const u64 nz = __ballot(v != 0);
+                if (nz) {
+                    const int l = __builtin_ctzll(nz);
+                    pw = w0 + l;
+                    pb = __builtin_ctzll(__shfl(v, l));
+                    break;
+                }
+            }
+            u64 mask = 0;
+            if (pw >= 0) mask = __ballot(lane < R && lane != j && ((m[lane * Wc + pw] >> pb) & 1ULL));
+            if (lane == 0) {
+                s_mask = mask;
+                count += (unsigned long long)__popcll(mask);
+                if (pivots) pivots[j] = pw < 0 ? -1 : (i64)pw * 64 + pb;
+            }
+        }
+        __syncthreads();
+        const u64 mask = s_mask;
+        if (mask) {
+            for (int k = threadIdx.x; k < total; k += 256) {
+                const int r = k / Wc, w = k - r * Wc;
+                if ((mask >> r) & 1ULL) m[k] ^= m[j * Wc + w];
+            }
+        }
+        __syncthreads();
+    }
+    for (int k = threadIdx.x; k < total; k += 256) rows[k] = m[k];
+    if (threadIdx.x == 0 && xor_count) *xor_count = count;
+}
+
 // ---- in-place reduction of a device matrix -------------------------------------------------------
 int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     hipStream_t st = ctx().stream;
     if (xor_count) *xor_count = 0;
     if (R <= 0 || Wc <= 0) return SYMGPU_OK;
     if (Wc >= ((i64)1 << 31) - 64) { set_error("rref: Wc too large"); return SYMGPU_E_INVALID; }
+    {   // one-workgroup path for small matrices (SYMGPU_GF2_SMALL=0 disables it: tests)
+        const char *env_small = getenv("SYMGPU_GF2_SMALL");
+        static const bool small_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rref_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                           SMALL_R * SMALL_WC * 8) == hipSuccess;
+        if (R <= SMALL_R && Wc <= SMALL_WC && small_attr && !(env_small && env_small[0] == '0')) {
+            Scratch piv, count;
+            SG_TRY(piv.alloc((size_t)R * 8));
+            SG_TRY(count.alloc(16));
+            HIP_TRY(hipMemsetAsync(count.p, 0, 16, st));
+            hipLaunchKernelGGL(k_rref_small, dim3(1), dim3(256), (size_t)R * Wc * 8, st, rows, (int)R, (int)Wc, piv.as<i64>(),
+                               count.as<unsigned long long>());
+            KERNEL_CHECK();
+            unsigned long long h = 0;
+            HIP_TRY(hipMemcpyAsync(&h, count.p, 8, hipMemcpyDeviceToHost, st));
+            if (pivots_host) HIP_TRY(hipMemcpyAsync(pivots_host, piv.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (xor_count) *xor_count = (i64)h;
+            return SYMGPU_OK;
+        }
+    }
     Scratch info, state, lead, sel, snap, count, piv, rowcnt;
     SG_TRY(info.alloc(2 * sizeof(BlockInfo)));
     SG_TRY(state.alloc(sizeof(SweepState)));

@@ -554,3 +554,18 @@ def test_rotation_chain_with_duplicates_and_tiny_terms(seed):
     R2 = P.perform_rotations([(PauliwordOp(q.reshape(1, -1), [1]), a) for q, a in mixed])
     er2, ec2 = onp.perform_rotations(symp, coeff, mixed)
     assert_op_equal(R2.symp_matrix, R2.coeff_vec, er2, ec2, exact=False, tol=TOL)
+
+
+@pytest.mark.parametrize('R,C,dens', [(64, 4096, 0.4), (33, 64, 0.5), (64, 3000, 0.01), (10, 40, 0.2)])
+def test_rref_small_and_blocked_paths_agree(R, C, dens, monkeypatch):
+    """Matrices with <= 64 rows and <= 64 words take the one-workgroup path; SYMGPU_GF2_SMALL=0 sends them through the blocked
+    path: same reduced matrix, pivots and reference row-XOR count, both equal to the oracle."""
+    rng = np.random.default_rng(R * 1000 + C)
+    m = rng.random((R, C)) < dens
+    packed = packing.pack_bits(m)
+    red1, cnt1, piv1 = kernels.rref(packed, want_pivots=True)
+    monkeypatch.setenv('SYMGPU_GF2_SMALL', '0')
+    red2, cnt2, piv2 = kernels.rref(packed, want_pivots=True)
+    ered, ecnt = onp.rref_noswap(m, count_xors=True)
+    assert np.array_equal(red1, red2) and cnt1 == cnt2 == ecnt and np.array_equal(piv1, piv2)
+    assert np.array_equal(packing.unpack_bits(red1, C), ered)
