@@ -43,7 +43,8 @@ static std::mutex g_alloc_mu;
 static std::multimap<size_t, void *> g_free;      // size class -> block
 static std::map<void *, size_t> g_live;           // block -> size class
 static size_t g_cached_bytes = 0;
-static const size_t kCacheLimit = (size_t)64 << 30;  // keep at most 64 GiB parked
+static size_t g_cache_limit = (size_t)64 << 30;       // parked blocks: at most 64 GiB, raised to half of the device memory at init
+                                                        // (hipMalloc / hipFree of multi-GB blocks cost ~10 ms per GB)
 
 static size_t size_class(size_t b) {
     if (b < 256) b = 256;
@@ -101,7 +102,7 @@ int dev_free(void *ptr) {
     }
     size_t c = it->second;
     g_live.erase(it);
-    if (g_cached_bytes + c > kCacheLimit) {
+    if (g_cached_bytes + c > g_cache_limit) {
         // stream-ordered safety: everything runs on one stream, but hipFree synchronises anyway
         (void)hipFree(ptr);
     } else {
@@ -306,6 +307,10 @@ int symgpu_init(int device) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c.device = device;
+    {
+        size_t f = 0, t = 0;
+        if (hipMemGetInfo(&f, &t) == hipSuccess && t / 2 > g_cache_limit) g_cache_limit = t / 2;
+    }
     c.ready = true;
     return SYMGPU_OK;
 }
