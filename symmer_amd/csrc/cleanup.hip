@@ -292,7 +292,7 @@ __global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 
 template <bool PACKED>
 __device__ __forceinline__ void segment_close(i64 pos, double re, double im, uint8_t *__restrict__ heads, const u32 *__restrict__ idx,
                                               const u64 *__restrict__ pk, double *__restrict__ cg, double thr, int use_thr,
-                                              u32 *__restrict__ markbits, PackedLayout L, u32 Ni) {
+                                              u32 *__restrict__ markbits, PackedLayout L, u32 Ni, u32 *__restrict__ pos_of) {
     const bool keep = use_thr ? (hypot(re, im) > thr) : true;
     if (!keep) return;
     double2 o; o.x = re; o.y = im;
@@ -302,12 +302,13 @@ __device__ __forceinline__ void segment_close(i64 pos, double re, double im, uin
     if (PACKED) { const u64 k = pk[pos]; first = L.o(k) * Ni + L.i(k); }
     else first = idx[pos];
     atomicOr(&markbits[first >> 5], 1u << (first & 31u));
+    if (pos_of) pos_of[first] = (u32)pos;                          // input index of the term -> sorted position of its sum
 }
 
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_segsum_heads(uint8_t *__restrict__ heads, const u32 *__restrict__ idx, const u64 *__restrict__ pk, i64 T,
                                                        double *__restrict__ cg, double thr, int use_thr, u32 *__restrict__ markbits, PackedLayout L,
-                                                       u32 Ni, i64 chunks_per_wave) {
+                                                       u32 Ni, i64 chunks_per_wave, u32 *__restrict__ pos_of) {
     const int lane = threadIdx.x & 63;
     const i64 n_chunks = (T + 63) / 64;
     const i64 c0 = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * chunks_per_wave;
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(256) void k_segsum_heads(uint8_t *__restrict__ head
     for (i64 chunk = c0;; ++chunk) {
         if (chunk >= c1 && !open) break;
         if (chunk >= n_chunks) {        // the carried segment ends with the data
-            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni);
+            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni, pos_of);
             break;
         }
         const i64 s = chunk * 64 + lane;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void k_segsum_heads(uint8_t *__restrict__ head
         }
         if (m == 0ULL) continue;                                  // no head in this chunk
         if (open) {
-            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni);
+            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni, pos_of);
             open = false;
         }
         if (chunk >= c1) break;                                   // beyond the own range only the carry had to be closed
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256) void k_segsum_heads(uint8_t *__restrict__ head
         // the last head of a full chunk may continue in the next chunk: carry it; everything else closes here
         const int last = 63 - __builtin_clzll(m);
         const bool carry = (chunk * 64 + 64 <= T) && true;       // a full chunk: lane `last` is a real head whose run reaches lane 63
-        if (is_head && !(carry && lane == last)) segment_close<PACKED>(s, re, im, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni);
+        if (is_head && !(carry && lane == last)) segment_close<PACKED>(s, re, im, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni, pos_of);
         if (carry) {
             open = true;
             are = __shfl(re, last);
@@ -369,45 +370,69 @@ __global__ void k_popc_words(const u32 *__restrict__ bits, i64 n_words, u32 *__r
     for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (i64)gridDim.x * blockDim.x) counts[w] = (u32)__popc(bits[w]);
 }
 
-// out position of a kept segment = number of marked first indices below its own (= idx at the head: the sort is stable):
-// word prefix + popcount of the lower bits of its word
-// out_src[p]: input index of the row, PACKED: its (o << bi) | i fields (k_gather_rows then needs no division)
-template <bool PACKED>
-__global__ void k_emit_heads(const uint8_t *__restrict__ heads, const u32 *__restrict__ idx, const u64 *__restrict__ pk, i64 T,
-                             const double *__restrict__ cg, const u32 *__restrict__ markbits, const u32 *__restrict__ wordprefix,
-                             double *__restrict__ out_coeff, u32 *__restrict__ out_src, PackedLayout L, u32 Ni) {
-    for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
-        if (heads[s] != 2u) continue;
-        u32 w, first;
-        if (PACKED) { const u64 k = pk[s]; w = L.fields(k); first = L.o(k) * Ni + L.i(k); }
-        else { w = idx[s]; first = w; }
-        const u32 p = wordprefix[first >> 5] + (u32)__popc(markbits[first >> 5] & ((1u << (first & 31u)) - 1u));
-        reinterpret_cast<double2 *>(out_coeff)[p] = reinterpret_cast<const double2 *>(cg)[s];
-        out_src[p] = w;
+// Output stage without any scatter.  The kept terms are the set bits of `markbits` (input index space), and input order IS the
+// output order: a wavefront takes 64 bitmap words (2048 input indices), expands their set bits into a compact list in LDS
+// (output slot of the k-th one = word prefix + k), and lane groups then write coefficient and row of every kept term to its
+// slot — consecutive slots, so the stores are contiguous.  The only random accesses left are the 4-byte look-up of the
+// term's sorted position (written by k_segsum_heads) and the 16-byte read of its summed coefficient.
+template <bool PAIR>
+__global__ __launch_bounds__(256) void k_emit_rows(const u32 *__restrict__ markbits, const u32 *__restrict__ wordprefix, i64 n_words,
+                                                    const u32 *__restrict__ pos_of, const double *__restrict__ cg, int Wq, int wpw,
+                                                    const u32x4 *__restrict__ rows, const u32x4 *__restrict__ inner, u32 Ni,
+                                                    const u32x4 *__restrict__ outer, u32x4 *__restrict__ out_rows, double *__restrict__ out_coeff) {
+    __shared__ u32 s_list[4][2048];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 *list = s_list[wave];
+    // wpw (power of two <= 64) bitmap words per wavefront and step: small inputs use narrow chunks so that enough waves exist
+    const i64 n_chunks = (n_words + wpw - 1) / wpw;
+    for (i64 chunk = (i64)blockIdx.x * 4 + wave; chunk < n_chunks; chunk += (i64)gridDim.x * 4) {
+        const i64 w = chunk * wpw + lane;
+        const u32 bits = (lane < wpw && w < n_words) ? markbits[w] : 0u;
+        const u32 cnt = (u32)__popc(bits);
+        u32 incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        const u32 K = __shfl(incl, 63);
+        if (K == 0) continue;                                        // wave-uniform
+        const u32 p_base = __shfl(wordprefix[chunk * wpw], 0);
+        {
+            u32 b = bits, k = incl - cnt;
+            while (b) { list[k++] = (u32)(w * 32) + (u32)__builtin_ctz(b); b &= b - 1; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 64 kept terms at a time: every lane fetches the metadata of one term (sorted position, summed coefficient) and
+        // stores its coefficient (coalesced); the rows of the 64 terms are then streamed out 1 KiB per wave store.
+        for (u32 k0 = 0; k0 < K; k0 += 64) {
+            const u32 k = k0 + lane;
+            const bool have = k < K;
+            const u32 t = have ? list[k] : 0u;
+            u32 ti = t, to = 0;
+            if (PAIR) { to = t / Ni; ti = t - to * Ni; }
+            if (have) {
+                const u32 sp = pos_of[t];
+                reinterpret_cast<double2 *>(out_coeff)[(i64)p_base + k] = reinterpret_cast<const double2 *>(cg)[sp];
+            }
+            const u32 n_here = K - k0 < 64u ? K - k0 : 64u;
+            const u32 n_chunks16 = n_here * (u32)Wq;                 // 16-byte chunks of these rows, contiguous in the output
+            u32x4 *dst = out_rows + ((i64)p_base + k0) * Wq;
+#pragma unroll 4
+            for (u32 f = lane; f < n_chunks16 + lane; f += 64) {     // uniform trip count: the shuffles need every lane
+                const bool live = f < n_chunks16;
+                const u32 e = live ? f / (u32)Wq : 0u;
+                const u32 c = f - e * (u32)Wq;
+                const u32 ei = __shfl(ti, (int)e), eo = __shfl(to, (int)e);
+                if (live) {
+                    const u32x4 v = PAIR ? (inner[(i64)ei * Wq + c] ^ outer[(i64)eo * Wq + c]) : rows[(i64)ei * Wq + c];
+                    __builtin_nontemporal_store(v, dst + f);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                             // the list is rewritten by the next chunk
     }
-}
-
-// gather surviving rows as 16-byte chunks: out[p][c] = row(out_src[p])[c].  One chunk per thread, one-shot grid,
-// non-temporal stores (the k_mul_rows store pattern: consecutive lanes -> consecutive 16-byte chunks).
-template <bool PAIR, bool PACKED>
-__global__ __launch_bounds__(256) void k_gather_rows(const u32 *__restrict__ out_src, i64 n_out, int Wq, const u32x4 *__restrict__ rows,
-                                                      const u32x4 *__restrict__ inner, u32 Ni, const u32x4 *__restrict__ outer,
-                                                      u32x4 *__restrict__ out, int bi) {
-    const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (k >= n_out * Wq) return;
-    const i64 p = k / Wq;
-    const int c = (int)(k - p * Wq);
-    const u32 t = out_src[p];
-    u32x4 v;
-    if (PAIR) {
-        u32 o, i;
-        if (PACKED) { o = t >> bi; i = t & ((1u << bi) - 1u); }
-        else { o = t / Ni; i = t - o * Ni; }
-        v = inner[(i64)i * Wq + c] ^ outer[(i64)o * Wq + c];
-    } else {
-        v = rows[(i64)t * Wq + c];
-    }
-    __builtin_nontemporal_store(v, out + k);
 }
 
 static int grid_for(i64 n, int block = 256, int cap = 8192) {
@@ -435,7 +460,7 @@ int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
 }
 
 int cleanup_finish(uint8_t *heads, const u32 *is, const u64 *pk, bool packed, PackedLayout L, i64 T, double *cg, double thr, int use_thr, bool pair,
-                   const u64 *rows, int W, const u64 *inner, i64 Ni, const u64 *outer, symgpu_op_t *out, int Wq_out) {
+                   const u64 *rows, int W, const u64 *inner, i64 Ni, const u64 *outer, symgpu_op_t *out, int Wq_out, u32 *pos_of) {
     hipStream_t st = ctx().stream;
     const i64 n_words = (T + 31) / 32;
     Scratch markbits, wordprefix;
@@ -448,9 +473,9 @@ int cleanup_finish(uint8_t *heads, const u32 *is, const u64 *pk, bool packed, Pa
         const i64 n_waves = (n_chunks + cpw - 1) / cpw;
         const dim3 gs((unsigned)((n_waves + 3) / 4));
         if (packed)
-            hipLaunchKernelGGL(k_segsum_heads<true>, gs, dim3(256), 0, st, heads, is, pk, T, cg, thr, use_thr, markbits.as<u32>(), L, (u32)Ni, cpw);
+            hipLaunchKernelGGL(k_segsum_heads<true>, gs, dim3(256), 0, st, heads, is, pk, T, cg, thr, use_thr, markbits.as<u32>(), L, (u32)Ni, cpw, pos_of);
         else
-            hipLaunchKernelGGL(k_segsum_heads<false>, gs, dim3(256), 0, st, heads, is, pk, T, cg, thr, use_thr, markbits.as<u32>(), L, 1u, cpw);
+            hipLaunchKernelGGL(k_segsum_heads<false>, gs, dim3(256), 0, st, heads, is, pk, T, cg, thr, use_thr, markbits.as<u32>(), L, 1u, cpw, pos_of);
     }
     hipLaunchKernelGGL(k_popc_words, dim3(grid_for(n_words)), dim3(256), 0, st, markbits.as<u32>(), n_words, wordprefix.as<u32>());
     KERNEL_CHECK();
@@ -465,29 +490,22 @@ int cleanup_finish(uint8_t *heads, const u32 *is, const u64 *pk, bool packed, Pa
     SG_TRY(symgpu_op_alloc(n_out > 0 ? n_out : 1, Wq_out, 1, &res));
     res->T = n_out;
     if (n_out > 0) {
-        Scratch src;
-        int rc = src.alloc((size_t)n_out * 4);
-        if (rc != SYMGPU_OK) { symgpu_op_free(res); return rc; }
-        if (packed)
-            hipLaunchKernelGGL(k_emit_heads<true>, dim3(grid_for(T)), dim3(256), 0, st, heads, is, pk, T, cg, markbits.as<u32>(), wordprefix.as<u32>(),
-                               res->coeff, src.as<u32>(), L, (u32)Ni);
-        else
-            hipLaunchKernelGGL(k_emit_heads<false>, dim3(grid_for(T)), dim3(256), 0, st, heads, is, pk, T, cg, markbits.as<u32>(), wordprefix.as<u32>(),
-                               res->coeff, src.as<u32>(), L, 1u);
         const int Wq = W / 2;
-        const dim3 gg((unsigned)((n_out * Wq + 255) / 256));
+        int wpw = 64;                                            // bitmap words per wavefront: aim at >= 16k wavefronts
+        while (wpw > 1 && (n_words + wpw - 1) / wpw < 16384) wpw >>= 1;
+        i64 ge = ((n_words + wpw - 1) / wpw + 3) / 4;
+        if (ge > 16384) ge = 16384;
         const u32x4 *pin = reinterpret_cast<const u32x4 *>(inner), *pout = reinterpret_cast<const u32x4 *>(outer);
         u32x4 *dst = reinterpret_cast<u32x4 *>(res->rows);
-        if (packed)
-            hipLaunchKernelGGL((k_gather_rows<true, true>), gg, dim3(256), 0, st, src.as<u32>(), n_out, Wq, (const u32x4 *)nullptr, pin, (u32)Ni, pout, dst, L.bi);
-        else if (pair)
-            hipLaunchKernelGGL((k_gather_rows<true, false>), gg, dim3(256), 0, st, src.as<u32>(), n_out, Wq, (const u32x4 *)nullptr, pin, (u32)Ni, pout, dst, 0);
+        if (pair)
+            hipLaunchKernelGGL(k_emit_rows<true>, dim3((unsigned)ge), dim3(256), 0, st, markbits.as<u32>(), wordprefix.as<u32>(), n_words, pos_of, cg, Wq, wpw,
+                               (const u32x4 *)nullptr, pin, (u32)Ni, pout, dst, res->coeff);
         else
-            hipLaunchKernelGGL((k_gather_rows<false, false>), gg, dim3(256), 0, st, src.as<u32>(), n_out, Wq, reinterpret_cast<const u32x4 *>(rows),
-                               (const u32x4 *)nullptr, 1u, (const u32x4 *)nullptr, dst, 0);
+            hipLaunchKernelGGL(k_emit_rows<false>, dim3((unsigned)ge), dim3(256), 0, st, markbits.as<u32>(), wordprefix.as<u32>(), n_words, pos_of, cg, Wq, wpw,
+                               reinterpret_cast<const u32x4 *>(rows), (const u32x4 *)nullptr, 1u, (const u32x4 *)nullptr, dst, res->coeff);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(st);   // src is freed on return; keep ordering simple
-        if (e != hipSuccess) { symgpu_op_free(res); return hip_fail(e, "cleanup emit/gather", __FILE__, __LINE__); }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);   // the scratch buffers are freed on return; keep ordering simple
+        if (e != hipSuccess) { symgpu_op_free(res); return hip_fail(e, "cleanup emit", __FILE__, __LINE__); }
     }
     *out = res;
     return SYMGPU_OK;
@@ -625,7 +643,9 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         set_error("cleanup: 64-bit row-hash collision survived 4 reseeds");
         return SYMGPU_E_COLLISION;
     }
-    return cleanup_finish(heads.as<uint8_t>(), is, ks, packed, L, T, cg.as<double>(), thr, use_thr, pair, rows, W, inner, Ni, outer, out, Wq_out);
+    // the key buffer the sort did NOT end in is free now: it becomes the input-index -> sorted-position map (4 of its 8 bytes per term)
+    u32 *pos_of = reinterpret_cast<u32 *>(ks == keys.as<u64>() ? keys2.p : keys.p);
+    return cleanup_finish(heads.as<uint8_t>(), is, ks, packed, L, T, cg.as<double>(), thr, use_thr, pair, rows, W, inner, Ni, outer, out, Wq_out, pos_of);
 }
 
 }  // namespace symgpu
