@@ -419,7 +419,6 @@ __global__ __launch_bounds__(256) void k_emit_rows(const u32 *__restrict__ markb
             const u32 n_here = K - k0 < 64u ? K - k0 : 64u;
             const u32 n_chunks16 = n_here * (u32)Wq;                 // 16-byte chunks of these rows, contiguous in the output
             u32x4 *dst = out_rows + ((i64)p_base + k0) * Wq;
-#pragma unroll 4
             for (u32 f = lane; f < n_chunks16 + lane; f += 64) {     // uniform trip count: the shuffles need every lane
                 const bool live = f < n_chunks16;
                 const u32 e = live ? f / (u32)Wq : 0u;
