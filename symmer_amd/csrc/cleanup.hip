@@ -178,26 +178,26 @@ __global__ __launch_bounds__(256) void k_heads(const u64 *__restrict__ keys, con
     for (i64 chunk = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += (i64)gridDim.x * 4) {
         const i64 s = chunk * 64 + lane;
         const bool valid = s < T;
-        // this position: input index t1 (PAIR: as (i1, o1)), full key f1
-        u64 f1 = 0, k1 = 0;
-        u32 t1 = 0, i1 = 0, o1 = 0;
-        auto decode = [&](i64 pos, u64 &k, u64 &f, u32 &t, u32 &ii, u32 &oo) {
-            k = keys[pos];
-            if (PACKED) {
-                ii = L.i(k); oo = L.o(k);
-                f = hI[ii] ^ hO[oo];
-            } else {
-                t = idx[pos];
-                f = k;
-                if (PAIR) { oo = t / Ni; ii = t - oo * Ni; }
-            }
-        };
-        if (valid) decode(s, k1, f1, t1, i1, o1);
-        // predecessor: neighbour lane, lane 0 decodes position s-1 itself
-        u64 f0 = __shfl_up(f1, 1);
-        u32 t0 = __shfl_up(t1, 1), i0 = __shfl_up(i1, 1), o0 = __shfl_up(o1, 1);
-        if (lane == 0 && valid && s > 0) { u64 k0; decode(s - 1, k0, f0, t0, i0, o0); }
-        const bool eq = valid && s > 0 && f1 == f0;
+        // this position: key k1, input index t1 (PAIR: as (i1, o1)); predecessor k0 / t0 / (i0, o0) from the neighbour lane
+        // (lane 0 reads position s-1 itself)
+        u64 k1 = valid ? keys[s] : 0ULL;
+        u64 k0 = __shfl_up(k1, 1);
+        if (lane == 0 && valid && s > 0) k0 = keys[s - 1];
+        u32 t1 = 0, i1 = 0, o1 = 0, t0 = 0, i0 = 0, o0 = 0;
+        bool eq;
+        if (PACKED) {
+            i1 = L.i(k1); o1 = L.o(k1); i0 = L.i(k0); o0 = L.o(k0);
+            // equal 64-bit keys?  Different hash prefixes: no.  P * P twins (i, o) / (o, i): yes, the two hash tables are the
+            // same.  Otherwise (about 1 % of the positions) the full keys are rebuilt from the operand hash tables.
+            eq = valid && s > 0 && (k1 >> L.F()) == (k0 >> L.F());
+            if (eq && !(inner == outer && i1 == o0 && o1 == i0)) eq = (hI[i1] ^ hO[o1]) == (hI[i0] ^ hO[o0]);
+        } else {
+            if (valid) t1 = idx[s];
+            t0 = __shfl_up(t1, 1);
+            if (lane == 0 && valid && s > 0) t0 = idx[s - 1];
+            if (PAIR) { o1 = t1 / Ni; i1 = t1 - o1 * Ni; o0 = t0 / Ni; i0 = t0 - o0 * Ni; }
+            eq = valid && s > 0 && k1 == k0;
+        }
         if (valid) {
             heads[s] = eq ? 0u : 1u;
             double2 c;
@@ -241,12 +241,15 @@ constexpr int FIX_MAX = 48;
 // PACKED: keys are packed pair keys (full key recomputed from the (i, o) fields), there is no separate idx array.
 template <bool PACKED>
 __global__ void k_fixup_mark(const u64 *__restrict__ keys, i64 T, int shift, uint8_t *__restrict__ need,
-                             const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L) {
+                             const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L, bool same_operand) {
     for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
         if (s == 0) continue;
         const u64 k = keys[s], kp = keys[s - 1];
         if ((k >> shift) != (kp >> shift)) continue;
-        if (PACKED ? (L.full_key(hI, hO, k) == L.full_key(hI, hO, kp)) : (k == kp)) continue;
+        if (PACKED) {
+            if (same_operand && L.i(k) == L.o(kp) && L.o(k) == L.i(kp)) continue;          // P * P twins: equal keys by construction
+            if (L.full_key(hI, hO, k) == L.full_key(hI, hO, kp)) continue;
+        } else if (k == kp) continue;
         i64 b = s - 1;
         while (b > 0 && (keys[b - 1] >> shift) == (kp >> shift)) --b;
         need[b] = 1u;
@@ -602,12 +605,12 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             // `heads` doubles as the run-start marker array here (it is overwritten by k_heads afterwards)
             HIP_TRY(hipMemsetAsync(heads.p, 0, (size_t)T, st));
             if (packed) {
-                hipLaunchKernelGGL(k_fixup_mark<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<uint8_t>(), hI.as<u64>(), hO.as<u64>(), L);
+                hipLaunchKernelGGL(k_fixup_mark<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<uint8_t>(), hI.as<u64>(), hO.as<u64>(), L, inner == outer);
                 hipLaunchKernelGGL(k_fixup_sort<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, (u32 *)nullptr, T, 64 - nbits, heads.as<uint8_t>(),
                                    collision.as<u32>() + 1, hI.as<u64>(), hO.as<u64>(), L);
             } else {
                 hipLaunchKernelGGL(k_fixup_mark<false>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<uint8_t>(), (const u64 *)nullptr,
-                                   (const u64 *)nullptr, L);
+                                   (const u64 *)nullptr, L, false);
                 hipLaunchKernelGGL(k_fixup_sort<false>, dim3(grid_for(T)), dim3(256), 0, st, ks, is, T, 64 - nbits, heads.as<uint8_t>(),
                                    collision.as<u32>() + 1, (const u64 *)nullptr, (const u64 *)nullptr, L);
             }
