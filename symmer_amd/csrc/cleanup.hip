@@ -288,9 +288,9 @@ __global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 
 // them one shuffle at a time — SEQUENTIALLY in ascending input order (the sort is stable), exactly np.add.at's order
 // (utils.py:273-274) — and a segment that runs past the end of a chunk is carried (wave-uniform accumulator) into the next
 // chunks, past the end of the wave's own range if necessary; the leading non-head positions of a range therefore belong to
-// the previous wave and are skipped.  The sum replaces cg[s] at the head; heads[s] becomes 2 if the term survives the strict
-// |c| > thr test (1 otherwise) and the first-occurrence index of a surviving term sets its bit in `markbits` (T bits:
-// 12.5 MB for 1e8 terms, cache resident, instead of a 4-byte flag per input index scattered over 400 MB).
+// the previous wave and are skipped.  If the term survives the strict |c| > thr test the sum replaces cg[s] at the head, the
+// first-occurrence index of the term sets its bit in `markbits` (T bits: 12.5 MB for 1e8 terms, cache resident) and the head's
+// sorted position is recorded under that index in `pos_of` for the output stage.
 // PACKED: idx is unused, the input index comes from the (o, i) fields of the packed pair keys pk.
 template <bool PACKED>
 __device__ __forceinline__ void segment_close(i64 pos, double re, double im, uint8_t *__restrict__ heads, const u32 *__restrict__ idx,
@@ -300,7 +300,7 @@ __device__ __forceinline__ void segment_close(i64 pos, double re, double im, uin
     if (!keep) return;
     double2 o; o.x = re; o.y = im;
     reinterpret_cast<double2 *>(cg)[pos] = o;
-    heads[pos] = 2u;
+    // (heads[pos] is not updated: the output stage walks the bitmap, not the head flags)
     u32 first;
     if (PACKED) { const u64 k = pk[pos]; first = L.o(k) * Ni + L.i(k); }
     else first = idx[pos];
