@@ -295,23 +295,22 @@ __global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 
 template <bool PACKED>
 __device__ __forceinline__ void segment_close(i64 pos, double re, double im, uint8_t *__restrict__ heads, const u32 *__restrict__ idx,
                                               const u64 *__restrict__ pk, double *__restrict__ cg, double thr, int use_thr,
-                                              u32 *__restrict__ markbits, PackedLayout L, u32 Ni, u32 *__restrict__ pos_of) {
+                                              u32 *__restrict__ markbits, PackedLayout L, u32 Ni, double *__restrict__ sum_of) {
     const bool keep = use_thr ? (hypot(re, im) > thr) : true;
     if (!keep) return;
     double2 o; o.x = re; o.y = im;
-    reinterpret_cast<double2 *>(cg)[pos] = o;
     // (heads[pos] is not updated: the output stage walks the bitmap, not the head flags)
     u32 first;
     if (PACKED) { const u64 k = pk[pos]; first = L.o(k) * Ni + L.i(k); }
     else first = idx[pos];
     atomicOr(&markbits[first >> 5], 1u << (first & 31u));
-    if (pos_of) pos_of[first] = (u32)pos;                          // input index of the term -> sorted position of its sum
+    reinterpret_cast<double2 *>(sum_of)[first] = o;                // the sum, filed under the input index of the term's first occurrence
 }
 
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_segsum_heads(uint8_t *__restrict__ heads, const u32 *__restrict__ idx, const u64 *__restrict__ pk, i64 T,
                                                        double *__restrict__ cg, double thr, int use_thr, u32 *__restrict__ markbits, PackedLayout L,
-                                                       u32 Ni, i64 chunks_per_wave, u32 *__restrict__ pos_of) {
+                                                       u32 Ni, i64 chunks_per_wave, double *__restrict__ sum_of) {
     const int lane = threadIdx.x & 63;
     const i64 n_chunks = (T + 63) / 64;
     const i64 c0 = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * chunks_per_wave;
@@ -323,7 +322,7 @@ __global__ __launch_bounds__(256) void k_segsum_heads(uint8_t *__restrict__ head
     for (i64 chunk = c0;; ++chunk) {
         if (chunk >= c1 && !open) break;
         if (chunk >= n_chunks) {        // the carried segment ends with the data
-            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni, pos_of);
+            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni, sum_of);
             break;
         }
         const i64 s = chunk * 64 + lane;
@@ -341,7 +340,7 @@ __global__ __launch_bounds__(256) void k_segsum_heads(uint8_t *__restrict__ head
         }
         if (m == 0ULL) continue;                                  // no head in this chunk
         if (open) {
-            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni, pos_of);
+            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni, sum_of);
             open = false;
         }
         if (chunk >= c1) break;                                   // beyond the own range only the carry had to be closed
@@ -359,7 +358,7 @@ __global__ __launch_bounds__(256) void k_segsum_heads(uint8_t *__restrict__ head
         // the last head of a full chunk may continue in the next chunk: carry it; everything else closes here
         const int last = 63 - __builtin_clzll(m);
         const bool carry = (chunk * 64 + 64 <= T) && true;       // a full chunk: lane `last` is a real head whose run reaches lane 63
-        if (is_head && !(carry && lane == last)) segment_close<PACKED>(s, re, im, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni, pos_of);
+        if (is_head && !(carry && lane == last)) segment_close<PACKED>(s, re, im, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni, sum_of);
         if (carry) {
             open = true;
             are = __shfl(re, last);
@@ -380,7 +379,7 @@ __global__ void k_popc_words(const u32 *__restrict__ bits, i64 n_words, u32 *__r
 // term's sorted position (written by k_segsum_heads) and the 16-byte read of its summed coefficient.
 template <bool PAIR>
 __global__ __launch_bounds__(256) void k_emit_rows(const u32 *__restrict__ markbits, const u32 *__restrict__ wordprefix, i64 n_words,
-                                                    const u32 *__restrict__ pos_of, const double *__restrict__ cg, int Wq, int wpw,
+                                                    const double *__restrict__ sum_of, int Wq, int wpw,
                                                     const u32x4 *__restrict__ rows, const u32x4 *__restrict__ inner, u32 Ni,
                                                     const u32x4 *__restrict__ outer, u32x4 *__restrict__ out_rows, double *__restrict__ out_coeff) {
     __shared__ u32 s_list[4][2048];
@@ -415,10 +414,7 @@ __global__ __launch_bounds__(256) void k_emit_rows(const u32 *__restrict__ markb
             const u32 t = have ? list[k] : 0u;
             u32 ti = t, to = 0;
             if (PAIR) { to = t / Ni; ti = t - to * Ni; }
-            if (have) {
-                const u32 sp = pos_of[t];
-                reinterpret_cast<double2 *>(out_coeff)[(i64)p_base + k] = reinterpret_cast<const double2 *>(cg)[sp];
-            }
+            if (have) reinterpret_cast<double2 *>(out_coeff)[(i64)p_base + k] = reinterpret_cast<const double2 *>(sum_of)[t];
             const u32 n_here = K - k0 < 64u ? K - k0 : 64u;
             const u32 n_chunks16 = n_here * (u32)Wq;                 // 16-byte chunks of these rows, contiguous in the output
             u32x4 *dst = out_rows + ((i64)p_base + k0) * Wq;
@@ -462,10 +458,11 @@ int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
 }
 
 int cleanup_finish(uint8_t *heads, const u32 *is, const u64 *pk, bool packed, PackedLayout L, i64 T, double *cg, double thr, int use_thr, bool pair,
-                   const u64 *rows, int W, const u64 *inner, i64 Ni, const u64 *outer, symgpu_op_t *out, int Wq_out, u32 *pos_of) {
+                   const u64 *rows, int W, const u64 *inner, i64 Ni, const u64 *outer, symgpu_op_t *out, int Wq_out) {
     hipStream_t st = ctx().stream;
     const i64 n_words = (T + 31) / 32;
-    Scratch markbits, wordprefix;
+    Scratch markbits, wordprefix, sum_of;
+    SG_TRY(sum_of.alloc((size_t)T * 16));                           // summed coefficient of a kept term, indexed by its first input index
     SG_TRY(markbits.alloc((size_t)n_words * 4));
     SG_TRY(wordprefix.alloc((size_t)n_words * 4));
     HIP_TRY(hipMemsetAsync(markbits.p, 0, (size_t)n_words * 4, st));
@@ -475,9 +472,9 @@ int cleanup_finish(uint8_t *heads, const u32 *is, const u64 *pk, bool packed, Pa
         const i64 n_waves = (n_chunks + cpw - 1) / cpw;
         const dim3 gs((unsigned)((n_waves + 3) / 4));
         if (packed)
-            hipLaunchKernelGGL(k_segsum_heads<true>, gs, dim3(256), 0, st, heads, is, pk, T, cg, thr, use_thr, markbits.as<u32>(), L, (u32)Ni, cpw, pos_of);
+            hipLaunchKernelGGL(k_segsum_heads<true>, gs, dim3(256), 0, st, heads, is, pk, T, cg, thr, use_thr, markbits.as<u32>(), L, (u32)Ni, cpw, sum_of.as<double>());
         else
-            hipLaunchKernelGGL(k_segsum_heads<false>, gs, dim3(256), 0, st, heads, is, pk, T, cg, thr, use_thr, markbits.as<u32>(), L, 1u, cpw, pos_of);
+            hipLaunchKernelGGL(k_segsum_heads<false>, gs, dim3(256), 0, st, heads, is, pk, T, cg, thr, use_thr, markbits.as<u32>(), L, 1u, cpw, sum_of.as<double>());
     }
     hipLaunchKernelGGL(k_popc_words, dim3(grid_for(n_words)), dim3(256), 0, st, markbits.as<u32>(), n_words, wordprefix.as<u32>());
     KERNEL_CHECK();
@@ -500,10 +497,10 @@ int cleanup_finish(uint8_t *heads, const u32 *is, const u64 *pk, bool packed, Pa
         const u32x4 *pin = reinterpret_cast<const u32x4 *>(inner), *pout = reinterpret_cast<const u32x4 *>(outer);
         u32x4 *dst = reinterpret_cast<u32x4 *>(res->rows);
         if (pair)
-            hipLaunchKernelGGL(k_emit_rows<true>, dim3((unsigned)ge), dim3(256), 0, st, markbits.as<u32>(), wordprefix.as<u32>(), n_words, pos_of, cg, Wq, wpw,
+            hipLaunchKernelGGL(k_emit_rows<true>, dim3((unsigned)ge), dim3(256), 0, st, markbits.as<u32>(), wordprefix.as<u32>(), n_words, sum_of.as<double>(), Wq, wpw,
                                (const u32x4 *)nullptr, pin, (u32)Ni, pout, dst, res->coeff);
         else
-            hipLaunchKernelGGL(k_emit_rows<false>, dim3((unsigned)ge), dim3(256), 0, st, markbits.as<u32>(), wordprefix.as<u32>(), n_words, pos_of, cg, Wq, wpw,
+            hipLaunchKernelGGL(k_emit_rows<false>, dim3((unsigned)ge), dim3(256), 0, st, markbits.as<u32>(), wordprefix.as<u32>(), n_words, sum_of.as<double>(), Wq, wpw,
                                reinterpret_cast<const u32x4 *>(rows), (const u32x4 *)nullptr, 1u, (const u32x4 *)nullptr, dst, res->coeff);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);   // the scratch buffers are freed on return; keep ordering simple
@@ -645,9 +642,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         set_error("cleanup: 64-bit row-hash collision survived 4 reseeds");
         return SYMGPU_E_COLLISION;
     }
-    // the key buffer the sort did NOT end in is free now: it becomes the input-index -> sorted-position map (4 of its 8 bytes per term)
-    u32 *pos_of = reinterpret_cast<u32 *>(ks == keys.as<u64>() ? keys2.p : keys.p);
-    return cleanup_finish(heads.as<uint8_t>(), is, ks, packed, L, T, cg.as<double>(), thr, use_thr, pair, rows, W, inner, Ni, outer, out, Wq_out, pos_of);
+    return cleanup_finish(heads.as<uint8_t>(), is, ks, packed, L, T, cg.as<double>(), thr, use_thr, pair, rows, W, inner, Ni, outer, out, Wq_out);
 }
 
 }  // namespace symgpu
