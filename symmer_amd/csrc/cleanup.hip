@@ -163,19 +163,50 @@ __device__ __forceinline__ bool differs(u32x4 a, u32x4 b) {
 }
 // PACKED (implies PAIR): keys are packed pair keys; idx and coeff are unused: the input index, the full key and the pair
 // coefficient c_i * c_o * i^e come from the key's fields and the operand tables hI / hO / ci / co.
+//
+// The SAME kernel forms the segment sums, so that neither the head flags nor the coefficients in sorted order are ever
+// written to memory: every wavefront owns a contiguous range of 64-position chunks; head lanes add the coefficients of the
+// non-head lanes that follow them one shuffle at a time — SEQUENTIALLY in ascending input order (the sort is stable), exactly
+// np.add.at's order (utils.py:273-274) — and a segment that runs past the end of a chunk is carried (wave-uniform
+// accumulator) into the next chunks, past the end of the wave's own range if necessary (those chunks are only decoded, their
+// owner verifies them); the leading non-head positions of a range therefore belong to the previous wave and are skipped.
+// A term that survives the strict |c| > thr test sets the bit of its first input index in `markbits` (T bits: 12.5 MB for
+// 1e8 terms, cache resident) and files its sum under that index in `sum_of` for the output stage.
 template <bool PAIR, bool PACKED>
-__global__ __launch_bounds__(256) void k_heads(const u64 *__restrict__ keys, const u32 *__restrict__ idx, i64 T, const u64 *__restrict__ rows, int W,
-                                                const u64 *__restrict__ inner, u32 Ni, const u64 *__restrict__ outer, int G,
-                                                const double *__restrict__ coeff, double *__restrict__ cg,
-                                                uint8_t *__restrict__ heads, u32 *__restrict__ collision,
-                                                const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L,
-                                                const double *__restrict__ ci, const double *__restrict__ co) {
+__global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys, const u32 *__restrict__ idx, i64 T, const u64 *__restrict__ rows, int W,
+                                                     const u64 *__restrict__ inner, u32 Ni, const u64 *__restrict__ outer, int G,
+                                                     const double *__restrict__ coeff, u32 *__restrict__ collision,
+                                                     const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L,
+                                                     const double *__restrict__ ci, const double *__restrict__ co,
+                                                     double thr, int use_thr, u32 *__restrict__ markbits, double *__restrict__ sum_of,
+                                                     i64 chunks_per_wave) {
     const int lane = threadIdx.x & 63;
     const int gi = lane / G, gl = lane % G;
     const int C = W / 2;                                             // 16-byte chunks per row
     const u64 gmask = G == 64 ? ~0ULL : (((1ULL << G) - 1ULL) << (gi * G));
     const i64 n_chunks = (T + 63) / 64;
-    for (i64 chunk = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += (i64)gridDim.x * 4) {
+    const i64 c0 = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * chunks_per_wave;
+    if (c0 >= n_chunks) return;
+    const i64 c1 = c0 + chunks_per_wave < n_chunks ? c0 + chunks_per_wave : n_chunks;
+
+    auto close = [&](u32 first, double re, double im) {            // strict threshold, bitmap, sum filed under the first index
+        if (use_thr && !(hypot(re, im) > thr)) return;
+        atomicOr(&markbits[first >> 5], 1u << (first & 31u));
+        double2 o; o.x = re; o.y = im;
+        reinterpret_cast<double2 *>(sum_of)[first] = o;
+    };
+
+    bool open = false;                  // wave-uniform: a segment is carried across chunk boundaries
+    double are = 0.0, aim = 0.0;        // its running sum
+    u32 afirst = 0;                     // input index of its first (head) element
+    bool mism = false;
+    for (i64 chunk = c0;; ++chunk) {
+        if (chunk >= c1 && !open) break;
+        if (chunk >= n_chunks) {        // the carried segment ends with the data
+            if (lane == 0) close(afirst, are, aim);
+            break;
+        }
+        const bool own = chunk < c1;    // beyond the own range: decode only, to finish the carried segment
         const i64 s = chunk * 64 + lane;
         const bool valid = s < T;
         // this position: key k1, input index t1 (PAIR: as (i1, o1)); predecessor k0 / t0 / (i0, o0) from the neighbour lane
@@ -187,6 +218,7 @@ __global__ __launch_bounds__(256) void k_heads(const u64 *__restrict__ keys, con
         bool eq;
         if (PACKED) {
             i1 = L.i(k1); o1 = L.o(k1); i0 = L.i(k0); o0 = L.o(k0);
+            t1 = o1 * Ni + i1;
             // equal 64-bit keys?  Different hash prefixes: no.  P * P twins (i, o) / (o, i): yes, the two hash tables are the
             // same.  Otherwise (about 1 % of the positions) the full keys are rebuilt from the operand hash tables.
             eq = valid && s > 0 && (k1 >> L.F()) == (k0 >> L.F());
@@ -198,38 +230,74 @@ __global__ __launch_bounds__(256) void k_heads(const u64 *__restrict__ keys, con
             if (PAIR) { o1 = t1 / Ni; i1 = t1 - o1 * Ni; o0 = t0 / Ni; i0 = t0 - o0 * Ni; }
             eq = valid && s > 0 && k1 == k0;
         }
+        double2 c; c.x = 0.0; c.y = 0.0;
         if (valid) {
-            heads[s] = eq ? 0u : 1u;
-            double2 c;
             if (PACKED) pair_coefficient(ci[2 * i1], ci[2 * i1 + 1], co[2 * o1], co[2 * o1 + 1], L.e(k1), c.x, c.y);
             else c = reinterpret_cast<const double2 *>(coeff)[t1];
-            reinterpret_cast<double2 *>(cg)[s] = c;
         }
-        // P * P: row(i, o) == row(o, i) by commutativity of XOR when both operands are the same array — nothing to read
-        const bool trivially_equal = PAIR && inner == outer && i1 == o0 && o1 == i0;
-        u64 sub = __ballot(eq && !trivially_equal) & gmask;          // this group's candidates
-        bool mism = false;
-        while (__ballot(sub != 0ULL)) {                              // wave-uniform
-            const bool act = sub != 0ULL;
-            const int p = act ? __builtin_ctzll(sub) : 0;
-            sub &= sub - 1;
-            if (PAIR) {
-                const i64 ci1 = __shfl(i1, p), co1 = __shfl(o1, p), ci0 = __shfl(i0, p), co0 = __shfl(o0, p);
-                if (act) {
-                    const u32x4 *r1 = reinterpret_cast<const u32x4 *>(inner + ci1 * W), *q1 = reinterpret_cast<const u32x4 *>(outer + co1 * W);
-                    const u32x4 *r0 = reinterpret_cast<const u32x4 *>(inner + ci0 * W), *q0 = reinterpret_cast<const u32x4 *>(outer + co0 * W);
-                    for (int c = gl; c < C; c += G) mism |= differs(r1[c] ^ q1[c], r0[c] ^ q0[c]);
-                }
-            } else {
-                const i64 a1 = __shfl(t1, p), a0 = __shfl(t0, p);
-                if (act) {
-                    const u32x4 *r1 = reinterpret_cast<const u32x4 *>(rows + a1 * W), *r0 = reinterpret_cast<const u32x4 *>(rows + a0 * W);
-                    for (int c = gl; c < C; c += G) mism |= differs(r1[c], r0[c]);
+        if (own) {
+            // exact verification of the equal-key neighbours.  P * P: row(i, o) == row(o, i) by commutativity of XOR when both
+            // operands are the same array — nothing to read
+            const bool trivially_equal = PAIR && inner == outer && i1 == o0 && o1 == i0;
+            u64 sub = __ballot(eq && !trivially_equal) & gmask;      // this group's candidates
+            while (__ballot(sub != 0ULL)) {                          // wave-uniform
+                const bool act = sub != 0ULL;
+                const int p = act ? __builtin_ctzll(sub) : 0;
+                sub &= sub - 1;
+                if (PAIR) {
+                    const i64 ci1 = __shfl(i1, p), co1 = __shfl(o1, p), ci0 = __shfl(i0, p), co0 = __shfl(o0, p);
+                    if (act) {
+                        const u32x4 *r1 = reinterpret_cast<const u32x4 *>(inner + ci1 * W), *q1 = reinterpret_cast<const u32x4 *>(outer + co1 * W);
+                        const u32x4 *r0 = reinterpret_cast<const u32x4 *>(inner + ci0 * W), *q0 = reinterpret_cast<const u32x4 *>(outer + co0 * W);
+                        for (int cc = gl; cc < C; cc += G) mism |= differs(r1[cc] ^ q1[cc], r0[cc] ^ q0[cc]);
+                    }
+                } else {
+                    const i64 a1 = __shfl(t1, p), a0 = __shfl(t0, p);
+                    if (act) {
+                        const u32x4 *r1 = reinterpret_cast<const u32x4 *>(rows + a1 * W), *r0 = reinterpret_cast<const u32x4 *>(rows + a0 * W);
+                        for (int cc = gl; cc < C; cc += G) mism |= differs(r1[cc], r0[cc]);
+                    }
                 }
             }
         }
-        if (__ballot(mism) && lane == 0) atomicOr(collision, 1u);
+        // ---- segment sums on the head flags (positions past the end act as heads: they end every run) ----
+        const u64 m = __ballot(!valid || !eq);
+        const int lead = m ? __builtin_ctzll(m) : 64;             // leading non-head lanes continue the carried segment
+        if (open) {
+            for (int k = 0; k < lead; ++k) {
+                are = __dadd_rn(are, __shfl(c.x, k));
+                aim = __dadd_rn(aim, __shfl(c.y, k));
+            }
+        }
+        if (m == 0ULL) continue;                                  // no head in this chunk
+        if (open) {
+            if (lane == 0) close(afirst, are, aim);
+            open = false;
+        }
+        if (!own) break;                                          // beyond the own range only the carry had to be closed
+        const bool is_head = valid && !eq;
+        const u64 above = lane == 63 ? 0ULL : (m >> (lane + 1));
+        const int run = above ? __builtin_ctzll(above) : 63 - lane;   // non-head lanes that follow this lane in the chunk
+        double re = __dadd_rn(0.0, c.x), im = __dadd_rn(0.0, c.y);
+        for (int k = 1; __ballot(is_head && k <= run); ++k) {
+            const double vx = __shfl_down(c.x, k), vy = __shfl_down(c.y, k);
+            if (is_head && k <= run) {
+                re = __dadd_rn(re, vx);
+                im = __dadd_rn(im, vy);
+            }
+        }
+        // the last head of a full chunk may continue in the next chunk: carry it; everything else closes here
+        const int last = 63 - __builtin_clzll(m);
+        const bool carry = chunk * 64 + 64 <= T;                  // a full chunk: lane `last` is a real head whose run reaches lane 63
+        if (is_head && !(carry && lane == last)) close(t1, re, im);
+        if (carry) {
+            open = true;
+            are = __shfl(re, last);
+            aim = __shfl(im, last);
+            afirst = __shfl(t1, last);
+        }
     }
+    if (__ballot(mism) && lane == 0) atomicOr(collision, 1u);
 }
 
 // Truncated sort fix-up.  The radix sort only orders the top `nb` key bits (random hash bits: ~log2(T)+5..12 of them already
@@ -283,91 +351,6 @@ __global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 
     }
 }
 
-// Segment sums without segment ids, wave-cooperative.  Every wavefront owns a contiguous range of 64-position chunks; the
-// heads / coefficients of a chunk are loaded coalesced, the head lanes add the coefficients of the non-head lanes that follow
-// them one shuffle at a time — SEQUENTIALLY in ascending input order (the sort is stable), exactly np.add.at's order
-// (utils.py:273-274) — and a segment that runs past the end of a chunk is carried (wave-uniform accumulator) into the next
-// chunks, past the end of the wave's own range if necessary; the leading non-head positions of a range therefore belong to
-// the previous wave and are skipped.  If the term survives the strict |c| > thr test the sum replaces cg[s] at the head, the
-// first-occurrence index of the term sets its bit in `markbits` (T bits: 12.5 MB for 1e8 terms, cache resident) and the head's
-// sorted position is recorded under that index in `pos_of` for the output stage.
-// PACKED: idx is unused, the input index comes from the (o, i) fields of the packed pair keys pk.
-template <bool PACKED>
-__device__ __forceinline__ void segment_close(i64 pos, double re, double im, uint8_t *__restrict__ heads, const u32 *__restrict__ idx,
-                                              const u64 *__restrict__ pk, double *__restrict__ cg, double thr, int use_thr,
-                                              u32 *__restrict__ markbits, PackedLayout L, u32 Ni, double *__restrict__ sum_of) {
-    const bool keep = use_thr ? (hypot(re, im) > thr) : true;
-    if (!keep) return;
-    double2 o; o.x = re; o.y = im;
-    // (heads[pos] is not updated: the output stage walks the bitmap, not the head flags)
-    u32 first;
-    if (PACKED) { const u64 k = pk[pos]; first = L.o(k) * Ni + L.i(k); }
-    else first = idx[pos];
-    atomicOr(&markbits[first >> 5], 1u << (first & 31u));
-    reinterpret_cast<double2 *>(sum_of)[first] = o;                // the sum, filed under the input index of the term's first occurrence
-}
-
-template <bool PACKED>
-__global__ __launch_bounds__(256) void k_segsum_heads(uint8_t *__restrict__ heads, const u32 *__restrict__ idx, const u64 *__restrict__ pk, i64 T,
-                                                       double *__restrict__ cg, double thr, int use_thr, u32 *__restrict__ markbits, PackedLayout L,
-                                                       u32 Ni, i64 chunks_per_wave, double *__restrict__ sum_of) {
-    const int lane = threadIdx.x & 63;
-    const i64 n_chunks = (T + 63) / 64;
-    const i64 c0 = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * chunks_per_wave;
-    if (c0 >= n_chunks) return;
-    const i64 c1 = c0 + chunks_per_wave < n_chunks ? c0 + chunks_per_wave : n_chunks;
-    bool open = false;                  // wave-uniform: a segment is carried across chunk boundaries
-    double are = 0.0, aim = 0.0;        // its running sum
-    i64 apos = 0;                       // position of its head
-    for (i64 chunk = c0;; ++chunk) {
-        if (chunk >= c1 && !open) break;
-        if (chunk >= n_chunks) {        // the carried segment ends with the data
-            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni, sum_of);
-            break;
-        }
-        const i64 s = chunk * 64 + lane;
-        const bool valid = s < T;
-        const u32 h = valid ? heads[s] : 1u;                      // positions past the end act as heads: they end every run
-        double2 c; c.x = 0.0; c.y = 0.0;
-        if (valid) c = reinterpret_cast<const double2 *>(cg)[s];
-        const u64 m = __ballot(h != 0u);
-        const int lead = m ? __builtin_ctzll(m) : 64;             // leading non-head lanes continue the carried segment
-        if (open) {
-            for (int k = 0; k < lead; ++k) {
-                are = __dadd_rn(are, __shfl(c.x, k));
-                aim = __dadd_rn(aim, __shfl(c.y, k));
-            }
-        }
-        if (m == 0ULL) continue;                                  // no head in this chunk
-        if (open) {
-            if (lane == 0) segment_close<PACKED>(apos, are, aim, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni, sum_of);
-            open = false;
-        }
-        if (chunk >= c1) break;                                   // beyond the own range only the carry had to be closed
-        const bool is_head = valid && h != 0u;
-        const u64 above = lane == 63 ? 0ULL : (m >> (lane + 1));
-        const int run = above ? __builtin_ctzll(above) : 63 - lane;   // non-head lanes that follow this lane in the chunk
-        double re = __dadd_rn(0.0, c.x), im = __dadd_rn(0.0, c.y);
-        for (int k = 1; __ballot(is_head && k <= run); ++k) {
-            const double vx = __shfl_down(c.x, k), vy = __shfl_down(c.y, k);
-            if (is_head && k <= run) {
-                re = __dadd_rn(re, vx);
-                im = __dadd_rn(im, vy);
-            }
-        }
-        // the last head of a full chunk may continue in the next chunk: carry it; everything else closes here
-        const int last = 63 - __builtin_clzll(m);
-        const bool carry = (chunk * 64 + 64 <= T) && true;       // a full chunk: lane `last` is a real head whose run reaches lane 63
-        if (is_head && !(carry && lane == last)) segment_close<PACKED>(s, re, im, heads, idx, pk, cg, thr, use_thr, markbits, L, Ni, sum_of);
-        if (carry) {
-            open = true;
-            are = __shfl(re, last);
-            aim = __shfl(im, last);
-            apos = chunk * 64 + last;
-        }
-    }
-}
-
 __global__ void k_popc_words(const u32 *__restrict__ bits, i64 n_words, u32 *__restrict__ counts) {
     for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (i64)gridDim.x * blockDim.x) counts[w] = (u32)__popc(bits[w]);
 }
@@ -376,7 +359,7 @@ __global__ void k_popc_words(const u32 *__restrict__ bits, i64 n_words, u32 *__r
 // output order: a wavefront takes 64 bitmap words (2048 input indices), expands their set bits into a compact list in LDS
 // (output slot of the k-th one = word prefix + k), and lane groups then write coefficient and row of every kept term to its
 // slot — consecutive slots, so the stores are contiguous.  The only random accesses left are the 4-byte look-up of the
-// term's sorted position (written by k_segsum_heads) and the 16-byte read of its summed coefficient.
+// 16-byte read of the term's summed coefficient (filed under its input index by k_heads_sums).
 template <bool PAIR>
 __global__ __launch_bounds__(256) void k_emit_rows(const u32 *__restrict__ markbits, const u32 *__restrict__ wordprefix, i64 n_words,
                                                     const double *__restrict__ sum_of, int Wq, int wpw,
@@ -457,26 +440,13 @@ int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
     return SYMGPU_OK;
 }
 
-int cleanup_finish(uint8_t *heads, const u32 *is, const u64 *pk, bool packed, PackedLayout L, i64 T, double *cg, double thr, int use_thr, bool pair,
-                   const u64 *rows, int W, const u64 *inner, i64 Ni, const u64 *outer, symgpu_op_t *out, int Wq_out) {
+int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, const u64 *rows, int W, const u64 *inner, i64 Ni,
+                   const u64 *outer, symgpu_op_t *out, int Wq_out) {
     hipStream_t st = ctx().stream;
     const i64 n_words = (T + 31) / 32;
-    Scratch markbits, wordprefix, sum_of;
-    SG_TRY(sum_of.alloc((size_t)T * 16));                           // summed coefficient of a kept term, indexed by its first input index
-    SG_TRY(markbits.alloc((size_t)n_words * 4));
+    Scratch wordprefix;
     SG_TRY(wordprefix.alloc((size_t)n_words * 4));
-    HIP_TRY(hipMemsetAsync(markbits.p, 0, (size_t)n_words * 4, st));
-    {
-        const i64 n_chunks = (T + 63) / 64;
-        const i64 cpw = (n_chunks + 32767) / 32768;               // ~32k wavefronts, each on a contiguous range of chunks
-        const i64 n_waves = (n_chunks + cpw - 1) / cpw;
-        const dim3 gs((unsigned)((n_waves + 3) / 4));
-        if (packed)
-            hipLaunchKernelGGL(k_segsum_heads<true>, gs, dim3(256), 0, st, heads, is, pk, T, cg, thr, use_thr, markbits.as<u32>(), L, (u32)Ni, cpw, sum_of.as<double>());
-        else
-            hipLaunchKernelGGL(k_segsum_heads<false>, gs, dim3(256), 0, st, heads, is, pk, T, cg, thr, use_thr, markbits.as<u32>(), L, 1u, cpw, sum_of.as<double>());
-    }
-    hipLaunchKernelGGL(k_popc_words, dim3(grid_for(n_words)), dim3(256), 0, st, markbits.as<u32>(), n_words, wordprefix.as<u32>());
+    hipLaunchKernelGGL(k_popc_words, dim3(grid_for(n_words)), dim3(256), 0, st, markbits_p, n_words, wordprefix.as<u32>());
     KERNEL_CHECK();
     Scratch total;
     SG_TRY(total.alloc(16));
@@ -497,10 +467,10 @@ int cleanup_finish(uint8_t *heads, const u32 *is, const u64 *pk, bool packed, Pa
         const u32x4 *pin = reinterpret_cast<const u32x4 *>(inner), *pout = reinterpret_cast<const u32x4 *>(outer);
         u32x4 *dst = reinterpret_cast<u32x4 *>(res->rows);
         if (pair)
-            hipLaunchKernelGGL(k_emit_rows<true>, dim3((unsigned)ge), dim3(256), 0, st, markbits.as<u32>(), wordprefix.as<u32>(), n_words, sum_of.as<double>(), Wq, wpw,
+            hipLaunchKernelGGL(k_emit_rows<true>, dim3((unsigned)ge), dim3(256), 0, st, markbits_p, wordprefix.as<u32>(), n_words, sum_of_p, Wq, wpw,
                                (const u32x4 *)nullptr, pin, (u32)Ni, pout, dst, res->coeff);
         else
-            hipLaunchKernelGGL(k_emit_rows<false>, dim3((unsigned)ge), dim3(256), 0, st, markbits.as<u32>(), wordprefix.as<u32>(), n_words, sum_of.as<double>(), Wq, wpw,
+            hipLaunchKernelGGL(k_emit_rows<false>, dim3((unsigned)ge), dim3(256), 0, st, markbits_p, wordprefix.as<u32>(), n_words, sum_of_p, Wq, wpw,
                                reinterpret_cast<const u32x4 *>(rows), (const u32x4 *)nullptr, 1u, (const u32x4 *)nullptr, dst, res->coeff);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);   // the scratch buffers are freed on return; keep ordering simple
@@ -538,12 +508,13 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         const char *e = getenv("SYMGPU_CLEANUP_UNPACKED");
         if (e && e[0] == '1') packed = false;
     }
-    Scratch keys, keys2, idx, idx2, heads, collision, cg, hI, hO, pair_coeff;
+    Scratch keys, keys2, idx, idx2, heads, collision, hI, hO, pair_coeff, markbits, sum_of;
     SG_TRY(keys.alloc((size_t)T * 8));
     SG_TRY(keys2.alloc((size_t)T * 8));
-    SG_TRY(heads.alloc((size_t)T));                                 // one byte per sorted position: 0 continuation, 1 head, 2 kept head
+    SG_TRY(heads.alloc((size_t)T));                                 // run-start markers of the truncated-sort fix-up
+    SG_TRY(markbits.alloc((size_t)((T + 31) / 32) * 4));            // kept terms by first input index (one bit each)
+    SG_TRY(sum_of.alloc((size_t)T * 16));                           // their summed coefficients, indexed the same way
     SG_TRY(collision.alloc(16));
-    SG_TRY(cg.alloc((size_t)T * 16));
     if (pair) {
         SG_TRY(hI.alloc((size_t)Ni * 8));
         SG_TRY(hO.alloc((size_t)No * 8));
@@ -599,7 +570,6 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         is = packed ? nullptr : (in_tmp ? idx2.as<u32>() : idx.as<u32>());
         HIP_TRY(hipMemsetAsync(collision.p, 0, 16, st));
         if (nbits < 64) {
-            // `heads` doubles as the run-start marker array here (it is overwritten by k_heads afterwards)
             HIP_TRY(hipMemsetAsync(heads.p, 0, (size_t)T, st));
             if (packed) {
                 hipLaunchKernelGGL(k_fixup_mark<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<uint8_t>(), hI.as<u64>(), hO.as<u64>(), L, inner == outer);
@@ -616,19 +586,22 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         {
             int G = 1;                                   // lanes per verified candidate: one 16-byte chunk each
             while (G < W / 2 && G < 64) G <<= 1;
-            i64 gh = ((T + 63) / 64 + 3) / 4;
-            if (gh > 16384) gh = 16384;
+            const i64 n_chunks = (T + 63) / 64;
+            const i64 cpw = (n_chunks + 32767) / 32768;           // ~32k wavefronts, each on a contiguous range of chunks
+            const i64 n_waves = (n_chunks + cpw - 1) / cpw;
+            const dim3 gs((unsigned)((n_waves + 3) / 4));
             const u64 *nul = nullptr;
             const double *nud = nullptr;
+            HIP_TRY(hipMemsetAsync(markbits.p, 0, (size_t)((T + 31) / 32) * 4, st));
             if (packed)
-                hipLaunchKernelGGL((k_heads<true, true>), dim3((unsigned)gh), dim3(256), 0, st, ks, (const u32 *)nullptr, T, nul, W, inner, (u32)Ni, outer, G,
-                                   nud, cg.as<double>(), heads.as<uint8_t>(), collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), L, ci, co);
+                hipLaunchKernelGGL((k_heads_sums<true, true>), gs, dim3(256), 0, st, ks, (const u32 *)nullptr, T, nul, W, inner, (u32)Ni, outer, G, nud,
+                                   collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), L, ci, co, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw);
             else if (pair)
-                hipLaunchKernelGGL((k_heads<true, false>), dim3((unsigned)gh), dim3(256), 0, st, ks, is, T, nul, W, inner, (u32)Ni, outer, G,
-                                   coeff, cg.as<double>(), heads.as<uint8_t>(), collision.as<u32>(), nul, nul, L, nud, nud);
+                hipLaunchKernelGGL((k_heads_sums<true, false>), gs, dim3(256), 0, st, ks, is, T, nul, W, inner, (u32)Ni, outer, G, coeff,
+                                   collision.as<u32>(), nul, nul, L, nud, nud, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw);
             else
-                hipLaunchKernelGGL((k_heads<false, false>), dim3((unsigned)gh), dim3(256), 0, st, ks, is, T, rows, W, nul, 1u, nul, G,
-                                   coeff, cg.as<double>(), heads.as<uint8_t>(), collision.as<u32>(), nul, nul, L, nud, nud);
+                hipLaunchKernelGGL((k_heads_sums<false, false>), gs, dim3(256), 0, st, ks, is, T, rows, W, nul, 1u, nul, G, coeff,
+                                   collision.as<u32>(), nul, nul, L, nud, nud, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw);
         }
         KERNEL_CHECK();
         u32 hflags[2] = {0, 0};
@@ -642,7 +615,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         set_error("cleanup: 64-bit row-hash collision survived 4 reseeds");
         return SYMGPU_E_COLLISION;
     }
-    return cleanup_finish(heads.as<uint8_t>(), is, ks, packed, L, T, cg.as<double>(), thr, use_thr, pair, rows, W, inner, Ni, outer, out, Wq_out);
+    return cleanup_finish(markbits.as<u32>(), sum_of.as<double>(), T, pair, rows, W, inner, Ni, outer, out, Wq_out);
 }
 
 }  // namespace symgpu
