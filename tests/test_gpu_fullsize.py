@@ -1,6 +1,6 @@
 """GPU: BASELINE.json's full sizes, checked through size-independent properties (round trips, linearity checksums,
 cross-kernel consistency) plus exact oracle comparison on sub-blocks the C oracle finishes in seconds."""
-import ctypes
+import ctypes, os
 import numpy as np
 import pytest
 from symmer_amd import PauliwordOp, IndependentOp, kernels, packing, _lib
@@ -140,3 +140,24 @@ def test_cfg5_adjacency_slice_full_width():
     assert s_bytes.value == int(out.sum()) == s_bits.value
     assert 0.45 < s_bytes.value / (rows * N) < 0.55
     _lib.check(lib.symgpu_dev_free(buf)); _lib.check(lib.symgpu_dev_free(bits)); A.free()
+
+
+def test_bench_line_schema_small_workload():
+    """bench.py prints ONE JSON line with the contract's keys (tiny workload; the roofline / cpu objects are present)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--left-terms', '4000',
+                          '--right-terms', '3000', '--qubits', '200', '--no-extras', '--no-cpu'], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+                'config', 'roofline'):
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True and d['value'] > 0
+    assert d['config']['workload'] == 'allpairs_product' and d['config']['pairs_per_step'] == 4000 * 3000
+    r = d['roofline']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert key in r, key
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
