@@ -144,11 +144,22 @@ def test_cfg5_adjacency_slice_full_width():
 
 def test_bench_line_schema_small_workload():
     """bench.py prints ONE JSON line with the contract's keys (tiny workload; the roofline / cpu objects are present)."""
-    import json, subprocess, sys
+    import json, sys, io, contextlib, importlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--left-terms', '4000',
-                          '--right-terms', '3000', '--qubits', '200', '--no-extras', '--no-cpu'], capture_output=True, text=True, timeout=600, cwd=root)
-    assert out.returncode == 0, out.stderr[-2000:]
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    argv, buf = sys.argv, io.StringIO()
+    sys.argv = ['bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1', '--left-terms', '4000', '--right-terms', '3000', '--qubits', '200',
+                '--no-extras', '--no-cpu']
+    try:
+        with contextlib.redirect_stdout(buf):                      # in-process: no exec from a process that holds the GPU
+            bench.main()
+    finally:
+        sys.argv = argv
+
+    class out:                                                      # same shape as a CompletedProcess for the checks below
+        stdout = buf.getvalue()
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
     d = json.loads(lines[0])
