@@ -132,6 +132,27 @@ class _TcpControl:
         self.peers = []
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on file descriptor 1 when a communicator is created; callers such as bench.py promise ONE
+    JSON line on stdout, so the C-level stdout is pointed at stderr while RCCL initialises."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            ctypes.CDLL(None).fflush(None)                          # the banner sits in the C stdio buffer: flush it while redirected
+        except Exception:
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 class Communicator:
     def __init__(self, rank=0, world=1, data_plane='none'):
         self.rank, self.world, self.data_plane = rank, world, data_plane
@@ -184,7 +205,8 @@ class Communicator:
         raw = (ctypes.c_uint8 * 128)()
         if self.rank == 0:
             try:
-                _lib.check(_lib.lib().symgpu_comm_unique_id(ctypes.addressof(raw)))
+                with _stdout_to_stderr():
+                    _lib.check(_lib.lib().symgpu_comm_unique_id(ctypes.addressof(raw)))
             except Exception as exc:                              # librccl missing / not loadable: broadcast an all-zero id
                 self.rccl_error = str(exc)
                 raw = (ctypes.c_uint8 * 128)()
@@ -194,7 +216,8 @@ class Communicator:
         else:
             try:
                 raw = (ctypes.c_uint8 * 128)(*ident)
-                _lib.check(_lib.lib().symgpu_comm_init(ctypes.addressof(raw), self.rank, self.world))
+                with _stdout_to_stderr():
+                    _lib.check(_lib.lib().symgpu_comm_init(ctypes.addressof(raw), self.rank, self.world))
             except Exception as exc:
                 self.rccl_error = str(exc)
         if self.max_over_ranks(1.0 if self.rccl_error else 0.0) > 0.0:
