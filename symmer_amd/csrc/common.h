@@ -99,8 +99,6 @@ int to_wordmajor(const u64 *rows, i64 T, int W, u64 *out, i64 Tpad, hipStream_t 
 // cached word-major copy of a whole operator (padded to a multiple of `mult` terms); built on the main stream
 int op_wordmajor(symgpu_op_s *op, i64 mult, const u64 **out, i64 *pad);
 void op_invalidate(symgpu_op_s *op);
-// bit-matrix transpose: in R rows x Wc words -> out (64*Wc rows) x ceil(R/64) words, only first C rows written
-int bit_transpose(const u64 *in, i64 R, i64 Wc_in, u64 *out, i64 Wc_out);
 
 // sort.hip
 int exclusive_scan_u32(const u32 *in, u32 *out, i64 n, u32 *total_dev /* may be null: device u32 */);
@@ -111,6 +109,8 @@ int radix_sort_keys_u64(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_
 // commute.hip
 int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits);
 int ycount_dev(const u64 *rows, i64 T, int Wq, int *out);
+// commute_m4r.hip — the same contract on the Four-Russians kernel (LDS tables)
+int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits);
 
 // product.hip
 // ---- shared device helpers ----------------------------------------------------------------------

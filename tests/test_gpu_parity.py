@@ -496,6 +496,49 @@ def test_commutes_bit_packed_output(n, N, M):
     _lib.check(lib.symgpu_dev_free(bits)); A.free(); B.free()
 
 
+@pytest.mark.parametrize('force', ['1', '0'])
+@pytest.mark.parametrize('n,N,M,dens', [(1000, 3000, 2500, 0.3), (2000, 700, 4100, 0.3), (100, 513, 257, 0.3), (1, 70, 300, 0.5),
+                                        (64, 1, 1000, 0.3), (4097, 40, 33, 0.3), (130, 1300, 2049, 0.01), (65, 2600, 64, 0.3),
+                                        (300, 1, 1, 0.3), (257, 1281, 2048, 0.3)])
+def test_commutes_both_kernels(n, N, M, dens, force, monkeypatch):
+    """The Four-Russians kernel (commute_m4r.hip: LDS tables, SYMGPU_COMMUTE_M4R=1) and the register-tile kernel (=0) on
+    the same ragged shapes — row counts around the 512/768/1280-row workgroup tiles, column counts around the 2048-column
+    tile and the 64-bit word, a sparse operand (most k-blocks skipped), N = 1 and M = 1 — bytes and bit-packed output."""
+    import ctypes
+    from symmer_amd import _lib
+    from symmer_amd.kernels import DeviceOp
+    monkeypatch.setenv('SYMGPU_COMMUTE_M4R', force)
+    rng = np.random.default_rng(300 + n + N)
+    a = packing.pack_rows(rng.random((N, 2 * n)) < dens); b = packing.pack_rows(rng.random((M, 2 * n)) < dens)
+    expect = oc.commutes(a, b)
+    assert np.array_equal(kernels.commutes(a, b), expect)
+    assert np.array_equal(kernels.commutes(a, a), oc.commutes(a, a))
+    # row range of a device operand + bit-packed output
+    A, B = DeviceOp.upload(a), DeviceOp.upload(b)
+    lo, hi = N // 3, N
+    words = (M + 63) // 64
+    lib = _lib.lib()
+    bits = ctypes.c_void_p()
+    _lib.check(lib.symgpu_dev_alloc(max(1, (hi - lo) * words * 8), ctypes.byref(bits)))
+    junk = np.full((hi - lo) * words, 0xFFFFFFFFFFFFFFFF, dtype='<u8')
+    _lib.check(lib.symgpu_dev_upload(bits, junk.ctypes.data, junk.nbytes))
+    _lib.check(lib.symgpu_commutes_bits_dev(A.handle, lo, hi, B.handle, bits))
+    out = np.empty((hi - lo, words), dtype='<u8')
+    _lib.check(lib.symgpu_dev_download(bits, out.ctypes.data, out.nbytes))
+    assert np.array_equal(out, packing.pack_bits(expect[lo:hi], words))
+    _lib.check(lib.symgpu_dev_free(bits)); A.free(); B.free()
+
+
+@pytest.mark.parametrize('r', ['16', '24', '40', '48', '116'])
+def test_commutes_m4r_tile_heights(r, monkeypatch):
+    """Every instantiation of the Four-Russians kernel (rows per 16-lane slot) on a shape that leaves partial row and column tiles."""
+    monkeypatch.setenv('SYMGPU_COMMUTE_M4R', '1'); monkeypatch.setenv('SYMGPU_M4R_R', r)
+    rng = np.random.default_rng(77)
+    n, N, M = 200, 1500, 4200
+    a = packing.pack_rows(rng.random((N, 2 * n)) < 0.3); b = packing.pack_rows(rng.random((M, 2 * n)) < 0.3)
+    assert np.array_equal(kernels.commutes(a, b), oc.commutes(a, b))
+
+
 @pytest.mark.parametrize('case', family('jordan'))
 def test_jordan_and_reindex_golden(case):
     """check_jordan_independent / reindex / jordan_generator_reconstruction against outputs of the reference."""
