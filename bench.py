@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+TRAFFIC_PROFILE = 'r02_traffic.json'   # written by tools/pmc_product.sh from the rocprofv3 --pmc passes of this bench
 
 
 def parse():
@@ -64,7 +65,7 @@ def main():
 
     _lib.init(local_rank)
     lib = _lib.lib()
-    comm = parallel.Communicator.from_env()       # gloo control plane + RCCL data plane when world > 1
+    comm = parallel.Communicator.from_env()       # TCP control plane + RCCL data plane when world > 1
 
     n, Ni, M = args.qubits, args.left_terms, args.right_terms
     wq = (n + 63) // 64
@@ -73,13 +74,13 @@ def main():
     Ts = (M + world - 1) // world
     my_rows = max(0, min(Ts, M - rank * Ts))
     if comm.gathers:
+        # the step all-gathers the right operand: RCCL over xGMI, or — if RCCL could not be brought up on every rank — the
+        # same exchange staged through host memory (comm.degraded says so and the JSON line carries it).  There is no
+        # silent "every rank generates everything" mode: a step without the exchange would not be the benchmark.
         shard = parallel.padded_random_shard(my_rows, Ts, n, 99991 + rank)
         right = DeviceOp.alloc(Ts * world, wq, with_coeff=True)
-    elif world > 1:
-        # RCCL could not be initialised (comm.rccl_error): every rank generates the whole right operand itself, so the
-        # per-GPU work is unchanged but the step has no all-gather; reported in config.parallelism
-        shard = right = DeviceOp.random(M, n, 0.3, seed=99991)
     else:
+        assert world == 1, 'multi-rank run without a data plane'
         shard = right = DeviceOp.random(my_rows, n, 0.3, seed=99991 + rank)
     slab = max(1, min(args.slab_rows, M))
     ring = [DeviceOp.alloc(slab * Ni, wq, with_coeff=True) for _ in range(2)]
@@ -126,14 +127,15 @@ def main():
         'vs_baseline': None, 'dtype': 'u64', 'data': 'synthetic',
         'config': {'workload': 'allpairs_product', 'n_qubits': n, 'left_terms_per_gpu': Ni, 'right_terms': M,
                    'pairs_per_step': world * pairs_per_step_rank, 'bytes_per_pair': 16 * wq + 16, 'slab_rows': slab,
-                   'parallelism': (f'left-axis shard x{world}, RCCL all-gather of right rows' if comm.gathers else
-                                   f'left-axis shard x{world}, right operand replicated (RCCL unavailable: {comm.rccl_error})') if world > 1 else 'single GPU'},
+                   'parallelism': (f'left-axis shard x{world}, all-gather of right rows ({comm.data_plane})' if world > 1 else 'single GPU')},
         'roofline': {'bound': 'hbm', 'kernel': 'k_mul_rows', 'bytes_per_pair': per_pair,
                      'note': 'k_mul_coeff (16 B/pair) runs concurrently on a side stream; incl. its bytes: %.0f GB/s' % (achieved * (16 * wq + 16) / (16 * wq)), 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'launches': n_launch.value, 'avg_launch_ms': launch_ms,
                      'algorithmic_bytes_per_launch': algo_bytes_launch,
                      'whole_step_GBps': pairs_per_step_rank * (16 * wq + 16) / (dt / args.steps) / 1e9},
     }
+    if comm.degraded:
+        out['degraded'] = comm.degraded          # top-level flag: the all-gather did not run over RCCL/xGMI
     # the same kernel WITHOUT the concurrent coefficient kernel (rows-only output slab), outside the timed region
     if rank == 0:
         rows_only = DeviceOp.alloc(slab * Ni, wq, with_coeff=False)
@@ -158,16 +160,25 @@ def main():
         out['roofline']['measured_fill_ceiling_GBps'] = fill.value
         out['roofline']['measured_copy_ceiling_GBps'] = cp.value
         out['roofline']['frac_of_measured_fill_ceiling'] = achieved / fill.value if fill.value else None
-    # HBM traffic of the dominant kernel from the committed PMC profile (counters cannot be read from inside this process)
+    # HBM traffic of the dominant kernel: hardware counters cannot be read from inside this process, so the figure comes from
+    # the committed rocprofv3 --pmc profile of THIS workload — and only if that profile was taken on the kernel source that
+    # is running now (sha256 of product.hip recorded next to it); otherwise traffic stays null.
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01e_traffic.json')) as f:
+        import hashlib
+        with open(os.path.join(ROOT, 'profiles', TRAFFIC_PROFILE)) as f:
             tr = json.load(f)
+        with open(os.path.join(ROOT, 'symmer_amd', 'csrc', 'product.hip'), 'rb') as f:
+            src = hashlib.sha256(f.read()).hexdigest()
         cfg = tr['config']
-        if (cfg['n_qubits'], cfg['left_terms_per_gpu'], cfg['right_terms'], cfg['slab_rows']) == (n, Ni, M, slab):
+        same_cfg = (cfg['n_qubits'], cfg['left_terms_per_gpu'], cfg['right_terms'], cfg['slab_rows']) == (n, Ni, M, slab)
+        if same_cfg and tr.get('kernel_source_sha256') == src:
             out['roofline']['traffic'] = tr['write_bytes_per_launch'] + tr['fetch_bytes_per_launch_corrected_x2']
-            out['roofline']['traffic_source'] = 'profiles/r01e_traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes)'
-    except Exception:
-        pass
+            out['roofline']['traffic_source'] = f'profiles/{TRAFFIC_PROFILE} (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes, same product.hip)'
+        else:
+            out['roofline']['traffic_source'] = (f'null: profiles/{TRAFFIC_PROFILE} was taken on a different ' +
+                                                 ('workload' if not same_cfg else 'revision of product.hip'))
+    except (OSError, KeyError, ValueError) as exc:
+        out['roofline']['traffic_source'] = f'null: no usable traffic profile ({type(exc).__name__})'
     for r in ring:
         r.free()
 

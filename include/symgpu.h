@@ -64,6 +64,9 @@ int symgpu_op_download(symgpu_op_t op, uint64_t *rows, double *coeff /* may be N
 int symgpu_op_info(symgpu_op_t op, int64_t *T, int *Wq, int64_t *capacity_rows);
 int symgpu_op_free(symgpu_op_t op);
 int symgpu_op_set_rows(symgpu_op_t op, int64_t T);   /* trim (T <= capacity), e.g. after an all-gather with padding */
+/* host rows (+ coefficients if both sides have them) -> rows [row_offset, row_offset + count) of an existing operator
+ * (within its capacity; T grows to cover them).  Used by the host-staged all-gather. */
+int symgpu_op_write(symgpu_op_t op, int64_t row_offset, const uint64_t *rows, const double *coeff /* may be NULL */, int64_t count);
 int symgpu_op_random(int64_t T, int n_qubits, double density, uint64_t seed, symgpu_op_t *out); /* synthetic input, generated on device */
 /* XOR-fold of all packed rows (2*Wq words) and plain sum of coefficients: size-independent checksums */
 int symgpu_op_checksum(symgpu_op_t op, uint64_t *xor_words /* [2*Wq] */, double *coeff_sum /* [2] */);
@@ -137,6 +140,7 @@ int symgpu_symmetry_kernel_dev(symgpu_op_t H, int n_qubits, uint64_t *out, int64
 
 /* ---- e: multi-GPU (one process per GPU; RCCL over xGMI) ------------------------------------------- */
 #define SYMGPU_UNIQUE_ID_BYTES 128
+int symgpu_comm_available(void);                                                /* librccl loadable? (no device, no collective) */
 int symgpu_comm_unique_id(uint8_t id[SYMGPU_UNIQUE_ID_BYTES]);                 /* rank 0 */
 int symgpu_comm_init(const uint8_t id[SYMGPU_UNIQUE_ID_BYTES], int rank, int nranks);
 int symgpu_comm_destroy(void);

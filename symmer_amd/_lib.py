@@ -46,6 +46,7 @@ SIGNATURES = {
     'symgpu_op_info': [P, P, P, P],
     'symgpu_op_free': [P],
     'symgpu_op_set_rows': [P, c_i64],
+    'symgpu_op_write': [P, c_i64, P, P, c_i64],
     'symgpu_op_random': [c_i64, c_int, c_dbl, c_u64, PP],
     'symgpu_op_checksum': [P, P, P],
     'symgpu_ycount': [P, c_i64, c_int, P],
@@ -70,6 +71,7 @@ SIGNATURES = {
     'symgpu_rref_dev': [P, c_i64, c_i64, P, P],
     'symgpu_symmetry_kernel': [P, c_i64, c_int, c_int, P, c_i64, P, P],
     'symgpu_symmetry_kernel_dev': [P, c_int, P, c_i64, P, P],
+    'symgpu_comm_available': [],
     'symgpu_comm_unique_id': [P],
     'symgpu_comm_init': [P, c_int, c_int],
     'symgpu_comm_destroy': [],

@@ -72,6 +72,12 @@ using namespace symgpu;
 
 extern "C" {
 
+int symgpu_comm_available(void) {
+    // no device needed: only resolves librccl and its entry points, so that every rank can report BEFORE any of them enters the
+    // collective ncclCommInitRank (a rank that cannot load the library would leave its peers blocked in there)
+    return load_rccl();
+}
+
 int symgpu_comm_unique_id(uint8_t id[SYMGPU_UNIQUE_ID_BYTES]) {
     SG_REQUIRE(id, "comm_unique_id");
     SG_TRY(load_rccl());

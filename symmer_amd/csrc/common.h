@@ -111,6 +111,7 @@ int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out,
 int ycount_dev(const u64 *rows, i64 T, int Wq, int *out);
 // commute_m4r.hip — the same contract on the Four-Russians kernel (LDS tables)
 int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits);
+bool commutes_m4r_worthwhile(i64 N, i64 M);
 
 // product.hip
 // ---- shared device helpers ----------------------------------------------------------------------

@@ -145,14 +145,14 @@ static i64 round_up(i64 x, i64 m) { return (x + m - 1) / m * m; }
 // A: N rows, B: M rows, row-major packed device pointers.  Exactly one of out / out_bits is non-null.
 // Which kernel: the Four-Russians kernel (commute_m4r.hip) does 1/16 of the VALU work per pair but pays a fixed price per
 // workgroup (operand transposes, 64 KiB table per k-block shared by >= 512 rows), so it needs enough rows and columns to fill
-// its 512..1536 x 2048 tiles; the register-tile kernel below serves everything smaller.  SYMGPU_COMMUTE_M4R=1 / 0 forces
+// the chip with its 512..1536 x 2048 tiles; the register-tile kernel below serves everything smaller.  SYMGPU_COMMUTE_M4R=1 / 0 forces
 // one or the other (the tests run both on every case).
 static bool use_m4r(i64 N, i64 M, int Wq) {
     if (const char *e = getenv("SYMGPU_COMMUTE_M4R")) {
         if (e[0] == '1') return true;
         if (e[0] == '0') return false;
     }
-    return N >= 512 && M >= 2048 && Wq >= 2 && (double)N * (double)M >= 16.0e6;
+    return commutes_m4r_worthwhile(N, M);
 }
 
 int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits) {

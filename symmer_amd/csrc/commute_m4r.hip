@@ -99,10 +99,14 @@ __global__ __launch_bounds__(256) void k_m4r_bt(const u64 *__restrict__ rows, i6
 
 // ---- main kernel ---------------------------------------------------------------------------------------------------
 // R = rows per 16-lane slot, WAVES = waves per workgroup (8: 256 VGPRs each, 16: 128), LOOK = ds_read_b128 in flight per wave
-template <int R, int WAVES, int LOOK>
+// BYTES: the epilogue expands the result bits to np.bool_ bytes itself (out_bits is then the uint8 output, out_stride = M,
+// M % 16 == 0 and a 16-byte aligned base); otherwise it stores bit-packed rows.
+template <int R, int WAVES, int LOOK, bool BYTES>
 __global__ __launch_bounds__(64 * WAVES) void k_commutes_m4r(const uint8_t *__restrict__ A8, i64 Npad, i64 N, const u64 *__restrict__ BT, i64 Mw_pad,
                                                               int Wq, const u32 *__restrict__ klist, const u32 *__restrict__ nk_ptr,
-                                                              u64 *__restrict__ out_bits, i64 out_stride, i64 Mw, u64 last_mask, int dbg) {
+                                                              u64 *__restrict__ out_bits, i64 out_stride, i64 m_cols, int dbg) {
+    // out_bits / out_stride: output base at this launch's first column and row stride (u64 words, or bytes if BYTES);
+    // m_cols: valid columns from there
     static_assert(R % 8 == 0, "indices arrive as dwordx2 = 8 rows");
     extern __shared__ __attribute__((aligned(16))) uint8_t m4r_lds[];
     const int lane = threadIdx.x & 63;
@@ -232,18 +236,59 @@ __global__ __launch_bounds__(64 * WAVES) void k_commutes_m4r(const uint8_t *__re
         }
     }
 
-    // commute = NOT parity; columns >= M stay zero
+    if constexpr (BYTES) {
+        // One byte per pair, 16-byte stores, a wave store = 1 KiB of one output row.  A lane holds 128 result bits of a row but
+        // must write 16 columns of it: the rows are turned round through the (now free) table area, 128 KiB / WAVES per wave =
+        // 4 * RP rows x 2048 bits per pass.
+        uint8_t *const out = reinterpret_cast<uint8_t *>(out_bits);
+        constexpr int RP = 128 / WAVES;                              // rows per slot and pass: WAVES x 4 RP x 256 B = 128 KiB
+        uint8_t *const region = m4r_lds + wave * (4 * RP * MK_ENTRY_BYTES);
+        const i64 wave_row0 = (i64)blockIdx.x * WG_ROWS + (i64)wave * (4 * R);
+        __syncthreads();                                             // every wave is done with the tables
 #pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const i64 i = row0 + j;
-        if (i < N) {
+        for (int p0 = 0; p0 < R; p0 += RP) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const i64 jw = tile_w0 + 2 * wp + h;
-                if (jw < Mw) {
-                    u64 v = ~acc[j][h];
-                    if (jw == Mw - 1) v &= last_mask;
-                    out_bits[i * out_stride + jw] = v;
+            for (int jj = 0; jj < RP; ++jj) {
+                if (p0 + jj < R) {
+                    const u64x2 v = {~acc[p0 + jj][0], ~acc[p0 + jj][1]};                       // commute = NOT parity
+                    *reinterpret_cast<u64x2 *>(region + (slot * RP + jj) * MK_ENTRY_BYTES + wp * 16) = v;
+                }
+            }
+            __syncthreads();
+            const int rows_here = (R - p0 < RP) ? R - p0 : RP;
+            for (int q = 0; q < 4 * rows_here * 2; ++q) {
+                const int half = q & 1, rl = q >> 1, s = rl / rows_here, jj = rl - s * rows_here;
+                const i64 i = wave_row0 + s * R + p0 + jj;
+                const i64 col = (tile_w0 << 6) + half * 1024 + lane * 16;           // m_cols % 16 == 0: whole chunks in or out
+                if (i < N && col < m_cols) {
+                    const u32 b16 = *reinterpret_cast<const uint16_t *>(region + (s * RP + jj) * MK_ENTRY_BYTES + half * 128 + lane * 2);
+                    u32x4 v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const u32 x = (b16 >> (4 * k)) & 0xFu;
+                        v[k] = (x | (x << 7) | (x << 14) | (x << 21)) & 0x01010101u;
+                    }
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out + i * out_stride + col));
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        // commute = NOT parity; columns >= M stay zero
+        const i64 Mw = (m_cols + 63) >> 6;
+        const u64 last_mask = (m_cols & 63) ? ((1ULL << (m_cols & 63)) - 1) : ~0ULL;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const i64 i = row0 + j;
+            if (i < N) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const i64 jw = tile_w0 + 2 * wp + h;
+                    if (jw < Mw) {
+                        u64 v = ~acc[j][h];
+                        if (jw == Mw - 1) v &= last_mask;
+                        out_bits[i * out_stride + jw] = v;
+                    }
                 }
             }
         }
@@ -277,48 +322,58 @@ __global__ __launch_bounds__(256) void k_bits_to_bytes(const u64 *__restrict__ b
 
 static i64 round_up_i64(i64 x, i64 m) { return (x + m - 1) / m * m; }
 
-template <int R, int WAVES, int LOOK>
-static int launch_m4r(const uint8_t *A8, i64 Npad, i64 N, const u64 *BT, i64 Mw_pad, int Wq, const u32 *klist, const u32 *nk, u64 *bits, i64 stride,
-                      i64 Mw, u64 last_mask) {
+template <int R, int WAVES, int LOOK, bool BYTES>
+static int launch_m4r(const uint8_t *A8, i64 Npad, i64 N, const u64 *BT, i64 Mw_pad, int Wq, const u32 *klist, const u32 *nk, void *out, i64 stride,
+                      i64 M) {
     const int dbg = getenv("SYMGPU_M4R_DBG") ? atoi(getenv("SYMGPU_M4R_DBG")) : 0;   // timing experiments only: 1 = no table build, 2 = no look-ups
     constexpr int lds = mk_lds_bytes(4 * WAVES * R);
-    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_commutes_m4r<R, WAVES, LOOK>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_commutes_m4r<R, WAVES, LOOK, BYTES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   lds) == hipSuccess;
     if (!attr) { set_error("commutes_m4r: %d bytes of LDS refused", lds); return SYMGPU_E_HIP; }
     const i64 gx = Npad / (4 * WAVES * R), gy = Mw_pad / MK_TILE_W;
     // blockIdx.x (fast) walks the row blocks: workgroups that run together share the BT column tile in L2
     for (i64 y0 = 0; y0 < gy; y0 += 65535) {
         const i64 ny = gy - y0 < 65535 ? gy - y0 : 65535;
-        hipLaunchKernelGGL((k_commutes_m4r<R, WAVES, LOOK>), dim3((unsigned)gx, (unsigned)ny), dim3(64 * WAVES), lds, ctx().stream, A8, Npad, N,
-                           BT + y0 * MK_TILE_W, Mw_pad, Wq, klist, nk, bits + y0 * MK_TILE_W, stride, Mw - y0 * MK_TILE_W, last_mask, dbg);
+        hipLaunchKernelGGL((k_commutes_m4r<R, WAVES, LOOK, BYTES>), dim3((unsigned)gx, (unsigned)ny), dim3(64 * WAVES), lds, ctx().stream, A8, Npad, N,
+                           BT + y0 * MK_TILE_W, Mw_pad, Wq, klist, nk,
+                           BYTES ? reinterpret_cast<u64 *>(static_cast<uint8_t *>(out) + y0 * MK_TILE_W * 64) : static_cast<u64 *>(out) + y0 * MK_TILE_W,
+                           stride, M - y0 * MK_TILE_W * 64, dbg);
         KERNEL_CHECK();
     }
     return SYMGPU_OK;
 }
 
-// tile variants: {rows per slot, waves} -> rows per workgroup = 4 * waves * R
+// tile variants: {rows per slot, waves} -> rows per workgroup = 4 * waves * R.  Taller tiles amortise the 64 KiB table over
+// more rows (cfg5 slice, n = 2000: R = 16 / 24 / 40 / 48 -> 9.8 / 7.8 / 6.2 / 5.8 ms) but need enough workgroups for 256 CUs.
 struct M4rVariant { int R, waves; };
-static M4rVariant m4r_pick(i64 N) {
+static i64 m4r_workgroups(i64 N, i64 M, int R) {
+    const i64 Mw = (M + 63) / 64;
+    return ((N + 32 * R - 1) / (32 * R)) * ((Mw + MK_TILE_W - 1) / MK_TILE_W);
+}
+static M4rVariant m4r_pick(i64 N, i64 M) {
     if (const char *e = getenv("SYMGPU_M4R_R")) {
         const int r = atoi(e);
         if (r == 16 || r == 24 || r == 40 || r == 48) return {r, 8};
-        if (r == 116) return {16, 16};
+        if (r == 116) return {16, 16};                               // 16 waves x 16 rows: measured slower than 8 x 40, kept for the tests
     }
-    if (N >= 2 * 32 * 40) return {40, 8};
-    if (N >= 32 * 24) return {24, 8};
+    const int cand[3] = {48, 40, 24};
+    for (int R : cand)
+        if (m4r_workgroups(N, M, R) >= 3 * ctx().num_cu) return {R, 8};
     return {16, 8};
 }
+// enough 512 x 2048 tiles to occupy most of the chip (below that the register-tile kernel wins: 1024 x 16384 at n = 2000 takes
+// 0.10 ms there and 0.6 ms here; 4096 x 65536: 1.03 ms against 0.66 ms)
+bool commutes_m4r_worthwhile(i64 N, i64 M) { return m4r_workgroups(N, M, 16) >= (3 * ctx().num_cu) / 4; }
 
 // Same contract as commutes_dev (commute.hip): exactly one of out / out_bits is non-null.
 int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits) {
     if (N == 0 || M == 0) return SYMGPU_OK;
     hipStream_t st = ctx().stream;
     const int W = 2 * Wq, nkb = 16 * Wq;
-    const M4rVariant var = m4r_pick(N);
+    const M4rVariant var = m4r_pick(N, M);
     const int R = var.R;
     const i64 Npad = round_up_i64(N, (i64)4 * var.waves * R);            // 512 .. 1280: multiples of 256
     const i64 Mw = (M + 63) / 64, Mw_pad = round_up_i64(Mw, MK_TILE_W);
-    const u64 last_mask = (M % 64) ? ((1ULL << (M % 64)) - 1) : ~0ULL;
     Scratch a8, bt, flags, klist, bits;
     SG_TRY(a8.alloc((size_t)nkb * Npad));
     SG_TRY(bt.alloc((size_t)64 * W * Mw_pad * 8));
@@ -332,29 +387,38 @@ int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *
     KERNEL_CHECK();
     hipLaunchKernelGGL(k_m4r_bt, dim3((unsigned)((Mw_pad / 8 + 3) / 4), (unsigned)W), dim3(256), 0, st, B, M, W, bt.as<u64>(), Mw_pad);
     KERNEL_CHECK();
-    u64 *dst_bits = out_bits;
+    // np.bool_ output: expanded by the kernel's own epilogue when rows can be written with aligned 16-byte stores, otherwise
+    // bit-packed rows to scratch + a separate expansion with byte stores
+    const bool fused_bytes = out && (M % 16 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && !getenv("SYMGPU_M4R_UNFUSED");
+    void *dst = out_bits;
     i64 stride = Mw;
-    if (!out_bits) {
+    if (fused_bytes) {
+        dst = out;
+        stride = M;
+    } else if (out) {
         SG_TRY(bits.alloc((size_t)N * Mw * 8));
-        dst_bits = bits.as<u64>();
+        dst = bits.p;
     }
     {
         ProfScope prof(1);
-#define M4R_ARGS a8.as<uint8_t>(), Npad, N, bt.as<u64>(), Mw_pad, Wq, klist.as<u32>(), nk, dst_bits, stride, Mw, last_mask
-        if (var.waves == 16) SG_TRY((launch_m4r<16, 16, 6>(M4R_ARGS)));
-        else if (R == 48) SG_TRY((launch_m4r<48, 8, 6>(M4R_ARGS)));
-        else if (R == 40) SG_TRY((launch_m4r<40, 8, 8>(M4R_ARGS)));
-        else if (R == 24) SG_TRY((launch_m4r<24, 8, 8>(M4R_ARGS)));
-        else SG_TRY((launch_m4r<16, 8, 8>(M4R_ARGS)));
+#define M4R_ARGS a8.as<uint8_t>(), Npad, N, bt.as<u64>(), Mw_pad, Wq, klist.as<u32>(), nk, dst, stride, M
+#define M4R_LAUNCH(BY)                                                        \
+        if (var.waves == 16) SG_TRY((launch_m4r<16, 16, 6, BY>(M4R_ARGS)));   \
+        else if (R == 48) SG_TRY((launch_m4r<48, 8, 6, BY>(M4R_ARGS)));       \
+        else if (R == 40) SG_TRY((launch_m4r<40, 8, 8, BY>(M4R_ARGS)));       \
+        else if (R == 24) SG_TRY((launch_m4r<24, 8, 8, BY>(M4R_ARGS)));       \
+        else SG_TRY((launch_m4r<16, 8, 8, BY>(M4R_ARGS)));
+        if (fused_bytes) { M4R_LAUNCH(true) } else { M4R_LAUNCH(false) }
+#undef M4R_LAUNCH
 #undef M4R_ARGS
     }
-    if (out) {
+    if (out && !fused_bytes) {
         const i64 total = N * ((M + 15) / 16);
         i64 g = (total + 255) / 256;
         if (g > 65536) g = 65536;
         const bool vec = (M % 16 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-        if (vec) hipLaunchKernelGGL(k_bits_to_bytes<true>, dim3((unsigned)g), dim3(256), 0, st, dst_bits, stride, N, M, out);
-        else hipLaunchKernelGGL(k_bits_to_bytes<false>, dim3((unsigned)g), dim3(256), 0, st, dst_bits, stride, N, M, out);
+        if (vec) hipLaunchKernelGGL(k_bits_to_bytes<true>, dim3((unsigned)g), dim3(256), 0, st, bits.as<u64>(), stride, N, M, out);
+        else hipLaunchKernelGGL(k_bits_to_bytes<false>, dim3((unsigned)g), dim3(256), 0, st, bits.as<u64>(), stride, N, M, out);
         KERNEL_CHECK();
     }
     return SYMGPU_OK;

@@ -520,6 +520,22 @@ int symgpu_op_set_rows(symgpu_op_t op, int64_t T) {
     return SYMGPU_OK;
 }
 
+int symgpu_op_write(symgpu_op_t op, int64_t row_offset, const uint64_t *rows, const double *coeff, int64_t count) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(op && row_offset >= 0 && count >= 0 && row_offset + count <= op->capacity, "op_write: row range exceeds the capacity");
+    SG_REQUIRE(count == 0 || rows, "op_write: null rows");
+    const size_t W = (size_t)2 * op->Wq;
+    if (count > 0) {
+        HIP_TRY(hipMemcpyAsync(op->rows + (size_t)row_offset * W, rows, (size_t)count * W * 8, hipMemcpyHostToDevice, ctx().stream));
+        if (coeff && op->coeff)
+            HIP_TRY(hipMemcpyAsync(op->coeff + 2 * (size_t)row_offset, coeff, (size_t)count * 16, hipMemcpyHostToDevice, ctx().stream));
+        HIP_TRY(hipStreamSynchronize(ctx().stream));
+    }
+    op_invalidate(op);
+    if (row_offset + count > op->T) op->T = row_offset + count;
+    return SYMGPU_OK;
+}
+
 int symgpu_op_upload(const uint64_t *rows, const double *coeff, int64_t T, int Wq, symgpu_op_t *out) {
     SG_TRY(require_ctx());
     SG_REQUIRE(out && T >= 0 && Wq >= 1 && (rows || T == 0), "op_upload");

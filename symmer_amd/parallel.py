@@ -11,6 +11,11 @@ Control plane (unique-id exchange, barriers, max-over-ranks timing): either a fe
 runtime and RCCL, which must not be mixed with the system ones this library links to) or ``torch.distributed`` with
 the gloo backend (``control='gloo'``).  With ``data_plane='gloo-host'`` the all-gather itself runs over gloo on host
 arrays, which is what the CPU tests (world_size 2) exercise.
+
+If RCCL cannot be brought up on EVERY rank (agreed over the control plane before anybody enters the collective
+``ncclCommInitRank``), the communicator falls back to ``data_plane='host-staged'``: the same all-gather, but D2H ->
+control plane -> H2D.  The step still exchanges the shards (3.2 MB per rank in the benchmark, a few ms next to a 0.45 s
+step); callers report the degraded data plane (``Communicator.degraded``).  Nothing ever silently replicates data.
 """
 import os
 import ctypes
@@ -97,13 +102,14 @@ class _TcpControl:
 
     @staticmethod
     def _recv(c, n):
-        buf = b''
-        while len(buf) < n:
-            chunk = c.recv(n - len(buf))
-            if not chunk:
+        buf = bytearray(n)
+        view, got = memoryview(buf), 0
+        while got < n:
+            k = c.recv_into(view[got:], n - got)
+            if k == 0:
                 raise ConnectionError('control-plane peer closed the connection')
-            buf += chunk
-        return buf
+            got += k
+        return bytes(buf)
 
     def bcast(self, payload, nbytes):
         if self.rank == 0:
@@ -122,6 +128,18 @@ class _TcpControl:
             return m
         self.peers[0].sendall(s.pack('<d', float(x)))
         return s.unpack('<d', self._recv(self.peers[0], 8))[0]
+
+    def allgather(self, payload):
+        """Equal-sized byte strings from every rank, concatenated in rank order, on every rank (through rank 0)."""
+        n = len(payload)
+        if self.rank == 0:
+            parts = [payload] + [self._recv(c, n) for c in self.peers]
+            whole = b''.join(parts)
+            for c in self.peers:
+                c.sendall(whole)
+            return whole
+        self.peers[0].sendall(payload)
+        return self._recv(self.peers[0], n * self.world)
 
     def close(self):
         for c in self.peers:
@@ -159,6 +177,7 @@ class Communicator:
         self._dist = None
         self._tcp = None
         self.rccl_error = None
+        self.degraded = None      # text when the data plane is not the one asked for (host-staged instead of RCCL)
         self.gathers = False      # True when the right operand must be assembled with the all-gather
 
     # ---- construction ------------------------------------------------------------------------------------
@@ -196,36 +215,48 @@ class Communicator:
         self._dist.broadcast(t, src=0)
         return bytes(t.tolist())
 
+    def _fallback(self, why):
+        """RCCL is unavailable: gather through host memory over the control plane instead (still a real exchange)."""
+        self.rccl_error = why
+        self.data_plane = 'host-staged'
+        self.degraded = f'host-staged all-gather over the control plane (RCCL unavailable: {why})'
+
     def _init_rccl(self):
         """RCCL communicator over the control plane.  Every step that can fail locally is followed by an agreement over the
-        control plane, so that either ALL ranks end up with a communicator or all of them fall back to ``rccl_error`` set
-        (callers such as bench.py then replicate the right operand instead of gathering it)."""
+        control plane, and the first agreement — "librccl loads on this rank" — happens BEFORE any rank enters the collective
+        ``ncclCommInitRank``: a rank that failed locally would otherwise leave its peers blocked inside it.  Either ALL ranks
+        end up with a communicator or all of them fall back to the host-staged data plane."""
         from . import _lib
         self.rccl_error = None
+        local = None
+        try:
+            with _stdout_to_stderr():
+                _lib.check(_lib.load().symgpu_comm_available())
+        except Exception as exc:
+            local = str(exc)
+        if self.max_over_ranks(1.0 if local else 0.0) > 0.0:
+            return self._fallback(local or 'librccl could not be loaded on another rank')
         raw = (ctypes.c_uint8 * 128)()
         if self.rank == 0:
             try:
                 with _stdout_to_stderr():
                     _lib.check(_lib.lib().symgpu_comm_unique_id(ctypes.addressof(raw)))
-            except Exception as exc:                              # librccl missing / not loadable: broadcast an all-zero id
-                self.rccl_error = str(exc)
+            except Exception as exc:                              # broadcast an all-zero id: everybody falls back
+                local = str(exc)
                 raw = (ctypes.c_uint8 * 128)()
         ident = self._bcast_bytes(bytes(raw), 128)
         if not any(ident):
-            self.rccl_error = self.rccl_error or 'rank 0 could not create an RCCL unique id'
-        else:
-            try:
-                raw = (ctypes.c_uint8 * 128)(*ident)
-                with _stdout_to_stderr():
-                    _lib.check(_lib.lib().symgpu_comm_init(ctypes.addressof(raw), self.rank, self.world))
-            except Exception as exc:
-                self.rccl_error = str(exc)
-        if self.max_over_ranks(1.0 if self.rccl_error else 0.0) > 0.0:
-            if self.rccl_error is None:
-                self.rccl_error = 'RCCL initialisation failed on another rank'
+            return self._fallback(local or 'rank 0 could not create an RCCL unique id')
+        try:
+            raw = (ctypes.c_uint8 * 128)(*ident)
+            with _stdout_to_stderr():
+                _lib.check(_lib.lib().symgpu_comm_init(ctypes.addressof(raw), self.rank, self.world))
+        except Exception as exc:
+            local = str(exc)
+        if self.max_over_ranks(1.0 if local else 0.0) > 0.0:
+            if local is None:
                 _lib.load().symgpu_comm_destroy()
-            self.gathers = False
-            self.data_plane = 'none'
+            return self._fallback(local or 'RCCL initialisation failed on another rank')
 
     # ---- control plane -----------------------------------------------------------------------------------
     def barrier(self):
@@ -250,8 +281,40 @@ class Communicator:
         from . import _lib
         if not self.gathers:
             raise ValueError('allgather_op without a communicator: use the shard directly')
-        _lib.check(_lib.lib().symgpu_comm_allgather_op(shard.handle, full.handle))
+        if self.data_plane == 'rccl':
+            _lib.check(_lib.lib().symgpu_comm_allgather_op(shard.handle, full.handle))
+        else:
+            self._allgather_op_host(shard, full)
         full.set_rows(n_rows_total)
+
+    def _allgather_bytes(self, payload):
+        if self._tcp is not None:
+            return self._tcp.allgather(payload)
+        import torch
+        mine = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+        parts = [torch.zeros_like(mine) for _ in range(self.world)]
+        self._dist.all_gather(parts, mine)
+        return b''.join(bytes(p.numpy().tobytes()) for p in parts)
+
+    def _allgather_op_host(self, shard, full):
+        """The same gather through host memory: shard (padded with identity rows to its capacity Ts) -> D2H -> control plane
+        -> H2D into ``full`` at the rows' global indices."""
+        from . import _lib
+        t, wq, ts = shard.info()
+        rows = np.zeros((ts, 2 * wq), dtype='<u8')
+        coeff = np.zeros(ts, dtype=np.complex128)
+        try:
+            r, c = shard.download()
+        except _lib.SymgpuError:                                  # rows-only operand (commutation needs no coefficients)
+            r, c = shard.download(with_coeff=False), None
+        rows[:t] = r
+        all_rows = np.frombuffer(self._allgather_bytes(rows.tobytes()), dtype='<u8').reshape(self.world * ts, 2 * wq)
+        all_coeff = None
+        if c is not None:
+            coeff[:t] = c
+            all_coeff = np.frombuffer(self._allgather_bytes(coeff.tobytes()), dtype=np.complex128)
+        _lib.check(_lib.lib().symgpu_op_write(full.handle, 0, all_rows.ctypes.data, None if all_coeff is None else all_coeff.ctypes.data,
+                                              self.world * ts))
 
     def allgather_rows_host(self, local_rows, n_rows_total):
         """Host arrays over gloo (CPU tests / PCIe staging): returns the full ``uint64[n_rows_total, W]`` array."""

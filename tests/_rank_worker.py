@@ -1,0 +1,48 @@
+# one rank of the multi-process GPU tests (not a test itself): python tests/_rank_worker.py
+# env: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run sets them.
+# Gathers a sharded right operand (RCCL over xGMI, or host-staged if RCCL is unavailable), checks it against the shards
+# every rank can regenerate from the seeds, then checks this rank's block of commutes_termwise and of the product against
+# the oracle.  Prints RANK_OK <rank> <data plane>.
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from symmer_amd import _lib, kernels, parallel
+from symmer_amd.kernels import DeviceOp
+from oracle import oracle_c as oc
+
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+_lib.init(int(os.environ.get('LOCAL_RANK', '0')))
+comm = parallel.Communicator.from_env()
+want = os.environ.get('EXPECT_PLANE')
+assert comm.gathers and (want is None or comm.data_plane == want), (comm.data_plane, comm.rccl_error)
+n, M, N = 130, 1003, 77 * world + 5
+wq = (n + 63) // 64
+ts, bounds = parallel.shard_bounds(M, world)
+mine = bounds[rank][1] - bounds[rank][0]
+shard = parallel.padded_random_shard(mine, ts, n, 4242 + rank)
+full = DeviceOp.alloc(ts * world, wq, with_coeff=True)
+for _ in range(2):                                            # twice: the gather must be repeatable into the same handle
+    comm.allgather_op(shard, full, M)
+rows, coeff = full.download()
+exp_r, exp_c = [], []
+for r in range(world):
+    o = DeviceOp.random(ts, n, 0.3, 4242 + r)
+    er, ec = o.download(); o.free()
+    k = bounds[r][1] - bounds[r][0]
+    er[k:] = 0; ec[k:] = 0                                    # the padding of a short shard is zero rows
+    exp_r.append(er); exp_c.append(ec)
+exp_r, exp_c = np.vstack(exp_r)[:M], np.hstack(exp_c)[:M]
+assert np.array_equal(rows, exp_r) and np.array_equal(coeff, exp_c), 'gathered operand differs from the shards'
+# this rank's block of the left axis against the gathered right operand
+left = DeviceOp.random(N, n, 0.3, 99)
+lr, lc = left.download()
+_, lb = parallel.shard_bounds(N, world)
+b0, b1 = lb[rank]
+assert np.array_equal(kernels.commutes(lr[b0:b1], rows), oc.commutes(lr[b0:b1], exp_r)), 'commutation block mismatch'
+pr, pc = kernels.mul_allpairs(lr[b0:b1], lc[b0:b1], rows, coeff, True)
+er, ec = oc.mul_allpairs(lr[b0:b1], lc[b0:b1], exp_r, exp_c, True)
+assert np.array_equal(pr, er) and np.array_equal(pc, ec), 'product block mismatch'      # same un-fused IEEE expression on both sides
+comm.barrier()
+plane = comm.data_plane
+comm.close()
+print(f'RANK_OK {rank} {plane}', flush=True)

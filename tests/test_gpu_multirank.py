@@ -1,0 +1,79 @@
+"""One process per GPU, world_size 2, on real hardware (`-m gpu`).
+
+* ``rccl``: needs two GPUs — RCCL all-gather over xGMI through ``Communicator.from_env`` + ``allgather_op`` (skipped on a
+  one-GPU box; the driver's 8-GPU scaling run exercises the same path through bench.py).
+* ``host-staged``: RCCL made unavailable on purpose (``SYMGPU_RCCL_DISABLE=1``) — the ranks must agree on the fallback
+  before anybody enters ``ncclCommInitRank`` and gather through host memory; with one GPU both ranks share device 0.
+* bench.py's launch line with two ranks (torch.distributed.run's environment), reduced workload.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _launch(argv, world, extra_env, timeout=300):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env)
+        procs.append(subprocess.Popen([sys.executable] + argv, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    return outs
+
+
+def _n_gpus():
+    from symmer_amd import _lib
+    return _lib.device_count()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('plane', ['rccl', 'host-staged'])
+def test_two_ranks_gather_and_blocks(plane):
+    if plane == 'rccl' and _n_gpus() < 2:
+        pytest.skip('RCCL needs one GPU per rank; this box has one')
+    env = {'EXPECT_PLANE': plane}
+    if plane == 'host-staged':
+        env['SYMGPU_RCCL_DISABLE'] = '1'
+    outs = _launch(['tests/_rank_worker.py'], 2, env)
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0 and f'RANK_OK {r} {plane}' in o, f'rank {r}: rc={rc}\n{o}\n{e[-3000:]}'
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_prints_one_json_line():
+    """bench.py under the driver's multi-rank environment: one JSON line on rank 0's stdout, n_gpus = 2, aggregate value, and the
+    data plane named (RCCL with two GPUs; with one GPU both ranks share it, RCCL refuses that, and the line is flagged degraded)."""
+    outs = _launch(['bench.py', '--gpus', '2', '--steps', '1', '--warmup', '1', '--left-terms', '20000', '--right-terms', '20000', '--no-extras', '--no-cpu'],
+                   2, {}, timeout=800)
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0, f'rank {r}: rc={rc}\n{o}\n{e[-3000:]}'
+    lines = [l for l in outs[0][1].splitlines() if l.strip()]
+    assert len(lines) == 1 and not outs[1][1].strip(), (outs[0][1], outs[1][1])
+    doc = json.loads(lines[0])
+    assert doc['n_gpus'] == 2 and doc['config']['pairs_per_step'] == 2 * 20000 * 20000 and doc['value'] > 0
+    if _n_gpus() >= 2:
+        assert 'degraded' not in doc and 'rccl' in doc['config']['parallelism']
+    else:
+        assert 'host-staged' in doc['degraded'] and 'host-staged' in doc['config']['parallelism']

@@ -529,14 +529,20 @@ def test_commutes_both_kernels(n, N, M, dens, force, monkeypatch):
     _lib.check(lib.symgpu_dev_free(bits)); A.free(); B.free()
 
 
+@pytest.mark.parametrize('M', [4208, 4200])
 @pytest.mark.parametrize('r', ['16', '24', '40', '48', '116'])
-def test_commutes_m4r_tile_heights(r, monkeypatch):
-    """Every instantiation of the Four-Russians kernel (rows per 16-lane slot) on a shape that leaves partial row and column tiles."""
+def test_commutes_m4r_tile_heights(r, M, monkeypatch):
+    """Every instantiation of the Four-Russians kernel (rows per 16-lane slot; '116' = 16 waves x 16 rows) on a shape that
+    leaves partial row and column tiles; M = 4208 takes the fused byte-expanding epilogue (16-byte stores), M = 4200 the
+    bit-packed rows + separate expansion, SYMGPU_M4R_UNFUSED forces the latter for the aligned shape as well."""
     monkeypatch.setenv('SYMGPU_COMMUTE_M4R', '1'); monkeypatch.setenv('SYMGPU_M4R_R', r)
     rng = np.random.default_rng(77)
-    n, N, M = 200, 1500, 4200
+    n, N = 200, 1500
     a = packing.pack_rows(rng.random((N, 2 * n)) < 0.3); b = packing.pack_rows(rng.random((M, 2 * n)) < 0.3)
-    assert np.array_equal(kernels.commutes(a, b), oc.commutes(a, b))
+    expect = oc.commutes(a, b)
+    assert np.array_equal(kernels.commutes(a, b), expect)
+    monkeypatch.setenv('SYMGPU_M4R_UNFUSED', '1')
+    assert np.array_equal(kernels.commutes(a, b), expect)
 
 
 @pytest.mark.parametrize('case', family('jordan'))

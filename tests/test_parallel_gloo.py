@@ -126,28 +126,39 @@ def test_tcp_control_plane_survives_an_occupied_port():
         blocker.close()
 
 
-def _rccl_fallback_worker(rank, world, port, q):
+def _rccl_fallback_worker(rank, world, port, q, disable_on):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        from symmer_amd import parallel
-        # no GPU here: rank 0 cannot create an RCCL unique id -> every rank must agree on the fallback instead of hanging
+        if rank in disable_on:
+            os.environ['SYMGPU_RCCL_DISABLE'] = '1'             # this rank cannot load librccl
+        from symmer_amd import parallel, _lib
+        calls = []
+        real = _lib.load().symgpu_comm_init
+        # no GPU here: (a) a rank that cannot load librccl reports it BEFORE anybody enters the collective ncclCommInitRank,
+        # (b) otherwise rank 0 cannot create a unique id; either way every rank must agree on the host-staged data plane
+        # instead of hanging, and nobody may have called symgpu_comm_init
+        _lib._lib.symgpu_comm_init = lambda *a: calls.append(a) or real(*a)
         comm = parallel.Communicator.from_env(data_plane='rccl', control='tcp')
-        ok = (not comm.gathers) and bool(comm.rccl_error) and comm.data_plane == 'none'
+        ok = comm.gathers and bool(comm.rccl_error) and comm.data_plane == 'host-staged' and bool(comm.degraded) and not calls
+        # the fallback's transport: equal-sized byte strings, concatenated in rank order on every rank
+        got = comm._allgather_bytes(bytes([rank + 1]) * 5000)
+        ok = ok and got == b''.join(bytes([r + 1]) * 5000 for r in range(world))
         comm.barrier()
         comm.close()
-        q.put((rank, ok, '' if ok else f'gathers={comm.gathers} error={comm.rccl_error}'))
+        q.put((rank, ok, '' if ok else f'gathers={comm.gathers} plane={comm.data_plane} error={comm.rccl_error} init_calls={len(calls)}'))
     except Exception:                                         # pragma: no cover
         import traceback
         q.put((rank, False, traceback.format_exc()))
 
 
 @pytest.mark.timeout(120)
-def test_rccl_failure_is_agreed_across_ranks():
+@pytest.mark.parametrize('disable_on', [(), (1,), (0,)])
+def test_rccl_failure_is_agreed_across_ranks(disable_on):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rccl_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rccl_fallback_worker, args=(r, 2, port, q, disable_on)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=100) for _ in procs]
