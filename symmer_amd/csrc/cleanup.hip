@@ -494,6 +494,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
     if (T == 0) {
         SG_TRY(symgpu_op_alloc(1, Wq_out, 1, &res));
         res->T = 0;
+        res->dup_free = 1;
         *out = res;
         return SYMGPU_OK;
     }

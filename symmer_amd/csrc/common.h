@@ -90,6 +90,9 @@ struct symgpu_op_s {
     // cached word-major copy of rows[0..T) (layout.hip), padded to wm_pad terms; dropped whenever rows/T change
     u64 *wm = nullptr;
     i64 wm_pad = 0, wm_T = -1;
+    // 1 = known to hold no two equal rows (result of a cleanup, or of a rotation of such an operator); 0 = unknown.
+    // Reset by op_invalidate, i.e. whenever rows change.  The odd-k Clifford rotation needs to know (rotate.hip).
+    int dup_free = 0;
 };
 
 namespace symgpu {

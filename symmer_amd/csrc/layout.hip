@@ -38,15 +38,20 @@ int to_wordmajor(const u64 *rows, i64 T, int W, u64 *out, i64 Tpad, hipStream_t 
     return SYMGPU_OK;
 }
 
-void op_invalidate(symgpu_op_s *op) {
+static void drop_wordmajor(symgpu_op_s *op) {
     if (op && op->wm) { dev_free(op->wm); op->wm = nullptr; }
     if (op) { op->wm_pad = 0; op->wm_T = -1; }
+}
+
+void op_invalidate(symgpu_op_s *op) {
+    drop_wordmajor(op);
+    if (op) op->dup_free = 0;
 }
 
 int op_wordmajor(symgpu_op_s *op, i64 mult, const u64 **out, i64 *pad) {
     const i64 need = (op->T + mult - 1) / mult * mult;
     if (!op->wm || op->wm_T != op->T || op->wm_pad % mult != 0 || op->wm_pad < need) {
-        op_invalidate(op);
+        drop_wordmajor(op);
         // pad to a multiple of 256 as well so that every all-pairs kernel can share the copy
         i64 m = mult;
         while (m % 256) m *= 2;

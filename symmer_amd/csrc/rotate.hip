@@ -12,7 +12,11 @@
 //           partners; Clifford (angle = k*pi/2): [rotated anticommuting | commuting], no merge (base.py:1139-1154);
 //           odd k: row ^ Q with c * i^e * (-i), k in {2,3}: negated (k is NOT reduced mod 4, base.py:1148).
 // Equivalent to the reference's three intermediate cleanups when the input has no duplicate rows
-// (every operator that left cleanup() qualifies).
+// (every operator that left cleanup() qualifies).  Inputs WITH duplicate rows: the non-Clifford path
+// detects them in its hash insert and falls back to stack + cleanup; the odd-k Clifford path forms anticom_self * Q
+// through __mul__ in the reference (base.py:1143), which merges duplicate product rows and thresholds the SUMS — so an
+// operator not known to be duplicate-free (symgpu_op_s::dup_free) is checked once with the same hash insert, and if
+// duplicates exist the rotated anticommuting part goes through cleanup before the commuting rows are appended.
 #include "common.h"
 #include <stdlib.h>
 
@@ -440,8 +444,31 @@ static int rotate_fast_clifford(symgpu_op_t in, const u64 *q_dev, const u32 *ant
     *done = 1;
     if (hc.nAnti == 0) { symgpu_op_free(res); *all_commute = 1; return SYMGPU_OK; }   // identity action (base.py:1131-1133)
     res->T = (i64)hc.nC + hc.nA + hc.nN;
+    res->dup_free = in->dup_free;      // distinct rows stay distinct: P^Q anticommutes with Q, so it never meets a commuting row
     *out = res;
     *all_commute = 0;
+    return SYMGPU_OK;
+}
+
+// Does the operator hold two equal rows?  Same open-addressing insert as the non-Clifford fast path (row hash + word-by-word
+// check); the answer is remembered on the handle.
+static int detect_duplicates(symgpu_op_t in, const u64 *hrows, bool *has_dup) {
+    hipStream_t st = ctx().stream;
+    const i64 T = in->T;
+    u32 cap = 1024;
+    while ((i64)cap < 4 * T) cap <<= 1;
+    Scratch table, cnt;
+    SG_TRY(table.alloc((size_t)cap * 4));
+    SG_TRY(cnt.alloc(sizeof(RotCounts)));
+    HIP_TRY(hipMemsetAsync(table.p, 0, (size_t)cap * 4, st));
+    HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(RotCounts), st));
+    hipLaunchKernelGGL(k_rotf_insert, dim3(grid_for(T)), dim3(256), 0, st, in->rows, hrows, T, 2 * in->Wq, table.as<u32>(), cap - 1, cnt.as<RotCounts>());
+    KERNEL_CHECK();
+    RotCounts hc;
+    HIP_TRY(hipMemcpyAsync(&hc, cnt.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *has_dup = hc.dup != 0;
+    if (!*has_dup) in->dup_free = 1;
     return SYMGPU_OK;
 }
 
@@ -497,6 +524,8 @@ static int rotate_fast_nonclifford(symgpu_op_t in, const u64 *q_dev, const u64 *
     if (hc.nAnti == 0) { symgpu_op_free(res); *all_commute = 1; *done = 1; return SYMGPU_OK; }   // identity action (base.py:1131-1133)
     if (hc.dup) { symgpu_op_free(res); return SYMGPU_OK; }     // duplicates in the input: general path
     res->T = (i64)hc.nC + hc.nA + hc.nN;
+    res->dup_free = 1;                 // the input had no duplicates (checked above) and every P^Q that met a row was merged into it
+    in->dup_free = 1;
     *out = res;
     *all_commute = 0;
     *done = 1;
@@ -533,7 +562,12 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
     SG_TRY(dprod.alloc((size_t)T * 4));
     HIP_TRY(hipMemcpyAsync(q.p, q_row_host, (size_t)W * 8, hipMemcpyHostToDevice, st));
     const bool clifford = clifford_k >= 0;
-    const bool try_fast = !clifford && !getenv("SYMGPU_ROTATE_GENERAL");
+    const bool general_only = getenv("SYMGPU_ROTATE_GENERAL") != nullptr;
+    const bool try_fast = !clifford && !general_only;
+    // odd multiples of pi/2 multiply by Q through the reference's __mul__ (merge + threshold on sums): the per-row fast path is
+    // only the same thing for an operator without duplicate rows
+    const bool need_dup_check = clifford && (clifford_k & 1) && !in->dup_free && !general_only;
+    const bool want_hash = try_fast || need_dup_check;
     Scratch hrows;
     int G = 1;
     while (G < Wq && G < 64) G <<= 1;
@@ -541,7 +575,7 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
         const int rpb = 256 / G;
         i64 g = (T + rpb - 1) / rpb;
         if (g > 1024) g = 1024;
-        if (try_fast) {
+        if (want_hash) {
             SG_TRY(ensure_hash_tables(ctx().hash_tab ? ctx().hash_seed : 1));
             SG_TRY(hrows.alloc((size_t)T * 8));
             hipLaunchKernelGGL(k_rot_analyze<true>, dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(),
@@ -559,14 +593,17 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
         *out = nullptr;
         *all_commute = 1;
     }
-    if (clifford && !getenv("SYMGPU_ROTATE_GENERAL")) {
+    bool has_dup = false;
+    if (need_dup_check) SG_TRY(detect_duplicates(in, hrows.as<u64>(), &has_dup));
+    if (clifford && !general_only && !has_dup) {
         int done = 0;
         SG_TRY(rotate_fast_clifford(in, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(), clifford_k, thr, out, all_commute, &done));
         if (done) return SYMGPU_OK;
         *out = nullptr;
         *all_commute = 1;
     }
-    const int drop_small = clifford && (clifford_k & 1);
+    // odd-k Clifford: every anticommuting row enters the product; the threshold applies to the merged sums below
+    const int drop_small = 0;
     hipLaunchKernelGGL(k_rot_keepflags, dim3(grid_for(T)), dim3(256), 0, st, anti.as<u32>(), in->coeff, T, thr, drop_small, sel.as<u32>());
     KERNEL_CHECK();
     u32 *tot = totals.as<u32>();
@@ -594,9 +631,38 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
                        reinterpret_cast<const u32x4 *>(q.p), T, Wq, dmain.as<u32>(), dprod.as<u32>(), reinterpret_cast<u32x4 *>(stack->rows));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { symgpu_op_free(stack); return hip_fail(e, "rotate build", __FILE__, __LINE__); }
-    if (clifford) {
+    if (clifford && !(clifford_k & 1)) {
         HIP_TRY(hipStreamSynchronize(st));
+        stack->dup_free = in->dup_free;
         *out = stack;
+        return SYMGPU_OK;
+    }
+    if (clifford) {
+        // (anticom_self * Q) of base.py:1143 = cleanup of the rotated rows: duplicates merged in input order, |sum| > thr kept
+        // (the exact factors -i / -1 commute with the IEEE sums); then the commuting rows, untouched (base.py:1151-1154)
+        symgpu_op_t merged = nullptr;
+        int rc = cleanup_core(stack->rows, stack->coeff, n_sel, W, nullptr, 0, nullptr, 0, thr, 1, &merged, Wq);
+        if (rc != SYMGPU_OK) { symgpu_op_free(stack); return rc; }
+        symgpu_op_t res = nullptr;
+        rc = symgpu_op_alloc(merged->T + n_comm > 0 ? merged->T + n_comm : 1, Wq, 1, &res);
+        hipError_t e = hipSuccess;
+        if (rc == SYMGPU_OK) {
+            if (merged->T > 0) {
+                e = hipMemcpyAsync(res->rows, merged->rows, (size_t)merged->T * W * 8, hipMemcpyDeviceToDevice, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(res->coeff, merged->coeff, (size_t)merged->T * 16, hipMemcpyDeviceToDevice, st);
+            }
+            if (e == hipSuccess && n_comm > 0) {
+                e = hipMemcpyAsync(res->rows + (size_t)merged->T * W, stack->rows + (size_t)n_sel * W, (size_t)n_comm * W * 8, hipMemcpyDeviceToDevice, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(res->coeff + 2 * (size_t)merged->T, stack->coeff + 2 * (size_t)n_sel, (size_t)n_comm * 16, hipMemcpyDeviceToDevice, st);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            res->T = merged->T + n_comm;
+        }
+        symgpu_op_free(merged);
+        symgpu_op_free(stack);
+        if (rc != SYMGPU_OK) return rc;
+        if (e != hipSuccess) { symgpu_op_free(res); return hip_fail(e, "rotate Clifford merge", __FILE__, __LINE__); }
+        *out = res;
         return SYMGPU_OK;
     }
     symgpu_op_t res = nullptr;

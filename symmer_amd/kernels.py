@@ -200,10 +200,11 @@ def rotation_args(angle, threshold=1e-18):
     return float(np.cos(angle)), float(np.sin(angle)), -1
 
 
-def rotate_single_dev(op, q_row, angle, zero_threshold=1e-15):
-    """Device-resident rotation: returns (DeviceOp or None, all_commute)."""
+def rotate_single_dev(op, q_row, angle, zero_threshold=1e-15, clifford_threshold=1e-18):
+    """Device-resident rotation: returns (DeviceOp or None, all_commute).  ``clifford_threshold`` is the reference's
+    ``threshold`` argument (base.py:1146): how close 2*angle/pi must be to an integer for the Clifford branch."""
     q_row = np.ascontiguousarray(q_row, dtype='<u8').reshape(-1)
-    cos_t, sin_t, k = rotation_args(angle)
+    cos_t, sin_t, k = rotation_args(angle, clifford_threshold)
     out = ctypes.c_void_p()
     allc = c_int(0)
     check(_lib.lib().symgpu_rotate_single_dev(op.handle, addr(q_row), cos_t, sin_t, k, float(zero_threshold), ctypes.byref(out),

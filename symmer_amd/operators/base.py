@@ -20,6 +20,14 @@ from .utils import (string_to_symplectic, symplectic_to_string, random_symplecti
 warnings.simplefilter('always', UserWarning)
 
 
+def _warn_large_angle(angle: float, threshold: float) -> None:
+    """base.py:1156-1157: the warning belongs to the non-Clifford branch of a rotation that acts non-trivially."""
+    multiple = angle * 2 / np.pi
+    if abs(round(multiple) - multiple) > threshold and abs(angle) > 1e6:
+        warnings.warn('Large angle can lead to precision errors: recommend using high-precision math library '
+                      'such as mpmath or redefine angle in range [-pi, pi]')
+
+
 class PauliwordOp:
     """Weighted sum of n-qubit Pauli strings in the symplectic representation
     (``symp_matrix`` bool ``[T, 2n]`` = ``[X | Z]``, ``coeff_vec`` complex128 ``[T]``)."""
@@ -448,8 +456,8 @@ class PauliwordOp:
     # ---- a7 ----------------------------------------------------------------------------------------------
     def _rotate_by_single_Pword(self, Pword: "PauliwordOp", angle: float = None, threshold: float = 1e-18
                                 ) -> "PauliwordOp":
-        """base.py:1090-1161 as one fused device pass (valid for operators without duplicate rows, i.e. anything
-        that has been through ``cleanup``; see ``csrc/rotate.hip``)."""
+        """base.py:1090-1161 as one fused device pass; ``threshold`` decides Clifford vs non-Clifford as in base.py:1146.
+        Operators with duplicate rows are detected on the device and take the merging path (``csrc/rotate.hip``)."""
         if angle is None:
             angle = np.pi / 2
         if angle.imag != 0:
@@ -461,15 +469,12 @@ class PauliwordOp:
             warnings.warn(f'Pword coefficient {Pword.coeff_vec[0]: .8f} has been set to 1')
         if self.n_terms == 0:
             return self
-        multiple = angle * 2 / np.pi
-        if abs(round(multiple) - multiple) > threshold and abs(angle) > 1e6:
-            warnings.warn('Large angle can lead to precision errors: recommend using high-precision math library '
-                          'such as mpmath or redefine angle in range [-pi, pi]')
         op = kernels.DeviceOp.upload(self.packed, self.coeff_vec)
         try:
-            res, all_commute = kernels.rotate_single_dev(op, Pword.packed[0], angle)
+            res, all_commute = kernels.rotate_single_dev(op, Pword.packed[0], angle, clifford_threshold=threshold)
             if all_commute:
                 return self                                     # identity action: the SAME object (base.py:1131-1133)
+            _warn_large_angle(angle, threshold)                 # only on the non-Clifford, non-commuting branch (base.py:1156-1157)
             rows, coeff = res.download()
             res.free()
         finally:
@@ -497,9 +502,13 @@ class PauliwordOp:
                     angle = np.pi / 2
                 if pauli_rotation.coeff_vec[0] != 1:
                     warnings.warn(f'Pword coefficient {pauli_rotation.coeff_vec[0]: .8f} has been set to 1')
+                if getattr(angle, 'imag', 0) != 0:
+                    warnings.warn('Complex component in angle: this will be ignored.')
+                angle = float(np.real(angle))
                 if dev.n_terms > 0:
-                    res, all_commute = kernels.rotate_single_dev(dev, pauli_rotation.packed[0], float(np.real(angle)))
+                    res, all_commute = kernels.rotate_single_dev(dev, pauli_rotation.packed[0], angle)
                     if not all_commute:
+                        _warn_large_angle(angle, 1e-18)
                         dev.free()
                         dev = res
                 if dev.n_terms == 0:

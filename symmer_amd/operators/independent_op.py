@@ -156,15 +156,28 @@ class IndependentOp(PauliwordOp):
             if fix.any():
                 self.stabilizer_rotations.append((PauliwordOp(fix, [1]), None))
 
-    def update_sector(self, ref_state: Union[List[int], np.ndarray], threshold: float = 0.5) -> None:
-        """independent_op.py:275-301 for a computational-basis reference state given as a bit array: the expectation
-        value of a stabiliser is (-1)^{|z & b|} if it is diagonal (no X/Y) and 0 otherwise (then the assignment is 0,
-        with the reference's warning).  ``QuantumState`` superpositions are outside the accelerated path."""
-        b = np.asarray(ref_state).reshape(-1)
-        assert b.shape[0] == self.n_qubits and set(np.unique(b)).issubset({0, 1}), 'reference state must be a bit array over all qubits'
-        diagonal = ~np.any(self.X_block, axis=1)
-        signs = (-1) ** np.sum(np.bitwise_and(self.Z_block, b.astype(bool)), axis=1)
-        self.coeff_vec = np.where(diagonal, signs, 0).astype(int)
+    def update_sector(self, ref_state, threshold: float = 0.5) -> None:
+        """independent_op.py:275-301.  A ``QuantumState`` (superpositions included) is measured stabiliser by stabiliser with
+        ``single_term_expval`` — two operator x state products on the device each — and assigned +-1 where |<S>| > 0.5, else 0
+        with the reference's warning; the state must be normalised (``AssertionError`` otherwise).  Like the reference, the
+        cut-off is the fixed 0.5 of ``assign_value`` (independent_op.py:376): the ``threshold`` argument is accepted and not
+        forwarded there either.  A computational-basis state given as a bit array takes the closed form
+        <b|S|b> = (-1)^{|z & b|} for a diagonal stabiliser and 0 otherwise (the same values, without the products)."""
+        from .quantum_state import QuantumState, single_term_expval
+        if isinstance(ref_state, QuantumState):
+            assert ref_state._is_normalized(), 'Reference state is not normalized.'
+            assert ref_state.n_qubits == self.n_qubits, 'reference state defined over a different number of qubits'
+            values = []
+            for stabilizer in self:
+                expval = single_term_expval(stabilizer, ref_state)
+                values.append(int(np.sign(expval)) if abs(expval) > 0.5 else 0)
+            self.coeff_vec = np.array(values, dtype=int)
+        else:
+            b = np.asarray(ref_state).reshape(-1)
+            assert b.shape[0] == self.n_qubits and set(np.unique(b)).issubset({0, 1}), 'reference state must be a bit array over all qubits'
+            diagonal = ~np.any(self.X_block, axis=1)
+            signs = (-1) ** np.sum(np.bitwise_and(self.Z_block, b.astype(bool)), axis=1)
+            self.coeff_vec = np.where(diagonal, signs, 0).astype(int)
         if np.any(self.coeff_vec == 0):
             from .utils import symplectic_to_string
             S_zero = [symplectic_to_string(r) for r in self.symp_matrix[self.coeff_vec == 0]]

@@ -121,6 +121,75 @@ def test_rotate_golden(case):
     assert n == case['in_symp'].shape[1] // 2
 
 
+@pytest.mark.parametrize('general', [False, True])
+@pytest.mark.parametrize('case', family('rotate_dup'))
+def test_rotate_duplicate_rows_and_threshold_golden(case, general, monkeypatch):
+    """Reference outputs for operators WITH duplicate rows (odd k: the rotated anticommuting rows are merged and the threshold
+    applies to the sums, the commuting rows stay as they are; base.py:1143-1154) and for caller-supplied Clifford thresholds
+    (base.py:1146), on the fast paths (duplicates detected on the device) and with the general path forced."""
+    if general:
+        monkeypatch.setenv('SYMGPU_ROTATE_GENERAL', '1')
+    P = PauliwordOp(as_bool(case['in_symp']), case['in_coeff'])
+    ang, thr = float(case['angle']), float(case['threshold'])
+    Q = PauliwordOp(as_bool(case['q']).reshape(1, -1), [1])
+    R = P._rotate_by_single_Pword(Q, ang, thr)
+    clifford = abs(round(2 * ang / np.pi) - 2 * ang / np.pi) <= thr
+    assert_op_equal(R.symp_matrix, R.coeff_vec, case['out_symp'], case['out_coeff'], exact=clifford, tol=TOL)
+    assert (R is P) == bool(case['same_object'])
+
+
+def test_rotation_chain_from_operator_with_duplicates():
+    """perform_rotations on an operator that still holds duplicate rows (the reference rotates first and cleans up after,
+    base.py:1185) — against the step-by-step oracle."""
+    rng = np.random.default_rng(91)
+    n, t = 40, 60
+    base_rows = rng.random((t, 2 * n)) < 0.3
+    symp = np.vstack([base_rows, base_rows[rng.integers(0, t, 25)]])
+    c = (rng.integers(-8, 9, symp.shape[0]) + 1j * rng.integers(-8, 9, symp.shape[0])) / 16.0
+    P = PauliwordOp(symp, c)
+    rots = [((rng.random(2 * n) < 0.4), a) for a in (np.pi / 2, 3 * np.pi / 2, 0.3, np.pi / 2, np.pi)]
+    R = P.perform_rotations([(PauliwordOp(q.reshape(1, -1), [1]), a) for q, a in rots])
+    er, ec = onp.perform_rotations(symp, c, rots)
+    assert_op_equal(R.symp_matrix, R.coeff_vec, er, ec, exact=False, tol=TOL)
+
+
+def test_large_angle_warning_only_when_the_rotation_acts():
+    """base.py:1156-1157: warned on the non-Clifford branch only, i.e. not when every term commutes with the rotation axis."""
+    import warnings as w
+    P = PauliwordOp.from_list(['ZZI', 'IZZ'], [1, 2])
+    with w.catch_warnings(record=True) as rec:
+        w.simplefilter('always')
+        assert P._rotate_by_single_Pword(PauliwordOp.from_list(['ZII']), 1e7 + 0.3) is P
+    assert not any('Large angle' in str(x.message) for x in rec)
+    with w.catch_warnings(record=True) as rec:
+        w.simplefilter('always')
+        P._rotate_by_single_Pword(PauliwordOp.from_list(['XII']), 1e7 + 0.3)
+    assert any('Large angle' in str(x.message) for x in rec)
+
+
+@pytest.mark.parametrize('case', family('sector'))
+def test_update_sector_with_quantum_state_golden(case):
+    """IndependentOp.update_sector with a QuantumState reference (basis states, dominated and balanced superpositions):
+    the reference's assignments incl. the zeros (independent_op.py:275-301, :364-383); an unnormalised state is refused."""
+    from symmer_amd.operators import QuantumState
+    import warnings as w
+    G = IndependentOp(as_bool(case['stab_symp']), np.ones(case['stab_symp'].shape[0], dtype=int))
+    psi = QuantumState(case['state_matrix'].astype(int), case['state_coeff'])
+    with w.catch_warnings(record=True) as rec:
+        w.simplefilter('always')
+        G.update_sector(psi)
+    assert np.array_equal(G.coeff_vec, case['sector'])
+    assert any('assigned zero values' in str(x.message) for x in rec) == bool(np.any(case['sector'] == 0))
+    if psi.n_terms == 1:                                          # a basis state: the bit-array form gives the same sector
+        G2 = IndependentOp(as_bool(case['stab_symp']), np.ones(case['stab_symp'].shape[0], dtype=int))
+        with w.catch_warnings():
+            w.simplefilter('ignore')
+            G2.update_sector(case['state_matrix'][0])
+        assert np.array_equal(G2.coeff_vec, case['sector'])
+    with pytest.raises(AssertionError):
+        G.update_sector(QuantumState(case['state_matrix'].astype(int), 2 * case['state_coeff']))
+
+
 @pytest.mark.parametrize('case', family('gf2'))
 def test_gf2_golden(case):
     m = unpackbits_matrix(case['m'], case['shape'])

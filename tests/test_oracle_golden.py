@@ -93,6 +93,16 @@ def test_rotate(case):
         assert_op_equal(*got, case['out_symp'], case['out_coeff'], exact=clifford)
 
 
+@pytest.mark.parametrize('case', family('rotate_dup'))
+def test_rotate_with_duplicate_rows_and_threshold(case):
+    """Operators that contain duplicate rows (odd multiples of pi/2 merge and threshold the product rows only, base.py:1143) and
+    caller-supplied Clifford thresholds (base.py:1146) — fixtures from oracle/tools/gen_golden_rotate_dup.py."""
+    ang, thr = float(case['angle']), float(case['threshold'])
+    got = onp.rotate_by_single_pword(as_bool(case['in_symp']), case['in_coeff'], as_bool(case['q']), ang, thr)
+    clifford = abs(round(2 * ang / np.pi) - 2 * ang / np.pi) <= thr
+    assert_op_equal(*got, case['out_symp'], case['out_coeff'], exact=clifford)
+
+
 @pytest.mark.parametrize('case', family('gf2'))
 def test_gf2(case):
     m = unpackbits_matrix(case['m'], case['shape'])
