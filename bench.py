@@ -274,10 +274,18 @@ def extras(_lib, kernels, DeviceOp):
     _lib.check(lib.symgpu_prof_enable(1, 0)); _lib.check(lib.symgpu_prof_read(1, ctypes.addressof(nl), ctypes.addressof(ms)))
     kt = ms.value / max(1, nl.value) * 1e-3
     pairs = nrow * 200000
-    ex['cfg5_commutation_slice'] = {'pairs': pairs, 'seconds': t, 'pairs_per_s': pairs / t, 'kernel_seconds': kt,
+    # The slice runs on the Four-Russians kernel (commute_m4r.hip): per row of A, 8-bit k-block and 2048-column tile one
+    # 256-byte table entry is read from LDS, so the kernel's own roofline is the LDS read path (256 B/clk/CU, MI355X_MICROARCH.md
+    # §LDS: 256 CUs x 256 B x 2.4 GHz = 157 TB/s); HBM only sees the 1 B/pair np.bool_ output.
+    n_kblocks = 2 * ((2000 + 7) // 8)                              # non-zero index bytes of a 2,000-qubit row (X and Z halves)
+    col_tiles = (200000 // 64 + 31) // 32
+    lds_bytes = nrow * n_kblocks * col_tiles * 256.0
+    ex['cfg5_commutation_slice'] = {'pairs': pairs, 'seconds': t, 'pairs_per_s': pairs / t, 'kernel': 'k_commutes_m4r', 'kernel_seconds': kt,
                                     'kernel_pairs_per_s': pairs / kt if kt else None,
-                                    'valu_frac': (pairs / kt * 4 * 32) / (256 * 4 * 32 * 2.4e9) if kt else None,
-                                    'hbm_GBps_at_1B_per_pair': pairs / kt / 1e9 if kt else None}
+                                    'hbm_GBps_at_1B_per_pair': pairs / kt / 1e9 if kt else None,
+                                    'lds_table_read_TBps': lds_bytes / kt / 1e12 if kt else None,
+                                    'lds_read_frac_of_157TBps': lds_bytes / kt / 157.3e12 if kt else None,
+                                    'register_tile_kernel_r01_pairs_per_s': 2.83e11}
     _lib.check(lib.symgpu_dev_free(buf)); C.free()
     # cfg4: GF(2) symmetry kernel, 2,000 qubits x 50,000 terms, 32 planted symmetries, Clifford-scrambled
     symp = rng.random((50000, 4000)) < 0.3

@@ -7,23 +7,35 @@
 // n = 2000) and is VALU-issue bound.  Here the contraction axis is cut into groups of 8 bits ("k-blocks" = one byte of an
 // A row).  For a k-block and a tile of 2048 columns a workgroup tabulates all 256 XOR-combinations of the 8 bit-rows of
 // the (bit-transposed, X/Z-swapped) right operand in LDS: 256 entries x 256 B = 64 KiB.  A row of A then needs ONE
-// ds_read_b128 per lane (entry = its byte, wave: 4 rows x 2048 columns) and 4 v_xor per 8 contraction bits and 128 pairs
-// per lane — 1/16 of the VALU work per pair; the kernel is bound by the LDS pipeline instead (ds_read_b128: 256 B/clk/CU).
-// The next table is built into the second 64 KiB buffer while the current one is read: one barrier per k-block.
+// ds_read_b128 per lane (entry = its byte; a wave instruction serves 4 rows x 2048 columns) and 4 v_xor + 1 v_perm per
+// 8 contraction bits and 128 pairs per lane — 1/13 of the VALU work per pair.  The next table is built into the second
+// 64 KiB buffer in the same iteration: one barrier per k-block.
+//
+// Bounds (tools/ubench_lds.hip, MI355X): the look-up stream runs at 5.1-5.5 cycles per ds_read_b128 wave instruction and CU
+// (LDS peak 4.0; without the v_perm 4.3: the 5 VALU instructions per read are the co-limit), a 64 KiB table costs 890
+// cycles of ds_write_b64 (1180 with its XOR chain).  Per k-block and 1536-row workgroup: 384 x 5.1 + 1100 = 3050 cycles;
+// measured in the kernel 3600-3860.  cfg5 slice (25,000 x 200,000, n = 2000): 5.8 ms = 8.6e11 pairs/s against 17.4 ms on
+// the register-tile kernel; 52 TB/s of table reads = 33 % of the 157 TB/s LDS read peak.
 //
 // Layouts prepared per call (all tiny next to the N x M output):
-//   A8[kb][i]   byte kb of packed row i (byte-major copy, i padded with zeros): a lane fetches the table indices of 16
-//               consecutive rows of ONE k-block with one global_load_dwordx4, so that they are dead after the k-block.
+//   A8[kb][i]   byte kb of packed row i (byte-major copy, i padded with zeros): the index bytes of a workgroup's rows for ONE
+//               k-block are contiguous.
 //   BT[c][jw]   bit c of B rows 64jw..64jw+63 (bit-major copy); row c of the contraction pairs A bit c with B bit c +- 64Wq
 //               (x with z', z with x'), which is just a row offset into BT.
 //   klist       the k-blocks in which A has any non-zero byte (all-zero bytes — padding above n, untouched qubits — look up
 //               entry 0 = 0 and are skipped for the whole launch).
 //
 // Wave = 4 row slots (16 lanes each) x R rows per slot; lane = (slot, word pair): accumulators acc[R][2] u64 in VGPRs
-// (R = 40: 160 VGPRs; 8 waves per CU x 256 VGPRs = the whole register file).  ds_read_b128's four 16-lane service groups
+// (R = 48: 192 VGPRs; 8 waves per CU x 256 VGPRs = the whole register file).  ds_read_b128's four 16-lane service groups
 // take lanes from different slots at disjoint word pairs, and the entry stride is exactly 256 B = 64 banks, so look-ups of
-// four different entries are conflict free.  Table index -> LDS address is ONE v_perm_b32 (byte of the index dword ->
-// byte 1 of the address, lane offset in byte 0, buffer select in byte 2).
+// four different entries are conflict free (SQ_LDS_IDX_ACTIVE = the ideal 4 cycles per read + 8 per ds_write2_b64).
+// Table index -> LDS address is ONE v_perm_b32 (byte of the index dword -> byte 1 of the address, lane offset in byte 0,
+// buffer select in byte 2).
+//
+// Measured and rejected: per-wave global loads of the BT rows / index bytes instead of the LDS hand-off (7.0 ms instead of
+// 5.8: 13 vector loads per wave and k-block, all L1 hits, cost more than the look-ups), 16 waves x 16 rows (7.1 ms: less
+// amortisation of the table), the two halves of the workgroup running look-ups and build in opposite order (6.7 ms), a
+// separate bits -> bytes expansion kernel (+1.2 ms: now the epilogue).
 #include "common.h"
 #include <stdlib.h>
 
@@ -104,7 +116,7 @@ __global__ __launch_bounds__(256) void k_m4r_bt(const u64 *__restrict__ rows, i6
 template <int R, int WAVES, int LOOK, bool BYTES>
 __global__ __launch_bounds__(64 * WAVES) void k_commutes_m4r(const uint8_t *__restrict__ A8, i64 Npad, i64 N, const u64 *__restrict__ BT, i64 Mw_pad,
                                                               int Wq, const u32 *__restrict__ klist, const u32 *__restrict__ nk_ptr,
-                                                              u64 *__restrict__ out_bits, i64 out_stride, i64 m_cols, int dbg) {
+                                                              u64 *__restrict__ out_bits, i64 out_stride, i64 m_cols) {
     // out_bits / out_stride: output base at this launch's first column and row stride (u64 words, or bytes if BYTES);
     // m_cols: valid columns from there
     static_assert(R % 8 == 0, "indices arrive as dwordx2 = 8 rows");
@@ -227,8 +239,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_commutes_m4r(const uint8_t *__re
             const u32 kb_next = t + 3 < nk ? klist[t + 3] : 0;
             // (measured: running the two phases in opposite order on the two halves of the workgroup, so that the look-ups of
             // one half overlap the table build of the other, is slower — 6.7 ms instead of 5.85 ms on the cfg5 slice)
-            if (!(dbg & 2)) lookups(t & 1u, t & 1u);
-            if (more && !(dbg & 1)) build((t + 1) & 1u, (t + 1) & 1u);
+            lookups(t & 1u, t & 1u);
+            if (more) build((t + 1) & 1u, (t + 1) & 1u);
             stage_store(st, t & 1u, more2, (t + 1) & 1u, more);
             kb_ix = kb_bt;
             kb_bt = kb_next;
@@ -325,7 +337,6 @@ static i64 round_up_i64(i64 x, i64 m) { return (x + m - 1) / m * m; }
 template <int R, int WAVES, int LOOK, bool BYTES>
 static int launch_m4r(const uint8_t *A8, i64 Npad, i64 N, const u64 *BT, i64 Mw_pad, int Wq, const u32 *klist, const u32 *nk, void *out, i64 stride,
                       i64 M) {
-    const int dbg = getenv("SYMGPU_M4R_DBG") ? atoi(getenv("SYMGPU_M4R_DBG")) : 0;   // timing experiments only: 1 = no table build, 2 = no look-ups
     constexpr int lds = mk_lds_bytes(4 * WAVES * R);
     static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_commutes_m4r<R, WAVES, LOOK, BYTES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   lds) == hipSuccess;
@@ -337,7 +348,7 @@ static int launch_m4r(const uint8_t *A8, i64 Npad, i64 N, const u64 *BT, i64 Mw_
         hipLaunchKernelGGL((k_commutes_m4r<R, WAVES, LOOK, BYTES>), dim3((unsigned)gx, (unsigned)ny), dim3(64 * WAVES), lds, ctx().stream, A8, Npad, N,
                            BT + y0 * MK_TILE_W, Mw_pad, Wq, klist, nk,
                            BYTES ? reinterpret_cast<u64 *>(static_cast<uint8_t *>(out) + y0 * MK_TILE_W * 64) : static_cast<u64 *>(out) + y0 * MK_TILE_W,
-                           stride, M - y0 * MK_TILE_W * 64, dbg);
+                           stride, M - y0 * MK_TILE_W * 64);
         KERNEL_CHECK();
     }
     return SYMGPU_OK;

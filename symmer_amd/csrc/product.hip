@@ -151,15 +151,16 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
 // ---- the HBM-write stream ------------------------------------------------------------------------
 // RCT = 16-byte chunks per lane, NT = non-temporal stores, rto = outer rows per block (runtime).
 template <int RCT, bool NT>
-__global__ __launch_bounds__(256) void k_mul_rows(const u32x4 *__restrict__ inner, i64 n_chunks, const u32x4 *__restrict__ outer,
-                                                   int Wq, i64 o_count, u32x4 *__restrict__ out, int rto) {
-    const i64 c0 = (i64)blockIdx.x * (256 * RCT) + threadIdx.x;
+__global__ __launch_bounds__(1024) void k_mul_rows(const u32x4 *__restrict__ inner, i64 n_chunks, const u32x4 *__restrict__ outer,
+                                                    int Wq, i64 o_count, u32x4 *__restrict__ out, int rto) {
+    const int BT = blockDim.x;                                      // 256 (default) .. 1024 threads: BT * 16 contiguous bytes per row
+    const i64 c0 = (i64)blockIdx.x * (BT * RCT) + threadIdx.x;
     u32x4 v[RCT];
     int wq[RCT];
     bool ok[RCT];
 #pragma unroll
     for (int k = 0; k < RCT; ++k) {
-        const i64 c = c0 + 256 * k;
+        const i64 c = c0 + BT * k;
         ok[k] = c < n_chunks;
         v[k] = ok[k] ? inner[c] : (u32x4)(0u);
         wq[k] = ok[k] ? (int)(c % Wq) : 0;
@@ -173,23 +174,25 @@ __global__ __launch_bounds__(256) void k_mul_rows(const u32x4 *__restrict__ inne
         for (int k = 0; k < RCT; ++k) {
             if (ok[k]) {
                 u32x4 r = v[k] ^ orow[wq[k]];
-                if (NT) __builtin_nontemporal_store(r, dst + 256 * k);
-                else dst[256 * k] = r;
+                if (NT) __builtin_nontemporal_store(r, dst + BT * k);
+                else dst[BT * k] = r;
             }
         }
     }
 }
 
 // tuning knobs (defaults are the measured best on MI355X; SYMGPU_ROWS_VARIANT="rc,rto,nt" overrides for experiments)
-struct RowsVariant { int rc = 1, rto = 12, nt = 1; bool parsed = false; };
+struct RowsVariant { int rc = 1, rto = 12, nt = 1, threads = 256; bool parsed = false; };
 static RowsVariant g_rv;
 static const RowsVariant &rows_variant() {
     if (!g_rv.parsed) {
         g_rv.parsed = true;
         const char *e = getenv("SYMGPU_ROWS_VARIANT");
         if (e) {
-            int a = 0, b2 = 0, c = 0;
-            if (sscanf(e, "%d,%d,%d", &a, &b2, &c) == 3 && (a == 1 || a == 2 || a == 4 || a == 8) && b2 >= 1) { g_rv.rc = a; g_rv.rto = b2; g_rv.nt = c != 0; }
+            int a = 0, b2 = 0, c = 0, d = 256;
+            const int got = sscanf(e, "%d,%d,%d,%d", &a, &b2, &c, &d);
+            if (got >= 3 && (a == 1 || a == 2 || a == 4 || a == 8) && b2 >= 1) { g_rv.rc = a; g_rv.rto = b2; g_rv.nt = c != 0; }
+            if (got == 4 && (d == 64 || d == 128 || d == 256 || d == 512 || d == 1024)) g_rv.threads = d;
         }
     }
     return g_rv;
@@ -262,7 +265,7 @@ int mul_rows_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 o_begin, i64 o_
     if (Ni == 0 || No <= 0) return SYMGPU_OK;
     const i64 n_chunks = Ni * Wq;
     const RowsVariant &rv = rows_variant();
-    const i64 gx = (n_chunks + 256 * rv.rc - 1) / (256 * rv.rc);
+    const i64 gx = (n_chunks + (i64)rv.threads * rv.rc - 1) / ((i64)rv.threads * rv.rc);
     const i64 max_gy = 65535;
     const i64 gy_total = (No + rv.rto - 1) / rv.rto;
     for (i64 y0 = 0; y0 < gy_total; y0 += max_gy) {
@@ -273,7 +276,7 @@ int mul_rows_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 o_begin, i64 o_
         const u32x4 *po = reinterpret_cast<const u32x4 *>(outer + (o_begin + ooff) * 2 * Wq);
         u32x4 *pd = reinterpret_cast<u32x4 *>(out_rows) + ooff * n_chunks;
         ProfScope prof(0);
-#define LAUNCH_ROWS(RCV, NTV) hipLaunchKernelGGL((k_mul_rows<RCV, NTV>), grid, dim3(256), 0, ctx().stream, pi, n_chunks, po, Wq, No - ooff, pd, rv.rto)
+#define LAUNCH_ROWS(RCV, NTV) hipLaunchKernelGGL((k_mul_rows<RCV, NTV>), grid, dim3(rv.threads), 0, ctx().stream, pi, n_chunks, po, Wq, No - ooff, pd, rv.rto)
         if (rv.nt) {
             if (rv.rc == 1) LAUNCH_ROWS(1, true); else if (rv.rc == 2) LAUNCH_ROWS(2, true); else if (rv.rc == 8) LAUNCH_ROWS(8, true); else LAUNCH_ROWS(4, true);
         } else {
