@@ -46,6 +46,11 @@ def parse():
     ap.add_argument('--left-terms', type=int, default=100000, help='left terms PER GPU')
     ap.add_argument('--right-terms', type=int, default=100000)
     ap.add_argument('--slab-rows', type=int, default=256, help='outer rows per output slab')
+    ap.add_argument('--workload', choices=['product', 'adjacency'], default='product',
+                    help="product (default, the north-star metric) or adjacency = BASELINE cfg5: commutes_termwise adjacency of a fixed "
+                         "--adj-terms x --adj-qubits operator, left-term axis sharded over the ranks (strong scaling)")
+    ap.add_argument('--adj-terms', type=int, default=200000)
+    ap.add_argument('--adj-qubits', type=int, default=2000)
     ap.add_argument('--no-extras', action='store_true')
     ap.add_argument('--no-cpu', action='store_true')
     return ap.parse_args()
@@ -66,6 +71,12 @@ def main():
     _lib.init(local_rank)
     lib = _lib.lib()
     comm = parallel.Communicator.from_env()       # TCP control plane + RCCL data plane when world > 1
+    if args.workload == 'adjacency':
+        out = adjacency(args, comm, rank, world, _lib, DeviceOp, parallel)
+        comm.close()
+        if rank == 0:
+            print(json.dumps(out))
+        return
 
     n, Ni, M = args.qubits, args.left_terms, args.right_terms
     wq = (n + 63) // 64
@@ -192,6 +203,73 @@ def main():
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def adjacency(args, comm, rank, world, _lib, DeviceOp, parallel):
+    """BASELINE cfg5: adjacency matrix (commutes_termwise with itself) of ONE T-term operator, rows sharded over the ranks.
+    Every rank owns T/world consecutive terms: they are its block of the left axis AND its shard of the right operand, so the
+    all-gather that assembles the right operand is also the distribution step.  Step = all-gather + this rank's
+    [T/world, T] block of np.bool_ results, written in 25,000-row slabs into a ring of two device buffers.  Strong scaling."""
+    lib = _lib.lib()
+    n, T = args.adj_qubits, args.adj_terms
+    wq = (n + 63) // 64
+    ts, bounds = parallel.shard_bounds(T, world)
+    b0, b1 = bounds[rank]
+    shard = parallel.padded_random_shard(b1 - b0, ts, n, 555 + rank)
+    full = DeviceOp.alloc(ts * world, wq, with_coeff=True) if comm.gathers else shard
+    slab = min(25000, max(1, b1 - b0))
+    ring = []
+    for _ in range(2):
+        p = ctypes.c_void_p()
+        _lib.check(lib.symgpu_dev_alloc(slab * T, ctypes.byref(p)))
+        ring.append(p)
+
+    def step():
+        if comm.gathers:
+            comm.allgather_op(shard, full, T)
+        k = 0
+        for r0 in range(0, b1 - b0, slab):
+            r1 = min(b1 - b0, r0 + slab)
+            _lib.check(lib.symgpu_commutes_dev(shard.handle, r0, r1, full.handle, ring[k & 1]))
+            k += 1
+
+    for _ in range(args.warmup):
+        step()
+    _lib.check(lib.symgpu_device_sync()); comm.barrier()
+    _lib.check(lib.symgpu_prof_enable(1, 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _lib.check(lib.symgpu_device_sync()); comm.barrier()
+    dt = comm.max_over_ranks(time.perf_counter() - t0)
+    _lib.check(lib.symgpu_prof_enable(1, 0))
+    nl, ms = ctypes.c_int64(0), ctypes.c_double(0)
+    _lib.check(lib.symgpu_prof_read(1, ctypes.addressof(nl), ctypes.addressof(ms)))
+    kt = ms.value / max(1, nl.value) * 1e-3
+    pairs = T * T
+    n_kblocks = 2 * ((n + 7) // 8)
+    launch_rows = (b1 - b0) * args.steps / max(1, nl.value)
+    lds_bytes = launch_rows * n_kblocks * (((T + 63) // 64 + 31) // 32) * 256.0
+    out = {'metric': 'pauli_term_pairs_per_sec', 'value': pairs * args.steps / dt, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+           'dtype': 'u64', 'data': 'synthetic',
+           'config': {'workload': 'commutes_termwise_adjacency', 'n_qubits': n, 'terms': T, 'rows_per_gpu': b1 - b0, 'pairs_per_step': pairs,
+                      'bytes_per_pair': 1, 'slab_rows': slab,
+                      'parallelism': (f'left-axis shard x{world}, all-gather of right rows ({comm.data_plane})' if world > 1 else 'single GPU')},
+           # the contract's roofline object is HBM-side (1 B/pair np.bool_ output); the kernel itself is bound by the LDS table
+           # reads of the Four-Russians product, reported next to it
+           'roofline': {'bound': 'hbm', 'kernel': 'k_commutes_m4r', 'achieved': launch_rows * T / kt / 1e9 if kt else None, 'peak': HBM_PEAK_GBS,
+                        'unit': 'GB/s', 'frac': launch_rows * T / kt / 1e9 / HBM_PEAK_GBS if kt else None, 'traffic': None,
+                        'launches': nl.value, 'avg_launch_ms': kt * 1e3,
+                        'note': 'not HBM-bound: Four-Russians GF(2) product, one 256-byte LDS table entry per row, 8-bit k-block and 2048-column tile',
+                        'lds': {'achieved_GBps': lds_bytes / kt / 1e9 if kt else None, 'peak_GBps': 157286.4,
+                                'frac': lds_bytes / kt / 1e9 / 157286.4 if kt else None,
+                                'peak_source': '256 CUs x 256 B/clk (ds_read_b128) x 2.4 GHz, MI355X_MICROARCH.md LDS table'}}}
+    if comm.degraded:
+        out['degraded'] = comm.degraded
+    for p in ring:
+        _lib.check(lib.symgpu_dev_free(p))
+    return out
+
+
 def timed(fn, reps):
     from symmer_amd import kernels
     fn()

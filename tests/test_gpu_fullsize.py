@@ -172,3 +172,25 @@ def test_bench_line_schema_small_workload():
     for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert key in r, key
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+
+
+def test_bench_adjacency_workload_schema():
+    """`bench.py --workload adjacency` (BASELINE cfg5 shape, reduced): one JSON line, strong scaling, T*T pairs per step."""
+    import json, sys, io, contextlib, importlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    argv, buf = sys.argv, io.StringIO()
+    sys.argv = ['bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1', '--workload', 'adjacency', '--adj-terms', '30000', '--adj-qubits', '300']
+    try:
+        with contextlib.redirect_stdout(buf):
+            bench.main()
+    finally:
+        sys.argv = argv
+    lines = [l for l in buf.getvalue().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['scaling'] == 'strong' and d['config']['workload'] == 'commutes_termwise_adjacency' and d['config']['pairs_per_step'] == 30000 ** 2
+    assert d['value'] > 0 and d['roofline']['bound'] == 'hbm' and d['roofline']['launches'] == 2 * 2      # two 25,000-row slabs per step
+    assert 0 < d['roofline']['lds']['frac'] < 1

@@ -77,3 +77,17 @@ def test_bench_two_ranks_prints_one_json_line():
         assert 'degraded' not in doc and 'rccl' in doc['config']['parallelism']
     else:
         assert 'host-staged' in doc['degraded'] and 'host-staged' in doc['config']['parallelism']
+
+
+@pytest.mark.timeout(900)
+def test_bench_adjacency_two_ranks():
+    """BASELINE cfg5 through bench.py with two ranks (reduced size): the all-gather distributes the operator, every rank computes
+    its block of the adjacency matrix; value counts all T*T pairs."""
+    outs = _launch(['bench.py', '--gpus', '2', '--steps', '1', '--warmup', '1', '--workload', 'adjacency', '--adj-terms', '20000', '--adj-qubits', '500'],
+                   2, {}, timeout=800)
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0, f'rank {r}: rc={rc}\n{o}\n{e[-3000:]}'
+    lines = [l for l in outs[0][1].splitlines() if l.strip()]
+    assert len(lines) == 1 and not outs[1][1].strip()
+    doc = json.loads(lines[0])
+    assert doc['n_gpus'] == 2 and doc['config']['rows_per_gpu'] == 10000 and doc['config']['pairs_per_step'] == 20000 ** 2 and doc['value'] > 0
