@@ -179,7 +179,10 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
                                                      const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L,
                                                      const double *__restrict__ ci, const double *__restrict__ co,
                                                      double thr, int use_thr, u32 *__restrict__ markbits, double *__restrict__ sum_of,
-                                                     i64 chunks_per_wave) {
+                                                     i64 chunks_per_wave, int squared) {
+    // squared (PACKED only, P * P): the keys are the pairs with i >= o; an off-diagonal pair stands for itself and its twin
+    // (o, i), whose coefficient is bit-identical in magnitude (IEEE products and sums commute): it counts twice if the two terms
+    // commute (e even) and not at all if they anticommute (e odd) — it then only marks the first occurrence of its row.
     const int lane = threadIdx.x & 63;
     const int gi = lane / G, gl = lane % G;
     const int C = W / 2;                                             // 16-byte chunks per row
@@ -232,8 +235,13 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
         }
         double2 c; c.x = 0.0; c.y = 0.0;
         if (valid) {
-            if (PACKED) pair_coefficient(ci[2 * i1], ci[2 * i1 + 1], co[2 * o1], co[2 * o1 + 1], L.e(k1), c.x, c.y);
-            else c = reinterpret_cast<const double2 *>(coeff)[t1];
+            if (PACKED) {
+                pair_coefficient(ci[2 * i1], ci[2 * i1 + 1], co[2 * o1], co[2 * o1 + 1], L.e(k1), c.x, c.y);
+                if (squared && i1 != o1) {
+                    if (L.e(k1) & 1) { c.x = 0.0; c.y = 0.0; }
+                    else { c.x = __dadd_rn(c.x, c.x); c.y = __dadd_rn(c.y, c.y); }
+                }
+            } else c = reinterpret_cast<const double2 *>(coeff)[t1];
         }
         if (own) {
             // exact verification of the equal-key neighbours.  P * P: row(i, o) == row(o, i) by commutativity of XOR when both
@@ -509,6 +517,15 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         const char *e = getenv("SYMGPU_CLEANUP_UNPACKED");
         if (e && e[0] == '1') packed = false;
     }
+    // P * P with one device operand for both factors: keys only for the pairs with i >= o (product.hip, KM = 2), weighted 1 / 2 / 0
+    // — valid when exact zeros are dropped anyway (strict |c| > thr with thr >= 0): without a threshold the reference keeps the
+    // rows of anticommuting pairs with coefficient 0, and the sum x + y - x of a row shared with other pairs need not equal y
+    bool squared = packed && inner == outer && Ni == No && ci == co && use_thr && thr >= 0.0;
+    {
+        const char *e = getenv("SYMGPU_CLEANUP_NOSQUARE");             // tests: the general pair path on a squared operator
+        if (e && e[0] == '1') squared = false;
+    }
+    i64 Tk = T;                                                         // number of keys that are sorted (T index space stays)
     Scratch keys, keys2, idx, idx2, heads, collision, hI, hO, pair_coeff, markbits, sum_of;
     SG_TRY(keys.alloc((size_t)T * 8));
     SG_TRY(keys2.alloc((size_t)T * 8));
@@ -527,11 +544,12 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
     u32 *is = nullptr;
     u64 seed = ctx().hash_tab ? ctx().hash_seed : 1;
     bool ok = false;
+    if (squared) Tk = Ni * (Ni + 1) / 2;                                // the pairs with i >= o
     // number of (top) key bits the radix sort orders; the rest is handled by k_fixup_mark / k_fixup_sort
     int nb = 64;
     {
         int lg = 0;
-        while (((i64)1 << lg) < T) ++lg;
+        while (((i64)1 << lg) < Tk) ++lg;
         const int want = (lg + 5 + 7) / 8 * 8;   // ~1-3 % of the keys then share a prefix with another key: cheap local fix-up
         if (want < 64) nb = want;
     }
@@ -546,8 +564,9 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             if (packed) {
                 PairKeyArgs ka;
                 ka.hI = hI.as<u64>(); ka.hO = hO.as<u64>(); ka.keys = keys.as<u64>(); ka.bi = L.bi; ka.bo = L.bo; ka.o_base = 0;
+                ka.squared = squared ? 1 : 0;
                 SG_TRY(mul_keys_dev(inner, Ni, outer, No, W / 2, inner_is_left, ka));
-                SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), T, 64 - nbits, 64, &in_tmp));
+                SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp));
             } else {
                 if (!idx.p) {
                     SG_TRY(idx.alloc((size_t)T * 4));
@@ -566,20 +585,20 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             hipLaunchKernelGGL(k_iota_keys_plain, dim3(grid_for(T)), dim3(256), 0, st, idx.as<u32>(), T);
             KERNEL_CHECK();
         }
-        if (!packed) SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), T, 64 - nbits, 64, &in_tmp));
+        if (!packed) SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), Tk, 64 - nbits, 64, &in_tmp));
         ks = in_tmp ? keys2.as<u64>() : keys.as<u64>();
         is = packed ? nullptr : (in_tmp ? idx2.as<u32>() : idx.as<u32>());
         HIP_TRY(hipMemsetAsync(collision.p, 0, 16, st));
         if (nbits < 64) {
-            HIP_TRY(hipMemsetAsync(heads.p, 0, (size_t)T, st));
+            HIP_TRY(hipMemsetAsync(heads.p, 0, (size_t)Tk, st));
             if (packed) {
-                hipLaunchKernelGGL(k_fixup_mark<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<uint8_t>(), hI.as<u64>(), hO.as<u64>(), L, inner == outer);
-                hipLaunchKernelGGL(k_fixup_sort<true>, dim3(grid_for(T)), dim3(256), 0, st, ks, (u32 *)nullptr, T, 64 - nbits, heads.as<uint8_t>(),
+                hipLaunchKernelGGL(k_fixup_mark<true>, dim3(grid_for(Tk)), dim3(256), 0, st, ks, Tk, 64 - nbits, heads.as<uint8_t>(), hI.as<u64>(), hO.as<u64>(), L, inner == outer);
+                hipLaunchKernelGGL(k_fixup_sort<true>, dim3(grid_for(Tk)), dim3(256), 0, st, ks, (u32 *)nullptr, Tk, 64 - nbits, heads.as<uint8_t>(),
                                    collision.as<u32>() + 1, hI.as<u64>(), hO.as<u64>(), L);
             } else {
-                hipLaunchKernelGGL(k_fixup_mark<false>, dim3(grid_for(T)), dim3(256), 0, st, ks, T, 64 - nbits, heads.as<uint8_t>(), (const u64 *)nullptr,
+                hipLaunchKernelGGL(k_fixup_mark<false>, dim3(grid_for(Tk)), dim3(256), 0, st, ks, Tk, 64 - nbits, heads.as<uint8_t>(), (const u64 *)nullptr,
                                    (const u64 *)nullptr, L, false);
-                hipLaunchKernelGGL(k_fixup_sort<false>, dim3(grid_for(T)), dim3(256), 0, st, ks, is, T, 64 - nbits, heads.as<uint8_t>(),
+                hipLaunchKernelGGL(k_fixup_sort<false>, dim3(grid_for(Tk)), dim3(256), 0, st, ks, is, Tk, 64 - nbits, heads.as<uint8_t>(),
                                    collision.as<u32>() + 1, (const u64 *)nullptr, (const u64 *)nullptr, L);
             }
             KERNEL_CHECK();
@@ -587,7 +606,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         {
             int G = 1;                                   // lanes per verified candidate: one 16-byte chunk each
             while (G < W / 2 && G < 64) G <<= 1;
-            const i64 n_chunks = (T + 63) / 64;
+            const i64 n_chunks = (Tk + 63) / 64;
             const i64 cpw = (n_chunks + 32767) / 32768;           // ~32k wavefronts, each on a contiguous range of chunks
             const i64 n_waves = (n_chunks + cpw - 1) / cpw;
             const dim3 gs((unsigned)((n_waves + 3) / 4));
@@ -595,20 +614,20 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             const double *nud = nullptr;
             HIP_TRY(hipMemsetAsync(markbits.p, 0, (size_t)((T + 31) / 32) * 4, st));
             if (packed)
-                hipLaunchKernelGGL((k_heads_sums<true, true>), gs, dim3(256), 0, st, ks, (const u32 *)nullptr, T, nul, W, inner, (u32)Ni, outer, G, nud,
-                                   collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), L, ci, co, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw);
+                hipLaunchKernelGGL((k_heads_sums<true, true>), gs, dim3(256), 0, st, ks, (const u32 *)nullptr, Tk, nul, W, inner, (u32)Ni, outer, G, nud,
+                                   collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), L, ci, co, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0);
             else if (pair)
-                hipLaunchKernelGGL((k_heads_sums<true, false>), gs, dim3(256), 0, st, ks, is, T, nul, W, inner, (u32)Ni, outer, G, coeff,
-                                   collision.as<u32>(), nul, nul, L, nud, nud, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw);
+                hipLaunchKernelGGL((k_heads_sums<true, false>), gs, dim3(256), 0, st, ks, is, Tk, nul, W, inner, (u32)Ni, outer, G, coeff,
+                                   collision.as<u32>(), nul, nul, L, nud, nud, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0);
             else
-                hipLaunchKernelGGL((k_heads_sums<false, false>), gs, dim3(256), 0, st, ks, is, T, rows, W, nul, 1u, nul, G, coeff,
-                                   collision.as<u32>(), nul, nul, L, nud, nud, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw);
+                hipLaunchKernelGGL((k_heads_sums<false, false>), gs, dim3(256), 0, st, ks, is, Tk, rows, W, nul, 1u, nul, G, coeff,
+                                   collision.as<u32>(), nul, nul, L, nud, nud, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0);
         }
         KERNEL_CHECK();
         u32 hflags[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(hflags, collision.p, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (hflags[1]) { nb = 64; packed = false; continue; }   // a long mixed prefix run: redo with a full 64-bit sort, same seed
+        if (hflags[1]) { nb = 64; packed = false; squared = false; Tk = T; continue; }   // a long mixed prefix run: redo with a full 64-bit sort over all pairs, same seed
         ok = (hflags[0] == 0);
         if (!ok) ++seed;                            // genuine 64-bit hash collision: reseed and retry
     }

@@ -137,9 +137,12 @@ __device__ __forceinline__ void pair_coefficient(double ar, double ai, double br
 // packed pair key of the fused product + cleanup: [hash: 64-F bits][e: 2][o: bo][i: bi], F = bi + bo + 2 (cleanup.hip)
 struct PairKeyArgs {
     const u64 *hI, *hO;     // per-operand row hashes
-    u64 *keys;              // [No*Ni] out, index o*Ni + i
+    u64 *keys;              // [No*Ni] out, index o*Ni + i  (squared mode: compacted, see below)
     int bi, bo;
     i64 o_base;             // absolute index of the launch's first outer row
+    // squared mode (P * P, cleanup.hip): only the pairs with i >= o get a key (the twin (o, i) of an off-diagonal pair is the
+    // same row with the same or the opposite coefficient), compacted in pair-index order: slot(o, i) = o*Ni - o(o-1)/2 + (i - o)
+    int squared = 0;
 };
 
 int mul_coeff_dev(const u64 *inner, const double *ci, i64 Ni, const u64 *outer, const double *co, i64 o_begin, i64 o_end,

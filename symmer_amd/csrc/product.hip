@@ -28,17 +28,24 @@ constexpr int PO = 8;   // outer terms per wave (SGPR operand)
 constexpr int PJ = 4;   // inner terms per lane: i = ibase + 64*b + lane
 constexpr int PW = 4;   // waves per block, stacked along o
 
-// KEYS: instead of the coefficient the kernel emits the packed cleanup key of every pair (hash | phase exponent e | o | i):
-// the 16-byte coefficient is never materialised, the cleanup rebuilds c_i * c_o * i^e from e and the two operand tables.
-template <bool INNER_LEFT, bool KEYS>
+// KM = 0: coefficients.  KM = 1 (keys): instead of the coefficient the kernel emits the packed cleanup key of every pair
+// (hash | phase exponent e | o | i): the 16-byte coefficient is never materialised, the cleanup rebuilds c_i * c_o * i^e from
+// e and the two operand tables.  KM = 2 (keys of a squared operator, both operands the same array): the twins (i, o) / (o, i)
+// of P * P are the same row with the same coefficient magnitude — equal if the two terms commute (e even), opposite if they
+// anticommute (e odd) — and the twin with i > o comes first in pair-index order.  Only the pairs with i >= o get a key, half
+// of them, written compacted in index order (slot = o*Ni - o(o-1)/2 + i - o); the cleanup weights them 1 (i == o), 2
+// (commuting) or 0 (anticommuting: the pair still fixes the first-occurrence position of its row).
+template <bool INNER_LEFT, int KM>
 __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i64 Ipad, i64 Ni, const double *__restrict__ ci,
                                                     const u64 *__restrict__ Ot, i64 Opad, i64 No, const double *__restrict__ co,
                                                     int Wq, double *__restrict__ out /* [(o)*Ni + i][2], o relative to slab */,
                                                     PairKeyArgs ka) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr bool KEYS = KM != 0;
     const i64 o0 = ((i64)blockIdx.y * PW + wave) * PO;   // wave-uniform, relative to the slab
     const i64 ibase = (i64)blockIdx.x * (64 * PJ);
+    if (KM == 2 && ibase + 64 * PJ - 1 < o0 + ka.o_base) return;       // tile strictly below the diagonal: no pair with i >= o
 
     u32 cnt[PO][PJ], flo[PO][PJ], fhi[PO][PJ];
     u32 yi[PJ];
@@ -103,6 +110,23 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
         const i64 o = (o0 + a < No) ? o0 + a : (No > 0 ? No - 1 : 0);    // clamped: rows past the end are computed, never stored
         if (KEYS) ho[a] = ka.hO[o];
         else { cor[a] = co[2 * o]; coi[a] = co[2 * o + 1]; }
+    }
+    if (KM == 2) {
+        const int F = ka.bi + ka.bo + 2;
+        const u64 hmask = ~((1ULL << F) - 1ULL);
+#pragma unroll
+        for (int a = 0; a < PO; ++a) {
+            const i64 o = o0 + a + ka.o_base;                               // absolute outer index
+            if (o0 + a >= No) break;                                        // wave-uniform
+            u64 *dst = ka.keys + (o * Ni - o * (o - 1) / 2 - o);            // + i
+#pragma unroll
+            for (int b = 0; b < PJ; ++b) {
+                const i64 i = ibase + 64 * b + lane;
+                const u64 e = (3u * (yi[b] + (u32)yo[a]) + cnt[a][b] + 2u * (__popc(flo[a][b] ^ fhi[a][b]) & 1u)) & 3u;
+                if (i < Ni && i >= o) dst[i] = ((ka.hI[i] ^ ho[a]) & hmask) | (e << (ka.bi + ka.bo)) | ((u64)o << ka.bi) | (u64)i;
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int b = 0; b < PJ; ++b) {
@@ -217,20 +241,20 @@ static int mul_coeff_launch(const u64 *It, i64 Ipad, const double *ci, i64 Ni, c
         const i64 ny = gy_total - y0 < max_gy ? gy_total - y0 : max_gy;
         const i64 ooff = y0 * PO * PW;
         dim3 grid((unsigned)gx, (unsigned)ny);
-#define LAUNCH_COEFF(L) hipLaunchKernelGGL((k_mul_coeff<L, false>), grid, dim3(256), 0, st, It, Ipad, Ni, ci, ot.as<u64>() + ooff, Opad, \
+#define LAUNCH_COEFF(L) hipLaunchKernelGGL((k_mul_coeff<L, 0>), grid, dim3(256), 0, st, It, Ipad, Ni, ci, ot.as<u64>() + ooff, Opad, \
                                               No - ooff, co + 2 * (o_begin + ooff), Wq, out_coeff + 2 * ooff * Ni, PairKeyArgs())
         if (keys) {
             // key mode runs over the whole outer operand (o_begin == 0); the o field stays absolute through o_base
             PairKeyArgs ka = *keys;
             ka.hO += ooff;
-            ka.keys += ooff * Ni;
+            if (!ka.squared) ka.keys += ooff * Ni;                          // dense keys: slot o*Ni + i; squared: compacted, absolute slots
             ka.o_base = ooff;
-            if (inner_is_left)
-                hipLaunchKernelGGL((k_mul_coeff<true, true>), grid, dim3(256), 0, st, It, Ipad, Ni, (const double *)nullptr, ot.as<u64>() + ooff, Opad, No - ooff,
-                                   (const double *)nullptr, Wq, (double *)nullptr, ka);
-            else
-                hipLaunchKernelGGL((k_mul_coeff<false, true>), grid, dim3(256), 0, st, It, Ipad, Ni, (const double *)nullptr, ot.as<u64>() + ooff, Opad, No - ooff,
-                                   (const double *)nullptr, Wq, (double *)nullptr, ka);
+#define LAUNCH_KEYS(L, M) hipLaunchKernelGGL((k_mul_coeff<L, M>), grid, dim3(256), 0, st, It, Ipad, Ni, (const double *)nullptr, ot.as<u64>() + ooff, Opad, \
+                                                No - ooff, (const double *)nullptr, Wq, (double *)nullptr, ka)
+            if (ka.squared) { LAUNCH_KEYS(true, 2); }                       // P * P: left and right are the same operand
+            else if (inner_is_left) { LAUNCH_KEYS(true, 1); }
+            else { LAUNCH_KEYS(false, 1); }
+#undef LAUNCH_KEYS
         } else {
             if (inner_is_left) LAUNCH_COEFF(true); else LAUNCH_COEFF(false);
         }

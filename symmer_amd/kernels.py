@@ -153,7 +153,8 @@ def mul_cleanup(inner, ci, outer, co, inner_is_left=True, zero_threshold=1e-15, 
     """Fused product + cleanup; the product rows are never materialised.  Products with more than ``max_pairs`` pairs are
     tiled over the outer (slow) index: every slab is cleaned on the device, the concatenation of the cleaned slabs is
     cleaned once more (same first-occurrence order; coefficient sums associate per slab, i.e. within 1e-16 relative)."""
-    inner, outer, ci, co = _rows(inner), _rows(outer), _coeff(ci), _coeff(co)
+    same = outer is inner and co is ci                          # P * P: one device operand serves both factors, which lets the
+    inner, outer, ci, co = _rows(inner), _rows(outer), _coeff(ci), _coeff(co)    # library sort half of the pairs (cleanup.hip)
     assert inner.shape[1] == outer.shape[1]
     ni, no = inner.shape[0], outer.shape[0]
     if ni == 0 or no == 0:
@@ -163,13 +164,14 @@ def mul_cleanup(inner, ci, outer, co, inner_is_left=True, zero_threshold=1e-15, 
     a = DeviceOp.upload(inner, ci)
     try:
         if ni * no <= max_pairs:
-            b = DeviceOp.upload(outer, co)
+            b = a if same else DeviceOp.upload(outer, co)
             out = ctypes.c_void_p()
             try:
                 check(_lib.lib().symgpu_mul_cleanup_dev(a.handle, b.handle, 1 if inner_is_left else 0, thr, use, ctypes.byref(out)))
                 return DeviceOp(out).download()
             finally:
-                b.free()
+                if b is not a:
+                    b.free()
         slab = max(1, max_pairs // ni)
         parts_r, parts_c = [], []
         for o0 in range(0, no, slab):

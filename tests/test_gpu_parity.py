@@ -287,6 +287,35 @@ def test_mul_cleanup_vs_oracle(n, N, M):
         assert rows_nothr.shape[0] == 1 + N * (N - 1) // 2                                # 124,751
 
 
+@pytest.mark.parametrize('n,N', [(100, 500), (3, 700), (1, 50), (70, 1), (1000, 257), (12, 3000)])
+def test_squared_operator_path_equals_general_pair_path(n, N, monkeypatch):
+    """P * P with one device operand sorts only the pairs with i >= o (half of the pairs; the twin (o, i) has the same coefficient if
+    the terms commute and the opposite one if they anticommute, so the pair is weighted 2 or 0 — a zero-weight pair still fixes the
+    first-occurrence position of its row, which small n exercises: n = 1, 3 have 4 / 64 distinct rows) — same rows, same order as
+    the general pair path (SYMGPU_CLEANUP_NOSQUARE=1) and as the oracle; coefficients bit-exact for dyadic inputs; Gaussian
+    coefficients within the tolerance rule (sums associate twin-first)."""
+    rng = np.random.default_rng(900 + n + N)
+    A = PauliwordOp(rng.random((N, 2 * n)) < 0.3, dyadic(rng, N))
+    for thr in (1e-15, 0.0, None):                                # None keeps zero sums: the library must not take the shortcut there
+        fast = kernels.mul_cleanup(A.packed, A.coeff_vec, A.packed, A.coeff_vec, True, thr)
+        monkeypatch.setenv('SYMGPU_CLEANUP_NOSQUARE', '1')
+        slow = kernels.mul_cleanup(A.packed, A.coeff_vec, A.packed, A.coeff_vec, True, thr)
+        monkeypatch.delenv('SYMGPU_CLEANUP_NOSQUARE')
+        assert np.array_equal(fast[0], slow[0]) and np.array_equal(fast[1], slow[1])
+    erows, ecoeff = oc.mul(A.packed, A.coeff_vec, A.packed, A.coeff_vec)
+    R = A * A
+    assert np.array_equal(R.packed, erows) and np.array_equal(R.coeff_vec, ecoeff)
+    G = PauliwordOp(A.symp_matrix, rng.standard_normal(N) + 1j * rng.standard_normal(N))
+    fast = G * G
+    monkeypatch.setenv('SYMGPU_CLEANUP_NOSQUARE', '1')
+    slow = G * G
+    monkeypatch.delenv('SYMGPU_CLEANUP_NOSQUARE')
+    # a row of the n = 1, 3 cases is the sum of thousands of O(1) products (N^2 / 4^n pairs per row): the two association orders
+    # differ by the rounding of such a sum, ~ terms x 1.1e-16 x partial sums, so the 1e-12 bar is scaled by the terms per row
+    per_row = max(1.0, N * N / 4.0 ** min(n, 30))
+    assert_op_equal(fast.symp_matrix, fast.coeff_vec, slow.symp_matrix, slow.coeff_vec, exact=False, tol=TOL * per_row)
+
+
 def test_mul_cleanup_gaussian_tolerance():
     rng = np.random.default_rng(11)
     n, N = 100, 300
