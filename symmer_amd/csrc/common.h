@@ -50,6 +50,12 @@ struct Context {
     // linear-hash tables (cleanup): 8 byte positions x 256 values x {h1,h2}; reseeded on collision
     u64 *hash_tab = nullptr;       // device, [8][256][2]
     u64 hash_seed = 0;
+    // rotation hash join (rotate.hip): persistent open-addressing table of [tag 32 | generation 10 | row index + 1 : 22] entries.
+    // An entry of another generation is empty, so the table is cleared once per 1023 rotations instead of once per rotation.
+    u64 *rot_table = nullptr;
+    size_t rot_table_cap = 0;      // entries (power of two)
+    u32 rot_gen = 0;
+    u32 *rot_flags = nullptr;      // device u32[4]: [0] = generation in which a duplicate input row was seen
 };
 Context &ctx();
 int require_ctx();
@@ -93,6 +99,10 @@ struct symgpu_op_s {
     // 1 = known to hold no two equal rows (result of a cleanup, or of a rotation of such an operator); 0 = unknown.
     // Reset by op_invalidate, i.e. whenever rows change.  The odd-k Clifford rotation needs to know (rotate.hip).
     int dup_free = 0;
+    // cached linear row hashes h1 of rows[0..T) under hash seed `hash_seed` (0 = none): a rotation hands them on to its result
+    // for free (h(P ^ Q) = h(P) ^ h(Q)), so a chain of rotations hashes the operator once.  Dropped by op_invalidate.
+    u64 *hash = nullptr;
+    u64 hash_seed = 0;
 };
 
 namespace symgpu {

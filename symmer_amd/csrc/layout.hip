@@ -45,7 +45,10 @@ static void drop_wordmajor(symgpu_op_s *op) {
 
 void op_invalidate(symgpu_op_s *op) {
     drop_wordmajor(op);
-    if (op) op->dup_free = 0;
+    if (!op) return;
+    op->dup_free = 0;
+    if (op->hash) { dev_free(op->hash); op->hash = nullptr; }
+    op->hash_seed = 0;
 }
 
 int op_wordmajor(symgpu_op_s *op, i64 mult, const u64 **out, i64 *pad) {

@@ -28,10 +28,44 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // HASH: also the linear row hash h1 of cleanup.hip (same tables, same per-lane Horner) for the hash-join fast path.
 __device__ __forceinline__ u64 rot_rotl64(u64 x, int r) { r &= 63; return r ? ((x << r) | (x >> (64 - r))) : x; }
 
-template <bool HASH>
+// Generation-tagged entries of the persistent join table (Context::rot_table): [tag = hash >> 32 | generation : 10 | row + 1 : 22].
+struct JoinTable {
+    u64 *slots;
+    u32 mask;          // capacity - 1
+    u32 gen;           // 1 .. 1023
+    u32 *flags;        // [0] = gen when a duplicate input row was seen
+};
+__device__ __forceinline__ u64 mix64(u64 h) { h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 29; return h; }
+__device__ __forceinline__ u32 jt_gen(u64 v) { return (u32)(v >> 22) & 1023u; }
+__device__ __forceinline__ i64 jt_row(u64 v) { return (i64)(v & 0x3FFFFFULL) - 1; }
+
+// insert row t (hash h) — duplicates (same tag AND same words) raise the flag; one lane per row
+__device__ __forceinline__ void jt_insert(const JoinTable jt, const u64 *__restrict__ rows, int W, i64 t, u64 h) {
+    const u64 entry = (h & 0xFFFFFFFF00000000ULL) | ((u64)jt.gen << 22) | (u64)(t + 1);
+    u32 pos = (u32)mix64(h) & jt.mask;
+    for (;;) {
+        u64 v = __hip_atomic_load(&jt.slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (jt_gen(v) != jt.gen) {                                   // empty (or left over from an earlier rotation): claim it
+            const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&jt.slots[pos]), (unsigned long long)v, (unsigned long long)entry);
+            if (old == v) return;
+            v = old;
+            if (jt_gen(v) != jt.gen) continue;                       // lost the race to a stale writer?  cannot happen, but retry the slot
+        }
+        if ((v >> 32) == (h >> 32)) {                                // same 32-bit tag: duplicate row, or a tag collision
+            const i64 o = jt_row(v);
+            bool same = true;
+            for (int w = 0; w < W; ++w) same &= (rows[o * W + w] == rows[t * W + w]);
+            if (same) { jt.flags[0] = jt.gen; return; }
+        }
+        pos = (pos + 1) & jt.mask;
+    }
+}
+
+// HASH: compute the row hashes (-> hout); otherwise INSERT reads them from hin.  INSERT: put every row into the join table.
+template <bool HASH, bool INSERT>
 __global__ __launch_bounds__(256) void k_rot_analyze(const u64 *__restrict__ rows, i64 T, int Wq, int G, const u64 *__restrict__ q,
                                                       u32 *__restrict__ flags, uint8_t *__restrict__ ph, const u64 *__restrict__ tab_g,
-                                                      u64 *__restrict__ hout) {
+                                                      u64 *__restrict__ hout, const u64 *__restrict__ hin, JoinTable jt) {
     __shared__ u64 tab[HASH ? 8 * 256 : 1];
     if (HASH) {
         for (int k = threadIdx.x; k < 8 * 256; k += 256) tab[k] = tab_g[2 * k];      // h1 entries only
@@ -90,6 +124,7 @@ __global__ __launch_bounds__(256) void k_rot_analyze(const u64 *__restrict__ row
             flags[t] = (u32)pp;
             ph[t] = (uint8_t)((3 * (yp + yq) + yout + 2 * fp) & 3);
             if (HASH) hout[t] = h1;
+            if (INSERT) jt_insert(jt, rows, W, t, HASH ? h1 : hin[t]);
         }
     }
 }
@@ -194,99 +229,64 @@ static int grid_for(i64 n, int block = 256, int cap = 8192) {
 // Output order and sums are those of the reference (base.py:1158-1161 + cleanup): kept commuting rows, kept
 // anticommuting rows with  cos*c_t + (-i sin) i^{e_p} c_p  (first-occurrence entry first), then the kept unmatched product
 // rows; strict |c| > thr everywhere.
-struct RotCounts { u32 nC, nA, nN, dup, nAnti; };
+struct RotCounts { u32 nC, nA, nN, nAnti, dup; };          // dup: a duplicate input row was seen by this call's join-table insert
 
-__device__ __forceinline__ u64 mix64(u64 h) { h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 29; return h; }
-
-__global__ void k_rotf_insert(const u64 *__restrict__ rows, const u64 *__restrict__ h, i64 T, int W, u32 *__restrict__ table, u32 mask,
-                              RotCounts *__restrict__ cnt) {
-    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (i64)gridDim.x * blockDim.x) {
-        const u64 ht = h[t];
-        u32 pos = (u32)mix64(ht) & mask;
-        for (;;) {
-            const u32 old = atomicCAS(&table[pos], 0u, (u32)t + 1u);
-            if (old == 0u) break;
-            const i64 o = (i64)old - 1;
-            if (h[o] == ht) {                                   // same hash: duplicate row (or a 64-bit collision)
-                bool same = true;
-                for (int w = 0; w < W; ++w) same &= (rows[o * W + w] == rows[t * W + w]);
-                if (same) { atomicOr(&cnt->dup, 1u); break; }
-            }
-            pos = (pos + 1) & mask;
-        }
-    }
-}
-
-// G lanes per row.  cls: bit0 kept commuting, bit1 kept anticommuting, bit2 kept new (unmatched product) row.
-__global__ __launch_bounds__(256) void k_rotf_match(const u64 *__restrict__ rows, const double *__restrict__ coeff, const u64 *__restrict__ h, i64 T,
-                                                     int Wq, int G, const u64 *__restrict__ q, u64 hq, const u32 *__restrict__ anti,
-                                                     const uint8_t *__restrict__ ph, const u32 *__restrict__ table, u32 mask, double cos_t,
-                                                     double sin_t, double thr, double *__restrict__ selfc, double *__restrict__ prodc,
-                                                     uint8_t *__restrict__ cls) {
-    const int W = 2 * Wq;
-    const int rows_per_block = 256 / G;
-    const int g = threadIdx.x % G, rsub = threadIdx.x / G;
-    const int lane = threadIdx.x & 63;
-    const u64 gmask = (G == 64) ? ~0ULL : (((1ULL << G) - 1ULL) << (lane - g));
-    for (i64 t0 = (i64)blockIdx.x * rows_per_block; t0 < T; t0 += (i64)gridDim.x * rows_per_block) {
-        const i64 t = t0 + rsub;
-        const bool valid = t < T;
-        const bool is_anti = valid && anti[t];
-        i64 partner = -1;
-        if (__ballot(is_anti) & gmask) {                        // group-uniform
-            const u64 key = h[t] ^ hq;
-            u32 pos = (u32)mix64(key) & mask;
-            for (;;) {
-                const u32 v = table[pos];
-                if (v == 0u) break;
-                const i64 o = (i64)v - 1;
-                if (h[o] == key) {
-                    bool mism = false;
-                    for (int w = g; w < W; w += G) mism |= (rows[o * W + w] != (rows[t * W + w] ^ q[w]));
-                    if (!(__ballot(mism) & gmask)) { partner = o; break; }
-                }
-                pos = (pos + 1) & mask;
-            }
-        }
-        if (g == 0 && valid) {
-            const double re = coeff[2 * t], im = coeff[2 * t + 1];
-            uint8_t c = 0;
-            if (!is_anti) {
-                selfc[2 * t] = re; selfc[2 * t + 1] = im;
-                if (hypot(re, im) > thr) c = 1;
-            } else {
-                double sr = __dmul_rn(re, cos_t), si = __dmul_rn(im, cos_t);
-                if (partner >= 0) {                              // merge: (0 + cos*c_t) + (-i sin) i^{e_p} c_p, in that order
-                    double pr, pi;
-                    phase_mul(coeff[2 * partner], coeff[2 * partner + 1], ph[partner], pr, pi);
-                    sr = __dadd_rn(sr, __dmul_rn(pi, sin_t));
-                    si = __dadd_rn(si, -__dmul_rn(pr, sin_t));
-                } else {                                         // its product row is new
-                    double pr, pi;
-                    phase_mul(re, im, ph[t], pr, pi);
-                    const double nr = __dmul_rn(pi, sin_t), ni = -__dmul_rn(pr, sin_t);
-                    prodc[2 * t] = nr; prodc[2 * t + 1] = ni;
-                    if (hypot(nr, ni) > thr) c |= 4;
-                }
-                selfc[2 * t] = sr; selfc[2 * t + 1] = si;
-                if (hypot(sr, si) > thr) c |= 2;
-            }
-            cls[t] = c;
-        }
-    }
-}
-
-// three exclusive scans (kept-commuting, kept-anticommuting, kept-new) + the anticommuting count, two small launches:
-// per-1024-element block counts, then every block adds the counts of the blocks before it (<= 4096 blocks) to its local ranks.
-__global__ __launch_bounds__(1024) void k_rotf_count(const uint8_t *__restrict__ cls, const u32 *__restrict__ anti, i64 T, u32 *__restrict__ blk) {
+// The same join, ONE lane per row, fused with the per-1024-row block counts (k_rotf_count): probe the generation-tagged table for
+// h(P) ^ h(Q); only a tag hit reads rows (a lane then compares the two rows word by word).  1024 rows per block.
+__global__ __launch_bounds__(1024) void k_rotf_match2(const u64 *__restrict__ rows, const double *__restrict__ coeff, const u64 *__restrict__ h, i64 T,
+                                                       int W, const u64 *__restrict__ q, u64 hq, const u32 *__restrict__ anti,
+                                                       const uint8_t *__restrict__ ph, JoinTable jt, double cos_t, double sin_t, double thr,
+                                                       double *__restrict__ selfc, double *__restrict__ prodc, uint8_t *__restrict__ cls,
+                                                       u32 *__restrict__ blk) {
     __shared__ u32 s_c[4];
     if (threadIdx.x < 4) s_c[threadIdx.x] = 0;
     __syncthreads();
     const i64 t = (i64)blockIdx.x * 1024 + threadIdx.x;
-    const uint8_t c = (t < T) ? cls[t] : 0;
-    const bool a = t < T && anti[t];
+    const bool valid = t < T;
+    const bool is_anti = valid && anti[t];
+    uint8_t c = 0;
+    if (valid) {
+        i64 partner = -1;
+        if (is_anti) {
+            const u64 key = h[t] ^ hq;
+            u32 pos = (u32)mix64(key) & jt.mask;
+            for (;;) {
+                const u64 v = jt.slots[pos];
+                if (jt_gen(v) != jt.gen) break;
+                if ((v >> 32) == (key >> 32)) {
+                    const i64 o = jt_row(v);
+                    bool same = true;
+                    for (int w = 0; w < W; ++w) same &= (rows[o * W + w] == (rows[t * W + w] ^ q[w]));
+                    if (same) { partner = o; break; }
+                }
+                pos = (pos + 1) & jt.mask;
+            }
+        }
+        const double re = coeff[2 * t], im = coeff[2 * t + 1];
+        if (!is_anti) {
+            selfc[2 * t] = re; selfc[2 * t + 1] = im;
+            if (hypot(re, im) > thr) c = 1;
+        } else {
+            double sr = __dmul_rn(re, cos_t), si = __dmul_rn(im, cos_t);
+            if (partner >= 0) {                                  // merge: (0 + cos*c_t) + (-i sin) i^{e_p} c_p, in that order
+                double pr, pi;
+                phase_mul(coeff[2 * partner], coeff[2 * partner + 1], ph[partner], pr, pi);
+                sr = __dadd_rn(sr, __dmul_rn(pi, sin_t));
+                si = __dadd_rn(si, -__dmul_rn(pr, sin_t));
+            } else {                                             // its product row is new
+                double pr, pi;
+                phase_mul(re, im, ph[t], pr, pi);
+                const double nr = __dmul_rn(pi, sin_t), ni = -__dmul_rn(pr, sin_t);
+                prodc[2 * t] = nr; prodc[2 * t + 1] = ni;
+                if (hypot(nr, ni) > thr) c |= 4;
+            }
+            selfc[2 * t] = sr; selfc[2 * t + 1] = si;
+            if (hypot(sr, si) > thr) c |= 2;
+        }
+        cls[t] = c;
+    }
     const int lane = threadIdx.x & 63;
-    const u64 b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4), b3 = __ballot(a);
+    const u64 b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4), b3 = __ballot(is_anti);
     if (lane == 0) {
         atomicAdd(&s_c[0], (u32)__popcll(b0)); atomicAdd(&s_c[1], (u32)__popcll(b1));
         atomicAdd(&s_c[2], (u32)__popcll(b2)); atomicAdd(&s_c[3], (u32)__popcll(b3));
@@ -295,8 +295,11 @@ __global__ __launch_bounds__(1024) void k_rotf_count(const uint8_t *__restrict__
     if (threadIdx.x < 4) blk[blockIdx.x * 4 + threadIdx.x] = s_c[threadIdx.x];
 }
 
+// three exclusive scans (kept-commuting, kept-anticommuting, kept-new) + the anticommuting count: the per-1024-row block counts
+// come from k_rotf_match2 / k_rotc_classify, every block here adds the counts of the blocks before it (<= 4096) to its local ranks.
 __global__ __launch_bounds__(1024) void k_rotf_scan3(const uint8_t *__restrict__ cls, i64 T, const u32 *__restrict__ blk, int n_blk,
-                                                      u32 *__restrict__ pos_self, u32 *__restrict__ pos_new, RotCounts *__restrict__ cnt) {
+                                                      u32 *__restrict__ pos_self, u32 *__restrict__ pos_new, RotCounts *__restrict__ cnt,
+                                                      const u32 *__restrict__ jt_flags, u32 jt_gen_now) {
     __shared__ u32 s_w[3][16];
     __shared__ u32 s_base[4], s_all[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -331,13 +334,17 @@ __global__ __launch_bounds__(1024) void k_rotf_scan3(const uint8_t *__restrict__
         pos_self[t] = (c & 1) ? s_base[0] + off[0] + ex[0] : s_base[1] + off[1] + ex[1];
         pos_new[t] = s_base[2] + off[2] + ex[2];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { cnt->nC = s_all[0]; cnt->nA = s_all[1]; cnt->nN = s_all[2]; cnt->nAnti = s_all[3]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        cnt->nC = s_all[0]; cnt->nA = s_all[1]; cnt->nN = s_all[2]; cnt->nAnti = s_all[3];
+        cnt->dup = (jt_flags && jt_flags[0] == jt_gen_now) ? 1u : 0u;        // one read-back for the counts and the duplicate flag
+    }
 }
 
 __global__ void k_rotf_write(const u32x4 *__restrict__ rows, const u32x4 *__restrict__ q, i64 T, int Wq, const uint8_t *__restrict__ cls,
                              const u32 *__restrict__ pos_self, const u32 *__restrict__ pos_new, const RotCounts *__restrict__ cnt,
                              const double *__restrict__ selfc, const double *__restrict__ prodc, u32x4 *__restrict__ out_rows,
-                             double *__restrict__ out_coeff, int clifford) {
+                             double *__restrict__ out_coeff, int clifford, const u64 *__restrict__ hin, u64 hq, u64 *__restrict__ hout) {
+    // hin / hout (may be null): row hashes of the input and of the result — h is linear, so h(P ^ Q) = h(P) ^ h(Q)
     const i64 total = T * Wq;
     // output order: non-Clifford [commuting | cos * anticommuting | new rows]; Clifford [rotated anticommuting | commuting]
     const i64 baseC = clifford ? (i64)cnt->nA + cnt->nN : 0;
@@ -352,12 +359,12 @@ __global__ void k_rotf_write(const u32x4 *__restrict__ rows, const u32x4 *__rest
         if (k & 3) {
             const i64 d = (k & 1) ? baseC + pos_self[t] : baseA + pos_self[t];
             out_rows[d * Wq + c] = v;
-            if (c == 0) { out_coeff[2 * d] = selfc[2 * t]; out_coeff[2 * d + 1] = selfc[2 * t + 1]; }
+            if (c == 0) { out_coeff[2 * d] = selfc[2 * t]; out_coeff[2 * d + 1] = selfc[2 * t + 1]; if (hout) hout[d] = hin[t]; }
         }
         if (k & 4) {
             const i64 d = baseN + pos_new[t];
             out_rows[d * Wq + c] = v ^ q[c];
-            if (c == 0) { out_coeff[2 * d] = prodc[2 * t]; out_coeff[2 * d + 1] = prodc[2 * t + 1]; }
+            if (c == 0) { out_coeff[2 * d] = prodc[2 * t]; out_coeff[2 * d + 1] = prodc[2 * t + 1]; if (hout) hout[d] = hin[t] ^ hq; }
         }
     }
 }
@@ -410,8 +417,8 @@ __global__ __launch_bounds__(1024) void k_rotc_classify(const u32 *__restrict__ 
 }
 
 // Clifford fast path: analyze (done by the caller) -> classify+count -> scan -> write, one host round trip at the very end.
-static int rotate_fast_clifford(symgpu_op_t in, const u64 *q_dev, const u32 *anti, const uint8_t *ph, int k, double thr, symgpu_op_t *out,
-                                int *all_commute, int *done) {
+static int rotate_fast_clifford(symgpu_op_t in, const u64 *q_dev, const u64 *q_host, const u32 *anti, const uint8_t *ph, int k, double thr,
+                                symgpu_op_t *out, int *all_commute, int *done) {
     hipStream_t st = ctx().stream;
     const i64 T = in->T;
     const int Wq = in->Wq;
@@ -429,13 +436,23 @@ static int rotate_fast_clifford(symgpu_op_t in, const u64 *q_dev, const u32 *ant
     hipLaunchKernelGGL(k_rotc_classify, dim3(n_blk), dim3(1024), 0, st, anti, ph, in->coeff, T, k, thr, cls.as<uint8_t>(), selfc.as<double>(),
                        prodc.as<double>(), blk.as<u32>());
     hipLaunchKernelGGL(k_rotf_scan3, dim3(n_blk), dim3(1024), 0, st, cls.as<uint8_t>(), T, blk.as<u32>(), n_blk, pself.as<u32>(), pnew.as<u32>(),
-                       cnt.as<RotCounts>());
+                       cnt.as<RotCounts>(), (const u32 *)nullptr, 0u);
     KERNEL_CHECK();
     symgpu_op_t res = nullptr;
     SG_TRY(symgpu_op_alloc(T, Wq, 1, &res));                   // a Clifford rotation never adds rows
+    // row hashes, if the operand carries them, are handed on (rotated rows: h ^ h(Q)) so that a later non-Clifford rotation or
+    // duplicate check of the chain does not hash again
+    const u64 *in_hash = (in->hash && ctx().hash_tab && in->hash_seed == ctx().hash_seed) ? in->hash : nullptr;
+    u64 hq = 0;
+    if (in_hash) {
+        hq = host_row_hash(q_host, 2 * Wq);
+        const int rc = dev_alloc((size_t)res->capacity * 8 + 16, (void **)&res->hash);
+        if (rc != SYMGPU_OK) { symgpu_op_free(res); return rc; }
+        res->hash_seed = in->hash_seed;
+    }
     hipLaunchKernelGGL(k_rotf_write, dim3(grid_for(T * Wq)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(in->rows),
                        reinterpret_cast<const u32x4 *>(q_dev), T, Wq, cls.as<uint8_t>(), pself.as<u32>(), pnew.as<u32>(), cnt.as<RotCounts>(),
-                       selfc.as<double>(), prodc.as<double>(), reinterpret_cast<u32x4 *>(res->rows), res->coeff, 1);
+                       selfc.as<double>(), prodc.as<double>(), reinterpret_cast<u32x4 *>(res->rows), res->coeff, 1, in_hash, hq, res->hash);
     RotCounts hc;
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&hc, cnt.p, sizeof(hc), hipMemcpyDeviceToHost, st);
@@ -450,72 +467,103 @@ static int rotate_fast_clifford(symgpu_op_t in, const u64 *q_dev, const u32 *ant
     return SYMGPU_OK;
 }
 
-// Does the operator hold two equal rows?  Same open-addressing insert as the non-Clifford fast path (row hash + word-by-word
-// check); the answer is remembered on the handle.
-static int detect_duplicates(symgpu_op_t in, const u64 *hrows, bool *has_dup) {
-    hipStream_t st = ctx().stream;
-    const i64 T = in->T;
-    u32 cap = 1024;
+// The persistent join table: at least 4 slots per row, a fresh generation per call (cleared when the 10-bit generation wraps).
+static int join_table_for(i64 T, JoinTable *jt) {
+    Context &c = ctx();
+    size_t cap = 1024;
     while ((i64)cap < 4 * T) cap <<= 1;
-    Scratch table, cnt;
-    SG_TRY(table.alloc((size_t)cap * 4));
-    SG_TRY(cnt.alloc(sizeof(RotCounts)));
-    HIP_TRY(hipMemsetAsync(table.p, 0, (size_t)cap * 4, st));
-    HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(RotCounts), st));
-    hipLaunchKernelGGL(k_rotf_insert, dim3(grid_for(T)), dim3(256), 0, st, in->rows, hrows, T, 2 * in->Wq, table.as<u32>(), cap - 1, cnt.as<RotCounts>());
-    KERNEL_CHECK();
-    RotCounts hc;
-    HIP_TRY(hipMemcpyAsync(&hc, cnt.p, sizeof(hc), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    *has_dup = hc.dup != 0;
-    if (!*has_dup) in->dup_free = 1;
+    if (!c.rot_flags) {
+        HIP_TRY(hipMalloc((void **)&c.rot_flags, 16));
+        HIP_TRY(hipMemsetAsync(c.rot_flags, 0, 16, c.stream));
+    }
+    if (cap > c.rot_table_cap) {
+        if (c.rot_table) { HIP_TRY(hipStreamSynchronize(c.stream)); (void)hipFree(c.rot_table); c.rot_table = nullptr; c.rot_table_cap = 0; }
+        HIP_TRY(hipMalloc((void **)&c.rot_table, cap * 8));
+        c.rot_table_cap = cap;
+        c.rot_gen = 0;
+    }
+    if (c.rot_gen == 0 || c.rot_gen >= 1023) {                 // new table, or the generation field wraps: every slot empty again
+        HIP_TRY(hipMemsetAsync(c.rot_table, 0, c.rot_table_cap * 8, c.stream));
+        HIP_TRY(hipMemsetAsync(c.rot_flags, 0, 16, c.stream));
+        c.rot_gen = 0;
+    }
+    ++c.rot_gen;
+    jt->slots = c.rot_table;
+    jt->mask = (u32)(cap - 1);                                 // a call uses the first `cap` slots of a possibly larger table
+    jt->gen = c.rot_gen;
+    jt->flags = c.rot_flags;
     return SYMGPU_OK;
 }
 
+// flags + phase exponents of every row; with `jt` also the join-table insert (duplicate detection included), for which the row
+// hashes are taken from the handle or computed now and cached on it
+static int analyze_rows(symgpu_op_t in, const u64 *q_dev, u32 *anti, uint8_t *ph, const JoinTable *jt) {
+    hipStream_t st = ctx().stream;
+    const i64 T = in->T;
+    const int Wq = in->Wq;
+    int G = 1;
+    while (G < Wq && G < 64) G <<= 1;
+    const int rpb = 256 / G;
+    i64 g = (T + rpb - 1) / rpb;
+    if (g > 1024) g = 1024;
+    const JoinTable none = {nullptr, 0, 0, nullptr};
+    if (!jt) {
+        hipLaunchKernelGGL((k_rot_analyze<false, false>), dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q_dev, anti, ph, (const u64 *)nullptr,
+                           (u64 *)nullptr, (const u64 *)nullptr, none);
+    } else if (in->hash && in->hash_seed == ctx().hash_seed) {
+        hipLaunchKernelGGL((k_rot_analyze<false, true>), dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q_dev, anti, ph, (const u64 *)nullptr,
+                           (u64 *)nullptr, in->hash, *jt);
+    } else {
+        if (in->hash) { dev_free(in->hash); in->hash = nullptr; }
+        SG_TRY(dev_alloc((size_t)in->capacity * 8 + 16, (void **)&in->hash));      // cached on the operand: its next rotation skips the hashing
+        in->hash_seed = ctx().hash_seed;
+        hipLaunchKernelGGL((k_rot_analyze<true, true>), dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q_dev, anti, ph, ctx().hash_tab,
+                           in->hash, (const u64 *)nullptr, *jt);
+    }
+    KERNEL_CHECK();
+    return SYMGPU_OK;
+}
+
+// Non-Clifford rotation as a hash join, four launches and no clearing pass:
+//   k_rot_analyze<.., INSERT>  flags + phase exponents (+ row hashes unless the handle carries them) + insert into the join table
+//   k_rotf_match2              probe h(P) ^ h(Q), verify, classify, coefficients, per-block counts
+//   k_rotf_scan3, k_rotf_write output slots, rows + coefficients + hashes of the result
 // returns SYMGPU_OK with *done = 1 (result in *out / *all_commute) or *done = 0 (duplicate rows: use the general path)
-static int rotate_fast_nonclifford(symgpu_op_t in, const u64 *q_dev, const u64 *q_host, const u32 *anti, const uint8_t *ph, const u64 *hrows, double cos_t,
+static int rotate_fast_nonclifford(symgpu_op_t in, const u64 *q_dev, const u64 *q_host, u32 *anti, uint8_t *ph, double cos_t,
                                    double sin_t, double thr, symgpu_op_t *out, int *all_commute, int *done) {
     hipStream_t st = ctx().stream;
     const i64 T = in->T;
     const int Wq = in->Wq, W = 2 * Wq;
     *done = 0;
-    if (T > ((i64)1 << 22)) return SYMGPU_OK;                  // block-count array of the 2-launch scan: <= 4096 blocks
+    if (T >= ((i64)1 << 22) - 1) return SYMGPU_OK;             // 22-bit row index of a table entry; block-count array of the scan
+    SG_TRY(ensure_hash_tables(ctx().hash_tab ? ctx().hash_seed : 1));
+    const u64 seed = ctx().hash_seed;
     const u64 hq = host_row_hash(q_host, W);
-    u32 cap = 1024;
-    while ((i64)cap < 4 * T) cap <<= 1;
-    Scratch table, selfc, prodc, cls, pself, pnew, cnt, blk;
+    JoinTable jt;
+    SG_TRY(join_table_for(T, &jt));
+    Scratch selfc, prodc, cls, pself, pnew, cnt, blk;
     const int n_blk = (int)((T + 1023) / 1024);
     SG_TRY(blk.alloc((size_t)n_blk * 16));
-    SG_TRY(table.alloc((size_t)cap * 4));
     SG_TRY(selfc.alloc((size_t)T * 16));
     SG_TRY(prodc.alloc((size_t)T * 16));
     SG_TRY(cls.alloc((size_t)T));
     SG_TRY(pself.alloc((size_t)T * 4));
     SG_TRY(pnew.alloc((size_t)T * 4));
     SG_TRY(cnt.alloc(sizeof(RotCounts)));
-    HIP_TRY(hipMemsetAsync(table.p, 0, (size_t)cap * 4, st));
-    HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(RotCounts), st));
-    hipLaunchKernelGGL(k_rotf_insert, dim3(grid_for(T)), dim3(256), 0, st, in->rows, hrows, T, W, table.as<u32>(), cap - 1, cnt.as<RotCounts>());
-    KERNEL_CHECK();
-    int G = 8;
-    while (G < W && G < 64) G <<= 1;
-    {
-        const int rpb = 256 / G;
-        i64 gr = (T + rpb - 1) / rpb;
-        if (gr > 8192) gr = 8192;
-        hipLaunchKernelGGL(k_rotf_match, dim3((unsigned)gr), dim3(256), 0, st, in->rows, in->coeff, hrows, T, Wq, G, q_dev, hq, anti, ph,
-                           table.as<u32>(), cap - 1, cos_t, sin_t, thr, selfc.as<double>(), prodc.as<double>(), cls.as<uint8_t>());
-        KERNEL_CHECK();
-    }
-    hipLaunchKernelGGL(k_rotf_count, dim3(n_blk), dim3(1024), 0, st, cls.as<uint8_t>(), anti, T, blk.as<u32>());
+    SG_TRY(analyze_rows(in, q_dev, anti, ph, &jt));
+    hipLaunchKernelGGL(k_rotf_match2, dim3(n_blk), dim3(1024), 0, st, in->rows, in->coeff, in->hash, T, W, q_dev, hq, anti, ph, jt, cos_t, sin_t, thr,
+                       selfc.as<double>(), prodc.as<double>(), cls.as<uint8_t>(), blk.as<u32>());
     hipLaunchKernelGGL(k_rotf_scan3, dim3(n_blk), dim3(1024), 0, st, cls.as<uint8_t>(), T, blk.as<u32>(), n_blk, pself.as<u32>(), pnew.as<u32>(),
-                       cnt.as<RotCounts>());
+                       cnt.as<RotCounts>(), jt.flags, jt.gen);
     KERNEL_CHECK();
     symgpu_op_t res = nullptr;
     SG_TRY(symgpu_op_alloc(2 * T, Wq, 1, &res));               // upper bound: no host round trip before the write kernel
+    int rc = dev_alloc((size_t)res->capacity * 8 + 16, (void **)&res->hash);
+    if (rc != SYMGPU_OK) { symgpu_op_free(res); return rc; }
+    res->hash_seed = seed;
     hipLaunchKernelGGL(k_rotf_write, dim3(grid_for(T * Wq)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(in->rows),
                        reinterpret_cast<const u32x4 *>(q_dev), T, Wq, cls.as<uint8_t>(), pself.as<u32>(), pnew.as<u32>(), cnt.as<RotCounts>(),
-                       selfc.as<double>(), prodc.as<double>(), reinterpret_cast<u32x4 *>(res->rows), res->coeff, 0);
+                       selfc.as<double>(), prodc.as<double>(), reinterpret_cast<u32x4 *>(res->rows), res->coeff, 0, in->hash, hq, res->hash);
     RotCounts hc;
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&hc, cnt.p, sizeof(hc), hipMemcpyDeviceToHost, st);
@@ -567,37 +615,35 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
     // odd multiples of pi/2 multiply by Q through the reference's __mul__ (merge + threshold on sums): the per-row fast path is
     // only the same thing for an operator without duplicate rows
     const bool need_dup_check = clifford && (clifford_k & 1) && !in->dup_free && !general_only;
-    const bool want_hash = try_fast || need_dup_check;
-    Scratch hrows;
-    int G = 1;
-    while (G < Wq && G < 64) G <<= 1;
-    {
-        const int rpb = 256 / G;
-        i64 g = (T + rpb - 1) / rpb;
-        if (g > 1024) g = 1024;
-        if (want_hash) {
-            SG_TRY(ensure_hash_tables(ctx().hash_tab ? ctx().hash_seed : 1));
-            SG_TRY(hrows.alloc((size_t)T * 8));
-            hipLaunchKernelGGL(k_rot_analyze<true>, dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(),
-                               ctx().hash_tab, hrows.as<u64>());
-        } else {
-            hipLaunchKernelGGL(k_rot_analyze<false>, dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(),
-                               (const u64 *)nullptr, (u64 *)nullptr);
-        }
-        KERNEL_CHECK();
-    }
+    bool analyzed = false, has_dup = false;
     if (try_fast) {
         int done = 0;
-        SG_TRY(rotate_fast_nonclifford(in, q.as<u64>(), q_row_host, anti.as<u32>(), ph.as<uint8_t>(), hrows.as<u64>(), cos_t, sin_t, thr, out, all_commute, &done));
+        SG_TRY(rotate_fast_nonclifford(in, q.as<u64>(), q_row_host, anti.as<u32>(), ph.as<uint8_t>(), cos_t, sin_t, thr, out, all_commute, &done));
         if (done) return SYMGPU_OK;
-        *out = nullptr;
-        *all_commute = 1;
+        *out = nullptr;                                            // duplicate rows, or too many rows for the join: general path;
+        *all_commute = 1;                                          // the flags and phase exponents are in place if the join ran
+        analyzed = T < ((i64)1 << 22) - 1;
     }
-    bool has_dup = false;
-    if (need_dup_check) SG_TRY(detect_duplicates(in, hrows.as<u64>(), &has_dup));
+    if (!analyzed) {
+        if (need_dup_check && T < ((i64)1 << 22) - 1) {
+            // flags + the same join-table insert as the non-Clifford path: does the operator hold two equal rows?
+            SG_TRY(ensure_hash_tables(ctx().hash_tab ? ctx().hash_seed : 1));
+            JoinTable jt;
+            SG_TRY(join_table_for(T, &jt));
+            SG_TRY(analyze_rows(in, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(), &jt));
+            u32 hflag = 0;
+            HIP_TRY(hipMemcpyAsync(&hflag, jt.flags, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            has_dup = hflag == jt.gen;
+            if (!has_dup) in->dup_free = 1;
+        } else {
+            has_dup = need_dup_check;                              // too large for the table: take the merging path
+            SG_TRY(analyze_rows(in, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(), nullptr));
+        }
+    }
     if (clifford && !general_only && !has_dup) {
         int done = 0;
-        SG_TRY(rotate_fast_clifford(in, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(), clifford_k, thr, out, all_commute, &done));
+        SG_TRY(rotate_fast_clifford(in, q.as<u64>(), q_row_host, anti.as<u32>(), ph.as<uint8_t>(), clifford_k, thr, out, all_commute, &done));
         if (done) return SYMGPU_OK;
         *out = nullptr;
         *all_commute = 1;

@@ -1,0 +1,71 @@
+// micro-benchmark: the write pattern of k_mul_rows (product.hip) taken apart.  Output = 256 outer rows x (1e5 inner rows x 256 B).
+//   0: one-shot fill of the same bytes (every thread one 16-byte nt store)           -> the ceiling
+//   1: the kernel's pattern, stores only (block = 4 KiB chunk x 12 outer rows)       -> is the pattern the limit?
+//   2: + the inner chunk loaded once                                                  3: + the outer chunk load per store (= k_mul_rows)
+//   4: as 3, the 12 outer chunks loaded before the first store                       5: as 1 with plain (temporal) stores
+//   6: as 1 with "sc1 nt" stores   7: as 1 with "sc0 sc1" stores
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef long long i64;
+template <int MODE>
+__global__ __launch_bounds__(256) void k(const u32x4 *__restrict__ inner, i64 n_chunks, const u32x4 *__restrict__ outer, int Wq, i64 o_count,
+                                         u32x4 *__restrict__ out, int rto) {
+    const i64 c0 = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (MODE == 0) {
+        const i64 i = ((i64)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        if (i < n_chunks * o_count) { u32x4 x = (u32x4)((unsigned)i); __builtin_nontemporal_store(x, out + i); }
+        return;
+    }
+    if (c0 >= n_chunks) return;
+    u32x4 v = MODE >= 2 && MODE <= 4 ? inner[c0] : (u32x4)((unsigned)c0);
+    const int wq = (int)(c0 % Wq);
+    const i64 ob = (i64)blockIdx.y * rto, oe = ob + rto < o_count ? ob + rto : o_count;
+    if (MODE == 4) {
+        u32x4 r[12];
+#pragma unroll
+        for (int k2 = 0; k2 < 12; ++k2) r[k2] = (ob + k2 < oe) ? outer[(ob + k2) * Wq + wq] : (u32x4)(0u);
+#pragma unroll
+        for (int k2 = 0; k2 < 12; ++k2) if (ob + k2 < oe) __builtin_nontemporal_store(v ^ r[k2], out + (ob + k2) * n_chunks + c0);
+        return;
+    }
+    for (i64 o = ob; o < oe; ++o) {
+        u32x4 r = v;
+        if (MODE == 3) r = v ^ outer[o * Wq + wq];
+        else r.x ^= (unsigned)o;
+        u32x4 *dst = out + o * n_chunks + c0;
+        if (MODE == 5) *dst = r;
+        else if (MODE == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(dst), "v"(r) : "memory");
+        else if (MODE == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(r) : "memory");
+        else __builtin_nontemporal_store(r, dst);
+    }
+}
+template <int MODE> void run(const char *name, const u32x4 *in, const u32x4 *outer, u32x4 *out) {
+    const i64 Ni = 100000, No = 256; const int Wq = 16, rto = 12;
+    const i64 n_chunks = Ni * Wq;
+    dim3 grid((unsigned)((n_chunks + 255) / 256), MODE == 0 ? (unsigned)No : (unsigned)((No + rto - 1) / rto));
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 6; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(k<MODE>, grid, dim3(256), 0, 0, in, n_chunks, outer, Wq, No, out, rto);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    printf("%-52s %.3f ms  %.2f TB/s\n", name, best, (double)n_chunks * No * 16 / (best * 1e-3) / 1e12);
+}
+int main() {
+    u32x4 *in, *outer, *out;
+    (void)hipMalloc(&in, 100000ull * 256); (void)hipMalloc(&outer, 256ull * 256); (void)hipMalloc(&out, 256ull * 100000 * 256);
+    (void)hipMemset(in, 1, 100000ull * 256); (void)hipMemset(outer, 2, 256ull * 256);
+    run<0>("0 one-shot fill", in, outer, out);
+    run<1>("1 pattern, stores only", in, outer, out);
+    run<2>("2 + inner chunk load", in, outer, out);
+    run<3>("3 + outer chunk load per store (= k_mul_rows)", in, outer, out);
+    run<4>("4 outer chunks loaded before the stores", in, outer, out);
+    run<5>("5 pattern, plain stores", in, outer, out);
+    run<6>("6 pattern, sc1 nt stores", in, outer, out);
+    run<7>("7 pattern, sc0 sc1 stores", in, outer, out);
+    return 0;
+}
