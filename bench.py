@@ -341,6 +341,15 @@ def extras(_lib, kernels, DeviceOp):
                            'chain4_seconds': t_chain, 'chain_terms': terms,
                            'clifford_chain': {'rotations': n_rot, 'seconds_per_rotation': t_cl, 'term_pairs_per_s': 1e5 / t_cl}}
     P.free()
+    # README claim 1 (a depth-2,000 Clifford circuit on 1,000 qubits "in one second"): 2,000 Clifford rotations of a 64-term,
+    # 1,000-qubit observable through perform_rotations — one single-workgroup launch for the whole run (rotate.hip)
+    rng_c = np.random.default_rng(1240)
+    obs = PauliwordOp(rng_c.random((64, 2000)) < 0.3, rng_c.standard_normal(64) + 0j).cleanup()
+    rots = [(PauliwordOp(rng_c.random((1, 2000)) < 0.02, [1]), float(rng_c.integers(1, 4)) * np.pi / 2) for _ in range(2000)]
+    obs.perform_rotations(rots[:20])
+    t0 = time.perf_counter(); rot_obs = obs.perform_rotations(rots); t_circ = time.perf_counter() - t0
+    ex['cfg2_rotation']['clifford_circuit_2000_rotations_64_terms'] = {'seconds': t_circ, 'seconds_per_rotation': t_circ / 2000, 'terms_out': rot_obs.n_terms,
+                                                                       'call': 'PauliwordOp.perform_rotations (Python API: upload, one chain launch, download)'}
     # cfg5 slice: 2,000 qubits, 25,000 x 200,000 commutation block (one rank's share of the 8-GPU adjacency)
     C = DeviceOp.random(200000, 2000, 0.3, seed=1239)
     nrow = 25000

@@ -484,6 +484,7 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
         if (e == hipSuccess) e = hipStreamSynchronize(st);   // the scratch buffers are freed on return; keep ordering simple
         if (e != hipSuccess) { symgpu_op_free(res); return hip_fail(e, "cleanup emit", __FILE__, __LINE__); }
     }
+    res->dup_free = 1;                                          // merged: no two equal rows
     *out = res;
     return SYMGPU_OK;
 }

@@ -580,6 +580,112 @@ static int rotate_fast_nonclifford(symgpu_op_t in, const u64 *q_dev, const u64 *
     return SYMGPU_OK;
 }
 
+// ---- a whole chain of Clifford rotations in ONE launch (small operators) ------------------------------------------------------
+// perform_rotations / CircuitSymmerlator apply thousands of pi/2-multiples to an operator of a few (hundred) terms: per rotation the
+// launches and the count read-back of the general path cost 60 us, the data movement nothing.  For an operator that is CLEAN —
+// no duplicate rows and every |c| > 1e-15, i.e. it has been through cleanup(), which is what perform_rotations guarantees after
+// its first step — a Clifford rotation drops nothing and merges nothing (base.py:1139-1154 followed by cleanup(), :1185): it is
+// a stable partition [anticommuting | commuting] with row ^= Q and c *= i^e (-i) (odd k), c = -c (k in {2,3}) on the anticommuting
+// part, or nothing at all if every term commutes.  One workgroup keeps flags, phase exponents and slots in LDS and ping-pongs
+// the rows between two global buffers (L2 resident), one block barrier per phase.
+constexpr int CHAIN_TMAX = 8192;               // rows: 8 per thread of the slot scan
+
+__global__ __launch_bounds__(1024) void k_clifford_chain(u64 *__restrict__ rowsA, double *__restrict__ coeffA, u64 *__restrict__ rowsB,
+                                                          double *__restrict__ coeffB, int T, int Wq, int G, const u64 *__restrict__ qs,
+                                                          const int *__restrict__ ks, int K, int *__restrict__ result_in_b) {
+    __shared__ uint8_t s_anti[CHAIN_TMAX], s_ph[CHAIN_TMAX];
+    __shared__ u32 s_pos[CHAIN_TMAX];
+    __shared__ u32 s_wsum[16], s_total;
+    const int W = 2 * Wq;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = threadIdx.x % G, rsub = threadIdx.x / G, rows_per_pass = 1024 / G;
+    u64 *cur_r = rowsA, *nxt_r = rowsB;
+    double *cur_c = coeffA, *nxt_c = coeffB;
+    int in_b = 0;
+    for (int r = 0; r < K; ++r) {
+        const u64 *q = qs + (i64)r * W;
+        const int k = ks[r];
+        // ---- phase 1: anticommutation flag and phase exponent of every row (G lanes per row, as k_rot_analyze) ----
+        int yq = 0;
+        for (int w = 0; w < Wq; ++w) yq += __popcll(q[w] & q[Wq + w]);
+        for (int t0 = 0; t0 < T; t0 += rows_per_pass) {
+            const int t = t0 + rsub;
+            u64 par = 0, flip = 0;
+            int yp = 0, yout = 0;
+            if (t < T) {
+                const u64 *row = cur_r + (i64)t * W;
+                for (int w = g; w < Wq; w += G) {
+                    const u64 x = row[w], z = row[Wq + w], xq = q[w], zq = q[Wq + w];
+                    par ^= (x & zq) ^ (z & xq);
+                    flip ^= x & zq;
+                    yp += __popcll(x & z);
+                    yout += __popcll((x ^ xq) & (z ^ zq));
+                }
+            }
+            int pp = __popcll(par) & 1, fp = __popcll(flip) & 1;
+            for (int off = G >> 1; off > 0; off >>= 1) {
+                pp ^= __shfl_xor(pp, off);
+                fp ^= __shfl_xor(fp, off);
+                yp += __shfl_xor(yp, off);
+                yout += __shfl_xor(yout, off);
+            }
+            if (g == 0 && t < T) {
+                s_anti[t] = (uint8_t)pp;
+                s_ph[t] = (uint8_t)((3 * (yp + yq) + yout + 2 * fp) & 3);
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: slots of the stable partition [anticommuting | commuting]: thread i owns rows 8i .. 8i+7 ----
+        u32 mine = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int t = 8 * (int)threadIdx.x + j; if (t < T) mine += s_anti[t]; }
+        u32 incl = mine;
+        for (int off = 1; off < 64; off <<= 1) { const u32 v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) { u32 acc = 0; for (int w2 = 0; w2 < 16; ++w2) { const u32 v = s_wsum[w2]; s_wsum[w2] = acc; acc += v; } s_total = acc; }
+        __syncthreads();
+        const u32 n_anti = s_total;
+        if (n_anti == 0) { __syncthreads(); continue; }              // every term commutes with Q: identity (base.py:1131-1133)
+        {
+            u32 a_before = s_wsum[wave] + incl - mine;                // anticommuting rows before row 8i
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = 8 * (int)threadIdx.x + j;
+                if (t < T) {
+                    const bool a = s_anti[t];
+                    s_pos[t] = a ? a_before : n_anti + ((u32)t - a_before);
+                    a_before += a;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: rows and coefficients to their slots in the other buffer ----
+        for (int t0 = 0; t0 < T; t0 += rows_per_pass) {
+            const int t = t0 + rsub;
+            if (t < T) {
+                const bool a = s_anti[t];
+                const bool flipq = a && (k & 1);
+                const u64 *row = cur_r + (i64)t * W;
+                u64 *dst = nxt_r + (i64)s_pos[t] * W;
+                for (int w = g; w < W; w += G) dst[w] = row[w] ^ (flipq ? q[w] : 0ULL);
+                if (g == 0) {
+                    double re = cur_c[2 * t], im = cur_c[2 * t + 1];
+                    if (a) {
+                        if (k & 1) { double x, y; phase_mul(re, im, s_ph[t], x, y); re = y; im = -x; }     // c * i^e * (-i)
+                        if (k == 2 || k == 3) { re = -re; im = -im; }
+                    }
+                    nxt_c[2 * s_pos[t]] = re; nxt_c[2 * s_pos[t] + 1] = im;
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        { u64 *tr = cur_r; cur_r = nxt_r; nxt_r = tr; double *tc = cur_c; cur_c = nxt_c; nxt_c = tc; in_b ^= 1; }
+    }
+    if (threadIdx.x == 0) *result_in_b = in_b;
+}
+
 }  // namespace symgpu
 
 using namespace symgpu;
@@ -708,6 +814,7 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
         symgpu_op_free(stack);
         if (rc != SYMGPU_OK) return rc;
         if (e != hipSuccess) { symgpu_op_free(res); return hip_fail(e, "rotate Clifford merge", __FILE__, __LINE__); }
+        res->dup_free = in->dup_free;                              // merged rotated rows + the untouched commuting rows
         *out = res;
         return SYMGPU_OK;
     }
@@ -740,6 +847,54 @@ int symgpu_rotate_single(const uint64_t *rows, const double *coeff, int64_t N, i
     }
     symgpu_op_free(res);
     return rc;
+}
+
+int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host, const int *ks_host, int64_t K, symgpu_op_t *out) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(in && out && K >= 0 && (K == 0 || (q_rows_host && ks_host)), "rotate_clifford_chain_dev: null argument");
+    SG_REQUIRE(in->coeff || in->T == 0, "rotate_clifford_chain_dev: operator has no coefficients");
+    SG_REQUIRE(in->dup_free, "rotate_clifford_chain_dev: the operator must come from a cleanup (no duplicate rows, |c| > threshold)");
+    SG_REQUIRE(in->T <= CHAIN_TMAX, "rotate_clifford_chain_dev: more rows than the single-workgroup chain handles (rotate one by one)");
+    for (i64 r = 0; r < K; ++r) SG_REQUIRE(ks_host[r] >= 0 && ks_host[r] <= 3, "rotate_clifford_chain_dev: k must be 0..3 (see rotation_args)");
+    hipStream_t st = ctx().stream;
+    const i64 T = in->T;
+    const int Wq = in->Wq, W = 2 * Wq;
+    *out = nullptr;
+    symgpu_op_t a = nullptr, b = nullptr;
+    SG_TRY(symgpu_op_alloc(T > 0 ? T : 1, Wq, 1, &a));
+    int rc = symgpu_op_alloc(T > 0 ? T : 1, Wq, 1, &b);
+    if (rc != SYMGPU_OK) { symgpu_op_free(a); return rc; }
+    Scratch qs, ks, which;
+    hipError_t e = hipSuccess;
+    int in_b = 0;
+    if (T > 0) {
+        e = hipMemcpyAsync(a->rows, in->rows, (size_t)T * W * 8, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(a->coeff, in->coeff, (size_t)T * 16, hipMemcpyDeviceToDevice, st);
+    }
+    if (e == hipSuccess && T > 0 && K > 0) {
+        rc = qs.alloc((size_t)K * W * 8);
+        if (rc == SYMGPU_OK) rc = ks.alloc((size_t)K * 4);
+        if (rc == SYMGPU_OK) rc = which.alloc(16);
+        if (rc != SYMGPU_OK) { symgpu_op_free(a); symgpu_op_free(b); return rc; }
+        e = hipMemcpyAsync(qs.p, q_rows_host, (size_t)K * W * 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(ks.p, ks_host, (size_t)K * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            int G = 1;
+            while (G < Wq && G < 64) G <<= 1;
+            hipLaunchKernelGGL(k_clifford_chain, dim3(1), dim3(1024), 0, st, a->rows, a->coeff, b->rows, b->coeff, (int)T, Wq, G, qs.as<u64>(),
+                               ks.as<int>(), (int)K, which.as<int>());
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&in_b, which.p, 4, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { symgpu_op_free(a); symgpu_op_free(b); return hip_fail(e, "rotate_clifford_chain_dev", __FILE__, __LINE__); }
+    symgpu_op_t res = in_b ? b : a;
+    symgpu_op_free(in_b ? a : b);
+    res->T = T;
+    res->dup_free = 1;                                              // a permutation of distinct rows XORed with Q on a Q-anticommuting subset
+    *out = res;
+    return SYMGPU_OK;
 }
 
 }  // extern "C"

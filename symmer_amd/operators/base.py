@@ -495,7 +495,9 @@ class PauliwordOp:
         # the first rotation of a user-supplied operator — and is skipped for the rest of the chain.
         clean = False
         try:
-            for pauli_rotation, angle in rotations:
+            step, n_rot = 0, len(rotations)
+            while step < n_rot:
+                pauli_rotation, angle = rotations[step]
                 assert pauli_rotation.n_terms == 1, 'Only rotation by single Pauliword allowed here'
                 assert pauli_rotation.n_qubits == self.n_qubits, 'Pauliwords defined for different number of qubits'
                 if angle is None:
@@ -505,6 +507,29 @@ class PauliwordOp:
                 if getattr(angle, 'imag', 0) != 0:
                     warnings.warn('Complex component in angle: this will be ignored.')
                 angle = float(np.real(angle))
+                if clean and 0 < dev.n_terms <= kernels.CLIFFORD_CHAIN_MAX_TERMS and kernels.rotation_args(angle)[2] >= 0:
+                    # A run of Clifford rotations of a clean, small operator (the circuit simulator's case) is ONE launch: no step
+                    # drops or merges anything (|c| is unchanged, distinct rows stay distinct), so the per-step cleanup() of the
+                    # reference is the identity and only the stable partition + row ^= Q + phase remains (csrc/rotate.hip).
+                    q_rows, ks = [pauli_rotation.packed[0]], [kernels.rotation_args(angle)[2]]
+                    step += 1
+                    while step < n_rot:
+                        nxt, nxt_angle = rotations[step]
+                        nxt_angle = np.pi / 2 if nxt_angle is None else nxt_angle
+                        if nxt.n_terms != 1 or nxt.n_qubits != self.n_qubits or getattr(nxt_angle, 'imag', 0) != 0:
+                            break                                   # let the single-step branch raise / warn
+                        k = kernels.rotation_args(float(np.real(nxt_angle)))[2]
+                        if k < 0:
+                            break
+                        if nxt.coeff_vec[0] != 1:
+                            warnings.warn(f'Pword coefficient {nxt.coeff_vec[0]: .8f} has been set to 1')
+                        q_rows.append(nxt.packed[0]); ks.append(k)
+                        step += 1
+                    res = kernels.rotate_clifford_chain_dev(dev, np.vstack(q_rows), ks)
+                    dev.free()
+                    dev = res
+                    continue
+                step += 1
                 if dev.n_terms > 0:
                     res, all_commute = kernels.rotate_single_dev(dev, pauli_rotation.packed[0], angle)
                     if not all_commute:

@@ -153,6 +153,72 @@ def test_rotation_chain_from_operator_with_duplicates():
     assert_op_equal(R.symp_matrix, R.coeff_vec, er, ec, exact=False, tol=TOL)
 
 
+@pytest.mark.parametrize('n,T,K', [(1000, 1, 300), (70, 37, 200), (5, 60, 120), (130, 1500, 60), (64, 1536, 30), (64, 1537, 12), (1, 4, 50)])
+def test_clifford_chain_single_launch_vs_oracle(n, T, K):
+    """perform_rotations with runs of Clifford rotations on a small clean operator = ONE launch per run (symgpu_rotate_clifford_chain_dev):
+    rows, row order and coefficients (exact phases: bit-exact) against the step-by-step oracle, every k in -2..5, rotations that
+    commute with everything, a non-Clifford rotation in the middle (splits the run), 1536 / 1537 terms (chain policy limit /
+    one-by-one)."""
+    rng = np.random.default_rng(5000 + n + T)
+    symp = rng.random((T, 2 * n)) < (0.3 if n > 1 else 0.5)
+    P = PauliwordOp(symp, dyadic(rng, T)).cleanup()
+    rots = []
+    for j in range(K):
+        q = rng.random(2 * n) < 0.4
+        if j % 17 == 5:
+            q[:] = False                                           # identity: commutes with everything
+        rots.append((q, float(rng.integers(-2, 6)) * np.pi / 2))
+    if K > 100 and P.n_terms < 500:
+        rots[K // 2] = (rots[K // 2][0], 0.3)                      # one non-Clifford step: the run is split around it
+    R = P.perform_rotations([(PauliwordOp(q.reshape(1, -1), [1]), a) for q, a in rots])
+    er, ec = onp.perform_rotations(P.symp_matrix, P.coeff_vec, rots)
+    exact = not any(abs(a - 0.3) < 1e-12 for _, a in rots)
+    assert_op_equal(R.symp_matrix, R.coeff_vec, er, ec, exact=exact, tol=TOL)
+
+
+def test_clifford_chain_kernel_at_its_row_limit():
+    """The chain kernel itself at 8192 rows (its limit; perform_rotations stops using it at 1536) against the one-by-one path."""
+    from symmer_amd.kernels import DeviceOp
+    rng = np.random.default_rng(8)
+    n, T, K = 100, kernels.CLIFFORD_CHAIN_KERNEL_LIMIT, 9
+    P = PauliwordOp(rng.random((T, 2 * n)) < 0.3, dyadic(rng, T)).cleanup()
+    dev = kernels.cleanup_dev(DeviceOp.upload(P.packed, P.coeff_vec))
+    assert dev.n_terms <= T
+    qs = packing.pack_rows(rng.random((K, 2 * n)) < 0.3)
+    ks = np.array([1, 3, 2, 0, 1, 1, 3, 2, 1], dtype=np.int32)
+    out = kernels.rotate_clifford_chain_dev(dev, qs, ks)
+    cur = dev
+    for j in range(K):
+        res, allc = kernels.rotate_single_dev(cur, qs[j], float(ks[j]) * np.pi / 2)
+        if not allc:
+            if cur is not dev:
+                cur.free()
+            cur = res
+    r0, c0 = out.download(); r1, c1 = cur.download()
+    assert np.array_equal(r0, r1) and np.array_equal(c0, c1)
+    for h in {id(dev): dev, id(out): out, id(cur): cur}.values():
+        h.free()
+
+
+def test_clifford_chain_abi_refuses_unclean_or_large_operators():
+    from symmer_amd import _lib
+    from symmer_amd.kernels import DeviceOp
+    rng = np.random.default_rng(3)
+    rows = packing.pack_rows(rng.random((10, 20)) < 0.5)
+    raw = DeviceOp.upload(rows, np.ones(10, dtype=complex))          # not from a cleanup: duplicate status unknown
+    q = packing.pack_rows(rng.random((2, 20)) < 0.5)
+    with pytest.raises(_lib.SymgpuError):
+        kernels.rotate_clifford_chain_dev(raw, q, [1, 3])
+    clean = kernels.cleanup_dev(raw)
+    with pytest.raises(_lib.SymgpuError):
+        kernels.rotate_clifford_chain_dev(clean, q, [1, 7])           # k outside 0..3
+    out = kernels.rotate_clifford_chain_dev(clean, q[:0], np.zeros(0, dtype=np.int32))    # empty chain: a copy
+    r0, c0 = clean.download(); r1, c1 = out.download()
+    assert np.array_equal(r0, r1) and np.array_equal(c0, c1)
+    for h in (raw, clean, out):
+        h.free()
+
+
 def test_large_angle_warning_only_when_the_rotation_acts():
     """base.py:1156-1157: warned on the non-Clifford branch only, i.e. not when every term commutes with the rotation axis."""
     import warnings as w
