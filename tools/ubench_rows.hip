@@ -40,8 +40,46 @@ __global__ __launch_bounds__(256) void k(const u32x4 *__restrict__ inner, i64 n_
         else __builtin_nontemporal_store(r, dst);
     }
 }
-template <int MODE> void run(const char *name, const u32x4 *in, const u32x4 *outer, u32x4 *out) {
-    const i64 Ni = 100000, No = 256; const int Wq = 16, rto = 12;
+// persistent variant: one workgroup per CU owns a contiguous segment of the inner operand (held in LDS) and writes that segment of
+// every outer row in turn: all CUs write the same output row at (roughly) the same time, like a sequential fill.
+template <bool LDSIN>
+__global__ __launch_bounds__(1024) void k_persist(const u32x4 *__restrict__ inner, i64 n_chunks, const u32x4 *__restrict__ outer, int Wq, i64 o_count,
+                                                   u32x4 *__restrict__ out) {
+    extern __shared__ u32x4 seg[];
+    const i64 per = (n_chunks + gridDim.x - 1) / gridDim.x;
+    const i64 c_lo = (i64)blockIdx.x * per, c_hi = c_lo + per < n_chunks ? c_lo + per : n_chunks;
+    if (LDSIN) {
+        for (i64 c = c_lo + threadIdx.x; c < c_hi; c += 1024) seg[c - c_lo] = inner[c];
+        __syncthreads();
+    }
+    for (i64 o = 0; o < o_count; ++o) {
+        const u32x4 *orow = outer + o * Wq;
+        u32x4 *dst = out + o * n_chunks;
+        for (i64 c = c_lo + threadIdx.x; c < c_hi; c += 1024) {
+            u32x4 v = LDSIN ? seg[c - c_lo] : (u32x4)((unsigned)c);
+            if (LDSIN) v ^= orow[c % Wq]; else v.x ^= (unsigned)o;
+            __builtin_nontemporal_store(v, dst + c);
+        }
+    }
+}
+template <bool LDSIN> void run_persist(const char *name, const u32x4 *in, const u32x4 *outer, u32x4 *out, int blocks) {
+    const i64 Ni = 100000, No = 256; const int Wq = 16;
+    const i64 n_chunks = Ni * Wq;
+    const size_t lds = LDSIN ? (size_t)((n_chunks + blocks - 1) / blocks) * 16 : 0;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_persist<LDSIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 6; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(k_persist<LDSIN>, dim3(blocks), dim3(1024), lds, 0, in, n_chunks, outer, Wq, No, out);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    printf("%-52s blocks=%4d lds=%6zu  %.3f ms  %.2f TB/s\n", name, blocks, lds, best, (double)n_chunks * No * 16 / (best * 1e-3) / 1e12);
+}
+template <int MODE> void run(const char *name, const u32x4 *in, const u32x4 *outer, u32x4 *out, int rto = 12) {
+    const i64 Ni = 100000, No = 256; const int Wq = 16;
     const i64 n_chunks = Ni * Wq;
     dim3 grid((unsigned)((n_chunks + 255) / 256), MODE == 0 ? (unsigned)No : (unsigned)((No + rto - 1) / rto));
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -53,7 +91,7 @@ template <int MODE> void run(const char *name, const u32x4 *in, const u32x4 *out
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         if (rep && ms < best) best = ms;
     }
-    printf("%-52s %.3f ms  %.2f TB/s\n", name, best, (double)n_chunks * No * 16 / (best * 1e-3) / 1e12);
+    printf("%-52s rto=%3d  %.3f ms  %.2f TB/s\n", name, rto, best, (double)n_chunks * No * 16 / (best * 1e-3) / 1e12);
 }
 int main() {
     u32x4 *in, *outer, *out;
@@ -67,5 +105,12 @@ int main() {
     run<5>("5 pattern, plain stores", in, outer, out);
     run<6>("6 pattern, sc1 nt stores", in, outer, out);
     run<7>("7 pattern, sc0 sc1 stores", in, outer, out);
+    run_persist<false>("8 persistent, stores only", in, outer, out, 256);
+    run_persist<false>("8 persistent, stores only", in, outer, out, 512);
+    run_persist<false>("8 persistent, stores only", in, outer, out, 1024);
+    run_persist<true>("9 persistent, inner segment in LDS", in, outer, out, 256);
+    run_persist<true>("9 persistent, inner segment in LDS", in, outer, out, 512);
+    for (int rto : {1, 2, 3, 4, 6, 8, 16, 32, 64, 256}) run<1>("1 pattern, stores only", in, outer, out, rto);
+    for (int rto : {1, 2, 4, 8, 32, 256}) run<3>("3 full kernel", in, outer, out, rto);
     return 0;
 }
