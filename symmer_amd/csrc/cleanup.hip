@@ -172,6 +172,21 @@ __device__ __forceinline__ bool differs(u32x4 a, u32x4 b) {
 // owner verifies them); the leading non-head positions of a range therefore belong to the previous wave and are skipped.
 // A term that survives the strict |c| > thr test sets the bit of its first input index in `markbits` (T bits: 12.5 MB for
 // 1e8 terms, cache resident) and files its sum under that index in `sum_of` for the output stage.
+// squared mode: slot of the pair (o, i), i >= o, in pair-index order, and back
+__device__ __forceinline__ u32 tri_slot(u32 o, u32 i, u32 N) { return (u32)((u64)o * N - (u64)o * (o - 1) / 2 - o + i); }   // o*(o-1)/2 = 0 for o = 0 (u64 wraps twice)
+__device__ __forceinline__ void tri_pair(u32 p, u32 N, u32 &o, u32 &i) {
+    // rows o start at off(o) = o*N - o(o-1)/2: largest o with off(o) <= p; float estimate, then exact correction
+    const double b = 2.0 * N + 1.0;
+    i64 oo = (i64)((b - sqrt(b * b - 8.0 * (double)p)) * 0.5);
+    if (oo < 0) oo = 0;
+    if (oo > (i64)N - 1) oo = (i64)N - 1;
+    auto off = [&](i64 x) { return x * (i64)N - x * (x - 1) / 2; };
+    while (oo > 0 && off(oo) > (i64)p) --oo;
+    while (oo + 1 < (i64)N && off(oo + 1) <= (i64)p) ++oo;
+    o = (u32)oo;
+    i = (u32)((i64)p - off(oo) + oo);
+}
+
 template <bool PAIR, bool PACKED>
 __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys, const u32 *__restrict__ idx, i64 T, const u64 *__restrict__ rows, int W,
                                                      const u64 *__restrict__ inner, u32 Ni, const u64 *__restrict__ outer, int G,
@@ -221,7 +236,9 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
         bool eq;
         if (PACKED) {
             i1 = L.i(k1); o1 = L.o(k1); i0 = L.i(k0); o0 = L.o(k0);
-            t1 = o1 * Ni + i1;
+            // index under which the term is filed: the pair index, or — squared mode — its slot in the compacted key order (the
+            // same order, half the index space: bitmap and sums stay dense)
+            t1 = squared ? tri_slot(o1, i1, Ni) : o1 * Ni + i1;
             // equal 64-bit keys?  Different hash prefixes: no.  P * P twins (i, o) / (o, i): yes, the two hash tables are the
             // same.  Otherwise (about 1 % of the positions) the full keys are rebuilt from the operand hash tables.
             eq = valid && s > 0 && (k1 >> L.F()) == (k0 >> L.F());
@@ -368,7 +385,8 @@ __global__ void k_popc_words(const u32 *__restrict__ bits, i64 n_words, u32 *__r
 // (output slot of the k-th one = word prefix + k), and lane groups then write coefficient and row of every kept term to its
 // slot — consecutive slots, so the stores are contiguous.  The only random accesses left are the 4-byte look-up of the
 // 16-byte read of the term's summed coefficient (filed under its input index by k_heads_sums).
-template <bool PAIR>
+// TRI (PAIR only): the index space is the compacted slot order of a squared operator (tri_slot / tri_pair).
+template <bool PAIR, bool TRI>
 __global__ __launch_bounds__(256) void k_emit_rows(const u32 *__restrict__ markbits, const u32 *__restrict__ wordprefix, i64 n_words,
                                                     const double *__restrict__ sum_of, int Wq, int wpw,
                                                     const u32x4 *__restrict__ rows, const u32x4 *__restrict__ inner, u32 Ni,
@@ -404,7 +422,8 @@ __global__ __launch_bounds__(256) void k_emit_rows(const u32 *__restrict__ markb
             const bool have = k < K;
             const u32 t = have ? list[k] : 0u;
             u32 ti = t, to = 0;
-            if (PAIR) { to = t / Ni; ti = t - to * Ni; }
+            if (PAIR && TRI) { if (have) tri_pair(t, Ni, to, ti); }
+            else if (PAIR) { to = t / Ni; ti = t - to * Ni; }
             if (have) reinterpret_cast<double2 *>(out_coeff)[(i64)p_base + k] = reinterpret_cast<const double2 *>(sum_of)[t];
             const u32 n_here = K - k0 < 64u ? K - k0 : 64u;
             const u32 n_chunks16 = n_here * (u32)Wq;                 // 16-byte chunks of these rows, contiguous in the output
@@ -448,8 +467,9 @@ int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
     return SYMGPU_OK;
 }
 
+// T = size of the index space the kept terms are filed under (pair indices, or the slots of a squared operator: `tri`)
 int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, const u64 *rows, int W, const u64 *inner, i64 Ni,
-                   const u64 *outer, symgpu_op_t *out, int Wq_out) {
+                   const u64 *outer, symgpu_op_t *out, int Wq_out, bool tri) {
     hipStream_t st = ctx().stream;
     const i64 n_words = (T + 31) / 32;
     Scratch wordprefix;
@@ -474,11 +494,14 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
         if (ge > 16384) ge = 16384;
         const u32x4 *pin = reinterpret_cast<const u32x4 *>(inner), *pout = reinterpret_cast<const u32x4 *>(outer);
         u32x4 *dst = reinterpret_cast<u32x4 *>(res->rows);
-        if (pair)
-            hipLaunchKernelGGL(k_emit_rows<true>, dim3((unsigned)ge), dim3(256), 0, st, markbits_p, wordprefix.as<u32>(), n_words, sum_of_p, Wq, wpw,
+        if (pair && tri)
+            hipLaunchKernelGGL((k_emit_rows<true, true>), dim3((unsigned)ge), dim3(256), 0, st, markbits_p, wordprefix.as<u32>(), n_words, sum_of_p, Wq, wpw,
+                               (const u32x4 *)nullptr, pin, (u32)Ni, pout, dst, res->coeff);
+        else if (pair)
+            hipLaunchKernelGGL((k_emit_rows<true, false>), dim3((unsigned)ge), dim3(256), 0, st, markbits_p, wordprefix.as<u32>(), n_words, sum_of_p, Wq, wpw,
                                (const u32x4 *)nullptr, pin, (u32)Ni, pout, dst, res->coeff);
         else
-            hipLaunchKernelGGL(k_emit_rows<false>, dim3((unsigned)ge), dim3(256), 0, st, markbits_p, wordprefix.as<u32>(), n_words, sum_of_p, Wq, wpw,
+            hipLaunchKernelGGL((k_emit_rows<false, false>), dim3((unsigned)ge), dim3(256), 0, st, markbits_p, wordprefix.as<u32>(), n_words, sum_of_p, Wq, wpw,
                                reinterpret_cast<const u32x4 *>(rows), (const u32x4 *)nullptr, 1u, (const u32x4 *)nullptr, dst, res->coeff);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);   // the scratch buffers are freed on return; keep ordering simple
@@ -613,7 +636,8 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             const dim3 gs((unsigned)((n_waves + 3) / 4));
             const u64 *nul = nullptr;
             const double *nud = nullptr;
-            HIP_TRY(hipMemsetAsync(markbits.p, 0, (size_t)((T + 31) / 32) * 4, st));
+            const i64 space = (squared && packed) ? Tk : T;               // index space of markbits / sum_of
+            HIP_TRY(hipMemsetAsync(markbits.p, 0, (size_t)((space + 31) / 32) * 4, st));
             if (packed)
                 hipLaunchKernelGGL((k_heads_sums<true, true>), gs, dim3(256), 0, st, ks, (const u32 *)nullptr, Tk, nul, W, inner, (u32)Ni, outer, G, nud,
                                    collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), L, ci, co, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0);
@@ -636,7 +660,8 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         set_error("cleanup: 64-bit row-hash collision survived 4 reseeds");
         return SYMGPU_E_COLLISION;
     }
-    return cleanup_finish(markbits.as<u32>(), sum_of.as<double>(), T, pair, rows, W, inner, Ni, outer, out, Wq_out);
+    const bool tri = squared && packed;
+    return cleanup_finish(markbits.as<u32>(), sum_of.as<double>(), tri ? Tk : T, pair, rows, W, inner, Ni, outer, out, Wq_out, tri);
 }
 
 }  // namespace symgpu

@@ -374,7 +374,9 @@ static M4rVariant m4r_pick(i64 N, i64 M) {
 }
 // enough 512 x 2048 tiles to occupy most of the chip (below that the register-tile kernel wins: 1024 x 16384 at n = 2000 takes
 // 0.10 ms there and 0.6 ms here; 4096 x 65536: 1.03 ms against 0.66 ms)
-bool commutes_m4r_worthwhile(i64 N, i64 M) { return m4r_workgroups(N, M, 16) >= (3 * ctx().num_cu) / 4; }
+// — and tiles that are at least half full in both directions: a 512 x 2048 tile costs the same whether it holds 1 row or 512
+// (100,000 x 1 at n = 1000: 0.14 ms on the register-tile kernel, 0.34 ms here)
+bool commutes_m4r_worthwhile(i64 N, i64 M) { return N >= 256 && M >= 1024 && m4r_workgroups(N, M, 16) >= (3 * ctx().num_cu) / 4; }
 
 // Same contract as commutes_dev (commute.hip): exactly one of out / out_bits is non-null.
 int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits) {
