@@ -103,6 +103,10 @@ struct symgpu_op_s {
     // for free (h(P ^ Q) = h(P) ^ h(Q)), so a chain of rotations hashes the operator once.  Dropped by op_invalidate.
     u64 *hash = nullptr;
     u64 hash_seed = 0;
+    // cached bit-major copy of rows[0..T) for the Four-Russians commutation kernel (commute_m4r.hip): bt[c][jw], bt_pad words per
+    // bit-row; valid while bt_T == T.  An adjacency matrix computed slab by slab transposes its right operand once.
+    u64 *bt = nullptr;
+    i64 bt_pad = 0, bt_T = -1;
 };
 
 namespace symgpu {
@@ -120,10 +124,11 @@ int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp,
 int radix_sort_keys_u64(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp);
 
 // commute.hip
-int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits);
+// b_owner (may be null): the operator B's rows belong to (all of them), so that per-operand layouts can be cached on it
+int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits, symgpu_op_s *b_owner = nullptr);
 int ycount_dev(const u64 *rows, i64 T, int Wq, int *out);
 // commute_m4r.hip — the same contract on the Four-Russians kernel (LDS tables)
-int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits);
+int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits, symgpu_op_s *b_owner = nullptr);
 bool commutes_m4r_worthwhile(i64 N, i64 M);
 
 // product.hip

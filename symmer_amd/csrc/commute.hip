@@ -155,9 +155,9 @@ static bool use_m4r(i64 N, i64 M, int Wq) {
     return commutes_m4r_worthwhile(N, M);
 }
 
-int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits) {
+int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits, symgpu_op_s *b_owner) {
     if (N == 0 || M == 0) return SYMGPU_OK;
-    if (use_m4r(N, M, Wq)) return commutes_m4r_dev(A, N, B, M, Wq, out, out_bits);
+    if (use_m4r(N, M, Wq)) return commutes_m4r_dev(A, N, B, M, Wq, out, out_bits, b_owner);
     const int W = 2 * Wq;
     const int cj = DJ;
     const bool same = (B == A && M == N);                 // adjacency: one word-major copy serves both sides
@@ -232,7 +232,7 @@ int symgpu_commutes_dev(symgpu_op_t A, int64_t a_begin, int64_t a_end, symgpu_op
     SG_REQUIRE(A && B && A->Wq == B->Wq, "commutes_dev: operands must share Wq");
     SG_REQUIRE(0 <= a_begin && a_begin <= a_end && a_end <= A->T, "commutes_dev: bad row range");
     SG_REQUIRE(out_dev || a_end == a_begin || B->T == 0, "commutes_dev: null output");
-    return commutes_dev(A->rows + a_begin * 2 * A->Wq, a_end - a_begin, B->rows, B->T, A->Wq, out_dev, nullptr);
+    return commutes_dev(A->rows + a_begin * 2 * A->Wq, a_end - a_begin, B->rows, B->T, A->Wq, out_dev, nullptr, B);
 }
 
 int symgpu_commutes_bits_dev(symgpu_op_t A, int64_t a_begin, int64_t a_end, symgpu_op_t B, uint64_t *out_bits_dev) {
@@ -240,7 +240,7 @@ int symgpu_commutes_bits_dev(symgpu_op_t A, int64_t a_begin, int64_t a_end, symg
     SG_REQUIRE(A && B && A->Wq == B->Wq, "commutes_bits_dev: operands must share Wq");
     SG_REQUIRE(0 <= a_begin && a_begin <= a_end && a_end <= A->T, "commutes_bits_dev: bad row range");
     SG_REQUIRE(out_bits_dev || a_end == a_begin || B->T == 0, "commutes_bits_dev: null output");
-    return commutes_dev(A->rows + a_begin * 2 * A->Wq, a_end - a_begin, B->rows, B->T, A->Wq, nullptr, out_bits_dev);
+    return commutes_dev(A->rows + a_begin * 2 * A->Wq, a_end - a_begin, B->rows, B->T, A->Wq, nullptr, out_bits_dev, B);
 }
 
 int symgpu_commutes(const uint64_t *A, int64_t N, const uint64_t *B, int64_t M, int Wq, uint8_t *out) {

@@ -379,7 +379,7 @@ static M4rVariant m4r_pick(i64 N, i64 M) {
 bool commutes_m4r_worthwhile(i64 N, i64 M) { return N >= 256 && M >= 1024 && m4r_workgroups(N, M, 16) >= (3 * ctx().num_cu) / 4; }
 
 // Same contract as commutes_dev (commute.hip): exactly one of out / out_bits is non-null.
-int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits) {
+int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits, symgpu_op_s *b_owner) {
     if (N == 0 || M == 0) return SYMGPU_OK;
     hipStream_t st = ctx().stream;
     const int W = 2 * Wq, nkb = 16 * Wq;
@@ -389,7 +389,24 @@ int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *
     const i64 Mw = (M + 63) / 64, Mw_pad = round_up_i64(Mw, MK_TILE_W);
     Scratch a8, bt, flags, klist, bits;
     SG_TRY(a8.alloc((size_t)nkb * Npad));
-    SG_TRY(bt.alloc((size_t)64 * W * Mw_pad * 8));
+    // the bit-major copy of B is cached on its operator (an adjacency matrix computed slab by slab transposes B once)
+    const u64 *bt_p = nullptr;
+    if (b_owner && b_owner->rows == B && b_owner->T == M) {
+        if (!b_owner->bt || b_owner->bt_T != M || b_owner->bt_pad != Mw_pad) {
+            if (b_owner->bt) { dev_free(b_owner->bt); b_owner->bt = nullptr; }
+            SG_TRY(dev_alloc((size_t)64 * W * Mw_pad * 8, (void **)&b_owner->bt));
+            hipLaunchKernelGGL(k_m4r_bt, dim3((unsigned)((Mw_pad / 8 + 3) / 4), (unsigned)W), dim3(256), 0, st, B, M, W, b_owner->bt, Mw_pad);
+            KERNEL_CHECK();
+            b_owner->bt_pad = Mw_pad;
+            b_owner->bt_T = M;
+        }
+        bt_p = b_owner->bt;
+    } else {
+        SG_TRY(bt.alloc((size_t)64 * W * Mw_pad * 8));
+        hipLaunchKernelGGL(k_m4r_bt, dim3((unsigned)((Mw_pad / 8 + 3) / 4), (unsigned)W), dim3(256), 0, st, B, M, W, bt.as<u64>(), Mw_pad);
+        KERNEL_CHECK();
+        bt_p = bt.p ? bt.as<u64>() : nullptr;
+    }
     SG_TRY(flags.alloc((size_t)(nkb + 1) * 4));
     SG_TRY(klist.alloc((size_t)nkb * 4));
     HIP_TRY(hipMemsetAsync(flags.p, 0, (size_t)(nkb + 1) * 4, st));
@@ -397,8 +414,6 @@ int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *
     KERNEL_CHECK();
     u32 *nk = flags.as<u32>() + nkb;
     hipLaunchKernelGGL(k_m4r_klist, dim3(1), dim3(64), 0, st, flags.as<u32>(), nkb, klist.as<u32>(), nk);
-    KERNEL_CHECK();
-    hipLaunchKernelGGL(k_m4r_bt, dim3((unsigned)((Mw_pad / 8 + 3) / 4), (unsigned)W), dim3(256), 0, st, B, M, W, bt.as<u64>(), Mw_pad);
     KERNEL_CHECK();
     // np.bool_ output: expanded by the kernel's own epilogue when rows can be written with aligned 16-byte stores, otherwise
     // bit-packed rows to scratch + a separate expansion with byte stores
@@ -414,7 +429,7 @@ int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *
     }
     {
         ProfScope prof(1);
-#define M4R_ARGS a8.as<uint8_t>(), Npad, N, bt.as<u64>(), Mw_pad, Wq, klist.as<u32>(), nk, dst, stride, M
+#define M4R_ARGS a8.as<uint8_t>(), Npad, N, bt_p, Mw_pad, Wq, klist.as<u32>(), nk, dst, stride, M
 #define M4R_LAUNCH(BY)                                                        \
         if (var.waves == 16) SG_TRY((launch_m4r<16, 16, 6, BY>(M4R_ARGS)));   \
         else if (R == 48) SG_TRY((launch_m4r<48, 8, 6, BY>(M4R_ARGS)));       \

@@ -49,6 +49,8 @@ void op_invalidate(symgpu_op_s *op) {
     op->dup_free = 0;
     if (op->hash) { dev_free(op->hash); op->hash = nullptr; }
     op->hash_seed = 0;
+    if (op->bt) { dev_free(op->bt); op->bt = nullptr; }
+    op->bt_pad = 0; op->bt_T = -1;
 }
 
 int op_wordmajor(symgpu_op_s *op, i64 mult, const u64 **out, i64 *pad) {
