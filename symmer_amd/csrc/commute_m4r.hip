@@ -35,7 +35,8 @@
 // Measured and rejected: per-wave global loads of the BT rows / index bytes instead of the LDS hand-off (7.0 ms instead of
 // 5.8: 13 vector loads per wave and k-block, all L1 hits, cost more than the look-ups), 16 waves x 16 rows (7.1 ms: less
 // amortisation of the table), the two halves of the workgroup running look-ups and build in opposite order (6.7 ms), a
-// separate bits -> bytes expansion kernel (+1.2 ms: now the epilogue).
+// separate bits -> bytes expansion kernel (+1.2 ms: now the epilogue), two tables per iteration read together and folded with one
+// v_bitop3 XOR3 per dword (3 instead of 5 VALU instructions per read, but no double buffering and a second barrier: 6.0 ms).
 #include "common.h"
 #include <stdlib.h>
 
