@@ -193,10 +193,17 @@ def main():
     for r in ring:
         r.free()
 
+    # the secondary measurements must never cost the headline line: a failure is reported in place of the numbers
     if rank == 0 and world == 1 and not args.no_extras:
-        out['extras'] = extras(_lib, kernels, DeviceOp)
+        try:
+            out['extras'] = extras(_lib, kernels, DeviceOp)
+        except Exception as exc:                                  # noqa: BLE001 - reported, not swallowed
+            out['extras'] = {'error': f'{type(exc).__name__}: {exc}'}
     if rank == 0 and world == 1 and not args.no_cpu:
-        out['cpu_baseline'] = cpu_baseline(n)
+        try:
+            out['cpu_baseline'] = cpu_baseline(n)
+        except Exception as exc:                                  # noqa: BLE001
+            out['cpu_baseline'] = {'error': f'{type(exc).__name__}: {exc}'}
     comm.close()
     if rank == 0:
         print(json.dumps(out))
@@ -282,129 +289,153 @@ def timed(fn, reps):
 
 
 def extras(_lib, kernels, DeviceOp):
-    """Other BASELINE.json configs on one GPU (device-resident inputs, C-ABI level; cfg1 through the Python classes)."""
+    """Other BASELINE.json configs on one GPU (device-resident inputs, C-ABI level; cfg1 through the Python classes).  Every
+    section runs on its own: one that fails reports its error and the others still run."""
     lib = _lib.lib()
-    ex = {}
-    # cfg1: the reference's own CPU-runnable case through the drop-in API, host buffers in / host result out
     from symmer_amd.operators import PauliwordOp
-    rng1 = np.random.default_rng(1235)
-    P1 = PauliwordOp(rng1.random((500, 200)) < 0.3, rng1.standard_normal(500) + 1j * rng1.standard_normal(500))
-    (P1 * P1)
-    t0 = time.perf_counter()
-    for _ in range(5):
-        P1._packed_cache = None
-        R1 = P1 * P1
-    t = (time.perf_counter() - t0) / 5
-    ex['cfg1_api_mul'] = {'call': 'PauliwordOp * PauliwordOp (pack + upload + fused product/cleanup + download)', 'pairs': 250000,
-                          'seconds': t, 'pairs_per_s': 250000 / t, 'terms_out': R1.n_terms}
-    # cfg3: 1,000 qubits, 10,000 terms squared (1e8 pairs) + cleanup
-    A = DeviceOp.random(10000, 1000, 0.3, seed=1237)
-
-    def cfg3():
-        h = ctypes.c_void_p()
-        _lib.check(lib.symgpu_mul_cleanup_dev(A.handle, A.handle, 1, 1e-15, 1, ctypes.byref(h)))
-        r = DeviceOp(h); cfg3.n_out = r.n_terms; r.free()
-    t = timed(cfg3, 2)
-    ex['cfg3_mul_cleanup'] = {'pairs': 10**8, 'seconds': t, 'pairs_per_s': 1e8 / t, 'terms_out': cfg3.n_out}
-    A.free()
-    # cfg2: 1,000 qubits, 100,000 terms, chain of non-Clifford single-Pauli rotations, device resident
-    rng = np.random.default_rng(1236)
     from symmer_amd import packing
-    P = DeviceOp.random(100000, 1000, 0.3, seed=1236)
-    qs = [packing.pack_rows((rng.random((1, 2000)) < 0.3))[0] for _ in range(8)]
-    t0 = time.perf_counter(); terms = []
-    cur = P
-    for q in qs[:4]:
-        res, allc = kernels.rotate_single_dev(cur, q, 0.3)
-        if cur is not P:
-            cur.free()
-        cur = res
-        terms.append(cur.n_terms)
-    kernels.sync(); t_chain = time.perf_counter() - t0
-    cur.free()
-    t1 = timed(lambda: kernels.rotate_single_dev(P, qs[0], 0.3)[0].free(), 5)
-    # chain of 128 Clifford (pi/2) rotations with the operator device resident (term count stays 1e5)
-    cur = P
-    kernels.sync(); t0 = time.perf_counter()
-    n_rot = 0
-    for k in range(128):
-        res, allc = kernels.rotate_single_dev(cur, qs[k % 8], np.pi / 2)
-        if allc:
-            continue
-        if cur is not P:
-            cur.free()
-        cur = res; n_rot += 1
-    kernels.sync(); t_cl = (time.perf_counter() - t0) / max(1, n_rot)
-    if cur is not P:
-        cur.free()
-    ex['cfg2_rotation'] = {'terms_in': 100000, 'first_rotation_seconds': t1, 'term_pairs_per_s': 1e5 / t1,
-                           'chain4_seconds': t_chain, 'chain_terms': terms,
-                           'clifford_chain': {'rotations': n_rot, 'seconds_per_rotation': t_cl, 'term_pairs_per_s': 1e5 / t_cl}}
-    P.free()
-    # README claim 1 (a depth-2,000 Clifford circuit on 1,000 qubits "in one second"): 2,000 Clifford rotations of a 64-term,
-    # 1,000-qubit observable through perform_rotations — one single-workgroup launch for the whole run (rotate.hip)
-    rng_c = np.random.default_rng(1240)
-    obs = PauliwordOp(rng_c.random((64, 2000)) < 0.3, rng_c.standard_normal(64) + 0j).cleanup()
-    rots = [(PauliwordOp(rng_c.random((1, 2000)) < 0.02, [1]), float(rng_c.integers(1, 4)) * np.pi / 2) for _ in range(2000)]
-    obs.perform_rotations(rots[:20])
-    t0 = time.perf_counter(); rot_obs = obs.perform_rotations(rots); t_circ = time.perf_counter() - t0
-    ex['cfg2_rotation']['clifford_circuit_2000_rotations_64_terms'] = {'seconds': t_circ, 'seconds_per_rotation': t_circ / 2000, 'terms_out': rot_obs.n_terms,
-                                                                       'call': 'PauliwordOp.perform_rotations (Python API: upload, one chain launch, download)'}
-    # cfg5 slice: 2,000 qubits, 25,000 x 200,000 commutation block (one rank's share of the 8-GPU adjacency)
-    C = DeviceOp.random(200000, 2000, 0.3, seed=1239)
-    nrow = 25000
-    buf = ctypes.c_void_p()
-    _lib.check(lib.symgpu_dev_alloc(nrow * 200000, ctypes.byref(buf)))
-    _lib.check(lib.symgpu_prof_enable(1, 1))
-    t = timed(lambda: _lib.check(lib.symgpu_commutes_dev(C.handle, 0, nrow, C.handle, buf)), 2)
-    nl, ms = ctypes.c_int64(0), ctypes.c_double(0)
-    _lib.check(lib.symgpu_prof_enable(1, 0)); _lib.check(lib.symgpu_prof_read(1, ctypes.addressof(nl), ctypes.addressof(ms)))
-    kt = ms.value / max(1, nl.value) * 1e-3
-    pairs = nrow * 200000
-    # The slice runs on the Four-Russians kernel (commute_m4r.hip): per row of A, 8-bit k-block and 2048-column tile one
-    # 256-byte table entry is read from LDS, so the kernel's own roofline is the LDS read path (256 B/clk/CU, MI355X_MICROARCH.md
-    # §LDS: 256 CUs x 256 B x 2.4 GHz = 157 TB/s); HBM only sees the 1 B/pair np.bool_ output.
-    n_kblocks = 2 * ((2000 + 7) // 8)                              # non-zero index bytes of a 2,000-qubit row (X and Z halves)
-    col_tiles = (200000 // 64 + 31) // 32
-    lds_bytes = nrow * n_kblocks * col_tiles * 256.0
-    ex['cfg5_commutation_slice'] = {'pairs': pairs, 'seconds': t, 'pairs_per_s': pairs / t, 'kernel': 'k_commutes_m4r', 'kernel_seconds': kt,
-                                    'kernel_pairs_per_s': pairs / kt if kt else None,
-                                    'hbm_GBps_at_1B_per_pair': pairs / kt / 1e9 if kt else None,
-                                    'lds_table_read_TBps': lds_bytes / kt / 1e12 if kt else None,
-                                    'lds_read_frac_of_157TBps': lds_bytes / kt / 157.3e12 if kt else None,
-                                    'register_tile_kernel_r01_pairs_per_s': 2.83e11}
-    _lib.check(lib.symgpu_dev_free(buf)); C.free()
-    # cfg4: GF(2) symmetry kernel, 2,000 qubits x 50,000 terms, 32 planted symmetries, Clifford-scrambled
-    symp = rng.random((50000, 4000)) < 0.3
-    symp[:, :32] = False
-    H = DeviceOp.upload(packing.pack_rows(symp), np.ones(50000, dtype=complex))
-    del symp
-    for _ in range(16):
-        q = packing.pack_rows((rng.random((1, 4000)) < 0.3))[0]
-        res, allc = kernels.rotate_single_dev(H, q, np.pi / 2)
-        if not allc:
-            H.free(); H = res
-    outg = np.zeros((4000, 64), dtype='<u8')
-    k, nx = ctypes.c_int64(0), ctypes.c_int64(0)
+    ex = {}
 
-    def cfg4():
-        _lib.check(lib.symgpu_symmetry_kernel_dev(H.handle, 2000, outg.ctypes.data, 4000, ctypes.addressof(k), ctypes.addressof(nx)))
-    t = timed(cfg4, 2)
-    wc = (50000 + 63) // 64 + 64
-    # physical traffic of the sweep launches (HIP events around every launch of the main sweep kernel): each pass reads and
-    # writes the whole 4000 x 846-word matrix once
-    _lib.check(lib.symgpu_prof_enable(2, 1))
-    cfg4(); kernels.sync()
-    _lib.check(lib.symgpu_prof_enable(2, 0))
-    nl4, ms4 = ctypes.c_int64(0), ctypes.c_double(0)
-    _lib.check(lib.symgpu_prof_read(2, ctypes.addressof(nl4), ctypes.addressof(ms4)))
-    sweep_s = ms4.value / max(1, nl4.value) * 1e-3
-    ex['cfg4_symmetry_kernel'] = {'rows': 4000, 'cols': 54000, 'generators_found': k.value, 'row_xors': nx.value, 'seconds': t,
-                                  'row_xors_per_s': nx.value / t, 'algorithmic_GBps': nx.value * 16 * wc / t / 1e9,
-                                  'sweep_launches': nl4.value, 'sweep_avg_launch_us': sweep_s * 1e6,
-                                  'sweep_physical_GBps': 2 * 4000 * wc * 8 / sweep_s / 1e9 if sweep_s else None,
-                                  'sweep_frac_of_hbm_peak': 2 * 4000 * wc * 8 / sweep_s / 1e9 / HBM_PEAK_GBS if sweep_s else None}
-    H.free()
+    def section(fn):
+        try:
+            fn()
+        except Exception as exc:                                  # noqa: BLE001 - reported in the JSON line
+            ex[fn.__name__] = {'error': f'{type(exc).__name__}: {exc}'}
+
+    def cfg1_api_mul():
+        # the reference's own CPU-runnable case through the drop-in API, host buffers in / host result out
+        rng1 = np.random.default_rng(1235)
+        P1 = PauliwordOp(rng1.random((500, 200)) < 0.3, rng1.standard_normal(500) + 1j * rng1.standard_normal(500))
+        (P1 * P1)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            P1._packed_cache = None
+            R1 = P1 * P1
+        t = (time.perf_counter() - t0) / 5
+        ex['cfg1_api_mul'] = {'call': 'PauliwordOp * PauliwordOp (pack + upload + fused product/cleanup + download)', 'pairs': 250000,
+                              'seconds': t, 'pairs_per_s': 250000 / t, 'terms_out': R1.n_terms}
+
+    def cfg3_mul_cleanup():
+        # 1,000 qubits, 10,000 terms squared (1e8 pairs) + cleanup
+        A = DeviceOp.random(10000, 1000, 0.3, seed=1237)
+        n_out = [0]
+
+        def run():
+            h = ctypes.c_void_p()
+            _lib.check(lib.symgpu_mul_cleanup_dev(A.handle, A.handle, 1, 1e-15, 1, ctypes.byref(h)))
+            r = DeviceOp(h); n_out[0] = r.n_terms; r.free()
+        t = timed(run, 2)
+        ex['cfg3_mul_cleanup'] = {'pairs': 10**8, 'seconds': t, 'pairs_per_s': 1e8 / t, 'terms_out': n_out[0],
+                                  'note': 'squared operator: keys for the pairs with i >= o only (cleanup.hip)'}
+        A.free()
+
+    def cfg2_rotation():
+        # 1,000 qubits, 100,000 terms, chain of non-Clifford single-Pauli rotations, device resident
+        rng = np.random.default_rng(1236)
+        P = DeviceOp.random(100000, 1000, 0.3, seed=1236)
+        qs = [packing.pack_rows((rng.random((1, 2000)) < 0.3))[0] for _ in range(8)]
+        t0 = time.perf_counter(); terms = []
+        cur = P
+        for q in qs[:4]:
+            res, allc = kernels.rotate_single_dev(cur, q, 0.3)
+            if cur is not P:
+                cur.free()
+            cur = res
+            terms.append(cur.n_terms)
+        kernels.sync(); t_chain = time.perf_counter() - t0
+        cur.free()
+        t1 = timed(lambda: kernels.rotate_single_dev(P, qs[0], 0.3)[0].free(), 5)
+        # chain of 128 Clifford (pi/2) rotations with the operator device resident (term count stays 1e5)
+        cur = P
+        kernels.sync(); t0 = time.perf_counter()
+        n_rot = 0
+        for k in range(128):
+            res, allc = kernels.rotate_single_dev(cur, qs[k % 8], np.pi / 2)
+            if allc:
+                continue
+            if cur is not P:
+                cur.free()
+            cur = res; n_rot += 1
+        kernels.sync(); t_cl = (time.perf_counter() - t0) / max(1, n_rot)
+        if cur is not P:
+            cur.free()
+        ex['cfg2_rotation'] = {'terms_in': 100000, 'first_rotation_seconds': t1, 'term_pairs_per_s': 1e5 / t1,
+                               'chain4_seconds': t_chain, 'chain_terms': terms,
+                               'clifford_chain': {'rotations': n_rot, 'seconds_per_rotation': t_cl, 'term_pairs_per_s': 1e5 / t_cl}}
+        P.free()
+        # README claim 1 (a depth-2,000 Clifford circuit on 1,000 qubits "in one second"): 2,000 Clifford rotations of a 64-term,
+        # 1,000-qubit observable through perform_rotations — one single-workgroup launch for the whole run (rotate.hip)
+        rng_c = np.random.default_rng(1240)
+        obs = PauliwordOp(rng_c.random((64, 2000)) < 0.3, rng_c.standard_normal(64) + 0j).cleanup()
+        rots = [(PauliwordOp(rng_c.random((1, 2000)) < 0.02, [1]), float(rng_c.integers(1, 4)) * np.pi / 2) for _ in range(2000)]
+        obs.perform_rotations(rots[:20])
+        t0 = time.perf_counter(); rot_obs = obs.perform_rotations(rots); t_circ = time.perf_counter() - t0
+        ex['cfg2_rotation']['clifford_circuit_2000_rotations_64_terms'] = {
+            'seconds': t_circ, 'seconds_per_rotation': t_circ / 2000, 'terms_out': rot_obs.n_terms,
+            'call': 'PauliwordOp.perform_rotations (Python API: upload, one chain launch, download)'}
+
+    def cfg5_commutation_slice():
+        # 2,000 qubits, 25,000 x 200,000 commutation block (one rank's share of the 8-GPU adjacency; `--workload adjacency` runs all of it)
+        C = DeviceOp.random(200000, 2000, 0.3, seed=1239)
+        nrow = 25000
+        buf = ctypes.c_void_p()
+        _lib.check(lib.symgpu_dev_alloc(nrow * 200000, ctypes.byref(buf)))
+        _lib.check(lib.symgpu_prof_enable(1, 1))
+        t = timed(lambda: _lib.check(lib.symgpu_commutes_dev(C.handle, 0, nrow, C.handle, buf)), 2)
+        nl, ms = ctypes.c_int64(0), ctypes.c_double(0)
+        _lib.check(lib.symgpu_prof_enable(1, 0)); _lib.check(lib.symgpu_prof_read(1, ctypes.addressof(nl), ctypes.addressof(ms)))
+        kt = ms.value / max(1, nl.value) * 1e-3
+        pairs = nrow * 200000
+        # The slice runs on the Four-Russians kernel (commute_m4r.hip): per row of A, 8-bit k-block and 2048-column tile one
+        # 256-byte table entry is read from LDS, so the kernel's own roofline is the LDS read path (256 B/clk/CU, MI355X_MICROARCH.md
+        # LDS table: 256 CUs x 256 B x 2.4 GHz = 157 TB/s); HBM only sees the 1 B/pair np.bool_ output.
+        n_kblocks = 2 * ((2000 + 7) // 8)                              # non-zero index bytes of a 2,000-qubit row (X and Z halves)
+        col_tiles = (200000 // 64 + 31) // 32
+        lds_bytes = nrow * n_kblocks * col_tiles * 256.0
+        ex['cfg5_commutation_slice'] = {'pairs': pairs, 'seconds': t, 'pairs_per_s': pairs / t, 'kernel': 'k_commutes_m4r', 'kernel_seconds': kt,
+                                        'kernel_pairs_per_s': pairs / kt if kt else None,
+                                        'hbm_GBps_at_1B_per_pair': pairs / kt / 1e9 if kt else None,
+                                        'lds_table_read_TBps': lds_bytes / kt / 1e12 if kt else None,
+                                        'lds_read_frac_of_157TBps': lds_bytes / kt / 157.3e12 if kt else None,
+                                        'register_tile_kernel_r01_pairs_per_s': 2.83e11}
+        _lib.check(lib.symgpu_dev_free(buf)); C.free()
+
+    def cfg4_symmetry_kernel():
+        # GF(2) symmetry kernel, 2,000 qubits x 50,000 terms, 32 planted symmetries, Clifford-scrambled
+        rng = np.random.default_rng(1238)
+        symp = rng.random((50000, 4000)) < 0.3
+        symp[:, :32] = False
+        H = DeviceOp.upload(packing.pack_rows(symp), np.ones(50000, dtype=complex))
+        del symp
+        for _ in range(16):
+            q = packing.pack_rows((rng.random((1, 4000)) < 0.3))[0]
+            res, allc = kernels.rotate_single_dev(H, q, np.pi / 2)
+            if not allc:
+                H.free(); H = res
+        outg = np.zeros((4000, 64), dtype='<u8')
+        k, nx = ctypes.c_int64(0), ctypes.c_int64(0)
+
+        def run():
+            _lib.check(lib.symgpu_symmetry_kernel_dev(H.handle, 2000, outg.ctypes.data, 4000, ctypes.addressof(k), ctypes.addressof(nx)))
+        t = timed(run, 2)
+        wc = (50000 + 63) // 64 + 64
+        # physical traffic of the sweep launches (HIP events around every launch of the main sweep kernel): each pass reads and
+        # writes the whole 4000 x 846-word matrix once
+        _lib.check(lib.symgpu_prof_enable(2, 1))
+        run(); kernels.sync()
+        _lib.check(lib.symgpu_prof_enable(2, 0))
+        nl4, ms4 = ctypes.c_int64(0), ctypes.c_double(0)
+        _lib.check(lib.symgpu_prof_read(2, ctypes.addressof(nl4), ctypes.addressof(ms4)))
+        sweep_s = ms4.value / max(1, nl4.value) * 1e-3
+        ex['cfg4_symmetry_kernel'] = {'rows': 4000, 'cols': 54000, 'generators_found': k.value, 'row_xors': nx.value, 'seconds': t,
+                                      'row_xors_per_s': nx.value / t, 'algorithmic_GBps': nx.value * 16 * wc / t / 1e9,
+                                      'sweep_launches': nl4.value, 'sweep_avg_launch_us': sweep_s * 1e6,
+                                      'sweep_physical_GBps': 2 * 4000 * wc * 8 / sweep_s / 1e9 if sweep_s else None,
+                                      'sweep_frac_of_hbm_peak': 2 * 4000 * wc * 8 / sweep_s / 1e9 / HBM_PEAK_GBS if sweep_s else None}
+        H.free()
+
+    for fn in (cfg1_api_mul, cfg3_mul_cleanup, cfg2_rotation, cfg5_commutation_slice, cfg4_symmetry_kernel):
+        section(fn)
     return ex
 
 
