@@ -91,3 +91,46 @@ def test_fuzz_rotation(seed):
             r, c = res.download(); res.free()
             assert np.array_equal(packing.unpack_rows(r, n), er) and np.array_equal(c, ec)
     op.free()
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_fuzz_round2_paths(seed, monkeypatch):
+    """Random shapes through the round-2 code paths: the Four-Russians commutation kernel forced on small ragged operands (every
+    tile height, bytes and bits epilogues), the squared-operator cleanup against the general pair path, rotations of operators
+    WITH duplicate rows, and single-launch Clifford chains — all against the oracle."""
+    from symmer_amd import PauliwordOp
+    rng = np.random.default_rng(12000 + seed)
+    n = int(rng.choice(N_QUBITS))
+    # (1) commutation, Four-Russians kernel forced
+    N, M = int(rng.integers(1, 700)), int(rng.integers(1, 2600))
+    a, b = _rows(rng, N, n), _rows(rng, M, n)
+    monkeypatch.setenv('SYMGPU_COMMUTE_M4R', '1')
+    monkeypatch.setenv('SYMGPU_M4R_R', str(rng.choice([16, 24, 40, 48, 116])))
+    if seed % 2:
+        monkeypatch.setenv('SYMGPU_M4R_UNFUSED', '1')
+    assert np.array_equal(kernels.commutes(a, b), oc.commutes(a, b))
+    for var in ('SYMGPU_COMMUTE_M4R', 'SYMGPU_M4R_R', 'SYMGPU_M4R_UNFUSED'):
+        monkeypatch.delenv(var, raising=False)
+    # (2) squared operator (duplicate-heavy every third seed): shortcut == general pair path == oracle
+    T = int(rng.integers(1, 260))
+    s = _rows(rng, T, n, pool=6 if seed % 3 == 0 else None)
+    cs = _dyadic(rng, T)
+    fast = kernels.mul_cleanup(s, cs, s, cs, True, 1e-15)
+    er, ec = oc.mul(s, cs, s, cs)
+    assert np.array_equal(fast[0], er) and np.array_equal(fast[1], ec)
+    # (3) a rotation of an operator with duplicate rows, Clifford and not
+    symp = packing.unpack_rows(s, n)
+    q = rng.random(2 * n) < 0.5
+    P = PauliwordOp(symp, cs); Q = PauliwordOp(q.reshape(1, -1), [1])
+    for ang in (float(rng.integers(-2, 6)) * np.pi / 2, 0.37):
+        R = P._rotate_by_single_Pword(Q, ang)
+        exp_r, exp_c = onp.rotate_by_single_pword(symp, cs, q, ang)
+        clifford = abs(round(2 * ang / np.pi) - 2 * ang / np.pi) <= 1e-18
+        assert np.array_equal(R.symp_matrix, exp_r)
+        assert np.array_equal(R.coeff_vec, exp_c) if clifford else np.allclose(R.coeff_vec, exp_c, rtol=0, atol=1e-12)
+    # (4) a run of Clifford rotations (one launch) on the cleaned operator
+    C = P.cleanup()
+    rots = [((rng.random(2 * n) < 0.4), float(rng.integers(-2, 6)) * np.pi / 2) for _ in range(int(rng.integers(2, 40)))]
+    R = C.perform_rotations([(PauliwordOp(qq.reshape(1, -1), [1]), ang) for qq, ang in rots])
+    exp_r, exp_c = onp.perform_rotations(C.symp_matrix, C.coeff_vec, rots)
+    assert np.array_equal(R.symp_matrix, exp_r) and np.array_equal(R.coeff_vec, exp_c)
