@@ -124,11 +124,13 @@ int symgpu_rotate_single(const uint64_t *rows, const double *coeff, int64_t N, i
 int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double cos_t, double sin_t, int clifford_k,
                              double thr, symgpu_op_t *out, int *all_commute);
 
-/* A chain of K Clifford rotations (perform_rotations, base.py:1163-1186, on pi/2-multiples; CircuitSymmerlator) in ONE launch
- * for a small, CLEAN operator: `in` must come from a cleanup (no duplicate rows, every |c| > 1e-15) and hold <= 8192 rows —
- * then every step is a stable partition [anticommuting | commuting] + row ^= Q + exact phase, exactly what the reference's
- * rotation followed by cleanup() returns.  q_rows: K packed rows; ks: clifford_k per rotation, 0..3 as for
- * symgpu_rotate_single (k = round(2*angle/pi) mapped as symmer_amd.kernels.rotation_args). */
+/* A run of K Clifford rotations (perform_rotations, base.py:1163-1186, on pi/2-multiples; CircuitSymmerlator) of a CLEAN
+ * operator: `in` must come from a cleanup (no duplicate rows, every |c| > 1e-15) — then every step is a stable partition
+ * [anticommuting | commuting] + row ^= Q + exact phase, exactly what the reference's rotation followed by cleanup() returns, the
+ * term count never changes and nothing has to come back to the host between the steps.  Up to 1,536 rows the whole run is ONE
+ * single-workgroup launch; larger operators (<= 2^22 rows) run the per-rotation kernels back to back without a read-back.
+ * q_rows: K packed rows; ks: clifford_k per rotation, 0..3 as for symgpu_rotate_single (k = round(2*angle/pi) mapped as
+ * symmer_amd.kernels.rotation_args). */
 int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host, const int *ks_host, int64_t K, symgpu_op_t *out);
 
 /* ---- a8: _rref_binary (utils.py:292-315): in place, no row swaps, leftmost pivot, eliminate above and

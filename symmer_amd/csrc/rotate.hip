@@ -588,7 +588,9 @@ static int rotate_fast_nonclifford(symgpu_op_t in, const u64 *q_dev, const u64 *
 // a stable partition [anticommuting | commuting] with row ^= Q and c *= i^e (-i) (odd k), c = -c (k in {2,3}) on the anticommuting
 // part, or nothing at all if every term commutes.  One workgroup keeps flags, phase exponents and slots in LDS and ping-pongs
 // the rows between two global buffers (L2 resident), one block barrier per phase.
-constexpr int CHAIN_TMAX = 8192;               // rows: 8 per thread of the slot scan
+constexpr int CHAIN_TMAX = 8192;               // rows the single-workgroup kernel can hold: 8 per thread of the slot scan
+constexpr int CHAIN_LOCAL_T = 1536;            // ... and up to where it beats the multi-workgroup kernels (29 us per rotation at 1,000 rows,
+                                               // 237 us at 8,000, against 36-40 us of back-to-back launches at any size)
 
 __global__ __launch_bounds__(1024) void k_clifford_chain(u64 *__restrict__ rowsA, double *__restrict__ coeffA, u64 *__restrict__ rowsB,
                                                           double *__restrict__ coeffB, int T, int Wq, int G, const u64 *__restrict__ qs,
@@ -854,7 +856,7 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
     SG_REQUIRE(in && out && K >= 0 && (K == 0 || (q_rows_host && ks_host)), "rotate_clifford_chain_dev: null argument");
     SG_REQUIRE(in->coeff || in->T == 0, "rotate_clifford_chain_dev: operator has no coefficients");
     SG_REQUIRE(in->dup_free, "rotate_clifford_chain_dev: the operator must come from a cleanup (no duplicate rows, |c| > threshold)");
-    SG_REQUIRE(in->T <= CHAIN_TMAX, "rotate_clifford_chain_dev: more rows than the single-workgroup chain handles (rotate one by one)");
+    SG_REQUIRE(in->T <= ((i64)1 << 22), "rotate_clifford_chain_dev: more than 2^22 rows (rotate one by one)");
     for (i64 r = 0; r < K; ++r) SG_REQUIRE(ks_host[r] >= 0 && ks_host[r] <= 3, "rotate_clifford_chain_dev: k must be 0..3 (see rotation_args)");
     hipStream_t st = ctx().stream;
     const i64 T = in->T;
@@ -878,14 +880,57 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
         if (rc != SYMGPU_OK) { symgpu_op_free(a); symgpu_op_free(b); return rc; }
         e = hipMemcpyAsync(qs.p, q_rows_host, (size_t)K * W * 8, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(ks.p, ks_host, (size_t)K * 4, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) {
-            int G = 1;
-            while (G < Wq && G < 64) G <<= 1;
+        int G = 1;
+        while (G < Wq && G < 64) G <<= 1;
+        i64 local_t = CHAIN_LOCAL_T;
+        if (const char *env = getenv("SYMGPU_CHAIN_LOCAL_T")) {      // tests: the single-workgroup kernel up to its own limit
+            local_t = atoll(env);
+            if (local_t > CHAIN_TMAX) local_t = CHAIN_TMAX;
+        }
+        if (e == hipSuccess && T <= local_t) {
+            // small operator: the whole run in one single-workgroup launch
             hipLaunchKernelGGL(k_clifford_chain, dim3(1), dim3(1024), 0, st, a->rows, a->coeff, b->rows, b->coeff, (int)T, Wq, G, qs.as<u64>(),
                                ks.as<int>(), (int)K, which.as<int>());
             e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(&in_b, which.p, 4, hipMemcpyDeviceToHost, st);
+        } else if (e == hipSuccess) {
+            // large operator: the per-rotation kernels of the Clifford fast path, enqueued back to back — T is constant for a
+            // clean operator (nothing is dropped: thr = -1), so no count has to come back to the host between the rotations
+            Scratch anti, ph, selfc, prodc, cls, pself, pnew, cnt, blk;
+            const int n_blk = (int)((T + 1023) / 1024);
+            rc = anti.alloc((size_t)T * 4);
+            if (rc == SYMGPU_OK) rc = ph.alloc((size_t)T);
+            if (rc == SYMGPU_OK) rc = selfc.alloc((size_t)T * 16);
+            if (rc == SYMGPU_OK) rc = prodc.alloc((size_t)T * 16);
+            if (rc == SYMGPU_OK) rc = cls.alloc((size_t)T);
+            if (rc == SYMGPU_OK) rc = pself.alloc((size_t)T * 4);
+            if (rc == SYMGPU_OK) rc = pnew.alloc((size_t)T * 4);
+            if (rc == SYMGPU_OK) rc = cnt.alloc(sizeof(RotCounts));
+            if (rc == SYMGPU_OK) rc = blk.alloc((size_t)n_blk * 16);
+            if (rc != SYMGPU_OK) { symgpu_op_free(a); symgpu_op_free(b); return rc; }
+            const int rpb = 256 / G;
+            i64 ga = (T + rpb - 1) / rpb;
+            if (ga > 1024) ga = 1024;
+            const JoinTable none = {nullptr, 0, 0, nullptr};
+            symgpu_op_t cur = a, nxt = b;
+            for (i64 r = 0; r < K; ++r) {
+                const u64 *q = qs.as<u64>() + r * W;
+                hipLaunchKernelGGL((k_rot_analyze<false, false>), dim3((unsigned)ga), dim3(256), 0, st, cur->rows, T, Wq, G, q, anti.as<u32>(), ph.as<uint8_t>(),
+                                   (const u64 *)nullptr, (u64 *)nullptr, (const u64 *)nullptr, none);
+                hipLaunchKernelGGL(k_rotc_classify, dim3(n_blk), dim3(1024), 0, st, anti.as<u32>(), ph.as<uint8_t>(), cur->coeff, T, ks_host[r], -1.0,
+                                   cls.as<uint8_t>(), selfc.as<double>(), prodc.as<double>(), blk.as<u32>());
+                hipLaunchKernelGGL(k_rotf_scan3, dim3(n_blk), dim3(1024), 0, st, cls.as<uint8_t>(), T, blk.as<u32>(), n_blk, pself.as<u32>(), pnew.as<u32>(),
+                                   cnt.as<RotCounts>(), (const u32 *)nullptr, 0u);
+                hipLaunchKernelGGL(k_rotf_write, dim3(grid_for(T * Wq)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(cur->rows),
+                                   reinterpret_cast<const u32x4 *>(q), T, Wq, cls.as<uint8_t>(), pself.as<u32>(), pnew.as<u32>(), cnt.as<RotCounts>(),
+                                   selfc.as<double>(), prodc.as<double>(), reinterpret_cast<u32x4 *>(nxt->rows), nxt->coeff, 1, (const u64 *)nullptr, (u64)0,
+                                   (u64 *)nullptr);
+                symgpu_op_t t2 = cur; cur = nxt; nxt = t2;
+            }
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(st);       // the scratch buffers go back to the allocator on return
+            in_b = (cur == b) ? 1 : 0;
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(&in_b, which.p, 4, hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { symgpu_op_free(a); symgpu_op_free(b); return hip_fail(e, "rotate_clifford_chain_dev", __FILE__, __LINE__); }

@@ -216,16 +216,15 @@ def rotate_single_dev(op, q_row, angle, zero_threshold=1e-15, clifford_threshold
     return DeviceOp(out), False
 
 
-# symgpu_rotate_clifford_chain_dev runs in one workgroup (kernel limit 8192 rows).  Measured on MI355X, 1,000 qubits, per rotation:
-# 3.5 us at 1 term, 5 us at 64, 29 us at 1,000, 237 us at 8,000 — against 45-50 us for the one-launch-set-per-rotation path at any
-# of these sizes: perform_rotations takes the chain up to this many terms.
-CLIFFORD_CHAIN_MAX_TERMS = 1536
+# symgpu_rotate_clifford_chain_dev: one single-workgroup launch for the whole run up to 1,536 terms (3.5 us per rotation at 1 term,
+# 5 us at 64, 29 us at 1,000; n = 1000), the per-rotation kernels back to back without a host read-back above that.
+CLIFFORD_CHAIN_MAX_TERMS = 1 << 22
 CLIFFORD_CHAIN_KERNEL_LIMIT = 8192
 
 
 def rotate_clifford_chain_dev(op, q_rows, ks):
     """K Clifford rotations of a CLEAN device operator (straight from a cleanup: no duplicate rows, |c| > 1e-15) with at most
-    CLIFFORD_CHAIN_MAX_TERMS terms in ONE kernel launch.  ``q_rows`` uint64[K, 2*Wq], ``ks`` the clifford_k of every rotation as
+    CLIFFORD_CHAIN_MAX_TERMS terms without any host round trip between them.  ``q_rows`` uint64[K, 2*Wq], ``ks`` the clifford_k of every rotation as
     returned by :func:`rotation_args` (0..3).  Returns a new DeviceOp."""
     q_rows = np.ascontiguousarray(q_rows, dtype='<u8')
     ks = np.ascontiguousarray(ks, dtype=np.int32)
