@@ -13,7 +13,7 @@ timed region.  Weak scaling: per-GPU work is fixed, value = all ranks' pairs / m
 
 roofline     — dominant kernel k_mul_rows (HBM-write stream): algorithmic bytes 16*Wq per pair (256 B at n=1000) x pairs
                per launch / average launch duration from HIP events recorded around every launch in the timed region
-               (library stream).  The VALU-bound coefficient kernel (16 B/pair) overlaps it on a side stream, so the
+               (library stream).  The VALU-bound coefficient kernel (16 B/pair) runs before it on the same stream; the
                whole step moves 16*Wq+16 B/pair (`whole_step_GBps`).  peak = 8 TB/s (MI355X_MICROARCH.md).
 cpu_baseline — the NumPy restatement of the reference algorithm (oracle/oracle_np.py: broadcast XOR on
                1-byte-per-bit matrices, per-bit popcount sums, complex outer product; base.py:783-792) timed on a
@@ -140,7 +140,8 @@ def main():
                    'pairs_per_step': world * pairs_per_step_rank, 'bytes_per_pair': 16 * wq + 16, 'slab_rows': slab,
                    'parallelism': (f'left-axis shard x{world}, all-gather of right rows ({comm.data_plane})' if world > 1 else 'single GPU')},
         'roofline': {'bound': 'hbm', 'kernel': 'k_mul_rows', 'bytes_per_pair': per_pair,
-                     'note': 'k_mul_coeff (16 B/pair) runs concurrently on a side stream; incl. its bytes: %.0f GB/s' % (achieved * (16 * wq + 16) / (16 * wq)), 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'note': 'one output row per block, grid.x a multiple of 8 so that every XCD keeps its eighth of the inner operand in L2; '
+                             'k_mul_coeff (16 B/pair, VALU-bound) runs before it on the same stream (whole_step_GBps counts both)', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'launches': n_launch.value, 'avg_launch_ms': launch_ms,
                      'algorithmic_bytes_per_launch': algo_bytes_launch,
                      'whole_step_GBps': pairs_per_step_rank * (16 * wq + 16) / (dt / args.steps) / 1e9},

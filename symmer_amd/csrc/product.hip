@@ -163,7 +163,11 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
         double2 *dst = reinterpret_cast<double2 *>(out) + o0 * Ni + i;
         if (full_o) {
 #pragma unroll
-            for (int a = 0; a < PO; ++a) dst[(i64)a * Ni] = v[a];
+            for (int a = 0; a < PO; ++a) {
+                typedef double f64x2 __attribute__((ext_vector_type(2)));
+                const f64x2 w = {v[a].x, v[a].y};
+                __builtin_nontemporal_store(w, reinterpret_cast<f64x2 *>(dst + (i64)a * Ni));   // streamed out: keep the operands in L2
+            }
         } else {
 #pragma unroll
             for (int a = 0; a < PO; ++a)
@@ -205,18 +209,20 @@ __global__ __launch_bounds__(1024) void k_mul_rows(const u32x4 *__restrict__ inn
     }
 }
 
-// tuning knobs (defaults are the measured best on MI355X; SYMGPU_ROWS_VARIANT="rc,rto,nt" overrides for experiments)
-struct RowsVariant { int rc = 1, rto = 12, nt = 1, threads = 256; bool parsed = false; };
+// tuning knobs (defaults are the measured best on MI355X; SYMGPU_ROWS_VARIANT="rc,rto,nt[,threads[,pad8]]" overrides for experiments):
+// 16-byte chunks per lane, outer rows per block, non-temporal stores, block size, grid.x padded to a multiple of 8
+struct RowsVariant { int rc = 1, rto = 1, nt = 1, threads = 256, pad8 = 1; bool parsed = false; };
 static RowsVariant g_rv;
 static const RowsVariant &rows_variant() {
     if (!g_rv.parsed) {
         g_rv.parsed = true;
         const char *e = getenv("SYMGPU_ROWS_VARIANT");
         if (e) {
-            int a = 0, b2 = 0, c = 0, d = 256;
-            const int got = sscanf(e, "%d,%d,%d,%d", &a, &b2, &c, &d);
+            int a = 0, b2 = 0, c = 0, d = 256, p8 = 1;
+            const int got = sscanf(e, "%d,%d,%d,%d,%d", &a, &b2, &c, &d, &p8);
             if (got >= 3 && (a == 1 || a == 2 || a == 4 || a == 8) && b2 >= 1) { g_rv.rc = a; g_rv.rto = b2; g_rv.nt = c != 0; }
-            if (got == 4 && (d == 64 || d == 128 || d == 256 || d == 512 || d == 1024)) g_rv.threads = d;
+            if (got >= 4 && (d == 64 || d == 128 || d == 256 || d == 512 || d == 1024)) g_rv.threads = d;
+            if (got >= 5) g_rv.pad8 = p8 != 0;
         }
     }
     return g_rv;
@@ -289,7 +295,13 @@ int mul_rows_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 o_begin, i64 o_
     if (Ni == 0 || No <= 0) return SYMGPU_OK;
     const i64 n_chunks = Ni * Wq;
     const RowsVariant &rv = rows_variant();
-    const i64 gx = (n_chunks + (i64)rv.threads * rv.rc - 1) / ((i64)rv.threads * rv.rc);
+    i64 gx = (n_chunks + (i64)rv.threads * rv.rc - 1) / ((i64)rv.threads * rv.rc);
+    // Workgroups go to the 8 XCDs round-robin by linear id (= by * gx + bx): with gx a multiple of 8 the inner chunk bx is ALWAYS
+    // read by XCD bx % 8, so each XCD's 4 MB L2 only ever sees its own eighth of the inner operand (3.2 MB of 25.6 MB at the
+    // benchmark size) and keeps it.  The re-reads of the inner operand then stop at the L2 instead of crossing the fabric, which
+    // makes ONE output row per block affordable — and that is the sequential write pattern the HBM likes (tools/ubench_rows.hip:
+    // 12 rows per block 6.27 TB/s either way; 1 row per block 3.76 TB/s unpadded, 7.14 TB/s padded).  The surplus blocks exit.
+    if (rv.pad8) gx = (gx + 7) / 8 * 8;
     const i64 max_gy = 65535;
     const i64 gy_total = (No + rv.rto - 1) / rv.rto;
     for (i64 y0 = 0; y0 < gy_total; y0 += max_gy) {
@@ -332,25 +344,35 @@ int symgpu_mul_allpairs_dev(symgpu_op_t inner, symgpu_op_t outer, int64_t o_begi
     op_invalidate(out);
     if (out->coeff && rows > 0) {
         SG_REQUIRE(inner->coeff && outer->coeff, "mul_allpairs_dev: operands have no coefficients");
-        // The VALU-bound coefficient kernel runs on a side stream and overlaps the HBM-bound row stream (measured on MI355X,
-        // 1e5 x 1e5 terms, n=1000: 2.2e10 pairs/s; ONE launch doing both was slower, 1.86e10: the long VALU prologue of every
-        // block delays its stores).
+        // Coefficient kernel (VALU-bound, 16 B/pair) and row stream (HBM-bound, 16*Wq B/pair) run ONE AFTER THE OTHER.  Round 1
+        // overlapped them on two streams, which paid while the row stream wrote 12 rows per block (6.1 TB/s either way); the
+        // one-row-per-block stream lives on the inner operand staying in each XCD's L2 (mul_rows_dev), and the coefficient kernel's
+        // 436 MB of traffic per slab running beside it evicts that: overlapped 1.34 ms per slab, in turn 0.95 + 0.15 = 1.10 ms.
+        // SYMGPU_PRODUCT_OVERLAP=1 brings the side stream back for experiments.  (ONE launch doing both was slower still in
+        // round 1, 1.86e10 pairs/s: the long VALU prologue of every block delays its stores.)
         Context &c = ctx();
         const u64 *It = nullptr;
         i64 Ipad = 0;
         SG_TRY(op_wordmajor(inner, 64 * PJ, &It, &Ipad));          // cached across slabs of the same inner operand
         Scratch ot;
-        HIP_TRY(hipEventRecord(c.ev_fork, c.stream));
-        HIP_TRY(hipStreamWaitEvent(c.stream2, c.ev_fork, 0));
-        int rc = mul_coeff_launch(It, Ipad, inner->coeff, inner->T, outer->rows, outer->coeff, o_begin, o_end, inner->Wq,
-                                  inner_is_left, out->coeff, c.stream2, ot);
-        hipError_t e1 = hipEventRecord(c.ev_join, c.stream2);
-        int rc2 = mul_rows_dev(inner->rows, inner->T, outer->rows, o_begin, o_end, inner->Wq, out->rows);
-        hipError_t e2 = hipStreamWaitEvent(c.stream, c.ev_join, 0);
-        if (rc != SYMGPU_OK) return rc;
-        if (rc2 != SYMGPU_OK) return rc2;
-        if (e1 != hipSuccess) return hip_fail(e1, "event record (join)", __FILE__, __LINE__);
-        if (e2 != hipSuccess) return hip_fail(e2, "stream wait (join)", __FILE__, __LINE__);
+        static const bool overlap = [] { const char *e = getenv("SYMGPU_PRODUCT_OVERLAP"); return e && e[0] == '1'; }();
+        if (overlap) {
+            HIP_TRY(hipEventRecord(c.ev_fork, c.stream));
+            HIP_TRY(hipStreamWaitEvent(c.stream2, c.ev_fork, 0));
+            int rc = mul_coeff_launch(It, Ipad, inner->coeff, inner->T, outer->rows, outer->coeff, o_begin, o_end, inner->Wq,
+                                      inner_is_left, out->coeff, c.stream2, ot);
+            hipError_t e1 = hipEventRecord(c.ev_join, c.stream2);
+            int rc2 = mul_rows_dev(inner->rows, inner->T, outer->rows, o_begin, o_end, inner->Wq, out->rows);
+            hipError_t e2 = hipStreamWaitEvent(c.stream, c.ev_join, 0);
+            if (rc != SYMGPU_OK) return rc;
+            if (rc2 != SYMGPU_OK) return rc2;
+            if (e1 != hipSuccess) return hip_fail(e1, "event record (join)", __FILE__, __LINE__);
+            if (e2 != hipSuccess) return hip_fail(e2, "stream wait (join)", __FILE__, __LINE__);
+        } else {
+            SG_TRY(mul_coeff_launch(It, Ipad, inner->coeff, inner->T, outer->rows, outer->coeff, o_begin, o_end, inner->Wq, inner_is_left, out->coeff,
+                                    c.stream, ot));
+            SG_TRY(mul_rows_dev(inner->rows, inner->T, outer->rows, o_begin, o_end, inner->Wq, out->rows));
+        }
     } else {
         SG_TRY(mul_rows_dev(inner->rows, inner->T, outer->rows, o_begin, o_end, inner->Wq, out->rows));
     }

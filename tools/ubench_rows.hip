@@ -78,10 +78,41 @@ template <bool LDSIN> void run_persist(const char *name, const u32x4 *in, const 
     }
     printf("%-52s blocks=%4d lds=%6zu  %.3f ms  %.2f TB/s\n", name, blocks, lds, best, (double)n_chunks * No * 16 / (best * 1e-3) / 1e12);
 }
-template <int MODE> void run(const char *name, const u32x4 *in, const u32x4 *outer, u32x4 *out, int rto = 12) {
-    const i64 Ni = 100000, No = 256; const int Wq = 16;
+// stores only, the block's `rto` rows are o = by + j * gridDim.y (interleaved row groups) instead of consecutive rows
+__global__ __launch_bounds__(256) void k_strided(i64 n_chunks, i64 o_count, u32x4 *__restrict__ out, int rto) {
+    const i64 c0 = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (c0 >= n_chunks) return;
+    u32x4 v = (u32x4)((unsigned)c0);
+    for (int j = 0; j < rto; ++j) {
+        const i64 o = (i64)blockIdx.y + (i64)j * gridDim.y;
+        if (o >= o_count) break;
+        v.x ^= (unsigned)o;
+        __builtin_nontemporal_store(v, out + o * n_chunks + c0);
+    }
+}
+void run_strided(u32x4 *out, i64 Ni, int rto) {
+    const i64 No = 256; const int Wq = 16;
     const i64 n_chunks = Ni * Wq;
-    dim3 grid((unsigned)((n_chunks + 255) / 256), MODE == 0 ? (unsigned)No : (unsigned)((No + rto - 1) / rto));
+    dim3 grid((unsigned)((n_chunks + 255) / 256), (unsigned)((No + rto - 1) / rto));
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 6; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(k_strided, grid, dim3(256), 0, 0, n_chunks, No, out, rto);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    printf("strided rows, stores only  Ni=%7lld rto=%3d  %.3f ms  %.2f TB/s\n", (long long)Ni, rto, best, (double)n_chunks * No * 16 / (best * 1e-3) / 1e12);
+}
+static int g_pad8 = 0;      // pad grid.x to a multiple of 8: workgroups go round-robin to the 8 XCDs by linear id, so chunk bx then
+                            // always lands on XCD bx % 8 and each XCD's L2 only ever sees its own eighth of the inner operand
+template <int MODE> void run(const char *name, const u32x4 *in, const u32x4 *outer, u32x4 *out, int rto = 12, i64 Ni = 100000) {
+    const i64 No = 256; const int Wq = 16;
+    const i64 n_chunks = Ni * Wq;
+    unsigned gx = (unsigned)((n_chunks + 255) / 256);
+    if (g_pad8) gx = (gx + 7) / 8 * 8;
+    dim3 grid(gx, MODE == 0 ? (unsigned)No : (unsigned)((No + rto - 1) / rto));
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float best = 1e9f;
     for (int rep = 0; rep < 6; ++rep) {
@@ -91,11 +122,11 @@ template <int MODE> void run(const char *name, const u32x4 *in, const u32x4 *out
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         if (rep && ms < best) best = ms;
     }
-    printf("%-52s rto=%3d  %.3f ms  %.2f TB/s\n", name, rto, best, (double)n_chunks * No * 16 / (best * 1e-3) / 1e12);
+    printf("%-52s Ni=%7lld rto=%3d pad8=%d  %.3f ms  %.2f TB/s\n", name, (long long)Ni, rto, g_pad8, best, (double)n_chunks * No * 16 / (best * 1e-3) / 1e12);
 }
 int main() {
     u32x4 *in, *outer, *out;
-    (void)hipMalloc(&in, 100000ull * 256); (void)hipMalloc(&outer, 256ull * 256); (void)hipMalloc(&out, 256ull * 100000 * 256);
+    (void)hipMalloc(&in, 100000ull * 256); (void)hipMalloc(&outer, 256ull * 256); (void)hipMalloc(&out, 256ull * 102400 * 256);
     (void)hipMemset(in, 1, 100000ull * 256); (void)hipMemset(outer, 2, 256ull * 256);
     run<0>("0 one-shot fill", in, outer, out);
     run<1>("1 pattern, stores only", in, outer, out);
@@ -105,6 +136,13 @@ int main() {
     run<5>("5 pattern, plain stores", in, outer, out);
     run<6>("6 pattern, sc1 nt stores", in, outer, out);
     run<7>("7 pattern, sc0 sc1 stores", in, outer, out);
+    for (int pad = 0; pad < 2; ++pad) { g_pad8 = pad; for (int rto : {1, 2, 3, 4, 6, 8, 12}) run<3>("3 full kernel", in, outer, out, rto); }
+    g_pad8 = 1; for (i64 Ni : {65536LL, 98304LL}) for (int rto : {1, 2, 4, 12}) run<3>("3 full kernel", in, outer, out, rto, Ni);
+    g_pad8 = 0;
+    return 0;
+    for (i64 Ni : {100000LL, 98304LL, 99999LL, 100352LL, 102400LL, 65536LL, 81920LL}) run<1>("1 pattern, stores only", in, outer, out, 12, Ni);
+    for (i64 Ni : {100000LL, 98304LL}) for (int rto : {4, 12, 32}) run_strided(out, Ni, rto);
+    return 0;
     run_persist<false>("8 persistent, stores only", in, outer, out, 256);
     run_persist<false>("8 persistent, stores only", in, outer, out, 512);
     run_persist<false>("8 persistent, stores only", in, outer, out, 1024);
