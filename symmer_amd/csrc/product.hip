@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
     constexpr bool KEYS = KM != 0;
     const i64 o0 = ((i64)blockIdx.y * PW + wave) * PO;   // wave-uniform, relative to the slab
     const i64 ibase = (i64)blockIdx.x * (64 * PJ);
+    if (ibase >= Ipad) return;                                         // surplus block of the grid padded to a multiple of 8 (below)
     if (KM == 2 && ibase + 64 * PJ - 1 < o0 + ka.o_base) return;       // tile strictly below the diagonal: no pair with i >= o
 
     u32 cnt[PO][PJ], flo[PO][PJ], fhi[PO][PJ];
@@ -240,7 +241,9 @@ static int mul_coeff_launch(const u64 *It, i64 Ipad, const double *ci, i64 Ni, c
     const i64 Opad = round_up(No, PO * PW);
     SG_TRY(ot.alloc((size_t)Opad * W * sizeof(u64)));
     SG_TRY(to_wordmajor(outer + o_begin * W, No, W, ot.as<u64>(), Opad, st));
-    const i64 gx = (Ni + 64 * PJ - 1) / (64 * PJ);
+    // grid.x a multiple of 8: inner tile bx is then always read by XCD bx % 8, whose L2 keeps its eighth of the word-major inner
+    // operand across the outer row blocks (same reasoning as in mul_rows_dev)
+    const i64 gx = ((Ni + 64 * PJ - 1) / (64 * PJ) + 7) / 8 * 8;
     const i64 gy_total = Opad / (PO * PW);
     const i64 max_gy = 65535;
     for (i64 y0 = 0; y0 < gy_total; y0 += max_gy) {
