@@ -631,7 +631,12 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             int G = 1;                                   // lanes per verified candidate: one 16-byte chunk each
             while (G < W / 2 && G < 64) G <<= 1;
             const i64 n_chunks = (Tk + 63) / 64;
-            const i64 cpw = (n_chunks + 32767) / 32768;           // ~32k wavefronts, each on a contiguous range of chunks
+            // The kernel is latency bound (dependent key load -> operand table gathers -> store per 64-position chunk; rocprofv3: 6 % of
+            // the wave cycles issue, 53 % wait on memory), so it wants many short waves rather than few long ones: cfg3 6.39 / 6.16 /
+            // 6.10 / 6.04 ms at 2^15 / 2^17 / 2^19 / 2^21 wavefronts (a wave also decodes the chunk after its range to close the
+            // segment it carries, so one chunk per wave reads the keys twice — still the fastest).
+            static const i64 HS_WAVES = [] { const char *e = getenv("SYMGPU_HS_WAVES"); return e ? atoll(e) : (i64)1 << 21; }();
+            const i64 cpw = (n_chunks + HS_WAVES - 1) / HS_WAVES;     // <= HS_WAVES wavefronts, each on a contiguous range of chunks
             const i64 n_waves = (n_chunks + cpw - 1) / cpw;
             const dim3 gs((unsigned)((n_waves + 3) / 4));
             const u64 *nul = nullptr;
