@@ -107,6 +107,10 @@ struct symgpu_op_s {
     // bit-row; valid while bt_T == T.  An adjacency matrix computed slab by slab transposes its right operand once.
     u64 *bt = nullptr;
     i64 bt_pad = 0, bt_T = -1;
+    // cached Y counts |x & z| of rows[0..T) (product.hip: the coefficient expansion adds 3 (Y_i + Y_o) to the phase bytes);
+    // valid while yc_T == T.  Dropped by op_invalidate.
+    int *yc = nullptr;
+    i64 yc_T = -1;
 };
 
 namespace symgpu {
@@ -115,6 +119,8 @@ namespace symgpu {
 int to_wordmajor(const u64 *rows, i64 T, int W, u64 *out, i64 Tpad, hipStream_t st = nullptr);
 // cached word-major copy of a whole operator (padded to a multiple of `mult` terms); built on the main stream
 int op_wordmajor(symgpu_op_s *op, i64 mult, const u64 **out, i64 *pad);
+// cached Y counts of a whole operator (int per term); built on the main stream
+int op_ycount(symgpu_op_s *op, const int **out);
 void op_invalidate(symgpu_op_s *op);
 
 // sort.hip

@@ -51,6 +51,20 @@ void op_invalidate(symgpu_op_s *op) {
     op->hash_seed = 0;
     if (op->bt) { dev_free(op->bt); op->bt = nullptr; }
     op->bt_pad = 0; op->bt_T = -1;
+    if (op->yc) { dev_free(op->yc); op->yc = nullptr; }
+    op->yc_T = -1;
+}
+
+int op_ycount(symgpu_op_s *op, const int **out) {
+    if (!op->yc || op->yc_T != op->T) {
+        if (op->yc) { dev_free(op->yc); op->yc = nullptr; }
+        op->yc_T = -1;
+        SG_TRY(dev_alloc((size_t)(op->T > 0 ? op->T : 1) * sizeof(int), (void **)&op->yc));
+        SG_TRY(ycount_dev(op->rows, op->T, op->Wq, op->yc));
+        op->yc_T = op->T;
+    }
+    *out = op->yc;
+    return SYMGPU_OK;
 }
 
 int op_wordmajor(symgpu_op_s *op, i64 mult, const u64 **out, i64 *pad) {

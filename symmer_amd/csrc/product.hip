@@ -12,6 +12,13 @@
 //    VGPRs across the outer loop) and streams  chunk ^ outer[o][chunk % Wq]  with non-temporal 16-byte
 //    stores, 1 KiB per wave instruction, perfectly coalesced.  Inputs stay in L2; algorithmic bytes == HBM
 //    bytes.  This is the kernel the north-star roofline is quoted on.
+//  * k_mul_rows_e + k_mul_coeff_expand (round 2, default when the product carries coefficients and a row is a power-of-two
+//    number of 16-byte chunks: n in 65..128, 193..256, 449..512, 961..1024, 1985..2048, 4033..4096, or n <= 64) — the row
+//    stream has its VALU idle, and in the row-major layout the X and the Z words of a term sit in the two halves of an aligned
+//    lane group: the phase sum  Y_out + 2|x_left & z_right|  of every output row is formed on the way (DPP lane exchange,
+//    v_bcnt, three DPP adds: measured free, tools/ubench_fused.hip) and leaves as ONE byte per pair; a purely streaming second
+//    kernel expands bytes to coefficients at HBM speed.  The word-major VALU-bound k_mul_coeff (0.158 ms per 2.56e7 pairs)
+//    is replaced by 0.075 ms of streaming: 1.083 -> 1.0 ms per slab.
 #include "common.h"
 #include <stdlib.h>
 #include <stdio.h>
@@ -210,6 +217,113 @@ __global__ __launch_bounds__(1024) void k_mul_rows(const u32x4 *__restrict__ inn
     }
 }
 
+
+// ---- the HBM-write stream that also leaves the phase sums ----------------------------------------
+// WQ = 16-byte chunks per row (= words per X block), a power of two <= 64: a row occupies an aligned group of WQ lanes, its X
+// words in the lower half and its Z words in the upper half, so lane ^ WQ/2 holds the other half of the same qubits.
+template <int CTRL> __device__ __forceinline__ u32 dpp(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_ROR8 = 0x128;
+template <int WQ> __device__ __forceinline__ u32 other_half(u32 v) {
+    if (WQ == 2) return dpp<DPP_XOR1>(v);
+    if (WQ == 4) return dpp<DPP_XOR2>(v);
+    if (WQ == 16) return dpp<DPP_ROR8>(v);
+    return (u32)__shfl_xor((int)v, WQ / 2);
+}
+// sum over the WQ/2 lanes of the half of the row the lane sits in (butterfly; every lane of the half gets the sum)
+template <int WQ> __device__ __forceinline__ u32 half_row_sum(u32 s) {
+    if (WQ >= 4) s += dpp<DPP_XOR1>(s);
+    if (WQ >= 8) s += dpp<DPP_XOR2>(s);
+    if (WQ >= 16) s += dpp<DPP_HALF_MIRROR>(s);     // quads hold equal values: lane 7-L supplies the other quad's
+    if (WQ >= 32) s += dpp<DPP_MIRROR>(s);
+    if (WQ >= 64) s += (u32)__shfl_xor((int)s, 16);
+    return s;
+}
+
+// One output row segment per block (the sequential write pattern of k_mul_rows<1, true>, rto = 1) plus, per output row, the byte
+// (Y_out + 2 |x_left & z_right|) mod 4.  The 256/WQ bytes of a block are gathered in LDS and leave as one store of wave 0.
+// e-byte index: o * gx * R + ((bx % 8) * (gx / 8) + bx / 8) * R + row in block, R = 256 / WQ: workgroups go to the XCDs round
+// robin, so the bytes of consecutive blocks OF ONE XCD are adjacent and fill whole lines in that XCD's L2 (plain stores) —
+// bytes of neighbouring blocks interleaved from 8 different L2s cost partial-line write-backs.
+template <int WQ, bool INNER_LEFT>
+__global__ __launch_bounds__(256) void k_mul_rows_e(const u32x4 *__restrict__ inner, i64 n_chunks, const u32x4 *__restrict__ outer,
+                                                     u32x4 *__restrict__ out, unsigned char *__restrict__ eb) {
+    constexpr int R = 256 / WQ;
+    __shared__ __attribute__((aligned(16))) unsigned char sb[R];
+    const i64 cb = (i64)blockIdx.x * 256;
+    if (cb >= n_chunks) return;                                      // surplus block of the padded grid
+    const i64 c0 = cb + threadIdx.x;
+    const bool ok = c0 < n_chunks;
+    const u32x4 v = ok ? inner[c0] : (u32x4)(0u);
+    const i64 o = blockIdx.y;
+    const u32x4 r = outer[o * WQ + (threadIdx.x & (WQ - 1))];
+    const u32x4 x = v ^ r;
+    if (ok) __builtin_nontemporal_store(x, out + o * n_chunks + c0);
+    u32 s;
+    if constexpr (WQ == 1) {                                         // the chunk is the whole row: x word, z word
+        const u32 cy = __popc(x.x & x.z) + __popc(x.y & x.w);
+        const u32 cf = INNER_LEFT ? __popc(v.x & r.z) + __popc(v.y & r.w) : __popc(v.z & r.x) + __popc(v.w & r.y);
+        s = cy + 2u * cf;
+    } else {
+        // Y_out: both halves of the row form the same x & z words.  flip: lower half x_inner & z_outer, upper half z_inner & x_outer.
+        u32 cy = __popc(x.x & other_half<WQ>(x.x));
+        cy += __popc(x.y & other_half<WQ>(x.y));
+        cy += __popc(x.z & other_half<WQ>(x.z));
+        cy += __popc(x.w & other_half<WQ>(x.w));
+        u32 cf = __popc(v.x & other_half<WQ>(r.x));
+        cf += __popc(v.y & other_half<WQ>(r.y));
+        cf += __popc(v.z & other_half<WQ>(r.z));
+        cf += __popc(v.w & other_half<WQ>(r.w));
+        s = half_row_sum<WQ>(cy + 2u * cf);
+    }
+    // the first lane of the half that holds x_left & z_right files the byte
+    if ((threadIdx.x & (WQ - 1)) == (INNER_LEFT ? 0 : WQ / 2)) sb[threadIdx.x / WQ] = (unsigned char)(s & 3u);
+    __syncthreads();
+    if (threadIdx.x < R / 4) {
+        const i64 gx = gridDim.x;
+        unsigned char *dst = eb + (o * gx + (i64)(blockIdx.x & 7) * (gx >> 3) + (i64)(blockIdx.x >> 3)) * R;
+        reinterpret_cast<u32 *>(dst)[threadIdx.x] = reinterpret_cast<const u32 *>(sb)[threadIdx.x];
+    }
+}
+
+// bytes -> coefficients: c_i * c_o * i^e, e = (3 (Y_i + Y_o) + byte) mod 4.  One lane per inner term, EO outer rows per block,
+// 16-byte non-temporal stores, 1 KiB contiguous per wave instruction.
+constexpr int EO = 16;
+__global__ __launch_bounds__(256) void k_mul_coeff_expand(const unsigned char *__restrict__ eb, i64 gx, int rshift, const int *__restrict__ yi,
+                                                           const int *__restrict__ yo, const double *__restrict__ ci, const double *__restrict__ co,
+                                                           i64 Ni, i64 No, double *__restrict__ out) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Ni) return;
+    const i64 R = 1LL << rshift, bx = i >> rshift;
+    const unsigned char *src = eb + ((bx & 7) * (gx >> 3) + (bx >> 3)) * R + (i & (R - 1));
+    const double ar = ci[2 * i], ai = ci[2 * i + 1];
+    const u32 y = (u32)yi[i];
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2 *dst = reinterpret_cast<f64x2 *>(out) + i;
+    const i64 ob = (i64)blockIdx.y * EO;
+    if (ob + EO <= No) {
+        u32 b[EO];
+#pragma unroll
+        for (int k = 0; k < EO; ++k) b[k] = src[(ob + k) * gx * R];
+#pragma unroll
+        for (int k = 0; k < EO; ++k) {
+            const i64 o = ob + k;
+            const int e = (int)((3u * (y + (u32)yo[o]) + b[k]) & 3u);
+            double re, im;
+            pair_coefficient(ar, ai, co[2 * o], co[2 * o + 1], e, re, im);
+            const f64x2 w = {re, im};
+            __builtin_nontemporal_store(w, dst + o * Ni);
+        }
+    } else {
+        for (i64 o = ob; o < No; ++o) {
+            const int e = (int)((3u * (y + (u32)yo[o]) + src[o * gx * R]) & 3u);
+            double re, im;
+            pair_coefficient(ar, ai, co[2 * o], co[2 * o + 1], e, re, im);
+            const f64x2 w = {re, im};
+            __builtin_nontemporal_store(w, dst + o * Ni);
+        }
+    }
+}
+
 // tuning knobs (defaults are the measured best on MI355X; SYMGPU_ROWS_VARIANT="rc,rto,nt[,threads[,pad8]]" overrides for experiments):
 // 16-byte chunks per lane, outer rows per block, non-temporal stores, block size, grid.x padded to a multiple of 8
 struct RowsVariant { int rc = 1, rto = 1, nt = 1, threads = 256, pad8 = 1; bool parsed = false; };
@@ -327,6 +441,54 @@ int mul_rows_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 o_begin, i64 o_
     return SYMGPU_OK;
 }
 
+
+// rows AND coefficients of the slab [o_begin, o_end) through the phase-byte row stream (k_mul_rows_e + k_mul_coeff_expand)
+static bool fused_rows_supported(int Wq) { return Wq >= 1 && Wq <= 64 && (Wq & (Wq - 1)) == 0; }
+static int mul_rows_coeff_fused(symgpu_op_s *inner, symgpu_op_s *outer, i64 o_begin, i64 o_end, int inner_is_left, symgpu_op_s *out) {
+    const i64 Ni = inner->T, No = o_end - o_begin;
+    const int Wq = inner->Wq;
+    const i64 n_chunks = Ni * Wq;
+    const int *yi = nullptr, *yo = nullptr;
+    SG_TRY(op_ycount(inner, &yi));
+    SG_TRY(op_ycount(outer, &yo));
+    const i64 gx = ((n_chunks + 255) / 256 + 7) / 8 * 8;               // a multiple of 8: see mul_rows_dev
+    const i64 R = 256 / Wq;
+    int rshift = 0;
+    while ((1LL << rshift) < R) ++rshift;
+    hipStream_t st = ctx().stream;
+    const i64 max_gy = 65535 / EO * EO;
+    Scratch eb;
+    SG_TRY(eb.alloc((size_t)(No < max_gy ? No : max_gy) * gx * R));
+    for (i64 y0 = 0; y0 < No; y0 += max_gy) {
+        const i64 ny = No - y0 < max_gy ? No - y0 : max_gy;
+        const u32x4 *pi = reinterpret_cast<const u32x4 *>(inner->rows);
+        const u32x4 *po = reinterpret_cast<const u32x4 *>(outer->rows + (o_begin + y0) * 2 * Wq);
+        u32x4 *pd = reinterpret_cast<u32x4 *>(out->rows) + y0 * n_chunks;
+        dim3 grid((unsigned)gx, (unsigned)ny);
+        {
+            ProfScope prof(0);
+#define LAUNCH_E(W) do { if (inner_is_left) hipLaunchKernelGGL((k_mul_rows_e<W, true>), grid, dim3(256), 0, st, pi, n_chunks, po, pd, eb.as<unsigned char>()); \
+                         else hipLaunchKernelGGL((k_mul_rows_e<W, false>), grid, dim3(256), 0, st, pi, n_chunks, po, pd, eb.as<unsigned char>()); } while (0)
+            switch (Wq) {
+                case 1: LAUNCH_E(1); break;
+                case 2: LAUNCH_E(2); break;
+                case 4: LAUNCH_E(4); break;
+                case 8: LAUNCH_E(8); break;
+                case 16: LAUNCH_E(16); break;
+                case 32: LAUNCH_E(32); break;
+                default: LAUNCH_E(64); break;
+            }
+#undef LAUNCH_E
+            KERNEL_CHECK();
+        }
+        dim3 ge((unsigned)((Ni + 255) / 256), (unsigned)((ny + EO - 1) / EO));
+        hipLaunchKernelGGL(k_mul_coeff_expand, ge, dim3(256), 0, st, eb.as<unsigned char>(), gx, rshift, yi, yo + o_begin + y0, inner->coeff,
+                           outer->coeff + 2 * (o_begin + y0), Ni, ny, out->coeff + 2 * y0 * Ni);
+        KERNEL_CHECK();
+    }
+    return SYMGPU_OK;
+}
+
 }  // namespace symgpu
 
 using namespace symgpu;
@@ -353,6 +515,15 @@ int symgpu_mul_allpairs_dev(symgpu_op_t inner, symgpu_op_t outer, int64_t o_begi
         // 436 MB of traffic per slab running beside it evicts that: overlapped 1.34 ms per slab, in turn 0.95 + 0.15 = 1.10 ms.
         // SYMGPU_PRODUCT_OVERLAP=1 brings the side stream back for experiments.  (ONE launch doing both was slower still in
         // round 1, 1.86e10 pairs/s: the long VALU prologue of every block delays its stores.)
+        // Default since round 2 where the row length allows it: the row stream forms the phase sums on the way (its VALU is idle)
+        // and a streaming kernel expands them (SYMGPU_PRODUCT_FUSED=0 selects the two kernels below).
+        const char *fe = getenv("SYMGPU_PRODUCT_FUSED");                // read per call: the tests run both paths in one process
+        const bool fused = !(fe && fe[0] == '0');
+        if (fused && fused_rows_supported(inner->Wq)) {
+            SG_TRY(mul_rows_coeff_fused(inner, outer, o_begin, o_end, inner_is_left, out));
+            out->T = rows;
+            return SYMGPU_OK;
+        }
         Context &c = ctx();
         const u64 *It = nullptr;
         i64 Ipad = 0;

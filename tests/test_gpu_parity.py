@@ -327,9 +327,19 @@ def test_matmul_gf2_vs_oracle():
     assert np.array_equal(numba_binary_matmal_GF2(A, B), onp.matmul_gf2(A, B)) and np.array_equal(numba_dot_matmal_GF2(A, B), onp.matmul_gf2(A, B))
 
 
+@pytest.mark.parametrize('fused', ['1', '0'])
 @pytest.mark.parametrize('n,Ni,No,left', [(1000, 700, 300, True), (1000, 300, 700, False), (100, 500, 500, True), (130, 1, 77, True),
-                                           (2000, 257, 9, False), (63, 1000, 3, True)])
-def test_mul_allpairs_vs_oracle(n, Ni, No, left):
+                                           (2000, 257, 9, False), (63, 1000, 3, True),
+                                           # every row length of the phase-byte row stream (16-byte chunks per row 1, 2, 4, 8, 16, 32, 64), both
+                                           # orientations, term counts that do not fill the last block / wave / row group
+                                           (1, 1001, 5, True), (64, 257, 33, False), (65, 129, 7, False), (128, 1, 1, True), (200, 333, 17, True),
+                                           (256, 65, 31, False), (449, 99, 20, True), (512, 31, 64, False), (961, 17, 5, False), (1024, 1023, 3, True),
+                                           (1985, 9, 40, True), (2048, 130, 2, False), (4033, 5, 9, False), (4096, 67, 4, True),
+                                           (300, 100, 7, True), (3000, 11, 13, False)])       # 5 and 47 chunks per row: the two-kernel path
+def test_mul_allpairs_vs_oracle(n, Ni, No, left, fused, monkeypatch):
+    """symgpu_mul_allpairs on both product paths: SYMGPU_PRODUCT_FUSED=1 (default: row stream + phase bytes + expansion where the
+    row length is a power-of-two number of chunks) and =0 (word-major coefficient kernel + plain row stream)."""
+    monkeypatch.setenv('SYMGPU_PRODUCT_FUSED', fused)
     rng = np.random.default_rng(200 + n + Ni)
     a = packing.pack_rows(rng.random((Ni, 2 * n)) < 0.3); b = packing.pack_rows(rng.random((No, 2 * n)) < 0.3)
     ca, cb = dyadic(rng, Ni), dyadic(rng, No)
