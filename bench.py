@@ -11,9 +11,10 @@ GPU).  One "step" = (N>1: RCCL all-gather of the packed right operand over xGMI,
 full product of this rank's left block against the whole right operand.  Inputs are resident in HBM before the
 timed region.  Weak scaling: per-GPU work is fixed, value = all ranks' pairs / max-over-ranks time.
 
-roofline     — dominant kernel k_mul_rows (HBM-write stream): algorithmic bytes 16*Wq per pair (256 B at n=1000) x pairs
-               per launch / average launch duration from HIP events recorded around every launch in the timed region
-               (library stream).  The VALU-bound coefficient kernel (16 B/pair) runs before it on the same stream; the
+roofline     — dominant kernel k_mul_rows_e (HBM-write stream of the product rows, which also leaves one phase byte per
+               pair): algorithmic bytes 16*Wq per pair (256 B at n=1000) x pairs per launch / average launch duration
+               from HIP events recorded around every launch in the timed region (library stream).  A second streaming
+               kernel (k_mul_coeff_expand) turns the phase bytes into the 16 B/pair coefficients right after it; the
                whole step moves 16*Wq+16 B/pair (`whole_step_GBps`).  peak = 8 TB/s (MI355X_MICROARCH.md).
 cpu_baseline — the NumPy restatement of the reference algorithm (oracle/oracle_np.py: broadcast XOR on
                1-byte-per-bit matrices, per-bit popcount sums, complex outer product; base.py:783-792) timed on a
@@ -128,7 +129,9 @@ def main():
     value = world * pairs_per_step_rank * args.steps / dt
     launch_pairs = pairs_per_step_rank * args.steps / max(1, n_launch.value)
     launch_ms = tot_ms.value / max(1, n_launch.value)
-    per_pair = 16 * wq                                   # the dominant kernel streams the rows; coefficients: side stream
+    per_pair = 16 * wq                                   # the dominant kernel streams the rows (+ 1 phase byte per pair, not counted)
+    fused_ok = os.environ.get('SYMGPU_PRODUCT_FUSED', '1') != '0' and wq & (wq - 1) == 0 and wq <= 64
+    ROW_KERNEL = 'k_mul_rows_e' if fused_ok else 'k_mul_rows'
     algo_bytes_launch = launch_pairs * per_pair
     achieved = algo_bytes_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
 
@@ -139,16 +142,17 @@ def main():
         'config': {'workload': 'allpairs_product', 'n_qubits': n, 'left_terms_per_gpu': Ni, 'right_terms': M,
                    'pairs_per_step': world * pairs_per_step_rank, 'bytes_per_pair': 16 * wq + 16, 'slab_rows': slab,
                    'parallelism': (f'left-axis shard x{world}, all-gather of right rows ({comm.data_plane})' if world > 1 else 'single GPU')},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_mul_rows', 'bytes_per_pair': per_pair,
+        'roofline': {'bound': 'hbm', 'kernel': ROW_KERNEL, 'bytes_per_pair': per_pair,
                      'note': 'one output row per block, grid.x a multiple of 8 so that every XCD keeps its eighth of the inner operand in L2; '
-                             'k_mul_coeff (16 B/pair, VALU-bound) runs before it on the same stream (whole_step_GBps counts both)', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'the row stream also forms the phase sums (DPP + v_bcnt, VALU otherwise idle) and leaves 1 B/pair, '
+                             'k_mul_coeff_expand streams the 16 B/pair coefficients after it (whole_step_GBps counts both kernels, 272 B/pair)', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'launches': n_launch.value, 'avg_launch_ms': launch_ms,
                      'algorithmic_bytes_per_launch': algo_bytes_launch,
                      'whole_step_GBps': pairs_per_step_rank * (16 * wq + 16) / (dt / args.steps) / 1e9},
     }
     if comm.degraded:
         out['degraded'] = comm.degraded          # top-level flag: the all-gather did not run over RCCL/xGMI
-    # the same kernel WITHOUT the concurrent coefficient kernel (rows-only output slab), outside the timed region
+    # the plain row stream k_mul_rows (rows-only output slab: no phase bytes, no coefficients), outside the timed region
     if rank == 0:
         rows_only = DeviceOp.alloc(slab * Ni, wq, with_coeff=False)
         o1 = min(M, slab)

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void k_mul_rows_e(const u32x4 *__restrict__ in
 
 // bytes -> coefficients: c_i * c_o * i^e, e = (3 (Y_i + Y_o) + byte) mod 4.  One lane per inner term, EO outer rows per block,
 // 16-byte non-temporal stores, 1 KiB contiguous per wave instruction.
-constexpr int EO = 16;
+constexpr int EO = 4;
 __global__ __launch_bounds__(256) void k_mul_coeff_expand(const unsigned char *__restrict__ eb, i64 gx, int rshift, const int *__restrict__ yi,
                                                            const int *__restrict__ yo, const double *__restrict__ ci, const double *__restrict__ co,
                                                            i64 Ni, i64 No, double *__restrict__ out) {

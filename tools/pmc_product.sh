@@ -18,8 +18,8 @@ def per_launch(db, counter, like):
     cur = sqlite3.connect(db).cursor()
     n, s = cur.execute("select count(*), sum(value) from counters_collection where counter_name=? and kernel_name like ?", (counter, like)).fetchone()
     return n, (s or 0.0) / max(1, n)
-nw, w = per_launch(f'{out}/w/w_results.db', 'WRITE_SIZE', '%k_mul_rows%')
-nr, r = per_launch(f'{out}/r/r_results.db', 'FETCH_SIZE', '%k_mul_rows%')
+nw, w = per_launch(f'{out}/w/w_results.db', 'WRITE_SIZE', '%k_mul_rows_e%')
+nr, r = per_launch(f'{out}/r/r_results.db', 'FETCH_SIZE', '%k_mul_rows_e%')
 _, cw = per_launch(f'{out}/w/w_results.db', 'WRITE_SIZE', '%k_probe_copy%')
 _, cr = per_launch(f'{out}/r/r_results.db', 'FETCH_SIZE', '%k_probe_copy%')
 line = [l for l in open(f'{out}/{tag}_bench_n1_under_rocprof.json') if l.startswith('{')][-1]
@@ -27,7 +27,7 @@ cfg = json.loads(line)['config']
 doc = {
     'source': f'rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes) on `python3 bench.py --steps 2 --warmup 1 --no-extras --no-cpu`, MI355X; summaries in profiles/{tag}_product_pmc.txt (tools/pmc_product.sh)',
     'config': {'n_qubits': cfg['n_qubits'], 'left_terms_per_gpu': cfg['left_terms_per_gpu'], 'right_terms': cfg['right_terms'], 'slab_rows': cfg['slab_rows']},
-    'kernel': 'k_mul_rows', 'launches_profiled': nw,
+    'kernel': 'k_mul_rows_e', 'launches_profiled': nw,
     'kernel_source_sha256': hashlib.sha256(open('symmer_amd/csrc/product.hip', 'rb').read()).hexdigest(),
     'write_bytes_per_launch': int(w * 1024), 'fetch_bytes_per_launch_raw': int(r * 1024), 'fetch_bytes_per_launch_corrected_x2': int(2 * r * 1024),
     'calibration_copy_4GiB': {'WRITE_SIZE_bytes': int(cw * 1024), 'FETCH_SIZE_bytes_raw': int(cr * 1024)},

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void kj(const u32x4 *__restrict__ inner, i64 n
     }
 }
 // K: one lane per pair, 16-byte coalesced nt stores
-__global__ __launch_bounds__(256) void kk(const unsigned char *__restrict__ eb, i64 gx, const int *__restrict__ yi, const int *__restrict__ yo,
+template <int EOK> __global__ __launch_bounds__(256) void kk(const unsigned char *__restrict__ eb, i64 gx, const int *__restrict__ yi, const int *__restrict__ yo,
                                           const f64x2 *__restrict__ ci, const f64x2 *__restrict__ co, f64x2 *__restrict__ outc, i64 Ni) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= Ni) return;
@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256) void kk(const unsigned char *__restrict__ eb, 
     const f64x2 a = ci[i];
     const int y = yi[i];
     const int sh = 2 * (int)(i & 3);
-    for (i64 o = (i64)blockIdx.y * 16; o < (i64)blockIdx.y * 16 + 16; ++o) {
+#pragma unroll
+    for (i64 o = (i64)blockIdx.y * EOK; o < (i64)blockIdx.y * EOK + EOK; ++o) {
         const u32 sv = eb[o * 4 * gx + ib] >> sh;
         const int e = (int)((3u * (u32)(y + yo[o]) + sv) & 3u);
         const f64x2 b = co[o];
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void kk(const unsigned char *__restrict__ eb, 
         __builtin_nontemporal_store(w, outc + o * Ni + i);
     }
 }
-template <int V> float runj(const char *name, const u32x4 *in, const u32x4 *outer, u32x4 *out, const int *yi, const int *yo,
+template <int V, int EOK = 16> float runj(const char *name, const u32x4 *in, const u32x4 *outer, u32x4 *out, const int *yi, const int *yo,
                                const f64x2 *ci, const f64x2 *co, f64x2 *outc, i64 Ni, i64 No, unsigned char *eb) {
     const i64 n_chunks = Ni * 16;
     unsigned gx = (unsigned)((n_chunks + 255) / 256);
@@ -296,7 +297,7 @@ template <int V> float runj(const char *name, const u32x4 *in, const u32x4 *oute
         (void)hipEventRecord(e0);
         hipLaunchKernelGGL(kj<V>, grid, dim3(256), 0, 0, in, n_chunks, outer, out, eb);
         (void)hipEventRecord(e1);
-        hipLaunchKernelGGL(kk, dim3((unsigned)((Ni + 255) / 256), (unsigned)(No / 16)), dim3(256), 0, 0, eb, (i64)gx, yi, yo, ci, co, outc, Ni);
+        hipLaunchKernelGGL(kk<EOK>, dim3((unsigned)(((Ni + 255) / 256 + 7) / 8 * 8), (unsigned)(No / EOK)), dim3(256), 0, 0, eb, (i64)gx, yi, yo, ci, co, outc, Ni);
         (void)hipEventRecord(e2); (void)hipEventSynchronize(e2);
         float ms, ms2; (void)hipEventElapsedTime(&ms, e0, e1); (void)hipEventElapsedTime(&ms2, e1, e2);
         if (rep >= 2) { sum += ms; sum2 += ms2; }
@@ -384,7 +385,11 @@ int main(int argc, char **argv) {
         runh<256, false>("H fused, LDS gather, plain coeff", pin, po, out, yi, yo, ci, co, outc, Ni, No);
         runh<512, true>("H fused, LDS gather, nt coeff", pin, po, out, yi, yo, ci, co, outc, Ni, No);
         runh<1024, true>("H fused, LDS gather, nt coeff", pin, po, out, yi, yo, ci, co, outc, Ni, No);
-        runj<0>("J byte per wave + K expand", pin, po, out, yi, yo, ci, co, outc, Ni, No, eb);
+        runj<1, 1>("J dword per block + K expand EO=1", pin, po, out, yi, yo, ci, co, outc, Ni, No, eb);
+        runj<1, 2>("J dword per block + K expand EO=2", pin, po, out, yi, yo, ci, co, outc, Ni, No, eb);
+        runj<1, 4>("J dword per block + K expand EO=4", pin, po, out, yi, yo, ci, co, outc, Ni, No, eb);
+        runj<1, 8>("J dword per block + K expand EO=8", pin, po, out, yi, yo, ci, co, outc, Ni, No, eb);
+        runj<1, 32>("J dword per block + K expand EO=32", pin, po, out, yi, yo, ci, co, outc, Ni, No, eb);
         runj<1>("J dword per block + K expand", pin, po, out, yi, yo, ci, co, outc, Ni, No, eb);
         run4<'E'>("E fused, 256 B coeff store per wave", pin, po, out, yi, yo, ci, co, outc, Ni, No);
         (void)hipMemset(outc, 0, (size_t)No * Ni * 16);
