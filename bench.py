@@ -330,7 +330,12 @@ def extras(_lib, kernels, DeviceOp):
             _lib.check(lib.symgpu_mul_cleanup_dev(A.handle, A.handle, 1, 1e-15, 1, ctypes.byref(h)))
             r = DeviceOp(h); n_out[0] = r.n_terms; r.free()
         t = timed(run, 2)
+        # algorithmic bytes of product + cleanup = T (16 Wq + 16) read + U_kept (16 Wq + 16) written (the T product rows
+        # themselves never exist in memory here)
+        algo = (10**8 + n_out[0]) * 272
         ex['cfg3_mul_cleanup'] = {'pairs': 10**8, 'seconds': t, 'pairs_per_s': 1e8 / t, 'terms_out': n_out[0],
+                                  'algorithmic_bytes': algo, 'algorithmic_GBps': algo / t / 1e9, 'frac_of_hbm_peak': algo / t / 1e9 / HBM_PEAK_GBS,
+                                  'physical_write_floor_s': n_out[0] * 272 / (HBM_PEAK_GBS * 1e9),
                                   'note': 'squared operator: keys for the pairs with i >= o only (cleanup.hip)'}
         A.free()
 
@@ -372,6 +377,7 @@ def extras(_lib, kernels, DeviceOp):
         t_run = (time.perf_counter() - t0) / 128
         Pc.free()
         ex['cfg2_rotation'] = {'terms_in': 100000, 'first_rotation_seconds': t1, 'term_pairs_per_s': 1e5 / t1,
+                               'algorithmic_GBps': (100000 + terms[0]) * 272 / t1 / 1e9,      # N (16 Wq + 16) read + N_out (...) written
                                'chain4_seconds': t_chain, 'chain_terms': terms,
                                'clifford_chain': {'rotations': n_rot, 'seconds_per_rotation': t_cl, 'term_pairs_per_s': 1e5 / t_cl,
                                                   'as_one_run_seconds_per_rotation': t_run, 'as_one_run_term_pairs_per_s': 1e5 / t_run}}

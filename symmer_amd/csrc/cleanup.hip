@@ -381,24 +381,36 @@ __global__ void k_popc_words(const u32 *__restrict__ bits, i64 n_words, u32 *__r
 }
 
 // Output stage without any scatter.  The kept terms are the set bits of `markbits` (input index space), and input order IS the
-// output order: a wavefront takes 64 bitmap words (2048 input indices), expands their set bits into a compact list in LDS
-// (output slot of the k-th one = word prefix + k), and lane groups then write coefficient and row of every kept term to its
-// slot — consecutive slots, so the stores are contiguous.  The only random accesses left are the 4-byte look-up of the
-// 16-byte read of the term's summed coefficient (filed under its input index by k_heads_sums).
+// output order.  Two kernels per BATCH of 2^17 bitmap words (4M input indices; emit_batch_words()):
+//  * k_emit_meta: a wavefront takes up to 64 bitmap words, expands their set bits into a compact list in LDS (output slot of the
+//    k-th one = word prefix + k), and every lane files one kept term: its summed coefficient (read from where k_heads_sums filed
+//    it, nearly sequential) at its output slot and its source (i, o) — 8 bytes — in the batch's list, coalesced.
+//  * k_emit_stream: the rows.  Block b writes the b-th 4 KiB of the batch's output — the sequential pattern of the product's row
+//    stream (product.hip), which is what the HBM wants.
+// Why batches: a saturated HBM write stream tolerates reads that hit in the L2s or in the Infinity Cache, but HBM READS mixed into
+// it halve it (tools/ubench_fused.hip, S3: the same stream kernel writes 6.1-6.3 TB/s while its 8-byte-per-row list comes out of
+// the Infinity Cache and 3.7-4.0 TB/s when the list was evicted by 256 MB of other traffic or is read with `nt` loads, which
+// bypass that cache).  The first version streamed the rows from the wavefronts that decode the bitmap, next to their HBM reads of
+// the filed sums (4.2 TB/s); a whole-operator list written first and streamed afterwards is out of the cache again by the time
+// it is read (3.8 TB/s).  A batch's list is 32 MB at most, written by one kernel and read by the next.
 // TRI (PAIR only): the index space is the compacted slot order of a squared operator (tri_slot / tri_pair).
+static i64 emit_batch_words() {                                  // SYMGPU_EMIT_BATCH = log2(bitmap words per batch), default 17 (4M indices)
+    static const i64 w = [] { const char *e = getenv("SYMGPU_EMIT_BATCH"); const int l = e ? atoi(e) : 17; return (i64)1 << (l >= 6 && l <= 26 ? l : 17); }();
+    return w;
+}
 template <bool PAIR, bool TRI>
-__global__ __launch_bounds__(256) void k_emit_rows(const u32 *__restrict__ markbits, const u32 *__restrict__ wordprefix, i64 n_words,
-                                                    const double *__restrict__ sum_of, int Wq, int wpw,
-                                                    const u32x4 *__restrict__ rows, const u32x4 *__restrict__ inner, u32 Ni,
-                                                    const u32x4 *__restrict__ outer, u32x4 *__restrict__ out_rows, double *__restrict__ out_coeff) {
-    __shared__ u32 s_list[4][2048];
+__global__ __launch_bounds__(256) void k_emit_meta(const u32 *__restrict__ markbits, const u32 *__restrict__ wordprefix, i64 w_begin, i64 w_end,
+                                                    const double *__restrict__ sum_of, int wpw, u32 Ni,
+                                                    uint2 *__restrict__ meta, double *__restrict__ out_coeff) {
+    __shared__ unsigned short s_list[4][2048];                       // offsets inside the chunk (< 2048)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    u32 *list = s_list[wave];
-    // wpw (power of two <= 64) bitmap words per wavefront and step: small inputs use narrow chunks so that enough waves exist
-    const i64 n_chunks = (n_words + wpw - 1) / wpw;
+    unsigned short *list = s_list[wave];
+    const u32 P0 = wordprefix[w_begin];                              // first output slot of the batch
+    // wpw (power of two <= 64) bitmap words per wavefront and step: narrow chunks so that enough waves exist
+    const i64 n_chunks = (w_end - w_begin + wpw - 1) / wpw;
     for (i64 chunk = (i64)blockIdx.x * 4 + wave; chunk < n_chunks; chunk += (i64)gridDim.x * 4) {
-        const i64 w = chunk * wpw + lane;
-        const u32 bits = (lane < wpw && w < n_words) ? markbits[w] : 0u;
+        const i64 w = w_begin + chunk * wpw + lane;
+        const u32 bits = (lane < wpw && w < w_end) ? markbits[w] : 0u;
         const u32 cnt = (u32)__popc(bits);
         u32 incl = cnt;
 #pragma unroll
@@ -408,38 +420,59 @@ __global__ __launch_bounds__(256) void k_emit_rows(const u32 *__restrict__ markb
         }
         const u32 K = __shfl(incl, 63);
         if (K == 0) continue;                                        // wave-uniform
-        const u32 p_base = __shfl(wordprefix[chunk * wpw], 0);
+        const u32 p_base = __shfl(wordprefix[w_begin + chunk * wpw], 0);
         {
             u32 b = bits, k = incl - cnt;
-            while (b) { list[k++] = (u32)(w * 32) + (u32)__builtin_ctz(b); b &= b - 1; }
+            while (b) { list[k++] = (unsigned short)(lane * 32 + __builtin_ctz(b)); b &= b - 1; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // 64 kept terms at a time: every lane fetches the metadata of one term (sorted position, summed coefficient) and
-        // stores its coefficient (coalesced); the rows of the 64 terms are then streamed out 1 KiB per wave store.
-        for (u32 k0 = 0; k0 < K; k0 += 64) {
-            const u32 k = k0 + lane;
-            const bool have = k < K;
-            const u32 t = have ? list[k] : 0u;
+        const u32 t_base = (u32)((w_begin + chunk * wpw) * 32);
+        for (u32 k = lane; k < K; k += 64) {
+            const u32 t = t_base + list[k];
             u32 ti = t, to = 0;
-            if (PAIR && TRI) { if (have) tri_pair(t, Ni, to, ti); }
+            if (PAIR && TRI) tri_pair(t, Ni, to, ti);
             else if (PAIR) { to = t / Ni; ti = t - to * Ni; }
-            if (have) reinterpret_cast<double2 *>(out_coeff)[(i64)p_base + k] = reinterpret_cast<const double2 *>(sum_of)[t];
-            const u32 n_here = K - k0 < 64u ? K - k0 : 64u;
-            const u32 n_chunks16 = n_here * (u32)Wq;                 // 16-byte chunks of these rows, contiguous in the output
-            u32x4 *dst = out_rows + ((i64)p_base + k0) * Wq;
-            for (u32 f = lane; f < n_chunks16 + lane; f += 64) {     // uniform trip count: the shuffles need every lane
-                const bool live = f < n_chunks16;
-                const u32 e = live ? f / (u32)Wq : 0u;
-                const u32 c = f - e * (u32)Wq;
-                const u32 ei = __shfl(ti, (int)e), eo = __shfl(to, (int)e);
-                if (live) {
-                    const u32x4 v = PAIR ? (inner[(i64)ei * Wq + c] ^ outer[(i64)eo * Wq + c]) : rows[(i64)ei * Wq + c];
-                    __builtin_nontemporal_store(v, dst + f);
-                }
-            }
+            reinterpret_cast<double2 *>(out_coeff)[(i64)p_base + k] = reinterpret_cast<const double2 *>(sum_of)[t];
+            meta[(p_base - P0) + k] = make_uint2(ti, to);
         }
         __builtin_amdgcn_wave_barrier();                             // the list is rewritten by the next chunk
+    }
+}
+
+// RC 16-byte chunks per lane, 256 apart: output chunk f = slot * Wq + c  <-  inner[i][c] ^ outer[o][c]   (plain mode: rows[i][c])
+// for the slots [*p_begin, *p_end) of the batch; the grid is sized for a batch whose every index is kept, surplus blocks exit.
+template <bool PAIR, int RC>
+__global__ __launch_bounds__(256) void k_emit_stream(const uint2 *__restrict__ meta, const u32 *__restrict__ p_begin, const u32 *__restrict__ p_end,
+                                                      int Wq, int wsh, const u32x4 *__restrict__ rows, const u32x4 *__restrict__ inner,
+                                                      const u32x4 *__restrict__ outer, u32x4 *__restrict__ out_rows) {
+    const i64 P0 = *p_begin;
+    const i64 n_chunks16 = ((i64)*p_end - P0) * Wq;
+    const i64 b0 = (i64)blockIdx.x * (256 * RC);
+    if (b0 >= n_chunks16) return;
+    const i64 f0 = b0 + threadIdx.x;
+    const i64 last = n_chunks16 - 1;
+    uint2 m[RC];
+    int c[RC];
+#pragma unroll
+    for (int k = 0; k < RC; ++k) {
+        const i64 f = f0 + 256 * k < last ? f0 + 256 * k : last;      // clamped: every load is unconditional
+        const i64 slot = wsh >= 0 ? f >> wsh : f / Wq;
+        c[k] = (int)(f - slot * Wq);
+        m[k] = meta[slot];                                            // plain load: served by the Infinity Cache (see above)
+    }
+    u32x4 v[RC];
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+        v[k] = PAIR ? (inner[(i64)m[k].x * Wq + c[k]] ^ outer[(i64)m[k].y * Wq + c[k]]) : rows[(i64)m[k].x * Wq + c[k]];
+    u32x4 *dst = out_rows + P0 * Wq + f0;
+    if (b0 + 256 * RC <= n_chunks16) {
+#pragma unroll
+        for (int k = 0; k < RC; ++k) __builtin_nontemporal_store(v[k], dst + 256 * k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+            if (f0 + 256 * k < n_chunks16) __builtin_nontemporal_store(v[k], dst + 256 * k);
     }
 }
 
@@ -488,21 +521,35 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
     res->T = n_out;
     if (n_out > 0) {
         const int Wq = W / 2;
-        int wpw = 64;                                            // bitmap words per wavefront: aim at >= 16k wavefronts
-        while (wpw > 1 && (n_words + wpw - 1) / wpw < 16384) wpw >>= 1;
-        i64 ge = ((n_words + wpw - 1) / wpw + 3) / 4;
-        if (ge > 16384) ge = 16384;
+        const int wsh = (Wq & (Wq - 1)) == 0 ? __builtin_ctz((unsigned)Wq) : -1;
         const u32x4 *pin = reinterpret_cast<const u32x4 *>(inner), *pout = reinterpret_cast<const u32x4 *>(outer);
         u32x4 *dst = reinterpret_cast<u32x4 *>(res->rows);
-        if (pair && tri)
-            hipLaunchKernelGGL((k_emit_rows<true, true>), dim3((unsigned)ge), dim3(256), 0, st, markbits_p, wordprefix.as<u32>(), n_words, sum_of_p, Wq, wpw,
-                               (const u32x4 *)nullptr, pin, (u32)Ni, pout, dst, res->coeff);
-        else if (pair)
-            hipLaunchKernelGGL((k_emit_rows<true, false>), dim3((unsigned)ge), dim3(256), 0, st, markbits_p, wordprefix.as<u32>(), n_words, sum_of_p, Wq, wpw,
-                               (const u32x4 *)nullptr, pin, (u32)Ni, pout, dst, res->coeff);
-        else
-            hipLaunchKernelGGL((k_emit_rows<false, false>), dim3((unsigned)ge), dim3(256), 0, st, markbits_p, wordprefix.as<u32>(), n_words, sum_of_p, Wq, wpw,
-                               reinterpret_cast<const u32x4 *>(rows), (const u32x4 *)nullptr, 1u, (const u32x4 *)nullptr, dst, res->coeff);
+        static const int rc_env = [] { const char *e = getenv("SYMGPU_EMIT_RC"); return e ? atoi(e) : 2; }();     // chunks per lane: 1: 115, 2: 97, 4: 97 us per batch
+        const int RCs = rc_env == 1 || rc_env == 4 ? rc_env : 2;
+        const i64 EMIT_BATCH_WORDS = emit_batch_words();
+        const i64 bw = n_words < EMIT_BATCH_WORDS ? n_words : EMIT_BATCH_WORDS;
+        Scratch meta;
+        int rc = meta.alloc((size_t)bw * 32 * sizeof(uint2));
+        if (rc != SYMGPU_OK) { symgpu_op_free(res); return rc; }
+        int wpw = 64;                                            // bitmap words per wavefront: aim at >= 16k wavefronts per batch
+        while (wpw > 1 && (bw + wpw - 1) / wpw < 16384) wpw >>= 1;
+        for (i64 w0 = 0; w0 < n_words; w0 += EMIT_BATCH_WORDS) {
+            const i64 w1 = w0 + EMIT_BATCH_WORDS < n_words ? w0 + EMIT_BATCH_WORDS : n_words;
+            i64 ge = ((w1 - w0 + wpw - 1) / wpw + 3) / 4;
+            if (ge > 16384) ge = 16384;
+#define LAUNCH_META(P, TR) hipLaunchKernelGGL((k_emit_meta<P, TR>), dim3((unsigned)ge), dim3(256), 0, st, markbits_p, wordprefix.as<u32>(), w0, w1, sum_of_p, wpw, \
+                                              (u32)(pair ? Ni : 1), meta.as<uint2>(), res->coeff)
+            if (pair && tri) LAUNCH_META(true, true); else if (pair) LAUNCH_META(true, false); else LAUNCH_META(false, false);
+#undef LAUNCH_META
+            const u32 *p_begin = wordprefix.as<u32>() + w0;
+            const u32 *p_end = w1 < n_words ? wordprefix.as<u32>() + w1 : total.as<u32>();
+            const i64 gs = ((w1 - w0) * 32 * Wq + 256 * RCs - 1) / (256 * RCs);     // as if every index of the batch were kept
+#define LAUNCH_STREAM(P, R) hipLaunchKernelGGL((k_emit_stream<P, R>), dim3((unsigned)gs), dim3(256), 0, st, meta.as<uint2>(), p_begin, p_end, Wq, wsh, \
+                                               reinterpret_cast<const u32x4 *>(rows), pin, pout, dst)
+            if (pair) { if (RCs == 1) LAUNCH_STREAM(true, 1); else if (RCs == 4) LAUNCH_STREAM(true, 4); else LAUNCH_STREAM(true, 2); }
+            else { if (RCs == 1) LAUNCH_STREAM(false, 1); else if (RCs == 4) LAUNCH_STREAM(false, 4); else LAUNCH_STREAM(false, 2); }
+#undef LAUNCH_STREAM
+        }
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);   // the scratch buffers are freed on return; keep ordering simple
         if (e != hipSuccess) { symgpu_op_free(res); return hip_fail(e, "cleanup emit", __FILE__, __LINE__); }

@@ -1,6 +1,7 @@
-# per-kernel breakdown of the cfg3 fused product+cleanup (run on the GPU box): bash tools/prof_cfg3.sh
+# rocprofv3 kernel trace of the cfg3 product + cleanup (run on the GPU box): bash tools/prof_cfg3.sh [tag]
 export TMPDIR=/tmp
-rm -rf gpurun_out/cfg3prof; mkdir -p gpurun_out/cfg3prof
-timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/cfg3prof -o t -- python3 tests/_bench_kernels.py ${1:-cfg3} > gpurun_out/cfg3prof/out.txt 2>&1
-python3 profiles/summarize_rocpd.py gpurun_out/cfg3prof/t_results.db | head -${2:-24}
-grep -E "cfg3|rotation|product|commute" gpurun_out/cfg3prof/out.txt
+tag=${1:-cfg3}
+out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
+timeout 600 rocprofv3 --kernel-trace --stats -d $out/cfg3 -o t -- python3 tests/_bench_kernels.py cfg3 > $out/cfg3.out 2> $out/cfg3.log
+{ grep cfg3 $out/cfg3.out; python3 profiles/summarize_rocpd.py $out/cfg3/t_results.db | head -${2:-16}; } > $out/cfg3_kernel_trace.txt
+cut -c1-150 $out/cfg3_kernel_trace.txt

@@ -308,6 +308,121 @@ template <int V, int EOK = 16> float runj(const char *name, const u32x4 *in, con
     return sum / 6;
 }
 
+
+// S: the cleanup's output stream (k_emit_stream, cleanup.hip) on the same buffers: 1-D grid, chunk f <- inner[(f >> 4) & mask] ^ outer[0]
+template <int V>
+__global__ __launch_bounds__(256) void ks(const u32x4 *__restrict__ inner, i64 n_chunks16, const u32x4 *__restrict__ outer, u32x4 *__restrict__ out, i64 mask) {
+    const i64 f = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_chunks16) return;
+    const i64 slot = f >> 4;
+    const int c = (int)(f & 15);
+    const i64 row = V == 0 ? (slot & mask) : slot % 99991;
+    const u32x4 v = inner[row * 16 + c] ^ outer[c];
+    __builtin_nontemporal_store(v, out + f);
+}
+template <int V> void runs(const char *name, const u32x4 *in, const u32x4 *outer, u32x4 *out, i64 n_chunks16, i64 mask) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float sum = 0;
+    for (int rep = 0; rep < 8; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(ks<V>, dim3((unsigned)((n_chunks16 + 255) / 256)), dim3(256), 0, 0, in, n_chunks16, outer, out, mask);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep >= 2) sum += ms;
+    }
+    printf("%-50s chunks=%lld mask=%lld  avg %.3f ms  %.2f TB/s\n", name, (long long)n_chunks16, (long long)mask, sum / 6, (double)n_chunks16 * 16 / (sum / 6 * 1e-3) / 1e12);
+}
+
+
+// S2: as S, plus one 8-byte list entry per 256-byte output row read from a buffer of `meta_slots` entries (wrapping): is it the
+// HBM READ inside a saturated write stream that halves k_emit_stream?  small buffer = L2 hits, 32 MB = Infinity Cache, 200 MB = HBM
+__global__ __launch_bounds__(256) void ks2(const u32x4 *__restrict__ inner, i64 n_chunks16, const u32x4 *__restrict__ outer, u32x4 *__restrict__ out,
+                                           const u64 *__restrict__ meta, i64 meta_slots) {
+    const i64 f = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_chunks16) return;
+    const i64 slot = f >> 4;
+    const int c = (int)(f & 15);
+    const u64 m = meta[slot % meta_slots];
+    const i64 row = (slot + (i64)(m & 1)) & 8191;
+    const u32x4 v = inner[row * 16 + c] ^ outer[c];
+    __builtin_nontemporal_store(v, out + f);
+}
+__global__ void k_fill_list(u64 *meta, i64 n, int nt) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (nt) __builtin_nontemporal_store((u64)(i * 2), meta + i); else meta[i] = (u64)(i * 2);
+}
+static int g_refill = 0;   // 1: the list is rewritten (plain stores) by a kernel right before every stream launch, 2: with nt stores
+void runs2(const u32x4 *in, const u32x4 *outer, u32x4 *out, i64 n_chunks16, u64 *meta, i64 meta_slots) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float sum = 0;
+    for (int rep = 0; rep < 8; ++rep) {
+        if (g_refill) hipLaunchKernelGGL(k_fill_list, dim3((unsigned)((meta_slots + 255) / 256)), dim3(256), 0, 0, meta, meta_slots, g_refill == 2);
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(ks2, dim3((unsigned)((n_chunks16 + 255) / 256)), dim3(256), 0, 0, in, n_chunks16, outer, out, meta, meta_slots);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep >= 2) sum += ms;
+    }
+    printf("S2 (refill %d) stream + 8-byte list entry per row, list of %9lld entries (%7.1f MB)  avg %.3f ms  %.2f TB/s\n", g_refill, (long long)meta_slots, meta_slots * 8 / 1e6,
+           sum / 6, (double)n_chunks16 * 16 / (sum / 6 * 1e-3) / 1e12);
+}
+
+
+// S3: k_emit_stream of cleanup.hip verbatim (RC chunks per lane, clamped index, nt list load)
+struct u2 { u32 x, y; };
+template <int RC, int VAR = 0>
+__global__ __launch_bounds__(256) void ks3(const u2 *__restrict__ meta, i64 n_chunks16, int Wq, int wsh,
+                                           const u32x4 *__restrict__ inner, const u32x4 *__restrict__ outer, u32x4 *__restrict__ out_rows) {
+    const i64 f0 = (i64)blockIdx.x * (256 * RC) + threadIdx.x;
+    const i64 last = n_chunks16 - 1;
+    u2 m[RC];
+    int c[RC];
+#pragma unroll
+    for (int k = 0; k < RC; ++k) {
+        const i64 f = (VAR & 2) ? f0 + 256 * k : (f0 + 256 * k < last ? f0 + 256 * k : last);
+        const i64 slot = (VAR & 8) ? f >> 4 : (wsh >= 0 ? f >> wsh : f / Wq);
+        c[k] = (int)(f - slot * Wq);
+        const u64 mm = (VAR & 1) ? reinterpret_cast<const u64 *>(meta)[slot] : __builtin_nontemporal_load(reinterpret_cast<const u64 *>(meta) + slot);
+        m[k].x = (u32)mm; m[k].y = (u32)(mm >> 32);
+        if (VAR & 4) { m[k].x = (u32)(slot & 8191) + (m[k].x & 1u); m[k].y = m[k].y & 1u; }
+    }
+    u32x4 v[RC];
+#pragma unroll
+    for (int k = 0; k < RC; ++k) v[k] = inner[(i64)m[k].x * Wq + c[k]] ^ outer[(i64)m[k].y * Wq + c[k]];
+    if ((i64)blockIdx.x * (256 * RC) + 256 * RC <= n_chunks16) {
+#pragma unroll
+        for (int k = 0; k < RC; ++k) __builtin_nontemporal_store(v[k], out_rows + f0 + 256 * k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+            if (f0 + 256 * k < n_chunks16) __builtin_nontemporal_store(v[k], out_rows + f0 + 256 * k);
+    }
+}
+// list entries as the cleanup of a squared operator produces them: outer index o fixed over long runs, inner index ascending with gaps
+__global__ void k_fill_tri(u64 *meta, i64 n, u32 N) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 o = (u32)(i / (N / 2)) % N, ii = (u32)((i % (N / 2)) * 2 + (i & 1)) % N;
+    meta[i] = (u64)ii | ((u64)o << 32);
+}
+static u64 *g_pollute = nullptr; static i64 g_pollute_n = 0;   // a buffer rewritten between the list fill and the stream
+template <int RC, int VAR = 0> void runs3(const char *name, const u32x4 *in, u32x4 *out, i64 n_slots, u64 *meta, int same_ops) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float sum = 0;
+    const i64 n_chunks16 = n_slots * 16;
+    for (int rep = 0; rep < 8; ++rep) {
+        if (same_ops >= 2) hipLaunchKernelGGL(k_fill_tri, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, 0, meta, n_slots, 10000u);
+        if (same_ops >= 3) hipLaunchKernelGGL(k_fill_list, dim3((unsigned)((g_pollute_n + 255) / 256)), dim3(256), 0, 0, g_pollute, g_pollute_n, 0);
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((ks3<RC, VAR>), dim3((unsigned)((n_chunks16 + 256 * RC - 1) / (256 * RC))), dim3(256), 0, 0, (const u2 *)meta, n_chunks16, 16, 4, in, in, out);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep >= 2) sum += ms;
+    }
+    printf("S3 var %2d %-40s RC=%d slots=%lld  avg %.3f ms  %.2f TB/s\n", VAR, name, RC, (long long)n_slots, sum / 6, (double)n_chunks16 * 16 / (sum / 6 * 1e-3) / 1e12);
+}
+
 // checker: one thread per pair
 __global__ void k_check(const u64 *inner, const u64 *outer, i64 Ni, i64 No, const f64x2 *ci, const f64x2 *co, const f64x2 *outc,
                         const u64 *outrows, int *bad) {
@@ -374,6 +489,36 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(k_ycount, dim3((unsigned)((No + 255) / 256)), dim3(256), 0, 0, outer, No, yo);
     unsigned char *eb; (void)hipMalloc(&eb, (size_t)No * (Ni + 4096) / 4 + 4096);
     const u32x4 *pin = (const u32x4 *)in, *po = (const u32x4 *)outer;
+    { u64 *meta; (void)hipMalloc(&meta, 26000000ull * 8); (void)hipMemset(meta, 0, 26000000ull * 8);
+      for (int rf = 0; rf < 3; ++rf) { g_refill = rf; for (i64 ms : {1000000LL, 4000000LL, 25600000LL}) runs2(pin, po, out, Ni * 16 * No, meta, ms); } }
+    { u64 *meta; (void)hipMalloc(&meta, 26000000ull * 8);
+      const i64 ns = 24992058;
+      hipLaunchKernelGGL(k_fill_list, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, 0, meta, ns, 0);
+      // k_fill_list leaves x = 2 i (all rows of a 1e5-row operand... clamp to 8192 rows): rewrite as i & 8191
+      hipLaunchKernelGGL(k_fill_tri, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, 0, meta, ns, 8192u);
+      runs3<1>("tri-like list over 8192 rows", pin, out, ns, meta, 1);
+      runs3<4>("tri-like list over 8192 rows", pin, out, ns, meta, 1);
+      hipLaunchKernelGGL(k_fill_tri, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, 0, meta, ns, 10000u);
+      runs3<1>("tri-like list over 10000 rows", pin, out, ns, meta, 1);
+      runs3<4>("tri-like list over 10000 rows", pin, out, ns, meta, 1);
+      runs3<1, 1>("plain load", pin, out, ns, meta, 1);
+      runs3<1, 2>("no clamp", pin, out, ns, meta, 1);
+      runs3<1, 4>("rows slot & 8191 + bit", pin, out, ns, meta, 1);
+      runs3<1, 8>("constant shift", pin, out, ns, meta, 1);
+      runs3<1, 15>("all four", pin, out, ns, meta, 1);
+      runs3<1, 7>("plain, no clamp, rows slot", pin, out, ns, meta, 1);
+      runs3<1, 6>("no clamp, rows slot", pin, out, ns, meta, 1);
+      runs3<1, 1>("plain load, list refilled before", pin, out, ns, meta, 2);
+      (void)hipMalloc(&g_pollute, 1ull << 30); g_pollute_n = (1ll << 30) / 8;
+      runs3<1, 1>("plain load, refilled, then 1 GB written", pin, out, ns, meta, 3);
+      g_pollute_n = (256ll << 20) / 8;
+      runs3<1, 1>("plain load, refilled, then 256 MB written", pin, out, ns, meta, 3);
+      g_pollute_n = (64ll << 20) / 8;
+      runs3<1, 1>("plain load, refilled, then 64 MB written", pin, out, ns, meta, 3);
+      for (i64 nsl : {250000LL, 1000000LL, 4000000LL, 8000000LL, 16000000LL}) { runs3<1, 0>("nt load, short list/output", pin, out, nsl, meta, 1); runs3<1, 1>("plain load, short list/output", pin, out, nsl, meta, 1); } }
+    runs<0>("S 1-D stream, rows slot & 8191", pin, po, out, Ni * 16 * No, 8191);
+    runs<0>("S 1-D stream, rows slot & 65535", pin, po, out, Ni * 16 * No, 65535);
+    runs<1>("S 1-D stream, rows slot % 99991", pin, po, out, Ni * 16 * No, 0);
     for (int rep = 0; rep < 2; ++rep) {
         run<0>("A rows only", pin, po, out, yi, yo, ci, co, outc, Ni, No);
         run<2>("C rows + phase exponents, no coeff store", pin, po, out, yi, yo, ci, co, outc, Ni, No);
