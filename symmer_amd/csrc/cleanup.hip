@@ -29,6 +29,24 @@ static u64 host_splitmix64(u64 &s) {
 }
 
 static std::vector<u64> g_host_tab;   // host copy of the device tables (to hash single rows, e.g. a rotation's Q)
+// k_hash_rows_long: columns of M^(2^j), M = the xorshift step of the per-lane Horner scheme (a linear map on GF(2)^64), j < 32
+static u64 host_xorshift_step(u64 h) { h ^= h << 13; h ^= h >> 7; h ^= h << 17; return h; }
+static int ensure_xs_pow() {
+    if (ctx().xs_pow) return SYMGPU_OK;
+    std::vector<u64> P(32 * 64);
+    for (int i = 0; i < 64; ++i) P[i] = host_xorshift_step(1ULL << i);
+    for (int j = 1; j < 32; ++j)
+        for (int i = 0; i < 64; ++i) {                               // column i of M^(2^j) = M^(2^(j-1)) applied to column i of M^(2^(j-1))
+            const u64 x = P[(j - 1) * 64 + i];
+            u64 y = 0;
+            for (int b = 0; b < 64; ++b)
+                if ((x >> b) & 1) y ^= P[(j - 1) * 64 + b];
+            P[j * 64 + i] = y;
+        }
+    HIP_TRY(hipMalloc((void **)&ctx().xs_pow, P.size() * sizeof(u64)));
+    HIP_TRY(hipMemcpy(ctx().xs_pow, P.data(), P.size() * sizeof(u64), hipMemcpyHostToDevice));
+    return SYMGPU_OK;
+}
 
 int ensure_hash_tables(u64 seed) {
     Context &c = ctx();
@@ -94,22 +112,33 @@ __global__ __launch_bounds__(256) void k_hash_rows(const u64 *__restrict__ rows,
         u64 h1[HU];
 #pragma unroll
         for (int u = 0; u < HU; ++u) h1[u] = 0;
-        for (int b = 0; b < n_blk; ++b) {
-            const int w = b * 64 + g;
-            u64 x[HU];
+        // BU 64-word blocks of every row group are loaded before the (sequential) Horner steps consume them: a 1e8-qubit row is
+        // 48,828 blocks long, and one dependent load per step made its hash 80 ms
+        constexpr int BU = 4;
+        for (int b0 = 0; b0 < n_blk; b0 += BU) {
+            u64 x[BU][HU];
 #pragma unroll
-            for (int u = 0; u < HU; ++u) {
-                const i64 t = t0 + (i64)u * rows_per_block + rsub;
-                x[u] = (t < T && w < W && g < 64) ? rows[t * W + w] : 0ULL;
+            for (int bu = 0; bu < BU; ++bu) {
+                const int w = (b0 + bu) * 64 + g;
+#pragma unroll
+                for (int u = 0; u < HU; ++u) {
+                    const i64 t = t0 + (i64)u * rows_per_block + rsub;
+                    x[bu][u] = (t < T && w < W && g < 64) ? rows[t * W + w] : 0ULL;
+                }
             }
 #pragma unroll
-            for (int u = 0; u < HU; ++u) {
-                u64 a1 = 0;
-                if (w < W && g < 64) {
+            for (int bu = 0; bu < BU; ++bu) {
+                if (b0 + bu >= n_blk) break;                            // uniform
+                const int w = (b0 + bu) * 64 + g;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) a1 ^= tab[k * 256 + (int)((x[u] >> (8 * k)) & 255)];
+                for (int u = 0; u < HU; ++u) {
+                    u64 a1 = 0;
+                    if (w < W && g < 64) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) a1 ^= tab[k * 256 + (int)((x[bu][u] >> (8 * k)) & 255)];
+                    }
+                    h1[u] = xorshift_step(h1[u]) ^ rotl64(a1, g);
                 }
-                h1[u] = xorshift_step(h1[u]) ^ rotl64(a1, g);
             }
         }
 #pragma unroll
@@ -119,6 +148,57 @@ __global__ __launch_bounds__(256) void k_hash_rows(const u64 *__restrict__ rows,
             if (g == 0 && t < T) out1[t] = h1[u];
         }
     }
+}
+
+// The same hash for VERY long rows (>= 8192 words: > 262,144 qubits; the reference's "two 100,000,000-qubit Pauli terms",
+// README.md:54).  The Horner scheme of k_hash_rows is one dependent step per 64 words — 48,828 steps, 37 ms, for a 1e8-qubit row on
+// ONE wavefront.  It is linear:  h_g = sum_b M^(n_blk-1-b) v_(b,g),  so a wavefront can run it over a SEGMENT of LSEG blocks and
+// shift its partial result to the end of the row with M^(n_blk - segment end) (square-and-multiply on the precomputed columns
+// of M^(2^j): <= 16 bit-matrix products), and the segments of a row combine with XOR (atomicXor; out1 zeroed by the caller).
+constexpr int LSEG = 64;
+__global__ __launch_bounds__(256) void k_hash_rows_long(const u64 *__restrict__ rows, i64 t_base, int W, const u64 *__restrict__ tab_g,
+                                                         const u64 *__restrict__ xs_pow, u64 *__restrict__ out1) {
+    __shared__ u64 tab[8 * 256];
+    for (int k = threadIdx.x; k < 8 * 256; k += 256) tab[k] = tab_g[2 * k];
+    __syncthreads();
+    const int g = threadIdx.x & 63;
+    const int n_blk = (W + 63) / 64;
+    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b_lo = seg * LSEG;
+    if (b_lo >= n_blk) return;
+    const int b_hi = b_lo + LSEG < n_blk ? b_lo + LSEG : n_blk;
+    const i64 t = t_base + blockIdx.y;
+    const u64 *row = rows + t * W;
+    u64 h = 0;
+    constexpr int BU = 8;
+    for (int b0 = b_lo; b0 < b_hi; b0 += BU) {
+        u64 x[BU];
+#pragma unroll
+        for (int bu = 0; bu < BU; ++bu) {
+            const int w = (b0 + bu) * 64 + g;
+            x[bu] = (b0 + bu < b_hi && w < W) ? row[w] : 0ULL;
+        }
+#pragma unroll
+        for (int bu = 0; bu < BU; ++bu) {
+            if (b0 + bu >= b_hi) break;                              // wave-uniform
+            u64 a1 = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a1 ^= tab[k * 256 + (int)((x[bu] >> (8 * k)) & 255)];   // padding words are zero: tab[..][0] = 0
+            h = xorshift_step(h) ^ rotl64(a1, g);
+        }
+    }
+    // h <- M^(n_blk - b_hi) h
+    for (unsigned k = (unsigned)(n_blk - b_hi), j = 0; k; k >>= 1, ++j) {
+        if (!(k & 1u)) continue;                                     // wave-uniform
+        const u64 *P = xs_pow + j * 64;
+        u64 y = 0;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) y ^= P[i] & (0ULL - ((h >> i) & 1ULL));
+        h = y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) h ^= __shfl_xor(h, off);
+    if (g == 0) atomicXor(reinterpret_cast<unsigned long long *>(out1 + t), (unsigned long long)h);
 }
 
 __global__ void k_iota_keys_plain(u32 *__restrict__ idx, i64 T) {
@@ -491,6 +571,18 @@ static int pow2_group(int W) {
 
 int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
     if (T == 0) return SYMGPU_OK;
+    if (W >= 64 * 128) {                                            // very long rows: segments in parallel (k_hash_rows_long)
+        SG_TRY(ensure_xs_pow());
+        hipStream_t st = ctx().stream;
+        HIP_TRY(hipMemsetAsync(out1, 0, (size_t)T * sizeof(u64), st));
+        const int n_seg = ((W + 63) / 64 + LSEG - 1) / LSEG;
+        for (i64 t0 = 0; t0 < T; t0 += 65535) {
+            const i64 nt = T - t0 < 65535 ? T - t0 : 65535;
+            hipLaunchKernelGGL(k_hash_rows_long, dim3((unsigned)((n_seg + 3) / 4), (unsigned)nt), dim3(256), 0, st, rows, t0, W, ctx().hash_tab, ctx().xs_pow, out1);
+            KERNEL_CHECK();
+        }
+        return SYMGPU_OK;
+    }
     const int G = pow2_group(W);
     const int rpb = 4 * (256 / G);                                  // k_hash_rows: HU = 4 row groups per step
     i64 g = (T + rpb - 1) / rpb;

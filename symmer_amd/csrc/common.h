@@ -50,6 +50,7 @@ struct Context {
     // linear-hash tables (cleanup): 8 byte positions x 256 values x {h1,h2}; reseeded on collision
     u64 *hash_tab = nullptr;       // device, [8][256][2]
     u64 hash_seed = 0;
+    u64 *xs_pow = nullptr;         // device, [32][64]: columns of M^(2^j), M = the hash's xorshift step (k_hash_rows_long, cleanup.hip)
     // rotation hash join (rotate.hip): persistent open-addressing table of [tag 32 | generation 10 | row index + 1 : 22] entries.
     // An entry of another generation is empty, so the table is cleared once per 1023 rotations instead of once per rotation.
     u64 *rot_table = nullptr;
@@ -171,6 +172,12 @@ int mul_coeff_dev(const u64 *inner, const double *ci, i64 Ni, const u64 *outer, 
 int mul_rows_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 o_begin, i64 o_end, int Wq, u64 *out_rows);
 // packed (hash | phase exponent | o | i) keys of all pairs, for the fused product + cleanup
 int mul_keys_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 No, int Wq, int inner_is_left, PairKeyArgs ka);
+
+// wide.hip — few pairs of very long rows: the word axis is the parallel one
+bool wide_pairs_worthwhile(i64 Ni, i64 No, int Wq);
+int wide_commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits);
+int wide_mul_coeff_dev(const u64 *inner, const double *ci, i64 Ni, const u64 *outer, const double *co, i64 o_begin, i64 o_end, int Wq,
+                       int inner_is_left, double *out_coeff, const PairKeyArgs *keys);
 
 // cleanup.hip
 int ensure_hash_tables(u64 seed);

@@ -131,8 +131,30 @@ __global__ void k_ycount(const u64 *__restrict__ rows, i64 T, int Wq, int *__res
     }
 }
 
+// long rows: one block per row, the words spread over its threads (one thread walking 1.5 million words took 0.2 s)
+__global__ __launch_bounds__(256) void k_ycount_long(const u64 *__restrict__ rows, i64 t_base, int Wq, int *__restrict__ out) {
+    __shared__ int red[4];
+    const i64 t = t_base + blockIdx.x;
+    const u64 *r = rows + t * 2 * Wq;
+    int c = 0;
+    for (int w = threadIdx.x; w < Wq; w += 256) c += __popcll(r[w] & r[Wq + w]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) out[t] = red[0] + red[1] + red[2] + red[3];
+}
+
 int ycount_dev(const u64 *rows, i64 T, int Wq, int *out) {
     if (T == 0) return SYMGPU_OK;
+    if (Wq >= 512) {
+        for (i64 t0 = 0; t0 < T; t0 += 0x7fffffff) {
+            const i64 nt = T - t0 < 0x7fffffff ? T - t0 : 0x7fffffff;
+            hipLaunchKernelGGL(k_ycount_long, dim3((unsigned)nt), dim3(256), 0, ctx().stream, rows, t0, Wq, out);
+            KERNEL_CHECK();
+        }
+        return SYMGPU_OK;
+    }
     int grid = (int)((T + 255) / 256);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(k_ycount, dim3(grid), dim3(256), 0, ctx().stream, rows, T, Wq, out);
@@ -158,6 +180,7 @@ static bool use_m4r(i64 N, i64 M, int Wq) {
 int commutes_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits, symgpu_op_s *b_owner) {
     if (N == 0 || M == 0) return SYMGPU_OK;
     if (use_m4r(N, M, Wq)) return commutes_m4r_dev(A, N, B, M, Wq, out, out_bits, b_owner);
+    if (wide_pairs_worthwhile(N, M, Wq)) return wide_commutes_dev(A, N, B, M, Wq, out, out_bits);      // few pairs of very long rows
     const int W = 2 * Wq;
     const int cj = DJ;
     const bool same = (B == A && M == N);                 // adjacency: one word-major copy serves both sides

@@ -321,6 +321,7 @@ int symgpu_shutdown(void) {
     (void)hipStreamSynchronize(c.stream);
     dev_cache_release();
     if (c.hash_tab) { (void)hipFree(c.hash_tab); c.hash_tab = nullptr; }
+    if (c.xs_pow) { (void)hipFree(c.xs_pow); c.xs_pow = nullptr; }
     if (c.rot_table) { (void)hipFree(c.rot_table); c.rot_table = nullptr; c.rot_table_cap = 0; c.rot_gen = 0; }
     if (c.rot_flags) { (void)hipFree(c.rot_flags); c.rot_flags = nullptr; }
     (void)hipEventDestroy(c.ev0);

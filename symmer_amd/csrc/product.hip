@@ -390,6 +390,8 @@ static int mul_coeff_launch(const u64 *It, i64 Ipad, const double *ci, i64 Ni, c
 int mul_coeff_dev(const u64 *inner, const double *ci, i64 Ni, const u64 *outer, const double *co, i64 o_begin, i64 o_end,
                   int Wq, int inner_is_left, double *out_coeff) {
     if (Ni == 0 || o_end - o_begin <= 0) return SYMGPU_OK;
+    if (wide_pairs_worthwhile(Ni, o_end - o_begin, Wq))           // few pairs of very long rows: parallel over the words (wide.hip)
+        return wide_mul_coeff_dev(inner, ci, Ni, outer, co, o_begin, o_end, Wq, inner_is_left, out_coeff, nullptr);
     const i64 Ipad = round_up(Ni, 64 * PJ);
     Scratch it, ot;
     SG_TRY(it.alloc((size_t)Ipad * 2 * Wq * sizeof(u64)));
@@ -399,6 +401,7 @@ int mul_coeff_dev(const u64 *inner, const double *ci, i64 Ni, const u64 *outer, 
 
 int mul_keys_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 No, int Wq, int inner_is_left, PairKeyArgs ka) {
     if (Ni == 0 || No <= 0) return SYMGPU_OK;
+    if (wide_pairs_worthwhile(Ni, No, Wq)) return wide_mul_coeff_dev(inner, nullptr, Ni, outer, nullptr, 0, No, Wq, inner_is_left, nullptr, &ka);
     const i64 Ipad = round_up(Ni, 64 * PJ);
     Scratch it, ot;
     SG_TRY(it.alloc((size_t)Ipad * 2 * Wq * sizeof(u64)));
@@ -521,6 +524,13 @@ int symgpu_mul_allpairs_dev(symgpu_op_t inner, symgpu_op_t outer, int64_t o_begi
         const bool fused = !(fe && fe[0] == '0');
         if (fused && fused_rows_supported(inner->Wq)) {
             SG_TRY(mul_rows_coeff_fused(inner, outer, o_begin, o_end, inner_is_left, out));
+            out->T = rows;
+            return SYMGPU_OK;
+        }
+        if (wide_pairs_worthwhile(inner->T, o_end - o_begin, inner->Wq)) {   // few pairs of very long rows (wide.hip)
+            SG_TRY(wide_mul_coeff_dev(inner->rows, inner->coeff, inner->T, outer->rows, outer->coeff, o_begin, o_end, inner->Wq, inner_is_left,
+                                      out->coeff, nullptr));
+            SG_TRY(mul_rows_dev(inner->rows, inner->T, outer->rows, o_begin, o_end, inner->Wq, out->rows));
             out->T = rows;
             return SYMGPU_OK;
         }

@@ -796,3 +796,79 @@ def test_rref_small_and_blocked_paths_agree(R, C, dens, monkeypatch):
     ered, ecnt = onp.rref_noswap(m, count_xors=True)
     assert np.array_equal(red1, red2) and cnt1 == cnt2 == ecnt and np.array_equal(piv1, piv2)
     assert np.array_equal(packing.unpack_bits(red1, C), ered)
+
+
+# ---------------------------------------------------------------- few pairs of very long rows (wide.hip) ---
+@pytest.mark.parametrize('force', ['1', '0', None])
+@pytest.mark.parametrize('n,N,M', [(70000, 1, 1), (20000, 3, 5), (16321, 7, 2), (200003, 2, 2), (130, 9, 11), (1000, 40, 33)])
+def test_wide_rows_word_parallel_path(n, N, M, force, monkeypatch):
+    """The word-parallel kernels for few pairs of very long rows (SYMGPU_WIDE=1 forces them at any width, =0 forbids them, unset:
+    rows of >= 256 words per block and <= 65536 pairs) against the C oracle: commutation bytes and bits, all-pairs product
+    (rows + coefficients, both orientations), fused product + cleanup (keys path; squared operator and general pair)."""
+    if force is None:
+        monkeypatch.delenv('SYMGPU_WIDE', raising=False)
+    else:
+        monkeypatch.setenv('SYMGPU_WIDE', force)
+    rng = np.random.default_rng(900 + n + N)
+    A = rng.random((N, 2 * n)) < 0.3; B = rng.random((M, 2 * n)) < 0.3
+    if N > 1:
+        A[1] = A[0]                                                    # duplicate rows: the cleanup has something to merge
+    a, b = packing.pack_rows(A), packing.pack_rows(B)
+    assert np.array_equal(kernels.commutes(a, b), oc.commutes(a, b))
+    assert np.array_equal(PauliwordOp(A, np.ones(N)).commutes_termwise(PauliwordOp(B, np.ones(M))), oc.commutes(a, b).astype(bool))
+    import ctypes
+    from symmer_amd import _lib
+    da, db = kernels.DeviceOp.upload(a), kernels.DeviceOp.upload(b)
+    words = (M + 63) // 64
+    bits = ctypes.c_void_p()
+    _lib.check(_lib.lib().symgpu_dev_alloc(N * words * 8, ctypes.byref(bits)))
+    _lib.check(_lib.lib().symgpu_commutes_bits_dev(da.handle, 0, N, db.handle, bits))
+    got = np.empty((N, words), dtype='<u8')
+    _lib.check(_lib.lib().symgpu_dev_download(bits, got.ctypes.data, got.nbytes))
+    _lib.check(_lib.lib().symgpu_dev_free(bits))
+    assert np.array_equal(np.unpackbits(got.view(np.uint8), axis=1, bitorder='little')[:, :M], oc.commutes(a, b))
+    da.free(); db.free()
+    ca, cb = dyadic(rng, N), dyadic(rng, M)
+    for left in (True, False):
+        rows, coeff = kernels.mul_allpairs(a, ca, b, cb, left)
+        erows, ecoeff = oc.mul_allpairs(a, ca, b, cb, left)
+        assert np.array_equal(rows, erows) and np.array_equal(coeff, ecoeff)
+    PA, PB = PauliwordOp(A, ca), PauliwordOp(B, cb)
+    for X, Y in ((PA, PB), (PB, PA), (PA, PA)):
+        R = X * Y
+        es, ec = onp.mul(X.symp_matrix, X.coeff_vec, Y.symp_matrix, Y.coeff_vec)
+        assert np.array_equal(R.symp_matrix, es) and np.array_equal(R.coeff_vec, ec)
+
+
+@pytest.mark.parametrize('n,T', [(524288 + 77, 6), (600000, 3)])
+def test_very_long_rows_segment_parallel_hash(n, T):
+    """Rows of >= 8192 words take the segment-parallel row hash (k_hash_rows_long); it must be the SAME function as the Horner
+    scheme of k_hash_rows, the host's host_row_hash (a rotation's Q row) and rotate.hip's in-kernel hash: cleanup merges duplicates,
+    and a rotation merges P with (P Q) Q — rows hashed by different implementations — exactly like the oracle."""
+    rng = np.random.default_rng(1300 + T)
+    S = rng.random((T, 2 * n)) < 0.3
+    c = dyadic(rng, T)
+    q = rng.random(2 * n) < 0.3
+    symp = np.vstack([S, S[: T // 2] ^ q, S[:2]])                     # P, P*Q partners, plain duplicates
+    coeff = np.hstack([c, dyadic(rng, T // 2), dyadic(rng, 2)])
+    P = PauliwordOp(symp, coeff)
+    C = P.cleanup()
+    es, ec = onp.cleanup_op(symp, coeff)
+    assert np.array_equal(C.symp_matrix, es) and np.array_equal(C.coeff_vec, ec) and C.n_terms == T + T // 2
+    Q = PauliwordOp(q.reshape(1, -1), [1])
+    for ang in (0.3, np.pi / 2):
+        R = C._rotate_by_single_Pword(Q, ang)
+        er, ec2 = onp.rotate_by_single_pword(es, ec, q, ang)
+        assert_op_equal(R.symp_matrix, R.coeff_vec, er, ec2, exact=ang != 0.3, tol=TOL)
+    assert np.array_equal(P.Y_count, (P.X_block & P.Z_block).sum(axis=1))     # one block per row (k_ycount_long)
+    R2 = P * P                                                          # fused product + cleanup on operand hashes from the long kernel
+    es2, ec3 = onp.mul(symp, coeff, symp, coeff)
+    assert np.array_equal(R2.symp_matrix, es2) and np.array_equal(R2.coeff_vec, ec3)
+
+
+@pytest.mark.parametrize('n,T', [(1, 300), (63, 1000), (1000, 5000), (32768, 40), (40000, 7)])
+def test_y_count_vs_numpy(n, T):
+    """PauliwordOp.Y_count (base.py:604-615): per-row popcount of X & Z, thread per row and block per row (>= 512 words)."""
+    rng = np.random.default_rng(1400 + n)
+    P = PauliwordOp(rng.random((T, 2 * n)) < 0.4, np.ones(T))
+    assert np.array_equal(P.Y_count, (P.X_block & P.Z_block).sum(axis=1))
