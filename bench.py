@@ -111,6 +111,11 @@ def main():
         # this process (PyTorch wheels bundle their own HIP runtime; the product uses the system one)
         _lib.check(lib.symgpu_device_sync())
 
+    if comm.gathers:
+        # one gather outside the timed region, checked bit for bit against the same shards gathered through host memory: a data
+        # plane that delivers wrong rows is replaced by the host-staged one and the line is flagged `degraded`
+        comm.allgather_op(shard, right, M)
+        comm.verify_allgather(shard, right, M)
     for _ in range(args.warmup):
         step()
     full_sync(); comm.barrier()
@@ -233,6 +238,10 @@ def adjacency(args, comm, rank, world, _lib, DeviceOp, parallel):
         p = ctypes.c_void_p()
         _lib.check(lib.symgpu_dev_alloc(slab * T, ctypes.byref(p)))
         ring.append(p)
+
+    if comm.gathers:
+        comm.allgather_op(shard, full, T)
+        comm.verify_allgather(shard, full, T)       # bit-for-bit against a host-staged gather, outside the timed region
 
     def step():
         if comm.gathers:

@@ -287,6 +287,35 @@ class Communicator:
             self._allgather_op_host(shard, full)
         full.set_rows(n_rows_total)
 
+    def verify_allgather(self, shard, full, n_rows_total):
+        """Self-check of the RCCL data plane (call once, outside any timed region): gather the same shards a second time through
+        host memory over the control plane and compare them with the device result of ``allgather_op`` — rows and coefficients,
+        bit for bit, at their global positions.  If ANY rank sees a difference, all ranks leave RCCL for the host-staged plane
+        (``degraded`` says why).  Returns True when the data plane in use after the call delivered the right operand."""
+        from . import _lib
+        if not self.gathers or self.data_plane != 'rccl':
+            return True
+        t, wq, ts = shard.info()
+        try:
+            r, c = shard.download()
+            fr, fc = full.download()
+        except _lib.SymgpuError:
+            r, c = shard.download(with_coeff=False), None
+            fr, fc = full.download(with_coeff=False), None
+        rows = np.zeros((ts, 2 * wq), dtype='<u8'); rows[:t] = r
+        exp_rows = np.frombuffer(self._allgather_bytes(rows.tobytes()), dtype='<u8').reshape(self.world * ts, 2 * wq)[:n_rows_total]
+        ok = fr.shape == exp_rows.shape and np.array_equal(fr, exp_rows)
+        if c is not None:
+            coeff = np.zeros(ts, dtype=np.complex128); coeff[:t] = c
+            exp_c = np.frombuffer(self._allgather_bytes(coeff.tobytes()), dtype=np.complex128)[:n_rows_total]
+            ok = ok and np.array_equal(fc.view(np.float64), exp_c.view(np.float64))
+        if self.max_over_ranks(0.0 if ok else 1.0) > 0.0:
+            _lib.load().symgpu_comm_destroy()
+            self._fallback('the RCCL all-gather delivered rows that differ from the shards')
+            self.allgather_op(shard, full, n_rows_total)
+            return False
+        return True
+
     def _allgather_bytes(self, payload):
         if self._tcp is not None:
             return self._tcp.allgather(payload)

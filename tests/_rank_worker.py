@@ -23,6 +23,7 @@ shard = parallel.padded_random_shard(mine, ts, n, 4242 + rank)
 full = DeviceOp.alloc(ts * world, wq, with_coeff=True)
 for _ in range(2):                                            # twice: the gather must be repeatable into the same handle
     comm.allgather_op(shard, full, M)
+assert comm.verify_allgather(shard, full, M) and comm.data_plane == (want or comm.data_plane)     # the self-check agrees with a healthy plane
 rows, coeff = full.download()
 exp_r, exp_c = [], []
 for r in range(world):

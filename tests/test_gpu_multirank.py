@@ -91,3 +91,12 @@ def test_bench_adjacency_two_ranks():
     assert len(lines) == 1 and not outs[1][1].strip()
     doc = json.loads(lines[0])
     assert doc['n_gpus'] == 2 and doc['config']['rows_per_gpu'] == 10000 and doc['config']['pairs_per_step'] == 20000 ** 2 and doc['value'] > 0
+
+
+@pytest.mark.timeout(300)
+def test_rccl_self_check_detects_a_wrong_gather_and_falls_back():
+    """Communicator.verify_allgather (bench.py runs it once before the timed region): RCCL with one rank (SYMGPU_FORCE_COMM=1);
+    a flipped bit in the gathered operand switches every rank to the host-staged plane, flagged `degraded`, operand repaired."""
+    outs = _launch(['tests/_rccl_selfcheck_worker.py'], 1, {'SYMGPU_FORCE_COMM': '1'})
+    rc, o, e = outs[0]
+    assert rc == 0 and 'SELFCHECK_OK' in o, f'rc={rc}\n{o}\n{e[-3000:]}'
