@@ -52,6 +52,9 @@ int symgpu_timer_stop(float *ms);
  * 1 = commutation k_commutes, 2 = GF(2) sweep k_sweep): enable, run, then read {launch count, total ms}. */
 int symgpu_prof_enable(int kernel_class, int on);
 int symgpu_prof_read(int kernel_class, int64_t *n_launches, double *total_ms);
+/* statistics for tests: which = 0: number of row-hash collisions that forced the cleanup to reseed its hash and retry (the exactness
+ * guard behind symplectic_cleanup, operators/utils.py:230-279; expected 0 outside the tests, which weaken the hash on purpose) */
+int symgpu_debug_counter(int which, int64_t *value);
 
 /* measured on-box HBM ceilings for the roofline: one-shot 16-byte-per-thread fill (GB/s written) and copy (GB/s read+written)
  * over scratch buffers of `bytes` each (best of 3). */

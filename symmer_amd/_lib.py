@@ -39,6 +39,7 @@ SIGNATURES = {
     'symgpu_timer_stop': [P],
     'symgpu_prof_enable': [c_int, c_int],
     'symgpu_prof_read': [c_int, P, P],
+    'symgpu_debug_counter': [c_int, P],
     'symgpu_membw_probe': [c_i64, P, P],
     'symgpu_op_upload': [P, P, c_i64, c_int, PP],
     'symgpu_op_alloc': [c_i64, c_int, c_int, PP],

@@ -28,6 +28,7 @@ static u64 host_splitmix64(u64 &s) {
     return z ^ (z >> 31);
 }
 
+i64 g_hash_reseeds = 0;                // statistics (symgpu_debug_counter 0)
 static std::vector<u64> g_host_tab;   // host copy of the device tables (to hash single rows, e.g. a rotation's Q)
 // k_hash_rows_long: columns of M^(2^j), M = the xorshift step of the per-lane Horner scheme (a linear map on GF(2)^64), j < 32
 static u64 host_xorshift_step(u64 h) { h ^= h << 13; h ^= h >> 7; h ^= h << 17; return h; }
@@ -57,6 +58,12 @@ int ensure_hash_tables(u64 seed) {
     u64 basis[2][64];
     for (int h = 0; h < 2; ++h)
         for (int b = 0; b < 64; ++b) basis[h][b] = host_splitmix64(s);
+    // test hook: SYMGPU_HASH_WEAK_ODD=1 leaves an odd seed only the 4 top hash bits, so that different rows collide in bulk and the
+    // exactness guard (row-against-row verification -> reseed -> retry; long mixed prefix runs -> full 64-bit sort) actually runs
+    if (const char *e = getenv("SYMGPU_HASH_WEAK_ODD"))
+        if (e[0] == '1' && (seed & 1))
+            for (int h = 0; h < 2; ++h)
+                for (int b = 0; b < 64; ++b) basis[h][b] &= 0xF000000000000000ULL;
     for (int k = 0; k < 8; ++k)
         for (int v = 0; v < 256; ++v)
             for (int h = 0; h < 2; ++h) {
@@ -798,7 +805,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         HIP_TRY(hipStreamSynchronize(st));
         if (hflags[1]) { nb = 64; packed = false; squared = false; Tk = T; continue; }   // a long mixed prefix run: redo with a full 64-bit sort over all pairs, same seed
         ok = (hflags[0] == 0);
-        if (!ok) ++seed;                            // genuine 64-bit hash collision: reseed and retry
+        if (!ok) { ++seed; ++g_hash_reseeds; }      // genuine 64-bit hash collision: reseed and retry
     }
     if (!ok) {
         set_error("cleanup: 64-bit row-hash collision survived 4 reseeds");

@@ -180,6 +180,7 @@ int wide_mul_coeff_dev(const u64 *inner, const double *ci, i64 Ni, const u64 *ou
                        int inner_is_left, double *out_coeff, const PairKeyArgs *keys);
 
 // cleanup.hip
+extern i64 g_hash_reseeds;                                      // row-hash collisions that forced a reseed (never seen outside the tests)
 int ensure_hash_tables(u64 seed);
 int hash_rows(const u64 *rows, i64 T, int W, u64 *out1);       // h1 of every row (current tables)
 u64 host_row_hash(const u64 *row, int W);                       // the same hash on the host

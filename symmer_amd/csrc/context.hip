@@ -419,6 +419,12 @@ int symgpu_prof_enable(int kernel_class, int on) {
     return SYMGPU_OK;
 }
 
+int symgpu_debug_counter(int which, int64_t *value) {
+    SG_REQUIRE(value && which == 0, "debug_counter: 0 = row-hash reseeds");
+    *value = g_hash_reseeds;
+    return SYMGPU_OK;
+}
+
 int symgpu_prof_read(int kernel_class, int64_t *n_launches, double *total_ms) {
     SG_TRY(require_ctx());
     SG_REQUIRE(kernel_class >= 0 && kernel_class < 3, "prof_read: class");

@@ -100,3 +100,15 @@ def test_rccl_self_check_detects_a_wrong_gather_and_falls_back():
     outs = _launch(['tests/_rccl_selfcheck_worker.py'], 1, {'SYMGPU_FORCE_COMM': '1'})
     rc, o, e = outs[0]
     assert rc == 0 and 'SELFCHECK_OK' in o, f'rc={rc}\n{o}\n{e[-3000:]}'
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('worker', [['tests/_weak_hash_worker.py'], ['tests/_weak_hash_worker2.py', 'square'], ['tests/_weak_hash_worker2.py', 'pair'],
+                                    ['tests/_weak_hash_worker2.py', 'rotate']])
+def test_row_hash_collisions_are_caught_and_reseeded(worker):
+    """The cleanup's exactness never rests on its 64-bit row hash: rows with equal hashes are compared word for word and a mismatch
+    reseeds the hash and redoes the pass.  SYMGPU_HASH_WEAK_ODD=1 cuts the first seed's hash to 4 bits in a fresh process, so the
+    guard (and the full-sort fallback for long mixed prefix runs) actually runs; results must still be the oracle's."""
+    outs = _launch(worker, 1, {'SYMGPU_HASH_WEAK_ODD': '1'})
+    rc, o, e = outs[0]
+    assert rc == 0 and 'WEAK_HASH_OK' in o, f'rc={rc}\n{o}\n{e[-3000:]}'
