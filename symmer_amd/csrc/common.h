@@ -57,6 +57,7 @@ struct Context {
     size_t rot_table_cap = 0;      // entries (power of two)
     u32 rot_gen = 0;
     u32 *rot_flags = nullptr;      // device u32[4]: [0] = generation in which a duplicate input row was seen
+    void *rot_host_cnt = nullptr, *rot_host_cnt_dev = nullptr;   // pinned host copy of a rotation's counts and its device address (rotate.hip)
 };
 Context &ctx();
 int require_ctx();

@@ -324,6 +324,7 @@ int symgpu_shutdown(void) {
     if (c.xs_pow) { (void)hipFree(c.xs_pow); c.xs_pow = nullptr; }
     if (c.rot_table) { (void)hipFree(c.rot_table); c.rot_table = nullptr; c.rot_table_cap = 0; c.rot_gen = 0; }
     if (c.rot_flags) { (void)hipFree(c.rot_flags); c.rot_flags = nullptr; }
+    if (c.rot_host_cnt) { (void)hipHostFree(c.rot_host_cnt); c.rot_host_cnt = nullptr; c.rot_host_cnt_dev = nullptr; }
     (void)hipEventDestroy(c.ev0);
     (void)hipEventDestroy(c.ev1);
     (void)hipStreamSynchronize(c.stream2);

@@ -62,15 +62,27 @@ __device__ __forceinline__ void jt_insert(const JoinTable jt, const u64 *__restr
 }
 
 // HASH: compute the row hashes (-> hout); otherwise INSERT reads them from hin.  INSERT: put every row into the join table.
-template <bool HASH, bool INSERT>
-__global__ __launch_bounds__(256) void k_rot_analyze(const u64 *__restrict__ rows, i64 T, int Wq, int G, const u64 *__restrict__ q,
+// QARG: the rotation's Pauli row Q arrives BY VALUE in the kernel arguments (rows of <= 64 words) instead of in `q_dev`, which
+// block 0 then fills for the kernels that follow on the stream — no host-to-device copy in front of the first kernel of a rotation.
+struct QArg { u64 w[64]; };
+template <bool HASH, bool INSERT, bool QARG = false>
+__global__ __launch_bounds__(256) void k_rot_analyze(const u64 *__restrict__ rows, i64 T, int Wq, int G, u64 *__restrict__ q_dev,
                                                       u32 *__restrict__ flags, uint8_t *__restrict__ ph, const u64 *__restrict__ tab_g,
-                                                      u64 *__restrict__ hout, const u64 *__restrict__ hin, JoinTable jt) {
+                                                      u64 *__restrict__ hout, const u64 *__restrict__ hin, JoinTable jt, QArg qa = QArg()) {
     __shared__ u64 tab[HASH ? 8 * 256 : 1];
+    __shared__ u64 sq[QARG ? 64 : 1];
+    if (QARG) {
+        if ((int)threadIdx.x < 2 * Wq) {
+            const u64 v = qa.w[threadIdx.x];
+            sq[threadIdx.x] = v;
+            if (blockIdx.x == 0) q_dev[threadIdx.x] = v;
+        }
+    }
     if (HASH) {
         for (int k = threadIdx.x; k < 8 * 256; k += 256) tab[k] = tab_g[2 * k];      // h1 entries only
-        __syncthreads();
     }
+    if (HASH || QARG) __syncthreads();
+    const u64 *q = QARG ? sq : q_dev;
     const int rows_per_block = 256 / G;
     const int g = threadIdx.x % G, rsub = threadIdx.x / G;
     // Y count of q (every lane redundantly; Wq is small)
@@ -126,6 +138,74 @@ __global__ __launch_bounds__(256) void k_rot_analyze(const u64 *__restrict__ row
             if (HASH) hout[t] = h1;
             if (INSERT) jt_insert(jt, rows, W, t, HASH ? h1 : hin[t]);
         }
+    }
+}
+
+
+// The same analysis with ONE 16-byte chunk of a row per lane (rows whose 16-byte chunk count WQ = words per X block is a power
+// of two <= 64 and whose hashes are cached): a row is an aligned group of WQ lanes, X words in its lower and Z words in its upper
+// half, loads are 1 KiB per wave instruction (k_rot_analyze reads 8 bytes per lane and walks six dependent chains per block at
+// 1e5 rows: 22 us; this: 9 us).  Lane exchange as in product.hip's row stream: x & z and (x ^ xq) & (z ^ zq) need the other half
+// of the row (DPP / ds_bpermute), x & zq and z & xq only the other half of Q, which every lane reads from LDS.
+template <int CTRL> __device__ __forceinline__ u32 rot_dpp(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
+template <int WQ> __device__ __forceinline__ u32 rot_other_half(u32 v) {
+    if (WQ == 2) return rot_dpp<0xB1>(v);
+    if (WQ == 4) return rot_dpp<0x4E>(v);
+    if (WQ == 16) return rot_dpp<0x128>(v);
+    return (u32)__shfl_xor((int)v, WQ / 2);
+}
+template <int WQ> __device__ __forceinline__ u32 rot_row_sum(u32 s) {          // over the WQ lanes of the row (butterfly)
+    if (WQ >= 2) s += rot_dpp<0xB1>(s);
+    if (WQ >= 4) s += rot_dpp<0x4E>(s);
+    if (WQ >= 8) s += rot_dpp<0x141>(s);
+    if (WQ >= 16) s += rot_dpp<0x140>(s);
+    if (WQ >= 32) s += (u32)__shfl_xor((int)s, 16);
+    if (WQ >= 64) s += (u32)__shfl_xor((int)s, 32);
+    return s;
+}
+template <int WQ, bool INSERT, bool QARG>
+__global__ __launch_bounds__(256) void k_rot_analyze_chunks(const u32x4 *__restrict__ rows, i64 T, u64 *__restrict__ q_dev, u32 *__restrict__ flags,
+                                                             uint8_t *__restrict__ ph, const u64 *__restrict__ hin, JoinTable jt, QArg qa) {
+    __shared__ __attribute__((aligned(16))) u64 sq[2 * WQ];
+    __shared__ int s_yq;
+    if ((int)threadIdx.x < 2 * WQ) {
+        const u64 v = QARG ? qa.w[threadIdx.x] : q_dev[threadIdx.x];
+        sq[threadIdx.x] = v;
+        if (QARG && blockIdx.x == 0) q_dev[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int y = 0;
+        for (int w = 0; w < WQ; ++w) y += __popcll(sq[w] & sq[WQ + w]);
+        s_yq = y;
+    }
+    __syncthreads();
+    constexpr int R = 256 / WQ;                                       // rows per block
+    const int c = threadIdx.x & (WQ - 1);                            // chunk of the row: c < WQ/2 holds X words (WQ == 1: x and z word)
+    const i64 t = (i64)blockIdx.x * R + threadIdx.x / WQ;
+    const bool valid = t < T;
+    const u32x4 v = valid ? rows[t * WQ + c] : (u32x4)(0u);
+    u32 par, ye;                                                      // par: |x & zq| + |z & xq| (+ |x & zq| << 16);  ye: Y_P | Y_out << 16
+    if constexpr (WQ == 1) {
+        const u32x4 qv = *reinterpret_cast<const u32x4 *>(sq);
+        const u32 f = __popc(v.x & qv.z) + __popc(v.y & qv.w);
+        par = f + __popc(v.z & qv.x) + __popc(v.w & qv.y) + (f << 16);
+        ye = (__popc(v.x & v.z) + __popc(v.y & v.w)) | ((__popc((v.x ^ qv.x) & (v.z ^ qv.z)) + __popc((v.y ^ qv.y) & (v.w ^ qv.w))) << 16);
+    } else {
+        const u32x4 qs = reinterpret_cast<const u32x4 *>(sq)[c], qo = reinterpret_cast<const u32x4 *>(sq)[c ^ (WQ / 2)];
+        const bool xhalf = c < WQ / 2;
+        const u32 p = __popc(v.x & qo.x) + __popc(v.y & qo.y) + __popc(v.z & qo.z) + __popc(v.w & qo.w);    // x & zq (X half), z & xq (Z half)
+        const u32x4 o = {rot_other_half<WQ>(v.x), rot_other_half<WQ>(v.y), rot_other_half<WQ>(v.z), rot_other_half<WQ>(v.w)};
+        const u32 yp = __popc(v.x & o.x) + __popc(v.y & o.y) + __popc(v.z & o.z) + __popc(v.w & o.w);
+        const u32 yo = __popc((v.x ^ qs.x) & (o.x ^ qo.x)) + __popc((v.y ^ qs.y) & (o.y ^ qo.y)) + __popc((v.z ^ qs.z) & (o.z ^ qo.z)) +
+                       __popc((v.w ^ qs.w) & (o.w ^ qo.w));
+        par = rot_row_sum<WQ>(p + (xhalf ? (p << 16) : 0u));
+        ye = rot_row_sum<WQ>(xhalf ? (yp | (yo << 16)) : 0u);          // both halves form the same x & z words: count them once
+    }
+    if (c == 0 && valid) {
+        flags[t] = par & 1u;
+        ph[t] = (uint8_t)((3u * ((ye & 0xFFFFu) + (u32)s_yq) + (ye >> 16) + 2u * ((par >> 16) & 1u)) & 3u);
+        if (INSERT) jt_insert(jt, reinterpret_cast<const u64 *>(rows), 2 * WQ, t, hin[t]);
     }
 }
 
@@ -231,6 +311,18 @@ static int grid_for(i64 n, int block = 256, int cap = 8192) {
 // rows; strict |c| > thr everywhere.
 struct RotCounts { u32 nC, nA, nN, nAnti, dup; };          // dup: a duplicate input row was seen by this call's join-table insert
 
+// pinned, device-mapped host copy of the counts (one per context): written by k_rotf_scan3, read after the final synchronisation
+static int host_counts(RotCounts **host, RotCounts **dev) {
+    Context &c = ctx();
+    if (!c.rot_host_cnt) {
+        HIP_TRY(hipHostMalloc(&c.rot_host_cnt, 64, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(&c.rot_host_cnt_dev, c.rot_host_cnt, 0));
+    }
+    *host = reinterpret_cast<RotCounts *>(c.rot_host_cnt);
+    *dev = reinterpret_cast<RotCounts *>(c.rot_host_cnt_dev);
+    return SYMGPU_OK;
+}
+
 // The same join, ONE lane per row, fused with the per-1024-row block counts (k_rotf_count): probe the generation-tagged table for
 // h(P) ^ h(Q); only a tag hit reads rows (a lane then compares the two rows word by word).  1024 rows per block.
 __global__ __launch_bounds__(1024) void k_rotf_match2(const u64 *__restrict__ rows, const double *__restrict__ coeff, const u64 *__restrict__ h, i64 T,
@@ -299,7 +391,7 @@ __global__ __launch_bounds__(1024) void k_rotf_match2(const u64 *__restrict__ ro
 // come from k_rotf_match2 / k_rotc_classify, every block here adds the counts of the blocks before it (<= 4096) to its local ranks.
 __global__ __launch_bounds__(1024) void k_rotf_scan3(const uint8_t *__restrict__ cls, i64 T, const u32 *__restrict__ blk, int n_blk,
                                                       u32 *__restrict__ pos_self, u32 *__restrict__ pos_new, RotCounts *__restrict__ cnt,
-                                                      const u32 *__restrict__ jt_flags, u32 jt_gen_now) {
+                                                      const u32 *__restrict__ jt_flags, u32 jt_gen_now, RotCounts *__restrict__ host_cnt = nullptr) {
     __shared__ u32 s_w[3][16];
     __shared__ u32 s_base[4], s_all[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -337,6 +429,9 @@ __global__ __launch_bounds__(1024) void k_rotf_scan3(const uint8_t *__restrict__
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         cnt->nC = s_all[0]; cnt->nA = s_all[1]; cnt->nN = s_all[2]; cnt->nAnti = s_all[3];
         cnt->dup = (jt_flags && jt_flags[0] == jt_gen_now) ? 1u : 0u;        // one read-back for the counts and the duplicate flag
+        // the same five words straight into pinned host memory: the host reads them after the stream synchronisation that ends the
+        // rotation, without a device-to-host copy in between
+        if (host_cnt) { host_cnt->nC = s_all[0]; host_cnt->nA = s_all[1]; host_cnt->nN = s_all[2]; host_cnt->nAnti = s_all[3]; host_cnt->dup = cnt->dup; }
     }
 }
 
@@ -435,8 +530,10 @@ static int rotate_fast_clifford(symgpu_op_t in, const u64 *q_dev, const u64 *q_h
     SG_TRY(cnt.alloc(sizeof(RotCounts)));
     hipLaunchKernelGGL(k_rotc_classify, dim3(n_blk), dim3(1024), 0, st, anti, ph, in->coeff, T, k, thr, cls.as<uint8_t>(), selfc.as<double>(),
                        prodc.as<double>(), blk.as<u32>());
+    RotCounts *hcnt = nullptr, *hcnt_dev = nullptr;
+    SG_TRY(host_counts(&hcnt, &hcnt_dev));
     hipLaunchKernelGGL(k_rotf_scan3, dim3(n_blk), dim3(1024), 0, st, cls.as<uint8_t>(), T, blk.as<u32>(), n_blk, pself.as<u32>(), pnew.as<u32>(),
-                       cnt.as<RotCounts>(), (const u32 *)nullptr, 0u);
+                       cnt.as<RotCounts>(), (const u32 *)nullptr, 0u, hcnt_dev);
     KERNEL_CHECK();
     symgpu_op_t res = nullptr;
     SG_TRY(symgpu_op_alloc(T, Wq, 1, &res));                   // a Clifford rotation never adds rows
@@ -453,11 +550,10 @@ static int rotate_fast_clifford(symgpu_op_t in, const u64 *q_dev, const u64 *q_h
     hipLaunchKernelGGL(k_rotf_write, dim3(grid_for(T * Wq)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(in->rows),
                        reinterpret_cast<const u32x4 *>(q_dev), T, Wq, cls.as<uint8_t>(), pself.as<u32>(), pnew.as<u32>(), cnt.as<RotCounts>(),
                        selfc.as<double>(), prodc.as<double>(), reinterpret_cast<u32x4 *>(res->rows), res->coeff, 1, in_hash, hq, res->hash);
-    RotCounts hc;
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(&hc, cnt.p, sizeof(hc), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { symgpu_op_free(res); return hip_fail(e, "rotate Clifford fast path", __FILE__, __LINE__); }
+    const RotCounts hc = *hcnt;
     *done = 1;
     if (hc.nAnti == 0) { symgpu_op_free(res); *all_commute = 1; return SYMGPU_OK; }   // identity action (base.py:1131-1133)
     res->T = (i64)hc.nC + hc.nA + hc.nN;
@@ -497,29 +593,56 @@ static int join_table_for(i64 T, JoinTable *jt) {
 
 // flags + phase exponents of every row; with `jt` also the join-table insert (duplicate detection included), for which the row
 // hashes are taken from the handle or computed now and cached on it
-static int analyze_rows(symgpu_op_t in, const u64 *q_dev, u32 *anti, uint8_t *ph, const JoinTable *jt) {
+static int analyze_rows(symgpu_op_t in, u64 *q_dev, u32 *anti, uint8_t *ph, const JoinTable *jt, const u64 *q_host_arg = nullptr) {
     hipStream_t st = ctx().stream;
     const i64 T = in->T;
     const int Wq = in->Wq;
     int G = 1;
     while (G < Wq && G < 64) G <<= 1;
     const int rpb = 256 / G;
+    // word kernel: grid-stride over <= 1024 blocks (uncapped measured 20.6 / 14.2 us against 22.4 / 10.8 us with / without the insert)
+    static const i64 cap = [] { const char *e = getenv("SYMGPU_ROT_ANALYZE_CAP"); return e ? atoll(e) : (i64)1024; }();
     i64 g = (T + rpb - 1) / rpb;
-    if (g > 1024) g = 1024;
+    if (g > cap) g = cap;
     const JoinTable none = {nullptr, 0, 0, nullptr};
-    if (!jt) {
-        hipLaunchKernelGGL((k_rot_analyze<false, false>), dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q_dev, anti, ph, (const u64 *)nullptr,
-                           (u64 *)nullptr, (const u64 *)nullptr, none);
-    } else if (in->hash && in->hash_seed == ctx().hash_seed) {
-        hipLaunchKernelGGL((k_rot_analyze<false, true>), dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q_dev, anti, ph, (const u64 *)nullptr,
-                           (u64 *)nullptr, in->hash, *jt);
+    QArg qa;
+    const bool by_arg = q_host_arg != nullptr && 2 * Wq <= 64;           // Q travels in the kernel arguments (see k_rot_analyze)
+    if (by_arg) for (int w = 0; w < 2 * Wq; ++w) qa.w[w] = q_host_arg[w];
+    else if (q_host_arg) HIP_TRY(hipMemcpyAsync(q_dev, q_host_arg, (size_t)2 * Wq * 8, hipMemcpyHostToDevice, st));
+#define LAUNCH_AN(H, I, HT, HO, HI, J) do { if (by_arg) hipLaunchKernelGGL((k_rot_analyze<H, I, true>), dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q_dev, anti, ph, HT, HO, HI, J, qa); \
+                                           else hipLaunchKernelGGL((k_rot_analyze<H, I, false>), dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q_dev, anti, ph, HT, HO, HI, J, qa); } while (0)
+    const bool have_hash = jt && in->hash && in->hash_seed == ctx().hash_seed;
+    static const bool chunks_on = [] { const char *e = getenv("SYMGPU_ROT_CHUNKS"); return !(e && e[0] == '0'); }();
+    if (chunks_on && (!jt || have_hash) && Wq <= 64 && (Wq & (Wq - 1)) == 0) {
+        // one 16-byte chunk per lane (k_rot_analyze_chunks); rows of other lengths and the launch that also hashes keep the word kernel
+        const u32x4 *pr = reinterpret_cast<const u32x4 *>(in->rows);
+        const i64 gb = (T + 256 / Wq - 1) / (256 / Wq);
+#define LAUNCH_CH(WQV) do { \
+            if (jt) { if (by_arg) hipLaunchKernelGGL((k_rot_analyze_chunks<WQV, true, true>), dim3((unsigned)gb), dim3(256), 0, st, pr, T, q_dev, anti, ph, in->hash, *jt, qa); \
+                      else hipLaunchKernelGGL((k_rot_analyze_chunks<WQV, true, false>), dim3((unsigned)gb), dim3(256), 0, st, pr, T, q_dev, anti, ph, in->hash, *jt, qa); } \
+            else { if (by_arg) hipLaunchKernelGGL((k_rot_analyze_chunks<WQV, false, true>), dim3((unsigned)gb), dim3(256), 0, st, pr, T, q_dev, anti, ph, (const u64 *)nullptr, none, qa); \
+                   else hipLaunchKernelGGL((k_rot_analyze_chunks<WQV, false, false>), dim3((unsigned)gb), dim3(256), 0, st, pr, T, q_dev, anti, ph, (const u64 *)nullptr, none, qa); } } while (0)
+        switch (Wq) {
+            case 1: LAUNCH_CH(1); break;
+            case 2: LAUNCH_CH(2); break;
+            case 4: LAUNCH_CH(4); break;
+            case 8: LAUNCH_CH(8); break;
+            case 16: LAUNCH_CH(16); break;
+            case 32: LAUNCH_CH(32); break;
+            default: LAUNCH_CH(64); break;
+        }
+#undef LAUNCH_CH
+    } else if (!jt) {
+        LAUNCH_AN(false, false, (const u64 *)nullptr, (u64 *)nullptr, (const u64 *)nullptr, none);
+    } else if (have_hash) {
+        LAUNCH_AN(false, true, (const u64 *)nullptr, (u64 *)nullptr, in->hash, *jt);
     } else {
         if (in->hash) { dev_free(in->hash); in->hash = nullptr; }
         SG_TRY(dev_alloc((size_t)in->capacity * 8 + 16, (void **)&in->hash));      // cached on the operand: its next rotation skips the hashing
         in->hash_seed = ctx().hash_seed;
-        hipLaunchKernelGGL((k_rot_analyze<true, true>), dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q_dev, anti, ph, ctx().hash_tab,
-                           in->hash, (const u64 *)nullptr, *jt);
+        LAUNCH_AN(true, true, ctx().hash_tab, in->hash, (const u64 *)nullptr, *jt);
     }
+#undef LAUNCH_AN
     KERNEL_CHECK();
     return SYMGPU_OK;
 }
@@ -529,7 +652,7 @@ static int analyze_rows(symgpu_op_t in, const u64 *q_dev, u32 *anti, uint8_t *ph
 //   k_rotf_match2              probe h(P) ^ h(Q), verify, classify, coefficients, per-block counts
 //   k_rotf_scan3, k_rotf_write output slots, rows + coefficients + hashes of the result
 // returns SYMGPU_OK with *done = 1 (result in *out / *all_commute) or *done = 0 (duplicate rows: use the general path)
-static int rotate_fast_nonclifford(symgpu_op_t in, const u64 *q_dev, const u64 *q_host, u32 *anti, uint8_t *ph, double cos_t,
+static int rotate_fast_nonclifford(symgpu_op_t in, u64 *q_dev, const u64 *q_host, bool q_pending, u32 *anti, uint8_t *ph, double cos_t,
                                    double sin_t, double thr, symgpu_op_t *out, int *all_commute, int *done) {
     hipStream_t st = ctx().stream;
     const i64 T = in->T;
@@ -550,11 +673,13 @@ static int rotate_fast_nonclifford(symgpu_op_t in, const u64 *q_dev, const u64 *
     SG_TRY(pself.alloc((size_t)T * 4));
     SG_TRY(pnew.alloc((size_t)T * 4));
     SG_TRY(cnt.alloc(sizeof(RotCounts)));
-    SG_TRY(analyze_rows(in, q_dev, anti, ph, &jt));
+    SG_TRY(analyze_rows(in, q_dev, anti, ph, &jt, q_pending ? q_host : nullptr));    // Q reaches the device with this launch
     hipLaunchKernelGGL(k_rotf_match2, dim3(n_blk), dim3(1024), 0, st, in->rows, in->coeff, in->hash, T, W, q_dev, hq, anti, ph, jt, cos_t, sin_t, thr,
                        selfc.as<double>(), prodc.as<double>(), cls.as<uint8_t>(), blk.as<u32>());
+    RotCounts *hcnt = nullptr, *hcnt_dev = nullptr;
+    SG_TRY(host_counts(&hcnt, &hcnt_dev));
     hipLaunchKernelGGL(k_rotf_scan3, dim3(n_blk), dim3(1024), 0, st, cls.as<uint8_t>(), T, blk.as<u32>(), n_blk, pself.as<u32>(), pnew.as<u32>(),
-                       cnt.as<RotCounts>(), jt.flags, jt.gen);
+                       cnt.as<RotCounts>(), jt.flags, jt.gen, hcnt_dev);
     KERNEL_CHECK();
     symgpu_op_t res = nullptr;
     SG_TRY(symgpu_op_alloc(2 * T, Wq, 1, &res));               // upper bound: no host round trip before the write kernel
@@ -564,11 +689,10 @@ static int rotate_fast_nonclifford(symgpu_op_t in, const u64 *q_dev, const u64 *
     hipLaunchKernelGGL(k_rotf_write, dim3(grid_for(T * Wq)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(in->rows),
                        reinterpret_cast<const u32x4 *>(q_dev), T, Wq, cls.as<uint8_t>(), pself.as<u32>(), pnew.as<u32>(), cnt.as<RotCounts>(),
                        selfc.as<double>(), prodc.as<double>(), reinterpret_cast<u32x4 *>(res->rows), res->coeff, 0, in->hash, hq, res->hash);
-    RotCounts hc;
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(&hc, cnt.p, sizeof(hc), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { symgpu_op_free(res); return hip_fail(e, "rotate fast path", __FILE__, __LINE__); }
+    const RotCounts hc = *hcnt;
     if (hc.nAnti == 0) { symgpu_op_free(res); *all_commute = 1; *done = 1; return SYMGPU_OK; }   // identity action (base.py:1131-1133)
     if (hc.dup) { symgpu_op_free(res); return SYMGPU_OK; }     // duplicates in the input: general path
     res->T = (i64)hc.nC + hc.nA + hc.nN;
@@ -589,8 +713,10 @@ static int rotate_fast_nonclifford(symgpu_op_t in, const u64 *q_dev, const u64 *
 // part, or nothing at all if every term commutes.  One workgroup keeps flags, phase exponents and slots in LDS and ping-pongs
 // the rows between two global buffers (L2 resident), one block barrier per phase.
 constexpr int CHAIN_TMAX = 8192;               // rows the single-workgroup kernel can hold: 8 per thread of the slot scan
-constexpr int CHAIN_LOCAL_T = 1536;            // ... and up to where it beats the multi-workgroup kernels (29 us per rotation at 1,000 rows,
-                                               // 237 us at 8,000, against 36-40 us of back-to-back launches at any size)
+constexpr int CHAIN_LOCAL_T = 448;             // ... and up to where it beats the multi-workgroup kernels (3.5 us per rotation at 1 row, 4.9 at
+                                               // 64, 29 at 1,000, 237 at 8,000, against 15.6 us of back-to-back launches at any size up to 8,000
+                                               // rows — four launches per rotation, launch-rate bound; 36-40 us before the chunk-per-lane
+                                               // analysis kernel and the copy-free Q / count hand-over)
 
 __global__ __launch_bounds__(1024) void k_clifford_chain(u64 *__restrict__ rowsA, double *__restrict__ coeffA, u64 *__restrict__ rowsB,
                                                           double *__restrict__ coeffB, int T, int Wq, int G, const u64 *__restrict__ qs,
@@ -716,7 +842,8 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
     SG_TRY(totals.alloc(16));
     SG_TRY(dmain.alloc((size_t)T * 4));
     SG_TRY(dprod.alloc((size_t)T * 4));
-    HIP_TRY(hipMemcpyAsync(q.p, q_row_host, (size_t)W * 8, hipMemcpyHostToDevice, st));
+    // Q is uploaded by the first analyze launch of the call (in its kernel arguments when the row has <= 64 words), see analyze_rows
+    bool q_pending = true;
     const bool clifford = clifford_k >= 0;
     const bool general_only = getenv("SYMGPU_ROTATE_GENERAL") != nullptr;
     const bool try_fast = !clifford && !general_only;
@@ -726,8 +853,9 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
     bool analyzed = false, has_dup = false;
     if (try_fast) {
         int done = 0;
-        SG_TRY(rotate_fast_nonclifford(in, q.as<u64>(), q_row_host, anti.as<u32>(), ph.as<uint8_t>(), cos_t, sin_t, thr, out, all_commute, &done));
+        SG_TRY(rotate_fast_nonclifford(in, q.as<u64>(), q_row_host, q_pending, anti.as<u32>(), ph.as<uint8_t>(), cos_t, sin_t, thr, out, all_commute, &done));
         if (done) return SYMGPU_OK;
+        if (T < ((i64)1 << 22) - 1) q_pending = false;              // the join ran: Q is on the device
         *out = nullptr;                                            // duplicate rows, or too many rows for the join: general path;
         *all_commute = 1;                                          // the flags and phase exponents are in place if the join ran
         analyzed = T < ((i64)1 << 22) - 1;
@@ -738,7 +866,8 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
             SG_TRY(ensure_hash_tables(ctx().hash_tab ? ctx().hash_seed : 1));
             JoinTable jt;
             SG_TRY(join_table_for(T, &jt));
-            SG_TRY(analyze_rows(in, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(), &jt));
+            SG_TRY(analyze_rows(in, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(), &jt, q_pending ? q_row_host : nullptr));
+            q_pending = false;
             u32 hflag = 0;
             HIP_TRY(hipMemcpyAsync(&hflag, jt.flags, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -746,9 +875,11 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
             if (!has_dup) in->dup_free = 1;
         } else {
             has_dup = need_dup_check;                              // too large for the table: take the merging path
-            SG_TRY(analyze_rows(in, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(), nullptr));
+            SG_TRY(analyze_rows(in, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(), nullptr, q_pending ? q_row_host : nullptr));
+            q_pending = false;
         }
     }
+    if (q_pending) HIP_TRY(hipMemcpyAsync(q.p, q_row_host, (size_t)W * 8, hipMemcpyHostToDevice, st));   // (not reached: every path analyzes first)
     if (clifford && !general_only && !has_dup) {
         int done = 0;
         SG_TRY(rotate_fast_clifford(in, q.as<u64>(), q_row_host, anti.as<u32>(), ph.as<uint8_t>(), clifford_k, thr, out, all_commute, &done));
@@ -908,15 +1039,14 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
             if (rc == SYMGPU_OK) rc = cnt.alloc(sizeof(RotCounts));
             if (rc == SYMGPU_OK) rc = blk.alloc((size_t)n_blk * 16);
             if (rc != SYMGPU_OK) { symgpu_op_free(a); symgpu_op_free(b); return rc; }
-            const int rpb = 256 / G;
-            i64 ga = (T + rpb - 1) / rpb;
-            if (ga > 1024) ga = 1024;
-            const JoinTable none = {nullptr, 0, 0, nullptr};
             symgpu_op_t cur = a, nxt = b;
             for (i64 r = 0; r < K; ++r) {
-                const u64 *q = qs.as<u64>() + r * W;
-                hipLaunchKernelGGL((k_rot_analyze<false, false>), dim3((unsigned)ga), dim3(256), 0, st, cur->rows, T, Wq, G, q, anti.as<u32>(), ph.as<uint8_t>(),
-                                   (const u64 *)nullptr, (u64 *)nullptr, (const u64 *)nullptr, none);
+                u64 *q = qs.as<u64>() + r * W;
+                {   // flags + phase exponents (chunk-per-lane kernel where the row length allows it)
+                    cur->T = T;
+                    const int rca = analyze_rows(cur, q, anti.as<u32>(), ph.as<uint8_t>(), nullptr);
+                    if (rca != SYMGPU_OK) { symgpu_op_free(a); symgpu_op_free(b); return rca; }
+                }
                 hipLaunchKernelGGL(k_rotc_classify, dim3(n_blk), dim3(1024), 0, st, anti.as<u32>(), ph.as<uint8_t>(), cur->coeff, T, ks_host[r], -1.0,
                                    cls.as<uint8_t>(), selfc.as<double>(), prodc.as<double>(), blk.as<u32>());
                 hipLaunchKernelGGL(k_rotf_scan3, dim3(n_blk), dim3(1024), 0, st, cls.as<uint8_t>(), T, blk.as<u32>(), n_blk, pself.as<u32>(), pnew.as<u32>(),

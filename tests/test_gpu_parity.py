@@ -153,12 +153,12 @@ def test_rotation_chain_from_operator_with_duplicates():
     assert_op_equal(R.symp_matrix, R.coeff_vec, er, ec, exact=False, tol=TOL)
 
 
-@pytest.mark.parametrize('n,T,K', [(1000, 1, 300), (70, 37, 200), (5, 60, 120), (130, 1500, 60), (64, 1536, 30), (64, 1537, 12), (1, 4, 50),
+@pytest.mark.parametrize('n,T,K', [(1000, 1, 300), (70, 37, 200), (5, 60, 120), (130, 1500, 60), (64, 448, 30), (64, 449, 12), (64, 1536, 30), (64, 1537, 12), (1, 4, 50),
                                    (200, 20000, 25)])
 def test_clifford_chain_single_launch_vs_oracle(n, T, K):
     """perform_rotations with runs of Clifford rotations on a small clean operator = ONE launch per run (symgpu_rotate_clifford_chain_dev):
     rows, row order and coefficients (exact phases: bit-exact) against the step-by-step oracle, every k in -2..5, rotations that
-    commute with everything, a non-Clifford rotation in the middle (splits the run), 1536 / 1537 / 20000 terms (single-workgroup
+    commute with everything, a non-Clifford rotation in the middle (splits the run), 448 / 449 / 1536 / 20000 terms (single-workgroup
     launch / back-to-back multi-workgroup launches)."""
     rng = np.random.default_rng(5000 + n + T)
     symp = rng.random((T, 2 * n)) < (0.3 if n > 1 else 0.5)
@@ -179,7 +179,7 @@ def test_clifford_chain_single_launch_vs_oracle(n, T, K):
 
 @pytest.mark.parametrize('local', ['8192', '0'])
 def test_clifford_chain_kernel_at_its_row_limit(local, monkeypatch):
-    """8192 rows: the single-workgroup chain kernel at its limit (SYMGPU_CHAIN_LOCAL_T=8192; by default it is used up to 1536 rows)
+    """8192 rows: the single-workgroup chain kernel at its limit (SYMGPU_CHAIN_LOCAL_T=8192; by default it is used up to 448 rows)
     and the back-to-back multi-workgroup chain (=0) against the one-by-one path."""
     from symmer_amd.kernels import DeviceOp
     monkeypatch.setenv('SYMGPU_CHAIN_LOCAL_T', local)
@@ -456,7 +456,9 @@ def test_symmetry_kernel_vs_oracle(n, M, k):
     assert np.all(S.commutes_termwise(H))
 
 
-@pytest.mark.parametrize('n,T', [(1000, 20000), (130, 5000)])
+@pytest.mark.parametrize('n,T', [(1000, 20000), (130, 5000),
+                                 # every row length of the chunk-per-lane analysis kernel (1, 2, 4, 8, 16, 32, 64 chunks per row) and two others
+                                 (40, 3000), (64, 777), (100, 2100), (256, 1500), (449, 900), (1024, 1300), (2000, 700), (4096, 300), (300, 800), (3000, 300)])
 def test_rotation_vs_oracle(n, T):
     rng = np.random.default_rng(700 + n)
     symp, c = onp.cleanup_op(rng.random((T, 2 * n)) < 0.3, dyadic(rng, T))
