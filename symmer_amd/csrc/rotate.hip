@@ -168,10 +168,23 @@ __global__ __launch_bounds__(256) void k_rot_analyze_chunks(const u32x4 *__restr
                                                              uint8_t *__restrict__ ph, const u64 *__restrict__ hin, JoinTable jt, QArg qa) {
     __shared__ __attribute__((aligned(16))) u64 sq[2 * WQ];
     __shared__ int s_yq;
+    if (INSERT) {
+        // The join-table insert needs nothing from the analysis (row index + cached hash), and done by the one lane per row group
+        // that ends the analysis it was a chain load -> atomic load -> CAS with 4 lanes of 64 busy: 10 of the kernel's 18 us.  The
+        // FIRST ceil(T / 256) blocks of the grid are insert blocks, ONE LANE PER ROW (dispatched first: their latency chain runs
+        // while the analysis blocks stream the rows behind them).
+        const i64 n_ins = (T + 255) / 256;
+        if ((i64)blockIdx.x < n_ins) {
+            const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+            if (t < T) jt_insert(jt, reinterpret_cast<const u64 *>(rows), 2 * WQ, t, hin[t]);
+            return;
+        }
+    }
+    const i64 bx = (i64)blockIdx.x - (INSERT ? (T + 255) / 256 : 0);     // analysis block index
     if ((int)threadIdx.x < 2 * WQ) {
         const u64 v = QARG ? qa.w[threadIdx.x] : q_dev[threadIdx.x];
         sq[threadIdx.x] = v;
-        if (QARG && blockIdx.x == 0) q_dev[threadIdx.x] = v;
+        if (QARG && bx == 0) q_dev[threadIdx.x] = v;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(256) void k_rot_analyze_chunks(const u32x4 *__restr
     __syncthreads();
     constexpr int R = 256 / WQ;                                       // rows per block
     const int c = threadIdx.x & (WQ - 1);                            // chunk of the row: c < WQ/2 holds X words (WQ == 1: x and z word)
-    const i64 t = (i64)blockIdx.x * R + threadIdx.x / WQ;
+    const i64 t = bx * R + threadIdx.x / WQ;
     const bool valid = t < T;
     const u32x4 v = valid ? rows[t * WQ + c] : (u32x4)(0u);
     u32 par, ye;                                                      // par: |x & zq| + |z & xq| (+ |x & zq| << 16);  ye: Y_P | Y_out << 16
@@ -205,7 +218,6 @@ __global__ __launch_bounds__(256) void k_rot_analyze_chunks(const u32x4 *__restr
     if (c == 0 && valid) {
         flags[t] = par & 1u;
         ph[t] = (uint8_t)((3u * ((ye & 0xFFFFu) + (u32)s_yq) + (ye >> 16) + 2u * ((par >> 16) & 1u)) & 3u);
-        if (INSERT) jt_insert(jt, reinterpret_cast<const u64 *>(rows), 2 * WQ, t, hin[t]);
     }
 }
 
@@ -616,10 +628,10 @@ static int analyze_rows(symgpu_op_t in, u64 *q_dev, u32 *anti, uint8_t *ph, cons
     if (chunks_on && (!jt || have_hash) && Wq <= 64 && (Wq & (Wq - 1)) == 0) {
         // one 16-byte chunk per lane (k_rot_analyze_chunks); rows of other lengths and the launch that also hashes keep the word kernel
         const u32x4 *pr = reinterpret_cast<const u32x4 *>(in->rows);
-        const i64 gb = (T + 256 / Wq - 1) / (256 / Wq);
+        const i64 gb = (T + 256 / Wq - 1) / (256 / Wq), gi = (T + 255) / 256;     // analysis blocks, then (with a join table) insert blocks
 #define LAUNCH_CH(WQV) do { \
-            if (jt) { if (by_arg) hipLaunchKernelGGL((k_rot_analyze_chunks<WQV, true, true>), dim3((unsigned)gb), dim3(256), 0, st, pr, T, q_dev, anti, ph, in->hash, *jt, qa); \
-                      else hipLaunchKernelGGL((k_rot_analyze_chunks<WQV, true, false>), dim3((unsigned)gb), dim3(256), 0, st, pr, T, q_dev, anti, ph, in->hash, *jt, qa); } \
+            if (jt) { if (by_arg) hipLaunchKernelGGL((k_rot_analyze_chunks<WQV, true, true>), dim3((unsigned)(gb + gi)), dim3(256), 0, st, pr, T, q_dev, anti, ph, in->hash, *jt, qa); \
+                      else hipLaunchKernelGGL((k_rot_analyze_chunks<WQV, true, false>), dim3((unsigned)(gb + gi)), dim3(256), 0, st, pr, T, q_dev, anti, ph, in->hash, *jt, qa); } \
             else { if (by_arg) hipLaunchKernelGGL((k_rot_analyze_chunks<WQV, false, true>), dim3((unsigned)gb), dim3(256), 0, st, pr, T, q_dev, anti, ph, (const u64 *)nullptr, none, qa); \
                    else hipLaunchKernelGGL((k_rot_analyze_chunks<WQV, false, false>), dim3((unsigned)gb), dim3(256), 0, st, pr, T, q_dev, anti, ph, (const u64 *)nullptr, none, qa); } } while (0)
         switch (Wq) {
