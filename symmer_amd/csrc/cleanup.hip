@@ -312,6 +312,22 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
             break;
         }
         const bool own = chunk < c1;    // beyond the own range: decode only, to finish the carried segment
+        if (!own) {
+            // Peek before decoding a foreign chunk: the carried segment only continues if the chunk's FIRST key equals the key before
+            // it — almost never (an operator without duplicate rows merges nothing).  Two wave-uniform loads instead of 64 keys,
+            // 128 coefficient-table gathers and the sum loop: with one chunk per wavefront this second pass was half of the kernel.
+            const i64 s0 = chunk * 64;                                // 0 < s0 < T
+            const u64 kb = keys[s0], ka = keys[s0 - 1];
+            bool eq0;
+            if (PACKED) {
+                eq0 = (kb >> L.F()) == (ka >> L.F());
+                if (eq0 && !(inner == outer && L.i(kb) == L.o(ka) && L.o(kb) == L.i(ka))) eq0 = (hI[L.i(kb)] ^ hO[L.o(kb)]) == (hI[L.i(ka)] ^ hO[L.o(ka)]);
+            } else eq0 = kb == ka;
+            if (!eq0) {
+                if (lane == 0) close(afirst, are, aim);
+                break;
+            }
+        }
         const i64 s = chunk * 64 + lane;
         const bool valid = s < T;
         // this position: key k1, input index t1 (PAIR: as (i1, o1)); predecessor k0 / t0 / (i0, o0) from the neighbour lane
