@@ -274,6 +274,79 @@ __device__ __forceinline__ void tri_pair(u32 p, u32 N, u32 &o, u32 &i) {
     i = (u32)((i64)p - off(oo) + oo);
 }
 
+
+// ---- the identity segment of a squared operator -------------------------------------------------------------------------------
+// P * P has N diagonal pairs (i, i), and every one of them is the identity row: N equal keys — with FULL KEY ZERO, because the row
+// hash is linear (h(0) = 0) — i.e. one segment of >= N elements at the very start of the sorted array.  k_heads_sums sums a
+// segment sequentially, one wavefront walking chunk after chunk: 157 dependent chunk steps for N = 10,000, 0.8 of the kernel's
+// 1.64 ms at cfg3, 40 of 44 us at cfg1.  The squared path already associates its sums differently from the reference (twin first:
+// exact for dyadic coefficients, rounding-level otherwise), so the zero-key segment is reduced in parallel here, in a FIXED order
+// (per-thread ascending positions, then threads, then blocks in order: deterministic), and k_heads_sums starts behind it.
+// Members that are not diagonal pairs (duplicate rows in P, or a 64-bit collision) are verified row against row like everywhere.
+constexpr int ZB = 4096;                                              // sorted positions per block
+__global__ __launch_bounds__(256) void k_zero_partial(const u64 *__restrict__ keys, i64 Tk, const u64 *__restrict__ hI, const u64 *__restrict__ hO,
+                                                       PackedLayout L, const u64 *__restrict__ rows, int W, const double *__restrict__ cf,
+                                                       double *__restrict__ part, u32 *__restrict__ part_n, u32 *__restrict__ collision) {
+    __shared__ double s_re[256], s_im[256];
+    __shared__ u32 s_n[256];
+    const i64 base = (i64)blockIdx.x * ZB;
+    if (L.full_key(hI, hO, keys[base]) != 0ULL) {                     // uniform: the zero keys are a prefix of the sorted array
+        if (threadIdx.x == 0) { part[2 * blockIdx.x] = 0.0; part[2 * blockIdx.x + 1] = 0.0; part_n[blockIdx.x] = 0u; }
+        return;
+    }
+    double re = 0.0, im = 0.0;
+    u32 n = 0;
+    bool mism = false;
+    for (int j = 0; j < ZB / 256; ++j) {
+        const i64 p = base + threadIdx.x + 256 * j;
+        if (p >= Tk) break;
+        const u64 k = keys[p];
+        if (L.full_key(hI, hO, k) != 0ULL) break;                     // behind the segment: so is everything this thread has left
+        const u32 i = L.i(k), o = L.o(k);
+        const int e = L.e(k);
+        double cr, cim;
+        pair_coefficient(cf[2 * i], cf[2 * i + 1], cf[2 * o], cf[2 * o + 1], e, cr, cim);
+        if (i != o) {
+            if (e & 1) { cr = 0.0; cim = 0.0; } else { cr = __dadd_rn(cr, cr); cim = __dadd_rn(cim, cim); }
+            for (int w = 0; w < W; ++w) mism |= rows[(i64)i * W + w] != rows[(i64)o * W + w];      // identity row <=> equal factors
+        }
+        re = __dadd_rn(re, cr);
+        im = __dadd_rn(im, cim);
+        ++n;
+    }
+    s_re[threadIdx.x] = re; s_im[threadIdx.x] = im; s_n[threadIdx.x] = n;
+    if (mism) atomicOr(collision, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0, q = 0.0;
+        u32 c = 0;
+        for (int t = 0; t < 256; ++t) { r = __dadd_rn(r, s_re[t]); q = __dadd_rn(q, s_im[t]); c += s_n[t]; }
+        part[2 * blockIdx.x] = r; part[2 * blockIdx.x + 1] = q; part_n[blockIdx.x] = c;
+    }
+}
+// blocks in order; files the identity term under the slot of the segment's first element and tells k_heads_sums where to start
+__global__ void k_zero_close(const u64 *__restrict__ keys, const double *__restrict__ part, const u32 *__restrict__ part_n, i64 n_blocks,
+                             PackedLayout L, u32 Ni, double thr, int use_thr, u32 *__restrict__ markbits, double *__restrict__ sum_of,
+                             u32 *__restrict__ zero_len) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double re = 0.0, im = 0.0;
+    u64 len = 0;
+    for (i64 b = 0; b < n_blocks; ++b) {
+        const u32 c = part_n[b];
+        if (c == 0) break;
+        re = __dadd_rn(re, part[2 * b]); im = __dadd_rn(im, part[2 * b + 1]);
+        len += c;
+        if (c < (u32)ZB) break;
+    }
+    *zero_len = (u32)len;
+    if (len == 0) return;
+    if (use_thr && !(hypot(re, im) > thr)) return;
+    const u64 k0 = keys[0];                                           // stable sort: the segment's smallest pair index
+    const u32 first = tri_slot(L.o(k0), L.i(k0), Ni);
+    atomicOr(&markbits[first >> 5], 1u << (first & 31u));
+    sum_of[2 * (i64)first] = re; sum_of[2 * (i64)first + 1] = im;
+}
+
 template <bool PAIR, bool PACKED>
 __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys, const u32 *__restrict__ idx, i64 T, const u64 *__restrict__ rows, int W,
                                                      const u64 *__restrict__ inner, u32 Ni, const u64 *__restrict__ outer, int G,
@@ -281,7 +354,10 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
                                                      const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L,
                                                      const double *__restrict__ ci, const double *__restrict__ co,
                                                      double thr, int use_thr, u32 *__restrict__ markbits, double *__restrict__ sum_of,
-                                                     i64 chunks_per_wave, int squared) {
+                                                     i64 chunks_per_wave, int squared, const u32 *__restrict__ zero_len = nullptr) {
+    // zero_len (squared operators): the first *zero_len sorted positions are the identity segment, already reduced by k_zero_partial /
+    // k_zero_close — they are treated like positions past the end (they end every run and contribute nothing)
+    const i64 ZL = zero_len ? (i64)*zero_len : 0;
     // squared (PACKED only, P * P): the keys are the pairs with i >= o; an off-diagonal pair stands for itself and its twin
     // (o, i), whose coefficient is bit-identical in magnitude (IEEE products and sums commute): it counts twice if the two terms
     // commute (e even) and not at all if they anticommute (e odd) — it then only marks the first occurrence of its row.
@@ -329,7 +405,7 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
             }
         }
         const i64 s = chunk * 64 + lane;
-        const bool valid = s < T;
+        const bool valid = s < T && s >= ZL;
         // this position: key k1, input index t1 (PAIR: as (i1, o1)); predecessor k0 / t0 / (i0, o0) from the neighbour lane
         // (lane 0 reads position s-1 itself)
         u64 k1 = valid ? keys[s] : 0ULL;
@@ -416,7 +492,8 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
         }
         // the last head of a full chunk may continue in the next chunk: carry it; everything else closes here
         const int last = 63 - __builtin_clzll(m);
-        const bool carry = chunk * 64 + 64 <= T;                  // a full chunk: lane `last` is a real head whose run reaches lane 63
+        // a full chunk whose last head is a real position: its run reaches lane 63 and may continue in the next chunk
+        const bool carry = chunk * 64 + 64 <= T && ((__ballot(valid) >> last) & 1ULL);
         if (is_head && !(carry && lane == last)) close(t1, re, im);
         if (carry) {
             open = true;
@@ -712,7 +789,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         if (e && e[0] == '1') squared = false;
     }
     i64 Tk = T;                                                         // number of keys that are sorted (T index space stays)
-    Scratch keys, keys2, idx, idx2, heads, collision, hI, hO, pair_coeff, markbits, sum_of;
+    Scratch keys, keys2, idx, idx2, heads, collision, hI, hO, pair_coeff, markbits, sum_of, zpart, zcount;
     SG_TRY(keys.alloc((size_t)T * 8));
     SG_TRY(keys2.alloc((size_t)T * 8));
     SG_TRY(heads.alloc((size_t)T));                                 // run-start markers of the truncated-sort fix-up
@@ -805,9 +882,24 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             const double *nud = nullptr;
             const i64 space = (squared && packed) ? Tk : T;               // index space of markbits / sum_of
             HIP_TRY(hipMemsetAsync(markbits.p, 0, (size_t)((space + 31) / 32) * 4, st));
+            const u32 *zero_len_p = nullptr;
+            static const bool zero_on = [] { const char *e = getenv("SYMGPU_CLEANUP_ZEROSEG"); return !(e && e[0] == '0'); }();
+            if (squared && packed && zero_on) {
+                // the identity segment (the N diagonal pairs and whatever else multiplies to the identity) in parallel, see k_zero_partial
+                const i64 n_zb = (Tk + ZB - 1) / ZB;
+                SG_TRY(zpart.alloc((size_t)n_zb * 16));
+                SG_TRY(zcount.alloc((size_t)n_zb * 4 + 16));
+                u32 *zl = zcount.as<u32>() + n_zb;
+                hipLaunchKernelGGL(k_zero_partial, dim3((unsigned)n_zb), dim3(256), 0, st, ks, Tk, hI.as<u64>(), hO.as<u64>(), L, inner, W, ci,
+                                   zpart.as<double>(), zcount.as<u32>(), collision.as<u32>());
+                hipLaunchKernelGGL(k_zero_close, dim3(1), dim3(64), 0, st, ks, zpart.as<double>(), zcount.as<u32>(), n_zb, L, (u32)Ni, thr, use_thr,
+                                   markbits.as<u32>(), sum_of.as<double>(), zl);
+                zero_len_p = zl;
+            }
             if (packed)
                 hipLaunchKernelGGL((k_heads_sums<true, true>), gs, dim3(256), 0, st, ks, (const u32 *)nullptr, Tk, nul, W, inner, (u32)Ni, outer, G, nud,
-                                   collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), L, ci, co, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0);
+                                   collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), L, ci, co, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0,
+                                   zero_len_p);
             else if (pair)
                 hipLaunchKernelGGL((k_heads_sums<true, false>), gs, dim3(256), 0, st, ks, is, Tk, nul, W, inner, (u32)Ni, outer, G, coeff,
                                    collision.as<u32>(), nul, nul, L, nud, nud, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0);
