@@ -457,8 +457,32 @@ __global__ void k_rotf_write(const u32x4 *__restrict__ rows, const u32x4 *__rest
     const i64 baseC = clifford ? (i64)cnt->nA + cnt->nN : 0;
     const i64 baseA = clifford ? 0 : (i64)cnt->nC;
     const i64 baseN = clifford ? 0 : (i64)cnt->nC + cnt->nA;
-    for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (i64)gridDim.x * blockDim.x) {
-        const i64 t = idx / Wq;
+    // The first ceil(T / 256) blocks move the 16-byte coefficients and the 8-byte hashes, ONE LANE PER ROW (consecutive rows of a class
+    // go to consecutive slots: near-coalesced); the remaining blocks move the rows, one 16-byte chunk per lane.  Done by the chunk-0
+    // lane of every row inside the row stream, the small stores — one lane of 16, scattered between the 256-byte row stores —
+    // are what the product's row stream showed to be expensive (product.hip, tools/ubench_fused.hip).
+    const i64 n_cf = (T + blockDim.x - 1) / blockDim.x;
+    if ((i64)blockIdx.x < n_cf) {
+        const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+        if (t >= T) return;
+        const uint8_t k = cls[t];
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        if (k & 3) {
+            const i64 d = (k & 1) ? baseC + pos_self[t] : baseA + pos_self[t];
+            reinterpret_cast<f64x2 *>(out_coeff)[d] = reinterpret_cast<const f64x2 *>(selfc)[t];
+            if (hout) hout[d] = hin[t];
+        }
+        if (k & 4) {
+            const i64 d = baseN + pos_new[t];
+            reinterpret_cast<f64x2 *>(out_coeff)[d] = reinterpret_cast<const f64x2 *>(prodc)[t];
+            if (hout) hout[d] = hin[t] ^ hq;
+        }
+        return;
+    }
+    const int wsh = (Wq & (Wq - 1)) == 0 ? __builtin_ctz((unsigned)Wq) : -1;      // chunks per row a power of two: shift instead of a 64-bit divide
+    const i64 n_row_blocks = (i64)gridDim.x - n_cf;
+    for (i64 idx = ((i64)blockIdx.x - n_cf) * blockDim.x + threadIdx.x; idx < total; idx += n_row_blocks * blockDim.x) {
+        const i64 t = wsh >= 0 ? idx >> wsh : idx / Wq;
         const int c = (int)(idx - t * Wq);
         const uint8_t k = cls[t];
         if (!k) continue;
@@ -466,12 +490,10 @@ __global__ void k_rotf_write(const u32x4 *__restrict__ rows, const u32x4 *__rest
         if (k & 3) {
             const i64 d = (k & 1) ? baseC + pos_self[t] : baseA + pos_self[t];
             out_rows[d * Wq + c] = v;
-            if (c == 0) { out_coeff[2 * d] = selfc[2 * t]; out_coeff[2 * d + 1] = selfc[2 * t + 1]; if (hout) hout[d] = hin[t]; }
         }
         if (k & 4) {
             const i64 d = baseN + pos_new[t];
             out_rows[d * Wq + c] = v ^ q[c];
-            if (c == 0) { out_coeff[2 * d] = prodc[2 * t]; out_coeff[2 * d + 1] = prodc[2 * t + 1]; if (hout) hout[d] = hin[t] ^ hq; }
         }
     }
 }
@@ -559,7 +581,7 @@ static int rotate_fast_clifford(symgpu_op_t in, const u64 *q_dev, const u64 *q_h
         if (rc != SYMGPU_OK) { symgpu_op_free(res); return rc; }
         res->hash_seed = in->hash_seed;
     }
-    hipLaunchKernelGGL(k_rotf_write, dim3(grid_for(T * Wq)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(in->rows),
+    hipLaunchKernelGGL(k_rotf_write, dim3(grid_for(T * Wq) + (unsigned)((T + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(in->rows),
                        reinterpret_cast<const u32x4 *>(q_dev), T, Wq, cls.as<uint8_t>(), pself.as<u32>(), pnew.as<u32>(), cnt.as<RotCounts>(),
                        selfc.as<double>(), prodc.as<double>(), reinterpret_cast<u32x4 *>(res->rows), res->coeff, 1, in_hash, hq, res->hash);
     hipError_t e = hipGetLastError();
@@ -698,7 +720,7 @@ static int rotate_fast_nonclifford(symgpu_op_t in, u64 *q_dev, const u64 *q_host
     int rc = dev_alloc((size_t)res->capacity * 8 + 16, (void **)&res->hash);
     if (rc != SYMGPU_OK) { symgpu_op_free(res); return rc; }
     res->hash_seed = seed;
-    hipLaunchKernelGGL(k_rotf_write, dim3(grid_for(T * Wq)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(in->rows),
+    hipLaunchKernelGGL(k_rotf_write, dim3(grid_for(T * Wq) + (unsigned)((T + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(in->rows),
                        reinterpret_cast<const u32x4 *>(q_dev), T, Wq, cls.as<uint8_t>(), pself.as<u32>(), pnew.as<u32>(), cnt.as<RotCounts>(),
                        selfc.as<double>(), prodc.as<double>(), reinterpret_cast<u32x4 *>(res->rows), res->coeff, 0, in->hash, hq, res->hash);
     hipError_t e = hipGetLastError();
@@ -1063,7 +1085,7 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
                                    cls.as<uint8_t>(), selfc.as<double>(), prodc.as<double>(), blk.as<u32>());
                 hipLaunchKernelGGL(k_rotf_scan3, dim3(n_blk), dim3(1024), 0, st, cls.as<uint8_t>(), T, blk.as<u32>(), n_blk, pself.as<u32>(), pnew.as<u32>(),
                                    cnt.as<RotCounts>(), (const u32 *)nullptr, 0u);
-                hipLaunchKernelGGL(k_rotf_write, dim3(grid_for(T * Wq)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(cur->rows),
+                hipLaunchKernelGGL(k_rotf_write, dim3(grid_for(T * Wq) + (unsigned)((T + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(cur->rows),
                                    reinterpret_cast<const u32x4 *>(q), T, Wq, cls.as<uint8_t>(), pself.as<u32>(), pnew.as<u32>(), cnt.as<RotCounts>(),
                                    selfc.as<double>(), prodc.as<double>(), reinterpret_cast<u32x4 *>(nxt->rows), nxt->coeff, 1, (const u64 *)nullptr, (u64)0,
                                    (u64 *)nullptr);
