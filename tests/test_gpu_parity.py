@@ -406,7 +406,8 @@ def test_mul_cleanup_gaussian_tolerance():
 
 
 @pytest.mark.parametrize('T,n,dup', [(200000, 1000, 0.5), (50000, 100, 0.9), (100000, 3, 1.0), (4097, 2000, 0.2), (3000, 5000, 0.6), (1, 70, 0.0),
-                                     (65, 64, 0.5)])
+                                     (65, 64, 0.5),
+                                     (9_000_000, 40, 0.45)])           # > 2 x 4M input indices: three batches of the output stage
 def test_cleanup_vs_oracle(T, n, dup):
     rng = np.random.default_rng(400 + n)
     base = packing.pack_rows(rng.random((max(1, int(T * (1 - dup)) + 1), 2 * n)) < 0.3)
