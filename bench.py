@@ -52,6 +52,7 @@ def parse():
                          "--adj-terms x --adj-qubits operator, left-term axis sharded over the ranks (strong scaling)")
     ap.add_argument('--adj-terms', type=int, default=200000)
     ap.add_argument('--adj-qubits', type=int, default=2000)
+    ap.add_argument('--adj-slab-rows', type=int, default=0, help='adjacency: rows per launch / output slab (0: as many as a quarter of the free HBM holds)')
     ap.add_argument('--no-extras', action='store_true')
     ap.add_argument('--no-cpu', action='store_true')
     return ap.parse_args()
@@ -232,9 +233,15 @@ def adjacency(args, comm, rank, world, _lib, DeviceOp, parallel):
     b0, b1 = bounds[rank]
     shard = parallel.padded_random_shard(b1 - b0, ts, n, 555 + rank)
     full = DeviceOp.alloc(ts * world, wq, with_coeff=True) if comm.gathers else shard
-    slab = min(25000, max(1, b1 - b0))
+    # Output slabs: as many rows per launch as a quarter of the free HBM holds (a 25,000-row launch is 6.5 rounds of workgroups on
+    # 256 CUs and costs 7; all 200,000 rows of one GPU in one launch: 50.1 rounds) — the whole 40 GB block of a single GPU fits.
+    free_b, total_b = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(lib.symgpu_mem_info(ctypes.addressof(free_b), ctypes.addressof(total_b)))
+    slab = min(max(1, b1 - b0), max(25000, int(free_b.value // 4 // max(1, T))))
+    if args.adj_slab_rows:
+        slab = min(max(1, b1 - b0), args.adj_slab_rows)
     ring = []
-    for _ in range(2):
+    for _ in range(1 if slab >= b1 - b0 else 2):
         p = ctypes.c_void_p()
         _lib.check(lib.symgpu_dev_alloc(slab * T, ctypes.byref(p)))
         ring.append(p)
@@ -249,7 +256,7 @@ def adjacency(args, comm, rank, world, _lib, DeviceOp, parallel):
         k = 0
         for r0 in range(0, b1 - b0, slab):
             r1 = min(b1 - b0, r0 + slab)
-            _lib.check(lib.symgpu_commutes_dev(shard.handle, r0, r1, full.handle, ring[k & 1]))
+            _lib.check(lib.symgpu_commutes_dev(shard.handle, r0, r1, full.handle, ring[k % len(ring)]))
             k += 1
 
     for _ in range(args.warmup):

@@ -182,7 +182,8 @@ def test_bench_adjacency_workload_schema():
         sys.path.insert(0, root)
     bench = importlib.import_module('bench')
     argv, buf = sys.argv, io.StringIO()
-    sys.argv = ['bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1', '--workload', 'adjacency', '--adj-terms', '30000', '--adj-qubits', '300']
+    sys.argv = ['bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1', '--workload', 'adjacency', '--adj-terms', '30000', '--adj-qubits', '300',
+                '--adj-slab-rows', '25000']
     try:
         with contextlib.redirect_stdout(buf):
             bench.main()
