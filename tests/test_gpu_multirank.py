@@ -112,3 +112,22 @@ def test_row_hash_collisions_are_caught_and_reseeded(worker):
     outs = _launch(worker, 1, {'SYMGPU_HASH_WEAK_ODD': '1'})
     rc, o, e = outs[0]
     assert rc == 0 and 'WEAK_HASH_OK' in o, f'rc={rc}\n{o}\n{e[-3000:]}'
+
+
+@pytest.mark.timeout(900)
+def test_bench_eight_ranks_rank_arithmetic():
+    """bench.py at the driver's largest world size, reduced workloads (on a one-GPU box the eight ranks share the device and the
+    host-staged plane runs): shard bounds with a remainder (20,003 right terms / 40,003 adjacency terms over 8 ranks), the TCP
+    control plane with 8 peers, one JSON line from rank 0 only, aggregate pair counts."""
+    for argv, pairs in ((['bench.py', '--gpus', '8', '--steps', '1', '--warmup', '1', '--left-terms', '6000', '--right-terms', '20003', '--no-extras', '--no-cpu'],
+                         8 * 6000 * 20003),
+                        (['bench.py', '--gpus', '8', '--steps', '1', '--warmup', '1', '--workload', 'adjacency', '--adj-terms', '40003', '--adj-qubits', '300'],
+                         40003 ** 2)):
+        outs = _launch(argv, 8, {}, timeout=800)
+        for r, (rc, o, e) in enumerate(outs):
+            assert rc == 0, f'rank {r}: rc={rc}\n{o}\n{e[-3000:]}'
+            assert (r == 0) == bool(o.strip()), (r, o)
+        doc = json.loads(outs[0][1].strip().splitlines()[-1])
+        assert doc['n_gpus'] == 8 and doc['config']['pairs_per_step'] == pairs and doc['value'] > 0
+        if _n_gpus() < 8:
+            assert 'host-staged' in doc.get('degraded', '')
