@@ -247,16 +247,32 @@ class Communicator:
         ident = self._bcast_bytes(bytes(raw), 128)
         if not any(ident):
             return self._fallback(local or 'rank 0 could not create an RCCL unique id')
-        try:
-            raw = (ctypes.c_uint8 * 128)(*ident)
-            with _stdout_to_stderr():
-                _lib.check(_lib.lib().symgpu_comm_init(ctypes.addressof(raw), self.rank, self.world))
-        except Exception as exc:
-            local = str(exc)
+        # ncclCommInitRank is collective and has no timeout of its own: run it on a watchdog thread, so that a bring-up that never
+        # returns on some rank (fabric / IPC trouble) ends in the host-staged plane and a `degraded` line instead of a hung job
+        import threading
+        raw = (ctypes.c_uint8 * 128)(*ident)
+        result = {}
+
+        def _init():
+            try:
+                with _stdout_to_stderr():
+                    _lib.check(_lib.lib().symgpu_comm_init(ctypes.addressof(raw), self.rank, self.world))
+                result['ok'] = True
+            except Exception as exc:                               # noqa: BLE001 - reported through the agreement below
+                result['error'] = str(exc)
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(float(os.environ.get('SYMGPU_RCCL_INIT_TIMEOUT', '180')))
+        hung = th.is_alive()
+        if hung:
+            local = 'ncclCommInitRank did not return within the time limit'
+        elif 'error' in result:
+            local = result['error']
         if self.max_over_ranks(1.0 if local else 0.0) > 0.0:
             if local is None:
                 _lib.load().symgpu_comm_destroy()
             return self._fallback(local or 'RCCL initialisation failed on another rank')
+        del hung
 
     # ---- control plane -----------------------------------------------------------------------------------
     def barrier(self):
