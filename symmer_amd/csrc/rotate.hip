@@ -749,10 +749,9 @@ static int rotate_fast_nonclifford(symgpu_op_t in, u64 *q_dev, const u64 *q_host
 constexpr int CHAIN_TMAX = 8192;               // rows the single-workgroup kernel can hold: 8 per thread of the slot scan
 constexpr int CHAIN_LOCAL_T = 128;             // ... and up to where it beats the multi-workgroup kernels: 3.5 us per rotation at 1 row, 5.0 at
                                                // 64, 6.6 at 128, 9.9 at 256, 29 at 1,000, against 6.7-7 us of the two-launch form (below)
-constexpr int CHAIN_TWO_T = 8192;              // two launches per rotation (k_cchain_flags / k_cchain_move) up to here: 6.7 us at 64-384 rows,
-                                               // 7.1 at 1,000, 12.9 at 8,000 against 15.6 us of the four-launch form (launch-rate bound); beyond,
-                                               // the per-block slot computation of the move kernel loses: 20.7 / 28.3 / 59 us at 16,384 / 32,768 /
-                                               // 131,072 rows against 17.3 / 20.5 / 32.4 us
+constexpr int CHAIN_TWO_T = 262144;            // two launches per rotation (k_cchain_flags / k_cchain_move) up to here (256 group counts): 6.7 us at
+                                               // 64-384 rows, 7.1 at 1,000, 10.4 at 8,000, 13.4 / 20.8 / 26.7 at 16,384 / 65,536 / 131,072 against 15.6
+                                               // us (launch-rate bound) up to 8,000 rows and 17.3 / 24.0 / 32.4 us of the four-launch form
 
 __global__ __launch_bounds__(1024) void k_clifford_chain(u64 *__restrict__ rowsA, double *__restrict__ coeffA, u64 *__restrict__ rowsB,
                                                           double *__restrict__ coeffB, int T, int Wq, int G, const u64 *__restrict__ qs,
@@ -859,7 +858,7 @@ __global__ __launch_bounds__(1024) void k_clifford_chain(u64 *__restrict__ rowsA
 // <= 256 group counts, rows before it inside its group from their byte flags — and moves rows and coefficients.  The group counts
 // ping-pong between two arrays (B of rotation r clears the array A of rotation r+1 adds to).  Rows of a power-of-two number of chunks,
 // <= CHAIN_TWO_T rows; everything else keeps the four-launch form.
-template <int WQ>
+template <int WQ, int CCH_ROWS>
 __global__ __launch_bounds__(256) void k_cchain_flags(const u32x4 *__restrict__ rows, const double *__restrict__ coeff, i64 T, const u64 *__restrict__ q_dev,
                                                        int k, uint8_t *__restrict__ af, double *__restrict__ nc, u32 *__restrict__ cnt) {
     __shared__ __attribute__((aligned(16))) u64 sq[2 * WQ];
@@ -868,65 +867,70 @@ __global__ __launch_bounds__(256) void k_cchain_flags(const u32x4 *__restrict__ 
     if ((int)threadIdx.x < 2 * WQ) sq[threadIdx.x] = q_dev[threadIdx.x];
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {                                          // Y count of Q: one wavefront
         int y = 0;
-        for (int w = 0; w < WQ; ++w) y += __popcll(sq[w] & sq[WQ + w]);
-        s_yq = y;
+        for (int w = threadIdx.x; w < WQ; w += 64) y += __popcll(sq[w] & sq[WQ + w]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) y += __shfl_xor(y, off);
+        if (threadIdx.x == 0) s_yq = y;
     }
     __syncthreads();
-    constexpr int R = 256 / WQ;
+    constexpr int R = 256 / WQ, ITER = CCH_ROWS / R;                 // CCH_ROWS rows per block: the block's fixed costs are paid once
     const int c = threadIdx.x & (WQ - 1);
-    const i64 t = (i64)blockIdx.x * R + threadIdx.x / WQ;
-    const bool valid = t < T;
-    const u32x4 v = valid ? rows[t * WQ + c] : (u32x4)(0u);
-    u32 par, ye;
-    if constexpr (WQ == 1) {
-        const u32x4 qv = *reinterpret_cast<const u32x4 *>(sq);
-        const u32 f = __popc(v.x & qv.z) + __popc(v.y & qv.w);
-        par = f + __popc(v.z & qv.x) + __popc(v.w & qv.y) + (f << 16);
-        ye = (__popc(v.x & v.z) + __popc(v.y & v.w)) | ((__popc((v.x ^ qv.x) & (v.z ^ qv.z)) + __popc((v.y ^ qv.y) & (v.w ^ qv.w))) << 16);
-    } else {
-        const u32x4 qs = reinterpret_cast<const u32x4 *>(sq)[c], qo = reinterpret_cast<const u32x4 *>(sq)[c ^ (WQ / 2)];
-        const bool xhalf = c < WQ / 2;
-        const u32 p = __popc(v.x & qo.x) + __popc(v.y & qo.y) + __popc(v.z & qo.z) + __popc(v.w & qo.w);
-        const u32x4 o = {rot_other_half<WQ>(v.x), rot_other_half<WQ>(v.y), rot_other_half<WQ>(v.z), rot_other_half<WQ>(v.w)};
-        const u32 yp = __popc(v.x & o.x) + __popc(v.y & o.y) + __popc(v.z & o.z) + __popc(v.w & o.w);
-        const u32 yo = __popc((v.x ^ qs.x) & (o.x ^ qo.x)) + __popc((v.y ^ qs.y) & (o.y ^ qo.y)) + __popc((v.z ^ qs.z) & (o.z ^ qo.z)) +
-                       __popc((v.w ^ qs.w) & (o.w ^ qo.w));
-        par = rot_row_sum<WQ>(p + (xhalf ? (p << 16) : 0u));
-        ye = rot_row_sum<WQ>(xhalf ? (yp | (yo << 16)) : 0u);
-    }
-    if (c == 0 && valid) {
-        const bool anti = par & 1u;
-        const int e = (int)((3u * ((ye & 0xFFFFu) + (u32)s_yq) + (ye >> 16) + 2u * ((par >> 16) & 1u)) & 3u);
-        double re = coeff[2 * t], im = coeff[2 * t + 1];
-        if (anti) {
-            if (k & 1) {                                              // c * i^e * (-i), negated for k = 3 (k_rotc_classify)
-                double x, y;
-                phase_mul(re, im, e, x, y);
-                re = y; im = -x;
-                if (k == 3) { re = -re; im = -im; }
-            } else if (k == 2) { re = -re; im = -im; }
-            atomicAdd(&s_n, 1u);
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const i64 t = (i64)blockIdx.x * CCH_ROWS + it * R + threadIdx.x / WQ;
+        const bool valid = t < T;
+        const u32x4 v = valid ? rows[t * WQ + c] : (u32x4)(0u);
+        u32 par, ye;
+        if constexpr (WQ == 1) {
+            const u32x4 qv = *reinterpret_cast<const u32x4 *>(sq);
+            const u32 f = __popc(v.x & qv.z) + __popc(v.y & qv.w);
+            par = f + __popc(v.z & qv.x) + __popc(v.w & qv.y) + (f << 16);
+            ye = (__popc(v.x & v.z) + __popc(v.y & v.w)) | ((__popc((v.x ^ qv.x) & (v.z ^ qv.z)) + __popc((v.y ^ qv.y) & (v.w ^ qv.w))) << 16);
+        } else {
+            const u32x4 qs = reinterpret_cast<const u32x4 *>(sq)[c], qo = reinterpret_cast<const u32x4 *>(sq)[c ^ (WQ / 2)];
+            const bool xhalf = c < WQ / 2;
+            const u32 p = __popc(v.x & qo.x) + __popc(v.y & qo.y) + __popc(v.z & qo.z) + __popc(v.w & qo.w);
+            const u32x4 o = {rot_other_half<WQ>(v.x), rot_other_half<WQ>(v.y), rot_other_half<WQ>(v.z), rot_other_half<WQ>(v.w)};
+            const u32 yp = __popc(v.x & o.x) + __popc(v.y & o.y) + __popc(v.z & o.z) + __popc(v.w & o.w);
+            const u32 yo = __popc((v.x ^ qs.x) & (o.x ^ qo.x)) + __popc((v.y ^ qs.y) & (o.y ^ qo.y)) + __popc((v.z ^ qs.z) & (o.z ^ qo.z)) +
+                           __popc((v.w ^ qs.w) & (o.w ^ qo.w));
+            par = rot_row_sum<WQ>(p + (xhalf ? (p << 16) : 0u));
+            ye = rot_row_sum<WQ>(xhalf ? (yp | (yo << 16)) : 0u);
         }
-        af[t] = anti ? 1 : 0;
-        nc[2 * t] = re; nc[2 * t + 1] = im;
+        if (c == 0 && valid) {
+            const bool anti = par & 1u;
+            const int e = (int)((3u * ((ye & 0xFFFFu) + (u32)s_yq) + (ye >> 16) + 2u * ((par >> 16) & 1u)) & 3u);
+            double re = coeff[2 * t], im = coeff[2 * t + 1];
+            if (anti) {
+                if (k & 1) {                                          // c * i^e * (-i), negated for k = 3 (k_rotc_classify)
+                    double x, y;
+                    phase_mul(re, im, e, x, y);
+                    re = y; im = -x;
+                    if (k == 3) { re = -re; im = -im; }
+                } else if (k == 2) { re = -re; im = -im; }
+                atomicAdd(&s_n, 1u);
+            }
+            af[t] = anti ? 1 : 0;
+            nc[2 * t] = re; nc[2 * t + 1] = im;
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0 && s_n) atomicAdd(&cnt[((i64)blockIdx.x * R) >> 10], s_n);   // R divides 1024: a block lies inside one group
+    if (threadIdx.x == 0 && s_n) atomicAdd(&cnt[((i64)blockIdx.x * CCH_ROWS) >> 10], s_n);   // CCH_ROWS divides 1024: a block lies inside one group
 }
 
-template <int WQ>
+template <int WQ, int CCH_ROWS>
 __global__ __launch_bounds__(256) void k_cchain_move(const u32x4 *__restrict__ rows, i64 T, const u64 *__restrict__ q_dev, int k,
                                                       const uint8_t *__restrict__ af, const double *__restrict__ nc, const u32 *__restrict__ cnt,
                                                       int n_cnt, u32 *__restrict__ cnt_next, u32x4 *__restrict__ out_rows, double *__restrict__ out_coeff) {
-    constexpr int R = 256 / WQ;
+    constexpr int R = 256 / WQ, ITER = CCH_ROWS / R;
     __shared__ u32 s_sum[3];                                          // anticommuting rows: in the groups before, in all groups, before the block inside its group
-    __shared__ uint8_t s_flag[R];
-    __shared__ u32 s_pos[R];
+    __shared__ uint8_t s_flag[CCH_ROWS];
+    __shared__ u32 s_pos[CCH_ROWS];
     if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
     __syncthreads();
-    const i64 t0 = (i64)blockIdx.x * R;
+    const i64 t0 = (i64)blockIdx.x * CCH_ROWS;
     const int g = (int)(t0 >> 10);
     const i64 g0 = (i64)g << 10;
     u32 before = 0, all = 0, inside = 0;
@@ -935,13 +939,9 @@ __global__ __launch_bounds__(256) void k_cchain_move(const u32x4 *__restrict__ r
         all = x;
         if ((int)threadIdx.x < g) before = x;
     }
-    {   // byte flags of the rows [g0, t0): at most 1020 bytes, one u32 per thread
+    {   // byte flags of the rows [g0, t0): at most 1020 bytes, one u32 per thread (t0 - g0 is a multiple of CCH_ROWS >= 4)
         const i64 w = g0 + 4 * (i64)threadIdx.x;
-        if (w < t0) {                                                 // t0 - g0 is a multiple of R; R >= 4 or the bytes are masked below
-            u32 x = *reinterpret_cast<const u32 *>(af + w);
-            if (w + 4 > t0) x &= (1u << (8 * (u32)(t0 - w))) - 1u;
-            inside = (x * 0x01010101u) >> 24;
-        }
+        if (w < t0) inside = (*reinterpret_cast<const u32 *>(af + w) * 0x01010101u) >> 24;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -949,11 +949,15 @@ __global__ __launch_bounds__(256) void k_cchain_move(const u32x4 *__restrict__ r
     }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&s_sum[0], before); atomicAdd(&s_sum[1], all); atomicAdd(&s_sum[2], inside); }
     if (blockIdx.x == 0 && (int)threadIdx.x < n_cnt) cnt_next[threadIdx.x] = 0;      // the array the next rotation's flags kernel adds to
-    if ((int)threadIdx.x < R) s_flag[threadIdx.x] = (t0 + threadIdx.x < T) ? af[t0 + threadIdx.x] : 0;
+    if ((int)threadIdx.x < CCH_ROWS) s_flag[threadIdx.x] = (t0 + threadIdx.x < T) ? af[t0 + threadIdx.x] : 0;
     __syncthreads();
-    if ((int)threadIdx.x < R && t0 + threadIdx.x < T) {
-        u32 rank = 0;
-        for (int r = 0; r < (int)threadIdx.x; ++r) rank += s_flag[r];
+    if ((int)threadIdx.x < CCH_ROWS && t0 + threadIdx.x < T) {
+        // rank among the block's rows: the flags of the same wavefront's lower lanes (CCH_ROWS <= 256: up to 4 wavefronts)
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const u64 bal = __ballot(s_flag[threadIdx.x] != 0);
+        u32 rank = (u32)__popcll(bal & ((1ULL << lane) - 1ULL));
+        for (int w2 = 0; w2 < wv; ++w2)
+            for (int r = 0; r < 64; ++r) rank += s_flag[w2 * 64 + r];
         const u32 a_before = s_sum[0] + s_sum[2] + rank;              // anticommuting rows before this one
         const i64 t = t0 + threadIdx.x;
         const u32 pos = s_flag[threadIdx.x] ? a_before : s_sum[1] + (u32)(t - a_before);
@@ -962,12 +966,17 @@ __global__ __launch_bounds__(256) void k_cchain_move(const u32x4 *__restrict__ r
         reinterpret_cast<f64x2 *>(out_coeff)[pos] = reinterpret_cast<const f64x2 *>(nc)[t];
     }
     __syncthreads();
-    const int c = threadIdx.x & (WQ - 1), rl = threadIdx.x / WQ;
-    const i64 t = t0 + rl;
-    if (t < T) {
-        u32x4 v = rows[t * WQ + c];
-        if (s_flag[rl] && (k & 1)) v ^= reinterpret_cast<const u32x4 *>(q_dev)[c];
-        out_rows[(i64)s_pos[rl] * WQ + c] = v;
+    const int c = threadIdx.x & (WQ - 1);
+    const u32x4 qc = reinterpret_cast<const u32x4 *>(q_dev)[c];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int rl = it * R + threadIdx.x / WQ;
+        const i64 t = t0 + rl;
+        if (t < T) {
+            u32x4 v = rows[t * WQ + c];
+            if (s_flag[rl] && (k & 1)) v ^= qc;
+            out_rows[(i64)s_pos[rl] * WQ + c] = v;
+        }
     }
 }
 
@@ -1198,7 +1207,7 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
             if (rc != SYMGPU_OK) { symgpu_op_free(a); symgpu_op_free(b); return rc; }
             symgpu_op_t cur = a, nxt = b;
             static const bool two_on = [] { const char *e2 = getenv("SYMGPU_CHAIN_TWO"); return !(e2 && e2[0] == '0'); }();
-            if (two_on && Wq <= 64 && (Wq & (Wq - 1)) == 0 && T <= CHAIN_TWO_T) {
+            if (two_on && Wq <= 64 && (Wq & (Wq - 1)) == 0 && T <= (getenv("SYMGPU_CHAIN_TWO_T") ? atoll(getenv("SYMGPU_CHAIN_TWO_T")) : CHAIN_TWO_T)) {
                 // two launches per rotation (k_cchain_flags / k_cchain_move)
                 Scratch af, nc, cnts;
                 const int n_cnt = (int)((T + 1023) / 1024);
@@ -1207,16 +1216,21 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
                 if (rc == SYMGPU_OK) rc = cnts.alloc(2 * 256 * sizeof(u32));
                 if (rc != SYMGPU_OK) { symgpu_op_free(a); symgpu_op_free(b); return rc; }
                 e = hipMemsetAsync(cnts.p, 0, 2 * 256 * sizeof(u32), st);
-                const i64 Rr = 256 / Wq, gb = (T + Rr - 1) / Rr;
+                // rows per block: 256 / WQ (one pass: lowest latency, 6.7-7.1 us per rotation up to 1,000 rows) or 64 (the block's fixed
+                // costs — Q, group counts, flag prefix — paid once per four passes: 10.4 / 13.4 / 20.8 / 26.7 us at 8,000 / 16,384 /
+                // 65,536 / 131,072 rows against 12.9 / 20.7 / 40.2 / 59.3 us)
+                const bool big = T > 4096;
                 for (i64 r = 0; r < K && e == hipSuccess; ++r) {
                     const u64 *q = qs.as<u64>() + r * W;
                     u32 *c_now = cnts.as<u32>() + (r & 1) * 256, *c_next = cnts.as<u32>() + ((r + 1) & 1) * 256;
                     const u32x4 *src = reinterpret_cast<const u32x4 *>(cur->rows);
                     u32x4 *dstr = reinterpret_cast<u32x4 *>(nxt->rows);
-#define LAUNCH_CC(WQV) do { \
-                        hipLaunchKernelGGL((k_cchain_flags<WQV>), dim3((unsigned)gb), dim3(256), 0, st, src, cur->coeff, T, q, ks_host[r], af.as<uint8_t>(), nc.as<double>(), c_now); \
-                        hipLaunchKernelGGL((k_cchain_move<WQV>), dim3((unsigned)gb), dim3(256), 0, st, src, T, q, ks_host[r], af.as<uint8_t>(), nc.as<double>(), c_now, n_cnt, \
+#define LAUNCH_CC2(WQV, ROWSV) do { \
+                        const i64 gb = (T + (ROWSV) - 1) / (ROWSV); \
+                        hipLaunchKernelGGL((k_cchain_flags<WQV, ROWSV>), dim3((unsigned)gb), dim3(256), 0, st, src, cur->coeff, T, q, ks_host[r], af.as<uint8_t>(), nc.as<double>(), c_now); \
+                        hipLaunchKernelGGL((k_cchain_move<WQV, ROWSV>), dim3((unsigned)gb), dim3(256), 0, st, src, T, q, ks_host[r], af.as<uint8_t>(), nc.as<double>(), c_now, n_cnt, \
                                            c_next, dstr, nxt->coeff); } while (0)
+#define LAUNCH_CC(WQV) do { if (big && 256 / (WQV) < 64) LAUNCH_CC2(WQV, 64); else LAUNCH_CC2(WQV, (256 / (WQV))); } while (0)
                     switch (Wq) {
                         case 1: LAUNCH_CC(1); break;
                         case 2: LAUNCH_CC(2); break;
@@ -1226,6 +1240,7 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
                         case 32: LAUNCH_CC(32); break;
                         default: LAUNCH_CC(64); break;
                     }
+#undef LAUNCH_CC2
 #undef LAUNCH_CC
                     symgpu_op_t t2 = cur; cur = nxt; nxt = t2;
                 }

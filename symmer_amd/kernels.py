@@ -216,7 +216,7 @@ def rotate_single_dev(op, q_row, angle, zero_threshold=1e-15, clifford_threshold
     return DeviceOp(out), False
 
 
-# symgpu_rotate_clifford_chain_dev: one single-workgroup launch for the whole run up to 128 terms, two launches per rotation up to 8,192 (3.5 us per rotation at 1 term,
+# symgpu_rotate_clifford_chain_dev: one single-workgroup launch for the whole run up to 128 terms, two launches per rotation up to 262,144 (3.5 us per rotation at 1 term,
 # 5 us at 64, 29 us at 1,000; n = 1000), the per-rotation kernels back to back without a host read-back above that.
 CLIFFORD_CHAIN_MAX_TERMS = 1 << 22
 CLIFFORD_CHAIN_KERNEL_LIMIT = 8192

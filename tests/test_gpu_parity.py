@@ -153,12 +153,12 @@ def test_rotation_chain_from_operator_with_duplicates():
     assert_op_equal(R.symp_matrix, R.coeff_vec, er, ec, exact=False, tol=TOL)
 
 
-@pytest.mark.parametrize('n,T,K', [(1000, 1, 300), (70, 37, 200), (5, 60, 120), (130, 1500, 60), (64, 128, 30), (64, 129, 12), (64, 448, 30), (64, 1537, 12), (100, 8192, 9), (100, 8193, 7), (1000, 3000, 11), (2000, 700, 9), (4096, 300, 9), (1, 4, 50),
+@pytest.mark.parametrize('n,T,K', [(1000, 1, 300), (70, 37, 200), (5, 60, 120), (130, 1500, 60), (64, 128, 30), (64, 129, 12), (64, 448, 30), (64, 1537, 12), (100, 4096, 9), (100, 4097, 7), (1000, 3000, 11), (2000, 700, 9), (4096, 300, 9), (1, 4, 50),
                                    (200, 20000, 25)])
 def test_clifford_chain_single_launch_vs_oracle(n, T, K):
     """perform_rotations with runs of Clifford rotations on a small clean operator = ONE launch per run (symgpu_rotate_clifford_chain_dev):
     rows, row order and coefficients (exact phases: bit-exact) against the step-by-step oracle, every k in -2..5, rotations that
-    commute with everything, a non-Clifford rotation in the middle (splits the run), 128 / 129 / 8192 / 8193 / 20000 terms (single-workgroup, two-launch, four-launch form;
+    commute with everything, a non-Clifford rotation in the middle (splits the run), 128 / 129 / 4096 / 4097 / 20000 terms (single-workgroup, two-launch, four-launch form;
     launch / back-to-back multi-workgroup launches)."""
     rng = np.random.default_rng(5000 + n + T)
     symp = rng.random((T, 2 * n)) < (0.3 if n > 1 else 0.5)
