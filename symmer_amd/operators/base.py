@@ -487,6 +487,13 @@ class PauliwordOp:
         if rotations == []:
             return self.copy().cleanup()
         wq = packing.words_per_block(self.n_qubits)
+        # pack the generators of the whole sequence in ONE vectorised call (a depth-2,000 circuit handed over as bool matrices spent
+        # 10 ms packing 2,000 single rows one by one: more than the 10 ms of its device run)
+        fresh = [r for r, _ in rotations if isinstance(r, PauliwordOp) and r._packed_cache is None and r._symp is not None
+                 and r.n_terms == 1 and r.n_qubits == self.n_qubits]
+        if len(fresh) > 4:
+            for r, row in zip(fresh, packing.pack_rows(np.concatenate([r._symp for r in fresh], axis=0))):
+                r._packed_cache = row.reshape(1, -1)
         dev = kernels.DeviceOp.upload(self.packed, self.coeff_vec)
         # The reference calls ``.cleanup()`` after every rotation (base.py:1185).  On an operator that has no duplicate rows and
         # no coefficient with |c| <= 1e-15 that cleanup is the identity, and the rotation kernels preserve both properties
