@@ -8,6 +8,7 @@ the MI355X (Heisenberg picture, sequence reversed), and ``evaluate`` sums the co
 from typing import List
 import numpy as np
 from ..operators import PauliwordOp
+from .. import packing
 
 _Q = np.pi / 2
 
@@ -35,10 +36,18 @@ class CircuitSymmerlator:
         pauli = list(pauli)
         assert len(pauli) == len(indices), 'Number of Paulis and indices do not match'
         assert set(pauli).issubset({'I', 'X', 'Y', 'Z'}), 'Pauli operators are either I, X, Y or Z.'
-        R = ['I'] * self.n_qubits
+        # the packed row directly (a few set bits) instead of an n-character string parsed by from_list: a depth-2,000 circuit on
+        # 1,000 qubits spent 0.48 s building its 4,000 generators that way — the device run takes 0.02 s
+        wq = packing.words_per_block(self.n_qubits)
+        row = np.zeros((1, 2 * wq), dtype='<u8')
         for i, P in zip(indices, pauli):
-            R[i] = P
-        return PauliwordOp.from_list([''.join(R)])
+            assert 0 <= i < self.n_qubits, 'qubit index out of range'
+            bit = np.uint64(1) << np.uint64(i & 63)
+            if P in 'XY':
+                row[0, i >> 6] |= bit
+            if P in 'ZY':
+                row[0, wq + (i >> 6)] |= bit
+        return PauliwordOp._from_packed(row, self.n_qubits, [1])
 
     def pi_2_multiple(self, multiple: int) -> float:
         return _Q * multiple
