@@ -849,6 +849,106 @@ __global__ __launch_bounds__(1024) void k_clifford_chain(u64 *__restrict__ rowsA
     if (threadIdx.x == 0) *result_in_b = in_b;
 }
 
+// The same run with the operator resident in LDS (<= 128 rows and <= 64 KiB of rows: the circuit simulator's observables).  The
+// global version above goes through L2 twice per rotation (rows written by the previous rotation are read back by other waves of
+// the workgroup: 4.9 us per rotation at 64 rows of 256 bytes); here rows and coefficients ping-pong between two LDS buffers, Q of
+// the NEXT rotation is fetched into registers while the current one runs, and a rotation is three barriers.
+constexpr int CHAIN_LDS_T = 128;
+__global__ __launch_bounds__(1024) void k_clifford_chain_lds(u64 *__restrict__ rows, double *__restrict__ coeff, int T, int Wq, int G,
+                                                              const u64 *__restrict__ qs, const int *__restrict__ ks, int K) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds_dyn[];    // [2][T * W] rows
+    __shared__ double s_c[2][2 * CHAIN_LDS_T];
+    __shared__ u64 s_q2[2][128];                                     // Q of this rotation / of the next one (written before the barrier
+                                                                      // that ends the previous rotation's row move, which still reads its Q)
+    __shared__ uint8_t s_anti[CHAIN_LDS_T], s_ph[CHAIN_LDS_T];
+    __shared__ u32 s_pos[CHAIN_LDS_T];
+    __shared__ u32 s_cnt[2];
+    const int W = 2 * Wq, n_words = T * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = threadIdx.x % G, rsub = threadIdx.x / G, rows_per_pass = 1024 / G;
+    u64 *buf0 = lds_dyn, *buf1 = lds_dyn + n_words;
+    for (int i = threadIdx.x; i < n_words; i += 1024) buf0[i] = rows[i];
+    for (int i = threadIdx.x; i < 2 * T; i += 1024) s_c[0][i] = coeff[i];
+    int cur = 0;
+    u64 q_next = (K > 0 && (int)threadIdx.x < W) ? qs[threadIdx.x] : 0ULL;
+    for (int r = 0; r < K; ++r) {
+        const int k = ks[r];
+        u64 *s_q = s_q2[r & 1];
+        if ((int)threadIdx.x < W) s_q[threadIdx.x] = q_next;
+        __syncthreads();                                              // Q in place; the previous rotation's buffers complete
+        if (r + 1 < K && (int)threadIdx.x < W) q_next = qs[(i64)(r + 1) * W + threadIdx.x];   // in flight during this rotation
+        u64 *cr = cur ? buf1 : buf0, *nr = cur ? buf0 : buf1;
+        double *cc = s_c[cur], *ncf = s_c[cur ^ 1];
+        // ---- flags + phase exponents (G lanes per row; the Y count of Q is formed along the way by the same lanes) ----
+        for (int t0 = 0; t0 < T; t0 += rows_per_pass) {
+            const int t = t0 + rsub;
+            u64 par = 0, flip = 0;
+            int yp = 0, yout = 0, yq = 0;
+            if (t < T) {
+                const u64 *row = cr + t * W;
+                for (int w = g; w < Wq; w += G) {
+                    const u64 x = row[w], z = row[Wq + w], xq = s_q[w], zq = s_q[Wq + w];
+                    par ^= (x & zq) ^ (z & xq);
+                    flip ^= x & zq;
+                    yp += __popcll(x & z);
+                    yout += __popcll((x ^ xq) & (z ^ zq));
+                    yq += __popcll(xq & zq);
+                }
+            }
+            int pp = __popcll(par) & 1, fp = __popcll(flip) & 1;
+            for (int off = G >> 1; off > 0; off >>= 1) {
+                pp ^= __shfl_xor(pp, off);
+                fp ^= __shfl_xor(fp, off);
+                yp += __shfl_xor(yp, off);
+                yout += __shfl_xor(yout, off);
+                yq += __shfl_xor(yq, off);
+            }
+            if (g == 0 && t < T) {
+                s_anti[t] = (uint8_t)pp;
+                s_ph[t] = (uint8_t)((3 * (yp + yq) + yout + 2 * fp) & 3);
+            }
+        }
+        __syncthreads();
+        // ---- slots of the stable partition [anticommuting | commuting]: waves 0 and 1, one row per lane ----
+        if (wave < 2) {
+            const int t = wave * 64 + lane;
+            const bool a = t < T && s_anti[t];
+            const u64 bal = __ballot(a);
+            if (lane == 0) s_cnt[wave] = (u32)__popcll(bal);
+            s_pos[t < CHAIN_LDS_T ? t : 0] = (u32)__popcll(bal & ((1ULL << lane) - 1ULL));      // rank inside the wave, completed below
+        }
+        __syncthreads();
+        const u32 n0 = s_cnt[0], n_anti = n0 + s_cnt[1];
+        if (n_anti == 0) continue;                                    // every term commutes with Q: identity (base.py:1131-1133)
+        // ---- rows and coefficients to their slots in the other buffer ----
+        for (int t0 = 0; t0 < T; t0 += rows_per_pass) {
+            const int t = t0 + rsub;
+            if (t < T) {
+                const bool a = s_anti[t];
+                const u32 a_before = s_pos[t] + (t >= 64 ? n0 : 0u);
+                const u32 pos = a ? a_before : n_anti + ((u32)t - a_before);
+                const bool flipq = a && (k & 1);
+                const u64 *row = cr + t * W;
+                u64 *dst = nr + pos * W;
+                for (int w = g; w < W; w += G) dst[w] = row[w] ^ (flipq ? s_q[w] : 0ULL);
+                if (g == 0) {
+                    double re = cc[2 * t], im = cc[2 * t + 1];
+                    if (a) {
+                        if (k & 1) { double x, y; phase_mul(re, im, s_ph[t], x, y); re = y; im = -x; }     // c * i^e * (-i)
+                        if (k == 2 || k == 3) { re = -re; im = -im; }
+                    }
+                    ncf[2 * pos] = re; ncf[2 * pos + 1] = im;
+                }
+            }
+        }
+        cur ^= 1;                                                     // the barrier at the top of the next rotation completes the move
+    }
+    __syncthreads();
+    const u64 *fr = cur ? buf1 : buf0;
+    for (int i = threadIdx.x; i < n_words; i += 1024) rows[i] = fr[i];
+    for (int i = threadIdx.x; i < 2 * T; i += 1024) coeff[i] = s_c[cur][i];
+}
+
 
 // ---- a run of Clifford rotations of a CLEAN operator, two launches per rotation -----------------------------------------------------
 // Back-to-back launches are launch-rate bound (3.9 us per launch, four per rotation: 15.6 us at any size up to 8,000 rows).  For a
@@ -1184,7 +1284,16 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
             local_t = atoll(env);
             if (local_t > CHAIN_TMAX) local_t = CHAIN_TMAX;
         }
-        if (e == hipSuccess && T <= local_t) {
+        const size_t lds_rows = (size_t)2 * T * W * 8;
+        static const bool lds_on = [] { const char *e3 = getenv("SYMGPU_CHAIN_LDS"); return !(e3 && e3[0] == '0'); }();
+        static const bool lds_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_clifford_chain_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         128 * 1024) == hipSuccess;
+        if (e == hipSuccess && lds_on && lds_attr && T <= local_t && T <= CHAIN_LDS_T && W <= 128 && lds_rows <= 128 * 1024) {
+            // small operator, resident in LDS for the whole run
+            hipLaunchKernelGGL(k_clifford_chain_lds, dim3(1), dim3(1024), lds_rows, st, a->rows, a->coeff, (int)T, Wq, G, qs.as<u64>(), ks.as<int>(), (int)K);
+            e = hipGetLastError();
+            in_b = 0;
+        } else if (e == hipSuccess && T <= local_t) {
             // small operator: the whole run in one single-workgroup launch
             hipLaunchKernelGGL(k_clifford_chain, dim3(1), dim3(1024), 0, st, a->rows, a->coeff, b->rows, b->coeff, (int)T, Wq, G, qs.as<u64>(),
                                ks.as<int>(), (int)K, which.as<int>());
