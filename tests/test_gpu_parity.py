@@ -154,6 +154,7 @@ def test_rotation_chain_from_operator_with_duplicates():
 
 
 @pytest.mark.parametrize('n,T,K', [(1000, 1, 300), (70, 37, 200), (5, 60, 120), (130, 1500, 60), (64, 128, 30), (64, 129, 12), (64, 448, 30), (64, 1537, 12), (100, 4096, 9), (100, 4097, 7), (1000, 3000, 11), (2000, 700, 9), (4096, 300, 9), (1, 4, 50),
+                                   (4096, 60, 15), (2000, 128, 10), (2048, 127, 10), (1000, 128, 12), (1, 128, 20),       # the LDS-resident kernel at its limits
                                    (200, 20000, 25)])
 def test_clifford_chain_single_launch_vs_oracle(n, T, K):
     """perform_rotations with runs of Clifford rotations on a small clean operator = ONE launch per run (symgpu_rotate_clifford_chain_dev):
