@@ -360,16 +360,19 @@ def extras(_lib, kernels, DeviceOp):
         rng = np.random.default_rng(1236)
         P = DeviceOp.random(100000, 1000, 0.3, seed=1236)
         qs = [packing.pack_rows((rng.random((1, 2000)) < 0.3))[0] for _ in range(8)]
-        t0 = time.perf_counter(); terms = []
-        cur = P
-        for q in qs[:4]:
-            res, allc = kernels.rotate_single_dev(cur, q, 0.3)
-            if cur is not P:
-                cur.free()
-            cur = res
-            terms.append(cur.n_terms)
-        kernels.sync(); t_chain = time.perf_counter() - t0
-        cur.free()
+        def chain4():
+            terms, cur = [], P
+            for q in qs[:4]:
+                res, allc = kernels.rotate_single_dev(cur, q, 0.3)
+                if cur is not P:
+                    cur.free()
+                cur = res
+                terms.append(cur.n_terms)
+            kernels.sync()
+            cur.free()
+            return terms
+        chain4()                                                     # first pass: the allocator meets the growing result sizes (hipMalloc)
+        t0 = time.perf_counter(); terms = chain4(); t_chain = time.perf_counter() - t0
         t1 = timed(lambda: kernels.rotate_single_dev(P, qs[0], 0.3)[0].free(), 5)
         # chain of 128 Clifford (pi/2) rotations with the operator device resident (term count stays 1e5)
         cur = P
