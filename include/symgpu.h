@@ -53,8 +53,13 @@ int symgpu_timer_stop(float *ms);
 int symgpu_prof_enable(int kernel_class, int on);
 int symgpu_prof_read(int kernel_class, int64_t *n_launches, double *total_ms);
 /* statistics for tests: which = 0: number of row-hash collisions that forced the cleanup to reseed its hash and retry (the exactness
- * guard behind symplectic_cleanup, operators/utils.py:230-279; expected 0 outside the tests, which weaken the hash on purpose) */
+ * guard behind symplectic_cleanup, operators/utils.py:230-279; expected 0 outside the tests, which weaken the hash on purpose);
+ * 1: rotations completed by the one-launch LDS-resident kernel; 2: calls of that kernel that reported a failed row verification or a
+ * barrier time-out (the multi-launch path then recomputes); 3: device allocations that were not served from the allocator's arena */
 int symgpu_debug_counter(int which, int64_t *value);
+/* tuning aid: with SYMGPU_RES_TRACE=1 every workgroup of the one-launch rotation kernel stamps the 100 MHz wall clock at its phase
+ * boundaries; this copies the stamps of the last traced launch, 16 words per workgroup */
+int symgpu_debug_rotation_trace(uint64_t *out, int max_workgroups, int *n_workgroups);
 
 /* measured on-box HBM ceilings for the roofline: one-shot 16-byte-per-thread fill (GB/s written) and copy (GB/s read+written)
  * over scratch buffers of `bytes` each (best of 3). */
@@ -156,6 +161,9 @@ int symgpu_comm_available(void);                                                
 int symgpu_comm_unique_id(uint8_t id[SYMGPU_UNIQUE_ID_BYTES]);                 /* rank 0 */
 int symgpu_comm_init(const uint8_t id[SYMGPU_UNIQUE_ID_BYTES], int rank, int nranks);
 int symgpu_comm_destroy(void);
+/* A caller whose watchdog gave up on a symgpu_comm_init that has not returned calls this: should ncclCommInitRank come back later,
+ * its communicator is destroyed instead of installed (the ranks have agreed on the host-staged data plane by then). */
+int symgpu_comm_abandon(void);
 /* all-gather equal-sized shards of packed rows (+coefficients if both have them) into `full`
  * (capacity >= nranks * shard rows); rank r's rows land at [r*T_shard, (r+1)*T_shard). */
 int symgpu_comm_allgather_op(symgpu_op_t shard, symgpu_op_t full);

@@ -40,6 +40,7 @@ SIGNATURES = {
     'symgpu_prof_enable': [c_int, c_int],
     'symgpu_prof_read': [c_int, P, P],
     'symgpu_debug_counter': [c_int, P],
+    'symgpu_debug_rotation_trace': [P, c_int, P],
     'symgpu_membw_probe': [c_i64, P, P],
     'symgpu_op_upload': [P, P, c_i64, c_int, PP],
     'symgpu_op_alloc': [c_i64, c_int, c_int, PP],
@@ -77,6 +78,7 @@ SIGNATURES = {
     'symgpu_comm_unique_id': [P],
     'symgpu_comm_init': [P, c_int, c_int],
     'symgpu_comm_destroy': [],
+    'symgpu_comm_abandon': [],
     'symgpu_comm_allgather_op': [P, P],
     'symgpu_comm_barrier': [],
 }

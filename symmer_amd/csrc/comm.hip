@@ -10,6 +10,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <string>
+#include <mutex>
 
 namespace symgpu {
 
@@ -23,6 +24,10 @@ struct Rccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    // a bring-up that did not return in time was given up by the caller (symgpu_comm_abandon): if ncclCommInitRank does come back
+    // later, its communicator is destroyed instead of installed — the ranks have agreed on another data plane by then
+    int init_generation = 0, abandoned_generation = -1;
+    std::mutex mu;
 };
 static Rccl g_rccl;
 
@@ -96,10 +101,28 @@ int symgpu_comm_init(const uint8_t id[SYMGPU_UNIQUE_ID_BYTES], int rank, int nra
     if (g_rccl.comm) { set_error("comm_init: communicator already exists"); return SYMGPU_E_INVALID; }
     ncclUniqueId u;
     memcpy(&u, id, SYMGPU_UNIQUE_ID_BYTES);
-    ncclResult_t r = g_rccl.CommInitRank(&g_rccl.comm, nranks, u, rank);
-    if (r != ncclSuccess) { g_rccl.comm = nullptr; return rccl_fail(r, "ncclCommInitRank"); }
-    g_rccl.rank = rank;
-    g_rccl.nranks = nranks;
+    int my_generation;
+    { std::lock_guard<std::mutex> lk(g_rccl.mu); my_generation = ++g_rccl.init_generation; }
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = g_rccl.CommInitRank(&comm, nranks, u, rank);
+    if (r != ncclSuccess) return rccl_fail(r, "ncclCommInitRank");
+    {
+        std::lock_guard<std::mutex> lk(g_rccl.mu);
+        if (g_rccl.abandoned_generation < my_generation) {
+            g_rccl.comm = comm;
+            g_rccl.rank = rank;
+            g_rccl.nranks = nranks;
+            return SYMGPU_OK;
+        }
+    }
+    g_rccl.CommDestroy(comm);                                       // came back after the caller had given up on it
+    set_error("comm_init: ncclCommInitRank returned after symgpu_comm_abandon; communicator destroyed");
+    return SYMGPU_E_RCCL;
+}
+
+int symgpu_comm_abandon(void) {
+    std::lock_guard<std::mutex> lk(g_rccl.mu);
+    g_rccl.abandoned_generation = g_rccl.init_generation;
     return SYMGPU_OK;
 }
 

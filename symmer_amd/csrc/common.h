@@ -58,8 +58,22 @@ struct Context {
     u32 rot_gen = 0;
     u32 *rot_flags = nullptr;      // device u32[4]: [0] = generation in which a duplicate input row was seen
     void *rot_host_cnt = nullptr, *rot_host_cnt_dev = nullptr;   // pinned host copy of a rotation's counts and its device address (rotate.hip)
+    // one-launch rotation (rotate_resident.hip): partner notes [generation 10 | row + 1 : 22] of the join (same generation as
+    // rot_table), the granules of the in-launch all-gathers + failure words, and the epoch that tags them (1 .. 16382)
+    u32 *rot_partner = nullptr;
+    size_t rot_partner_cap = 0;
+    u64 *res_table = nullptr;      // its join table [canonical-key tag 32 | row + 1 : 32], all-zero between launches
+    size_t res_table_cap = 0;
+    bool res_dirty = false;        // a launch did not complete: table and notes must be cleared before the next one
+    u64 *res_state = nullptr;
+    u32 res_epoch = 0;
+    u32 *sort_state = nullptr;     // one-launch radix sort (sort.hip): barrier counter, time-out flag, tile histograms
+    u32 sort_bar_base = 0;
+    bool sort_coop_disabled = false;
+    bool res_disabled = false;     // a barrier timed out once (workgroups not co-resident): the process keeps to the multi-launch paths
 };
 Context &ctx();
+extern i64 g_counters[4];                  // debug counters (symgpu_debug_counter): [1] one-launch rotations, [2] their failures, [3] hipMalloc calls of dev_alloc
 int require_ctx();
 
 // per-launch event timing of one kernel class (bench.py roofline leg)
@@ -130,6 +144,9 @@ int exclusive_scan_u32(const u32 *in, u32 *out, i64 n, u32 *total_dev /* may be 
 int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp, i64 n, int begin_bit, int end_bit,
                              bool *result_in_tmp);
 int radix_sort_keys_u64(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp);
+// the same as one persistent launch (up to 2^19 keys); *done = false: not applicable, use the multi-launch form
+int radix_sort_keys_u64_coop(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done);
+int radix_sort_coop_check(bool *timed_out);     // after a stream synchronisation: did a one-launch sort give up (output invalid)?
 
 // commute.hip
 // b_owner (may be null): the operator B's rows belong to (all of them), so that per-operand layouts can be cached on it

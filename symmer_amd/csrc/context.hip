@@ -28,12 +28,21 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
 }
 
 static Context g_ctx;
+i64 g_counters[4] = {0, 0, 0, 0};          // symgpu_debug_counter 1..3 (0 is g_hash_reseeds, cleanup.hip)
 Context &ctx() { return g_ctx; }
 
 int require_ctx() {
     if (!g_ctx.ready) {
         set_error("symgpu_init() has not been called (or no HIP device)");
         return SYMGPU_E_NODEVICE;
+    }
+    // HIP's current device is per host thread and starts at 0: a thread other than the one that called symgpu_init (e.g. the
+    // watchdog thread of symmer_amd/parallel.py) must be bound to the context's device before it touches the runtime, or a
+    // rank > 0 would create its RCCL communicator on device 0
+    static thread_local int bound = -1;
+    if (bound != g_ctx.device) {
+        HIP_TRY(hipSetDevice(g_ctx.device));
+        bound = g_ctx.device;
     }
     return SYMGPU_OK;
 }
@@ -75,6 +84,7 @@ int dev_alloc(size_t bytes, void **ptr) {
             return SYMGPU_OK;
         }
     }
+    ++g_counters[3];
     hipError_t e = hipMalloc(ptr, c);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -324,6 +334,10 @@ int symgpu_shutdown(void) {
     if (c.xs_pow) { (void)hipFree(c.xs_pow); c.xs_pow = nullptr; }
     if (c.rot_table) { (void)hipFree(c.rot_table); c.rot_table = nullptr; c.rot_table_cap = 0; c.rot_gen = 0; }
     if (c.rot_flags) { (void)hipFree(c.rot_flags); c.rot_flags = nullptr; }
+    if (c.rot_partner) { (void)hipFree(c.rot_partner); c.rot_partner = nullptr; c.rot_partner_cap = 0; }
+    if (c.sort_state) { (void)hipFree(c.sort_state); c.sort_state = nullptr; c.sort_bar_base = 0; }
+    if (c.res_table) { (void)hipFree(c.res_table); c.res_table = nullptr; c.res_table_cap = 0; }
+    if (c.res_state) { (void)hipFree(c.res_state); c.res_state = nullptr; c.res_epoch = 0; }
     if (c.rot_host_cnt) { (void)hipHostFree(c.rot_host_cnt); c.rot_host_cnt = nullptr; c.rot_host_cnt_dev = nullptr; }
     (void)hipEventDestroy(c.ev0);
     (void)hipEventDestroy(c.ev1);
@@ -421,8 +435,8 @@ int symgpu_prof_enable(int kernel_class, int on) {
 }
 
 int symgpu_debug_counter(int which, int64_t *value) {
-    SG_REQUIRE(value && which == 0, "debug_counter: 0 = row-hash reseeds");
-    *value = g_hash_reseeds;
+    SG_REQUIRE(value && which >= 0 && which <= 3, "debug_counter: 0 = row-hash reseeds, 1 = rotations done by the one-launch kernel, 2 = its failures (verification / time-out), 3 = device allocations that went to hipMalloc");
+    *value = which == 0 ? g_hash_reseeds : g_counters[which];
     return SYMGPU_OK;
 }
 

@@ -18,26 +18,15 @@
 // operator not known to be duplicate-free (symgpu_op_s::dup_free) is checked once with the same hash insert, and if
 // duplicates exist the rotated anticommuting part goes through cleanup before the commuting rows are appended.
 #include "common.h"
+#include "rotate_common.h"
 #include <stdlib.h>
 
 namespace symgpu {
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // flags[t] = 1 iff row t anticommutes with q;  ph[t] = phase exponent e of (row_t * q).
 // HASH: also the linear row hash h1 of cleanup.hip (same tables, same per-lane Horner) for the hash-join fast path.
 __device__ __forceinline__ u64 rot_rotl64(u64 x, int r) { r &= 63; return r ? ((x << r) | (x >> (64 - r))) : x; }
-
-// Generation-tagged entries of the persistent join table (Context::rot_table): [tag = hash >> 32 | generation : 10 | row + 1 : 22].
-struct JoinTable {
-    u64 *slots;
-    u32 mask;          // capacity - 1
-    u32 gen;           // 1 .. 1023
-    u32 *flags;        // [0] = gen when a duplicate input row was seen
-};
-__device__ __forceinline__ u64 mix64(u64 h) { h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 29; return h; }
-__device__ __forceinline__ u32 jt_gen(u64 v) { return (u32)(v >> 22) & 1023u; }
-__device__ __forceinline__ i64 jt_row(u64 v) { return (i64)(v & 0x3FFFFFULL) - 1; }
 
 // insert row t (hash h) — duplicates (same tag AND same words) raise the flag; one lane per row
 __device__ __forceinline__ void jt_insert(const JoinTable jt, const u64 *__restrict__ rows, int W, i64 t, u64 h) {
@@ -64,7 +53,6 @@ __device__ __forceinline__ void jt_insert(const JoinTable jt, const u64 *__restr
 // HASH: compute the row hashes (-> hout); otherwise INSERT reads them from hin.  INSERT: put every row into the join table.
 // QARG: the rotation's Pauli row Q arrives BY VALUE in the kernel arguments (rows of <= 64 words) instead of in `q_dev`, which
 // block 0 then fills for the kernels that follow on the stream — no host-to-device copy in front of the first kernel of a rotation.
-struct QArg { u64 w[64]; };
 template <bool HASH, bool INSERT, bool QARG = false>
 __global__ __launch_bounds__(256) void k_rot_analyze(const u64 *__restrict__ rows, i64 T, int Wq, int G, u64 *__restrict__ q_dev,
                                                       u32 *__restrict__ flags, uint8_t *__restrict__ ph, const u64 *__restrict__ tab_g,
@@ -147,22 +135,6 @@ __global__ __launch_bounds__(256) void k_rot_analyze(const u64 *__restrict__ row
 // half, loads are 1 KiB per wave instruction (k_rot_analyze reads 8 bytes per lane and walks six dependent chains per block at
 // 1e5 rows: 22 us; this: 9 us).  Lane exchange as in product.hip's row stream: x & z and (x ^ xq) & (z ^ zq) need the other half
 // of the row (DPP / ds_bpermute), x & zq and z & xq only the other half of Q, which every lane reads from LDS.
-template <int CTRL> __device__ __forceinline__ u32 rot_dpp(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
-template <int WQ> __device__ __forceinline__ u32 rot_other_half(u32 v) {
-    if (WQ == 2) return rot_dpp<0xB1>(v);
-    if (WQ == 4) return rot_dpp<0x4E>(v);
-    if (WQ == 16) return rot_dpp<0x128>(v);
-    return (u32)__shfl_xor((int)v, WQ / 2);
-}
-template <int WQ> __device__ __forceinline__ u32 rot_row_sum(u32 s) {          // over the WQ lanes of the row (butterfly)
-    if (WQ >= 2) s += rot_dpp<0xB1>(s);
-    if (WQ >= 4) s += rot_dpp<0x4E>(s);
-    if (WQ >= 8) s += rot_dpp<0x141>(s);
-    if (WQ >= 16) s += rot_dpp<0x140>(s);
-    if (WQ >= 32) s += (u32)__shfl_xor((int)s, 16);
-    if (WQ >= 64) s += (u32)__shfl_xor((int)s, 32);
-    return s;
-}
 template <int WQ, bool INSERT, bool QARG>
 __global__ __launch_bounds__(256) void k_rot_analyze_chunks(const u32x4 *__restrict__ rows, i64 T, u64 *__restrict__ q_dev, u32 *__restrict__ flags,
                                                              uint8_t *__restrict__ ph, const u64 *__restrict__ hin, JoinTable jt, QArg qa) {
@@ -229,15 +201,6 @@ __global__ void k_rot_keepflags(const u32 *__restrict__ anti, const double *__re
         u32 k = anti[t];
         if (k && drop_small && !(hypot(coeff[2 * t], coeff[2 * t + 1]) > thr)) k = 0;
         keep[t] = k;
-    }
-}
-
-__device__ __forceinline__ void phase_mul(double re, double im, int e, double &ore, double &oim) {
-    switch (e & 3) {
-        case 0: ore = re; oim = im; break;
-        case 1: ore = -im; oim = re; break;
-        case 2: ore = -re; oim = -im; break;
-        default: ore = im; oim = -re; break;
     }
 }
 
@@ -321,10 +284,9 @@ static int grid_for(i64 n, int block = 256, int cap = 8192) {
 // Output order and sums are those of the reference (base.py:1158-1161 + cleanup): kept commuting rows, kept
 // anticommuting rows with  cos*c_t + (-i sin) i^{e_p} c_p  (first-occurrence entry first), then the kept unmatched product
 // rows; strict |c| > thr everywhere.
-struct RotCounts { u32 nC, nA, nN, nAnti, dup; };          // dup: a duplicate input row was seen by this call's join-table insert
 
 // pinned, device-mapped host copy of the counts (one per context): written by k_rotf_scan3, read after the final synchronisation
-static int host_counts(RotCounts **host, RotCounts **dev) {
+int host_counts(RotCounts **host, RotCounts **dev) {
     Context &c = ctx();
     if (!c.rot_host_cnt) {
         HIP_TRY(hipHostMalloc(&c.rot_host_cnt, 64, hipHostMallocMapped));
@@ -598,7 +560,7 @@ static int rotate_fast_clifford(symgpu_op_t in, const u64 *q_dev, const u64 *q_h
 }
 
 // The persistent join table: at least 4 slots per row, a fresh generation per call (cleared when the 10-bit generation wraps).
-static int join_table_for(i64 T, JoinTable *jt) {
+int join_table_for(i64 T, JoinTable *jt) {
     Context &c = ctx();
     size_t cap = 1024;
     while ((i64)cap < 4 * T) cap <<= 1;
@@ -727,7 +689,7 @@ static int rotate_fast_nonclifford(symgpu_op_t in, u64 *q_dev, const u64 *q_host
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { symgpu_op_free(res); return hip_fail(e, "rotate fast path", __FILE__, __LINE__); }
     const RotCounts hc = *hcnt;
-    if (hc.nAnti == 0) { symgpu_op_free(res); *all_commute = 1; *done = 1; return SYMGPU_OK; }   // identity action (base.py:1131-1133)
+    if (hc.nAnti == 0) { symgpu_op_free(res); if (!hc.dup) in->dup_free = 1; *all_commute = 1; *done = 1; return SYMGPU_OK; }   // identity action (base.py:1131-1133)
     if (hc.dup) { symgpu_op_free(res); return SYMGPU_OK; }     // duplicates in the input: general path
     res->T = (i64)hc.nC + hc.nA + hc.nN;
     res->dup_free = 1;                 // the input had no duplicates (checked above) and every P^Q that met a row was merged into it
@@ -1098,6 +1060,14 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
     *all_commute = 1;
     if (T == 0) return SYMGPU_OK;
     SG_REQUIRE(T < ((i64)1 << 31), "rotate_single_dev: too many rows");
+    if (!getenv("SYMGPU_ROTATE_GENERAL")) {
+        // one persistent launch with the rows resident in LDS (rotate_resident.hip): duplicate-free operators that fit the chip's LDS
+        int done = 0;
+        SG_TRY(rotate_resident_try(in, q_row_host, cos_t, sin_t, clifford_k, thr, out, all_commute, &done));
+        if (done) return SYMGPU_OK;
+        *out = nullptr;
+        *all_commute = 1;
+    }
     Scratch q, anti, sel, apos, cpos, ph, totals, dmain, dprod;
     SG_TRY(q.alloc((size_t)W * 8));
     SG_TRY(anti.alloc((size_t)T * 4));
@@ -1225,6 +1195,12 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
     return SYMGPU_OK;
 }
 
+int symgpu_debug_rotation_trace(uint64_t *out, int max_workgroups, int *n_workgroups) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(out && n_workgroups && max_workgroups >= 0, "debug_rotation_trace");
+    return rotate_resident_trace(out, max_workgroups, n_workgroups);
+}
+
 int symgpu_rotate_single(const uint64_t *rows, const double *coeff, int64_t N, int Wq, const uint64_t *q_row, double cos_t, double sin_t,
                          int clifford_k, double thr, uint64_t *out_rows, double *out_coeff, int64_t capacity, int64_t *n_out,
                          int *all_commute) {
@@ -1299,6 +1275,10 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
                                ks.as<int>(), (int)K, which.as<int>());
             e = hipGetLastError();
             if (e == hipSuccess) e = hipMemcpyAsync(&in_b, which.p, 4, hipMemcpyDeviceToHost, st);
+        } else if (e == hipSuccess && clifford_chain_registers_applicable(T, Wq)) {
+            // the whole run with the rows in registers and ONE sort of the accumulated partition bits per 40 rotations (rotate_chain.hip)
+            rc = clifford_chain_registers(a, b, T, qs.as<u64>(), ks_host, K, &in_b);
+            if (rc != SYMGPU_OK) { symgpu_op_free(a); symgpu_op_free(b); return rc; }
         } else if (e == hipSuccess) {
             // large operator: the per-rotation kernels of the Clifford fast path, enqueued back to back — T is constant for a
             // clean operator (nothing is dropped: thr = -1), so no count has to come back to the host between the rotations

@@ -1,0 +1,749 @@
+// rotate_resident.hip — a single-Pauli rotation (reference: PauliwordOp._rotate_by_single_Pword, symmer/operators/base.py:1090-1161)
+// as ONE persistent launch.
+//
+// The multi-launch paths of rotate.hip (analyze | match | scan | write) are bound by their three kernel boundaries, by the second
+// pass over the rows and by the host round trips between them, not by bytes: 40 us of kernels for 8.5 us of traffic at 10^5 terms of
+// 1,000 qubits.  Here the operator is spread over the chip instead: one workgroup per CU, each owning a contiguous block of
+// ceil(T / G) rows that it reads from HBM ONCE into its LDS (256 CUs x <= 150 KiB = 38 MB of operator; BASELINE cfg2 is 25.6 MB),
+// and everything that the kernel boundaries used to order is ordered inside the launch by two all-gathers of 8-byte granules
+// {tag, counts} (cdna_hip_programming.md Guideline 16, form R2: the data is the flag, agent-scope relaxed stores and loads, no fence
+// because no plain-stored payload crosses workgroups):
+//
+//   A   rows -> LDS, with the flags and phase exponents of every row formed on the way in registers (one 16-byte chunk per lane, DPP
+//       lane exchange as in product.hip's row stream; rows that are not a power-of-two number of chunks: from LDS afterwards);
+//       non-Clifford: every anticommuting row enters the join table with ONE compare-and-swap under its CANONICAL key
+//       min(h, h ^ h(Q)) — a row P_k and the row P_k ^ Q it would merge with share that key, so whoever of the two comes second
+//       finds the other in the slot, notes it in LDS and tells the first through partner[] (agent-scope store).  Table and notes
+//       are all-zero between launches: every claimed slot and every note read is zeroed again by its owner after all-gather #1
+//   g1  all-gather #1: kept commuting rows per workgroup (and: every partner note is in place)
+//   B   final coefficients (cos c_t + (-i sin) i^e' c_partner, or the new row's (-i sin) i^e c_t), classes, ranks inside the block
+//   g2  all-gather #2: kept anticommuting / new rows per workgroup; the commuting rows are written while it is in flight
+//   C   rows (LDS -> HBM, 16 bytes per lane), coefficients and handed-on hashes to their final slots; counts to pinned host memory
+//
+// Output order, sums and thresholds are those of rotate.hip's hash-join path (commuting | cos * anticommuting (+ partner) | new rows,
+// strict |c| > thr; Clifford: rotated anticommuting | commuting), bit for bit — tests/test_gpu_parity.py runs both.
+// Exactness does not rest on the hash: the second row of every pair is compared with its partner chunk by chunk (row ^ Q against
+// the partner's row in HBM); a mismatch, a third row under one canonical key, or an all-gather that does not complete (workgroups
+// not co-resident) makes the call report failure and the caller takes the multi-launch path.
+// Preconditions (else *done = 0): the operator is known to be duplicate free (symgpu_op_s::dup_free), carries its row hashes
+// (non-Clifford), has rows of <= 64 words, and its block of rows fits the LDS.
+#include "common.h"
+#include "rotate_common.h"
+#include <stdlib.h>
+
+namespace symgpu {
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int RES_THREADS = 1024;
+constexpr int RES_MAX_WG = 256;                   // granules are swept by ONE wavefront, four per lane
+constexpr u32 RES_SPIN_LIMIT = 1u << 20;          // ~1 s of polling: the workgroups are not co-resident (another process on the GPU)
+constexpr size_t RES_LDS_MAX = 160 * 1024;
+constexpr int RES_MIN_ROWS = 64;                  // rows per workgroup below which more workgroups only lengthen the all-gathers
+constexpr int RES_LD_UNROLL = 8;                  // 16-byte loads in flight per lane (cfg2: 6,256 chunks per block = one round of 8,192)
+constexpr u32 RES_NO_SLOT = 0xFFFFFFFFu;
+constexpr int RES_PENDING = -2;                  // s_part: the row's first probe met an occupied slot; resolved after the loads
+
+struct ResLayout { int rows, coef, prod, hash, part, slot, pos, posn, info, cls, q, wtot, misc, total; };
+__host__ __device__ inline ResLayout res_layout(int R, int Wq) {
+    ResLayout L;
+    int o = 0;
+    L.rows = o; o += R * Wq * 16;
+    L.coef = o; o += R * 16;
+    L.prod = o; o += R * 16;
+    L.hash = o; o += R * 8;
+    L.part = o; o += R * 4;
+    L.slot = o; o += R * 4;
+    L.pos = o; o += R * 4;
+    L.posn = o; o += R * 4;
+    L.info = o; o += R;
+    L.cls = o; o += R;
+    o = (o + 15) & ~15;
+    L.q = o; o += 64 * 8;
+    L.wtot = o; o += 256 * 8;
+    L.misc = o; o += 32 * 4;
+    L.total = o;
+    return L;
+}
+
+struct ResArgs {
+    const u32x4 *rows; const double *coeff; const u64 *hin;
+    i64 T; int Wq, R, GA; u32 yq;
+    u32x4 *out_rows; double *out_coeff; u64 *out_hash;
+    double cos_t, sin_t, thr; int k;
+    u64 hq;
+    u64 *slots; u32 mask; u32 *partner;           // join table [canonical-key tag 32 | row + 1 : 32] and partner notes (row + 1), zero between launches
+    u64 *gran1, *gran2; u32 *fail;                // fail[0] / fail[1] = epoch of a failed verification / of a time-out
+    u32 *finished; u32 finish_target;             // fail[2]: workgroups that have left, counted over all launches; the one that reaches the target reports
+    u32 epoch;
+    u64 *trace;                                   // [G][16] wall-clock stamps of the phases (SYMGPU_RES_TRACE=1), else null
+    int inject;                                   // tests: the last workgroup leaves at once without a word (SYMGPU_RES_INJECT=1)
+    RotCounts *host_cnt;
+    QArg q;
+};
+
+enum { M_OK = 1, M_FAIL = 2, M_NC = 3, M_NA = 4, M_NN = 5, M_NANTI = 6, M_PREF_C = 8, M_TOT_C = 9, M_PREF_A = 10, M_TOT_A = 11, M_PREF_N = 12,
+       M_TOT_N = 13, M_TOT_ANTI = 14 };
+
+__device__ __forceinline__ u64 ag_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ag_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u32 ag_load32(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ag_store32(u32 *p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One wavefront re-reads all G granules until every tag is `tag`; on success the three 16-bit count fields are summed over the
+// workgroups before `w` (pref) and over all of them (tot).  Returns false after RES_SPIN_LIMIT sweeps.
+__device__ __forceinline__ bool ag_sweep(const u64 *gran, int G, u32 tag, int w, int lane, u32 (&pref)[3], u32 (&tot)[3]) {
+    u64 v[4];
+    for (u32 spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = lane + 64 * j;
+            v[j] = idx < G ? ag_load(gran + idx) : ((u64)tag << 48);
+            ok &= (u32)(v[j] >> 48) == tag;
+        }
+        if (__ballot(ok) == ~0ULL) break;
+        if (spins >= RES_SPIN_LIMIT) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+#pragma unroll
+    for (int f = 0; f < 3; ++f) { pref[f] = 0; tot[f] = 0; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = lane + 64 * j;
+        if (idx < G) {
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const u32 x = (u32)(v[j] >> (16 * f)) & 0xFFFFu;
+                tot[f] += x;
+                if (idx < w) pref[f] += x;
+            }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 3; ++f)
+        for (int off = 32; off > 0; off >>= 1) { pref[f] += (u32)__shfl_xor((int)pref[f], off); tot[f] += (u32)__shfl_xor((int)tot[f], off); }
+    return true;
+}
+
+// A workgroup leaves (done or timed out): the LAST one to leave — it sees every failure word written before the others' arrivals —
+// writes the counts and the status to pinned host memory.
+__device__ __forceinline__ void res_leave(const ResArgs &a, u32 totC, u32 totA, u32 totN, u32 totAnti) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const u32 prev = atomicAdd(a.finished, 1u);
+    if (prev + 1u == a.finish_target) {
+        u32 code = 0;
+        if (ag_load32(&a.fail[0]) == a.epoch) code = 2;
+        if (ag_load32(&a.fail[1]) == a.epoch) code = 3;
+        a.host_cnt->nC = totC; a.host_cnt->nA = totA; a.host_cnt->nN = totN; a.host_cnt->nAnti = totAnti;
+        // the status word goes last, system scope: the host polls it in pinned memory instead of synchronising the stream
+        __hip_atomic_store(&a.host_cnt->dup, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+#define RES_STAMP(i) do { if (a.trace && tid == 0) a.trace[(size_t)w * 16 + (i)] = wall_clock64(); } while (0)
+
+// |c| > thr as NumPy's abs(complex) decides it (hypot), without the hypot for every coefficient that has a component above thr
+__device__ __forceinline__ bool res_keep(double re, double im, double thr) {
+    return (fabs(re) > thr || fabs(im) > thr) ? true : hypot(re, im) > thr;
+}
+
+// flag and the two phase exponents of a row from its counts (rotate.hip: k_rot_analyze): bit 0 = anticommutes with Q, bits 1-2 = the
+// exponent e of P * Q, bits 3-4 = the exponent e' of (P ^ Q) * Q, i.e. the e of the row's partner
+__device__ __forceinline__ uint8_t res_info(u32 anti, u32 fp, u32 yp, u32 yout, u32 yq) {
+    const u32 e = (3u * (yp + yq) + yout + 2u * fp) & 3u;
+    const u32 ep = (3u * (yout + yq) + yp + 2u * (fp ^ (yq & 1u))) & 3u;
+    return (uint8_t)((anti & 1u) | (e << 1) | (ep << 3));
+}
+
+// MODE 0: non-Clifford (hash join); MODE 1: Clifford (k = clifford_k of rotation_args, 0..3)
+// WQ: 16-byte chunks per row if that is a power of two <= 64 (analysis in registers while the rows stream in), else 0 (from LDS)
+template <int MODE, int WQ>
+__global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ResLayout L = res_layout(a.R, a.Wq);
+    u32x4 *s_rows = reinterpret_cast<u32x4 *>(smem + L.rows);
+    f64x2 *s_coef = reinterpret_cast<f64x2 *>(smem + L.coef);
+    f64x2 *s_prod = reinterpret_cast<f64x2 *>(smem + L.prod);
+    u64 *s_hash = reinterpret_cast<u64 *>(smem + L.hash);
+    int *s_part = reinterpret_cast<int *>(smem + L.part);
+    u32 *s_slot = reinterpret_cast<u32 *>(smem + L.slot);
+    u32 *s_pos = reinterpret_cast<u32 *>(smem + L.pos);
+    u32 *s_posn = reinterpret_cast<u32 *>(smem + L.posn);
+    uint8_t *s_info = smem + L.info;
+    uint8_t *s_cls = smem + L.cls;
+    u64 *s_q = reinterpret_cast<u64 *>(smem + L.q);
+    u64 *s_wtot = reinterpret_cast<u64 *>(smem + L.wtot);
+    u32 *s_misc = reinterpret_cast<u32 *>(smem + L.misc);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Wq = WQ > 0 ? WQ : a.Wq, W = 2 * Wq;
+    const int G = gridDim.x, w = blockIdx.x;
+    if (a.inject && w == G - 1) return;
+    RES_STAMP(0);
+    const i64 row0 = (i64)w * a.R;
+    const int Rw = (int)(a.T - row0 < (i64)a.R ? a.T - row0 : (i64)a.R);
+    const int nchunk = Rw * Wq;
+    const u32 tag1 = 2 * a.epoch, tag2 = 2 * a.epoch + 1;
+    const f64x2 *coeff2 = reinterpret_cast<const f64x2 *>(a.coeff);
+    const u32 yq = a.yq;
+
+    if (tid < W) s_q[tid] = a.q.w[tid];
+    if (tid < 32) s_misc[tid] = 0;
+    __syncthreads();
+    const u32x4 *sq4 = reinterpret_cast<const u32x4 *>(s_q);
+    // ---- A1: the block's rows, coefficients and hashes: HBM -> LDS, read once; flags and phase exponents on the way ------------
+    {
+        const u32x4 *src = a.rows + row0 * Wq;
+        for (int i0 = 0; i0 < nchunk; i0 += RES_LD_UNROLL * RES_THREADS) {
+            u32x4 v[RES_LD_UNROLL];
+#pragma unroll
+            for (int j = 0; j < RES_LD_UNROLL; ++j) {
+                const int i = i0 + j * RES_THREADS + tid;
+                v[j] = i < nchunk ? __builtin_nontemporal_load(src + i) : (u32x4)(0u);
+            }
+            if (i0 == 0)
+                for (int r = tid; r < Rw; r += RES_THREADS) {
+                    s_coef[r] = coeff2[row0 + r];
+                    s_hash[r] = a.hin ? a.hin[row0 + r] : 0ULL;
+                }
+            u64 hrow[RES_LD_UNROLL], casold[RES_LD_UNROLL];
+            u32 caspos[RES_LD_UNROLL];
+            if constexpr (WQ > 0) {
+                // a row is an aligned group of WQ lanes (RES_THREADS is a multiple of WQ): X words in its lower, Z words in its upper half
+                const int c = tid & (WQ - 1);
+                // non-Clifford: the chunk-0 lane of an anticommuting row issues the row's compare-and-swap on the join table as soon as
+                // the flag is known; the answers (~2 us each) come back while the remaining chunks are analysed and stored
+                if (MODE == 0) {
+#pragma unroll
+                    for (int j = 0; j < RES_LD_UNROLL; ++j) {
+                        const int i = i0 + j * RES_THREADS + tid;
+                        hrow[j] = (c == 0 && i < nchunk) ? a.hin[row0 + i / WQ] : 0ULL;
+                        casold[j] = 0; caspos[j] = RES_NO_SLOT;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < RES_LD_UNROLL; ++j) {
+                    const int i = i0 + j * RES_THREADS + tid;
+                    const u32x4 x = v[j];
+                    u32 par, ye;                                               // par: |x & zq| + |z & xq| (+ |x & zq| << 16);  ye: Y_P | Y_out << 16
+                    if constexpr (WQ == 1) {
+                        const u32x4 qv = sq4[0];
+                        const u32 f = __popc(x.x & qv.z) + __popc(x.y & qv.w);
+                        par = f + __popc(x.z & qv.x) + __popc(x.w & qv.y) + (f << 16);
+                        ye = (__popc(x.x & x.z) + __popc(x.y & x.w)) | ((__popc((x.x ^ qv.x) & (x.z ^ qv.z)) + __popc((x.y ^ qv.y) & (x.w ^ qv.w))) << 16);
+                    } else {
+                        const u32x4 qs = sq4[c], qo = sq4[c ^ (WQ / 2)];
+                        const bool xhalf = c < WQ / 2;
+                        const u32 p = __popc(x.x & qo.x) + __popc(x.y & qo.y) + __popc(x.z & qo.z) + __popc(x.w & qo.w);
+                        const u32x4 o = {rot_other_half<WQ>(x.x), rot_other_half<WQ>(x.y), rot_other_half<WQ>(x.z), rot_other_half<WQ>(x.w)};
+                        const u32 yp = __popc(x.x & o.x) + __popc(x.y & o.y) + __popc(x.z & o.z) + __popc(x.w & o.w);
+                        const u32 yo = __popc((x.x ^ qs.x) & (o.x ^ qo.x)) + __popc((x.y ^ qs.y) & (o.y ^ qo.y)) + __popc((x.z ^ qs.z) & (o.z ^ qo.z)) +
+                                       __popc((x.w ^ qs.w) & (o.w ^ qo.w));
+                        par = rot_row_sum<WQ>(p + (xhalf ? (p << 16) : 0u));
+                        ye = rot_row_sum<WQ>(xhalf ? (yp | (yo << 16)) : 0u);
+                    }
+                    if (c == 0 && i < nchunk) {
+                        s_info[i / WQ] = res_info(par & 1u, (par >> 16) & 1u, ye & 0xFFFFu, ye >> 16, yq);
+                        if (MODE == 0 && (par & 1u)) {
+                            const u64 h = hrow[j], hp = h ^ a.hq, ck = h < hp ? h : hp;
+                            caspos[j] = (u32)mix64(ck) & a.mask;
+                            casold[j] = atomicCAS(reinterpret_cast<unsigned long long *>(&a.slots[caspos[j]]), 0ULL,
+                                                  (unsigned long long)((ck & 0xFFFFFFFF00000000ULL) | (u64)(row0 + i / WQ + 1)));
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RES_LD_UNROLL; ++j) { const int i = i0 + j * RES_THREADS + tid; if (i < nchunk) s_rows[i] = v[j]; }
+            if constexpr (WQ > 0 && MODE == 0) {
+                // What the first probes found (only now: the empty statement keeps the compiler from testing each answer right behind
+                // its compare-and-swap, which would serialise the eight round trips): 0 = the slot is this row's; an occupant is
+                // left in s_prod for A3, which continues the walk from there.
+                asm volatile("" : "+v"(casold[0]), "+v"(casold[1]), "+v"(casold[2]), "+v"(casold[3]), "+v"(casold[4]), "+v"(casold[5]), "+v"(casold[6]), "+v"(casold[7]));
+                static_assert(RES_LD_UNROLL == 8, "the statement above names eight answers");
+                const int c = tid & (WQ - 1);
+#pragma unroll
+                for (int j = 0; j < RES_LD_UNROLL; ++j) {
+                    const int i = i0 + j * RES_THREADS + tid;
+                    if (c == 0 && i < nchunk) {
+                        const bool pending = caspos[j] != RES_NO_SLOT && casold[j] != 0;
+                        s_slot[i / WQ] = caspos[j];                             // RES_NO_SLOT for a commuting row; for a pending row: where it stands
+                        s_part[i / WQ] = pending ? RES_PENDING : -1;
+                        if (pending) reinterpret_cast<u64 *>(s_prod)[2 * (i / WQ)] = casold[j];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if constexpr (WQ == 0) {
+        // ---- A2: flags and phase exponents from LDS, GA lanes per row (row lengths that are not a power-of-two number of chunks) ---
+        const int GA = a.GA, g = tid & (GA - 1), rsub = tid / GA, rpp = RES_THREADS / GA;
+        const u64 *rows64 = reinterpret_cast<const u64 *>(s_rows);
+        for (int r0 = 0; r0 < Rw; r0 += rpp) {
+            const int r = r0 + rsub;
+            u32 pf = 0, yy = 0;                     // pf: parity of |x & zq| + |z & xq| (bit 0) and of |x & zq| (bit 1); yy: Y_P | Y_out << 16
+            if (r < Rw) {
+                const u64 *row = rows64 + (size_t)r * W;
+                u64 par = 0, flip = 0;
+                for (int ww = g; ww < Wq; ww += GA) {
+                    const u64 x = row[ww], z = row[Wq + ww], xq = s_q[ww], zq = s_q[Wq + ww];
+                    par ^= (x & zq) ^ (z & xq);
+                    flip ^= x & zq;
+                    yy += (u32)__popcll(x & z) + ((u32)__popcll((x ^ xq) & (z ^ zq)) << 16);
+                }
+                pf = ((u32)__popcll(par) & 1u) | (((u32)__popcll(flip) & 1u) << 1);
+            }
+            for (int off = GA >> 1; off > 0; off >>= 1) { pf ^= (u32)__shfl_xor((int)pf, off); yy += (u32)__shfl_xor((int)yy, off); }
+            if (g == 0 && r < Rw) s_info[r] = res_info(pf & 1u, (pf >> 1) & 1u, yy & 0xFFFFu, yy >> 16, yq);
+        }
+        __syncthreads();
+    }
+    RES_STAMP(1);
+
+    u32 prefC = 0, totC = 0;
+    if (MODE == 0) {
+        // ---- A3: commuting rows are classified; every anticommuting row meets its partner, if it has one, in the join table ----
+        u32 nC = 0;
+        bool bad = false;
+        for (int r = tid; r < Rw; r += RES_THREADS) {
+            const uint8_t info = s_info[r];
+            int part = -1;
+            u32 slot = RES_NO_SLOT;
+            uint8_t cls = 0;
+            if (!(info & 1)) {
+                const f64x2 c = s_coef[r];
+                if (res_keep(c.x, c.y, a.thr)) { cls = 1; ++nC; }
+            } else if (WQ > 0 && s_part[r] != RES_PENDING) {
+                slot = s_slot[r];                                              // claimed by the probe issued from the load loop
+            } else {
+                // generic row lengths: the whole walk; otherwise: the first probe met the occupant left in s_prod — the walk goes on there
+                const i64 t = row0 + r;
+                const u64 h = s_hash[r], hp = h ^ a.hq, ck = h < hp ? h : hp;
+                const u64 entry = (ck & 0xFFFFFFFF00000000ULL) | (u64)(t + 1);
+                u32 pos = WQ > 0 ? s_slot[r] : (u32)mix64(ck) & a.mask;
+                bool have_old = WQ > 0;
+                for (;;) {
+                    const u64 old = have_old ? reinterpret_cast<const u64 *>(s_prod)[2 * r]
+                                             : atomicCAS(reinterpret_cast<unsigned long long *>(&a.slots[pos]), 0ULL, (unsigned long long)entry);
+                    have_old = false;
+                    if (old == 0) { slot = pos; break; }                       // first of its key: a partner, if any, will leave a note
+                    if ((old >> 32) == (ck >> 32)) {
+                        const i64 o = (i64)(old & 0xFFFFFFFFULL) - 1;
+                        const u64 ho = a.hin[o];
+                        if (ho == hp) {                                        // the row this one merges with (verified below)
+                            part = (int)o;
+                            ag_store32(&a.partner[o], (u32)(t + 1));
+                            break;
+                        }
+                        if (ho == h) { bad = true; break; }                    // two rows with one hash: not for this path
+                    }
+                    pos = (pos + 1) & a.mask;
+                }
+            }
+            s_part[r] = part;
+            s_slot[r] = slot;
+            s_cls[r] = cls;
+        }
+        for (int off = 32; off > 0; off >>= 1) nC += (u32)__shfl_xor((int)nC, off);
+        if (lane == 0 && nC) atomicAdd(&s_misc[M_NC], nC);
+        if (bad) s_misc[M_FAIL] = 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // every partner note has left this wavefront
+        __syncthreads();
+        if (tid == 0) ag_store(&a.gran1[w], ((u64)tag1 << 48) | s_misc[M_NC]);
+        RES_STAMP(2);
+        // verification of the pairs found from THIS block (while the all-gather is in flight): row ^ Q against the partner's row
+        {
+            int r = tid / Wq, c = tid - r * Wq;
+            const int dr = RES_THREADS / Wq, dc = RES_THREADS - dr * Wq;
+            bool mism = false;
+            for (int i = tid; i < nchunk; i += RES_THREADS) {
+                const int p = s_part[r];
+                if (p >= 0) {
+                    const u32x4 mine = s_rows[i] ^ sq4[c], theirs = a.rows[(i64)p * Wq + c];
+                    mism |= (mine.x != theirs.x) | (mine.y != theirs.y) | (mine.z != theirs.z) | (mine.w != theirs.w);
+                }
+                r += dr; c += dc;
+                if (c >= Wq) { c -= Wq; ++r; }
+            }
+            if (mism) s_misc[M_FAIL] = 1;
+        }
+        // ---- g1 ----------------------------------------------------------------------------------------------------------------
+        if (wave == 0) {
+            u32 pref[3], tot[3];
+            const bool ok = ag_sweep(a.gran1, G, tag1, w, lane, pref, tot);
+            if (lane == 0) { s_misc[M_OK] = ok ? 1u : 0u; s_misc[M_PREF_C] = pref[0]; s_misc[M_TOT_C] = tot[0]; }
+        }
+        __syncthreads();
+        RES_STAMP(3);
+        if (s_misc[M_FAIL] && tid == 0) ag_store32(&a.fail[0], a.epoch);
+        if (!s_misc[M_OK]) {                                                   // time-out: release the others and leave
+            if (tid == 0) {
+                ag_store32(&a.fail[1], a.epoch);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ag_store(&a.gran2[w], (u64)tag2 << 48);
+                res_leave(a, 0, 0, 0, 1);
+            }
+            return;
+        }
+        prefC = s_misc[M_PREF_C]; totC = s_misc[M_TOT_C];
+        // ---- B: final coefficients and classes of the anticommuting rows; their slots and notes go back to zero ---------------
+        for (int r = tid; r < Rw; r += RES_THREADS) {
+            const uint8_t info = s_info[r];
+            if (!(info & 1)) continue;
+            int part = s_part[r];
+            const u32 slot = s_slot[r];
+            if (slot != RES_NO_SLOT) {
+                const u32 pv = ag_load32(&a.partner[row0 + r]);
+                if (pv) { part = (int)pv - 1; ag_store32(&a.partner[row0 + r], 0u); }
+                ag_store(&a.slots[slot], 0ULL);
+            }
+            const f64x2 c = s_coef[r];
+            double sr = __dmul_rn(c.x, a.cos_t), si = __dmul_rn(c.y, a.cos_t);
+            uint8_t cls = 0;
+            double pr, pi;
+            if (part >= 0) {                                                   // (0 + cos c_t) + (-i sin) i^{e'} c_p, in that order
+                const f64x2 cp = coeff2[part];
+                phase_mul(cp.x, cp.y, (info >> 3) & 3, pr, pi);
+                sr = __dadd_rn(sr, __dmul_rn(pi, a.sin_t));
+                si = __dadd_rn(si, -__dmul_rn(pr, a.sin_t));
+            } else {                                                           // its product row is new
+                phase_mul(c.x, c.y, (info >> 1) & 3, pr, pi);
+                const double nr = __dmul_rn(pi, a.sin_t), ni = -__dmul_rn(pr, a.sin_t);
+                s_prod[r] = f64x2{nr, ni};
+                if (res_keep(nr, ni, a.thr)) cls |= 4;
+            }
+            s_coef[r] = f64x2{sr, si};
+            if (res_keep(sr, si, a.thr)) cls |= 2;
+            s_cls[r] = cls;
+        }
+    } else {
+        // ---- Clifford: class and rotated coefficient per row (k_rotc_classify of rotate.hip) -----------------------------------
+        const int k = a.k;
+        for (int r = tid; r < Rw; r += RES_THREADS) {
+            const uint8_t info = s_info[r];
+            uint8_t cls = 0;
+            if (!(info & 1)) {
+                cls = 1;
+            } else {
+                const f64x2 c = s_coef[r];
+                if (k & 1) {
+                    if (res_keep(c.x, c.y, a.thr)) {
+                        double x, y;
+                        phase_mul(c.x, c.y, (info >> 1) & 3, x, y);
+                        double pr = y, pi = -x;                                // c * i^e * (-i)
+                        if (k == 3) { pr = -pr; pi = -pi; }
+                        s_coef[r] = f64x2{pr, pi};
+                        cls = 4;
+                    }
+                } else {
+                    if (k == 2) s_coef[r] = f64x2{-c.x, -c.y};
+                    cls = 2;
+                }
+            }
+            s_cls[r] = cls;
+        }
+    }
+    __syncthreads();
+    RES_STAMP(4);
+    // ---- ranks of the rows inside the block: ballots per pass of 1,024 rows give the rank inside the wavefront and the counts per
+    //      (pass, wavefront); wavefront 0 adds them up and publishes the block's granule at once (the all-gather is in flight while
+    //      everybody turns the ranks into block-wide ones)
+    {
+        const int K = (Rw + RES_THREADS - 1) / RES_THREADS;                    // <= 16
+        const u64 lt = (1ULL << lane) - 1ULL;
+        for (int j = 0; j < K; ++j) {
+            const int r = j * RES_THREADS + tid;
+            const uint8_t cl = r < Rw ? s_cls[r] : 0;
+            const bool an = r < Rw && (s_info[r] & 1);
+            const u64 b0 = __ballot(cl & 1), b1 = __ballot(cl & 2), b2 = __ballot(cl & 4), b3 = __ballot(an);
+            if (r < Rw) {
+                s_pos[r] = (u32)__popcll(((cl & 1) ? b0 : b1) & lt);
+                s_posn[r] = (u32)__popcll(b2 & lt);
+            }
+            if (lane == 0) s_wtot[j * 16 + wave] = (u64)__popcll(b0) | ((u64)__popcll(b1) << 16) | ((u64)__popcll(b2) << 32) | ((u64)__popcll(b3) << 48);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int ne = K * 16;                                             // <= 256 entries, four per lane
+            u64 sum = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int e = lane + 64 * i; if (e < ne) sum += s_wtot[e]; }
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+            if (lane == 0) {
+                const u64 nC = sum & 0xFFFFu, nA = (sum >> 16) & 0xFFFFu, nN = (sum >> 32) & 0xFFFFu, nAnti = (sum >> 48) & 0xFFFFu;
+                // Clifford: ONE all-gather carries {rotated rows (class 2 or 4: only one of them occurs per k), commuting rows, all anticommuting}
+                if (MODE == 1) ag_store(&a.gran2[w], ((u64)tag2 << 48) | (nA + nN) | (nC << 16) | (nAnti << 32));
+                else ag_store(&a.gran2[w], ((u64)tag2 << 48) | nA | (nN << 16) | (nAnti << 32));
+            }
+        }
+        for (int j = 0; j < K; ++j) {
+            const int r = j * RES_THREADS + tid;
+            u64 base = 0;
+            for (int e = 0; e < j * 16 + wave; ++e) base += s_wtot[e];
+            if (r < Rw) {
+                s_pos[r] += (s_cls[r] & 1) ? (u32)base & 0xFFFFu : (u32)(base >> 16) & 0xFFFFu;
+                s_posn[r] += (u32)(base >> 32) & 0xFFFFu;
+            }
+        }
+    }
+    __syncthreads();
+    f64x2 *out_coeff2 = reinterpret_cast<f64x2 *>(a.out_coeff);
+    if (MODE == 0) {
+        // ---- C1: the commuting rows go out while the second all-gather is in flight -------------------------------------------
+        int r = tid / Wq, c = tid - r * Wq;
+        const int dr = RES_THREADS / Wq, dc = RES_THREADS - dr * Wq;
+        for (int i = tid; i < nchunk; i += RES_THREADS) {
+            if (s_cls[r] & 1) __builtin_nontemporal_store(s_rows[i], &a.out_rows[(i64)(prefC + s_pos[r]) * Wq + c]);
+            r += dr; c += dc;
+            if (c >= Wq) { c -= Wq; ++r; }
+        }
+        for (int r2 = tid; r2 < Rw; r2 += RES_THREADS)
+            if (s_cls[r2] & 1) {
+                const i64 d = (i64)prefC + s_pos[r2];
+                out_coeff2[d] = s_coef[r2];
+                if (a.out_hash) a.out_hash[d] = s_hash[r2];
+            }
+    }
+    RES_STAMP(5);
+    // ---- g2 ------------------------------------------------------------------------------------------------------------------------
+    if (wave == 0) {
+        u32 pref[3], tot[3];
+        const bool ok = ag_sweep(a.gran2, G, tag2, w, lane, pref, tot);
+        if (lane == 0) {
+            s_misc[M_OK] = ok ? 1u : 0u;
+            if (MODE == 1) {      // rotated rows first (filed under A or N, whichever this k produces), then the commuting ones
+                s_misc[M_PREF_A] = pref[0]; s_misc[M_TOT_A] = (a.k & 1) ? 0 : tot[0]; s_misc[M_PREF_N] = pref[0]; s_misc[M_TOT_N] = (a.k & 1) ? tot[0] : 0;
+                s_misc[M_PREF_C] = pref[1]; s_misc[M_TOT_C] = tot[1];
+            } else {
+                s_misc[M_PREF_A] = pref[0]; s_misc[M_TOT_A] = tot[0]; s_misc[M_PREF_N] = pref[1]; s_misc[M_TOT_N] = tot[1];
+            }
+            s_misc[M_TOT_ANTI] = tot[2];
+        }
+    }
+    __syncthreads();
+    RES_STAMP(6);
+    if (!s_misc[M_OK]) {
+        if (tid == 0) {
+            ag_store32(&a.fail[1], a.epoch);
+            res_leave(a, 0, 0, 0, 1);
+        }
+        return;
+    }
+    if (MODE == 1) { prefC = s_misc[M_PREF_C]; totC = s_misc[M_TOT_C]; }
+    const u32 prefA = s_misc[M_PREF_A], totA = s_misc[M_TOT_A], prefN = s_misc[M_PREF_N], totN = s_misc[M_TOT_N];
+    // output order: non-Clifford [commuting | cos * anticommuting | new rows]; Clifford [rotated anticommuting | commuting]
+    const i64 baseC = (MODE == 1 ? (i64)totA + totN : 0) + prefC;
+    const i64 baseA = (MODE == 1 ? 0 : (i64)totC) + prefA;
+    const i64 baseN = (MODE == 1 ? 0 : (i64)totC + totA) + prefN;
+    // ---- C2: the remaining rows, coefficients and hashes ----------------------------------------------------------------------
+    {
+        int r = tid / Wq, c = tid - r * Wq;
+        const int dr = RES_THREADS / Wq, dc = RES_THREADS - dr * Wq;
+        for (int i = tid; i < nchunk; i += RES_THREADS) {
+            const uint8_t cl = s_cls[r];
+            if (MODE == 1 && (cl & 1)) __builtin_nontemporal_store(s_rows[i], &a.out_rows[(baseC + s_pos[r]) * Wq + c]);
+            if (cl & 2) __builtin_nontemporal_store(s_rows[i], &a.out_rows[(baseA + s_pos[r]) * Wq + c]);
+            if (cl & 4) __builtin_nontemporal_store(s_rows[i] ^ sq4[c], &a.out_rows[(baseN + s_posn[r]) * Wq + c]);
+            r += dr; c += dc;
+            if (c >= Wq) { c -= Wq; ++r; }
+        }
+        for (int r2 = tid; r2 < Rw; r2 += RES_THREADS) {
+            const uint8_t cl = s_cls[r2];
+            if (MODE == 1 && (cl & 1)) {
+                const i64 d = baseC + s_pos[r2];
+                out_coeff2[d] = s_coef[r2];
+                if (a.out_hash) a.out_hash[d] = s_hash[r2];
+            }
+            if (cl & 2) {
+                const i64 d = baseA + s_pos[r2];
+                out_coeff2[d] = s_coef[r2];
+                if (a.out_hash) a.out_hash[d] = s_hash[r2];
+            }
+            if (cl & 4) {
+                const i64 d = baseN + s_posn[r2];
+                out_coeff2[d] = MODE == 0 ? s_prod[r2] : s_coef[r2];
+                if (a.out_hash) a.out_hash[d] = s_hash[r2] ^ a.hq;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // every wavefront's rows have left ...
+    __syncthreads();
+    RES_STAMP(7);
+    if (tid == 0) res_leave(a, totC, totA, totN, s_misc[M_TOT_ANTI]);              // ... before the block counts as gone
+}
+
+typedef void (*ResKernel)(const ResArgs);
+static ResKernel res_kernel(bool clifford, int Wq) {
+#define RES_PICK(M) \
+    switch (Wq) { case 1: return k_rot_resident<M, 1>; case 2: return k_rot_resident<M, 2>; case 4: return k_rot_resident<M, 4>; case 8: return k_rot_resident<M, 8>; \
+                  case 16: return k_rot_resident<M, 16>; case 32: return k_rot_resident<M, 32>; default: return k_rot_resident<M, 0>; }
+    if (clifford) { RES_PICK(1) } else { RES_PICK(0) }
+#undef RES_PICK
+}
+
+static u64 *g_res_trace = nullptr;
+static int g_res_trace_wgs = 0;
+
+int rotate_resident_trace(u64 *out, int max_wgs, int *n_wgs) {
+    if (!g_res_trace) { *n_wgs = 0; return SYMGPU_OK; }
+    const int n = g_res_trace_wgs < max_wgs ? g_res_trace_wgs : max_wgs;
+    HIP_TRY(hipStreamSynchronize(ctx().stream));
+    HIP_TRY(hipMemcpy(out, g_res_trace, (size_t)n * 16 * 8, hipMemcpyDeviceToHost));
+    *n_wgs = n;
+    return SYMGPU_OK;
+}
+
+int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double sin_t, int clifford_k, double thr, symgpu_op_t *out,
+                        int *all_commute, int *done) {
+    *done = 0;
+    Context &c = ctx();
+    if (const char *e = getenv("SYMGPU_ROT_RESIDENT")) {                          // read on every call: 0 = off, 2 = on again after a failure
+        if (e[0] == '0') return SYMGPU_OK;
+        if (e[0] == '2') c.res_disabled = false;
+    }
+    if (c.res_disabled) return SYMGPU_OK;
+    const i64 T = in->T;
+    const int Wq = in->Wq, W = 2 * Wq;
+    if (T < 1 || W > 64 || T >= ((i64)1 << 22) - 1) return SYMGPU_OK;
+    const bool clifford = clifford_k >= 0;
+    if ((!clifford || (clifford_k & 1)) && !in->dup_free) return SYMGPU_OK;      // merges possible: the multi-launch paths check / handle them
+    bool have_hash = in->hash && c.hash_tab && in->hash_seed == c.hash_seed;
+    // geometry: at most one workgroup per CU, at least RES_MIN_ROWS rows each
+    i64 G = (T + RES_MIN_ROWS - 1) / RES_MIN_ROWS;
+    const i64 gmax = c.num_cu < RES_MAX_WG ? c.num_cu : RES_MAX_WG;
+    if (G > gmax) G = gmax;
+    const i64 R = (T + G - 1) / G;
+    G = (T + R - 1) / R;
+    if (R > 16384) return SYMGPU_OK;
+    const ResLayout L = res_layout((int)R, Wq);
+    if ((size_t)L.total > RES_LDS_MAX) return SYMGPU_OK;
+    static const bool attr_ok = [] {
+        for (int m = 0; m < 2; ++m)
+            for (int wq : {1, 2, 4, 8, 16, 32, 3})
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(res_kernel(m == 1, wq)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS_MAX) != hipSuccess) return false;
+        return true;
+    }();
+    if (!attr_ok) { (void)hipGetLastError(); c.res_disabled = true; return SYMGPU_OK; }
+    hipStream_t st = c.stream;
+    if (!clifford && !have_hash) {
+        // a duplicate-free operator without cached hashes (straight from a cleanup): hash its rows once, on the handle
+        SG_TRY(ensure_hash_tables(c.hash_tab ? c.hash_seed : 1));
+        if (in->hash) { dev_free(in->hash); in->hash = nullptr; }
+        SG_TRY(dev_alloc((size_t)in->capacity * 8 + 16, (void **)&in->hash));
+        in->hash_seed = c.hash_seed;
+        SG_TRY(hash_rows(in->rows, T, W, in->hash));
+        have_hash = true;
+    }
+    constexpr size_t state_words = 2 * RES_MAX_WG + 2;                            // granules, {fail[0], fail[1]}, {finished, -}
+    static u32 finished_base = 0;
+    if (!c.res_state) {
+        HIP_TRY(hipMalloc((void **)&c.res_state, state_words * 8));
+        c.res_epoch = 0;
+    }
+    if (c.res_epoch == 0 || c.res_epoch >= 16382) {                               // fresh state, or the 16-bit granule tag wraps
+        HIP_TRY(hipMemsetAsync(c.res_state, 0, state_words * 8, st));
+        c.res_epoch = 0;
+        finished_base = 0;
+    }
+    ++c.res_epoch;
+    ResArgs a;
+    a.rows = reinterpret_cast<const u32x4 *>(in->rows); a.coeff = in->coeff; a.hin = have_hash ? in->hash : nullptr;
+    a.T = T; a.Wq = Wq; a.R = (int)R;
+    int GA = 1;
+    while (GA < Wq && GA < 64) GA <<= 1;
+    a.GA = GA;
+    a.yq = 0;
+    for (int ww = 0; ww < Wq; ++ww) a.yq += (u32)__builtin_popcountll(q_host[ww] & q_host[Wq + ww]);
+    a.cos_t = cos_t; a.sin_t = sin_t; a.thr = thr; a.k = clifford_k;
+    a.hq = have_hash ? host_row_hash(q_host, W) : 0;
+    a.slots = nullptr; a.mask = 0; a.partner = nullptr;
+    if (!clifford) {
+        // join table (>= 4 slots per row) and partner notes: all-zero between launches — the kernel zeroes what it used; after a
+        // launch that did not complete (res_dirty) they are cleared here
+        size_t cap = 4096;
+        while ((i64)cap < 4 * T) cap <<= 1;
+        if (cap > c.res_table_cap) {
+            if (c.res_table) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(c.res_table); c.res_table = nullptr; c.res_table_cap = 0; }
+            HIP_TRY(hipMalloc((void **)&c.res_table, cap * 8));
+            c.res_table_cap = cap;
+            HIP_TRY(hipMemsetAsync(c.res_table, 0, cap * 8, st));
+        } else if (c.res_dirty) {
+            HIP_TRY(hipMemsetAsync(c.res_table, 0, c.res_table_cap * 8, st));
+        }
+        if ((size_t)T > c.rot_partner_cap) {
+            if (c.rot_partner) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(c.rot_partner); c.rot_partner = nullptr; c.rot_partner_cap = 0; }
+            size_t pcap = 4096;
+            while (pcap < (size_t)T) pcap <<= 1;
+            HIP_TRY(hipMalloc((void **)&c.rot_partner, pcap * 4));
+            c.rot_partner_cap = pcap;
+            HIP_TRY(hipMemsetAsync(c.rot_partner, 0, pcap * 4, st));
+        } else if (c.res_dirty) {
+            HIP_TRY(hipMemsetAsync(c.rot_partner, 0, c.rot_partner_cap * 4, st));
+        }
+        c.res_dirty = false;
+        a.slots = c.res_table; a.mask = (u32)(cap - 1); a.partner = c.rot_partner;
+    }
+    a.gran1 = c.res_state; a.gran2 = c.res_state + RES_MAX_WG; a.fail = reinterpret_cast<u32 *>(c.res_state + 2 * RES_MAX_WG);
+    a.finished = a.fail + 2; a.finish_target = finished_base + (u32)G;
+    finished_base += (u32)G;
+    a.epoch = c.res_epoch;
+    { const char *e = getenv("SYMGPU_RES_INJECT"); a.inject = (e && e[0] == '1') ? 1 : 0; }
+    a.trace = nullptr;
+    if (const char *e = getenv("SYMGPU_RES_TRACE")) if (e[0] == '1') {
+        if (!g_res_trace) { HIP_TRY(hipMalloc((void **)&g_res_trace, (size_t)RES_MAX_WG * 16 * 8)); }
+        HIP_TRY(hipMemsetAsync(g_res_trace, 0, (size_t)RES_MAX_WG * 16 * 8, st));
+        a.trace = g_res_trace;
+        g_res_trace_wgs = (int)G;
+    }
+    RotCounts *hcnt = nullptr, *hcnt_dev = nullptr;
+    SG_TRY(host_counts(&hcnt, &hcnt_dev));
+    a.host_cnt = hcnt_dev;
+    for (int ww = 0; ww < 64; ++ww) a.q.w[ww] = ww < W ? q_host[ww] : 0ULL;
+    symgpu_op_t res = nullptr;
+    SG_TRY(symgpu_op_alloc(clifford ? T : 2 * T, Wq, 1, &res));                   // upper bound: no host round trip before the rows are written
+    if (have_hash) {
+        const int rc = dev_alloc((size_t)res->capacity * 8 + 16, (void **)&res->hash);
+        if (rc != SYMGPU_OK) { symgpu_op_free(res); return rc; }
+        res->hash_seed = in->hash_seed;
+    }
+    a.out_rows = reinterpret_cast<u32x4 *>(res->rows); a.out_coeff = res->coeff; a.out_hash = res->hash;
+    __atomic_store_n(&hcnt->dup, 0xFFFFFFFFu, __ATOMIC_RELEASE);                   // poison: the kernel must report
+    hipLaunchKernelGGL(res_kernel(clifford, Wq), dim3((unsigned)G), dim3(RES_THREADS), (size_t)L.total, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { symgpu_op_free(res); c.res_dirty = true; return hip_fail(e, "rotate resident", __FILE__, __LINE__); }
+    // The last workgroup to leave writes the counts and then the status word into pinned host memory: poll that word instead of
+    // synchronising the stream (whose wake-up costs more than the kernel's tail) — whatever is enqueued next is stream ordered
+    // behind the kernel anyway.  The kernel gives up by itself after ~1 s; no word although the stream is idle: failure.
+    {
+        volatile u32 *status = &hcnt->dup;
+        bool seen = false;
+        for (u64 spin = 0; spin < (1ULL << 34); ++spin) {
+            if (__atomic_load_n(status, __ATOMIC_ACQUIRE) != 0xFFFFFFFFu) { seen = true; break; }
+            if ((spin & 0xFFFFF) == 0xFFFFF) {
+                const hipError_t qe = hipStreamQuery(st);
+                if (qe != hipErrorNotReady) { if (qe != hipSuccess) e = qe; break; }       // finished (or failed) without a word
+            }
+        }
+        if (!seen && e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { symgpu_op_free(res); c.res_dirty = true; return hip_fail(e, "rotate resident", __FILE__, __LINE__); }
+    }
+    const RotCounts hc = *hcnt;
+    if (hc.dup != 0) {                                                             // verification failed, timed out, or no report at all
+        symgpu_op_free(res);
+        ++g_counters[2];
+        if (hc.dup != 2) { c.res_disabled = true; c.res_epoch = 0; c.res_dirty = true; }   // time-out: arrival counts, table and notes are in an unknown state
+        return SYMGPU_OK;
+    }
+    *done = 1;
+    ++g_counters[1];
+    if (hc.nAnti == 0) { symgpu_op_free(res); *all_commute = 1; return SYMGPU_OK; }   // identity action (base.py:1131-1133)
+    res->T = (i64)hc.nC + hc.nA + hc.nN;
+    res->dup_free = clifford ? in->dup_free : 1;
+    *out = res;
+    *all_commute = 0;
+    return SYMGPU_OK;
+}
+
+}  // namespace symgpu

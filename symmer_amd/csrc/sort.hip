@@ -9,8 +9,11 @@
 // (12 B).  Tiles of 4096 elements are ranked with 64-wide wavefront ballots (one match mask per lane from 8
 // __ballot calls), staged through LDS in digit order and written out as contiguous per-digit runs.
 #include "common.h"
+#include <stdlib.h>
 
 namespace symgpu {
+
+typedef int32_t i32;
 
 // ------------------------------------------------------------------------------------------------
 // exclusive scan (u32), 2048 elements per block, recursive over block sums
@@ -249,6 +252,186 @@ int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp,
         in_tmp = !in_tmp;
     }
     *result_in_tmp = in_tmp;
+    return SYMGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same sort as ONE persistent launch (keys only, up to COOP_MAX_TILES tiles): at 10^5 keys a pass of the multi-launch form is
+// four or five launches of a few microseconds each — launch bound (26 us per pass); here the passes are separated by two counter
+// barriers each.  Everything that crosses workgroups (keys, tile histograms, the barrier counter) moves through agent-scope
+// relaxed loads and stores (write-through / L1-bypassing: cdna_hip_programming.md Guideline 16), so the barriers need no fences.
+// The workgroups must be co-resident: <= COOP_MAX_TILES blocks of 256 threads and 35 KB of LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int COOP_MAX_TILES = 128;
+
+// returns false if the other workgroups did not arrive within ~2^22 polls (not co-resident): the caller's kernel gives up, bar[1] says so
+__device__ __forceinline__ bool coop_barrier(u32 *bar, u32 target, int G, u32 *s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // this wavefront's write-through stores have left
+    __syncthreads();
+    if (G > 1 && threadIdx.x == 0) {
+        atomicAdd(bar, 1u);
+        u32 ok = 1;
+        for (u32 spin = 0; (i32)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0; ++spin) {
+            if (spin >= (1u << 22) || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = ok;
+    }
+    __syncthreads();
+    return G == 1 || *s_flag != 0;
+}
+
+__global__ __launch_bounds__(256) void k_rs_coop(u64 *__restrict__ buf_a, u64 *__restrict__ buf_b, i64 n, int begin_bit, int n_passes,
+                                                  u32 *__restrict__ tile_hist /* [256][G] */, u32 *__restrict__ bar, u32 bar_base) {
+    __shared__ u64 s_key[RS_TILE];
+    __shared__ volatile u32 s_cnt[4][256];                  // indexed directly: through a pointer the accesses become flat loads
+    __shared__ u32 s_dig_off[256];
+    __shared__ u32 s_gbase[256];
+    __shared__ u32 s_wave[4];
+    __shared__ u32 s_ok;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int G = gridDim.x, tile = blockIdx.x;
+    const i64 tile_base = (i64)tile * RS_TILE;
+    const u64 lt_mask = (1ULL << lane) - 1ULL;
+    u32 n_bar = 0;
+    for (int p = 0; p < n_passes; ++p) {
+        const int shift = begin_bit + 8 * p;
+        const u64 *src = (p & 1) ? buf_b : buf_a;
+        u64 *dst = (p & 1) ? buf_a : buf_b;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
+        __syncthreads();
+        u64 key[RS_ITEMS];
+        u32 pos[RS_ITEMS];
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r) {                                   // all sixteen loads in flight before the first one is used
+            const i64 idx = tile_base + (i64)wave * RS_WSEG + r * 64 + lane;
+            key[r] = idx < n ? __hip_atomic_load(src + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ULL;
+        }
+        asm volatile("" : "+v"(key[0]), "+v"(key[1]), "+v"(key[2]), "+v"(key[3]), "+v"(key[4]), "+v"(key[5]), "+v"(key[6]), "+v"(key[7]));
+        asm volatile("" : "+v"(key[8]), "+v"(key[9]), "+v"(key[10]), "+v"(key[11]), "+v"(key[12]), "+v"(key[13]), "+v"(key[14]), "+v"(key[15]));
+        static_assert(RS_ITEMS == 16, "the two statements above name sixteen keys");
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r) {
+            const i64 idx = tile_base + (i64)wave * RS_WSEG + r * 64 + lane;
+            const bool valid = idx < n;
+            const u32 d = (u32)(key[r] >> shift) & 255u;
+            u64 m = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const u64 bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            const u32 rank = __popcll(m & lt_mask);
+            const u32 count = __popcll(m);
+            u32 base = 0;
+            if (valid) base = s_cnt[wave][d];
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == 0) s_cnt[wave][d] = base + count;
+            __builtin_amdgcn_wave_barrier();
+            pos[r] = base + rank;
+        }
+        __syncthreads();
+        u32 my_count;
+        {   // per digit: exclusive offsets over the wavefronts, the tile's count, exclusive scan over the digits
+            const int d = threadIdx.x;
+            u32 run = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const u32 c = s_cnt[k][d]; s_cnt[k][d] = run; run += c; }
+            my_count = run;
+            u32 total;
+            s_dig_off[d] = block_excl_scan_256(run, s_wave, &total);
+            __hip_atomic_store(&tile_hist[(i64)d * G + tile], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!coop_barrier(bar, bar_base + (u32)G * (++n_bar), G, &s_ok)) return;
+        {   // global base of every digit for this tile: keys of smaller digits (all tiles) + keys of this digit in earlier tiles
+            const int d = threadIdx.x;
+            u32 all = 0, before = 0;
+            if (G == 1) all = my_count;
+            else
+                for (int t0 = 0; t0 < G; t0 += 16) {                           // sixteen independent loads per round
+                    u32 x[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        x[k] = t0 + k < G ? __hip_atomic_load(&tile_hist[(i64)d * G + t0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+                    asm volatile("" : "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { all += x[k]; if (t0 + k < tile) before += x[k]; }
+                }
+            u32 total;
+            s_gbase[d] = block_excl_scan_256(all, s_wave, &total) + before;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r) {
+            const i64 idx = tile_base + (i64)wave * RS_WSEG + r * 64 + lane;
+            if (idx < n) {
+                const u32 d = (u32)(key[r] >> shift) & 255u;
+                s_key[s_dig_off[d] + s_cnt[wave][d] + pos[r]] = key[r];
+            }
+        }
+        __syncthreads();
+        const i64 n_valid = (n - tile_base < RS_TILE) ? (n - tile_base) : RS_TILE;
+#pragma unroll 4
+        for (int k = 0; k < RS_ITEMS; ++k) {
+            const int sidx = k * 256 + threadIdx.x;
+            if (sidx < n_valid) {
+                const u64 kk = s_key[sidx];
+                const u32 d = (u32)(kk >> shift) & 255u;
+                __hip_atomic_store(dst + ((i64)s_gbase[d] + (sidx - (int)s_dig_off[d])), kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (!coop_barrier(bar, bar_base + (u32)G * (++n_bar), G, &s_ok)) return;
+    }
+}
+
+// returns SYMGPU_OK with *done = false if the array is too large for the one-launch form
+int radix_sort_keys_u64_coop(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done) {
+    *done = false;
+    *result_in_tmp = false;
+    if (n <= 1) { *done = true; return SYMGPU_OK; }
+    const i64 n_tiles = (n + RS_TILE - 1) / RS_TILE;
+    if (n_tiles > COOP_MAX_TILES) return SYMGPU_OK;
+    if (const char *e = getenv("SYMGPU_SORT_COOP")) if (e[0] == '0') return SYMGPU_OK;
+    Context &c = ctx();
+    if (c.sort_coop_disabled) return SYMGPU_OK;
+    hipStream_t st = c.stream;
+    // c.sort_state: [0] barrier counter (monotonic over the launches; cleared before it can wrap), [1] time-out flag, [64 ..] tile histograms
+    if (!c.sort_state) {
+        HIP_TRY(hipMalloc((void **)&c.sort_state, (64 + 256 * COOP_MAX_TILES) * sizeof(u32)));
+        HIP_TRY(hipMemsetAsync(c.sort_state, 0, 64 * sizeof(u32), st));
+        c.sort_bar_base = 0;
+    }
+    const int n_passes = (end_bit - begin_bit + 7) / 8;
+    const u32 arrivals = (u32)n_tiles * 2u * (u32)n_passes;
+    if (c.sort_bar_base > 0x70000000u - arrivals) {
+        HIP_TRY(hipMemsetAsync(c.sort_state, 0, 64 * sizeof(u32), st));
+        c.sort_bar_base = 0;
+    }
+    hipLaunchKernelGGL(k_rs_coop, dim3((unsigned)n_tiles), dim3(256), 0, st, keys, keys_tmp, n, begin_bit, n_passes, c.sort_state + 64, c.sort_state,
+                       c.sort_bar_base);
+    KERNEL_CHECK();
+    c.sort_bar_base += n_tiles > 1 ? arrivals : 0u;
+    *result_in_tmp = (n_passes & 1) != 0;
+    *done = true;
+    return SYMGPU_OK;
+}
+
+// After the stream has been synchronised: did a one-launch sort since the last check give up at a barrier?  Then its output is garbage;
+// the form is switched off for the rest of the process and the caller reports the failure.
+int radix_sort_coop_check(bool *timed_out) {
+    Context &c = ctx();
+    *timed_out = false;
+    if (!c.sort_state || c.sort_coop_disabled) return SYMGPU_OK;
+    u32 flag = 0;
+    HIP_TRY(hipMemcpy(&flag, c.sort_state + 1, 4, hipMemcpyDeviceToHost));
+    if (flag) {
+        *timed_out = true;
+        c.sort_coop_disabled = true;
+    }
     return SYMGPU_OK;
 }
 

@@ -1,0 +1,51 @@
+# fresh process: the one-launch rotation kernel must report what it cannot do exactly, and the caller must still get the right result.
+#   weakhash: SYMGPU_HASH_WEAK_ODD=1 keeps 4 bits of the row hash -> distinct rows with equal hashes -> verification failure (code 2)
+#   timeout : SYMGPU_RES_INJECT=1 lets one workgroup leave without a word -> the all-gather times out (code 3), the path is switched off
+import os, sys, ctypes
+mode = sys.argv[1]
+if mode == 'weakhash':
+    os.environ['SYMGPU_HASH_WEAK_ODD'] = '1'
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from symmer_amd import _lib, kernels, packing
+from symmer_amd.kernels import DeviceOp
+from oracle import oracle_np as onp
+
+
+def counter(which):
+    v = ctypes.c_int64(-1)
+    _lib.check(_lib.lib().symgpu_debug_counter(which, ctypes.addressof(v)))
+    return v.value
+
+
+rng = np.random.default_rng(41)
+dy = lambda t: (rng.integers(-8, 9, t) + 1j * rng.integers(-8, 9, t)) / 16.0
+n, T = 200, 4000
+symp, c = onp.cleanup_op(rng.random((T, 2 * n)) < 0.3, dy(T))
+q = rng.random(2 * n) < 0.3
+half = symp.shape[0] // 2
+symp, c = onp.cleanup_op(np.vstack([symp, symp[:half] ^ q]), np.hstack([c, dy(half)]))
+qp = packing.pack_rows(q.reshape(1, -1))[0]
+op = DeviceOp.upload(packing.pack_rows(symp), c)
+first, _ = kernels.rotate_single_dev(op, qp, 0.7)               # multi-launch path: duplicate status and hashes of `op`
+first.free()
+assert counter(1) == 0 and counter(2) == 0
+if mode == 'timeout':
+    os.environ['SYMGPU_RES_INJECT'] = '1'
+res, allc = kernels.rotate_single_dev(op, qp, 0.3)
+assert counter(2) == 1 and counter(1) == 0, (counter(1), counter(2))
+rows, coeff = res.download()
+er, ec = onp.rotate_by_single_pword(symp, c, q, 0.3)
+kd, ko = np.abs(coeff) > 1e-12, np.abs(ec) > 1e-12
+assert np.array_equal(rows[kd], packing.pack_rows(er)[ko]) and np.allclose(coeff[kd], ec[ko], rtol=0, atol=1e-12)
+if mode == 'timeout':
+    os.environ.pop('SYMGPU_RES_INJECT')
+    r2, _ = kernels.rotate_single_dev(op, qp, 0.3)             # switched off after a time-out: multi-launch path, no new attempt
+    assert counter(2) == 1 and counter(1) == 0
+    os.environ['SYMGPU_ROT_RESIDENT'] = '2'                     # ... until it is asked for again
+    r3, _ = kernels.rotate_single_dev(op, qp, 0.3)
+    assert counter(1) == 1, counter(1)
+    a, b = r2.download(), r3.download()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+print('RESIDENT_FAIL_OK', flush=True)

@@ -1,4 +1,4 @@
-# per-kernel breakdown of any helper script (run on the GPU box): bash tools/prof_any.sh tests/_bench_gf2.py [rows]
+# per-kernel breakdown of any helper script (run on the GPU box): bash tools/prof_any.sh tools/bench_gf2.py [rows]
 export TMPDIR=/tmp
 rm -rf gpurun_out/anyprof; mkdir -p gpurun_out/anyprof
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/anyprof -o t -- python3 "$1" > gpurun_out/anyprof/out.txt 2>&1
