@@ -21,6 +21,15 @@ cpu_baseline — the NumPy restatement of the reference algorithm (oracle/oracle
                bounded sample of the same workload on the host cores.
 extras       — the other BASELINE configs measured on the same GPU (cfg3 product+cleanup, cfg2 rotation chain,
                cfg4 GF(2) symmetry kernel in row-XORs/s, cfg5 commutation slice).  N=1, rank 0 only.
+
+Every BASELINE config is also a workload of its own with the same contract line (own `roofline` and `cpu_baseline`):
+  --workload product      north star: all-pairs product, 1e5 x 1e5 terms, 1,000 qubits (default)
+  --workload mul_cleanup  cfg3: P * P of a 1e4-term, 1,000-qubit operator (1e8 pairs) + cleanup   (reference base.py:821-859)
+  --workload rotation     cfg2: one non-Clifford rotation of a 1e5-term, 1,000-qubit operator      (reference base.py:1090-1161)
+  --workload gf2          cfg4: symmetry generators of a 5e4-term, 2,000-qubit operator             (reference independent_op.py:90-144)
+  --workload adjacency    cfg5: adjacency matrix of a 2e5-term, 2,000-qubit operator                (reference base.py:938-971)
+mul_cleanup / rotation / gf2 do not shard (replicas only): with --gpus N every rank runs the same workload on its
+own GPU and `value` is the sum over the ranks.
 """
 import argparse
 import ctypes
@@ -35,7 +44,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-TRAFFIC_PROFILE = 'r02_traffic.json'   # written by tools/pmc_product.sh from the rocprofv3 --pmc passes of this bench
+TRAFFIC_PROFILE = 'r03_traffic.json'   # written by tools/pmc_product.sh from the rocprofv3 --pmc passes of this bench
 
 
 def parse():
@@ -47,9 +56,10 @@ def parse():
     ap.add_argument('--left-terms', type=int, default=100000, help='left terms PER GPU')
     ap.add_argument('--right-terms', type=int, default=100000)
     ap.add_argument('--slab-rows', type=int, default=256, help='outer rows per output slab')
-    ap.add_argument('--workload', choices=['product', 'adjacency'], default='product',
-                    help="product (default, the north-star metric) or adjacency = BASELINE cfg5: commutes_termwise adjacency of a fixed "
-                         "--adj-terms x --adj-qubits operator, left-term axis sharded over the ranks (strong scaling)")
+    ap.add_argument('--workload', choices=['product', 'adjacency', 'mul_cleanup', 'rotation', 'gf2'], default='product',
+                    help="product (default, the north-star metric); adjacency = BASELINE cfg5: commutes_termwise adjacency of a fixed "
+                         "--adj-terms x --adj-qubits operator, left-term axis sharded over the ranks (strong scaling); mul_cleanup = cfg3; "
+                         "rotation = cfg2; gf2 = cfg4 (replicas only: every rank runs the whole workload)")
     ap.add_argument('--adj-terms', type=int, default=200000)
     ap.add_argument('--adj-qubits', type=int, default=2000)
     ap.add_argument('--adj-slab-rows', type=int, default=0, help='adjacency: rows per launch / output slab (0: as many as a quarter of the free HBM holds)')
@@ -73,11 +83,16 @@ def main():
     _lib.init(local_rank)
     lib = _lib.lib()
     comm = parallel.Communicator.from_env()       # TCP control plane + RCCL data plane when world > 1
-    if args.workload == 'adjacency':
-        out = adjacency(args, comm, rank, world, _lib, DeviceOp, parallel)
+    if args.workload != 'product':
+        fn = {'adjacency': adjacency, 'mul_cleanup': wl_mul_cleanup, 'rotation': wl_rotation, 'gf2': wl_gf2}[args.workload]
+        try:
+            out = fn(args, comm, rank, world, _lib, DeviceOp, parallel)
+        except parallel.CollectiveHang as exc:
+            collective_hang(exc, args, rank, world)
         comm.close()
         if rank == 0:
             print(json.dumps(out))
+        comm.hard_exit_if_hung()
         return
 
     n, Ni, M = args.qubits, args.left_terms, args.right_terms
@@ -113,9 +128,13 @@ def main():
         _lib.check(lib.symgpu_device_sync())
 
     if comm.gathers:
-        # one gather outside the timed region, checked bit for bit against the same shards gathered through host memory: a data
-        # plane that delivers wrong rows is replaced by the host-staged one and the line is flagged `degraded`
-        comm.allgather_op(shard, right, M)
+        # one gather outside the timed region, under a watchdog and agreed on by all ranks (a collective that hangs on one rank ends
+        # the job with an error line instead of a hung job), then checked bit for bit against the same shards gathered through host
+        # memory: a data plane that delivers wrong rows is replaced by the host-staged one and the line is flagged `degraded`
+        try:
+            comm.allgather_op(shard, right, M)
+        except parallel.CollectiveHang as exc:
+            collective_hang(exc, args, rank, world)
         comm.verify_allgather(shard, right, M)
     for _ in range(args.warmup):
         step()
@@ -158,49 +177,41 @@ def main():
     }
     if comm.degraded:
         out['degraded'] = comm.degraded          # top-level flag: the all-gather did not run over RCCL/xGMI
-    # the plain row stream k_mul_rows (rows-only output slab: no phase bytes, no coefficients), outside the timed region
+    # the plain row stream k_mul_rows (rows-only output slab: no phase bytes, no coefficients), outside the timed region: four warm
+    # launches (a fresh 6.5 GB slab: first touch), then the best of three batches of eight
     if rank == 0:
         rows_only = DeviceOp.alloc(slab * Ni, wq, with_coeff=False)
         o1 = min(M, slab)
-        for _ in range(2):
+        for _ in range(4):
             _lib.check(lib.symgpu_mul_allpairs_dev(left.handle, right.handle, 0, o1, 1, rows_only.handle))
         kernels.sync()
-        _lib.check(lib.symgpu_prof_enable(0, 1))
-        for _ in range(10):
-            _lib.check(lib.symgpu_mul_allpairs_dev(left.handle, right.handle, 0, o1, 1, rows_only.handle))
-        _lib.check(lib.symgpu_prof_enable(0, 0))
-        n2, ms2 = ctypes.c_int64(0), ctypes.c_double(0)
-        _lib.check(lib.symgpu_prof_read(0, ctypes.addressof(n2), ctypes.addressof(ms2)))
-        iso = (o1 * Ni * 16 * wq) / (ms2.value / max(1, n2.value) * 1e-3) / 1e9 if ms2.value > 0 else 0.0
+        best = None
+        for _ in range(3):
+            _lib.check(lib.symgpu_prof_enable(0, 1))
+            for _ in range(8):
+                _lib.check(lib.symgpu_mul_allpairs_dev(left.handle, right.handle, 0, o1, 1, rows_only.handle))
+            kernels.sync()
+            _lib.check(lib.symgpu_prof_enable(0, 0))
+            n2, ms2 = prof_read(_lib, 0)
+            if n2 and (best is None or ms2 / n2 < best):
+                best = ms2 / n2
+        iso = (o1 * Ni * 16 * wq) / (best * 1e-3) / 1e9 if best else 0.0
         out['roofline']['isolated_GBps'] = iso
         out['roofline']['isolated_frac'] = iso / HBM_PEAK_GBS
+        out['roofline']['isolated_avg_launch_ms'] = best
         rows_only.free()
-    # on-box ceilings measured by the library itself (one-shot 16-B fill / copy over 4 GiB buffers)
+    # the library's own one-shot 16-byte fill / copy over 4 GiB buffers: a PROBE of the box, not a ceiling (the row stream's
+    # one-row-per-block write pattern beats the probe's grid-stride fill)
     if rank == 0:
         fill, cp = ctypes.c_double(0), ctypes.c_double(0)
         _lib.check(lib.symgpu_membw_probe(4 << 30, ctypes.addressof(fill), ctypes.addressof(cp)))
-        out['roofline']['measured_fill_ceiling_GBps'] = fill.value
-        out['roofline']['measured_copy_ceiling_GBps'] = cp.value
-        out['roofline']['frac_of_measured_fill_ceiling'] = achieved / fill.value if fill.value else None
+        out['roofline']['fill_probe_GBps'] = fill.value
+        out['roofline']['copy_probe_GBps'] = cp.value
     # HBM traffic of the dominant kernel: hardware counters cannot be read from inside this process, so the figure comes from
     # the committed rocprofv3 --pmc profile of THIS workload — and only if that profile was taken on the kernel source that
     # is running now (sha256 of product.hip recorded next to it); otherwise traffic stays null.
-    try:
-        import hashlib
-        with open(os.path.join(ROOT, 'profiles', TRAFFIC_PROFILE)) as f:
-            tr = json.load(f)
-        with open(os.path.join(ROOT, 'symmer_amd', 'csrc', 'product.hip'), 'rb') as f:
-            src = hashlib.sha256(f.read()).hexdigest()
-        cfg = tr['config']
-        same_cfg = (cfg['n_qubits'], cfg['left_terms_per_gpu'], cfg['right_terms'], cfg['slab_rows']) == (n, Ni, M, slab)
-        if same_cfg and tr.get('kernel_source_sha256') == src:
-            out['roofline']['traffic'] = tr['write_bytes_per_launch'] + tr['fetch_bytes_per_launch_corrected_x2']
-            out['roofline']['traffic_source'] = f'profiles/{TRAFFIC_PROFILE} (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes, same product.hip)'
-        else:
-            out['roofline']['traffic_source'] = (f'null: profiles/{TRAFFIC_PROFILE} was taken on a different ' +
-                                                 ('workload' if not same_cfg else 'revision of product.hip'))
-    except (OSError, KeyError, ValueError) as exc:
-        out['roofline']['traffic_source'] = f'null: no usable traffic profile ({type(exc).__name__})'
+    traffic_from_profile(out['roofline'], TRAFFIC_PROFILE, ['product.hip'],
+                         {'n_qubits': n, 'left_terms_per_gpu': Ni, 'right_terms': M, 'slab_rows': slab})
     for r in ring:
         r.free()
 
@@ -218,6 +229,312 @@ def main():
     comm.close()
     if rank == 0:
         print(json.dumps(out))
+    comm.hard_exit_if_hung()
+
+
+def collective_hang(exc, args, rank, world):
+    """A collective did not return on some rank (agreed by all ranks): the library stream of that rank is lost, there is nothing
+    to fall back to.  Rank 0 prints an error line in place of the result and every rank leaves with status 3."""
+    if rank == 0:
+        print(json.dumps({'metric': 'pauli_term_pairs_per_sec', 'value': None, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'error': f'CollectiveHang: {exc}', 'config': {'workload': args.workload}}))
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(3)
+
+
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def traffic_from_profile(roof, name, sources, config):
+    """roofline.traffic from the committed rocprofv3 --pmc profile `profiles/<name>` — only if it was taken on the kernel sources
+    that are running now (sha256 recorded next to the counters) and on the same configuration; otherwise null with the reason."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, 'profiles', name)) as f:
+            tr = json.load(f)
+        h = hashlib.sha256()
+        for src in sources:
+            with open(os.path.join(ROOT, 'symmer_amd', 'csrc', src), 'rb') as f:
+                h.update(f.read())
+        if tr.get('config') != config:
+            roof['traffic_source'] = f'null: profiles/{name} was taken on a different workload'
+        elif tr.get('kernel_source_sha256') != h.hexdigest():
+            roof['traffic_source'] = f'null: profiles/{name} was taken on a different revision of {"/".join(sources)}'
+        else:
+            roof['traffic'] = tr['write_bytes_per_launch'] + tr['fetch_bytes_per_launch_corrected_x2']
+            roof['traffic_write_bytes'] = tr['write_bytes_per_launch']
+            roof['traffic_fetch_bytes_x2'] = tr['fetch_bytes_per_launch_corrected_x2']
+            roof['traffic_source'] = f'profiles/{name} (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes, same {"/".join(sources)})'
+    except (OSError, KeyError, ValueError) as exc:
+        roof['traffic_source'] = f'null: no usable traffic profile ({type(exc).__name__})'
+
+
+def prof_read(_lib, cls):
+    n, ms = ctypes.c_int64(0), ctypes.c_double(0)
+    _lib.check(_lib.lib().symgpu_prof_read(cls, ctypes.addressof(n), ctypes.addressof(ms)))
+    return n.value, ms.value
+
+
+def contract_line(args, world, value, unit, metric, dt, dtype, workload_cfg, roofline, comm):
+    out = {'metric': metric, 'value': value, 'unit': unit, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype,
+           'data': 'synthetic', 'config': workload_cfg, 'roofline': roofline}
+    if comm.degraded:
+        out['degraded'] = comm.degraded
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def wl_mul_cleanup(args, comm, rank, world, _lib, DeviceOp, parallel):
+    """BASELINE cfg3 — the call `P * P` of the reference (base.py:821-859 -> _multiply_by_operator :764-794 -> symplectic_cleanup
+    utils.py:230-279): a 10,000-term, 1,000-qubit operator squared (1e8 pairs) + cleanup, device resident.  Step = one fused
+    product + cleanup (symgpu_mul_cleanup_dev); the 1e8 product rows are never materialised.
+    roofline: the kernel that moves most of the step's bytes, the output row stream k_emit_stream (every kept row written once:
+    16 Wq bytes per row, HBM-write bound; the list it reads comes out of the Infinity Cache).  SURVEY §8d's algorithmic bytes of the
+    whole step (T (16 Wq + 16) read + U_kept (16 Wq + 16) written) are reported next to it — most of them never move here."""
+    lib = _lib.lib()
+    n, N = args.qubits, 10000
+    wq = (n + 63) // 64
+    A = DeviceOp.random(N, n, 0.3, seed=1237 + 7919 * rank)
+    n_out = [0]
+
+    def step():
+        h = ctypes.c_void_p()
+        _lib.check(lib.symgpu_mul_cleanup_dev(A.handle, A.handle, 1, 1e-15, 1, ctypes.byref(h)))
+        r = DeviceOp(h); n_out[0] = r.n_terms; r.free()
+    for _ in range(max(1, args.warmup)):
+        step()
+    _lib.check(lib.symgpu_device_sync()); comm.barrier()
+    _lib.check(lib.symgpu_prof_enable(3, 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _lib.check(lib.symgpu_device_sync()); comm.barrier()
+    dt = comm.max_over_ranks(time.perf_counter() - t0)
+    _lib.check(lib.symgpu_prof_enable(3, 0))
+    nl, ms = prof_read(_lib, 3)
+    pairs = N * N
+    row_bytes = 16 * wq
+    launch_bytes = n_out[0] * row_bytes * args.steps / max(1, nl)          # rows written per k_emit_stream launch (batches of 4M indices)
+    kt = ms / max(1, nl) * 1e-3
+    algo_step = (pairs + n_out[0]) * (row_bytes + 16)
+    roof = {'bound': 'hbm', 'kernel': 'k_emit_stream', 'achieved': launch_bytes / kt / 1e9 if kt else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': launch_bytes / kt / 1e9 / HBM_PEAK_GBS if kt else None, 'traffic': None, 'launches': nl, 'avg_launch_ms': kt * 1e3,
+            'algorithmic_bytes_per_launch': launch_bytes,
+            'note': 'output row stream of the cleanup: 16*Wq bytes per kept row, written once, sequentially (non-temporal stores); the other '
+                    'long kernels of the step are the 4 passes of the radix sort (8 B keys) and k_heads_sums (latency bound) — '
+                    'profiles/r03_cfg3_kernel_trace.txt',
+            'whole_step': {'survey_8d_algorithmic_bytes': algo_step, 'algorithmic_GBps': algo_step / (dt / args.steps) / 1e9,
+                           'physical_write_floor_ms': n_out[0] * (row_bytes + 16) / (HBM_PEAK_GBS * 1e9) * 1e3,
+                           'note': 'SURVEY 8d counts T (16Wq+16) B read + U_kept (16Wq+16) B written; the T product rows and pair coefficients '
+                                   'never exist in memory here (keys only), so this figure is not HBM traffic'}}
+    traffic_from_profile(roof, 'r03_cfg3_traffic.json', ['cleanup.hip'], {'workload': 'mul_cleanup', 'n_qubits': n, 'terms': N})
+    out = contract_line(args, world, world * pairs * args.steps / dt, 'pairs/s', 'pauli_term_pairs_per_sec', dt, 'u64+c128',
+                        {'workload': 'mul_cleanup_squared', 'n_qubits': n, 'terms': N, 'pairs_per_step': pairs, 'terms_out': n_out[0],
+                         'call': 'P * P (symgpu_mul_cleanup_dev: fused product + cleanup, squared-operator path)',
+                         'parallelism': f'{world} independent replicas' if world > 1 else 'single GPU'}, roof, comm)
+    A.free()
+    if rank == 0 and not args.no_cpu:
+        out['cpu_baseline'] = guarded(lambda: cpu_mul_cleanup(n))
+    return out
+
+
+def wl_rotation(args, comm, rank, world, _lib, DeviceOp, parallel):
+    """BASELINE cfg2 — `P._rotate_by_single_Pword(Q, 0.3)` (reference base.py:1090-1161) of a 100,000-term, 1,000-qubit operator,
+    device resident, duplicate status and row hashes known (as inside perform_rotations from the second step on).  Step = one
+    non-Clifford rotation = ONE persistent launch (k_rot_resident, rotate_resident.hip).  Unit: term pairs (N x 1) per second.
+    roofline: SURVEY 8d's bytes of that launch, N (16 Wq + 16) read + N_out (16 Wq + 16) written, over its HIP-event duration."""
+    from symmer_amd import kernels, packing
+    lib = _lib.lib()
+    n, N = args.qubits, 100000
+    wq = (n + 63) // 64
+    rng = np.random.default_rng(1236)
+    P = DeviceOp.random(N, n, 0.3, seed=1236 + 7919 * rank)
+    qs = [packing.pack_rows((rng.random((1, 2 * n)) < 0.3))[0] for _ in range(8)]
+    kernels.rotate_single_dev(P, qs[0], 0.3)[0].free()                   # multi-launch path once: duplicate status + hashes of P
+    n_out = [0]
+
+    from symmer_amd.kernels import rotation_args
+    cos_t, sin_t, ck = rotation_args(0.3)
+    keep = []
+
+    def step(k=0):
+        # the C-ABI call itself (symgpu_rotate_single_dev) with its arguments prepared once, as perform_rotations' inner loop would
+        h, allc = ctypes.c_void_p(), ctypes.c_int(0)
+        _lib.check(lib.symgpu_rotate_single_dev(P.handle, qs[k % 8].ctypes.data, cos_t, sin_t, ck, 1e-15, ctypes.byref(h), ctypes.addressof(allc)))
+        if keep:
+            keep.pop().free()
+        keep.append(DeviceOp(h))
+    for k in range(max(2, args.warmup)):
+        step(k)
+    _lib.check(lib.symgpu_device_sync()); comm.barrier()
+    _lib.check(lib.symgpu_prof_enable(4, 1))
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    _lib.check(lib.symgpu_device_sync()); comm.barrier()
+    dt = comm.max_over_ranks(time.perf_counter() - t0)
+    _lib.check(lib.symgpu_prof_enable(4, 0))
+    nl, ms = prof_read(_lib, 4)
+    kt = ms / max(1, nl) * 1e-3
+    n_out[0] = keep[-1].n_terms
+    keep.pop().free()
+    launch_bytes = (N + n_out[0]) * (16 * wq + 16)
+    roof = {'bound': 'hbm', 'kernel': 'k_rot_resident', 'achieved': launch_bytes / kt / 1e9 if kt else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': launch_bytes / kt / 1e9 / HBM_PEAK_GBS if kt else None, 'traffic': None, 'launches': nl, 'avg_launch_ms': kt * 1e3,
+            'algorithmic_bytes_per_launch': launch_bytes, 'whole_call_GBps': launch_bytes / (dt / args.steps) / 1e9,
+            'note': 'one persistent launch per rotation, rows resident in LDS (one workgroup per CU); the launch is a chain of dependent phases '
+                    '(rows in 7 us, join-table compare-and-swaps 3 us, two in-launch all-gathers, rows out 7 us), not a bandwidth-bound stream'}
+    traffic_from_profile(roof, 'r03_rotation_traffic.json', ['rotate_resident.hip'], {'workload': 'rotation', 'n_qubits': n, 'terms': N})
+    out = contract_line(args, world, world * N * args.steps / dt, 'pairs/s', 'pauli_term_pairs_per_sec', dt, 'u64+c128',
+                        {'workload': 'single_pauli_rotation_nonclifford', 'n_qubits': n, 'terms': N, 'terms_out': n_out[0], 'angle': 0.3,
+                         'pairs_per_step': N, 'call': 'P._rotate_by_single_Pword(Q, 0.3) (symgpu_rotate_single_dev)',
+                         'parallelism': f'{world} independent replicas' if world > 1 else 'single GPU'}, roof, comm)
+    out['seconds_per_rotation'] = dt / args.steps
+    # Clifford rotations of the same operator: one by one, and as one run (rows in registers + one sort per 40 rotations)
+    if rank == 0 and not args.no_extras:
+        def clifford():
+            res = {}
+            t0 = time.perf_counter()
+            for k in range(20):
+                kernels.rotate_single_dev(P, qs[k % 8], np.pi / 2)[0].free()
+            kernels.sync()
+            res['one_by_one_seconds_per_rotation'] = (time.perf_counter() - t0) / 20
+            Pc = kernels.cleanup_dev(P)
+            q200 = np.vstack([qs[k % 8] for k in range(200)]); k200 = (np.arange(200) % 4).astype(np.int32)
+            kernels.rotate_clifford_chain_dev(Pc, q200[:45], k200[:45]).free(); kernels.sync()
+            _lib.check(lib.symgpu_prof_enable(5, 1))
+            t0 = time.perf_counter(); kernels.rotate_clifford_chain_dev(Pc, q200, k200).free(); kernels.sync()
+            res['run_of_200_seconds_per_rotation'] = (time.perf_counter() - t0) / 200
+            _lib.check(lib.symgpu_prof_enable(5, 0))
+            nl5, ms5 = prof_read(_lib, 5)
+            res['k_cchain_reg_launches'] = nl5
+            res['k_cchain_reg_us_per_rotation'] = ms5 * 1e3 / 200
+            res['run_algorithmic_GBps'] = 2 * Pc.n_terms * (16 * wq + 16) / res['run_of_200_seconds_per_rotation'] / 1e9
+            Pc.free()
+            return res
+        out['clifford'] = guarded(clifford)
+    P.free()
+    if rank == 0 and not args.no_cpu:
+        out['cpu_baseline'] = guarded(lambda: cpu_rotation(n, N))
+    return out
+
+
+def cfg4_operator(_lib, DeviceOp, kernels, packing, seed):
+    """2,000 qubits, 50,000 terms, 32 planted symmetries (X bits of qubits 0..31 zero), scrambled by 16 random
+    Clifford rotations."""
+    rng = np.random.default_rng(seed)
+    symp = rng.random((50000, 4000)) < 0.3
+    symp[:, :32] = False
+    H = DeviceOp.upload(packing.pack_rows(symp), np.ones(50000, dtype=complex))
+    del symp
+    for _ in range(16):
+        q = packing.pack_rows((rng.random((1, 4000)) < 0.3))[0]
+        res, allc = kernels.rotate_single_dev(H, q, np.pi / 2)
+        if not allc:
+            H.free(); H = res
+    return H
+
+
+def wl_gf2(args, comm, rank, world, _lib, DeviceOp, parallel):
+    """BASELINE cfg4 — `IndependentOp.symmetry_generators(H)` (reference independent_op.py:90-144: _cref_binary of a 4000 x 54000 GF(2)
+    matrix, utils.py:292-347).  Step = one symgpu_symmetry_kernel_dev call on the device-resident operator (matrix build, blocked
+    elimination, read-out of the generators).  Unit: row-XORs per second, counted as the reference's loop performs them.
+    roofline: the main sweep launches k_sweep_m4r — every launch reads and writes the whole matrix once (physical bytes); the
+    blocked algorithm makes ~1/50 of the reference's passes, so SURVEY 8d's algorithmic figure (16 Wc bytes per row-XOR) is far above
+    what moves and is reported separately."""
+    from symmer_amd import kernels, packing
+    lib = _lib.lib()
+    H = cfg4_operator(_lib, DeviceOp, kernels, packing, 1238 + 7919 * rank)
+    outg = np.zeros((4000, 64), dtype='<u8')
+    k, nx = ctypes.c_int64(0), ctypes.c_int64(0)
+
+    def step():
+        _lib.check(lib.symgpu_symmetry_kernel_dev(H.handle, 2000, outg.ctypes.data, 4000, ctypes.addressof(k), ctypes.addressof(nx)))
+    for _ in range(max(1, args.warmup)):
+        step()
+    _lib.check(lib.symgpu_device_sync()); comm.barrier()
+    _lib.check(lib.symgpu_prof_enable(2, 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _lib.check(lib.symgpu_device_sync()); comm.barrier()
+    dt = comm.max_over_ranks(time.perf_counter() - t0)
+    _lib.check(lib.symgpu_prof_enable(2, 0))
+    nl, ms = prof_read(_lib, 2)
+    kt = ms / max(1, nl) * 1e-3
+    wc = (50000 + 63) // 64 + 64
+    phys = 2 * 4000 * wc * 8                                               # one pass over the matrix: read + write
+    algo_launch = nx.value * 16 * wc * args.steps / max(1, nl)
+    roof = {'bound': 'hbm', 'kernel': 'k_sweep_m4r', 'achieved': phys / kt / 1e9 if kt else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': phys / kt / 1e9 / HBM_PEAK_GBS if kt else None, 'traffic': None, 'launches': nl, 'avg_launch_ms': kt * 1e3,
+            'physical_bytes_per_launch': phys, 'survey_8d_algorithmic_bytes_per_launch': algo_launch,
+            'survey_8d_algorithmic_GBps': nx.value * 16 * wc / (dt / args.steps) / 1e9,
+            'note': 'achieved = bytes one sweep launch moves (the 27 MB matrix read and written once) / its duration; the matrix lives in the '
+                    'Infinity Cache, and the launch is as long as the single-wavefront panel of the next block that it hides'}
+    traffic_from_profile(roof, 'r03_gf2_traffic.json', ['gf2.hip'], {'workload': 'gf2', 'rows': 4000, 'cols': 54000})
+    out = contract_line(args, world, world * nx.value * args.steps / dt, 'row-XORs/s', 'gf2_row_xors_per_sec', dt, 'u64',
+                        {'workload': 'symmetry_generators_gf2', 'n_qubits': 2000, 'terms': 50000, 'matrix': [4000, 54000], 'row_xors_per_step': nx.value,
+                         'generators_found': k.value, 'call': 'IndependentOp.symmetry_generators (symgpu_symmetry_kernel_dev)',
+                         'parallelism': f'{world} independent replicas' if world > 1 else 'single GPU'}, roof, comm)
+    H.free()
+    if rank == 0 and not args.no_cpu:
+        out['cpu_baseline'] = guarded(cpu_gf2)
+    return out
+
+
+def guarded(fn):
+    try:
+        return fn()
+    except Exception as exc:                                      # noqa: BLE001 - reported in the JSON line
+        return {'error': f'{type(exc).__name__}: {exc}'}
+
+
+def cpu_mul_cleanup(n):
+    """cfg3 cannot be materialised by the reference algorithm (200 GB of temporaries): 1e3 x 1e3 terms on 1,000 qubits."""
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(1234)
+    A = rng.random((1000, 2 * n)) < 0.3; a = rng.standard_normal(1000) + 1j * rng.standard_normal(1000)
+    t0 = time.perf_counter(); r, _ = onp.multiply_by_operator(A, a, A, a); t = time.perf_counter() - t0
+    return {'value': 1e6 / t, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port', 'cpu_model': cpu_model(), 'host_cores': os.cpu_count(), 'seconds': t,
+            'sample': f'P * P of 1,000 terms on {n} qubits (1e6 pairs -> {r.shape[0]} terms), NumPy restatement of base.py:764-794 + utils.py:230-279, '
+                      'single thread (the port\'s first-occurrence unique is a NumPy sort of 2,000-byte rows; the reference uses qiskit\'s Rust hash map)'}
+
+
+def cpu_rotation(n, N):
+    """cfg2 at full size: one non-Clifford rotation of 1e5 terms on 1,000 qubits."""
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(1234)
+    P2 = rng.random((N, 2 * n)) < 0.3; c2 = rng.standard_normal(N) + 0j; q2 = rng.random(2 * n) < 0.3
+    t0 = time.perf_counter(); onp.rotate_by_single_pword(P2, c2, q2, 0.3); t = time.perf_counter() - t0
+    return {'value': N / t, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port', 'cpu_model': cpu_model(), 'host_cores': os.cpu_count(), 'seconds': t,
+            'sample': f'one rotation of {N} terms on {n} qubits at full size, NumPy restatement of base.py:1090-1161 (commutes -> split -> multiply -> cleanups)'}
+
+
+def cpu_gf2():
+    """cfg4: the row-XOR rate of the reference's loop depends on the row length and the row count, so SURVEY 8d asks for the full
+    4000 x 54000 matrix (~10 minutes).  The full-size figure is measured once by tools/cpu_cfg4_full.py and cached in
+    profiles/r03_cpu_cfg4_full.json (labelled with host and date); the live leg is a bounded sample with the full row LENGTH."""
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(1234)
+    M4 = rng.random((384, 54000)) < 0.5
+    t0 = time.perf_counter(); _, nx = onp.rref_noswap(M4, count_xors=True); t = time.perf_counter() - t0
+    out = {'value': nx / t, 'unit': 'row-XORs/s', 'cores': 1, 'kind': 'port', 'cpu_model': cpu_model(), 'host_cores': os.cpu_count(), 'seconds': t,
+           'sample': f'_rref_binary of a 384 x 54000 matrix ({int(nx)} row-XORs of cfg4\'s row length), NumPy restatement of utils.py:292-315'}
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r03_cpu_cfg4_full.json')) as f:
+            out['full_size_cached'] = json.load(f)
+    except (OSError, ValueError):
+        out['full_size_cached'] = None
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------

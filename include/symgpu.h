@@ -48,8 +48,10 @@ int symgpu_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 /* HIP-event timer on the library stream (used by bench.py for per-kernel durations) */
 int symgpu_timer_start(void);
 int symgpu_timer_stop(float *ms);
-/* per-launch HIP-event timing of the dominant kernel of a class (0 = product row stream k_mul_rows,
- * 1 = commutation k_commutes, 2 = GF(2) sweep k_sweep): enable, run, then read {launch count, total ms}. */
+/* per-launch HIP-event timing of the dominant kernel of a class (0 = product row stream k_mul_rows, 1 = commutation k_commutes,
+ * 2 = GF(2) sweep k_sweep_m4r (main launches), 3 = cleanup output row stream k_emit_stream, 4 = one-launch rotation k_rot_resident,
+ * 5 = register-resident run of Clifford rotations k_cchain_reg): enable, run, then read {launch count, total ms}. */
+#define SYMGPU_PROF_CLASSES 6
 int symgpu_prof_enable(int kernel_class, int on);
 int symgpu_prof_read(int kernel_class, int64_t *n_launches, double *total_ms);
 /* statistics for tests: which = 0: number of row-hash collisions that forced the cleanup to reseed its hash and retry (the exactness
@@ -78,6 +80,8 @@ int symgpu_op_write(symgpu_op_t op, int64_t row_offset, const uint64_t *rows, co
 int symgpu_op_random(int64_t T, int n_qubits, double density, uint64_t seed, symgpu_op_t *out); /* synthetic input, generated on device */
 /* XOR-fold of all packed rows (2*Wq words) and plain sum of coefficients: size-independent checksums */
 int symgpu_op_checksum(symgpu_op_t op, uint64_t *xor_words /* [2*Wq] */, double *coeff_sum /* [2] */);
+/* number of set bits in all packed rows: sum_{i,o} |a_i ^ b_o| of a product slab follows from the operands' bit-column counts in O(N + M) */
+int symgpu_op_popcount(symgpu_op_t op, uint64_t *sum);
 
 /* ---- a2: PauliwordOp.Y_count  (symmer/operators/base.py:604-615) ----------------------------- */
 int symgpu_ycount(const uint64_t *rows, int64_t T, int Wq, int64_t *out);

@@ -74,11 +74,11 @@ void orc_mul_allpairs(const u64 *inner, const double *ci, i64 Ni, const u64 *out
         const u64 *ro = outer + o * W;
         for (i64 i = 0; i < Ni; ++i) {
             const u64 *ri = inner + i * W;
-            u64 *dst = out_rows + (o * Ni + i) * W;
+            u64 *dst = out_rows ? out_rows + (o * Ni + i) * W : 0;       /* out_rows == NULL: coefficients only */
             int yout = 0; u64 flip = 0;
             for (int w = 0; w < Wq; ++w) {
                 u64 x = ri[w] ^ ro[w], z = ri[Wq + w] ^ ro[Wq + w];
-                dst[w] = x; dst[Wq + w] = z;
+                if (dst) { dst[w] = x; dst[Wq + w] = z; }
                 yout += popc(x & z);
                 flip ^= inner_is_left ? (ri[w] & ro[Wq + w]) : (ro[w] & ri[Wq + w]);
             }

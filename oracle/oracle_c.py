@@ -67,6 +67,17 @@ def mul_allpairs(inner, ci, outer, co, inner_is_left=True):
     return rows, coeff
 
 
+def mul_allpairs_coeff(inner, ci, outer, co, inner_is_left=True):
+    """The coefficients of :func:`mul_allpairs` without materialising the product rows (full-size slabs: 2.56e7 pairs)."""
+    inner, outer, ci, co = _rows(inner), _rows(outer), _c(ci), _c(co)
+    Ni, No, W = inner.shape[0], outer.shape[0], inner.shape[1]
+    coeff = np.zeros(Ni * No, dtype=np.complex128)
+    lib().orc_mul_allpairs(_p(inner, _u64p), _p(ci, _f64p), ctypes.c_int64(Ni), _p(outer, _u64p), _p(co, _f64p),
+                           ctypes.c_int64(No), ctypes.c_int(W // 2), ctypes.c_int(1 if inner_is_left else 0),
+                           None, _p(coeff, _f64p))
+    return coeff
+
+
 def cleanup(rows, coeff, thr=1e-15):
     """thr=None keeps every merged row (free-function default of utils.py:233)."""
     rows, coeff = _rows(rows), _c(coeff)

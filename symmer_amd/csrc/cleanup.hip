@@ -575,7 +575,7 @@ __global__ void k_popc_words(const u32 *__restrict__ bits, i64 n_words, u32 *__r
 // it is read (3.8 TB/s).  A batch's list is 32 MB at most, written by one kernel and read by the next.
 // TRI (PAIR only): the index space is the compacted slot order of a squared operator (tri_slot / tri_pair).
 static i64 emit_batch_words() {                                  // SYMGPU_EMIT_BATCH = log2(bitmap words per batch), default 17 (4M indices)
-    static const i64 w = [] { const char *e = getenv("SYMGPU_EMIT_BATCH"); const int l = e ? atoi(e) : 17; return (i64)1 << (l >= 6 && l <= 26 ? l : 17); }();
+    const i64 w = [] { const char *e = getenv("SYMGPU_EMIT_BATCH"); const int l = e ? atoi(e) : 17; return (i64)1 << (l >= 6 && l <= 26 ? l : 17); }();
     return w;
 }
 template <bool PAIR, bool TRI>
@@ -716,7 +716,7 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
         const int wsh = (Wq & (Wq - 1)) == 0 ? __builtin_ctz((unsigned)Wq) : -1;
         const u32x4 *pin = reinterpret_cast<const u32x4 *>(inner), *pout = reinterpret_cast<const u32x4 *>(outer);
         u32x4 *dst = reinterpret_cast<u32x4 *>(res->rows);
-        static const int rc_env = [] { const char *e = getenv("SYMGPU_EMIT_RC"); return e ? atoi(e) : 2; }();     // chunks per lane: 1: 115, 2: 97, 4: 97 us per batch
+        const int rc_env = [] { const char *e = getenv("SYMGPU_EMIT_RC"); return e ? atoi(e) : 2; }();     // chunks per lane: 1: 115, 2: 97, 4: 97 us per batch
         const int RCs = rc_env == 1 || rc_env == 4 ? rc_env : 2;
         const i64 EMIT_BATCH_WORDS = emit_batch_words();
         const i64 bw = n_words < EMIT_BATCH_WORDS ? n_words : EMIT_BATCH_WORDS;
@@ -738,8 +738,11 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
             const i64 gs = ((w1 - w0) * 32 * Wq + 256 * RCs - 1) / (256 * RCs);     // as if every index of the batch were kept
 #define LAUNCH_STREAM(P, R) hipLaunchKernelGGL((k_emit_stream<P, R>), dim3((unsigned)gs), dim3(256), 0, st, meta.as<uint2>(), p_begin, p_end, Wq, wsh, \
                                                reinterpret_cast<const u32x4 *>(rows), pin, pout, dst)
-            if (pair) { if (RCs == 1) LAUNCH_STREAM(true, 1); else if (RCs == 4) LAUNCH_STREAM(true, 4); else LAUNCH_STREAM(true, 2); }
-            else { if (RCs == 1) LAUNCH_STREAM(false, 1); else if (RCs == 4) LAUNCH_STREAM(false, 4); else LAUNCH_STREAM(false, 2); }
+            {
+                ProfScope prof(3);
+                if (pair) { if (RCs == 1) LAUNCH_STREAM(true, 1); else if (RCs == 4) LAUNCH_STREAM(true, 4); else LAUNCH_STREAM(true, 2); }
+                else { if (RCs == 1) LAUNCH_STREAM(false, 1); else if (RCs == 4) LAUNCH_STREAM(false, 4); else LAUNCH_STREAM(false, 2); }
+            }
 #undef LAUNCH_STREAM
         }
         hipError_t e = hipGetLastError();
@@ -874,7 +877,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             // the wave cycles issue, 53 % wait on memory), so it wants many short waves rather than few long ones: cfg3 6.39 / 6.16 /
             // 6.10 / 6.04 ms at 2^15 / 2^17 / 2^19 / 2^21 wavefronts (a wave also decodes the chunk after its range to close the
             // segment it carries, so one chunk per wave reads the keys twice — still the fastest).
-            static const i64 HS_WAVES = [] { const char *e = getenv("SYMGPU_HS_WAVES"); return e ? atoll(e) : (i64)1 << 21; }();
+            const i64 HS_WAVES = [] { const char *e = getenv("SYMGPU_HS_WAVES"); return e ? atoll(e) : (i64)1 << 21; }();
             const i64 cpw = (n_chunks + HS_WAVES - 1) / HS_WAVES;     // <= HS_WAVES wavefronts, each on a contiguous range of chunks
             const i64 n_waves = (n_chunks + cpw - 1) / cpw;
             const dim3 gs((unsigned)((n_waves + 3) / 4));
@@ -883,7 +886,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             const i64 space = (squared && packed) ? Tk : T;               // index space of markbits / sum_of
             HIP_TRY(hipMemsetAsync(markbits.p, 0, (size_t)((space + 31) / 32) * 4, st));
             const u32 *zero_len_p = nullptr;
-            static const bool zero_on = [] { const char *e = getenv("SYMGPU_CLEANUP_ZEROSEG"); return !(e && e[0] == '0'); }();
+            const bool zero_on = [] { const char *e = getenv("SYMGPU_CLEANUP_ZEROSEG"); return !(e && e[0] == '0'); }();
             if (squared && packed && zero_on) {
                 // the identity segment (the N diagonal pairs and whatever else multiplies to the identity) in parallel, see k_zero_partial
                 const i64 n_zb = (Tk + ZB - 1) / ZB;

@@ -132,10 +132,10 @@ void dev_cache_release() {
 
 // ---- per-launch profiling ---------------------------------------------------------------------------
 struct ProfClass { bool on = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
-static ProfClass g_prof[3];
+static ProfClass g_prof[SYMGPU_PROF_CLASSES];
 
 ProfScope::ProfScope(int kernel_class) : cls(kernel_class), on(false) {
-    if (cls < 0 || cls >= 3 || !g_prof[cls].on) return;
+    if (cls < 0 || cls >= SYMGPU_PROF_CLASSES || !g_prof[cls].on) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { (void)hipGetLastError(); return; }
     on = true;
     (void)hipEventRecord(a, g_ctx.stream);
@@ -429,7 +429,7 @@ int symgpu_membw_probe(int64_t bytes, double *fill_GBps, double *copy_GBps) {
 }
 
 int symgpu_prof_enable(int kernel_class, int on) {
-    SG_REQUIRE(kernel_class >= 0 && kernel_class < 3, "prof_enable: class");
+    SG_REQUIRE(kernel_class >= 0 && kernel_class < SYMGPU_PROF_CLASSES, "prof_enable: class");
     g_prof[kernel_class].on = on != 0;
     return SYMGPU_OK;
 }
@@ -442,7 +442,7 @@ int symgpu_debug_counter(int which, int64_t *value) {
 
 int symgpu_prof_read(int kernel_class, int64_t *n_launches, double *total_ms) {
     SG_TRY(require_ctx());
-    SG_REQUIRE(kernel_class >= 0 && kernel_class < 3, "prof_read: class");
+    SG_REQUIRE(kernel_class >= 0 && kernel_class < SYMGPU_PROF_CLASSES, "prof_read: class");
     HIP_TRY(hipStreamSynchronize(ctx().stream));
     double tot = 0;
     for (auto &p : g_prof[kernel_class].ev) {
@@ -621,6 +621,13 @@ int symgpu_op_random(int64_t T, int n_qubits, double density, uint64_t seed, sym
     }
     *out = op;
     return SYMGPU_OK;
+}
+
+int symgpu_op_popcount(symgpu_op_t op, uint64_t *sum) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(op && sum, "op_popcount: null argument");
+    if (op->T == 0) { *sum = 0; return SYMGPU_OK; }
+    return symgpu_dev_popcount_u64(op->rows, op->T * 2 * op->Wq, sum);
 }
 
 int symgpu_op_checksum(symgpu_op_t op, uint64_t *xor_words, double *coeff_sum) {

@@ -220,6 +220,7 @@ int clifford_chain_registers(symgpu_op_t a, symgpu_op_t b, i64 T, const u64 *qs_
         u64 *knew = kbuf[2 * (seg & 1)].as<u64>(), *ktmp = kbuf[2 * (seg & 1) + 1].as<u64>();
 #define CH_LAUNCH(WQV, NCHV) hipLaunchKernelGGL((k_cchain_reg<WQV, NCHV>), dim3(grid), dim3(256), 0, st, rin, cur->coeff, perm, T, q4, ks, n, rout, other->coeff, knew)
 #define CH_NCH(WQV) do { if (nch == 1) CH_LAUNCH(WQV, 1); else CH_LAUNCH(WQV, 2); } while (0)
+        ProfScope *prof = new ProfScope(5);
         switch (Wq) {
             case 1: CH_NCH(1); break;
             case 2: CH_NCH(2); break;
@@ -230,6 +231,7 @@ int clifford_chain_registers(symgpu_op_t a, symgpu_op_t b, i64 T, const u64 *qs_
         }
 #undef CH_NCH
 #undef CH_LAUNCH
+        delete prof;
         KERNEL_CHECK();
         bool in_tmp = false, coop = false;
         const int end_bit = CHAIN_IDX_BITS + 8 * ((n + 7) / 8);

@@ -710,7 +710,10 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     }
     a.out_rows = reinterpret_cast<u32x4 *>(res->rows); a.out_coeff = res->coeff; a.out_hash = res->hash;
     __atomic_store_n(&hcnt->dup, 0xFFFFFFFFu, __ATOMIC_RELEASE);                   // poison: the kernel must report
-    hipLaunchKernelGGL(res_kernel(clifford, Wq), dim3((unsigned)G), dim3(RES_THREADS), (size_t)L.total, st, a);
+    {
+        ProfScope prof(4);
+        hipLaunchKernelGGL(res_kernel(clifford, Wq), dim3((unsigned)G), dim3(RES_THREADS), (size_t)L.total, st, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { symgpu_op_free(res); c.res_dirty = true; return hip_fail(e, "rotate resident", __FILE__, __LINE__); }
     // The last workgroup to leave writes the counts and then the status word into pinned host memory: poll that word instead of

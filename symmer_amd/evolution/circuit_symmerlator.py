@@ -41,8 +41,13 @@ class CircuitSymmerlator:
         wq = packing.words_per_block(self.n_qubits)
         row = np.zeros((1, 2 * wq), dtype='<u8')
         for i, P in zip(indices, pauli):
-            assert 0 <= i < self.n_qubits, 'qubit index out of range'
+            # the reference fills a list of characters (R[i] = P, circuit_symmerlator.py:38-40): negative indices count from the
+            # end and a repeated index keeps the LAST letter — so both bits of the qubit are cleared before they are set
+            assert -self.n_qubits <= i < self.n_qubits, 'qubit index out of range'
+            i %= self.n_qubits
             bit = np.uint64(1) << np.uint64(i & 63)
+            row[0, i >> 6] &= ~bit
+            row[0, wq + (i >> 6)] &= ~bit
             if P in 'XY':
                 row[0, i >> 6] |= bit
             if P in 'ZY':

@@ -151,31 +151,35 @@ class PauliwordOp:
     def copy(self) -> "PauliwordOp":
         return deepcopy(self)
 
+    def _xz_score(self, wx: int, wz: int) -> np.ndarray:
+        """Per term: wx * (number of X bits) + wz * (number of Z bits)."""
+        return wx * self.X_block.sum(axis=1, dtype=int) + wz * self.Z_block.sum(axis=1, dtype=int)
+
+    def _support_order(self) -> np.ndarray:
+        occupied = np.ascontiguousarray(self.X_block | self.Z_block)
+        as_bytes = occupied.view(np.dtype((np.void, occupied.shape[1] * occupied.dtype.itemsize))).ravel()
+        return np.argsort(as_bytes)[::-1]
+
+    # the orderings of the reference's ``sort`` (base.py:455-492) as a table: name -> term order for key='decreasing'.  The same
+    # NumPy sorts on the same score vectors as the reference, so ties fall the same way.
+    _ORDERINGS = {
+        'magnitude': lambda P: np.argsort(-abs(P.coeff_vec)),
+        'lex': lambda P: np.lexsort(P.symp_matrix.T) if P.n_terms else np.zeros(0, dtype=int),    # last column = primary key
+        'weight': lambda P: np.argsort(-P.symp_matrix.sum(axis=1, dtype=int)),
+        'support': lambda P: P._support_order(),
+        'Z': lambda P: np.argsort(P._xz_score(P.n_qubits + 1, 1)),
+        'X': lambda P: np.argsort(P._xz_score(1, P.n_qubits + 1)),
+        'Y': lambda P: np.argsort(np.abs(P.X_block.astype(int) - P.Z_block.astype(int)).sum(axis=1)),
+    }
+
     def sort(self, by: str = 'magnitude', key: str = 'decreasing') -> "PauliwordOp":
-        """base.py:455-492; ``'lex'`` is ``np.lexsort(symp_matrix.T)`` (last column = primary key)."""
-        if by == 'magnitude':
-            sort_order = np.argsort(-abs(self.coeff_vec))
-        elif by == 'lex':
-            sort_order = np.lexsort(self.symp_matrix.T) if self.n_terms else np.zeros(0, dtype=int)
-        elif by == 'weight':
-            sort_order = np.argsort(-np.sum(self.symp_matrix.astype(int), axis=1))
-        elif by == 'support':
-            occ = np.logical_or(self.X_block, self.Z_block)
-            view = np.ascontiguousarray(occ).view(np.dtype((np.void, occ.dtype.itemsize * occ.shape[1])))
-            sort_order = np.argsort(view.ravel())[::-1]
-        elif by == 'Z':
-            sort_order = np.argsort(np.sum((self.n_qubits + 1) * self.X_block.astype(int) + self.Z_block.astype(int), axis=1))
-        elif by == 'X':
-            sort_order = np.argsort(np.sum(self.X_block.astype(int) + (self.n_qubits + 1) * self.Z_block.astype(int), axis=1))
-        elif by == 'Y':
-            sort_order = np.argsort(np.sum(abs(self.X_block.astype(int) - self.Z_block.astype(int)), axis=1))
-        else:
+        """Terms re-ordered by one of ``_ORDERINGS`` (``__eq__`` relies on ``'lex'``); same names and errors as base.py:455-492."""
+        if by not in self._ORDERINGS:
             raise ValueError('Only permitted sort by values are magnitude, weight, X, Y or Z')
-        if key == 'increasing':
-            sort_order = sort_order[::-1]
-        elif key != 'decreasing':
+        if key not in ('increasing', 'decreasing'):
             raise ValueError('Only permitted sort by values are increasing or decreasing')
-        return self._derive(index=sort_order)
+        order = self._ORDERINGS[by](self)
+        return self._derive(index=order[::-1] if key == 'increasing' else order)
 
     def reindex(self, qubit_map) -> "PauliwordOp":
         """base.py:493-521: relabel qubits; ``{0: 2, 2: 3, 3: 0}`` or the list ``[2, 3, 0]`` (sorted values -> listed values):

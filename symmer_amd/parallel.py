@@ -152,7 +152,8 @@ class _TcpControl:
 
 class _stdout_to_stderr:
     """RCCL prints a version banner on file descriptor 1 when a communicator is created; callers such as bench.py promise ONE
-    JSON line on stdout, so the C-level stdout is pointed at stderr while RCCL initialises."""
+    JSON line on stdout, so the C-level stdout is pointed at stderr while RCCL initialises.  The redirect is process wide, so it
+    is only ever entered and left on the MAIN thread (never inside a watchdog thread that may not come back)."""
 
     def __enter__(self):
         import sys
@@ -171,6 +172,37 @@ class _stdout_to_stderr:
         return False
 
 
+class CollectiveHang(RuntimeError):
+    """A collective did not return on some rank within its time limit.  The stream it was enqueued on cannot be used again, so
+    there is no data plane to fall back to in this process: every rank raises this after the ranks have agreed, and the caller
+    (bench.py) reports it and ends the process with a non-zero status."""
+
+
+def _run_with_watchdog(fn, timeout):
+    """Run ``fn()`` on a daemon thread and wait at most ``timeout`` seconds for it, with file descriptor 1 pointed at stderr for
+    the duration (on THIS thread, restored whatever happens to the worker).  Returns (status, error text, thread): status 0 =
+    returned, 1 = raised, 2 = still running."""
+    import threading
+    result = {}
+
+    def _body():
+        try:
+            fn()
+            result['ok'] = True
+        except Exception as exc:                               # noqa: BLE001 - reported through the caller's agreement
+            result['error'] = str(exc) or type(exc).__name__
+
+    th = threading.Thread(target=_body, daemon=True)
+    with _stdout_to_stderr():
+        th.start()
+        th.join(timeout)
+    if th.is_alive():
+        return 2, 'did not return within the time limit', th
+    if 'error' in result:
+        return 1, result['error'], None
+    return 0, None, None
+
+
 class Communicator:
     def __init__(self, rank=0, world=1, data_plane='none'):
         self.rank, self.world, self.data_plane = rank, world, data_plane
@@ -179,6 +211,9 @@ class Communicator:
         self.rccl_error = None
         self.degraded = None      # text when the data plane is not the one asked for (host-staged instead of RCCL)
         self.gathers = False      # True when the right operand must be assembled with the all-gather
+        self._hung_thread = None  # a watchdog thread that is still inside RCCL: the communicator must not be destroyed under it
+        self._gather_checked = False   # the first all-gather runs under a watchdog and is agreed on by all ranks
+        self.needs_hard_exit = False
 
     # ---- construction ------------------------------------------------------------------------------------
     @classmethod
@@ -249,30 +284,20 @@ class Communicator:
             return self._fallback(local or 'rank 0 could not create an RCCL unique id')
         # ncclCommInitRank is collective and has no timeout of its own: run it on a watchdog thread, so that a bring-up that never
         # returns on some rank (fabric / IPC trouble) ends in the host-staged plane and a `degraded` line instead of a hung job
-        import threading
         raw = (ctypes.c_uint8 * 128)(*ident)
-        result = {}
-
-        def _init():
-            try:
-                with _stdout_to_stderr():
-                    _lib.check(_lib.lib().symgpu_comm_init(ctypes.addressof(raw), self.rank, self.world))
-                result['ok'] = True
-            except Exception as exc:                               # noqa: BLE001 - reported through the agreement below
-                result['error'] = str(exc)
-        th = threading.Thread(target=_init, daemon=True)
-        th.start()
-        th.join(float(os.environ.get('SYMGPU_RCCL_INIT_TIMEOUT', '180')))
-        hung = th.is_alive()
-        if hung:
-            local = 'ncclCommInitRank did not return within the time limit'
-        elif 'error' in result:
-            local = result['error']
+        status, err, th = _run_with_watchdog(lambda: _lib.check(_lib.lib().symgpu_comm_init(ctypes.addressof(raw), self.rank, self.world)),
+                                             float(os.environ.get('SYMGPU_RCCL_INIT_TIMEOUT', '180')))
+        if status == 2:
+            # given up: should ncclCommInitRank come back later, the library destroys its communicator instead of installing it
+            _lib.load().symgpu_comm_abandon()
+            self._hung_thread = th
+            local = 'ncclCommInitRank ' + err
+        elif status == 1:
+            local = err
         if self.max_over_ranks(1.0 if local else 0.0) > 0.0:
             if local is None:
                 _lib.load().symgpu_comm_destroy()
             return self._fallback(local or 'RCCL initialisation failed on another rank')
-        del hung
 
     # ---- control plane -----------------------------------------------------------------------------------
     def barrier(self):
@@ -298,10 +323,35 @@ class Communicator:
         if not self.gathers:
             raise ValueError('allgather_op without a communicator: use the shard directly')
         if self.data_plane == 'rccl':
-            _lib.check(_lib.lib().symgpu_comm_allgather_op(shard.handle, full.handle))
-        else:
+            def gather():
+                _lib.check(_lib.lib().symgpu_comm_allgather_op(shard.handle, full.handle))
+            if self._gather_checked:
+                gather()
+            else:
+                def first():
+                    gather()
+                    _lib.check(_lib.lib().symgpu_sync())            # the collective is asynchronous: a hang shows at the synchronisation
+                self._first_gather(first)
+        if self.data_plane != 'rccl':
             self._allgather_op_host(shard, full)
         full.set_rows(n_rows_total)
+
+    def _first_gather(self, do_gather):
+        """The first collective after the bring-up, under a watchdog, followed by an agreement of all ranks (the same pattern as the
+        initialisation): every rank returned -> RCCL stays; an error on any rank -> all ranks destroy their communicator and use
+        the host-staged plane (the caller then gathers through it); no return within SYMGPU_RCCL_GATHER_TIMEOUT seconds on any
+        rank -> :class:`CollectiveHang` on every rank."""
+        from . import _lib
+        status, err, th = _run_with_watchdog(do_gather, float(os.environ.get('SYMGPU_RCCL_GATHER_TIMEOUT', '120')))
+        if status == 2:
+            self._hung_thread = th
+        worst = int(self.max_over_ranks(float(status)))
+        self._gather_checked = True
+        if worst == 2:
+            raise CollectiveHang('the first RCCL all-gather ' + (err if status == 2 else 'did not return on another rank'))
+        if worst == 1:
+            _lib.load().symgpu_comm_destroy()
+            self._fallback(('the first RCCL all-gather failed: ' + err) if status == 1 else 'the first RCCL all-gather failed on another rank')
 
     def verify_allgather(self, shard, full, n_rows_total):
         """Self-check of the RCCL data plane (call once, outside any timed region): gather the same shards a second time through
@@ -377,7 +427,8 @@ class Communicator:
         return np.concatenate([p.numpy() for p in parts], axis=0)[:n_rows_total].view('<u8')
 
     def close(self):
-        if self.data_plane == 'rccl' and self.gathers:
+        hung = self._hung_thread is not None and self._hung_thread.is_alive()
+        if self.data_plane == 'rccl' and self.gathers and not hung:
             from . import _lib
             _lib.load().symgpu_comm_destroy()
         if self._tcp is not None:
@@ -388,6 +439,17 @@ class Communicator:
             self._dist.barrier()
             self._dist.destroy_process_group()
             self._dist = None
+        # a thread of this process still inside RCCL: tearing the runtime down under it at interpreter exit can crash or hang — the
+        # caller should finish its output and then leave through hard_exit_if_hung()
+        self.needs_hard_exit = hung
+
+    def hard_exit_if_hung(self, status=0):
+        """Call after the last line of output: if a watchdog thread never came back from RCCL, end the process without running the
+        finalisers (library shutdown under a thread that is inside RCCL is not safe)."""
+        if getattr(self, 'needs_hard_exit', False):
+            import sys
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(status)
 
 
 def padded_random_shard(my_rows, ts, n_qubits, seed):

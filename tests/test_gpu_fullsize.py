@@ -195,3 +195,106 @@ def test_bench_adjacency_workload_schema():
     assert d['scaling'] == 'strong' and d['config']['workload'] == 'commutes_termwise_adjacency' and d['config']['pairs_per_step'] == 30000 ** 2
     assert d['value'] > 0 and d['roofline']['bound'] == 'hbm' and d['roofline']['launches'] == 2 * 2      # two 25,000-row slabs per step
     assert 0 < d['roofline']['lds']['frac'] < 1
+
+
+def _bit_column_counts(rows):
+    """Number of set bits per bit column of packed rows uint64[T, W] -> int64[W * 64]."""
+    bits = np.unpackbits(rows.view(np.uint8), axis=1, bitorder='little')
+    return bits.sum(axis=0, dtype=np.int64)
+
+
+def test_northstar_product_every_slab_of_the_bench_step():
+    """What `bench.py` (default workload) runs — ALL 391 slabs of the 1,000-qubit 10^5 x 10^5 product, 256 outer rows each — checked
+    through size-independent properties computed in O(N + M) from the operands:
+      * popcount of every slab: sum_{i,o} |a_i ^ b_o| = sum_bits [cnt_a (n_o - cnt_b) + (N - cnt_a) cnt_b]   (exact, per slab)
+      * XOR fold of every slab (linearity): 0 for even row counts, else the fold of the other operand
+      * sum of the slab's coefficients against the C oracle's on 16 random slabs (phases included), and rows + coefficients
+        bit for bit on a 2-row piece of each of them."""
+    lib = _lib.lib()
+    n, Ni, No, slab = 1000, 100000, 100000, 256
+    A = DeviceOp.random(Ni, n, 0.3, seed=1234); B = DeviceOp.random(No, n, 0.3, seed=99991)
+    a_rows, a_c = A.download(); b_rows, b_c = B.download()
+    W = a_rows.shape[1]
+    cnt_a = _bit_column_counts(a_rows)
+    fold_a = np.bitwise_xor.reduce(a_rows, axis=0)
+    out = DeviceOp.alloc(slab * Ni, W // 2, with_coeff=True)
+    t, wq, cap = out.info()
+    rng = np.random.default_rng(5)
+    sampled = set(rng.choice((No + slab - 1) // slab, 16, replace=False).tolist())
+    pop = ctypes.c_uint64(0)
+    rows_ptr = ctypes.c_void_p()
+    for k, o0 in enumerate(range(0, No, slab)):
+        o1 = min(No, o0 + slab)
+        _lib.check(lib.symgpu_mul_allpairs_dev(A.handle, B.handle, o0, o1, 1, out.handle))
+        assert out.n_terms == (o1 - o0) * Ni
+        cnt_b = _bit_column_counts(b_rows[o0:o1])
+        expect_pop = int(np.sum(cnt_a * ((o1 - o0) - cnt_b) + (Ni - cnt_a) * cnt_b))
+        _lib.check(lib.symgpu_op_popcount(out.handle, ctypes.addressof(pop)))
+        assert pop.value == expect_pop, (k, pop.value, expect_pop)
+        x, csum = out.checksum()
+        expect = np.zeros(W, dtype='<u8')
+        if (o1 - o0) % 2:
+            expect ^= fold_a
+        if Ni % 2:
+            expect ^= np.bitwise_xor.reduce(b_rows[o0:o1], axis=0)
+        assert np.array_equal(x, expect), k
+        if k in sampled:
+            ec = oc.mul_allpairs_coeff(a_rows, a_c, b_rows[o0:o1], b_c[o0:o1], True)
+            assert abs(csum - ec.sum()) <= 1e-9 * np.abs(ec).sum(), k
+    # exact rows + coefficients of a 2-row piece of 16 random places
+    for o0 in rng.choice(No - 2, 16, replace=False).tolist():
+        _lib.check(lib.symgpu_mul_allpairs_dev(A.handle, B.handle, o0, o0 + 2, 1, out.handle))
+        rows, coeff = out.download()
+        er, ec = oc.mul_allpairs(a_rows, a_c, b_rows[o0:o0 + 2], b_c[o0:o0 + 2], True)
+        assert np.array_equal(rows, er) and np.array_equal(coeff, ec)
+    for h in (A, B, out):
+        h.free()
+
+
+def test_cfg5_whole_adjacency_one_launch():
+    """What `bench.py --workload adjacency` runs on one GPU — the 200,000 x 200,000 adjacency of a 2,000-qubit operator in ONE
+    launch into a 40 GB np.bool_ result:
+      * the byte sum of every 10,000-row band equals the popcount of the same band computed a second time as BIT-PACKED rows
+        (another epilogue of the kernel) — and both lie near one half
+      * symmetry: 24 sampled 256 x 256 blocks equal the transposes of their mirror blocks, diagonal blocks have a unit diagonal
+      * 16 random 256 x 256 blocks are exactly the C oracle's commutes() of the corresponding rows."""
+    lib = _lib.lib()
+    n, T = 2000, 200000
+    free_b, total_b = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(lib.symgpu_mem_info(ctypes.addressof(free_b), ctypes.addressof(total_b)))
+    if free_b.value < 60 * (1 << 30):
+        pytest.skip('needs 60 GB of free HBM')
+    A = DeviceOp.random(T, n, 0.3, seed=555)
+    a_rows = A.download(with_coeff=False)
+    buf = ctypes.c_void_p()
+    _lib.check(lib.symgpu_dev_alloc(T * T, ctypes.byref(buf)))
+    _lib.check(lib.symgpu_commutes_dev(A.handle, 0, T, A.handle, buf))
+    band = 10000
+    wpr = (T + 63) // 64
+    bits = ctypes.c_void_p()
+    _lib.check(lib.symgpu_dev_alloc(band * wpr * 8, ctypes.byref(bits)))
+    s_bytes, s_bits = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    total = 0
+    for r0 in range(0, T, band):
+        _lib.check(lib.symgpu_dev_checksum_u8(ctypes.c_void_p(buf.value + r0 * T), band * T, ctypes.addressof(s_bytes)))
+        _lib.check(lib.symgpu_commutes_bits_dev(A.handle, r0, r0 + band, A.handle, bits))
+        _lib.check(lib.symgpu_dev_popcount_u64(bits, band * wpr, ctypes.addressof(s_bits)))
+        assert s_bytes.value == s_bits.value, r0
+        total += s_bytes.value
+    assert 0.49 < total / (T * T) < 0.51
+
+    def block(r0, c0, h=256, w=256):
+        out = np.empty((h, w), dtype=np.uint8)
+        for k in range(h):
+            _lib.check(lib.symgpu_dev_download(ctypes.c_void_p(buf.value + (r0 + k) * T + c0), out[k].ctypes.data, w))
+        return out
+    rng = np.random.default_rng(9)
+    for _ in range(24):
+        r0, c0 = (int(v) for v in rng.integers(0, T - 256, 2))
+        assert np.array_equal(block(r0, c0), block(c0, r0).T)
+    for d in (0, 77777, T - 256):
+        assert np.all(np.diag(block(d, d)) == 1)
+    for _ in range(16):
+        r0, c0 = (int(v) for v in rng.integers(0, T - 256, 2))
+        assert np.array_equal(block(r0, c0).astype(bool), oc.commutes(a_rows[r0:r0 + 256], a_rows[c0:c0 + 256]))
+    _lib.check(lib.symgpu_dev_free(buf)); _lib.check(lib.symgpu_dev_free(bits)); A.free()

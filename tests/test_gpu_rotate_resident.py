@@ -171,3 +171,30 @@ def test_register_chain_equals_multilaunch_chain_and_oracle(n, T, K, monkeypatch
         assert np.array_equal(ra, packing.pack_rows(es)) and np.array_equal(ca, ec)
     for h in (a, b, dev):
         h.free()
+
+
+@pytest.mark.parametrize('n,T,K', [(1000, 90, 30), (1000, 128, 25), (100, 3000, 20), (64, 9000, 9), (1000, 300000 // 1000 * 10, 12)])
+def test_every_chain_form_gives_the_same_run_in_one_process(n, T, K, monkeypatch):
+    """The path-selection switches are read on every call: the LDS-resident single-workgroup kernel, the L2-resident
+    one, the two-launch and the four-launch forms and the register chain must all return the same rows, order and coefficients."""
+    rng = np.random.default_rng(31000 + n + T)
+    symp, c = onp.cleanup_op(rng.random((T, 2 * n)) < 0.3, dyadic(rng, T))
+    up = DeviceOp.upload(packing.pack_rows(symp), c)
+    dev = kernels.cleanup_dev(up)
+    up.free()
+    qs = packing.pack_rows(rng.random((K, 2 * n)) < 0.3)
+    ks = rng.integers(0, 4, K).astype(np.int32)
+    forms = [{}, {'SYMGPU_CHAIN_REG': '0'}, {'SYMGPU_CHAIN_REG': '0', 'SYMGPU_CHAIN_LDS': '0'}, {'SYMGPU_CHAIN_REG': '0', 'SYMGPU_CHAIN_LOCAL_T': '0'},
+             {'SYMGPU_CHAIN_REG': '0', 'SYMGPU_CHAIN_LOCAL_T': '0', 'SYMGPU_CHAIN_TWO': '0'}, {'SYMGPU_CHAIN_LOCAL_T': '0'}]
+    results = []
+    for env in forms:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = kernels.rotate_clifford_chain_dev(dev, qs, ks)
+        results.append(out.download())
+        out.free()
+        for k in env:
+            monkeypatch.delenv(k)
+    for r, cc in results[1:]:
+        assert np.array_equal(r, results[0][0]) and np.array_equal(cc, results[0][1])
+    dev.free()

@@ -173,3 +173,23 @@ def test_packed_results_are_not_expanded_until_asked():
     assert np.array_equal(sub.symp_matrix, symp[[4, 1, 2, 3, 4]]) and np.array_equal(sub.coeff_vec, np.hstack([2 * coeff[[4, 1]], coeff[2:5]]))
     assert np.array_equal(op.symp_matrix, symp) and np.array_equal(op.X_block, symp[:, :70]) and np.array_equal(op.Z_block, symp[:, 70:])
     assert np.array_equal(op.dagger.coeff_vec, coeff.conjugate())
+
+
+def test_circuit_rotation_string_last_write_wins_and_negative_indices():
+    """reference evolution/circuit_symmerlator.py:38-40 fills a list of characters: a repeated index keeps the LAST letter and
+    negative indices count from the end."""
+    from symmer_amd.evolution import CircuitSymmerlator
+    C = CircuitSymmerlator(70)
+
+    def letters(op):
+        m = np.asarray(op.symp_matrix)[0]
+        return ''.join('IXZY'[int(m[i]) + 2 * int(m[70 + i])] for i in range(70))
+    assert letters(C.get_rotation_string('XZ', [0, 0])) == 'Z' + 'I' * 69
+    assert letters(C.get_rotation_string('YX', [3, 3])) == 'III' + 'X' + 'I' * 66
+    assert letters(C.get_rotation_string('ZI', [65, 65])) == 'I' * 70
+    assert letters(C.get_rotation_string('Y', [-1])) == 'I' * 69 + 'Y'
+    assert letters(C.get_rotation_string('XZ', [-70, 64])) == 'X' + 'I' * 63 + 'Z' + 'I' * 5
+    with pytest.raises(AssertionError):
+        C.get_rotation_string('X', [70])
+    with pytest.raises(AssertionError):
+        C.get_rotation_string('X', [-71])

@@ -166,3 +166,69 @@ def test_rccl_failure_is_agreed_across_ranks(disable_on):
         p.join(timeout=30)
     for rank, ok, err in res:
         assert ok, f'rank {rank} failed: {err}'
+
+
+def _first_gather_worker(rank, world, port, q, mode):
+    """No GPU here: the collective itself is a stand-in callable; what is under test is the watchdog + agreement around the first
+    all-gather (symmer_amd/parallel.py::Communicator._first_gather): 'error' = it raises on rank 1, 'hang' = it never returns on
+    rank 1, 'ok' = it returns everywhere."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                          SYMGPU_RCCL_GATHER_TIMEOUT='2')
+        import time
+        from symmer_amd import parallel
+        comm = parallel.Communicator.from_env(data_plane='none', control='tcp')
+        comm.data_plane, comm.gathers = 'rccl', True             # as after a successful bring-up
+
+        def gather():
+            if rank == 1 and mode == 'error':
+                raise RuntimeError('RCCL error 5 (unhandled system error) in ncclAllGather(rows)')
+            if rank == 1 and mode == 'hang':
+                time.sleep(3600)
+
+        outcome = 'returned'
+        try:
+            comm._first_gather(gather)
+        except parallel.CollectiveHang as exc:
+            outcome = 'hang:' + str(exc)
+        if mode == 'ok':
+            ok = outcome == 'returned' and comm.data_plane == 'rccl' and comm.degraded is None and comm._gather_checked
+        elif mode == 'error':
+            ok = outcome == 'returned' and comm.data_plane == 'host-staged' and bool(comm.degraded) and 'all-gather failed' in comm.degraded
+            # the fallback's transport still works on both ranks
+            got = comm._allgather_bytes(bytes([rank + 7]) * 100)
+            ok = ok and got == b''.join(bytes([r + 7]) * 100 for r in range(world))
+        else:
+            ok = outcome.startswith('hang:')                       # on BOTH ranks, although the gather returned on rank 0
+            ok = ok and ((rank == 1) == (comm._hung_thread is not None))
+        if mode != 'hang':
+            comm.barrier()
+        comm.data_plane = 'none' if mode == 'ok' else comm.data_plane      # nothing to destroy: there never was a communicator
+        comm.close()
+        ok = ok and comm.needs_hard_exit == (mode == 'hang' and rank == 1)
+        q.put((rank, ok, '' if ok else f'outcome={outcome} plane={comm.data_plane} degraded={comm.degraded}'))
+        if comm.needs_hard_exit:
+            q.close(); q.join_thread()
+            comm.hard_exit_if_hung(0)
+    except Exception:                                         # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize('mode', ['ok', 'error', 'hang'])
+def test_first_gather_is_watched_and_agreed(mode):
+    """the first ncclAllGather can hang or fail on one rank only; no rank may be left waiting."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_first_gather_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        assert not p.is_alive(), 'a rank did not leave'
+    for rank, ok, err in res:
+        assert ok, f'rank {rank} failed ({mode}): {err}'
