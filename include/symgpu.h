@@ -77,6 +77,8 @@ int symgpu_op_set_rows(symgpu_op_t op, int64_t T);   /* trim (T <= capacity), e.
 /* host rows (+ coefficients if both sides have them) -> rows [row_offset, row_offset + count) of an existing operator
  * (within its capacity; T grows to cover them).  Used by the host-staged all-gather. */
 int symgpu_op_write(symgpu_op_t op, int64_t row_offset, const uint64_t *rows, const double *coeff /* may be NULL */, int64_t count);
+/* device-to-device: rows (and coefficients, if both have them) src[src_offset .. +count) -> dst[dst_offset ..); stream ordered */
+int symgpu_op_copy_rows(symgpu_op_t dst, int64_t dst_offset, symgpu_op_t src, int64_t src_offset, int64_t count);
 int symgpu_op_random(int64_t T, int n_qubits, double density, uint64_t seed, symgpu_op_t *out); /* synthetic input, generated on device */
 /* XOR-fold of all packed rows (2*Wq words) and plain sum of coefficients: size-independent checksums */
 int symgpu_op_checksum(symgpu_op_t op, uint64_t *xor_words /* [2*Wq] */, double *coeff_sum /* [2] */);

@@ -62,6 +62,7 @@ SIGNATURES = {
     'symgpu_dev_checksum_u8': [P, c_i64, P],
     'symgpu_dev_popcount_u64': [P, c_i64, P],
     'symgpu_op_popcount': [P, P],
+    'symgpu_op_copy_rows': [P, c_i64, P, c_i64, c_i64],
     'symgpu_mul_allpairs': [P, P, c_i64, P, P, c_i64, c_int, c_int, P, P],
     'symgpu_mul_allpairs_dev': [P, P, c_i64, c_i64, c_int, P],
     'symgpu_cleanup': [P, P, c_i64, c_int, c_dbl, c_int, P, P, c_i64, P],

@@ -6,6 +6,7 @@
 #include <vector>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <map>
 #include <vector>
@@ -47,13 +48,24 @@ int require_ctx() {
     return SYMGPU_OK;
 }
 
-// ---- cached allocator: power-of-two-ish size classes, blocks kept until shutdown/release ----------
+// ---- cached allocator ------------------------------------------------------------------------------------------------------
+// Size classes (power-of-two-ish), freed blocks parked per class until shutdown / release.  A class that has no parked block is
+// carved from an ARENA — 4 GiB chunks, bump pointer, blocks up to 1 GiB — instead of going to hipMalloc (100 us .. 10 ms per call):
+// a chain of rotations whose term count grows meets a new size class with every step, and with the arena its first pass costs what
+// every later pass costs (round 2 needed a warm-up pass in the bench for that).  Carved blocks are never returned to the runtime
+// one by one; a chunk is released as a whole when none of its blocks is in use (dev_cache_release).
 static std::mutex g_alloc_mu;
-static std::multimap<size_t, void *> g_free;      // size class -> block
-static std::map<void *, size_t> g_live;           // block -> size class
+static std::multimap<size_t, void *> g_free;      // size class -> parked block
+struct LiveBlock { size_t cls; int chunk; };      // chunk: index into g_chunks, -1 = its own hipMalloc
+static std::map<void *, LiveBlock> g_live;        // block in use -> class / origin
+static std::map<void *, int> g_parked_chunk;      // parked block -> origin (only arena blocks)
+struct Chunk { char *base; size_t size, used; i64 live; };
+static std::vector<Chunk> g_chunks;
 static size_t g_cached_bytes = 0;
 static size_t g_cache_limit = (size_t)64 << 30;       // parked blocks: at most 64 GiB, raised to half of the device memory at init
                                                         // (hipMalloc / hipFree of multi-GB blocks cost ~10 ms per GB)
+static const size_t ARENA_CHUNK = (size_t)4 << 30, ARENA_MAX_BLOCK = (size_t)1 << 30;
+static bool g_arena_on = true;
 
 static size_t size_class(size_t b) {
     if (b < 256) b = 256;
@@ -70,6 +82,29 @@ static size_t size_class(size_t b) {
     return (b + step - 1) / step * step;
 }
 
+// carve `c` bytes (a multiple of 256) from the arena; nullptr if the arena is off, the block is too large or memory is short
+static void *arena_carve(size_t c, int *chunk) {
+    if (!g_arena_on || c > ARENA_MAX_BLOCK) return nullptr;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = (int)g_chunks.size() - 1; i >= 0; --i) {
+            Chunk &ch = g_chunks[i];
+            if (ch.base && ch.size - ch.used >= c) {
+                void *p = ch.base + ch.used;
+                ch.used += c;
+                ++ch.live;
+                *chunk = i;
+                return p;
+            }
+        }
+        if (pass == 1) break;
+        void *base = nullptr;
+        ++g_counters[3];
+        if (hipMalloc(&base, ARENA_CHUNK) != hipSuccess) { (void)hipGetLastError(); g_arena_on = false; return nullptr; }
+        g_chunks.push_back(Chunk{static_cast<char *>(base), ARENA_CHUNK, 0, 0});
+    }
+    return nullptr;
+}
+
 int dev_alloc(size_t bytes, void **ptr) {
     SG_TRY(require_ctx());
     size_t c = size_class(bytes);
@@ -80,7 +115,16 @@ int dev_alloc(size_t bytes, void **ptr) {
             *ptr = it->second;
             g_free.erase(it);
             g_cached_bytes -= c;
-            g_live[*ptr] = c;
+            int chunk = -1;
+            auto pc = g_parked_chunk.find(*ptr);
+            if (pc != g_parked_chunk.end()) { chunk = pc->second; g_parked_chunk.erase(pc); ++g_chunks[chunk].live; }
+            g_live[*ptr] = LiveBlock{c, chunk};
+            return SYMGPU_OK;
+        }
+        int chunk = -1;
+        if (void *p = arena_carve(c, &chunk)) {
+            *ptr = p;
+            g_live[p] = LiveBlock{c, chunk};
             return SYMGPU_OK;
         }
     }
@@ -98,7 +142,7 @@ int dev_alloc(size_t bytes, void **ptr) {
         }
     }
     std::lock_guard<std::mutex> lk(g_alloc_mu);
-    g_live[*ptr] = c;
+    g_live[*ptr] = LiveBlock{c, -1};
     return SYMGPU_OK;
 }
 
@@ -110,14 +154,19 @@ int dev_free(void *ptr) {
         set_error("dev_free: unknown pointer");
         return SYMGPU_E_INVALID;
     }
-    size_t c = it->second;
+    const LiveBlock blk = it->second;
     g_live.erase(it);
-    if (g_cached_bytes + c > g_cache_limit) {
+    if (blk.chunk >= 0) {                              // arena block: parked, whatever the limit says (it cannot go back on its own)
+        --g_chunks[blk.chunk].live;
+        g_parked_chunk[ptr] = blk.chunk;
+        g_free.insert({blk.cls, ptr});
+        g_cached_bytes += blk.cls;
+    } else if (g_cached_bytes + blk.cls > g_cache_limit) {
         // stream-ordered safety: everything runs on one stream, but hipFree synchronises anyway
         (void)hipFree(ptr);
     } else {
-        g_free.insert({c, ptr});
-        g_cached_bytes += c;
+        g_free.insert({blk.cls, ptr});
+        g_cached_bytes += blk.cls;
     }
     return SYMGPU_OK;
 }
@@ -125,9 +174,22 @@ int dev_free(void *ptr) {
 void dev_cache_release() {
     std::lock_guard<std::mutex> lk(g_alloc_mu);
     if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
-    for (auto &kv : g_free) (void)hipFree(kv.second);
-    g_free.clear();
-    g_cached_bytes = 0;
+    for (auto it = g_free.begin(); it != g_free.end();) {
+        auto pc = g_parked_chunk.find(it->second);
+        if (pc == g_parked_chunk.end()) {              // its own hipMalloc
+            (void)hipFree(it->second);
+            g_cached_bytes -= it->first;
+            it = g_free.erase(it);
+        } else if (g_chunks[pc->second].live == 0) {   // arena block of a chunk nobody uses: goes with its chunk below
+            g_cached_bytes -= it->first;
+            g_parked_chunk.erase(pc);
+            it = g_free.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    for (Chunk &ch : g_chunks)
+        if (ch.base && ch.live == 0) { (void)hipFree(ch.base); ch.base = nullptr; ch.size = ch.used = 0; }
 }
 
 // ---- per-launch profiling ---------------------------------------------------------------------------
@@ -321,6 +383,7 @@ int symgpu_init(int device) {
         size_t f = 0, t = 0;
         if (hipMemGetInfo(&f, &t) == hipSuccess && t / 2 > g_cache_limit) g_cache_limit = t / 2;
     }
+    if (const char *e = getenv("SYMGPU_ARENA")) g_arena_on = !(e[0] == '0');       // 0: every size class straight from hipMalloc (round 2's allocator)
     c.ready = true;
     return SYMGPU_OK;
 }
@@ -329,10 +392,11 @@ int symgpu_shutdown(void) {
     Context &c = ctx();
     if (!c.ready) return SYMGPU_OK;
     (void)hipStreamSynchronize(c.stream);
+    if (c.rot_table) { dev_free(c.rot_table); c.rot_table = nullptr; c.rot_table_cap = 0; c.rot_gen = 0; }
     dev_cache_release();
     if (c.hash_tab) { (void)hipFree(c.hash_tab); c.hash_tab = nullptr; }
     if (c.xs_pow) { (void)hipFree(c.xs_pow); c.xs_pow = nullptr; }
-    if (c.rot_table) { (void)hipFree(c.rot_table); c.rot_table = nullptr; c.rot_table_cap = 0; c.rot_gen = 0; }
+    if (c.rot_table) { dev_free(c.rot_table); c.rot_table = nullptr; c.rot_table_cap = 0; c.rot_gen = 0; }
     if (c.rot_flags) { (void)hipFree(c.rot_flags); c.rot_flags = nullptr; }
     if (c.rot_partner) { (void)hipFree(c.rot_partner); c.rot_partner = nullptr; c.rot_partner_cap = 0; }
     if (c.sort_state) { (void)hipFree(c.sort_state); c.sort_state = nullptr; c.sort_bar_base = 0; }
@@ -557,6 +621,22 @@ int symgpu_op_write(symgpu_op_t op, int64_t row_offset, const uint64_t *rows, co
     }
     op_invalidate(op);
     if (row_offset + count > op->T) op->T = row_offset + count;
+    return SYMGPU_OK;
+}
+
+int symgpu_op_copy_rows(symgpu_op_t dst, int64_t dst_offset, symgpu_op_t src, int64_t src_offset, int64_t count) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(dst && src && dst != src && dst->Wq == src->Wq, "op_copy_rows: handles");
+    SG_REQUIRE(count >= 0 && dst_offset >= 0 && src_offset >= 0 && dst_offset + count <= dst->capacity && src_offset + count <= src->T,
+               "op_copy_rows: row range");
+    const size_t W = (size_t)2 * dst->Wq;
+    if (count > 0) {
+        HIP_TRY(hipMemcpyAsync(dst->rows + (size_t)dst_offset * W, src->rows + (size_t)src_offset * W, (size_t)count * W * 8, hipMemcpyDeviceToDevice, ctx().stream));
+        if (dst->coeff && src->coeff)
+            HIP_TRY(hipMemcpyAsync(dst->coeff + 2 * (size_t)dst_offset, src->coeff + 2 * (size_t)src_offset, (size_t)count * 16, hipMemcpyDeviceToDevice, ctx().stream));
+    }
+    op_invalidate(dst);
+    if (dst_offset + count > dst->T) dst->T = dst_offset + count;
     return SYMGPU_OK;
 }
 

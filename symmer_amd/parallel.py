@@ -353,6 +353,50 @@ class Communicator:
             _lib.load().symgpu_comm_destroy()
             self._fallback(('the first RCCL all-gather failed: ' + err) if status == 1 else 'the first RCCL all-gather failed on another rank')
 
+    def mul_cleanup_sharded(self, inner_full, outer_block, inner_is_left=True, zero_threshold=1e-15):
+        """Fused product + cleanup of ``inner_full`` (all of one operand, on every rank — gather it with :meth:`allgather_op` if it
+        is sharded) with the OUTER operand sharded in contiguous blocks, ranks in order ("cleanup across GPUs").
+        Pair ``(i, o)`` has index ``o * Ni + i`` in the reference (``_multiply_by_operator``, base.py:764-794): with the outer index
+        sharded contiguously every pair of rank r precedes every pair of rank r + 1, so rank-major order IS the reference's order,
+        and the first-occurrence order / sequential sums of ``symplectic_cleanup`` (utils.py:271-278) are those of
+        (1) a local fused product + cleanup per rank WITHOUT threshold (a term may only cancel across ranks),
+        (2) an all-gather of the cleaned partial operators (padded to the longest, then compacted in rank order),
+        (3) one cleanup of the concatenation with the threshold — on every rank (the result is replicated).
+        Sums associate per rank (exact for dyadic coefficients, <= 1e-16 relative otherwise), as in the tiled ``kernels.mul_cleanup``.
+        Returns a DeviceOp."""
+        from . import _lib, kernels
+        lib = _lib.lib()
+        out = ctypes.c_void_p()
+        _lib.check(lib.symgpu_mul_cleanup_dev(inner_full.handle, outer_block.handle, 1 if inner_is_left else 0, 0.0, 0, ctypes.byref(out)))
+        part = kernels.DeviceOp(out)
+        if not self.gathers:
+            res = kernels.cleanup_dev(part, zero_threshold)
+            part.free()
+            return res
+        n_loc, wq, _ = part.info()
+        counts = np.frombuffer(self._allgather_bytes(np.int64(n_loc).tobytes()), dtype=np.int64)
+        ts = max(1, int(counts.max()))
+        shard = kernels.DeviceOp.alloc(ts, wq, with_coeff=True)
+        _lib.check(lib.symgpu_op_copy_rows(shard.handle, 0, part.handle, 0, n_loc))
+        shard.set_rows(n_loc)
+        part.free()
+        full = kernels.DeviceOp.alloc(ts * self.world, wq, with_coeff=True)
+        self.allgather_op(shard, full, ts * self.world)
+        shard.free()
+        # compact: rank r's rows [r * ts, r * ts + counts[r]) one after the other (the padding rows are identity rows with coefficient
+        # 0: left in place they would be harmless for the sums but could take the identity's first-occurrence position)
+        total = int(counts.sum())
+        cat = kernels.DeviceOp.alloc(max(1, total), wq, with_coeff=True)
+        pos = 0
+        for r in range(self.world):
+            _lib.check(lib.symgpu_op_copy_rows(cat.handle, pos, full.handle, r * ts, int(counts[r])))
+            pos += int(counts[r])
+        cat.set_rows(total)
+        full.free()
+        res = kernels.cleanup_dev(cat, zero_threshold)
+        cat.free()
+        return res
+
     def verify_allgather(self, shard, full, n_rows_total):
         """Self-check of the RCCL data plane (call once, outside any timed region): gather the same shards a second time through
         host memory over the control plane and compare them with the device result of ``allgather_op`` — rows and coefficients,
@@ -486,3 +530,29 @@ def sharded_product(a_rows_global, a_coeff_global, b_rows_local, b_coeff_local, 
     c_full = comm.allgather_rows_host(c.view('<u8'), n_b_total).view(np.float64).reshape(-1, 2).copy().view(np.complex128).reshape(-1)
     rows, coeff = kernel(np.ascontiguousarray(a_rows_global[b0:b1]), a_coeff_global[b0:b1], b_full, c_full, True)
     return (b0, b1), rows, coeff
+
+
+def sharded_mul_cleanup(inner_rows, inner_coeff, outer_rows_local, outer_coeff_local, comm, inner_is_left=True, zero_threshold=1e-15,
+                        mul_kernel=None, cleanup_kernel=None):
+    """Host arrays, gloo (CPU tests / the algorithm of :meth:`Communicator.mul_cleanup_sharded`): this rank holds ALL of the inner
+    operand and its contiguous block of the outer one (ranks in order).  ``mul_kernel(inner, ci, outer, co, inner_is_left, thr)`` =
+    fused product + cleanup (thr None: keep everything), ``cleanup_kernel(rows, coeff, thr)`` = first-occurrence cleanup; the CPU
+    tests inject the C oracle.  Returns the cleaned product (rows, coeff), identical on every rank."""
+    if mul_kernel is None or cleanup_kernel is None:
+        from . import kernels
+        mul_kernel = mul_kernel or (lambda a, ca, b, cb, left, thr: kernels.mul_cleanup(a, ca, b, cb, left, thr))
+        cleanup_kernel = cleanup_kernel or kernels.cleanup
+    rows, coeff = mul_kernel(inner_rows, inner_coeff, outer_rows_local, outer_coeff_local, inner_is_left, None)
+    rows = np.ascontiguousarray(rows, dtype='<u8'); coeff = np.ascontiguousarray(coeff, dtype=np.complex128)
+    if comm.world == 1:
+        return cleanup_kernel(rows, coeff, zero_threshold)
+    W = inner_rows.shape[1]
+    counts = np.frombuffer(comm._allgather_bytes(np.int64(rows.shape[0]).tobytes()), dtype=np.int64)
+    ts = max(1, int(counts.max()))
+    pad_r = np.zeros((ts, W), dtype='<u8'); pad_r[:rows.shape[0]] = rows
+    pad_c = np.zeros(ts, dtype=np.complex128); pad_c[:coeff.shape[0]] = coeff
+    all_r = np.frombuffer(comm._allgather_bytes(pad_r.tobytes()), dtype='<u8').reshape(comm.world, ts, W)
+    all_c = np.frombuffer(comm._allgather_bytes(pad_c.tobytes()), dtype=np.complex128).reshape(comm.world, ts)
+    cat_r = np.concatenate([all_r[r, :counts[r]] for r in range(comm.world)], axis=0)
+    cat_c = np.concatenate([all_c[r, :counts[r]] for r in range(comm.world)])
+    return cleanup_kernel(cat_r, cat_c, zero_threshold)

@@ -43,6 +43,22 @@ assert np.array_equal(kernels.commutes(lr[b0:b1], rows), oc.commutes(lr[b0:b1], 
 pr, pc = kernels.mul_allpairs(lr[b0:b1], lc[b0:b1], rows, coeff, True)
 er, ec = oc.mul_allpairs(lr[b0:b1], lc[b0:b1], exp_r, exp_c, True)
 assert np.array_equal(pr, er) and np.array_equal(pc, ec), 'product block mismatch'      # same un-fused IEEE expression on both sides
+# product + cleanup with the OUTER operand sharded (SURVEY 8e stretch): rows, row order and coefficients of the single-process oracle
+rng = np.random.default_rng(17)
+n2, Ni2, No2 = 70, 300, 201
+from oracle import oracle_np as onp
+A2 = onp.pack_rows(rng.random((Ni2, 2 * n2)) < 0.4); B2 = onp.pack_rows(rng.random((No2, 2 * n2)) < 0.4)
+A2[50:80] = A2[:30]; B2[100:120] = B2[:20]                    # duplicate rows: merges inside and across the ranks' blocks
+a2 = (rng.integers(-8, 9, Ni2) + 1j * rng.integers(-8, 9, Ni2)) / 16.0; b2 = (rng.integers(-8, 9, No2) + 1j * rng.integers(-8, 9, No2)) / 16.0
+_, ob = parallel.shard_bounds(No2, world)
+inner = DeviceOp.upload(A2, a2)
+outer = DeviceOp.upload(B2[ob[rank][0]:ob[rank][1]], b2[ob[rank][0]:ob[rank][1]])
+res = comm.mul_cleanup_sharded(inner, outer, True, 1e-15)
+rr, rc = res.download()
+er, ec = oc.mul(A2, a2, B2, b2)
+assert np.array_equal(rr, er) and np.array_equal(rc, ec), 'sharded product + cleanup differs from the oracle'
+for h in (inner, outer, res):
+    h.free()
 comm.barrier()
 plane = comm.data_plane
 comm.close()

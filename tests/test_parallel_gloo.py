@@ -232,3 +232,53 @@ def test_first_gather_is_watched_and_agreed(mode):
         assert not p.is_alive(), 'a rank did not leave'
     for rank, ok, err in res:
         assert ok, f'rank {rank} failed ({mode}): {err}'
+
+
+def _mul_cleanup_worker(rank, world, port, q):
+    """SURVEY 8e stretch: product + cleanup with the outer operand sharded — rows, ROW ORDER and coefficients
+    must equal the single-process oracle's (dyadic coefficients: bit for bit).  The per-rank kernels are the C oracle's."""
+    try:
+        sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        from symmer_amd import parallel
+        from oracle import oracle_c as oc, oracle_np as onp
+        comm = parallel.Communicator.from_env(data_plane='gloo-host', control='gloo')
+        ok = True
+        for case, (n, N, M) in enumerate([(3, 60, 41), (70, 50, 33), (5, 7, 1), (130, 40, 40)]):
+            rng = np.random.default_rng(900 + case)                   # same global operands on every rank
+            A = onp.pack_rows(rng.random((N, 2 * n)) < 0.4); B = onp.pack_rows(rng.random((M, 2 * n)) < 0.4)
+            if case == 0:
+                A[10:20] = A[:10]; B[5:9] = B[:4]                     # duplicate rows inside and across the ranks' blocks
+            a = (rng.integers(-8, 9, N) + 1j * rng.integers(-8, 9, N)) / 16.0; b = (rng.integers(-8, 9, M) + 1j * rng.integers(-8, 9, M)) / 16.0
+            # reference order: the operand with fewer terms is the outer one (base.py:847-852); N >= M here, so B is outer, A inner and left
+            _, bounds = parallel.shard_bounds(M, world)
+            m0, m1 = bounds[rank]
+
+            def mul_kernel(inner, ci, outer, co, left, thr):
+                r, c = oc.mul_allpairs(inner, ci, outer, co, left) if outer.shape[0] else (np.zeros((0, inner.shape[1]), dtype='<u8'), np.zeros(0, dtype=complex))
+                return oc.cleanup(r, c, thr) if r.shape[0] else (r, c)
+            rows, coeff = parallel.sharded_mul_cleanup(A, a, B[m0:m1], b[m0:m1], comm, True, 1e-15, mul_kernel=mul_kernel,
+                                                       cleanup_kernel=lambda r, c, thr: oc.cleanup(r, c, thr))
+            er, ec = oc.mul(A, a, B, b)
+            ok = ok and np.array_equal(rows, er) and np.array_equal(coeff, ec)
+        comm.close()
+        q.put((rank, bool(ok), ''))
+    except Exception:                                         # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_mul_cleanup_equals_the_oracle(world):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mul_cleanup_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, err in res:
+        assert ok, f'rank {rank} failed: {err}'

@@ -1,5 +1,5 @@
-import sys, time, ctypes, numpy as np
-sys.path.insert(0, '/root/repo')
+import sys, os, time, ctypes, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from symmer_amd import kernels, packing, _lib
 from symmer_amd.kernels import DeviceOp
 lib = _lib.lib()
