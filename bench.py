@@ -373,12 +373,13 @@ def wl_rotation(args, comm, rank, world, _lib, DeviceOp, parallel):
         if keep:
             keep.pop().free()
         keep.append(DeviceOp(h))
-    for k in range(max(2, args.warmup)):
+    ROT = 100                                                            # per-rotation time over >= 100 rotations, operator device resident
+    for k in range(max(1, args.warmup) * ROT):
         step(k)
     _lib.check(lib.symgpu_device_sync()); comm.barrier()
     _lib.check(lib.symgpu_prof_enable(4, 1))
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(args.steps * ROT):
         step(k)
     _lib.check(lib.symgpu_device_sync()); comm.barrier()
     dt = comm.max_over_ranks(time.perf_counter() - t0)
@@ -390,15 +391,15 @@ def wl_rotation(args, comm, rank, world, _lib, DeviceOp, parallel):
     launch_bytes = (N + n_out[0]) * (16 * wq + 16)
     roof = {'bound': 'hbm', 'kernel': 'k_rot_resident', 'achieved': launch_bytes / kt / 1e9 if kt else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': launch_bytes / kt / 1e9 / HBM_PEAK_GBS if kt else None, 'traffic': None, 'launches': nl, 'avg_launch_ms': kt * 1e3,
-            'algorithmic_bytes_per_launch': launch_bytes, 'whole_call_GBps': launch_bytes / (dt / args.steps) / 1e9,
+            'algorithmic_bytes_per_launch': launch_bytes, 'whole_call_GBps': launch_bytes / (dt / (args.steps * ROT)) / 1e9,
             'note': 'one persistent launch per rotation, rows resident in LDS (one workgroup per CU); the launch is a chain of dependent phases '
                     '(rows in 7 us, join-table compare-and-swaps 3 us, two in-launch all-gathers, rows out 7 us), not a bandwidth-bound stream'}
     traffic_from_profile(roof, 'r03_rotation_traffic.json', ['rotate_resident.hip'], {'workload': 'rotation', 'n_qubits': n, 'terms': N})
-    out = contract_line(args, world, world * N * args.steps / dt, 'pairs/s', 'pauli_term_pairs_per_sec', dt, 'u64+c128',
+    out = contract_line(args, world, world * N * ROT * args.steps / dt, 'pairs/s', 'pauli_term_pairs_per_sec', dt, 'u64+c128',
                         {'workload': 'single_pauli_rotation_nonclifford', 'n_qubits': n, 'terms': N, 'terms_out': n_out[0], 'angle': 0.3,
-                         'pairs_per_step': N, 'call': 'P._rotate_by_single_Pword(Q, 0.3) (symgpu_rotate_single_dev)',
+                         'rotations_per_step': ROT, 'pairs_per_step': N * ROT, 'call': 'P._rotate_by_single_Pword(Q, 0.3) (symgpu_rotate_single_dev), one call per rotation',
                          'parallelism': f'{world} independent replicas' if world > 1 else 'single GPU'}, roof, comm)
-    out['seconds_per_rotation'] = dt / args.steps
+    out['seconds_per_rotation'] = dt / (args.steps * ROT)
     # Clifford rotations of the same operator: one by one, and as one run (rows in registers + one sort per 40 rotations)
     if rank == 0 and not args.no_extras:
         def clifford():

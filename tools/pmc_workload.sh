@@ -9,7 +9,7 @@ tag=${1:-r03}; wl=${2:-rotation}
 case $wl in
   mul_cleanup) short=cfg3; like='%k_emit_stream%'; srcs="cleanup.hip";;
   rotation)    short=rotation; like='%k_rot_resident%'; srcs="rotate_resident.hip";;
-  gf2)         short=gf2; like='%k_sweep_m4r%'; srcs="gf2.hip";;
+  gf2)         short=gf2; like='%k_sweep_m4r<1>%'; srcs="gf2.hip";;
   *) echo "unknown workload $wl"; exit 2;;
 esac
 out=gpurun_out/${tag}_$wl; rm -rf $out; mkdir -p $out
