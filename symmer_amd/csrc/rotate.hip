@@ -1266,7 +1266,14 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
         const bool lds_on = [] { const char *e3 = getenv("SYMGPU_CHAIN_LDS"); return !(e3 && e3[0] == '0'); }();
         static const bool lds_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_clifford_chain_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                          128 * 1024) == hipSuccess;
-        if (e == hipSuccess && lds_on && lds_attr && T <= local_t && T <= CHAIN_LDS_T && W <= 128 && lds_rows <= 128 * 1024) {
+        const bool reg_chain = clifford_chain_registers_applicable(T, Wq) && !getenv("SYMGPU_CHAIN_LOCAL_T");
+        if (e == hipSuccess && reg_chain) {
+            // the whole run with the rows in registers and ONE sort of the accumulated partition bits per 40 rotations (rotate_chain.hip):
+            // faster than every other form at every size (1 term: 0.5 us per rotation against 1.6 of the LDS-resident kernel, 128 terms:
+            // 1.2 against 3.7, 10^5 terms: 5.3 against 22.9 of the two-launch form)
+            rc = clifford_chain_registers(a, b, T, qs.as<u64>(), ks_host, K, &in_b);
+            if (rc != SYMGPU_OK) { symgpu_op_free(a); symgpu_op_free(b); return rc; }
+        } else if (e == hipSuccess && lds_on && lds_attr && T <= local_t && T <= CHAIN_LDS_T && W <= 128 && lds_rows <= 128 * 1024) {
             // small operator, resident in LDS for the whole run
             hipLaunchKernelGGL(k_clifford_chain_lds, dim3(1), dim3(1024), lds_rows, st, a->rows, a->coeff, (int)T, Wq, G, qs.as<u64>(), ks.as<int>(), (int)K);
             e = hipGetLastError();
@@ -1278,7 +1285,7 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
             e = hipGetLastError();
             if (e == hipSuccess) e = hipMemcpyAsync(&in_b, which.p, 4, hipMemcpyDeviceToHost, st);
         } else if (e == hipSuccess && clifford_chain_registers_applicable(T, Wq)) {
-            // the whole run with the rows in registers and ONE sort of the accumulated partition bits per 40 rotations (rotate_chain.hip)
+            // (SYMGPU_CHAIN_LOCAL_T set and T above it: the tests' way to the register chain next to the single-workgroup kernels)
             rc = clifford_chain_registers(a, b, T, qs.as<u64>(), ks_host, K, &in_b);
             if (rc != SYMGPU_OK) { symgpu_op_free(a); symgpu_op_free(b); return rc; }
         } else if (e == hipSuccess) {

@@ -63,7 +63,7 @@ template <int WQ> __device__ __forceinline__ u32 ch_row_xor(u32 s) {
 }
 
 template <int WQ, int NCH>
-__global__ __launch_bounds__(256, 6) void k_cchain_reg(const u32x4 *__restrict__ rows, const double *__restrict__ coeff, const u64 *__restrict__ perm, i64 T,
+__global__ __launch_bounds__(256, NCH == 4 ? 4 : 6) void k_cchain_reg(const u32x4 *__restrict__ rows, const double *__restrict__ coeff, const u64 *__restrict__ perm, i64 T,
                                                      const u32x4 *__restrict__ qs, const ChainKs ks, int K, u32x4 *__restrict__ out_rows,
                                                      double *__restrict__ out_coeff, u64 *__restrict__ keys) {
     const int tid = threadIdx.x;
@@ -95,10 +95,13 @@ __global__ __launch_bounds__(256, 6) void k_cchain_reg(const u32x4 *__restrict__
             yp[j] = ch_row_sum<WQ>(popc4(v[j] & o) & xm);
         }
     }
-    u32x4 qs_n = qs[c], qo_n = WQ == 1 ? qs[0] : qs[c ^ (WQ / 2)];
+    // the segment's Q rows go to LDS first (<= 40 x 512 bytes): a small operator's rotation is shorter than the latency of a load
+    // from L2, so fetching Q(r + 1) during rotation r would leave every rotation waiting for its Q
+    __shared__ u32x4 s_q[CHAIN_SEG * WQ];
+    for (int i = tid; i < K * WQ; i += 256) s_q[i] = qs[i];
+    __syncthreads();
     for (int r = 0; r < K; ++r) {
-        const u32x4 q_s = qs_n, q_o = qo_n;                                    // this lane's chunk of Q and the other half's
-        if (r + 1 < K) { qs_n = qs[(r + 1) * WQ + c]; qo_n = WQ == 1 ? qs_n : qs[(r + 1) * WQ + (c ^ (WQ / 2))]; }
+        const u32x4 q_s = s_q[r * WQ + c], q_o = WQ == 1 ? q_s : s_q[r * WQ + (c ^ (WQ / 2))];     // this lane's chunk of Q and the other half's
         const u32 k = r < 32 ? (u32)(ks.lo >> (2 * r)) & 3u : (ks.hi >> (2 * (r - 32))) & 3u;
         const u32 kneg = (k == 2 || k == 3) ? 2u : 0u;
         const bool low = CHAIN_IDX_BITS + r < 32;
@@ -203,7 +206,8 @@ int clifford_chain_registers(symgpu_op_t a, symgpu_op_t b, i64 T, const u64 *qs_
     // chunks per lane: 2 (74 VGPRs: six wavefronts per SIMD, no spills; the kernel is VALU bound and its wavefronts are independent, so
     // many short ones balance best: 4 chunks per lane need 128 VGPRs and run 1.5 rounds of wavefronts at 10^5 terms, 8 spill) unless
     // that leaves fewer than ~4,096 wavefronts
-    const int nch = total / 128 >= 8192 ? 2 : 1;
+    // (rows of 32 chunks exchange halves through ds_bpermute instead of DPP: their per-rotation overhead wants 4 chunks per lane)
+    const int nch = total / 128 >= 8192 ? (Wq == 32 ? 4 : 2) : 1;
     const unsigned grid = (unsigned)((total + 256 * (i64)nch - 1) / (256 * (i64)nch));
     symgpu_op_t cur = a, other = b;
     const u64 *perm = nullptr;
@@ -219,7 +223,7 @@ int clifford_chain_registers(symgpu_op_t a, symgpu_op_t b, i64 T, const u64 *qs_
         u32x4 *rout = reinterpret_cast<u32x4 *>(other->rows);
         u64 *knew = kbuf[2 * (seg & 1)].as<u64>(), *ktmp = kbuf[2 * (seg & 1) + 1].as<u64>();
 #define CH_LAUNCH(WQV, NCHV) hipLaunchKernelGGL((k_cchain_reg<WQV, NCHV>), dim3(grid), dim3(256), 0, st, rin, cur->coeff, perm, T, q4, ks, n, rout, other->coeff, knew)
-#define CH_NCH(WQV) do { if (nch == 1) CH_LAUNCH(WQV, 1); else CH_LAUNCH(WQV, 2); } while (0)
+#define CH_NCH(WQV) do { if (nch == 1) CH_LAUNCH(WQV, 1); else if (nch == 2) CH_LAUNCH(WQV, 2); else CH_LAUNCH(WQV, 4); } while (0)
         ProfScope *prof = new ProfScope(5);
         switch (Wq) {
             case 1: CH_NCH(1); break;

@@ -139,14 +139,15 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ keys
                                                      u64 *__restrict__ out_keys, u32 *__restrict__ out_vals) {
     __shared__ u64 s_key[RS_TILE];
     __shared__ u32 s_val[HAS_VALS ? RS_TILE : 1];
-    __shared__ u32 s_cnt[4][256];      // per-wave running digit counters, then per-wave exclusive offsets
+    __shared__ u32 s_cnt[4][256];      // per-wave running digit counters, then per-wave exclusive offsets.  NOT volatile and not
+                                       // through a pointer: both turn every access into a flat, system-scope load / store with a
+                                       // wait behind it; wavefront-scope fences order the lanes' reads and writes instead
     __shared__ u32 s_dig_off[256];     // exclusive offset of each digit inside the tile
     __shared__ u32 s_gbase[256];       // global base of each digit for this tile
     __shared__ u32 s_wave[4];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const i64 tile_base = (i64)blockIdx.x * RS_TILE;
-    volatile u32 *cnt = s_cnt[wave];
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
     s_gbase[threadIdx.x] = tile_off[(i64)threadIdx.x * n_tiles + blockIdx.x];
@@ -173,9 +174,11 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ keys
         const u32 rank = __popcll(m & lt_mask);
         const u32 count = __popcll(m);
         u32 base = 0;
-        if (valid) base = cnt[d];
+        if (valid) base = s_cnt[wave][d];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) cnt[d] = base + count;
+        if (valid && rank == 0) s_cnt[wave][d] = base + count;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         pos[r] = base + rank;
     }
@@ -285,7 +288,7 @@ __device__ __forceinline__ bool coop_barrier(u32 *bar, u32 target, int G, u32 *s
 __global__ __launch_bounds__(256) void k_rs_coop(u64 *__restrict__ buf_a, u64 *__restrict__ buf_b, i64 n, int begin_bit, int n_passes,
                                                   u32 *__restrict__ tile_hist /* [256][G] */, u32 *__restrict__ bar, u32 bar_base) {
     __shared__ u64 s_key[RS_TILE];
-    __shared__ volatile u32 s_cnt[4][256];                  // indexed directly: through a pointer the accesses become flat loads
+    __shared__ u32 s_cnt[4][256];                           // see k_rs_scatter: plain LDS accesses ordered by wavefront-scope fences
     __shared__ u32 s_dig_off[256];
     __shared__ u32 s_gbase[256];
     __shared__ u32 s_wave[4];
@@ -328,8 +331,10 @@ __global__ __launch_bounds__(256) void k_rs_coop(u64 *__restrict__ buf_a, u64 *_
             const u32 count = __popcll(m);
             u32 base = 0;
             if (valid) base = s_cnt[wave][d];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (valid && rank == 0) s_cnt[wave][d] = base + count;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             pos[r] = base + rank;
         }
