@@ -42,19 +42,23 @@ constexpr size_t RES_LDS_MAX = 160 * 1024;
 constexpr int RES_MIN_ROWS = 64;                  // rows per workgroup below which more workgroups only lengthen the all-gathers
 constexpr int RES_LD_UNROLL = 8;                  // 16-byte loads in flight per lane (cfg2: 6,256 chunks per block = one round of 8,192)
 constexpr u32 RES_NO_SLOT = 0xFFFFFFFFu;
-constexpr int RES_PENDING = -2;                  // s_part: the row's first probe met an occupied slot; resolved after the loads
+// class byte of a row: bits 0-2 = kept commuting row / kept anticommuting row / kept new row (what is written out); bit 3 = the row has
+// a partner (its coefficient in LDS is final); join state in s_ps: bit 4 = it claimed slot s_ps, bit 5 = it found its partner s_ps,
+// bit 6 = its first probe met the occupant {s_posn : s_ps} (resolved after the loads)
+enum { CL_C = 1, CL_A = 2, CL_N = 4, CL_MATCHED = 8, CL_CLAIMED = 16, CL_SECOND = 32, CL_PENDING = 64 };
 
-struct ResLayout { int rows, coef, prod, hash, part, slot, pos, posn, info, cls, q, wtot, misc, total; };
-__host__ __device__ inline ResLayout res_layout(int R, int Wq) {
+// LDS of one workgroup: the rows' 16-byte chunks (minus the first `nreg` x 1,024, which stay in registers), then 26 bytes per row:
+// coefficient (16), one word that is first the row's join state (claimed slot / partner / occupant) and later its rank (4), the rank
+// of its new row (4), info and class bytes.  Hashes are read from HBM where they are needed (twice, coalesced).
+struct ResLayout { int rows, coef, ps, posn, info, cls, q, wtot, misc, total, lds_chunks; };
+__host__ __device__ inline ResLayout res_layout(int R, int Wq, int nreg) {
     ResLayout L;
     int o = 0;
-    L.rows = o; o += R * Wq * 16;
+    L.lds_chunks = R * Wq - nreg * 1024;
+    if (L.lds_chunks < 0) L.lds_chunks = 0;
+    L.rows = o; o += L.lds_chunks * 16;
     L.coef = o; o += R * 16;
-    L.prod = o; o += R * 16;
-    L.hash = o; o += R * 8;
-    L.part = o; o += R * 4;
-    L.slot = o; o += R * 4;
-    L.pos = o; o += R * 4;
+    L.ps = o; o += R * 4;
     L.posn = o; o += R * 4;
     L.info = o; o += R;
     L.cls = o; o += R;
@@ -68,7 +72,7 @@ __host__ __device__ inline ResLayout res_layout(int R, int Wq) {
 
 struct ResArgs {
     const u32x4 *rows; const double *coeff; const u64 *hin;
-    i64 T; int Wq, R, GA; u32 yq;
+    i64 T; int Wq, R, GA, nreg; u32 yq;          // nreg: 1,024-chunk rounds of the row load that stay in registers (0 or 2)
     u32x4 *out_rows; double *out_coeff; u64 *out_hash;
     double cos_t, sin_t, thr; int k;
     u64 hq;
@@ -161,15 +165,12 @@ __device__ __forceinline__ uint8_t res_info(u32 anti, u32 fp, u32 yp, u32 yout, 
 template <int MODE, int WQ>
 __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const ResLayout L = res_layout(a.R, a.Wq);
+    const int nreg = WQ > 0 ? a.nreg : 0;                                      // (rows of a generic length are analysed from LDS: all of them live there)
+    const ResLayout L = res_layout(a.R, a.Wq, nreg);
     u32x4 *s_rows = reinterpret_cast<u32x4 *>(smem + L.rows);
     f64x2 *s_coef = reinterpret_cast<f64x2 *>(smem + L.coef);
-    f64x2 *s_prod = reinterpret_cast<f64x2 *>(smem + L.prod);
-    u64 *s_hash = reinterpret_cast<u64 *>(smem + L.hash);
-    int *s_part = reinterpret_cast<int *>(smem + L.part);
-    u32 *s_slot = reinterpret_cast<u32 *>(smem + L.slot);
-    u32 *s_pos = reinterpret_cast<u32 *>(smem + L.pos);
-    u32 *s_posn = reinterpret_cast<u32 *>(smem + L.posn);
+    u32 *s_ps = reinterpret_cast<u32 *>(smem + L.ps);                          // join state, later: rank of the row in its class
+    u32 *s_posn = reinterpret_cast<u32 *>(smem + L.posn);                      // (high word of a pending row's occupant), later: rank of the new row
     uint8_t *s_info = smem + L.info;
     uint8_t *s_cls = smem + L.cls;
     u64 *s_q = reinterpret_cast<u64 *>(smem + L.q);
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
     const i64 row0 = (i64)w * a.R;
     const int Rw = (int)(a.T - row0 < (i64)a.R ? a.T - row0 : (i64)a.R);
     const int nchunk = Rw * Wq;
+    const int reg_chunks = nreg * RES_THREADS;                                 // chunks [0, reg_chunks) of the block live in keep0 / keep1
     const u32 tag1 = 2 * a.epoch, tag2 = 2 * a.epoch + 1;
     const f64x2 *coeff2 = reinterpret_cast<const f64x2 *>(a.coeff);
     const u32 yq = a.yq;
@@ -192,7 +194,10 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
     if (tid < 32) s_misc[tid] = 0;
     __syncthreads();
     const u32x4 *sq4 = reinterpret_cast<const u32x4 *>(s_q);
-    // ---- A1: the block's rows, coefficients and hashes: HBM -> LDS, read once; flags and phase exponents on the way ------------
+    u32x4 keep0 = (u32x4)(0u), keep1 = (u32x4)(0u);
+    // chunk `it * 1024 + tid` of the block, from the registers or from LDS
+#define RES_CHUNK(it, i) (((it) < nreg) ? ((it) == 0 ? keep0 : keep1) : s_rows[(i) - reg_chunks])
+    // ---- A1: the block's rows and coefficients: HBM -> registers / LDS, read once; flags and phase exponents on the way ---------
     {
         const u32x4 *src = a.rows + row0 * Wq;
         for (int i0 = 0; i0 < nchunk; i0 += RES_LD_UNROLL * RES_THREADS) {
@@ -203,10 +208,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
                 v[j] = i < nchunk ? __builtin_nontemporal_load(src + i) : (u32x4)(0u);
             }
             if (i0 == 0)
-                for (int r = tid; r < Rw; r += RES_THREADS) {
-                    s_coef[r] = coeff2[row0 + r];
-                    s_hash[r] = a.hin ? a.hin[row0 + r] : 0ULL;
-                }
+                for (int r = tid; r < Rw; r += RES_THREADS) s_coef[r] = coeff2[row0 + r];
             u64 hrow[RES_LD_UNROLL], casold[RES_LD_UNROLL];
             u32 caspos[RES_LD_UNROLL];
             if constexpr (WQ > 0) {
@@ -255,11 +257,15 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
                 }
             }
 #pragma unroll
-            for (int j = 0; j < RES_LD_UNROLL; ++j) { const int i = i0 + j * RES_THREADS + tid; if (i < nchunk) s_rows[i] = v[j]; }
+            for (int j = 0; j < RES_LD_UNROLL; ++j) {
+                const int i = i0 + j * RES_THREADS + tid;
+                if (i0 == 0 && j < 2 && j < nreg) { if (j == 0) keep0 = v[j]; else keep1 = v[j]; }
+                else if (i < nchunk) s_rows[i - reg_chunks] = v[j];
+            }
             if constexpr (WQ > 0 && MODE == 0) {
                 // What the first probes found (only now: the empty statement keeps the compiler from testing each answer right behind
                 // its compare-and-swap, which would serialise the eight round trips): 0 = the slot is this row's; an occupant is
-                // left in s_prod for A3, which continues the walk from there.
+                // left in {s_posn : s_ps} for A3, which continues the walk from there.
                 asm volatile("" : "+v"(casold[0]), "+v"(casold[1]), "+v"(casold[2]), "+v"(casold[3]), "+v"(casold[4]), "+v"(casold[5]), "+v"(casold[6]), "+v"(casold[7]));
                 static_assert(RES_LD_UNROLL == 8, "the statement above names eight answers");
                 const int c = tid & (WQ - 1);
@@ -267,10 +273,10 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
                 for (int j = 0; j < RES_LD_UNROLL; ++j) {
                     const int i = i0 + j * RES_THREADS + tid;
                     if (c == 0 && i < nchunk) {
-                        const bool pending = caspos[j] != RES_NO_SLOT && casold[j] != 0;
-                        s_slot[i / WQ] = caspos[j];                             // RES_NO_SLOT for a commuting row; for a pending row: where it stands
-                        s_part[i / WQ] = pending ? RES_PENDING : -1;
-                        if (pending) reinterpret_cast<u64 *>(s_prod)[2 * (i / WQ)] = casold[j];
+                        const bool anti = caspos[j] != RES_NO_SLOT, pending = anti && casold[j] != 0;
+                        s_ps[i / WQ] = pending ? (u32)casold[j] : caspos[j];
+                        s_posn[i / WQ] = (u32)(casold[j] >> 32);
+                        s_cls[i / WQ] = (uint8_t)(pending ? CL_PENDING : (anti ? CL_CLAIMED : 0));
                     }
                 }
             }
@@ -309,31 +315,30 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
         bool bad = false;
         for (int r = tid; r < Rw; r += RES_THREADS) {
             const uint8_t info = s_info[r];
-            int part = -1;
-            u32 slot = RES_NO_SLOT;
             uint8_t cls = 0;
+            u32 ps = 0;
             if (!(info & 1)) {
                 const f64x2 c = s_coef[r];
-                if (res_keep(c.x, c.y, a.thr)) { cls = 1; ++nC; }
-            } else if (WQ > 0 && s_part[r] != RES_PENDING) {
-                slot = s_slot[r];                                              // claimed by the probe issued from the load loop
+                if (res_keep(c.x, c.y, a.thr)) { cls = CL_C; ++nC; }
+            } else if (WQ > 0 && (s_cls[r] & CL_CLAIMED)) {
+                cls = CL_CLAIMED; ps = s_ps[r];                                // claimed by the probe issued from the load loop
             } else {
-                // generic row lengths: the whole walk; otherwise: the first probe met the occupant left in s_prod — the walk goes on there
+                // generic row lengths: the whole walk; otherwise: the first probe met the occupant left in {s_posn : s_ps} — the walk goes on there
                 const i64 t = row0 + r;
-                const u64 h = s_hash[r], hp = h ^ a.hq, ck = h < hp ? h : hp;
+                const u64 h = a.hin[t], hp = h ^ a.hq, ck = h < hp ? h : hp;
                 const u64 entry = (ck & 0xFFFFFFFF00000000ULL) | (u64)(t + 1);
-                u32 pos = WQ > 0 ? s_slot[r] : (u32)mix64(ck) & a.mask;
+                u32 pos = (u32)mix64(ck) & a.mask;
                 bool have_old = WQ > 0;
                 for (;;) {
-                    const u64 old = have_old ? reinterpret_cast<const u64 *>(s_prod)[2 * r]
+                    const u64 old = have_old ? (((u64)s_posn[r] << 32) | s_ps[r])
                                              : atomicCAS(reinterpret_cast<unsigned long long *>(&a.slots[pos]), 0ULL, (unsigned long long)entry);
                     have_old = false;
-                    if (old == 0) { slot = pos; break; }                       // first of its key: a partner, if any, will leave a note
+                    if (old == 0) { cls = CL_CLAIMED; ps = pos; break; }       // first of its key: a partner, if any, will leave a note
                     if ((old >> 32) == (ck >> 32)) {
                         const i64 o = (i64)(old & 0xFFFFFFFFULL) - 1;
                         const u64 ho = a.hin[o];
                         if (ho == hp) {                                        // the row this one merges with (verified below)
-                            part = (int)o;
+                            cls = CL_SECOND; ps = (u32)o;
                             ag_store32(&a.partner[o], (u32)(t + 1));
                             break;
                         }
@@ -342,8 +347,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
                     pos = (pos + 1) & a.mask;
                 }
             }
-            s_part[r] = part;
-            s_slot[r] = slot;
+            s_ps[r] = ps;
             s_cls[r] = cls;
         }
         for (int off = 32; off > 0; off >>= 1) nC += (u32)__shfl_xor((int)nC, off);
@@ -358,10 +362,9 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
             int r = tid / Wq, c = tid - r * Wq;
             const int dr = RES_THREADS / Wq, dc = RES_THREADS - dr * Wq;
             bool mism = false;
-            for (int i = tid; i < nchunk; i += RES_THREADS) {
-                const int p = s_part[r];
-                if (p >= 0) {
-                    const u32x4 mine = s_rows[i] ^ sq4[c], theirs = a.rows[(i64)p * Wq + c];
+            for (int it = 0, i = tid; i < nchunk; ++it, i += RES_THREADS) {
+                if (s_cls[r] & CL_SECOND) {
+                    const u32x4 mine = RES_CHUNK(it, i) ^ sq4[c], theirs = a.rows[(i64)s_ps[r] * Wq + c];
                     mism |= (mine.x != theirs.x) | (mine.y != theirs.y) | (mine.z != theirs.z) | (mine.w != theirs.w);
                 }
                 r += dr; c += dc;
@@ -388,16 +391,16 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
             return;
         }
         prefC = s_misc[M_PREF_C]; totC = s_misc[M_TOT_C];
-        // ---- B: final coefficients and classes of the anticommuting rows; their slots and notes go back to zero ---------------
+        // ---- B: classes of the anticommuting rows and the final coefficient of those that merge; slots and notes go back to zero ---
         for (int r = tid; r < Rw; r += RES_THREADS) {
             const uint8_t info = s_info[r];
             if (!(info & 1)) continue;
-            int part = s_part[r];
-            const u32 slot = s_slot[r];
-            if (slot != RES_NO_SLOT) {
+            const uint8_t st = s_cls[r];
+            int part = (st & CL_SECOND) ? (int)s_ps[r] : -1;
+            if (st & CL_CLAIMED) {
                 const u32 pv = ag_load32(&a.partner[row0 + r]);
                 if (pv) { part = (int)pv - 1; ag_store32(&a.partner[row0 + r], 0u); }
-                ag_store(&a.slots[slot], 0ULL);
+                ag_store(&a.slots[s_ps[r]], 0ULL);
             }
             const f64x2 c = s_coef[r];
             double sr = __dmul_rn(c.x, a.cos_t), si = __dmul_rn(c.y, a.cos_t);
@@ -408,14 +411,13 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
                 phase_mul(cp.x, cp.y, (info >> 3) & 3, pr, pi);
                 sr = __dadd_rn(sr, __dmul_rn(pi, a.sin_t));
                 si = __dadd_rn(si, -__dmul_rn(pr, a.sin_t));
+                s_coef[r] = f64x2{sr, si};                                     // final; an unmatched row keeps c: cos c and the new row's
+                cls |= CL_MATCHED;                                             // coefficient are formed from it when they are written
             } else {                                                           // its product row is new
                 phase_mul(c.x, c.y, (info >> 1) & 3, pr, pi);
-                const double nr = __dmul_rn(pi, a.sin_t), ni = -__dmul_rn(pr, a.sin_t);
-                s_prod[r] = f64x2{nr, ni};
-                if (res_keep(nr, ni, a.thr)) cls |= 4;
+                if (res_keep(__dmul_rn(pi, a.sin_t), -__dmul_rn(pr, a.sin_t), a.thr)) cls |= CL_N;
             }
-            s_coef[r] = f64x2{sr, si};
-            if (res_keep(sr, si, a.thr)) cls |= 2;
+            if (res_keep(sr, si, a.thr)) cls |= CL_A;
             s_cls[r] = cls;
         }
     } else {
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
             const uint8_t info = s_info[r];
             uint8_t cls = 0;
             if (!(info & 1)) {
-                cls = 1;
+                cls = CL_C;
             } else {
                 const f64x2 c = s_coef[r];
                 if (k & 1) {
@@ -435,11 +437,11 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
                         double pr = y, pi = -x;                                // c * i^e * (-i)
                         if (k == 3) { pr = -pr; pi = -pi; }
                         s_coef[r] = f64x2{pr, pi};
-                        cls = 4;
+                        cls = CL_N | CL_MATCHED;                               // (MATCHED: the coefficient in LDS is the one to write)
                     }
                 } else {
                     if (k == 2) s_coef[r] = f64x2{-c.x, -c.y};
-                    cls = 2;
+                    cls = CL_A | CL_MATCHED;
                 }
             }
             s_cls[r] = cls;
@@ -447,6 +449,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
     }
     __syncthreads();
     RES_STAMP(4);
+    u32 *s_pos = s_ps;                                                         // the join state is dead: the word now holds the row's rank
     // ---- ranks of the rows inside the block: ballots per pass of 1,024 rows give the rank inside the wavefront and the counts per
     //      (pass, wavefront); wavefront 0 adds them up and publishes the block's granule at once (the all-gather is in flight while
     //      everybody turns the ranks into block-wide ones)
@@ -457,9 +460,9 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
             const int r = j * RES_THREADS + tid;
             const uint8_t cl = r < Rw ? s_cls[r] : 0;
             const bool an = r < Rw && (s_info[r] & 1);
-            const u64 b0 = __ballot(cl & 1), b1 = __ballot(cl & 2), b2 = __ballot(cl & 4), b3 = __ballot(an);
+            const u64 b0 = __ballot(cl & CL_C), b1 = __ballot(cl & CL_A), b2 = __ballot(cl & CL_N), b3 = __ballot(an);
             if (r < Rw) {
-                s_pos[r] = (u32)__popcll(((cl & 1) ? b0 : b1) & lt);
+                s_pos[r] = (u32)__popcll(((cl & CL_C) ? b0 : b1) & lt);
                 s_posn[r] = (u32)__popcll(b2 & lt);
             }
             if (lane == 0) s_wtot[j * 16 + wave] = (u64)__popcll(b0) | ((u64)__popcll(b1) << 16) | ((u64)__popcll(b2) << 32) | ((u64)__popcll(b3) << 48);
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
             for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
             if (lane == 0) {
                 const u64 nC = sum & 0xFFFFu, nA = (sum >> 16) & 0xFFFFu, nN = (sum >> 32) & 0xFFFFu, nAnti = (sum >> 48) & 0xFFFFu;
-                // Clifford: ONE all-gather carries {rotated rows (class 2 or 4: only one of them occurs per k), commuting rows, all anticommuting}
+                // Clifford: ONE all-gather carries {rotated rows (class A or N: only one of them occurs per k), commuting rows, all anticommuting}
                 if (MODE == 1) ag_store(&a.gran2[w], ((u64)tag2 << 48) | (nA + nN) | (nC << 16) | (nAnti << 32));
                 else ag_store(&a.gran2[w], ((u64)tag2 << 48) | nA | (nN << 16) | (nAnti << 32));
             }
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
             u64 base = 0;
             for (int e = 0; e < j * 16 + wave; ++e) base += s_wtot[e];
             if (r < Rw) {
-                s_pos[r] += (s_cls[r] & 1) ? (u32)base & 0xFFFFu : (u32)(base >> 16) & 0xFFFFu;
+                s_pos[r] += (s_cls[r] & CL_C) ? (u32)base & 0xFFFFu : (u32)(base >> 16) & 0xFFFFu;
                 s_posn[r] += (u32)(base >> 32) & 0xFFFFu;
             }
         }
@@ -494,16 +497,16 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
         // ---- C1: the commuting rows go out while the second all-gather is in flight -------------------------------------------
         int r = tid / Wq, c = tid - r * Wq;
         const int dr = RES_THREADS / Wq, dc = RES_THREADS - dr * Wq;
-        for (int i = tid; i < nchunk; i += RES_THREADS) {
-            if (s_cls[r] & 1) __builtin_nontemporal_store(s_rows[i], &a.out_rows[(i64)(prefC + s_pos[r]) * Wq + c]);
+        for (int it = 0, i = tid; i < nchunk; ++it, i += RES_THREADS) {
+            if (s_cls[r] & CL_C) __builtin_nontemporal_store(RES_CHUNK(it, i), &a.out_rows[(i64)(prefC + s_pos[r]) * Wq + c]);
             r += dr; c += dc;
             if (c >= Wq) { c -= Wq; ++r; }
         }
         for (int r2 = tid; r2 < Rw; r2 += RES_THREADS)
-            if (s_cls[r2] & 1) {
+            if (s_cls[r2] & CL_C) {
                 const i64 d = (i64)prefC + s_pos[r2];
                 out_coeff2[d] = s_coef[r2];
-                if (a.out_hash) a.out_hash[d] = s_hash[r2];
+                if (a.out_hash) a.out_hash[d] = a.hin[row0 + r2];
             }
     }
     RES_STAMP(5);
@@ -541,33 +544,46 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
     {
         int r = tid / Wq, c = tid - r * Wq;
         const int dr = RES_THREADS / Wq, dc = RES_THREADS - dr * Wq;
-        for (int i = tid; i < nchunk; i += RES_THREADS) {
+        for (int it = 0, i = tid; i < nchunk; ++it, i += RES_THREADS) {
             const uint8_t cl = s_cls[r];
-            if (MODE == 1 && (cl & 1)) __builtin_nontemporal_store(s_rows[i], &a.out_rows[(baseC + s_pos[r]) * Wq + c]);
-            if (cl & 2) __builtin_nontemporal_store(s_rows[i], &a.out_rows[(baseA + s_pos[r]) * Wq + c]);
-            if (cl & 4) __builtin_nontemporal_store(s_rows[i] ^ sq4[c], &a.out_rows[(baseN + s_posn[r]) * Wq + c]);
+            if (cl & ((MODE == 1 ? CL_C : 0) | CL_A | CL_N)) {
+                const u32x4 x = RES_CHUNK(it, i);
+                if (MODE == 1 && (cl & CL_C)) __builtin_nontemporal_store(x, &a.out_rows[(baseC + s_pos[r]) * Wq + c]);
+                if (cl & CL_A) __builtin_nontemporal_store(x, &a.out_rows[(baseA + s_pos[r]) * Wq + c]);
+                if (cl & CL_N) __builtin_nontemporal_store(x ^ sq4[c], &a.out_rows[(baseN + s_posn[r]) * Wq + c]);
+            }
             r += dr; c += dc;
             if (c >= Wq) { c -= Wq; ++r; }
         }
         for (int r2 = tid; r2 < Rw; r2 += RES_THREADS) {
             const uint8_t cl = s_cls[r2];
-            if (MODE == 1 && (cl & 1)) {
+            if (!(cl & ((MODE == 1 ? CL_C : 0) | CL_A | CL_N))) continue;
+            const f64x2 c = s_coef[r2];
+            const u64 h = a.out_hash ? a.hin[row0 + r2] : 0ULL;
+            if (MODE == 1 && (cl & CL_C)) {
                 const i64 d = baseC + s_pos[r2];
-                out_coeff2[d] = s_coef[r2];
-                if (a.out_hash) a.out_hash[d] = s_hash[r2];
+                out_coeff2[d] = c;
+                if (a.out_hash) a.out_hash[d] = h;
             }
-            if (cl & 2) {
+            if (cl & CL_A) {
                 const i64 d = baseA + s_pos[r2];
-                out_coeff2[d] = s_coef[r2];
-                if (a.out_hash) a.out_hash[d] = s_hash[r2];
+                out_coeff2[d] = (cl & CL_MATCHED) ? c : f64x2{__dmul_rn(c.x, a.cos_t), __dmul_rn(c.y, a.cos_t)};
+                if (a.out_hash) a.out_hash[d] = h;
             }
-            if (cl & 4) {
+            if (cl & CL_N) {
                 const i64 d = baseN + s_posn[r2];
-                out_coeff2[d] = MODE == 0 ? s_prod[r2] : s_coef[r2];
-                if (a.out_hash) a.out_hash[d] = s_hash[r2] ^ a.hq;
+                f64x2 cn = c;
+                if (MODE == 0) {                                               // (-i sin) i^e c, from the row's own coefficient
+                    double pr, pi;
+                    phase_mul(c.x, c.y, (s_info[r2] >> 1) & 3, pr, pi);
+                    cn = f64x2{__dmul_rn(pi, a.sin_t), -__dmul_rn(pr, a.sin_t)};
+                }
+                out_coeff2[d] = cn;
+                if (a.out_hash) a.out_hash[d] = h ^ a.hq;
             }
         }
     }
+#undef RES_CHUNK
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // every wavefront's rows have left ...
     __syncthreads();
     RES_STAMP(7);
@@ -617,7 +633,12 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     const i64 R = (T + G - 1) / G;
     G = (T + R - 1) / R;
     if (R > 16384) return SYMGPU_OK;
-    const ResLayout L = res_layout((int)R, Wq);
+    // the rows of the block in LDS; if they do not fit, the first two 1,024-chunk rounds of the load stay in registers (+32 KB per CU:
+    // 1.46e5 -> 1.76e5 terms of 1,000 qubits — the operator a repeated rotation of 1e5 terms grows into, 1.5e5, is resident)
+    const bool pow2 = Wq <= 32 && (Wq & (Wq - 1)) == 0;
+    int nreg = 0;
+    ResLayout L = res_layout((int)R, Wq, 0);
+    if ((size_t)L.total > RES_LDS_MAX && pow2) { nreg = 2; L = res_layout((int)R, Wq, nreg); }
     if ((size_t)L.total > RES_LDS_MAX) return SYMGPU_OK;
     static const bool attr_ok = [] {
         for (int m = 0; m < 2; ++m)
@@ -654,6 +675,7 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     int GA = 1;
     while (GA < Wq && GA < 64) GA <<= 1;
     a.GA = GA;
+    a.nreg = nreg;
     a.yq = 0;
     for (int ww = 0; ww < Wq; ++ww) a.yq += (u32)__builtin_popcountll(q_host[ww] & q_host[Wq + ww]);
     a.cos_t = cos_t; a.sin_t = sin_t; a.thr = thr; a.k = clifford_k;
