@@ -146,6 +146,14 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
  * q_rows: K packed rows; ks: clifford_k per rotation, 0..3 as for symgpu_rotate_single (k = round(2*angle/pi) mapped as
  * symmer_amd.kernels.rotation_args). */
 int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host, const int *ks_host, int64_t K, symgpu_op_t *out);
+/* perform_rotations (base.py:1163-1186) on a device-resident operator in ONE call: rotations r = 0 .. K-1 (q_rows[r][2*Wq], cos_t[r], sin_t[r],
+ * ks[r] = clifford_k as for symgpu_rotate_single_dev) applied in order, each followed by the reference's cleanup() — which is the identity once the
+ * operator is clean (`clean` != 0 on entry says it already is), so it runs once; runs of Clifford rotations of a clean operator go through the chain
+ * entry point.  acted[r] (may be NULL; zeroed by the caller) is set where a single rotation changed the operator.  Returns early with *n_done < K when
+ * the operator has lost all its terms after rotation *n_done - 1 (the reference then alternates between 0 * I and the empty operator, which the
+ * caller reproduces).  *out = NULL: nothing changed, keep using `in` (which is never freed here). */
+int symgpu_perform_rotations_dev(symgpu_op_t in, const uint64_t *q_rows_host, const double *cos_t, const double *sin_t, const int *ks_host, int64_t K,
+                                 double thr, int clean, symgpu_op_t *out, uint8_t *acted, int64_t *n_done, int *clean_out);
 
 /* ---- a8: _rref_binary (utils.py:292-315): in place, no row swaps, leftmost pivot, eliminate above and
  * below.  xor_count (may be NULL) = sum_i |update_set_i| as the reference loop performs them.

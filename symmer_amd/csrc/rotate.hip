@@ -1197,6 +1197,54 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
     return SYMGPU_OK;
 }
 
+int symgpu_perform_rotations_dev(symgpu_op_t in, const uint64_t *q_rows_host, const double *cos_t, const double *sin_t, const int *ks_host, int64_t K,
+                                 double thr, int clean, symgpu_op_t *out, uint8_t *acted, int64_t *n_done, int *clean_out) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(in && out && n_done && clean_out && K >= 0 && (K == 0 || (q_rows_host && cos_t && sin_t && ks_host)), "perform_rotations_dev: null argument");
+    const int W = 2 * in->Wq;
+    symgpu_op_t cur = in;                                            // borrowed while cur == in, owned otherwise
+    auto replace = [&](symgpu_op_t next) { if (cur != in) symgpu_op_free(cur); cur = next; };
+    *out = nullptr;
+    i64 step = 0;
+    int rc = SYMGPU_OK;
+    while (step < K && rc == SYMGPU_OK) {
+        if (clean && cur->T > 0 && cur->T <= ((i64)1 << 22) && ks_host[step] >= 0) {
+            // a run of Clifford rotations of a clean operator: no step drops or merges anything, so the reference's per-step cleanup()
+            // is the identity and the whole run goes to the chain entry point
+            i64 e = step;
+            while (e < K && ks_host[e] >= 0) ++e;
+            symgpu_op_t res = nullptr;
+            rc = symgpu_rotate_clifford_chain_dev(cur, q_rows_host + step * W, ks_host + step, e - step, &res);
+            if (rc != SYMGPU_OK) break;
+            replace(res);
+            step = e;
+            continue;
+        }
+        if (cur->T > 0) {
+            symgpu_op_t res = nullptr;
+            int allc = 1;
+            rc = symgpu_rotate_single_dev(cur, q_rows_host + step * W, cos_t[step], sin_t[step], ks_host[step], thr, &res, &allc);
+            if (rc != SYMGPU_OK) break;
+            if (!allc) { if (acted) acted[step] = 1; replace(res); }
+            else if (res) symgpu_op_free(res);
+        }
+        ++step;
+        if (cur->T == 0) break;                                     // the caller reproduces the reference's 0 * I alternation (base.py:631-632)
+        if (!clean) {
+            symgpu_op_t cleaned = nullptr;
+            rc = symgpu_cleanup_dev(cur, thr, 1, &cleaned);
+            if (rc != SYMGPU_OK) break;
+            replace(cleaned);
+            clean = 1;
+        }
+    }
+    if (rc != SYMGPU_OK) { if (cur != in) symgpu_op_free(cur); return rc; }
+    *n_done = step;
+    *clean_out = clean;
+    *out = cur != in ? cur : nullptr;                                // nullptr: the operator is unchanged, keep using `in`
+    return SYMGPU_OK;
+}
+
 int symgpu_debug_rotation_trace(uint64_t *out, int max_workgroups, int *n_workgroups) {
     SG_TRY(require_ctx());
     SG_REQUIRE(out && n_workgroups && max_workgroups >= 0, "debug_rotation_trace");

@@ -685,7 +685,8 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
         // join table (>= 4 slots per row) and partner notes: all-zero between launches — the kernel zeroes what it used; after a
         // launch that did not complete (res_dirty) they are cleared here
         size_t cap = 4096;
-        while ((i64)cap < 4 * T) cap <<= 1;
+        static const int slots_per_row = [] { const char *e = getenv("SYMGPU_RES_SLOTS"); const int v = e ? atoi(e) : 4; return v >= 2 && v <= 64 ? v : 4; }();
+        while ((i64)cap < (i64)slots_per_row * T) cap <<= 1;
         if (cap > c.res_table_cap) {
             if (c.res_table) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(c.res_table); c.res_table = nullptr; c.res_table_cap = 0; }
             HIP_TRY(hipMalloc((void **)&c.res_table, cap * 8));

@@ -198,7 +198,7 @@ def rotation_args(angle, threshold=1e-18):
     k = round(multiple)
     if abs(k - multiple) <= threshold:
         ck = k if k in (2, 3) else (k % 2)
-        return float(np.cos(angle)), float(np.sin(angle)), int(ck)
+        return 0.0, 0.0, int(ck)             # the Clifford branch never uses cos / sin (base.py:1139-1154): not computed (2 us each)
     return float(np.cos(angle)), float(np.sin(angle)), -1
 
 
@@ -232,6 +232,22 @@ def rotate_clifford_chain_dev(op, q_rows, ks):
     out = ctypes.c_void_p()
     check(_lib.lib().symgpu_rotate_clifford_chain_dev(op.handle, addr(q_rows), addr(ks), q_rows.shape[0], ctypes.byref(out)))
     return DeviceOp(out)
+
+
+def perform_rotations_dev(op, q_rows, cos_t, sin_t, ks, clean, zero_threshold=1e-15):
+    """``perform_rotations`` on a device operator in one library call (``symgpu_perform_rotations_dev``): returns
+    (new DeviceOp or None if nothing changed, rotations done, uint8 flags of the single rotations that acted, clean flag).
+    Fewer rotations done than given: the operator has lost all its terms (the caller handles the reference's 0*I alternation)."""
+    q_rows = np.ascontiguousarray(q_rows, dtype='<u8')
+    cos_t, sin_t = np.ascontiguousarray(cos_t, dtype=np.float64), np.ascontiguousarray(sin_t, dtype=np.float64)
+    ks = np.ascontiguousarray(ks, dtype=np.int32)
+    K = q_rows.shape[0]
+    acted = np.zeros(K, dtype=np.uint8)
+    out = ctypes.c_void_p()
+    n_done, clean_out = c_i64(0), c_int(0)
+    check(_lib.lib().symgpu_perform_rotations_dev(op.handle, addr(q_rows), addr(cos_t), addr(sin_t), addr(ks), K, float(zero_threshold),
+                                                  1 if clean else 0, ctypes.byref(out), addr(acted), ctypes.addressof(n_done), ctypes.addressof(clean_out)))
+    return (DeviceOp(out) if out.value else None), n_done.value, acted, bool(clean_out.value)
 
 
 def cleanup_dev(op, zero_threshold=1e-15):

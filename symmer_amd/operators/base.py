@@ -498,67 +498,53 @@ class PauliwordOp:
         if len(fresh) > 4:
             for r, row in zip(fresh, packing.pack_rows(np.concatenate([r._symp for r in fresh], axis=0))):
                 r._packed_cache = row.reshape(1, -1)
+        # every rotation is checked (and warned about) before the first one runs; angles, generators and Clifford multiples of the
+        # whole sequence go to the device library in ONE call (symgpu_perform_rotations_dev: no Python between the rotations)
+        K = len(rotations)
+        q_rows = np.zeros((K, 2 * wq), dtype='<u8')
+        cos_t, sin_t = np.zeros(K), np.zeros(K)
+        ks = np.zeros(K, dtype=np.int32)
+        angles = []
+        for r, (pauli_rotation, angle) in enumerate(rotations):
+            assert pauli_rotation.n_terms == 1, 'Only rotation by single Pauliword allowed here'
+            assert pauli_rotation.n_qubits == self.n_qubits, 'Pauliwords defined for different number of qubits'
+            if angle is None:
+                angle = np.pi / 2
+            if pauli_rotation.coeff_vec[0] != 1:
+                warnings.warn(f'Pword coefficient {pauli_rotation.coeff_vec[0]: .8f} has been set to 1')
+            if getattr(angle, 'imag', 0) != 0:
+                warnings.warn('Complex component in angle: this will be ignored.')
+            angle = float(np.real(angle))
+            angles.append(angle)
+            q_rows[r] = pauli_rotation.packed[0]
+            cos_t[r], sin_t[r], ks[r] = kernels.rotation_args(angle)
         dev = kernels.DeviceOp.upload(self.packed, self.coeff_vec)
         # The reference calls ``.cleanup()`` after every rotation (base.py:1185).  On an operator that has no duplicate rows and
         # no coefficient with |c| <= 1e-15 that cleanup is the identity, and the rotation kernels preserve both properties
         # (a rotated row P*Q can only coincide with an input row, which the kernels merge themselves; they also apply the
         # strict threshold).  So the device cleanup runs until the operator is known to be in that state — i.e. once, after
-        # the first rotation of a user-supplied operator — and is skipped for the rest of the chain.
+        # the first rotation of a user-supplied operator — and is skipped for the rest of the chain; a run of Clifford rotations
+        # of a clean operator is one call of the chain entry point (rows in registers, csrc/rotate_chain.hip).
         clean = False
         try:
-            step, n_rot = 0, len(rotations)
-            while step < n_rot:
-                pauli_rotation, angle = rotations[step]
-                assert pauli_rotation.n_terms == 1, 'Only rotation by single Pauliword allowed here'
-                assert pauli_rotation.n_qubits == self.n_qubits, 'Pauliwords defined for different number of qubits'
-                if angle is None:
-                    angle = np.pi / 2
-                if pauli_rotation.coeff_vec[0] != 1:
-                    warnings.warn(f'Pword coefficient {pauli_rotation.coeff_vec[0]: .8f} has been set to 1')
-                if getattr(angle, 'imag', 0) != 0:
-                    warnings.warn('Complex component in angle: this will be ignored.')
-                angle = float(np.real(angle))
-                if clean and 0 < dev.n_terms <= kernels.CLIFFORD_CHAIN_MAX_TERMS and kernels.rotation_args(angle)[2] >= 0:
-                    # A run of Clifford rotations of a clean, small operator (the circuit simulator's case) is ONE launch: no step
-                    # drops or merges anything (|c| is unchanged, distinct rows stay distinct), so the per-step cleanup() of the
-                    # reference is the identity and only the stable partition + row ^= Q + phase remains (csrc/rotate.hip).
-                    q_rows, ks = [pauli_rotation.packed[0]], [kernels.rotation_args(angle)[2]]
-                    step += 1
-                    while step < n_rot:
-                        nxt, nxt_angle = rotations[step]
-                        nxt_angle = np.pi / 2 if nxt_angle is None else nxt_angle
-                        if nxt.n_terms != 1 or nxt.n_qubits != self.n_qubits or getattr(nxt_angle, 'imag', 0) != 0:
-                            break                                   # let the single-step branch raise / warn
-                        k = kernels.rotation_args(float(np.real(nxt_angle)))[2]
-                        if k < 0:
-                            break
-                        if nxt.coeff_vec[0] != 1:
-                            warnings.warn(f'Pword coefficient {nxt.coeff_vec[0]: .8f} has been set to 1')
-                        q_rows.append(nxt.packed[0]); ks.append(k)
-                        step += 1
-                    res = kernels.rotate_clifford_chain_dev(dev, np.vstack(q_rows), ks)
-                    dev.free()
-                    dev = res
-                    continue
-                step += 1
+            step = 0
+            while step < K:
                 if dev.n_terms > 0:
-                    res, all_commute = kernels.rotate_single_dev(dev, pauli_rotation.packed[0], angle)
-                    if not all_commute:
-                        _warn_large_angle(angle, 1e-18)
+                    res, n_done, acted, clean = kernels.perform_rotations_dev(dev, q_rows[step:], cos_t[step:], sin_t[step:], ks[step:], clean)
+                    for r in np.flatnonzero(acted[:n_done]):
+                        _warn_large_angle(angles[step + int(r)], 1e-18)
+                    if res is not None:
                         dev.free()
                         dev = res
+                    step += n_done
+                else:
+                    step += 1
                 if dev.n_terms == 0:
                     # an operator without terms becomes 0*I under cleanup(), and 0*I loses its only term again under the
                     # next one (base.py:631-632): the reference alternates between the two states
-                    cleaned = kernels.DeviceOp.upload(np.zeros((1, 2 * wq), dtype='<u8'), np.zeros(1, dtype=complex))
+                    dev.free()
+                    dev = kernels.DeviceOp.upload(np.zeros((1, 2 * wq), dtype='<u8'), np.zeros(1, dtype=complex))
                     clean = False
-                elif not clean:
-                    cleaned = kernels.cleanup_dev(dev)
-                    clean = True
-                else:
-                    continue
-                dev.free()
-                dev = cleaned
             rows, coeff = dev.download()
         finally:
             dev.free()

@@ -536,8 +536,8 @@ def sharded_mul_cleanup(inner_rows, inner_coeff, outer_rows_local, outer_coeff_l
                         mul_kernel=None, cleanup_kernel=None):
     """Host arrays, gloo (CPU tests / the algorithm of :meth:`Communicator.mul_cleanup_sharded`): this rank holds ALL of the inner
     operand and its contiguous block of the outer one (ranks in order).  ``mul_kernel(inner, ci, outer, co, inner_is_left, thr)`` =
-    fused product + cleanup (thr None: keep everything), ``cleanup_kernel(rows, coeff, thr)`` = first-occurrence cleanup; the CPU
-    tests inject the C oracle.  Returns the cleaned product (rows, coeff), identical on every rank."""
+    fused product + cleanup (thr None: keep everything), ``cleanup_kernel(rows, coeff, thr)`` = first-occurrence cleanup (the CPU
+    tests inject their reference checker).  Returns the cleaned product (rows, coeff), identical on every rank."""
     if mul_kernel is None or cleanup_kernel is None:
         from . import kernels
         mul_kernel = mul_kernel or (lambda a, ca, b, cb, left, thr: kernels.mul_cleanup(a, ca, b, cb, left, thr))

@@ -298,3 +298,40 @@ def test_cfg5_whole_adjacency_one_launch():
         r0, c0 = (int(v) for v in rng.integers(0, T - 256, 2))
         assert np.array_equal(block(r0, c0).astype(bool), oc.commutes(a_rows[r0:r0 + 256], a_rows[c0:c0 + 256]))
     _lib.check(lib.symgpu_dev_free(buf)); _lib.check(lib.symgpu_dev_free(bits)); A.free()
+
+
+@pytest.mark.parametrize('workload,metric,kernel', [('mul_cleanup', 'pauli_term_pairs_per_sec', 'k_emit_stream'),
+                                                    ('rotation', 'pauli_term_pairs_per_sec', 'k_rot_resident'),
+                                                    ('gf2', 'gf2_row_xors_per_sec', 'k_sweep_m4r')])
+def test_bench_workloads_of_the_other_baseline_configs(workload, metric, kernel):
+    """`bench.py --workload mul_cleanup | rotation | gf2` (BASELINE cfg3 / cfg2 / cfg4 at full size): ONE JSON line
+    with the contract's keys, an own roofline object measured with HIP events on the workload's dominant kernel, and the result
+    of the step checked where the line carries it (terms out, generators found)."""
+    import json, sys, io, contextlib, importlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    argv, buf = sys.argv, io.StringIO()
+    sys.argv = ['bench.py', '--gpus', '1', '--steps', '1', '--warmup', '1', '--workload', workload, '--no-extras', '--no-cpu']
+    try:
+        with contextlib.redirect_stdout(buf):                      # in-process: no exec from a process that holds the GPU
+            bench.main()
+    finally:
+        sys.argv = argv
+    lines = [l for l in buf.getvalue().splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+                'config', 'roofline'):
+        assert key in d, key
+    r = d['roofline']
+    assert d['metric'] == metric and d['value'] > 0 and d['n_gpus'] == 1 and d['vs_baseline'] is None and 'workload' in d['config']
+    assert r['bound'] == 'hbm' and r['kernel'] == kernel and r['launches'] > 0 and 0 < r['frac'] < 1.2 and r['peak'] == 8000.0
+    assert abs(r['achieved'] / r['peak'] - r['frac']) < 1e-9 and 'traffic' in r
+    if workload == 'mul_cleanup':
+        assert d['config']['pairs_per_step'] == 10 ** 8 and 2.4e7 < d['config']['terms_out'] < 2.6e7
+    if workload == 'rotation':
+        assert d['config']['terms'] == 100000 and 1.4e5 < d['config']['terms_out'] <= 1.5e5 and r['launches'] == 100
+    if workload == 'gf2':
+        assert d['config']['generators_found'] == 32 and d['config']['matrix'] == [4000, 54000] and 7e6 < d['config']['row_xors_per_step'] < 9e6
