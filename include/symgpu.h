@@ -57,7 +57,8 @@ int symgpu_prof_read(int kernel_class, int64_t *n_launches, double *total_ms);
 /* statistics for tests: which = 0: number of row-hash collisions that forced the cleanup to reseed its hash and retry (the exactness
  * guard behind symplectic_cleanup, operators/utils.py:230-279; expected 0 outside the tests, which weaken the hash on purpose);
  * 1: rotations completed by the one-launch LDS-resident kernel; 2: calls of that kernel that reported a failed row verification or a
- * barrier time-out (the multi-launch path then recomputes); 3: device allocations that were not served from the allocator's arena */
+ * barrier time-out (the multi-launch path then recomputes); 3: device allocations that were not served from the allocator's arena;
+ * 4-6: host nanoseconds spent by the one-launch rotation in preparation, in the launch call and waiting for the kernel's status word */
 int symgpu_debug_counter(int which, int64_t *value);
 /* tuning aid: with SYMGPU_RES_TRACE=1 every workgroup of the one-launch rotation kernel stamps the 100 MHz wall clock at its phase
  * boundaries; this copies the stamps of the last traced launch, 16 words per workgroup */

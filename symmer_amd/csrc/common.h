@@ -73,7 +73,7 @@ struct Context {
     bool res_disabled = false;     // a barrier timed out once (workgroups not co-resident): the process keeps to the multi-launch paths
 };
 Context &ctx();
-extern i64 g_counters[4];                  // debug counters (symgpu_debug_counter): [1] one-launch rotations, [2] their failures, [3] hipMalloc calls of dev_alloc
+extern i64 g_counters[8];                  // debug counters (symgpu_debug_counter): [1] one-launch rotations, [2] their failures, [3] hipMalloc calls of dev_alloc
 int require_ctx();
 
 // per-launch event timing of one kernel class (bench.py roofline leg)

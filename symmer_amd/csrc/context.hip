@@ -29,7 +29,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
 }
 
 static Context g_ctx;
-i64 g_counters[4] = {0, 0, 0, 0};          // symgpu_debug_counter 1..3 (0 is g_hash_reseeds, cleanup.hip)
+i64 g_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // symgpu_debug_counter 1..6 (0 is g_hash_reseeds, cleanup.hip)
 Context &ctx() { return g_ctx; }
 
 int require_ctx() {
@@ -499,7 +499,7 @@ int symgpu_prof_enable(int kernel_class, int on) {
 }
 
 int symgpu_debug_counter(int which, int64_t *value) {
-    SG_REQUIRE(value && which >= 0 && which <= 3, "debug_counter: 0 = row-hash reseeds, 1 = rotations done by the one-launch kernel, 2 = its failures (verification / time-out), 3 = device allocations that went to hipMalloc");
+    SG_REQUIRE(value && which >= 0 && which <= 6, "debug_counter: 0 = row-hash reseeds, 1 = rotations done by the one-launch kernel, 2 = its failures (verification / time-out), 3 = device allocations that went to hipMalloc, 4-6 = host nanoseconds of the one-launch rotation (preparation, launch call, wait)");
     *value = which == 0 ? g_hash_reseeds : g_counters[which];
     return SYMGPU_OK;
 }

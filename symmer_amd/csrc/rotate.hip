@@ -290,6 +290,7 @@ int host_counts(RotCounts **host, RotCounts **dev) {
     Context &c = ctx();
     if (!c.rot_host_cnt) {
         HIP_TRY(hipHostMalloc(&c.rot_host_cnt, 64, hipHostMallocMapped));
+        for (int i = 0; i < 8; ++i) reinterpret_cast<volatile u64 *>(c.rot_host_cnt)[i] = 0;
         HIP_TRY(hipHostGetDevicePointer(&c.rot_host_cnt_dev, c.rot_host_cnt, 0));
     }
     *host = reinterpret_cast<RotCounts *>(c.rot_host_cnt);

@@ -29,9 +29,12 @@
 // (non-Clifford), has rows of <= 64 words, and its block of rows fits the LDS.
 #include "common.h"
 #include "rotate_common.h"
+#include <time.h>
 #include <stdlib.h>
 
 namespace symgpu {
+
+static inline i64 host_ns() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (i64)ts.tv_sec * 1000000000LL + ts.tv_nsec; }
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
@@ -82,7 +85,7 @@ struct ResArgs {
     u32 epoch;
     u64 *trace;                                   // [G][16] wall-clock stamps of the phases (SYMGPU_RES_TRACE=1), else null
     int inject;                                   // tests: the last workgroup leaves at once without a word (SYMGPU_RES_INJECT=1)
-    RotCounts *host_cnt;
+    u64 *host_words; u32 *host_late; u32 host_tag; u32 *published;   // pinned host memory: the report (res_report) and the late-failure word
     QArg q;
 };
 
@@ -94,9 +97,11 @@ __device__ __forceinline__ void ag_store(u64 *p, u64 v) { __hip_atomic_store(p, 
 __device__ __forceinline__ u32 ag_load32(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ag_store32(u32 *p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// One wavefront re-reads all G granules until every tag is `tag`; on success the three 16-bit count fields are summed over the
-// workgroups before `w` (pref) and over all of them (tot).  Returns false after RES_SPIN_LIMIT sweeps.
-__device__ __forceinline__ bool ag_sweep(const u64 *gran, int G, u32 tag, int w, int lane, u32 (&pref)[3], u32 (&tot)[3]) {
+// One wavefront re-reads all G granules until every tag is `tag`; on success the three count fields (16, 16 and 15 bits) are summed
+// over the workgroups before `w` (pref) and over all of them (tot); `flagged`: some workgroup set bit 47 (RES_GRAN_FAIL: it failed a
+// verification or gave up).  Returns false after RES_SPIN_LIMIT sweeps.
+constexpr u64 RES_GRAN_FAIL = 1ULL << 47;
+__device__ __forceinline__ bool ag_sweep(const u64 *gran, int G, u32 tag, int w, int lane, u32 (&pref)[3], u32 (&tot)[3], bool &flagged) {
     u64 v[4];
     for (u32 spins = 0;; ++spins) {
         bool ok = true;
@@ -112,13 +117,15 @@ __device__ __forceinline__ bool ag_sweep(const u64 *gran, int G, u32 tag, int w,
     }
 #pragma unroll
     for (int f = 0; f < 3; ++f) { pref[f] = 0; tot[f] = 0; }
+    bool fl = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int idx = lane + 64 * j;
         if (idx < G) {
+            fl |= (v[j] & RES_GRAN_FAIL) != 0;
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
-                const u32 x = (u32)(v[j] >> (16 * f)) & 0xFFFFu;
+                const u32 x = (u32)(v[j] >> (16 * f)) & (f == 2 ? 0x7FFFu : 0xFFFFu);
                 tot[f] += x;
                 if (idx < w) pref[f] += x;
             }
@@ -127,21 +134,33 @@ __device__ __forceinline__ bool ag_sweep(const u64 *gran, int G, u32 tag, int w,
 #pragma unroll
     for (int f = 0; f < 3; ++f)
         for (int off = 32; off > 0; off >>= 1) { pref[f] += (u32)__shfl_xor((int)pref[f], off); tot[f] += (u32)__shfl_xor((int)tot[f], off); }
+    flagged = __ballot(fl) != 0ULL;
     return true;
 }
 
-// A workgroup leaves (done or timed out): the LAST one to leave — it sees every failure word written before the others' arrivals —
-// writes the counts and the status to pinned host memory.
-__device__ __forceinline__ void res_leave(const ResArgs &a, u32 totC, u32 totA, u32 totN, u32 totAnti) {
+// The counts of a launch in pinned host memory: two 8-byte words that carry the call's tag — the data is the flag, the host waits
+// until both show it.  [tag 16 | nC 22 | nA 22], [tag 16 | code 4 | nN 22 | nAnti 22]
+__device__ __forceinline__ void res_report(const ResArgs &a, u32 code, u32 nC, u32 nA, u32 nN, u32 nAnti) {
+    __hip_atomic_store(&a.host_words[0], ((u64)a.host_tag << 48) | ((u64)nC << 22) | nA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&a.host_words[1], ((u64)a.host_tag << 48) | ((u64)code << 44) | ((u64)nN << 22) | nAnti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// A workgroup leaves (done or timed out).  Success is reported EARLY, by one workgroup as soon as the second all-gather has told it
+// the counts (k_rot_resident): the host prepares and enqueues whatever comes next while the rows are still on their way out.  Failures
+// are reported by the LAST workgroup to leave — it sees every failure word written before the others' arrivals; should one appear
+// after success has been reported (a time-out behind a completed all-gather: not reachable by construction) it goes to the `late`
+// word, which fails the next call loudly.
+__device__ __forceinline__ void res_leave(const ResArgs &a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const u32 prev = atomicAdd(a.finished, 1u);
     if (prev + 1u == a.finish_target) {
         u32 code = 0;
         if (ag_load32(&a.fail[0]) == a.epoch) code = 2;
         if (ag_load32(&a.fail[1]) == a.epoch) code = 3;
-        a.host_cnt->nC = totC; a.host_cnt->nA = totA; a.host_cnt->nN = totN; a.host_cnt->nAnti = totAnti;
-        // the status word goes last, system scope: the host polls it in pinned memory instead of synchronising the stream
-        __hip_atomic_store(&a.host_cnt->dup, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (code) {
+            if (ag_load32(a.published) == a.epoch) __hip_atomic_store(a.host_late, ((u32)a.epoch << 4) | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else res_report(a, code, 0, 0, 0, 1);
+        }
     }
 }
 
@@ -375,7 +394,8 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
         // ---- g1 ----------------------------------------------------------------------------------------------------------------
         if (wave == 0) {
             u32 pref[3], tot[3];
-            const bool ok = ag_sweep(a.gran1, G, tag1, w, lane, pref, tot);
+            bool flagged;
+            const bool ok = ag_sweep(a.gran1, G, tag1, w, lane, pref, tot, flagged);
             if (lane == 0) { s_misc[M_OK] = ok ? 1u : 0u; s_misc[M_PREF_C] = pref[0]; s_misc[M_TOT_C] = tot[0]; }
         }
         __syncthreads();
@@ -385,8 +405,8 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
             if (tid == 0) {
                 ag_store32(&a.fail[1], a.epoch);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                ag_store(&a.gran2[w], (u64)tag2 << 48);
-                res_leave(a, 0, 0, 0, 1);
+                ag_store(&a.gran2[w], ((u64)tag2 << 48) | RES_GRAN_FAIL);
+                res_leave(a);
             }
             return;
         }
@@ -478,7 +498,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
                 const u64 nC = sum & 0xFFFFu, nA = (sum >> 16) & 0xFFFFu, nN = (sum >> 32) & 0xFFFFu, nAnti = (sum >> 48) & 0xFFFFu;
                 // Clifford: ONE all-gather carries {rotated rows (class A or N: only one of them occurs per k), commuting rows, all anticommuting}
                 if (MODE == 1) ag_store(&a.gran2[w], ((u64)tag2 << 48) | (nA + nN) | (nC << 16) | (nAnti << 32));
-                else ag_store(&a.gran2[w], ((u64)tag2 << 48) | nA | (nN << 16) | (nAnti << 32));
+                else ag_store(&a.gran2[w], ((u64)tag2 << 48) | nA | (nN << 16) | (nAnti << 32) | (s_misc[M_FAIL] ? RES_GRAN_FAIL : 0ULL));
             }
         }
         for (int j = 0; j < K; ++j) {
@@ -492,6 +512,18 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
         }
     }
     __syncthreads();
+    // ---- the report: the last wavefront of the last workgroup (the one with the shortest block) follows all-gather #2 before it
+    //      turns to its share of the rows, and tells the host the counts the moment they are final and nobody has failed
+    if (w == G - 1 && wave == RES_THREADS / 64 - 1) {
+        u32 pref[3], tot[3];
+        bool flagged;
+        const bool ok = ag_sweep(a.gran2, G, tag2, w, lane, pref, tot, flagged);
+        if (lane == 0 && ok && !flagged) {
+            ag_store32(a.published, a.epoch);
+            if (MODE == 1) res_report(a, 0, tot[1], (a.k & 1) ? 0 : tot[0], (a.k & 1) ? tot[0] : 0, tot[2]);
+            else res_report(a, 0, totC, tot[0], tot[1], tot[2]);
+        }
+    }
     f64x2 *out_coeff2 = reinterpret_cast<f64x2 *>(a.out_coeff);
     if (MODE == 0) {
         // ---- C1: the commuting rows go out while the second all-gather is in flight -------------------------------------------
@@ -513,7 +545,8 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
     // ---- g2 ------------------------------------------------------------------------------------------------------------------------
     if (wave == 0) {
         u32 pref[3], tot[3];
-        const bool ok = ag_sweep(a.gran2, G, tag2, w, lane, pref, tot);
+        bool flagged;
+        const bool ok = ag_sweep(a.gran2, G, tag2, w, lane, pref, tot, flagged);
         if (lane == 0) {
             s_misc[M_OK] = ok ? 1u : 0u;
             if (MODE == 1) {      // rotated rows first (filed under A or N, whichever this k produces), then the commuting ones
@@ -530,7 +563,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
     if (!s_misc[M_OK]) {
         if (tid == 0) {
             ag_store32(&a.fail[1], a.epoch);
-            res_leave(a, 0, 0, 0, 1);
+            res_leave(a);
         }
         return;
     }
@@ -587,7 +620,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // every wavefront's rows have left ...
     __syncthreads();
     RES_STAMP(7);
-    if (tid == 0) res_leave(a, totC, totA, totN, s_misc[M_TOT_ANTI]);              // ... before the block counts as gone
+    if (tid == 0) res_leave(a);              // ... before the block counts as gone
 }
 
 typedef void (*ResKernel)(const ResArgs);
@@ -615,6 +648,7 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
                         int *all_commute, int *done) {
     *done = 0;
     Context &c = ctx();
+    const i64 t_enter = host_ns();
     if (const char *e = getenv("SYMGPU_ROT_RESIDENT")) {                          // read on every call: 0 = off, 2 = on again after a failure
         if (e[0] == '0') return SYMGPU_OK;
         if (e[0] == '2') c.res_disabled = false;
@@ -657,7 +691,7 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
         SG_TRY(hash_rows(in->rows, T, W, in->hash));
         have_hash = true;
     }
-    constexpr size_t state_words = 2 * RES_MAX_WG + 2;                            // granules, {fail[0], fail[1]}, {finished, -}
+    constexpr size_t state_words = 2 * RES_MAX_WG + 2;                            // granules, {fail[0], fail[1]}, {finished, published}
     static u32 finished_base = 0;
     if (!c.res_state) {
         HIP_TRY(hipMalloc((void **)&c.res_state, state_words * 8));
@@ -720,9 +754,21 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
         a.trace = g_res_trace;
         g_res_trace_wgs = (int)G;
     }
+    // the report: bytes 32..55 of the context's pinned count block ([late 4 | - 4 | word0 8 | word1 8]); tags 1..65535 (the block starts zeroed)
     RotCounts *hcnt = nullptr, *hcnt_dev = nullptr;
     SG_TRY(host_counts(&hcnt, &hcnt_dev));
-    a.host_cnt = hcnt_dev;
+    volatile u32 *host_late = reinterpret_cast<u32 *>(hcnt) + 8;
+    volatile u64 *host_words = reinterpret_cast<u64 *>(hcnt) + 5;
+    if (*host_late != 0) {                                                        // a launch failed AFTER it had reported its counts
+        c.res_disabled = true; c.res_epoch = 0; c.res_dirty = true;
+        *host_late = 0;
+        set_error("rotate resident: a previous launch failed after it had reported success; its result is invalid");
+        return SYMGPU_E_HIP;
+    }
+    static u32 host_tag = 0;
+    host_tag = host_tag >= 65535 ? 1 : host_tag + 1;
+    a.host_late = reinterpret_cast<u32 *>(hcnt_dev) + 8; a.host_words = reinterpret_cast<u64 *>(hcnt_dev) + 5; a.host_tag = host_tag;
+    a.published = a.fail + 3;
     for (int ww = 0; ww < 64; ++ww) a.q.w[ww] = ww < W ? q_host[ww] : 0ULL;
     symgpu_op_t res = nullptr;
     SG_TRY(symgpu_op_alloc(clifford ? T : 2 * T, Wq, 1, &res));                   // upper bound: no host round trip before the rows are written
@@ -732,31 +778,48 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
         res->hash_seed = in->hash_seed;
     }
     a.out_rows = reinterpret_cast<u32x4 *>(res->rows); a.out_coeff = res->coeff; a.out_hash = res->hash;
-    __atomic_store_n(&hcnt->dup, 0xFFFFFFFFu, __ATOMIC_RELEASE);                   // poison: the kernel must report
+    const i64 t_launch = host_ns();
     {
         ProfScope prof(4);
         hipLaunchKernelGGL(res_kernel(clifford, Wq), dim3((unsigned)G), dim3(RES_THREADS), (size_t)L.total, st, a);
     }
     hipError_t e = hipGetLastError();
+    const i64 t_wait = host_ns();
+    g_counters[4] += t_launch - t_enter; g_counters[5] += t_wait - t_launch;
     if (e != hipSuccess) { symgpu_op_free(res); c.res_dirty = true; return hip_fail(e, "rotate resident", __FILE__, __LINE__); }
-    // The last workgroup to leave writes the counts and then the status word into pinned host memory: poll that word instead of
-    // synchronising the stream (whose wake-up costs more than the kernel's tail) — whatever is enqueued next is stream ordered
-    // behind the kernel anyway.  The kernel gives up by itself after ~1 s; no word although the stream is idle: failure.
+    // One workgroup reports the counts as soon as they are final (after the second all-gather, while the rows are still being written):
+    // poll the two tagged words in pinned memory instead of synchronising the stream — whatever the caller enqueues next is stream
+    // ordered behind the kernel, and its preparation overlaps the kernel's tail.  The kernel gives up by itself after ~1 s and then
+    // reports a failure code from its last workgroup; no report although the stream is idle: failure.
+    u64 w0 = 0, w1 = 0;
     {
-        volatile u32 *status = &hcnt->dup;
         bool seen = false;
         for (u64 spin = 0; spin < (1ULL << 34); ++spin) {
-            if (__atomic_load_n(status, __ATOMIC_ACQUIRE) != 0xFFFFFFFFu) { seen = true; break; }
+            w0 = __atomic_load_n(host_words, __ATOMIC_ACQUIRE); w1 = __atomic_load_n(host_words + 1, __ATOMIC_ACQUIRE);
+            if ((u32)(w0 >> 48) == host_tag && (u32)(w1 >> 48) == host_tag) { seen = true; break; }
             if ((spin & 0xFFFFF) == 0xFFFFF) {
                 const hipError_t qe = hipStreamQuery(st);
-                if (qe != hipErrorNotReady) { if (qe != hipSuccess) e = qe; break; }       // finished (or failed) without a word
+                if (qe != hipErrorNotReady) {                                    // finished (or failed): one last look
+                    if (qe != hipSuccess) e = qe;
+                    w0 = __atomic_load_n(host_words, __ATOMIC_ACQUIRE); w1 = __atomic_load_n(host_words + 1, __ATOMIC_ACQUIRE);
+                    seen = (u32)(w0 >> 48) == host_tag && (u32)(w1 >> 48) == host_tag;
+                    break;
+                }
             }
         }
-        if (!seen && e == hipSuccess) e = hipStreamSynchronize(st);
+        if (!seen && e == hipSuccess) {
+            e = hipStreamSynchronize(st);
+            w0 = __atomic_load_n(host_words, __ATOMIC_ACQUIRE); w1 = __atomic_load_n(host_words + 1, __ATOMIC_ACQUIRE);
+            seen = (u32)(w0 >> 48) == host_tag && (u32)(w1 >> 48) == host_tag;
+        }
         if (e != hipSuccess) { symgpu_op_free(res); c.res_dirty = true; return hip_fail(e, "rotate resident", __FILE__, __LINE__); }
+        if (!seen) { w0 = 0; w1 = 1ULL << 44; }                                   // no report at all: code 1
     }
-    const RotCounts hc = *hcnt;
-    if (hc.dup != 0) {                                                             // verification failed, timed out, or no report at all
+    g_counters[6] += host_ns() - t_wait;
+    RotCounts hc;
+    hc.nC = (u32)(w0 >> 22) & 0x3FFFFFu; hc.nA = (u32)w0 & 0x3FFFFFu; hc.nN = (u32)(w1 >> 22) & 0x3FFFFFu; hc.nAnti = (u32)w1 & 0x3FFFFFu;
+    hc.dup = (u32)(w1 >> 44) & 0xFu;
+    if (hc.dup != 0) {                                                             // verification failed (2), timed out (3), or no report at all (1)
         symgpu_op_free(res);
         ++g_counters[2];
         if (hc.dup != 2) { c.res_disabled = true; c.res_epoch = 0; c.res_dirty = true; }   // time-out: arrival counts, table and notes are in an unknown state
