@@ -397,7 +397,7 @@ def wl_rotation(args, comm, rank, world, _lib, DeviceOp, parallel):
     roof = {'bound': 'hbm', 'kernel': 'k_rot_resident', 'achieved': launch_bytes / kt / 1e9 if kt else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': launch_bytes / kt / 1e9 / HBM_PEAK_GBS if kt else None, 'traffic': None, 'launches': nl, 'avg_launch_ms': kt * 1e3,
             'algorithmic_bytes_per_launch': launch_bytes, 'whole_call_GBps': launch_bytes / (dt / (args.steps * ROT)) / 1e9,
-            'events_pass': 'a second pass of the same steps right after the timed region (events inside every 39 us call would be part of it)',
+            'events_pass': 'a second pass of the same steps right after the timed region (events inside every 27 us call would be part of it)',
             'note': 'one persistent launch per rotation, rows resident in LDS (one workgroup per CU); the launch is a chain of dependent phases '
                     '(rows in 7 us, join-table compare-and-swaps 3 us, two in-launch all-gathers, rows out 7 us), not a bandwidth-bound stream'}
     traffic_from_profile(roof, 'r03_rotation_traffic.json', ['rotate_resident.hip'], {'workload': 'rotation', 'n_qubits': n, 'terms': N})
