@@ -275,6 +275,102 @@ __device__ __forceinline__ void tri_pair(u32 p, u32 N, u32 &o, u32 &i) {
 }
 
 
+// ---- terms that merge with nothing ("singles") never pass through the sorted order ------------------------------------------------
+// An operator product without repeated rows — the common case, and the benchmark's — merges nothing: every sorted key is a segment of
+// its own.  Filing 2.5e7 sums under their first index from the SORTED order is a random 16-byte scatter plus a bitmap atomic per
+// term (WRITE_SIZE 1.56 GB for 0.4 GB of sums: 1.0 of k_heads_sums' 1.36 ms at cfg3), and the output stage then reads them back.
+// Instead the fate of a term AS IF IT WERE ALONE is decided here, in INDEX order and before the sort — strict |c| > thr on
+// 0.0 + c, exactly the sum k_heads_sums forms for a one-element segment — with coalesced bitmap stores; the packed pair key's
+// phase exponent goes to two more bitmaps (the sort scrambles the keys).  k_heads_sums then only touches the members of segments
+// with MORE than one element: the followers clear their bits, the head files the sum and sets its `patch` bit; k_emit_meta takes a
+// patched term's coefficient from the filed sum and rebuilds every other one from the operand tables (cache resident).  Nothing
+// about the result changes: same kept set, same order, same sums.
+// PACKED: keys[s] is the packed key of index s (pair index, or slot of a squared operator); otherwise coeff[s].
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_mark_singles(const u64 *__restrict__ keys, const double *__restrict__ coeff, i64 space, PackedLayout L,
+                                                       const double *__restrict__ ci, const double *__restrict__ co, int squared, double thr, int use_thr,
+                                                       u64 *__restrict__ markbits64, u64 *__restrict__ e_lo64, u64 *__restrict__ e_hi64) {
+    const int lane = threadIdx.x & 63;
+    const i64 n_steps = (space + 255) / 256;                          // four 64-index chunks per wavefront and step, their loads in flight together
+    for (i64 g = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); g < n_steps; g += (i64)gridDim.x * 4) {
+        u64 k[4];
+        double2 cf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i64 sidx = g * 256 + 64 * j + lane;
+            k[j] = 0ULL; cf[j].x = 0.0; cf[j].y = 0.0;
+            if (sidx < space) {
+                if (PACKED) k[j] = keys[sidx];
+                else cf[j] = reinterpret_cast<const double2 *>(coeff)[sidx];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i64 sidx = g * 256 + 64 * j + lane;
+            if (g * 256 + 64 * j >= space) break;                     // wave-uniform
+            const bool valid = sidx < space;
+            double cx = cf[j].x, cy = cf[j].y;
+            int e = 0;
+            if (PACKED && valid) {
+                const u32 i = L.i(k[j]), o = L.o(k[j]);
+                e = L.e(k[j]);
+                pair_coefficient(ci[2 * i], ci[2 * i + 1], co[2 * o], co[2 * o + 1], e, cx, cy);
+                if (squared && i != o) {
+                    if (e & 1) { cx = 0.0; cy = 0.0; }
+                    else { cx = __dadd_rn(cx, cx); cy = __dadd_rn(cy, cy); }
+                }
+            }
+            // strict |c| > thr: a component that alone exceeds thr decides it (hypot is faithfully rounded and >= either component)
+            // (and an exact zero — every anticommuting pair of a squared operator — needs no hypot either)
+            const bool zero = cx == 0.0 && cy == 0.0;
+            const bool keep = valid && (!use_thr || (zero ? 0.0 > thr : (fabs(cx) > thr || fabs(cy) > thr || hypot(__dadd_rn(0.0, cx), __dadd_rn(0.0, cy)) > thr)));
+            const u64 mk = __ballot(keep);
+            const i64 chunk = g * 4 + j;
+            if (PACKED) {
+                const u64 lo = __ballot(e & 1), hi = __ballot(e & 2);
+                if (lane == 0) { markbits64[chunk] = mk; e_lo64[chunk] = lo; e_hi64[chunk] = hi; }
+            } else if (lane == 0) markbits64[chunk] = mk;
+        }
+    }
+}
+
+// lazy mode, after the sort: which 64-position chunks of the sorted keys hold a member of a segment with more than one element?
+// A position that equals its predecessor (the test k_heads_sums makes: prefix, then P * P twins, then the full keys rebuilt from the
+// operand hash tables) marks its own chunk and its predecessor's.  Four chunks per wavefront and step, all loads of a step in flight.
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_find_merges(const u64 *__restrict__ keys, i64 T, const u32 *__restrict__ zero_len, PackedLayout L,
+                                                      const u64 *__restrict__ hI, const u64 *__restrict__ hO, int same_operand, u32 *__restrict__ dirtybits) {
+    const i64 ZL = zero_len ? (i64)*zero_len : 0;
+    const int lane = threadIdx.x & 63;
+    const i64 n_steps = (T + 255) / 256;
+    for (i64 g = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); g < n_steps; g += (i64)gridDim.x * 4) {
+        const i64 base = g * 256;
+        u64 k[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const i64 sp = base + 64 * j + lane; k[j] = sp < T ? keys[sp] : 0ULL; }
+        const u64 prev = base > 0 ? keys[base - 1] : 0ULL;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i64 sp = base + 64 * j + lane;
+            u64 k0 = __shfl_up(k[j], 1);
+            const u64 carry_in = j > 0 ? __shfl(k[j > 0 ? j - 1 : 0], 63) : prev;
+            if (lane == 0) k0 = carry_in;
+            const bool valid = sp < T && sp >= ZL;
+            bool eq;
+            if (PACKED) {
+                eq = valid && sp > 0 && (k[j] >> L.F()) == (k0 >> L.F());
+                if (eq && !(same_operand && L.i(k[j]) == L.o(k0) && L.o(k[j]) == L.i(k0))) eq = L.full_key(hI, hO, k[j]) == L.full_key(hI, hO, k0);
+            } else eq = valid && sp > 0 && k[j] == k0;
+            const u64 b = __ballot(eq);
+            if (b != 0ULL && lane == 0) {
+                const i64 chunk = base / 64 + j;
+                atomicOr(&dirtybits[chunk >> 5], 1u << (chunk & 31));
+                if ((b & 1ULL) && chunk > 0) atomicOr(&dirtybits[(chunk - 1) >> 5], 1u << ((chunk - 1) & 31));
+            }
+        }
+    }
+}
+
 // ---- the identity segment of a squared operator -------------------------------------------------------------------------------
 // P * P has N diagonal pairs (i, i), and every one of them is the identity row: N equal keys — with FULL KEY ZERO, because the row
 // hash is linear (h(0) = 0) — i.e. one segment of >= N elements at the very start of the sorted array.  k_heads_sums sums a
@@ -286,7 +382,8 @@ __device__ __forceinline__ void tri_pair(u32 p, u32 N, u32 &o, u32 &i) {
 constexpr int ZB = 4096;                                              // sorted positions per block
 __global__ __launch_bounds__(256) void k_zero_partial(const u64 *__restrict__ keys, i64 Tk, const u64 *__restrict__ hI, const u64 *__restrict__ hO,
                                                        PackedLayout L, const u64 *__restrict__ rows, int W, const double *__restrict__ cf,
-                                                       double *__restrict__ part, u32 *__restrict__ part_n, u32 *__restrict__ collision) {
+                                                       double *__restrict__ part, u32 *__restrict__ part_n, u32 *__restrict__ collision,
+                                                       u32 Ni, u32 *__restrict__ lazy_markbits) {
     __shared__ double s_re[256], s_im[256];
     __shared__ u32 s_n[256];
     const i64 base = (i64)blockIdx.x * ZB;
@@ -313,6 +410,10 @@ __global__ __launch_bounds__(256) void k_zero_partial(const u64 *__restrict__ ke
         re = __dadd_rn(re, cr);
         im = __dadd_rn(im, cim);
         ++n;
+        if (lazy_markbits) {                                          // not a single: whatever k_mark_singles decided is void (k_zero_close files the head)
+            const u32 slot = tri_slot(o, i, Ni);
+            atomicAnd(&lazy_markbits[slot >> 5], ~(1u << (slot & 31u)));
+        }
     }
     s_re[threadIdx.x] = re; s_im[threadIdx.x] = im; s_n[threadIdx.x] = n;
     if (mism) atomicOr(collision, 1u);
@@ -327,7 +428,7 @@ __global__ __launch_bounds__(256) void k_zero_partial(const u64 *__restrict__ ke
 // blocks in order; files the identity term under the slot of the segment's first element and tells k_heads_sums where to start
 __global__ void k_zero_close(const u64 *__restrict__ keys, const double *__restrict__ part, const u32 *__restrict__ part_n, i64 n_blocks,
                              PackedLayout L, u32 Ni, double thr, int use_thr, u32 *__restrict__ markbits, double *__restrict__ sum_of,
-                             u32 *__restrict__ zero_len) {
+                             u32 *__restrict__ zero_len, u32 *__restrict__ patchbits) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double re = 0.0, im = 0.0;
     u64 len = 0;
@@ -344,6 +445,7 @@ __global__ void k_zero_close(const u64 *__restrict__ keys, const double *__restr
     const u64 k0 = keys[0];                                           // stable sort: the segment's smallest pair index
     const u32 first = tri_slot(L.o(k0), L.i(k0), Ni);
     atomicOr(&markbits[first >> 5], 1u << (first & 31u));
+    if (patchbits) atomicOr(&patchbits[first >> 5], 1u << (first & 31u));
     sum_of[2 * (i64)first] = re; sum_of[2 * (i64)first + 1] = im;
 }
 
@@ -354,7 +456,10 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
                                                      const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L,
                                                      const double *__restrict__ ci, const double *__restrict__ co,
                                                      double thr, int use_thr, u32 *__restrict__ markbits, double *__restrict__ sum_of,
-                                                     i64 chunks_per_wave, int squared, const u32 *__restrict__ zero_len = nullptr) {
+                                                     i64 chunks_per_wave, int squared, const u32 *__restrict__ zero_len = nullptr,
+                                                     u32 *__restrict__ patchbits = nullptr, const u32 *__restrict__ dirtybits = nullptr) {
+    // patchbits != null ("lazy" mode, see k_mark_singles): one-element segments are not touched at all, and wavefront w only works on
+    // the chunks whose bit is set in dirtybits[w] (k_find_merges: the chunks that hold a member of a segment of more than one element)
     // zero_len (squared operators): the first *zero_len sorted positions are the identity segment, already reduced by k_zero_partial /
     // k_zero_close — they are treated like positions past the end (they end every run and contribute nothing)
     const i64 ZL = zero_len ? (i64)*zero_len : 0;
@@ -366,13 +471,23 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
     const int C = W / 2;                                             // 16-byte chunks per row
     const u64 gmask = G == 64 ? ~0ULL : (((1ULL << G) - 1ULL) << (gi * G));
     const i64 n_chunks = (T + 63) / 64;
-    const i64 c0 = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * chunks_per_wave;
-    if (c0 >= n_chunks) return;
-    const i64 c1 = c0 + chunks_per_wave < n_chunks ? c0 + chunks_per_wave : n_chunks;
+    const i64 gw = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    u32 dirty = 0;
+    if (dirtybits) {
+        if (gw >= (n_chunks + 31) / 32) return;
+        dirty = __builtin_amdgcn_readfirstlane(dirtybits[gw]);
+        if (dirty == 0) return;
+    }
 
-    auto close = [&](u32 first, double re, double im) {            // strict threshold, bitmap, sum filed under the first index
-        if (use_thr && !(hypot(re, im) > thr)) return;
+    const bool lazy = patchbits != nullptr;
+    auto close = [&](u32 first, double re, double im, bool multi) {   // strict threshold, bitmap, sum filed under the first index
+        if (lazy && !multi) return;                                   // a single: decided by k_mark_singles, rebuilt by k_emit_meta
+        if (use_thr && !(hypot(re, im) > thr)) {
+            if (lazy) atomicAnd(&markbits[first >> 5], ~(1u << (first & 31u)));
+            return;
+        }
         atomicOr(&markbits[first >> 5], 1u << (first & 31u));
+        if (lazy) atomicOr(&patchbits[first >> 5], 1u << (first & 31u));
         double2 o; o.x = re; o.y = im;
         reinterpret_cast<double2 *>(sum_of)[first] = o;
     };
@@ -380,11 +495,25 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
     bool open = false;                  // wave-uniform: a segment is carried across chunk boundaries
     double are = 0.0, aim = 0.0;        // its running sum
     u32 afirst = 0;                     // input index of its first (head) element
+    bool amulti = false;                // it has more than one element so far
     bool mism = false;
+    for (;;) {                          // the wavefront's chunk ranges: one, or — dirtybits — one per set bit
+    i64 c0, c1;
+    if (dirtybits) {
+        if (dirty == 0) break;
+        c0 = gw * 32 + __builtin_ctz(dirty);
+        dirty &= dirty - 1;
+        c1 = c0 + 1;
+        open = false;
+    } else {
+        c0 = gw * chunks_per_wave;
+        if (c0 >= n_chunks) break;
+        c1 = c0 + chunks_per_wave < n_chunks ? c0 + chunks_per_wave : n_chunks;
+    }
     for (i64 chunk = c0;; ++chunk) {
         if (chunk >= c1 && !open) break;
         if (chunk >= n_chunks) {        // the carried segment ends with the data
-            if (lane == 0) close(afirst, are, aim);
+            if (lane == 0) close(afirst, are, aim, amulti);
             break;
         }
         const bool own = chunk < c1;    // beyond the own range: decode only, to finish the carried segment
@@ -400,7 +529,7 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
                 if (eq0 && !(inner == outer && L.i(kb) == L.o(ka) && L.o(kb) == L.i(ka))) eq0 = (hI[L.i(kb)] ^ hO[L.o(kb)]) == (hI[L.i(ka)] ^ hO[L.o(ka)]);
             } else eq0 = kb == ka;
             if (!eq0) {
-                if (lane == 0) close(afirst, are, aim);
+                if (lane == 0) close(afirst, are, aim, amulti);
                 break;
             }
         }
@@ -430,7 +559,15 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
             eq = valid && s > 0 && k1 == k0;
         }
         double2 c; c.x = 0.0; c.y = 0.0;
-        if (valid) {
+        // lazy: only members of segments with more than one element need their coefficient — a position that equals its predecessor,
+        // one whose successor equals it, and lane 63 (its successor is in the next chunk)
+        bool need = valid;
+        if (lazy) {
+            const int eq_next = __shfl_down((int)eq, 1);
+            need = valid && (eq || eq_next || lane == 63);
+            if (valid && eq) atomicAnd(&markbits[t1 >> 5], ~(1u << (t1 & 31u)));      // a follower is never the first occurrence
+        }
+        if (need) {
             if (PACKED) {
                 pair_coefficient(ci[2 * i1], ci[2 * i1 + 1], co[2 * o1], co[2 * o1 + 1], L.e(k1), c.x, c.y);
                 if (squared && i1 != o1) {
@@ -472,10 +609,11 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
                 are = __dadd_rn(are, __shfl(c.x, k));
                 aim = __dadd_rn(aim, __shfl(c.y, k));
             }
+            if (lead > 0) amulti = true;
         }
         if (m == 0ULL) continue;                                  // no head in this chunk
         if (open) {
-            if (lane == 0) close(afirst, are, aim);
+            if (lane == 0) close(afirst, are, aim, amulti);
             open = false;
         }
         if (!own) break;                                          // beyond the own range only the carry had to be closed
@@ -494,13 +632,16 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
         const int last = 63 - __builtin_clzll(m);
         // a full chunk whose last head is a real position: its run reaches lane 63 and may continue in the next chunk
         const bool carry = chunk * 64 + 64 <= T && ((__ballot(valid) >> last) & 1ULL);
-        if (is_head && !(carry && lane == last)) close(t1, re, im);
+        if (is_head && !(carry && lane == last)) close(t1, re, im, run > 0);
         if (carry) {
             open = true;
             are = __shfl(re, last);
             aim = __shfl(im, last);
             afirst = __shfl(t1, last);
+            amulti = __shfl(run, last) > 0;
         }
+    }
+    if (!dirtybits) break;
     }
     if (__ballot(mism) && lane == 0) atomicOr(collision, 1u);
 }
@@ -510,48 +651,108 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
 // run holds more than one distinct key it is re-ordered here by (full key, input order) with a stable insertion sort.
 // Runs longer than FIX_MAX that are not uniform raise `fallback`: the caller then redoes a full 64-bit sort.
 constexpr int FIX_MAX = 48;
-// phase 1 (read-only): a position whose key differs from its predecessor's INSIDE a prefix run marks the run's start.
+// Round 3: the keys that need a look at all — a run's first key, and a key inside a run that differs from its predecessor: 0.6 % of
+// the positions, but one in every other wavefront — are flagged by a streaming pass (k_fixup_find: four chunks per wavefront and step,
+// one 64-bit word of flags per chunk, plain stores: appending to ONE list counter instead serialises 4e5 returning atomics on one
+// address, 2.8 ms) and worked off by wavefronts that expand the flags of 4,096 positions into a dense list (k_fixup_work): the thread of a run's START
+// walks it (<= FIX_MAX elements) and sorts it if it holds more than one distinct key; a differing key inside a run measures the run and
+// raises `fallback` if it is longer than FIX_MAX (a long UNIFORM run — the identity segment of a squared operator — costs nothing).
+// Threads of one run may read keys while its start thread reorders them: all of them share the prefix, which is all the others look
+// at.  (The two launches this replaces walked the runs from inside the streaming pass: 0.33 ms at cfg3, now 0.11.)
 // PACKED: keys are packed pair keys (full key recomputed from the (i, o) fields), there is no separate idx array.
 template <bool PACKED>
-__global__ void k_fixup_mark(const u64 *__restrict__ keys, i64 T, int shift, uint8_t *__restrict__ need,
-                             const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L, bool same_operand) {
-    for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < T; s += (i64)gridDim.x * blockDim.x) {
-        if (s == 0) continue;
-        const u64 k = keys[s], kp = keys[s - 1];
-        if ((k >> shift) != (kp >> shift)) continue;
-        if (PACKED) {
-            if (same_operand && L.i(k) == L.o(kp) && L.o(k) == L.i(kp)) continue;          // P * P twins: equal keys by construction
-            if (L.full_key(hI, hO, k) == L.full_key(hI, hO, kp)) continue;
-        } else if (k == kp) continue;
-        i64 b = s - 1;
-        while (b > 0 && (keys[b - 1] >> shift) == (kp >> shift)) --b;
-        need[b] = 1u;
+__device__ __forceinline__ bool fixup_differ(u64 k, u64 kp, const u64 *__restrict__ hI, const u64 *__restrict__ hO, const PackedLayout &L, bool same_operand) {
+    if (PACKED) {
+        if (same_operand && L.i(k) == L.o(kp) && L.o(k) == L.i(kp)) return false;         // P * P twins: equal keys by construction
+        return L.full_key(hI, hO, k) != L.full_key(hI, hO, kp);
+    }
+    return k != kp;
+}
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_fixup_find(const u64 *__restrict__ keys, i64 T, int shift, const u64 *__restrict__ hI, const u64 *__restrict__ hO,
+                                                     PackedLayout L, bool same_operand, u64 *__restrict__ rarebits) {
+    const int lane = threadIdx.x & 63;
+    const i64 n_steps = (T + 255) / 256;
+    for (i64 g = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); g < n_steps; g += (i64)gridDim.x * 4) {
+        const i64 base = g * 256;
+        u64 k[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const i64 sp = base + 64 * j + lane; k[j] = sp < T ? keys[sp] : 0ULL; }
+        const u64 prev = base > 0 ? keys[base - 1] : 0ULL;
+        const u64 next = base + 256 < T ? keys[base + 256] : 0ULL;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i64 sp = base + 64 * j + lane;
+            u64 kp = __shfl_up(k[j], 1), kn = __shfl_down(k[j], 1);
+            const u64 in_lo = j > 0 ? __shfl(k[j > 0 ? j - 1 : 0], 63) : prev;
+            const u64 in_hi = j < 3 ? __shfl(k[j < 3 ? j + 1 : 3], 0) : next;
+            if (lane == 0) kp = in_lo;
+            if (lane == 63) kn = in_hi;
+            const bool valid = sp < T;
+            const bool with_prev = valid && sp > 0 && (kp >> shift) == (k[j] >> shift);
+            const bool with_next = valid && sp + 1 < T && (kn >> shift) == (k[j] >> shift);
+            bool rare = !with_prev && with_next;
+            if (with_prev) rare = fixup_differ<PACKED>(k[j], kp, hI, hO, L, same_operand);
+            const u64 b = __ballot(rare);
+            if (lane == 0 && base + 64 * j < T) rarebits[base / 64 + j] = b;
+        }
     }
 }
-// phase 2: the marked run starts (one thread per mixed run) sort their run
 template <bool PACKED>
-__global__ void k_fixup_sort(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 T, int shift, const uint8_t *__restrict__ need, u32 *__restrict__ fallback,
-                             const u64 *__restrict__ hI, const u64 *__restrict__ hO, PackedLayout L) {
-    for (i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x; b < T; b += (i64)gridDim.x * blockDim.x) {
-        if (!need[b]) continue;
-        const u64 pfx = keys[b] >> shift;
-        i64 e = b + 1;
-        while (e < T && (keys[e] >> shift) == pfx) ++e;
-        if (e - b > FIX_MAX) { atomicOr(fallback, 1u); continue; }
-        for (i64 a = b + 1; a < e; ++a) {                                     // stable insertion sort by full key
-            const u64 ka = keys[a];
-            if (PACKED) {
-                const u64 fa = L.full_key(hI, hO, ka);
-                i64 c = a - 1;
-                while (c >= b && L.full_key(hI, hO, keys[c]) > fa) { keys[c + 1] = keys[c]; --c; }
-                keys[c + 1] = ka;
-            } else {
-                const u32 ia = idx[a];
-                i64 c = a - 1;
-                while (c >= b && keys[c] > ka) { keys[c + 1] = keys[c]; idx[c + 1] = idx[c]; --c; }
-                keys[c + 1] = ka;
-                idx[c + 1] = ia;
+__global__ __launch_bounds__(256) void k_fixup_work(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 T, int shift, const u64 *__restrict__ rarebits,
+                                                     u32 *__restrict__ fallback, const u64 *__restrict__ hI,
+                                                     const u64 *__restrict__ hO, PackedLayout L, bool same_operand) {
+    __shared__ unsigned short s_list[4][4096];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned short *list = s_list[wave];
+    const i64 n_chunks = (T + 63) / 64;
+    const i64 cw = ((i64)blockIdx.x * 4 + wave) * 64 + lane;                  // this lane's chunk: 64 chunks = 4,096 positions per wavefront
+    u64 bits = cw < n_chunks ? rarebits[cw] : 0ULL;
+    const u32 cnt = (u32)__popcll(bits);
+    u32 incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    const u32 n = __shfl(incl, 63);
+    if (n == 0) return;                                                       // wave-uniform
+    {
+        u32 at = incl - cnt;
+        while (bits) { list[at++] = (unsigned short)(lane * 64 + __builtin_ctzll(bits)); bits &= bits - 1; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const i64 wbase = ((i64)blockIdx.x * 4 + wave) * 4096;
+    for (u32 it = lane; it < n; it += 64) {
+        const i64 sp = wbase + list[it];
+        const u64 k = keys[sp];
+        const bool with_prev = sp > 0 && (keys[sp - 1] >> shift) == (k >> shift);
+        if (!with_prev) {                                                     // the start of a run
+            i64 e = sp + 1;
+            bool mixed = false;
+            while (e < T && e - sp <= FIX_MAX && (keys[e] >> shift) == (k >> shift)) { mixed |= fixup_differ<PACKED>(keys[e], keys[e - 1], hI, hO, L, same_operand); ++e; }
+            if (e - sp > FIX_MAX || !mixed) continue;                         // long: judged by its members below; uniform: nothing to do
+            for (i64 a = sp + 1; a < e; ++a) {                                // stable insertion sort by full key
+                const u64 ka = keys[a];
+                if (PACKED) {
+                    const u64 fa = L.full_key(hI, hO, ka);
+                    i64 c = a - 1;
+                    while (c >= sp && L.full_key(hI, hO, keys[c]) > fa) { keys[c + 1] = keys[c]; --c; }
+                    keys[c + 1] = ka;
+                } else {
+                    const u32 ia = idx[a];
+                    i64 c = a - 1;
+                    while (c >= sp && keys[c] > ka) { keys[c + 1] = keys[c]; idx[c + 1] = idx[c]; --c; }
+                    keys[c + 1] = ka;
+                    idx[c + 1] = ia;
+                }
             }
+        } else {                                                              // a differing key inside a run: is the run too long?
+            i64 b = sp - 1, e = sp + 1;
+            while (b > 0 && sp - b <= FIX_MAX && (keys[b - 1] >> shift) == (k >> shift)) --b;
+            while (e < T && e - b <= FIX_MAX && (keys[e] >> shift) == (k >> shift)) ++e;
+            if (e - b > FIX_MAX) atomicOr(fallback, 1u);
         }
     }
 }
@@ -578,10 +779,17 @@ static i64 emit_batch_words() {                                  // SYMGPU_EMIT_
     const i64 w = [] { const char *e = getenv("SYMGPU_EMIT_BATCH"); const int l = e ? atoi(e) : 17; return (i64)1 << (l >= 6 && l <= 26 ? l : 17); }();
     return w;
 }
+// where k_emit_meta takes a kept term's coefficient from: mode 0 = the filed sums only; 1 / 2 = filed sums for patched terms, the
+// operand tables (packed products) / the input coefficients (indexed operators) for all others (k_mark_singles)
+struct LazyEmit {
+    int mode = 0, squared = 0;
+    const u32 *patchbits = nullptr, *e_lo = nullptr, *e_hi = nullptr;
+    const double *ci = nullptr, *co = nullptr, *coeff = nullptr;
+};
 template <bool PAIR, bool TRI>
 __global__ __launch_bounds__(256) void k_emit_meta(const u32 *__restrict__ markbits, const u32 *__restrict__ wordprefix, i64 w_begin, i64 w_end,
                                                     const double *__restrict__ sum_of, int wpw, u32 Ni,
-                                                    uint2 *__restrict__ meta, double *__restrict__ out_coeff) {
+                                                    uint2 *__restrict__ meta, double *__restrict__ out_coeff, LazyEmit lz) {
     __shared__ unsigned short s_list[4][2048];                       // offsets inside the chunk (< 2048)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned short *list = s_list[wave];
@@ -613,7 +821,22 @@ __global__ __launch_bounds__(256) void k_emit_meta(const u32 *__restrict__ markb
             u32 ti = t, to = 0;
             if (PAIR && TRI) tri_pair(t, Ni, to, ti);
             else if (PAIR) { to = t / Ni; ti = t - to * Ni; }
-            reinterpret_cast<double2 *>(out_coeff)[(i64)p_base + k] = reinterpret_cast<const double2 *>(sum_of)[t];
+            double2 cf;
+            if (lz.mode == 0 || ((lz.patchbits[t >> 5] >> (t & 31u)) & 1u)) cf = reinterpret_cast<const double2 *>(sum_of)[t];
+            else if (lz.mode == 1) {                                  // a single of a packed product: c_i * c_o * i^e from the operand tables
+                const int e = (int)(((lz.e_lo[t >> 5] >> (t & 31u)) & 1u) | (((lz.e_hi[t >> 5] >> (t & 31u)) & 1u) << 1));
+                double cx, cy;
+                pair_coefficient(lz.ci[2 * ti], lz.ci[2 * ti + 1], lz.co[2 * to], lz.co[2 * to + 1], e, cx, cy);
+                if (lz.squared && ti != to) {
+                    if (e & 1) { cx = 0.0; cy = 0.0; }
+                    else { cx = __dadd_rn(cx, cx); cy = __dadd_rn(cy, cy); }
+                }
+                cf.x = __dadd_rn(0.0, cx); cf.y = __dadd_rn(0.0, cy);
+            } else {                                                  // a single of an indexed operator: 0.0 + its own coefficient
+                const double2 c0 = reinterpret_cast<const double2 *>(lz.coeff)[t];
+                cf.x = __dadd_rn(0.0, c0.x); cf.y = __dadd_rn(0.0, c0.y);
+            }
+            reinterpret_cast<double2 *>(out_coeff)[(i64)p_base + k] = cf;
             meta[(p_base - P0) + k] = make_uint2(ti, to);
         }
         __builtin_amdgcn_wave_barrier();                             // the list is rewritten by the next chunk
@@ -694,7 +917,7 @@ int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
 
 // T = size of the index space the kept terms are filed under (pair indices, or the slots of a squared operator: `tri`)
 int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, const u64 *rows, int W, const u64 *inner, i64 Ni,
-                   const u64 *outer, symgpu_op_t *out, int Wq_out, bool tri) {
+                   const u64 *outer, symgpu_op_t *out, int Wq_out, bool tri, const LazyEmit &lz) {
     hipStream_t st = ctx().stream;
     const i64 n_words = (T + 31) / 32;
     Scratch wordprefix;
@@ -730,7 +953,7 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
             i64 ge = ((w1 - w0 + wpw - 1) / wpw + 3) / 4;
             if (ge > 16384) ge = 16384;
 #define LAUNCH_META(P, TR) hipLaunchKernelGGL((k_emit_meta<P, TR>), dim3((unsigned)ge), dim3(256), 0, st, markbits_p, wordprefix.as<u32>(), w0, w1, sum_of_p, wpw, \
-                                              (u32)(pair ? Ni : 1), meta.as<uint2>(), res->coeff)
+                                              (u32)(pair ? Ni : 1), meta.as<uint2>(), res->coeff, lz)
             if (pair && tri) LAUNCH_META(true, true); else if (pair) LAUNCH_META(true, false); else LAUNCH_META(false, false);
 #undef LAUNCH_META
             const u32 *p_begin = wordprefix.as<u32>() + w0;
@@ -792,11 +1015,17 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         if (e && e[0] == '1') squared = false;
     }
     i64 Tk = T;                                                         // number of keys that are sorted (T index space stays)
-    Scratch keys, keys2, idx, idx2, heads, collision, hI, hO, pair_coeff, markbits, sum_of, zpart, zcount;
+    Scratch keys, keys2, idx, idx2, fixlist, collision, hI, hO, pair_coeff, markbits, sum_of, zpart, zcount, patchbits, e_lo, e_hi, dirtybits;
+    // singles decided in index order, only merged terms filed from the sorted order (k_mark_singles); SYMGPU_CLEANUP_LAZY=0: every term filed
+    const bool lazy = [] { const char *e = getenv("SYMGPU_CLEANUP_LAZY"); return !(e && e[0] == '0'); }();
+    const size_t bitmap_bytes = (size_t)((T + 63) / 64) * 8;         // whole 64-bit words: k_mark_singles stores one per wavefront
     SG_TRY(keys.alloc((size_t)T * 8));
     SG_TRY(keys2.alloc((size_t)T * 8));
-    SG_TRY(heads.alloc((size_t)T));                                 // run-start markers of the truncated-sort fix-up
-    SG_TRY(markbits.alloc((size_t)((T + 31) / 32) * 4));            // kept terms by first input index (one bit each)
+    SG_TRY(markbits.alloc(bitmap_bytes));                            // kept terms by first input index (one bit each)
+    if (lazy) {
+        SG_TRY(patchbits.alloc(bitmap_bytes));                       // ... whose coefficient is a filed sum
+        if (pair) { SG_TRY(e_lo.alloc(bitmap_bytes)); SG_TRY(e_hi.alloc(bitmap_bytes)); }   // phase exponents of the pairs, by index
+    }
     SG_TRY(sum_of.alloc((size_t)T * 16));                           // their summed coefficients, indexed the same way
     SG_TRY(collision.alloc(16));
     if (pair) {
@@ -832,6 +1061,11 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 ka.hI = hI.as<u64>(); ka.hO = hO.as<u64>(); ka.keys = keys.as<u64>(); ka.bi = L.bi; ka.bo = L.bo; ka.o_base = 0;
                 ka.squared = squared ? 1 : 0;
                 SG_TRY(mul_keys_dev(inner, Ni, outer, No, W / 2, inner_is_left, ka));
+                if (lazy) {                                          // the keys are still in index order
+                    hipLaunchKernelGGL(k_mark_singles<true>, dim3(grid_for((Tk + 255) / 256, 4, 16384)), dim3(256), 0, st, keys.as<u64>(), (const double *)nullptr, Tk, L, ci, co,
+                                       squared ? 1 : 0, thr, use_thr, markbits.as<u64>(), e_lo.as<u64>(), e_hi.as<u64>());
+                    KERNEL_CHECK();
+                }
                 SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp));
             } else {
                 if (!idx.p) {
@@ -851,21 +1085,28 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             hipLaunchKernelGGL(k_iota_keys_plain, dim3(grid_for(T)), dim3(256), 0, st, idx.as<u32>(), T);
             KERNEL_CHECK();
         }
+        if (!packed && lazy) {
+            hipLaunchKernelGGL(k_mark_singles<false>, dim3(grid_for((T + 255) / 256, 4, 16384)), dim3(256), 0, st, (const u64 *)nullptr, coeff, T, L, (const double *)nullptr,
+                               (const double *)nullptr, 0, thr, use_thr, markbits.as<u64>(), (u64 *)nullptr, (u64 *)nullptr);
+            KERNEL_CHECK();
+        }
         if (!packed) SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), Tk, 64 - nbits, 64, &in_tmp));
         ks = in_tmp ? keys2.as<u64>() : keys.as<u64>();
         is = packed ? nullptr : (in_tmp ? idx2.as<u32>() : idx.as<u32>());
         HIP_TRY(hipMemsetAsync(collision.p, 0, 16, st));
         if (nbits < 64) {
-            HIP_TRY(hipMemsetAsync(heads.p, 0, (size_t)Tk, st));
+            const i64 n_ch = (Tk + 63) / 64;
+            SG_TRY(fixlist.alloc((size_t)n_ch * 8 + 16));                         // one word of flags per 64 positions
+            const dim3 gff((unsigned)grid_for((Tk + 255) / 256, 4, 8192));
+            const dim3 gfw((unsigned)((n_ch + 255) / 256));
             if (packed) {
-                hipLaunchKernelGGL(k_fixup_mark<true>, dim3(grid_for(Tk)), dim3(256), 0, st, ks, Tk, 64 - nbits, heads.as<uint8_t>(), hI.as<u64>(), hO.as<u64>(), L, inner == outer);
-                hipLaunchKernelGGL(k_fixup_sort<true>, dim3(grid_for(Tk)), dim3(256), 0, st, ks, (u32 *)nullptr, Tk, 64 - nbits, heads.as<uint8_t>(),
-                                   collision.as<u32>() + 1, hI.as<u64>(), hO.as<u64>(), L);
+                hipLaunchKernelGGL(k_fixup_find<true>, gff, dim3(256), 0, st, ks, Tk, 64 - nbits, hI.as<u64>(), hO.as<u64>(), L, inner == outer, fixlist.as<u64>());
+                hipLaunchKernelGGL(k_fixup_work<true>, gfw, dim3(256), 0, st, ks, (u32 *)nullptr, Tk, 64 - nbits, fixlist.as<u64>(), collision.as<u32>() + 1,
+                                   hI.as<u64>(), hO.as<u64>(), L, inner == outer);
             } else {
-                hipLaunchKernelGGL(k_fixup_mark<false>, dim3(grid_for(Tk)), dim3(256), 0, st, ks, Tk, 64 - nbits, heads.as<uint8_t>(), (const u64 *)nullptr,
-                                   (const u64 *)nullptr, L, false);
-                hipLaunchKernelGGL(k_fixup_sort<false>, dim3(grid_for(Tk)), dim3(256), 0, st, ks, is, Tk, 64 - nbits, heads.as<uint8_t>(),
-                                   collision.as<u32>() + 1, (const u64 *)nullptr, (const u64 *)nullptr, L);
+                hipLaunchKernelGGL(k_fixup_find<false>, gff, dim3(256), 0, st, ks, Tk, 64 - nbits, (const u64 *)nullptr, (const u64 *)nullptr, L, false, fixlist.as<u64>());
+                hipLaunchKernelGGL(k_fixup_work<false>, gfw, dim3(256), 0, st, ks, is, Tk, 64 - nbits, fixlist.as<u64>(), collision.as<u32>() + 1,
+                                   (const u64 *)nullptr, (const u64 *)nullptr, L, false);
             }
             KERNEL_CHECK();
         }
@@ -884,7 +1125,9 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             const u64 *nul = nullptr;
             const double *nud = nullptr;
             const i64 space = (squared && packed) ? Tk : T;               // index space of markbits / sum_of
-            HIP_TRY(hipMemsetAsync(markbits.p, 0, (size_t)((space + 31) / 32) * 4, st));
+            if (lazy) HIP_TRY(hipMemsetAsync(patchbits.p, 0, (size_t)((space + 63) / 64) * 8, st));
+            else HIP_TRY(hipMemsetAsync(markbits.p, 0, (size_t)((space + 31) / 32) * 4, st));
+            u32 *patch_p = lazy ? patchbits.as<u32>() : nullptr;
             const u32 *zero_len_p = nullptr;
             const bool zero_on = [] { const char *e = getenv("SYMGPU_CLEANUP_ZEROSEG"); return !(e && e[0] == '0'); }();
             if (squared && packed && zero_on) {
@@ -894,21 +1137,37 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 SG_TRY(zcount.alloc((size_t)n_zb * 4 + 16));
                 u32 *zl = zcount.as<u32>() + n_zb;
                 hipLaunchKernelGGL(k_zero_partial, dim3((unsigned)n_zb), dim3(256), 0, st, ks, Tk, hI.as<u64>(), hO.as<u64>(), L, inner, W, ci,
-                                   zpart.as<double>(), zcount.as<u32>(), collision.as<u32>());
+                                   zpart.as<double>(), zcount.as<u32>(), collision.as<u32>(), (u32)Ni, lazy ? markbits.as<u32>() : (u32 *)nullptr);
                 hipLaunchKernelGGL(k_zero_close, dim3(1), dim3(64), 0, st, ks, zpart.as<double>(), zcount.as<u32>(), n_zb, L, (u32)Ni, thr, use_thr,
-                                   markbits.as<u32>(), sum_of.as<double>(), zl);
+                                   markbits.as<u32>(), sum_of.as<double>(), zl, patch_p);
                 zero_len_p = zl;
             }
+            const u32 *dirty_p = nullptr;
+            dim3 gsl = gs;
+            if (lazy) {
+                // the chunks that hold a member of a segment of more than one element; k_heads_sums then works on those only
+                const i64 n_dw = (n_chunks + 31) / 32;
+                SG_TRY(dirtybits.alloc((size_t)n_dw * 4 + 16));
+                HIP_TRY(hipMemsetAsync(dirtybits.p, 0, (size_t)n_dw * 4 + 16, st));
+                const dim3 gf((unsigned)grid_for((Tk + 255) / 256, 4, 8192));
+                if (packed) hipLaunchKernelGGL(k_find_merges<true>, gf, dim3(256), 0, st, ks, Tk, zero_len_p, L, hI.as<u64>(), hO.as<u64>(), inner == outer ? 1 : 0, dirtybits.as<u32>());
+                else hipLaunchKernelGGL(k_find_merges<false>, gf, dim3(256), 0, st, ks, Tk, zero_len_p, L, nul, nul, 0, dirtybits.as<u32>());
+                KERNEL_CHECK();
+                dirty_p = dirtybits.as<u32>();
+                gsl = dim3((unsigned)((n_dw + 3) / 4));
+            }
             if (packed)
-                hipLaunchKernelGGL((k_heads_sums<true, true>), gs, dim3(256), 0, st, ks, (const u32 *)nullptr, Tk, nul, W, inner, (u32)Ni, outer, G, nud,
+                hipLaunchKernelGGL((k_heads_sums<true, true>), gsl, dim3(256), 0, st, ks, (const u32 *)nullptr, Tk, nul, W, inner, (u32)Ni, outer, G, nud,
                                    collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), L, ci, co, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0,
-                                   zero_len_p);
+                                   zero_len_p, patch_p, dirty_p);
             else if (pair)
-                hipLaunchKernelGGL((k_heads_sums<true, false>), gs, dim3(256), 0, st, ks, is, Tk, nul, W, inner, (u32)Ni, outer, G, coeff,
-                                   collision.as<u32>(), nul, nul, L, nud, nud, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0);
+                hipLaunchKernelGGL((k_heads_sums<true, false>), gsl, dim3(256), 0, st, ks, is, Tk, nul, W, inner, (u32)Ni, outer, G, coeff,
+                                   collision.as<u32>(), nul, nul, L, nud, nud, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0,
+                                   (const u32 *)nullptr, patch_p, dirty_p);
             else
-                hipLaunchKernelGGL((k_heads_sums<false, false>), gs, dim3(256), 0, st, ks, is, Tk, rows, W, nul, 1u, nul, G, coeff,
-                                   collision.as<u32>(), nul, nul, L, nud, nud, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0);
+                hipLaunchKernelGGL((k_heads_sums<false, false>), gsl, dim3(256), 0, st, ks, is, Tk, rows, W, nul, 1u, nul, G, coeff,
+                                   collision.as<u32>(), nul, nul, L, nud, nud, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0,
+                                   (const u32 *)nullptr, patch_p, dirty_p);
         }
         KERNEL_CHECK();
         u32 hflags[2] = {0, 0};
@@ -923,7 +1182,13 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         return SYMGPU_E_COLLISION;
     }
     const bool tri = squared && packed;
-    return cleanup_finish(markbits.as<u32>(), sum_of.as<double>(), tri ? Tk : T, pair, rows, W, inner, Ni, outer, out, Wq_out, tri);
+    LazyEmit lz;
+    if (lazy) {
+        lz.mode = packed ? 1 : 2; lz.squared = tri ? 1 : 0;
+        lz.patchbits = patchbits.as<u32>(); lz.e_lo = e_lo.as<u32>(); lz.e_hi = e_hi.as<u32>();
+        lz.ci = ci; lz.co = co; lz.coeff = coeff;
+    }
+    return cleanup_finish(markbits.as<u32>(), sum_of.as<double>(), tri ? Tk : T, pair, rows, W, inner, Ni, outer, out, Wq_out, tri, lz);
 }
 
 }  // namespace symgpu
