@@ -119,16 +119,36 @@ constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = 256 * RS_ITEMS;   // 4096
 constexpr int RS_WSEG = 64 * RS_ITEMS;    // keys per wave segment
 
+// the lanes of the wavefront that hold the same 8-bit digit as this lane (and are valid): per bit one sign-extended field, one
+// compare for the ballot and one three-input op per mask half (m & ~(ballot ^ sel)); the plain `m &= bit ? bal : ~bal` compiled to
+// 95 VALU instructions per key, this to 45
+__device__ __forceinline__ u64 match_digit(u32 d, bool valid) {
+    const u64 m0 = __ballot(valid);
+    u32 lo = (u32)m0, hi = (u32)(m0 >> 32);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int sel = __builtin_amdgcn_sbfe((int)d, b, 1);                 // 0 or -1
+        const u64 bal = __ballot(sel != 0);
+        lo = __builtin_amdgcn_bitop3_b32(lo, (u32)bal, (u32)sel, 0x90);       // lo & ~(bal ^ sel)
+        hi = __builtin_amdgcn_bitop3_b32(hi, (u32)(bal >> 32), (u32)sel, 0x90);
+    }
+    return ((u64)hi << 32) | lo;
+}
+
 __global__ __launch_bounds__(256) void k_rs_hist(const u64 *__restrict__ keys, i64 n, int shift, i64 n_tiles, u32 *__restrict__ tile_hist) {
     __shared__ u32 h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
     const i64 base = (i64)blockIdx.x * RS_TILE;
-#pragma unroll 4
-    for (int k = 0; k < RS_ITEMS; ++k) {
+    u64 kk[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {                               // sixteen loads in flight
         const i64 idx = base + k * 256 + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255], 1u);
+        kk[k] = idx < n ? keys[idx] : 0ULL;
     }
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k)
+        if (base + k * 256 + threadIdx.x < n) atomicAdd(&h[(kk[k] >> shift) & 255], 1u);
     __syncthreads();
     tile_hist[(i64)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];   // digit-major
 }
@@ -147,30 +167,43 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ keys
     __shared__ u32 s_wave[4];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const i64 tile_base = (i64)blockIdx.x * RS_TILE;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
-    s_gbase[threadIdx.x] = tile_off[(i64)threadIdx.x * n_tiles + blockIdx.x];
-    __syncthreads();
-
+    // XCD-aware tile order: workgroups go round-robin over the 8 XCDs, and consecutive tiles append to the same 256 digit streams — the
+    // runs of one tile end in the middle of cache lines that the next tile completes.  Every XCD therefore takes a CONTIGUOUS eighth of
+    // the tiles, in order: the partial lines meet in ONE L2 instead of leaving two XCDs as masked partial writes.
+    const i64 per_xcd = (n_tiles + 7) / 8;
+    const i64 tile = (i64)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const i64 tile_base = tile * RS_TILE;
+    const u32 gbase = tile_off[(i64)threadIdx.x * n_tiles + tile];            // issued first, stored to LDS behind the key loads
     u64 key[RS_ITEMS];
     u32 val[RS_ITEMS];
     u32 pos[RS_ITEMS];
     const u64 lt_mask = (1ULL << lane) - 1ULL;
+    // all sixteen loads in flight before the first key is used: the wavefront fences of the ranking loop otherwise pin every load
+    // behind its own s_waitcnt vmcnt(0) — sixteen dependent round trips per tile (round 3: 331 -> see DESIGN §3.3 per pass at cfg3)
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const i64 idx = tile_base + (i64)wave * RS_WSEG + r * 64 + lane;
         const bool valid = idx < n;
         key[r] = valid ? keys[idx] : ~0ULL;
         val[r] = (HAS_VALS && valid) ? vals[idx] : 0u;
-        const u32 d = (u32)(key[r] >> shift) & 255u;
-        u64 m = __ballot(valid);
+    }
+    asm volatile("" : "+v"(key[0]), "+v"(key[1]), "+v"(key[2]), "+v"(key[3]), "+v"(key[4]), "+v"(key[5]), "+v"(key[6]), "+v"(key[7]));
+    asm volatile("" : "+v"(key[8]), "+v"(key[9]), "+v"(key[10]), "+v"(key[11]), "+v"(key[12]), "+v"(key[13]), "+v"(key[14]), "+v"(key[15]));
+    if (HAS_VALS) {
+        asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]));
+        asm volatile("" : "+v"(val[8]), "+v"(val[9]), "+v"(val[10]), "+v"(val[11]), "+v"(val[12]), "+v"(val[13]), "+v"(val[14]), "+v"(val[15]));
+    }
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
-        }
+    for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
+    s_gbase[threadIdx.x] = gbase;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const i64 idx = tile_base + (i64)wave * RS_WSEG + r * 64 + lane;
+        const bool valid = idx < n;
+        const u32 d = (u32)(key[r] >> shift) & 255u;
+        const u64 m = match_digit(d, valid);
         const u32 rank = __popcll(m & lt_mask);
         const u32 count = __popcll(m);
         u32 base = 0;
@@ -245,9 +278,9 @@ int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp,
         KERNEL_CHECK();
         SG_TRY(exclusive_scan_u32(hist.as<u32>(), hist.as<u32>(), n_tiles * 256, nullptr));
         if (vals)
-            hipLaunchKernelGGL(k_rs_scatter<true>, dim3((unsigned)n_tiles), dim3(256), 0, st, ksrc, vsrc, n, shift, n_tiles, hist.as<u32>(), kdst, vdst);
+            hipLaunchKernelGGL(k_rs_scatter<true>, dim3((unsigned)((n_tiles + 7) / 8 * 8)), dim3(256), 0, st, ksrc, vsrc, n, shift, n_tiles, hist.as<u32>(), kdst, vdst);
         else
-            hipLaunchKernelGGL(k_rs_scatter<false>, dim3((unsigned)n_tiles), dim3(256), 0, st, ksrc, (const u32 *)nullptr, n, shift, n_tiles,
+            hipLaunchKernelGGL(k_rs_scatter<false>, dim3((unsigned)((n_tiles + 7) / 8 * 8)), dim3(256), 0, st, ksrc, (const u32 *)nullptr, n, shift, n_tiles,
                                hist.as<u32>(), kdst, (u32 *)nullptr);
         KERNEL_CHECK();
         u64 *tk = ksrc; ksrc = kdst; kdst = tk;
@@ -320,13 +353,7 @@ __global__ __launch_bounds__(256) void k_rs_coop(u64 *__restrict__ buf_a, u64 *_
             const i64 idx = tile_base + (i64)wave * RS_WSEG + r * 64 + lane;
             const bool valid = idx < n;
             const u32 d = (u32)(key[r] >> shift) & 255u;
-            u64 m = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const u64 bal = __ballot(bit);
-                m &= bit ? bal : ~bal;
-            }
+            const u64 m = match_digit(d, valid);
             const u32 rank = __popcll(m & lt_mask);
             const u32 count = __popcll(m);
             u32 base = 0;
