@@ -879,6 +879,83 @@ __global__ __launch_bounds__(256) void k_emit_stream(const uint2 *__restrict__ m
     }
 }
 
+// Fused output stage (round 3): ONE launch, one 64-bit bitmap word (64 indices) per wavefront.  The set lanes file their term — source
+// (i, o) into LDS, coefficient to its output slot — and the wavefront then streams the K kept rows, 64 consecutive 16-byte chunks per
+// step, into [prefix, prefix + K): consecutive wavefronts and workgroups write consecutive pieces (a workgroup's four words make
+// ~32 KB at n = 1000), so the chip still writes one moving window.  No list, no batches, no second launch: with the sums of the
+// singles no longer read back from HBM (k_mark_singles) nothing but the bitmaps is read beside the row stream.
+constexpr int EF_NW = 4;                                              // bitmap words per wavefront
+template <bool PAIR, bool TRI>
+__global__ __launch_bounds__(256) void k_emit_fused(const u64 *__restrict__ markbits64, const u32 *__restrict__ wordprefix, i64 T, const double *__restrict__ sum_of,
+                                                     u32 Ni, int Wq, int wsh, const u32x4 *__restrict__ rows, const u32x4 *__restrict__ inner,
+                                                     const u32x4 *__restrict__ outer, u32x4 *__restrict__ out_rows, double *__restrict__ out_coeff, LazyEmit lz) {
+    __shared__ u32 s_i[4][64 * EF_NW], s_o[4][64 * EF_NW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 w0 = ((i64)blockIdx.x * 4 + wave) * EF_NW;
+    if (w0 * 64 >= T) return;
+    // EF_NW words per wavefront: the dependent chain bitmap -> prefix -> phase / patch bits -> operand tables is paid once per 256
+    // indices (a wavefront per word spent two thirds of its life in it: 4.5 TB/s)
+    u64 bits[EF_NW];
+    u32 off[EF_NW + 1];
+    off[0] = 0;
+#pragma unroll
+    for (int u = 0; u < EF_NW; ++u) {
+        const i64 w = w0 + u;
+        bits[u] = w * 64 < T ? markbits64[w] : 0ULL;
+        if (w * 64 < T && T - w * 64 < 64) bits[u] &= (1ULL << (T - w * 64)) - 1ULL;   // the bitmap's last word may be half written (32-bit words)
+        off[u + 1] = off[u] + (u32)__popcll(bits[u]);
+    }
+    const u32 K = off[EF_NW];
+    if (K == 0) return;                                              // wave-uniform
+    const i64 p_base = wordprefix[2 * w0];
+#pragma unroll
+    for (int u = 0; u < EF_NW; ++u) {
+        if ((bits[u] >> lane) & 1ULL) {
+            const u32 rank = off[u] + (u32)__popcll(bits[u] & ((1ULL << lane) - 1ULL));
+            const u32 t = (u32)((w0 + u) * 64 + lane);
+            u32 ti = t, to = 0;
+            if (PAIR && TRI) tri_pair(t, Ni, to, ti);
+            else if (PAIR) { to = t / Ni; ti = t - to * Ni; }
+            double2 cf;
+            if (lz.mode == 0 || ((lz.patchbits[t >> 5] >> (t & 31u)) & 1u)) cf = reinterpret_cast<const double2 *>(sum_of)[t];
+            else if (lz.mode == 1) {                                  // a single of a packed product: c_i * c_o * i^e from the operand tables
+                const int e = (int)(((lz.e_lo[t >> 5] >> (t & 31u)) & 1u) | (((lz.e_hi[t >> 5] >> (t & 31u)) & 1u) << 1));
+                double cx, cy;
+                pair_coefficient(lz.ci[2 * ti], lz.ci[2 * ti + 1], lz.co[2 * to], lz.co[2 * to + 1], e, cx, cy);
+                if (lz.squared && ti != to) {
+                    if (e & 1) { cx = 0.0; cy = 0.0; }
+                    else { cx = __dadd_rn(cx, cx); cy = __dadd_rn(cy, cy); }
+                }
+                cf.x = __dadd_rn(0.0, cx); cf.y = __dadd_rn(0.0, cy);
+            } else {                                                  // a single of an indexed operator: 0.0 + its own coefficient
+                const double2 c0 = reinterpret_cast<const double2 *>(lz.coeff)[t];
+                cf.x = __dadd_rn(0.0, c0.x); cf.y = __dadd_rn(0.0, c0.y);
+            }
+            reinterpret_cast<double2 *>(out_coeff)[p_base + rank] = cf;
+            s_i[wave][rank] = ti; s_o[wave][rank] = to;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const u32 n_ch = K * (u32)Wq;
+    u32x4 *dst = out_rows + p_base * Wq;
+    constexpr int EF_U = 4;                                           // steps of 64 chunks in flight
+    for (u32 f0 = 0; f0 < n_ch; f0 += 64 * EF_U) {
+        u32x4 v[EF_U];
+#pragma unroll
+        for (int u = 0; u < EF_U; ++u) {
+            const u32 f = f0 + 64 * u + lane < n_ch ? f0 + 64 * u + lane : n_ch - 1;
+            const u32 r = wsh >= 0 ? f >> wsh : f / (u32)Wq;
+            const u32 c = f - r * (u32)Wq;
+            v[u] = PAIR ? (inner[(i64)s_i[wave][r] * Wq + c] ^ outer[(i64)s_o[wave][r] * Wq + c]) : rows[(i64)s_i[wave][r] * Wq + c];
+        }
+#pragma unroll
+        for (int u = 0; u < EF_U; ++u)
+            if (f0 + 64 * u + lane < n_ch) __builtin_nontemporal_store(v[u], dst + f0 + 64 * u + lane);
+    }
+}
+
 static int grid_for(i64 n, int block = 256, int cap = 8192) {
     i64 g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -939,6 +1016,16 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
         const int wsh = (Wq & (Wq - 1)) == 0 ? __builtin_ctz((unsigned)Wq) : -1;
         const u32x4 *pin = reinterpret_cast<const u32x4 *>(inner), *pout = reinterpret_cast<const u32x4 *>(outer);
         u32x4 *dst = reinterpret_cast<u32x4 *>(res->rows);
+        const bool fused = [] { const char *e = getenv("SYMGPU_EMIT_FUSED"); return !(e && e[0] == '0'); }();
+        if (fused) {
+            const i64 n_w64 = (T + 63) / 64;
+            const dim3 gfu((unsigned)((n_w64 + 4 * EF_NW - 1) / (4 * EF_NW)));
+            ProfScope prof(3);
+#define LAUNCH_FUSED(P, TR) hipLaunchKernelGGL((k_emit_fused<P, TR>), gfu, dim3(256), 0, st, reinterpret_cast<const u64 *>(markbits_p), wordprefix.as<u32>(), T, sum_of_p, \
+                                               (u32)(pair ? Ni : 1), Wq, wsh, reinterpret_cast<const u32x4 *>(rows), pin, pout, dst, res->coeff, lz)
+            if (pair && tri) LAUNCH_FUSED(true, true); else if (pair) LAUNCH_FUSED(true, false); else LAUNCH_FUSED(false, false);
+#undef LAUNCH_FUSED
+        } else {
         const int rc_env = [] { const char *e = getenv("SYMGPU_EMIT_RC"); return e ? atoi(e) : 2; }();     // chunks per lane: 1: 115, 2: 97, 4: 97 us per batch
         const int RCs = rc_env == 1 || rc_env == 4 ? rc_env : 2;
         const i64 EMIT_BATCH_WORDS = emit_batch_words();
@@ -967,6 +1054,7 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
                 else { if (RCs == 1) LAUNCH_STREAM(false, 1); else if (RCs == 4) LAUNCH_STREAM(false, 4); else LAUNCH_STREAM(false, 2); }
             }
 #undef LAUNCH_STREAM
+        }
         }
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);   // the scratch buffers are freed on return; keep ordering simple

@@ -637,6 +637,36 @@ def test_cleanup_long_segments_sum_in_input_order(T, n):
     assert np.array_equal(r, er) and np.array_equal(c, ec)
 
 
+@pytest.mark.parametrize('n,N,M', [(3, 300, 200), (100, 400, 300), (1, 60, 50), (1000, 150, 90), (12, 2500, 40)])
+def test_cleanup_lazy_and_fused_switches(n, N, M, monkeypatch):
+    """Round 3: terms that merge with nothing are decided in index order before the sort (k_mark_singles) and the output stage is one
+    fused launch (k_emit_fused).  SYMGPU_CLEANUP_LAZY=0 files every term from the sorted order, SYMGPU_EMIT_FUSED=0 takes the
+    batched list + stream stage: all four combinations give the oracle's rows, order and sums — on a general product, a squared
+    operator and a plain cleanup, duplicate-heavy (n = 1, 3: a handful of distinct rows) and duplicate-free alike."""
+    rng = np.random.default_rng(4100 + n + N)
+    A = PauliwordOp(rng.random((N, 2 * n)) < 0.3, dyadic(rng, N))
+    B = PauliwordOp(rng.random((M, 2 * n)) < 0.3, dyadic(rng, M))
+    stacked_rows = np.concatenate([A.packed, B.packed, A.packed[: N // 2]])
+    stacked_coeff = np.concatenate([A.coeff_vec, B.coeff_vec, -A.coeff_vec[: N // 2]])     # exact cancellations among them
+    want_ab = oc.mul(A.packed, A.coeff_vec, B.packed, B.coeff_vec)
+    want_aa = oc.mul(A.packed, A.coeff_vec, A.packed, A.coeff_vec)
+    want_c = oc.cleanup(stacked_rows, stacked_coeff, 1e-15)
+    for lazy in ('1', '0'):
+        for fused in ('1', '0'):
+            monkeypatch.setenv('SYMGPU_CLEANUP_LAZY', lazy)
+            monkeypatch.setenv('SYMGPU_EMIT_FUSED', fused)
+            for thr in (1e-15, None):
+                got = kernels.mul_cleanup(A.packed, A.coeff_vec, B.packed, B.coeff_vec, True, thr)
+                ref = want_ab if thr is not None else oc.mul(A.packed, A.coeff_vec, B.packed, B.coeff_vec, None)
+                assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), (lazy, fused, thr)
+            got = kernels.mul_cleanup(A.packed, A.coeff_vec, A.packed, A.coeff_vec, True, 1e-15)
+            assert np.array_equal(got[0], want_aa[0]) and np.array_equal(got[1], want_aa[1]), (lazy, fused, 'squared')
+            got = kernels.cleanup(stacked_rows, stacked_coeff, 1e-15)
+            assert np.array_equal(got[0], want_c[0]) and np.array_equal(got[1], want_c[1]), (lazy, fused, 'cleanup')
+    monkeypatch.delenv('SYMGPU_CLEANUP_LAZY')
+    monkeypatch.delenv('SYMGPU_EMIT_FUSED')
+
+
 def test_mul_cleanup_unpacked_fallback_path(monkeypatch):
     """The fused product + cleanup normally sorts packed (hash | e | o | i) keys; operands whose index fields need more than
     32 bits, or a long mixed prefix run, use separate 64-bit keys + index values with materialised pair coefficients."""
