@@ -670,7 +670,9 @@ __device__ __forceinline__ bool fixup_differ(u64 k, u64 kp, const u64 *__restric
 }
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_fixup_find(const u64 *__restrict__ keys, i64 T, int shift, const u64 *__restrict__ hI, const u64 *__restrict__ hO,
-                                                     PackedLayout L, bool same_operand, u64 *__restrict__ rarebits) {
+                                                     PackedLayout L, bool same_operand, u64 *__restrict__ rarebits, u32 *__restrict__ dirtybits) {
+    // dirtybits (lazy cleanup): a key that EQUALS its predecessor is a merged term — its chunk and its predecessor's are the ones
+    // k_heads_sums has to visit (k_find_merges' job, done here in the same pass; a run that k_fixup_work reorders is marked again there)
     const int lane = threadIdx.x & 63;
     const i64 n_steps = (T + 255) / 256;
     for (i64 g = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); g < n_steps; g += (i64)gridDim.x * 4) {
@@ -695,13 +697,21 @@ __global__ __launch_bounds__(256) void k_fixup_find(const u64 *__restrict__ keys
             if (with_prev) rare = fixup_differ<PACKED>(k[j], kp, hI, hO, L, same_operand);
             const u64 b = __ballot(rare);
             if (lane == 0 && base + 64 * j < T) rarebits[base / 64 + j] = b;
+            if (dirtybits) {
+                const u64 m = __ballot(with_prev && !rare);
+                if (m != 0ULL && lane == 0) {
+                    const i64 chunk = base / 64 + j;
+                    atomicOr(&dirtybits[chunk >> 5], 1u << (chunk & 31));
+                    if ((m & 1ULL) && chunk > 0) atomicOr(&dirtybits[(chunk - 1) >> 5], 1u << ((chunk - 1) & 31));
+                }
+            }
         }
     }
 }
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_fixup_work(u64 *__restrict__ keys, u32 *__restrict__ idx, i64 T, int shift, const u64 *__restrict__ rarebits,
                                                      u32 *__restrict__ fallback, const u64 *__restrict__ hI,
-                                                     const u64 *__restrict__ hO, PackedLayout L, bool same_operand) {
+                                                     const u64 *__restrict__ hO, PackedLayout L, bool same_operand, u32 *__restrict__ dirtybits) {
     __shared__ unsigned short s_list[4][4096];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned short *list = s_list[wave];
@@ -748,6 +758,13 @@ __global__ __launch_bounds__(256) void k_fixup_work(u64 *__restrict__ keys, u32 
                     idx[c + 1] = ia;
                 }
             }
+            if (dirtybits)                                                    // the merged terms of the reordered run, where they are now
+                for (i64 a = sp + 1; a < e; ++a)
+                    if (!fixup_differ<PACKED>(keys[a], keys[a - 1], hI, hO, L, same_operand)) {
+                        const i64 ca = a / 64, cb = (a - 1) / 64;
+                        atomicOr(&dirtybits[ca >> 5], 1u << (ca & 31));
+                        if (cb != ca) atomicOr(&dirtybits[cb >> 5], 1u << (cb & 31));
+                    }
         } else {                                                              // a differing key inside a run: is the run too long?
             i64 b = sp - 1, e = sp + 1;
             while (b > 0 && sp - b <= FIX_MAX && (keys[b - 1] >> shift) == (k >> shift)) --b;
@@ -1182,19 +1199,28 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         ks = in_tmp ? keys2.as<u64>() : keys.as<u64>();
         is = packed ? nullptr : (in_tmp ? idx2.as<u32>() : idx.as<u32>());
         HIP_TRY(hipMemsetAsync(collision.p, 0, 16, st));
+        bool merges_found = false;                                     // lazy: dirtybits already filled by the fix-up passes
         if (nbits < 64) {
             const i64 n_ch = (Tk + 63) / 64;
             SG_TRY(fixlist.alloc((size_t)n_ch * 8 + 16));                         // one word of flags per 64 positions
+            u32 *dirty_fx = nullptr;
+            if (lazy) {                                                           // the chunks with merged terms are found in the same pass
+                const i64 n_dw = (n_ch + 31) / 32;
+                SG_TRY(dirtybits.alloc((size_t)n_dw * 4 + 16));
+                HIP_TRY(hipMemsetAsync(dirtybits.p, 0, (size_t)n_dw * 4 + 16, st));
+                dirty_fx = dirtybits.as<u32>();
+                merges_found = true;
+            }
             const dim3 gff((unsigned)grid_for((Tk + 255) / 256, 4, 8192));
             const dim3 gfw((unsigned)((n_ch + 255) / 256));
             if (packed) {
-                hipLaunchKernelGGL(k_fixup_find<true>, gff, dim3(256), 0, st, ks, Tk, 64 - nbits, hI.as<u64>(), hO.as<u64>(), L, inner == outer, fixlist.as<u64>());
+                hipLaunchKernelGGL(k_fixup_find<true>, gff, dim3(256), 0, st, ks, Tk, 64 - nbits, hI.as<u64>(), hO.as<u64>(), L, inner == outer, fixlist.as<u64>(), dirty_fx);
                 hipLaunchKernelGGL(k_fixup_work<true>, gfw, dim3(256), 0, st, ks, (u32 *)nullptr, Tk, 64 - nbits, fixlist.as<u64>(), collision.as<u32>() + 1,
-                                   hI.as<u64>(), hO.as<u64>(), L, inner == outer);
+                                   hI.as<u64>(), hO.as<u64>(), L, inner == outer, dirty_fx);
             } else {
-                hipLaunchKernelGGL(k_fixup_find<false>, gff, dim3(256), 0, st, ks, Tk, 64 - nbits, (const u64 *)nullptr, (const u64 *)nullptr, L, false, fixlist.as<u64>());
+                hipLaunchKernelGGL(k_fixup_find<false>, gff, dim3(256), 0, st, ks, Tk, 64 - nbits, (const u64 *)nullptr, (const u64 *)nullptr, L, false, fixlist.as<u64>(), dirty_fx);
                 hipLaunchKernelGGL(k_fixup_work<false>, gfw, dim3(256), 0, st, ks, is, Tk, 64 - nbits, fixlist.as<u64>(), collision.as<u32>() + 1,
-                                   (const u64 *)nullptr, (const u64 *)nullptr, L, false);
+                                   (const u64 *)nullptr, (const u64 *)nullptr, L, false, dirty_fx);
             }
             KERNEL_CHECK();
         }
@@ -1235,12 +1261,14 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             if (lazy) {
                 // the chunks that hold a member of a segment of more than one element; k_heads_sums then works on those only
                 const i64 n_dw = (n_chunks + 31) / 32;
+                if (!merges_found) {
                 SG_TRY(dirtybits.alloc((size_t)n_dw * 4 + 16));
                 HIP_TRY(hipMemsetAsync(dirtybits.p, 0, (size_t)n_dw * 4 + 16, st));
                 const dim3 gf((unsigned)grid_for((Tk + 255) / 256, 4, 8192));
                 if (packed) hipLaunchKernelGGL(k_find_merges<true>, gf, dim3(256), 0, st, ks, Tk, zero_len_p, L, hI.as<u64>(), hO.as<u64>(), inner == outer ? 1 : 0, dirtybits.as<u32>());
                 else hipLaunchKernelGGL(k_find_merges<false>, gf, dim3(256), 0, st, ks, Tk, zero_len_p, L, nul, nul, 0, dirtybits.as<u32>());
                 KERNEL_CHECK();
+                }
                 dirty_p = dirtybits.as<u32>();
                 gsl = dim3((unsigned)((n_dw + 3) / 4));
             }
