@@ -286,18 +286,26 @@ __device__ __forceinline__ void tri_pair(u32 p, u32 N, u32 &o, u32 &i) {
 // patched term's coefficient from the filed sum and rebuilds every other one from the operand tables (cache resident).  Nothing
 // about the result changes: same kept set, same order, same sums.
 // PACKED: keys[s] is the packed key of index s (pair index, or slot of a squared operator); otherwise coeff[s].
+// One workgroup per tile of SORT_TILE indices (= the radix sort's tile).  hist != null (packed keys): the same pass forms the digit
+// histograms of the sort's first pass, which reads these very keys in this very order (one HBM pass over the keys less).
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_mark_singles(const u64 *__restrict__ keys, const double *__restrict__ coeff, i64 space, PackedLayout L,
                                                        const double *__restrict__ ci, const double *__restrict__ co, int squared, double thr, int use_thr,
-                                                       u64 *__restrict__ markbits64, u64 *__restrict__ e_lo64, u64 *__restrict__ e_hi64) {
-    const int lane = threadIdx.x & 63;
-    const i64 n_steps = (space + 255) / 256;                          // four 64-index chunks per wavefront and step, their loads in flight together
-    for (i64 g = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); g < n_steps; g += (i64)gridDim.x * 4) {
+                                                       u64 *__restrict__ markbits64, u64 *__restrict__ e_lo64, u64 *__restrict__ e_hi64,
+                                                       u32 *__restrict__ hist, int hist_shift, i64 n_tiles) {
+    __shared__ u32 s_h[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (hist) { s_h[threadIdx.x] = 0; __syncthreads(); }
+    const i64 tile_base = (i64)blockIdx.x * SORT_TILE;
+#pragma unroll 1
+    for (int step = 0; step < SORT_TILE / 1024; ++step) {             // four 64-index chunks per wavefront and step, their loads in flight together
+        const i64 g0 = tile_base + step * 1024 + wave * 256;
+        if (g0 >= space) break;                                       // wave-uniform
         u64 k[4];
         double2 cf[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const i64 sidx = g * 256 + 64 * j + lane;
+            const i64 sidx = g0 + 64 * j + lane;
             k[j] = 0ULL; cf[j].x = 0.0; cf[j].y = 0.0;
             if (sidx < space) {
                 if (PACKED) k[j] = keys[sidx];
@@ -306,12 +314,13 @@ __global__ __launch_bounds__(256) void k_mark_singles(const u64 *__restrict__ ke
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const i64 sidx = g * 256 + 64 * j + lane;
-            if (g * 256 + 64 * j >= space) break;                     // wave-uniform
+            const i64 sidx = g0 + 64 * j + lane;
+            if (g0 + 64 * j >= space) break;                          // wave-uniform
             const bool valid = sidx < space;
             double cx = cf[j].x, cy = cf[j].y;
             int e = 0;
             if (PACKED && valid) {
+                if (hist) atomicAdd(&s_h[(u32)(k[j] >> hist_shift) & 255u], 1u);
                 const u32 i = L.i(k[j]), o = L.o(k[j]);
                 e = L.e(k[j]);
                 pair_coefficient(ci[2 * i], ci[2 * i + 1], co[2 * o], co[2 * o + 1], e, cx, cy);
@@ -325,12 +334,16 @@ __global__ __launch_bounds__(256) void k_mark_singles(const u64 *__restrict__ ke
             const bool zero = cx == 0.0 && cy == 0.0;
             const bool keep = valid && (!use_thr || (zero ? 0.0 > thr : (fabs(cx) > thr || fabs(cy) > thr || hypot(__dadd_rn(0.0, cx), __dadd_rn(0.0, cy)) > thr)));
             const u64 mk = __ballot(keep);
-            const i64 chunk = g * 4 + j;
+            const i64 chunk = (g0 + 64 * j) / 64;
             if (PACKED) {
                 const u64 lo = __ballot(e & 1), hi = __ballot(e & 2);
                 if (lane == 0) { markbits64[chunk] = mk; e_lo64[chunk] = lo; e_hi64[chunk] = hi; }
             } else if (lane == 0) markbits64[chunk] = mk;
         }
+    }
+    if (hist) {
+        __syncthreads();
+        hist[(i64)threadIdx.x * n_tiles + blockIdx.x] = s_h[threadIdx.x];     // digit-major, as k_rs_hist files it
     }
 }
 
@@ -1120,7 +1133,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         if (e && e[0] == '1') squared = false;
     }
     i64 Tk = T;                                                         // number of keys that are sorted (T index space stays)
-    Scratch keys, keys2, idx, idx2, fixlist, collision, hI, hO, pair_coeff, markbits, sum_of, zpart, zcount, patchbits, e_lo, e_hi, dirtybits;
+    Scratch keys, keys2, idx, idx2, fixlist, collision, hI, hO, pair_coeff, markbits, sum_of, zpart, zcount, patchbits, e_lo, e_hi, dirtybits, sort_hist;
     // singles decided in index order, only merged terms filed from the sorted order (k_mark_singles); SYMGPU_CLEANUP_LAZY=0: every term filed
     const bool lazy = [] { const char *e = getenv("SYMGPU_CLEANUP_LAZY"); return !(e && e[0] == '0'); }();
     const size_t bitmap_bytes = (size_t)((T + 63) / 64) * 8;         // whole 64-bit words: k_mark_singles stores one per wavefront
@@ -1166,12 +1179,16 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 ka.hI = hI.as<u64>(); ka.hO = hO.as<u64>(); ka.keys = keys.as<u64>(); ka.bi = L.bi; ka.bo = L.bo; ka.o_base = 0;
                 ka.squared = squared ? 1 : 0;
                 SG_TRY(mul_keys_dev(inner, Ni, outer, No, W / 2, inner_is_left, ka));
+                u32 *first_hist = nullptr;
                 if (lazy) {                                          // the keys are still in index order
-                    hipLaunchKernelGGL(k_mark_singles<true>, dim3(grid_for((Tk + 255) / 256, 4, 16384)), dim3(256), 0, st, keys.as<u64>(), (const double *)nullptr, Tk, L, ci, co,
-                                       squared ? 1 : 0, thr, use_thr, markbits.as<u64>(), e_lo.as<u64>(), e_hi.as<u64>());
+                    const i64 n_tiles = (Tk + SORT_TILE - 1) / SORT_TILE;
+                    SG_TRY(sort_hist.alloc((size_t)n_tiles * 256 * sizeof(u32)));
+                    first_hist = sort_hist.as<u32>();
+                    hipLaunchKernelGGL(k_mark_singles<true>, dim3((unsigned)n_tiles), dim3(256), 0, st, keys.as<u64>(), (const double *)nullptr, Tk, L, ci, co,
+                                       squared ? 1 : 0, thr, use_thr, markbits.as<u64>(), e_lo.as<u64>(), e_hi.as<u64>(), first_hist, 64 - nbits, n_tiles);
                     KERNEL_CHECK();
                 }
-                SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp));
+                SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp, first_hist));
             } else {
                 if (!idx.p) {
                     SG_TRY(idx.alloc((size_t)T * 4));
@@ -1191,8 +1208,8 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             KERNEL_CHECK();
         }
         if (!packed && lazy) {
-            hipLaunchKernelGGL(k_mark_singles<false>, dim3(grid_for((T + 255) / 256, 4, 16384)), dim3(256), 0, st, (const u64 *)nullptr, coeff, T, L, (const double *)nullptr,
-                               (const double *)nullptr, 0, thr, use_thr, markbits.as<u64>(), (u64 *)nullptr, (u64 *)nullptr);
+            hipLaunchKernelGGL(k_mark_singles<false>, dim3((unsigned)((T + SORT_TILE - 1) / SORT_TILE)), dim3(256), 0, st, (const u64 *)nullptr, coeff, T, L, (const double *)nullptr,
+                               (const double *)nullptr, 0, thr, use_thr, markbits.as<u64>(), (u64 *)nullptr, (u64 *)nullptr, (u32 *)nullptr, 0, (i64)0);
             KERNEL_CHECK();
         }
         if (!packed) SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), Tk, 64 - nbits, 64, &in_tmp));

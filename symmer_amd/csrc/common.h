@@ -141,9 +141,13 @@ void op_invalidate(symgpu_op_s *op);
 
 // sort.hip
 int exclusive_scan_u32(const u32 *in, u32 *out, i64 n, u32 *total_dev /* may be null: device u32 */);
+// first_hist (optional, device, 256 * ceil(n / SORT_TILE) u32): the digit-major tile histograms of the FIRST pass
+// (hist[digit * n_tiles + tile] = keys of tile `tile` whose bits [begin_bit, begin_bit + 8) equal `digit`), formed by a kernel of the
+// caller's that reads the keys anyway; the buffer then serves the later passes
+constexpr int SORT_TILE = 4096;
 int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp, i64 n, int begin_bit, int end_bit,
-                             bool *result_in_tmp);
-int radix_sort_keys_u64(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp);
+                             bool *result_in_tmp, u32 *first_hist = nullptr);
+int radix_sort_keys_u64(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, u32 *first_hist = nullptr);
 // the same as one persistent launch (up to 2^19 keys); *done = false: not applicable, use the multi-launch form
 int radix_sort_keys_u64_coop(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done);
 int radix_sort_coop_check(bool *timed_out);     // after a stream synchronisation: did a one-launch sort give up (output invalid)?

@@ -258,8 +258,9 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ keys
 
 // Sort n pairs by key bits [begin_bit, end_bit) (multiple of 8 wide), stable.  Ping-pongs between the
 // given buffers; *result_in_tmp tells where the sorted data ended up.  vals == nullptr: keys only.
+static_assert(RS_TILE == SORT_TILE, "the tile size callers form their first histogram with");
 int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp, i64 n, int begin_bit, int end_bit,
-                             bool *result_in_tmp) {
+                             bool *result_in_tmp, u32 *first_hist) {
     *result_in_tmp = false;
     if (n <= 1) return SYMGPU_OK;
     if (n >= ((i64)1 << 32)) {
@@ -268,20 +269,23 @@ int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp,
     }
     hipStream_t st = ctx().stream;
     const i64 n_tiles = (n + RS_TILE - 1) / RS_TILE;
-    Scratch hist;
-    SG_TRY(hist.alloc((size_t)n_tiles * 256 * sizeof(u32)));
+    Scratch hist_own;
+    if (!first_hist) SG_TRY(hist_own.alloc((size_t)n_tiles * 256 * sizeof(u32)));
+    u32 *hist_p = first_hist ? first_hist : hist_own.as<u32>();
     u64 *ksrc = keys, *kdst = keys_tmp;
     u32 *vsrc = vals, *vdst = vals_tmp;
     bool in_tmp = false;
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
-        hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)n_tiles), dim3(256), 0, st, ksrc, n, shift, n_tiles, hist.as<u32>());
-        KERNEL_CHECK();
-        SG_TRY(exclusive_scan_u32(hist.as<u32>(), hist.as<u32>(), n_tiles * 256, nullptr));
+        if (!(first_hist && shift == begin_bit)) {
+            hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)n_tiles), dim3(256), 0, st, ksrc, n, shift, n_tiles, hist_p);
+            KERNEL_CHECK();
+        }
+        SG_TRY(exclusive_scan_u32(hist_p, hist_p, n_tiles * 256, nullptr));
         if (vals)
-            hipLaunchKernelGGL(k_rs_scatter<true>, dim3((unsigned)((n_tiles + 7) / 8 * 8)), dim3(256), 0, st, ksrc, vsrc, n, shift, n_tiles, hist.as<u32>(), kdst, vdst);
+            hipLaunchKernelGGL(k_rs_scatter<true>, dim3((unsigned)((n_tiles + 7) / 8 * 8)), dim3(256), 0, st, ksrc, vsrc, n, shift, n_tiles, hist_p, kdst, vdst);
         else
             hipLaunchKernelGGL(k_rs_scatter<false>, dim3((unsigned)((n_tiles + 7) / 8 * 8)), dim3(256), 0, st, ksrc, (const u32 *)nullptr, n, shift, n_tiles,
-                               hist.as<u32>(), kdst, (u32 *)nullptr);
+                               hist_p, kdst, (u32 *)nullptr);
         KERNEL_CHECK();
         u64 *tk = ksrc; ksrc = kdst; kdst = tk;
         u32 *tv = vsrc; vsrc = vdst; vdst = tv;
@@ -467,8 +471,8 @@ int radix_sort_coop_check(bool *timed_out) {
     return SYMGPU_OK;
 }
 
-int radix_sort_keys_u64(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp) {
-    return radix_sort_pairs_u64_u32(keys, nullptr, keys_tmp, nullptr, n, begin_bit, end_bit, result_in_tmp);
+int radix_sort_keys_u64(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, u32 *first_hist) {
+    return radix_sort_pairs_u64_u32(keys, nullptr, keys_tmp, nullptr, n, begin_bit, end_bit, result_in_tmp, first_hist);
 }
 
 }  // namespace symgpu
