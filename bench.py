@@ -297,8 +297,8 @@ def wl_mul_cleanup(args, comm, rank, world, _lib, DeviceOp, parallel):
     """BASELINE cfg3 — the call `P * P` of the reference (base.py:821-859 -> _multiply_by_operator :764-794 -> symplectic_cleanup
     utils.py:230-279): a 10,000-term, 1,000-qubit operator squared (1e8 pairs) + cleanup, device resident.  Step = one fused
     product + cleanup (symgpu_mul_cleanup_dev); the 1e8 product rows are never materialised.
-    roofline: the kernel that moves most of the step's bytes, the output row stream k_emit_stream (every kept row written once:
-    16 Wq bytes per row, HBM-write bound; the list it reads comes out of the Infinity Cache).  SURVEY §8d's algorithmic bytes of the
+    roofline: the kernel that moves most of the step's bytes, the fused output stage k_emit_fused (every kept row and its coefficient
+    written once: 16 Wq + 16 bytes per row, HBM-write bound; beside the stream it only reads bitmaps and the cache-resident operands).  SURVEY §8d's algorithmic bytes of the
     whole step (T (16 Wq + 16) read + U_kept (16 Wq + 16) written) are reported next to it — most of them never move here."""
     lib = _lib.lib()
     n, N = args.qubits, 10000
@@ -323,15 +323,15 @@ def wl_mul_cleanup(args, comm, rank, world, _lib, DeviceOp, parallel):
     nl, ms = prof_read(_lib, 3)
     pairs = N * N
     row_bytes = 16 * wq
-    launch_bytes = n_out[0] * row_bytes * args.steps / max(1, nl)          # rows written per k_emit_stream launch (batches of 4M indices)
+    launch_bytes = n_out[0] * (row_bytes + 16) * args.steps / max(1, nl)   # rows + coefficients written by the one k_emit_fused launch of a step
     kt = ms / max(1, nl) * 1e-3
     algo_step = (pairs + n_out[0]) * (row_bytes + 16)
-    roof = {'bound': 'hbm', 'kernel': 'k_emit_stream', 'achieved': launch_bytes / kt / 1e9 if kt else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+    roof = {'bound': 'hbm', 'kernel': 'k_emit_fused', 'achieved': launch_bytes / kt / 1e9 if kt else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': launch_bytes / kt / 1e9 / HBM_PEAK_GBS if kt else None, 'traffic': None, 'launches': nl, 'avg_launch_ms': kt * 1e3,
             'algorithmic_bytes_per_launch': launch_bytes,
-            'note': 'output row stream of the cleanup: 16*Wq bytes per kept row, written once, sequentially (non-temporal stores); the other '
-                    'long kernels of the step are the 4 passes of the radix sort (8 B keys) and k_heads_sums (latency bound) — '
-                    'profiles/r03_cfg3_kernel_trace.txt',
+            'note': 'output stage of the cleanup in one launch: 16*Wq + 16 bytes per kept row, written once (non-temporal stores), rows '
+                    'gathered from the L2-resident operand; the other long kernels of the step are the 4 passes of the radix sort '
+                    '(8 B keys: scatter 0.17 ms + histogram 0.09 ms each) and the key generation — profiles/r03_cfg3_kernel_trace.txt',
             'whole_step': {'survey_8d_algorithmic_bytes': algo_step, 'algorithmic_GBps': algo_step / (dt / args.steps) / 1e9,
                            'physical_write_floor_ms': n_out[0] * (row_bytes + 16) / (HBM_PEAK_GBS * 1e9) * 1e3,
                            'note': 'SURVEY 8d counts T (16Wq+16) B read + U_kept (16Wq+16) B written; the T product rows and pair coefficients '

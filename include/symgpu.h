@@ -49,7 +49,7 @@ int symgpu_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 int symgpu_timer_start(void);
 int symgpu_timer_stop(float *ms);
 /* per-launch HIP-event timing of the dominant kernel of a class (0 = product row stream k_mul_rows, 1 = commutation k_commutes,
- * 2 = GF(2) sweep k_sweep_m4r (main launches), 3 = cleanup output row stream k_emit_stream, 4 = one-launch rotation k_rot_resident,
+ * 2 = GF(2) sweep k_sweep_m4r (main launches), 3 = cleanup output stage k_emit_fused (k_emit_stream with SYMGPU_EMIT_FUSED=0), 4 = one-launch rotation k_rot_resident,
  * 5 = register-resident run of Clifford rotations k_cchain_reg): enable, run, then read {launch count, total ms}. */
 #define SYMGPU_PROF_CLASSES 6
 int symgpu_prof_enable(int kernel_class, int on);

@@ -7,7 +7,7 @@
 export TMPDIR=/tmp
 tag=${1:-r03}; wl=${2:-rotation}
 case $wl in
-  mul_cleanup) short=cfg3; like='%k_emit_stream%'; srcs="cleanup.hip";;
+  mul_cleanup) short=cfg3; like='%k_emit_fused%'; srcs="cleanup.hip";;
   rotation)    short=rotation; like='%k_rot_resident%'; srcs="rotate_resident.hip";;
   gf2)         short=gf2; like='%k_sweep_m4r<1>%'; srcs="gf2.hip";;
   *) echo "unknown workload $wl"; exit 2;;
@@ -18,7 +18,7 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE -d $out/w -o w -- python3 $cmd > $out/w.l
 timeout 900 rocprofv3 --pmc FETCH_SIZE -d $out/r -o r -- python3 $cmd > $out/r.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats -d $out/t -o t -- python3 $cmd > $out/${tag}_${short}_n1.json 2> $out/t.log
 python3 profiles/summarize_rocpd.py $out/t/t_results.db | head -24 > $out/${tag}_${short}_kernel_trace.txt
-python3 profiles/summarize_rocpd.py --pmc $out/w/w_results.db --pmc $out/r/r_results.db | grep -E "^#|counter|k_emit|k_rot_res|k_sweep|k_heads|k_rs_|k_select|k_mul_coeff" > $out/${tag}_${short}_pmc.txt
+python3 profiles/summarize_rocpd.py --pmc $out/w/w_results.db --pmc $out/r/r_results.db | grep -E "^#|counter|k_emit|k_rot_res|k_sweep|k_heads|k_rs_|k_select|k_mul_coeff|k_mark|k_fixup|k_find" > $out/${tag}_${short}_pmc.txt
 python3 - "$out" "$tag" "$wl" "$short" "$like" $srcs <<'PY'
 import sqlite3, json, sys, hashlib
 out, tag, wl, short, like = sys.argv[1:6]
