@@ -155,6 +155,24 @@ __global__ __launch_bounds__(64) void k_wpanel(const u64 *__restrict__ rows, i64
 
 // selectors of all rows (in terms of the OLD block rows), reference-order XOR count, snapshot of the old block rows.
 // One wavefront per row, lane j <-> pivot j: the 64 pivot-column bits are fetched in parallel and f is ONE __ballot.
+// one wavefront, one row: its selector in terms of the OLD block rows, and the row's share of the reference-order XOR count
+__device__ __forceinline__ u64 select_row(const u64 *__restrict__ rows, i64 Wc, i64 r, int lane, i64 i0, int kk, int pw, int pb, u64 mj, u64 Tj,
+                                          u32 *__restrict__ rowcnt) {
+    if (r >= i0 && r < i0 + kk) {
+        // new_r = XOR_{i in T_r} old_i = old_r ^ XOR_{i in T_r xor {r}} old_i
+        return readlane64(Tj, (int)(r - i0)) ^ (1ULL << (r - i0));
+    }
+    const bool bit = (lane < kk && pw >= 0) ? ((rows[r * Wc + pw] >> pb) & 1ULL) : false;
+    const u64 f = __ballot(bit);
+    // sequential-time selector t_j = f_j ^ parity(f & mask_j & (2^j-1)): |t| row-XORs in the reference loop
+    const bool tj = bit ^ (bool)(__popcll(f & mj) & 1);
+    const u64 t = __ballot(tj);
+    if (lane == 0) rowcnt[r] += (u32)__popcll(t);                     // one wave per row: no atomics, summed at the end
+    u64 x = bit ? Tj : 0ULL;                                          // g = XOR_{j in f} T_j
+    for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off);
+    return x;
+}
+
 __global__ __launch_bounds__(256) void k_select(const u64 *__restrict__ rows, i64 R, i64 Wc, const BlockInfo *__restrict__ info,
                                                  u64 *__restrict__ sel, u64 *__restrict__ snap, u32 *__restrict__ rowcnt) {
     const int kk = info->kk;
@@ -166,21 +184,7 @@ __global__ __launch_bounds__(256) void k_select(const u64 *__restrict__ rows, i6
     const u64 Tj = info->T[lane];
     const i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r < R) {
-        u64 g;
-        if (r >= i0 && r < i0 + kk) {
-            // new_r = XOR_{i in T_r} old_i = old_r ^ XOR_{i in T_r xor {r}} old_i
-            g = readlane64(Tj, (int)(r - i0)) ^ (1ULL << (r - i0));
-        } else {
-            const bool bit = (lane < kk && pw >= 0) ? ((rows[r * Wc + pw] >> pb) & 1ULL) : false;
-            const u64 f = __ballot(bit);
-            // sequential-time selector t_j = f_j ^ parity(f & mask_j & (2^j-1)): |t| row-XORs in the reference loop
-            const bool tj = bit ^ (bool)(__popcll(f & mj) & 1);
-            const u64 t = __ballot(tj);
-            if (lane == 0) rowcnt[r] += (u32)__popcll(t);             // one wave per row: no atomics, summed at the end
-            u64 x = bit ? Tj : 0ULL;                                  // g = XOR_{j in f} T_j
-            for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off);
-            g = x;
-        }
+        const u64 g = select_row(rows, Wc, r, lane, i0, kk, pw, pb, mj, Tj, rowcnt);
         if (lane == 0) sel[r] = g;
     }
     // snapshot of the old block rows (the sweep overwrites them while other workgroups still read them)
@@ -262,18 +266,66 @@ constexpr int M4_NT = 1024;                     // threads per workgroup (16 wav
 constexpr int M4_U = 4;                         // rows in flight per wave
 constexpr size_t M4_LDS = (size_t)16 * 16 * M4_TW * sizeof(u64);
 
+// PHASE 3 (round 3) = phase 0 and the selector launch in ONE grid: blocks 0..3 compute the selectors of the next block's 64 rows and
+// publish them (agent-scope stores, one tagged flag per row), the next n_tiles blocks are phase 0's tile workgroups — they build their
+// tables straight from the old block rows (nobody writes those in this launch) and wait for the 64 flags before they touch the next
+// block's rows — and the remaining blocks compute the selectors of all other rows (which phase 0 never touches) and the snapshot.
+// One kernel boundary less on the critical path of every block: select 5 us -> hidden behind phase 0.
+constexpr int SEL_PRI = 4;                      // priority blocks: 16 rows (wavefronts) each = the next block's 64 rows
+struct FusedSelect {
+    u64 *sel;                                   // writable view of the selectors
+    u64 *snap;
+    u32 *rowcnt;
+    u32 *ready;                                 // [64] flags: == epoch when the row's selector has been published
+    u32 epoch;
+    u32 *fail;                                  // a tile workgroup gave up waiting
+};
 template <int PHASE>
 __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64 R, i64 Wc, const BlockInfo *__restrict__ info,
                                                       const u64 *__restrict__ sel, const u64 *__restrict__ snap, int n_tiles, int n_chunks,
                                                       BlockInfo *__restrict__ info_next, SweepState *__restrict__ st, i64 *__restrict__ pivots,
-                                                      unsigned long long *__restrict__ xor_count, int *__restrict__ lead) {
+                                                      unsigned long long *__restrict__ xor_count, int *__restrict__ lead, FusedSelect fs) {
     extern __shared__ u64 tab[];                                    // [16 groups][16 entries][64 words]
+    __shared__ u64 s_sel[WK];
+    __shared__ int s_ok;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kk = info->kk;
     const i64 i0n = info->i0 + kk;                                  // first row of the next block
     // rows of the next block: [nb, ne)   (PHASE 2: plain sweep of all rows, no lookahead)
     const i64 nb = PHASE == 2 ? 0 : (i0n < R ? i0n : R), ne = PHASE == 2 ? 0 : (i0n + WK < R ? i0n + WK : R);
     int k = blockIdx.x;
+    if (PHASE == 3) {
+        if (k < SEL_PRI || k >= SEL_PRI + n_tiles) {
+            // ---- selector role: one wavefront per row ----
+            if (kk == 0) return;
+            const i64 i0 = info->i0;
+            const int pw = info->pivw[lane], pb = info->pivb[lane];
+            const u64 mj = info->mask[lane] & ((1ULL << lane) - 1ULL);
+            const u64 Tj = info->T[lane];
+            i64 r = -1;
+            if (k < SEL_PRI) { r = nb + (i64)k * 16 + wave; if (r >= ne) r = -1; }
+            else {
+                const i64 v = (i64)(k - SEL_PRI - n_tiles) * 16 + wave, n_other = R - (ne - nb);
+                if (v < n_other) r = v < nb ? v : v + (ne - nb);
+            }
+            if (r >= 0) {
+                const u64 g = select_row(rows, Wc, r, lane, i0, kk, pw, pb, mj, Tj, fs.rowcnt);
+                if (lane == 0) {
+                    if (k < SEL_PRI) {
+                        __hip_atomic_store(&fs.sel[r], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_store(&fs.ready[r - nb], fs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else fs.sel[r] = g;
+                }
+            }
+            // snapshot of the old block rows for phase 1 (which overwrites them while other workgroups still read them)
+            const i64 n_sel = (i64)gridDim.x - n_tiles, me = k < SEL_PRI ? k : k - n_tiles;
+            const i64 total = (i64)kk * Wc;
+            for (i64 x = me * M4_NT + threadIdx.x; x < total; x += n_sel * M4_NT) fs.snap[x] = rows[i0 * Wc + x];
+            return;
+        }
+        k -= SEL_PRI;
+    }
     if (PHASE == 1) {
         if (k == 0) {
             // ---- panel workgroup: one wavefront; the leading words were collected by phase 0 (reset for the next block) ----
@@ -286,10 +338,11 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
         }
         --k;
     }
-    if (kk == 0 && PHASE != 0) return;
+    constexpr bool P0 = PHASE == 0 || PHASE == 3;
+    if (kk == 0 && !P0) return;
     const int tile = k % n_tiles, chunk = k / n_tiles;
     // rows of this chunk: PHASE 0 the next block's rows, PHASE 1 / 2 the virtual index space of all OTHER rows
-    const i64 n_rows = PHASE == 0 ? ne - nb : R - (ne - nb);
+    const i64 n_rows = P0 ? ne - nb : R - (ne - nb);
     const i64 per = (n_rows + n_chunks - 1) / n_chunks;
     const i64 v_lo = (i64)chunk * per, v_hi = v_lo + per < n_rows ? v_lo + per : n_rows;
     if (v_lo >= v_hi) return;
@@ -301,7 +354,8 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
         for (int g = wave; g < 16; g += M4_NT / 64) {
             u64 sv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sv[i] = (4 * g + i < kk) ? snap[(i64)(4 * g + i) * Wc + wl] : 0ULL;
+            for (int i = 0; i < 4; ++i)
+                sv[i] = (4 * g + i < kk) ? (PHASE == 3 ? rows[(info->i0 + 4 * g + i) * Wc + wl] : snap[(i64)(4 * g + i) * Wc + wl]) : 0ULL;
             u64 t[16];
             t[0] = 0; t[1] = sv[0]; t[2] = sv[1]; t[3] = sv[0] ^ sv[1];
 #pragma unroll
@@ -312,7 +366,23 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
             for (int e = 0; e < 16; ++e) tab[(g * 16 + e) * M4_TW + lane] = t[e];
         }
     }
+    if (PHASE == 3 && kk != 0) {
+        // the selectors of the next block's rows come from blocks 0..3 of this launch: wait for their flags (bounded), then read them
+        if (wave == 0) {
+            const int nr = (int)(ne - nb);
+            bool ok = true;
+            for (u32 spins = 0;; ++spins) {
+                const u32 v = lane < nr ? __hip_atomic_load(&fs.ready[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : fs.epoch;
+                if (__ballot(v == fs.epoch) == ~0ULL) break;
+                if (spins >= (1u << 22)) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            s_sel[lane] = (ok && lane < nr) ? __hip_atomic_load(&fs.sel[nb + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+            if (lane == 0) { s_ok = ok ? 1 : 0; if (!ok) atomicOr(fs.fail, 1u); }
+        }
+    }
     __syncthreads();
+    if (PHASE == 3 && kk != 0 && !s_ok) return;                      // flagged: the call fails loudly
     // ---- stream the rows: M4_U per wave and step, software pipelined (the loads of step i+1 are in flight while step i
     //      does its table look-ups: a wave only runs a handful of steps, so nothing else would hide the load latency) ----
     const i64 shift = ne - nb;
@@ -323,8 +393,8 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
 #pragma unroll
         for (int u = 0; u < M4_U; ++u) {
             const i64 v = v0 + u < v_hi ? v0 + u : (v0 < v_hi ? v0 : v_lo);   // tail: surplus slots repeat a valid row, never stored
-            rn[u] = PHASE == 0 ? nb + v : (v < nb ? v : v + shift);
-            sn[u] = kk != 0 ? sel[rn[u]] : 0ULL;
+            rn[u] = P0 ? nb + v : (v < nb ? v : v + shift);
+            sn[u] = kk != 0 ? (PHASE == 3 ? s_sel[rn[u] - nb] : sel[rn[u]]) : 0ULL;
             xn[u] = rows[rn[u] * Wc + wl];
         }
     };
@@ -352,7 +422,7 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
                 }
                 if (live && mine) rows[r[u] * Wc + w] = x[u];
             }
-            if (PHASE == 0 && mine) {
+            if (P0 && mine) {
                 // leading word of the next block's rows for its panel: minimum over the column tiles
                 const u64 nz = __ballot(live && x[u] != 0);
                 if (nz && lane == 0) atomicMin(&lead[r[u] - nb], tile * M4_TW + (int)__builtin_ctzll(nz));
@@ -439,7 +509,7 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
             return SYMGPU_OK;
         }
     }
-    Scratch info, state, lead, sel, snap, count, piv, rowcnt;
+    Scratch info, state, lead, sel, snap, count, piv, rowcnt, ready;
     SG_TRY(info.alloc(2 * sizeof(BlockInfo)));
     SG_TRY(state.alloc(sizeof(SweepState)));
     SG_TRY(lead.alloc(WK * sizeof(int)));
@@ -450,6 +520,8 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     SG_TRY(rowcnt.alloc((size_t)R * 4));
     HIP_TRY(hipMemsetAsync(rowcnt.p, 0, (size_t)R * 4, st));
     HIP_TRY(hipMemsetAsync(count.p, 0, 16, st));
+    SG_TRY(ready.alloc(WK * sizeof(u32)));
+    HIP_TRY(hipMemsetAsync(ready.p, 0, WK * sizeof(u32), st));
     HIP_TRY(hipMemsetAsync(state.p, 0, sizeof(SweepState), st));
     HIP_TRY(hipMemsetAsync(info.p, 0, 2 * sizeof(BlockInfo), st));   // {i0 = 0, kk = 0}: "nothing swept yet, next block starts at row 0"
     constexpr int SW_ROWS = 16;                                     // rows per sweep workgroup, held in VGPRs
@@ -460,7 +532,8 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     static const bool m4r_attr = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess &&
                hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess;
+               hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess;
     }();
     const char *env_m4r = getenv("SYMGPU_GF2_M4R"), *env_la = getenv("SYMGPU_GF2_LOOKAHEAD");   // read per call: the tests switch paths
     const bool m4r = m4r_attr && !(env_m4r && env_m4r[0] == '0'), m4r_plain = m4r;
@@ -469,6 +542,11 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     if ((i64)m4_chunks > (R + 127) / 128) m4_chunks = (int)((R + 127) / 128);   // the table costs about 100 rows of work
     if (m4_chunks < 1) m4_chunks = 1;
     const bool lookahead = !(env_la && env_la[0] == '0');
+    // SYMGPU_GF2_FUSED_SELECT=0: the selector launch on its own in front of phase 0 (three launches per block instead of two)
+    const bool fused_select = [] { const char *e = getenv("SYMGPU_GF2_FUSED_SELECT"); return !(e && e[0] == '0'); }();
+    FusedSelect fs;
+    fs.sel = sel.as<u64>(); fs.snap = snap.as<u64>(); fs.rowcnt = rowcnt.as<u32>(); fs.ready = ready.as<u32>(); fs.epoch = 0;
+    fs.fail = reinterpret_cast<u32 *>(count.p) + 2;
     if (lookahead && m4r && (i64)m4_tiles * m4_chunks + 1 < ((i64)1 << 31)) {
         // Pipeline, three launches per block: select(b) -> phase 0: sweep of the rows of block b+1 + their leading words ->
         // phase 1: panel of block b+1 (-> the other info buffer) inside the sweep of all remaining rows.  The very first
@@ -487,14 +565,22 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
             if (n_iter > 4096) n_iter = 4096;
             for (i64 k = 0; k < n_iter; ++k, ++it) {
                 BlockInfo *cur = binfo + ((it + 1) & 1), *next = binfo + (it & 1);      // cur: block it-1 (to sweep), next: block it (to panel)
-                if (it > 0)
-                    hipLaunchKernelGGL(k_select, dim3(gsel), dim3(256), 0, st, rows, R, Wc, cur, sel.as<u64>(), snap.as<u64>(), rowcnt.as<u32>());
-                hipLaunchKernelGGL(k_sweep_m4r<0>, dim3(m4_tiles), dim3(M4_NT), M4_LDS, st, rows, R, Wc, cur, sel.as<u64>(), snap.as<u64>(),
-                                   m4_tiles, 1, next, state.as<SweepState>(), piv.as<i64>(), count.as<unsigned long long>(), lead.as<int>());
+                fs.epoch = (u32)(it + 1);
+                if (fused_select) {
+                    // selectors of block it-1 and phase 0 in one grid (the very first iteration has no block to select for: kk == 0)
+                    const unsigned g3 = (unsigned)(SEL_PRI + m4_tiles + (R + 15) / 16);
+                    hipLaunchKernelGGL(k_sweep_m4r<3>, dim3(g3), dim3(M4_NT), M4_LDS, st, rows, R, Wc, cur, sel.as<u64>(), snap.as<u64>(),
+                                       m4_tiles, 1, next, state.as<SweepState>(), piv.as<i64>(), count.as<unsigned long long>(), lead.as<int>(), fs);
+                } else {
+                    if (it > 0)
+                        hipLaunchKernelGGL(k_select, dim3(gsel), dim3(256), 0, st, rows, R, Wc, cur, sel.as<u64>(), snap.as<u64>(), rowcnt.as<u32>());
+                    hipLaunchKernelGGL(k_sweep_m4r<0>, dim3(m4_tiles), dim3(M4_NT), M4_LDS, st, rows, R, Wc, cur, sel.as<u64>(), snap.as<u64>(),
+                                       m4_tiles, 1, next, state.as<SweepState>(), piv.as<i64>(), count.as<unsigned long long>(), lead.as<int>(), fs);
+                }
                 ProfScope prof(2);
                 hipLaunchKernelGGL(k_sweep_m4r<1>, dim3(m4_tiles * m4_chunks + 1), dim3(M4_NT), M4_LDS, st, rows, R, Wc, cur, sel.as<u64>(),
                                    snap.as<u64>(), m4_tiles, m4_chunks, next, state.as<SweepState>(), piv.as<i64>(), count.as<unsigned long long>(),
-                                   lead.as<int>());
+                                   lead.as<int>(), fs);
                 KERNEL_CHECK();
             }
             // the block that has been panelled but not swept yet: kk == 0 means the matrix is exhausted
@@ -521,7 +607,7 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
             ProfScope prof(2);
             if (m4r_plain)
                 hipLaunchKernelGGL(k_sweep_m4r<2>, dim3(m4_tiles * m4_chunks), dim3(M4_NT), M4_LDS, st, rows, R, Wc, binfo, sel.as<u64>(), snap.as<u64>(),
-                                   m4_tiles, m4_chunks, binfo, state.as<SweepState>(), piv.as<i64>(), count.as<unsigned long long>(), lead.as<int>());
+                                   m4_tiles, m4_chunks, binfo, state.as<SweepState>(), piv.as<i64>(), count.as<unsigned long long>(), lead.as<int>(), fs);
             else
             hipLaunchKernelGGL((k_sweep<SW_ROWS, 4>), dim3(gx, gy), dim3(256), 0, st, rows, R, Wc, binfo, sel.as<u64>(), snap.as<u64>());
             KERNEL_CHECK();
@@ -535,11 +621,15 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     }
     hipLaunchKernelGGL(k_sum_u32, dim3(256), dim3(256), 0, st, rowcnt.as<u32>(), R, count.as<unsigned long long>());
     KERNEL_CHECK();
-    unsigned long long h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, count.p, 8, hipMemcpyDeviceToHost, st));
+    unsigned long long hb[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(hb, count.p, 16, hipMemcpyDeviceToHost, st));
     if (pivots_host) HIP_TRY(hipMemcpyAsync(pivots_host, piv.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (xor_count) *xor_count = (i64)h;
+    if ((u32)hb[1] != 0) {
+        set_error("rref: a phase-0 workgroup timed out waiting for the selectors of its rows (SYMGPU_GF2_FUSED_SELECT=0 separates the launches)");
+        return SYMGPU_E_HIP;
+    }
+    if (xor_count) *xor_count = (i64)hb[0];
     return SYMGPU_OK;
 }
 

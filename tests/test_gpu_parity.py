@@ -786,11 +786,13 @@ def test_rotate_golden_general_path(case, monkeypatch):
     test_rotate_golden(case)
 
 
-@pytest.mark.parametrize('env', [{'SYMGPU_GF2_LOOKAHEAD': '0'}, {'SYMGPU_GF2_M4R': '0'}])
+@pytest.mark.parametrize('env', [{'SYMGPU_GF2_LOOKAHEAD': '0'}, {'SYMGPU_GF2_M4R': '0'}, {'SYMGPU_GF2_FUSED_SELECT': '0'},
+                                 {'SYMGPU_GF2_FUSED_SELECT': '0', 'SYMGPU_GF2_SMALL': '0'}, {'SYMGPU_GF2_SMALL': '0'}])
 @pytest.mark.parametrize('case', family('gf2')[::4])
 def test_gf2_golden_other_sweep_paths(case, env, monkeypatch):
-    """The GF(2) elimination has three schedules: lookahead + Four-Russians sweep (default), Four-Russians sweep without
-    lookahead, and the flag-per-block-row sweep; all must reproduce the reference's matrices."""
+    """The GF(2) elimination has these schedules: lookahead + Four-Russians sweep with the selector launch fused into phase 0
+    (default: two launches per block), the same with the selector launch on its own (three), Four-Russians sweep without lookahead,
+    and the flag-per-block-row sweep; all must reproduce the reference's matrices (small matrices too: SYMGPU_GF2_SMALL=0)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     test_gf2_golden(case)
@@ -815,6 +817,23 @@ def test_rotation_chain_with_duplicates_and_tiny_terms(seed):
     R2 = P.perform_rotations([(PauliwordOp(q.reshape(1, -1), [1]), a) for q, a in mixed])
     er2, ec2 = onp.perform_rotations(symp, coeff, mixed)
     assert_op_equal(R2.symp_matrix, R2.coeff_vec, er2, ec2, exact=False, tol=TOL)
+
+
+@pytest.mark.parametrize('R,C,dens', [(700, 700, 0.5), (700, 700, 0.003), (1500, 5000, 0.3), (300, 9000, 0.05), (129, 64, 0.5)])
+def test_rref_fused_selector_launch_equals_separate(R, C, dens, monkeypatch):
+    """Round 3: the selectors of a block are computed inside phase 0's launch (the tile workgroups wait for the 64 selectors of their
+    rows, published by the first four workgroups of the grid).  Same reduced matrix, pivots and reference row-XOR count as with the
+    selector launch on its own, and as the oracle — dense, sparse (blocks of a few rows), wide and tall."""
+    rng = np.random.default_rng(R * 31 + C)
+    m = rng.random((R, C)) < dens
+    packed = packing.pack_bits(m)
+    red1, cnt1, piv1 = kernels.rref(packed, want_pivots=True)
+    monkeypatch.setenv('SYMGPU_GF2_FUSED_SELECT', '0')
+    red2, cnt2, piv2 = kernels.rref(packed, want_pivots=True)
+    monkeypatch.delenv('SYMGPU_GF2_FUSED_SELECT')
+    ered, ecnt = onp.rref_noswap(m, count_xors=True)
+    assert np.array_equal(red1, red2) and cnt1 == cnt2 == ecnt and np.array_equal(piv1, piv2)
+    assert np.array_equal(packing.unpack_bits(red1, C), ered)
 
 
 @pytest.mark.parametrize('R,C,dens', [(64, 4096, 0.4), (33, 64, 0.5), (64, 3000, 0.01), (10, 40, 0.2)])
