@@ -300,7 +300,7 @@ def test_cfg5_whole_adjacency_one_launch():
     _lib.check(lib.symgpu_dev_free(buf)); _lib.check(lib.symgpu_dev_free(bits)); A.free()
 
 
-@pytest.mark.parametrize('workload,metric,kernel', [('mul_cleanup', 'pauli_term_pairs_per_sec', 'k_emit_stream'),
+@pytest.mark.parametrize('workload,metric,kernel', [('mul_cleanup', 'pauli_term_pairs_per_sec', 'k_emit_fused'),
                                                     ('rotation', 'pauli_term_pairs_per_sec', 'k_rot_resident'),
                                                     ('gf2', 'gf2_row_xors_per_sec', 'k_sweep_m4r')])
 def test_bench_workloads_of_the_other_baseline_configs(workload, metric, kernel):
