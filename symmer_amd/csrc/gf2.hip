@@ -24,6 +24,7 @@
 // sum_j |mask_j| + sum_r |t(r)|  (derivation in DESIGN.md §3.5).
 #include "common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace symgpu {
 
@@ -73,6 +74,18 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l) {
     return ((u64)hi << 32) | lo;
 }
 
+// Where the 4-word window starts: at the smallest leading word of the block's rows, but never so far left that the first non-zero
+// row (lane jf) falls out of it.  (Round 2 started it AT the first row's leading word: when the pivots cross a word boundary some
+// rows still lead in the word before — a dense matrix then lost a one-row block every 64 columns.)
+__device__ __forceinline__ int window_start(int a, bool valid, int jf) {
+    const int a_first = __builtin_amdgcn_readlane(a, jf);
+    int lo = (valid && a != NOLEAD) ? a : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(lo, off); lo = o < lo ? o : lo; }
+    const int floor_w = a_first - (WN - 1);
+    return lo > floor_w ? lo : floor_w;
+}
+
 // the panel proper: ONE wavefront (lane = block row), `a` = this lane's leading word (lead[] semantics), block starts at i0
 __device__ __forceinline__ void panel_wave(const u64 *__restrict__ rows, i64 R, i64 Wc, i64 i0, int a, int lane, SweepState *__restrict__ st,
                                            BlockInfo *__restrict__ info, i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count) {
@@ -87,7 +100,7 @@ __device__ __forceinline__ void panel_wave(const u64 *__restrict__ rows, i64 R, 
     u64 tv = 1ULL << lane;                                          // T row of this lane
     if (fin_m != 0) {
         const int jf = __builtin_ctzll(fin_m);
-        const int w_lo = __builtin_amdgcn_readlane(a, jf);
+        const int w_lo = window_start(a, valid, jf);
         const u64 in_m = __ballot(valid && a != NOLEAD && a >= w_lo && a < w_lo + WN);
         u64 C[WN];
 #pragma unroll
@@ -144,6 +157,71 @@ __device__ __forceinline__ void panel_wave(const u64 *__restrict__ rows, i64 R, 
         info->kk = kk;
         st->next_i0 = i0 + kk;
         if (c) atomicAdd(xor_count, c);
+    }
+}
+
+// ---- full-row panel (round 3): sparse rows lead at scattered words, and the 4-word window then ends a block after a row or two
+// (700 x 700 at density 0.003: 450 blocks instead of 11, 8.7x the dense time).  When the window would end the block early and the
+// rows are at most FULL_WC words long, the whole workgroup runs the reference loop on the 64 FULL rows in LDS (<= 128 KiB, the
+// sweep's table area): wavefront 0 finds the pivot of row j and the block rows that hold its column and keeps T, everybody XORs
+// row j into those rows.  Two barriers per pivot (~0.5 us) instead of ~0.25 us in registers, but the block never ends early.
+constexpr int FULL_WC = 256;
+__device__ __forceinline__ void panel_full(const u64 *__restrict__ rows, i64 R, i64 Wc, i64 i0, int a, u64 *__restrict__ m /* LDS [64][Wc] */,
+                                           u64 *__restrict__ s_bc /* LDS [4] */, SweepState *__restrict__ st, BlockInfo *__restrict__ info,
+                                           i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nt = blockDim.x;
+    const int W = (int)Wc;
+    const int n_valid = (int)(R - i0 < WK ? R - i0 : WK);
+    for (int x = threadIdx.x; x < n_valid * W; x += nt) m[x] = rows[i0 * Wc + x];
+    __syncthreads();
+    int pw = -1, pb = 0;                                            // wavefront 0, lane = block row
+    u64 my_mask = 0, tv = 1ULL << lane;
+    for (int j = 0; j < n_valid; ++j) {
+        if (wave == 0) {
+            int jw = -1, jb = 0;
+            if (__builtin_amdgcn_readlane(a, j) != NOLEAD) {        // rows that were zero when phase 0 looked stay zero: nothing touches them
+                for (int w0 = 0; w0 < W; w0 += 64) {
+                    const int w = w0 + lane;
+                    const u64 v = w < W ? m[j * W + w] : 0ULL;
+                    const u64 nz = __ballot(v != 0);
+                    if (nz) {
+                        const int l = __builtin_ctzll(nz);
+                        jw = w0 + l;
+                        jb = __builtin_ctzll(readlane64(v, l));
+                        break;
+                    }
+                }
+            }
+            u64 mk = 0;
+            if (jw >= 0) mk = __ballot(lane < n_valid && lane != j && ((m[lane * W + jw] >> jb) & 1ULL));
+            if (lane == j) { pw = jw; pb = jb; my_mask = mk; }
+            const u64 tj = readlane64(tv, j);
+            if ((mk >> lane) & 1ULL) tv ^= tj;
+            if (lane == 0) s_bc[0] = mk;
+        }
+        __syncthreads();
+        const u64 mk = s_bc[0];
+        // a wavefront per flagged row (wave-uniform test: unflagged rows cost nothing), lanes over the words
+        for (int r = wave; r < n_valid; r += nt / 64)
+            if ((mk >> r) & 1ULL)
+                for (int w = lane; w < W; w += 64) m[r * W + w] ^= m[j * W + w];
+        __syncthreads();
+    }
+    if (wave == 0) {
+        const bool mine = lane < n_valid;
+        info->pivw[lane] = mine ? pw : -1;
+        info->pivb[lane] = mine ? pb : 0;
+        info->mask[lane] = mine ? my_mask : 0ULL;
+        info->T[lane] = mine ? tv : 0ULL;
+        if (mine && pivots) pivots[i0 + lane] = pw < 0 ? -1 : (i64)pw * 64 + pb;
+        unsigned long long c = mine ? (unsigned long long)__popcll(my_mask) : 0ULL;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+        if (lane == 0) {
+            info->i0 = i0;
+            info->kk = n_valid;
+            st->next_i0 = i0 + n_valid;
+            if (c) atomicAdd(xor_count, c);
+        }
     }
 }
 
@@ -279,6 +357,7 @@ struct FusedSelect {
     u32 *ready;                                 // [64] flags: == epoch when the row's selector has been published
     u32 epoch;
     u32 *fail;                                  // a tile workgroup gave up waiting
+    int full_panel;                             // 1: the panel may switch to the full rows in LDS (panel_full)
 };
 template <int PHASE>
 __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64 R, i64 Wc, const BlockInfo *__restrict__ info,
@@ -328,12 +407,30 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
     }
     if (PHASE == 1) {
         if (k == 0) {
-            // ---- panel workgroup: one wavefront; the leading words were collected by phase 0 (reset for the next block) ----
+            // ---- panel workgroup; the leading words were collected by phase 0 (reset for the next block).  One wavefront on a 4-word
+            //      window — or, when the window would end the block early and the rows fit, the whole workgroup on the full rows ----
+            int a = -1;
+            if (wave == 0 && i0n + lane < R) a = lead[lane];
             if (wave == 0) {
-                int a = -1;
-                if (i0n + lane < R) { a = lead[lane]; lead[lane] = NOLEAD; }
-                panel_wave(rows, R, Wc, i0n, a, lane, st, info_next, pivots, xor_count);
+                bool full = false;
+                if (fs.full_panel && Wc <= FULL_WC && i0n < R) {
+                    const bool valid = a >= 0;
+                    const u64 fin_m = __ballot(valid && a != NOLEAD);
+                    if (fin_m != 0) {
+                        const int w_lo = window_start(a, valid, __builtin_ctzll(fin_m));
+                        const u64 bad = __ballot(valid && a != NOLEAD && !(a >= w_lo && a < w_lo + WN));   // rows that lead outside the window
+                        const int n_valid = __popcll(__ballot(valid));
+                        full = bad != 0 && __builtin_ctzll(bad) < (n_valid < 32 ? n_valid : 32);
+                    }
+                }
+                if (lane == 0) { s_ok = full ? 1 : 0; if (full) atomicAdd(fs.fail + 1, 1u); }
+                if (i0n + lane < R) lead[lane] = NOLEAD;
             }
+            __syncthreads();
+            if (s_ok) {
+                if (wave != 0) a = 0;
+                panel_full(rows, R, Wc, i0n, a, tab, s_sel, st, info_next, pivots, xor_count);
+            } else if (wave == 0) panel_wave(rows, R, Wc, i0n, a, lane, st, info_next, pivots, xor_count);
             return;
         }
         --k;
@@ -547,6 +644,7 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     FusedSelect fs;
     fs.sel = sel.as<u64>(); fs.snap = snap.as<u64>(); fs.rowcnt = rowcnt.as<u32>(); fs.ready = ready.as<u32>(); fs.epoch = 0;
     fs.fail = reinterpret_cast<u32 *>(count.p) + 2;
+    fs.full_panel = [] { const char *e = getenv("SYMGPU_GF2_FULL_PANEL"); return !(e && e[0] == '0'); }() ? 1 : 0;
     if (lookahead && m4r && (i64)m4_tiles * m4_chunks + 1 < ((i64)1 << 31)) {
         // Pipeline, three launches per block: select(b) -> phase 0: sweep of the rows of block b+1 + their leading words ->
         // phase 1: panel of block b+1 (-> the other info buffer) inside the sweep of all remaining rows.  The very first
@@ -625,6 +723,7 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     HIP_TRY(hipMemcpyAsync(hb, count.p, 16, hipMemcpyDeviceToHost, st));
     if (pivots_host) HIP_TRY(hipMemcpyAsync(pivots_host, piv.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (getenv("SYMGPU_GF2_DEBUG")) fprintf(stderr, "rref %lld x %lld words: full-row panels %u\n", (long long)R, (long long)Wc, (u32)(hb[1] >> 32));
     if ((u32)hb[1] != 0) {
         set_error("rref: a phase-0 workgroup timed out waiting for the selectors of its rows (SYMGPU_GF2_FUSED_SELECT=0 separates the launches)");
         return SYMGPU_E_HIP;

@@ -819,7 +819,8 @@ def test_rotation_chain_with_duplicates_and_tiny_terms(seed):
     assert_op_equal(R2.symp_matrix, R2.coeff_vec, er2, ec2, exact=False, tol=TOL)
 
 
-@pytest.mark.parametrize('R,C,dens', [(700, 700, 0.5), (700, 700, 0.003), (1500, 5000, 0.3), (300, 9000, 0.05), (129, 64, 0.5)])
+@pytest.mark.parametrize('R,C,dens', [(700, 700, 0.5), (700, 700, 0.003), (1500, 5000, 0.3), (300, 9000, 0.05), (129, 64, 0.5), (1500, 3000, 0.003),
+                                      (900, 16384, 0.001), (257, 16400, 0.002), (640, 2000, 0.01), (70, 130, 0.02)])
 def test_rref_fused_selector_launch_equals_separate(R, C, dens, monkeypatch):
     """Round 3: the selectors of a block are computed inside phase 0's launch (the tile workgroups wait for the 64 selectors of their
     rows, published by the first four workgroups of the grid).  Same reduced matrix, pivots and reference row-XOR count as with the
@@ -831,8 +832,13 @@ def test_rref_fused_selector_launch_equals_separate(R, C, dens, monkeypatch):
     monkeypatch.setenv('SYMGPU_GF2_FUSED_SELECT', '0')
     red2, cnt2, piv2 = kernels.rref(packed, want_pivots=True)
     monkeypatch.delenv('SYMGPU_GF2_FUSED_SELECT')
+    # the panel on the full rows in LDS (sparse rows of <= 256 words: the 4-word window would end the blocks after a row or two)
+    monkeypatch.setenv('SYMGPU_GF2_FULL_PANEL', '0')
+    red3, cnt3, piv3 = kernels.rref(packed, want_pivots=True)
+    monkeypatch.delenv('SYMGPU_GF2_FULL_PANEL')
     ered, ecnt = onp.rref_noswap(m, count_xors=True)
     assert np.array_equal(red1, red2) and cnt1 == cnt2 == ecnt and np.array_equal(piv1, piv2)
+    assert np.array_equal(red1, red3) and cnt3 == ecnt and np.array_equal(piv1, piv3)
     assert np.array_equal(packing.unpack_bits(red1, C), ered)
 
 
