@@ -86,6 +86,49 @@ __device__ __forceinline__ int window_start(int a, bool valid, int jf) {
     return lo > floor_w ? lo : floor_w;
 }
 
+// the reference loop on a window of WNT words per block row (registers of ONE wavefront, lane = block row).
+// Rows still to process, in order (genuinely zero rows have no pivot and are never modified: skipped).  ONE exit test per pivot:
+// the row's leading word lies outside the window, or the row cancelled to zero inside it -> it opens the next block (re-windowed).
+template <int WNT>
+__device__ __forceinline__ void panel_loop(const u64 *__restrict__ rows, i64 Wc, i64 i0, int lane, bool valid, int w_lo, u64 in_m, u64 todo,
+                                           int &kk, int &pw, int &pb, u64 &my_mask, u64 &tv) {
+    u64 C[WNT];
+#pragma unroll
+    for (int k = 0; k < WNT; ++k) C[k] = (valid && (i64)w_lo + k < Wc) ? rows[(i0 + lane) * Wc + w_lo + k] : 0ULL;
+    while (todo) {
+        const int j = __builtin_ctzll(todo);
+        u64 p[WNT];
+#pragma unroll
+        for (int k = 0; k < WNT; ++k) p[k] = readlane64(C[k], j);
+        if (!((in_m >> j) & 1ULL)) { kk = j; break; }
+        int k0 = 0, b;
+        u64 mk;
+        if (p[0] != 0) {                                            // common case: the pivot sits in the first window word
+            b = __builtin_ctzll(p[0]);
+            mk = __ballot((C[0] >> b) & 1ULL);
+        } else {
+            k0 = -1;
+#pragma unroll
+            for (int k = WNT - 1; k >= 1; --k) if (p[k] != 0) k0 = k;
+            if (k0 < 0) { kk = j; break; }
+            u64 pk = p[1], ck = C[1];
+#pragma unroll
+            for (int k = 2; k < WNT; ++k) if (k == k0) { pk = p[k]; ck = C[k]; }
+            b = __builtin_ctzll(pk);
+            mk = __ballot((ck >> b) & 1ULL);
+        }
+        mk &= ~(1ULL << j);
+        todo &= todo - 1;
+        if (lane == j) { pw = w_lo + k0; pb = b; my_mask = mk; }
+        const u64 tj = readlane64(tv, j);
+        if ((mk >> lane) & 1ULL) {
+#pragma unroll
+            for (int k = 0; k < WNT; ++k) C[k] ^= p[k];
+            tv ^= tj;
+        }
+    }
+}
+
 // the panel proper: ONE wavefront (lane = block row), `a` = this lane's leading word (lead[] semantics), block starts at i0
 __device__ __forceinline__ void panel_wave(const u64 *__restrict__ rows, i64 R, i64 Wc, i64 i0, int a, int lane, SweepState *__restrict__ st,
                                            BlockInfo *__restrict__ info, i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count) {
@@ -101,46 +144,15 @@ __device__ __forceinline__ void panel_wave(const u64 *__restrict__ rows, i64 R, 
     if (fin_m != 0) {
         const int jf = __builtin_ctzll(fin_m);
         const int w_lo = window_start(a, valid, jf);
-        const u64 in_m = __ballot(valid && a != NOLEAD && a >= w_lo && a < w_lo + WN);
-        u64 C[WN];
-#pragma unroll
-        for (int k = 0; k < WN; ++k) C[k] = (valid && (i64)w_lo + k < Wc) ? rows[(i0 + lane) * Wc + w_lo + k] : 0ULL;
-        // rows still to process, in order (genuinely zero rows have no pivot and are never modified: skipped).  ONE exit test
-        // per pivot: the row's leading word lies outside the window, or the row cancelled to zero inside it -> it opens the
-        // next block (re-windowed at its own leading word).
-        u64 todo = (n_valid >= 64 ? ~0ULL : ((1ULL << n_valid) - 1ULL)) & ~zero_m;
-        while (todo) {
-            const int j = __builtin_ctzll(todo);
-            u64 p[WN];
-#pragma unroll
-            for (int k = 0; k < WN; ++k) p[k] = readlane64(C[k], j);
-            if (!((in_m >> j) & 1ULL)) { kk = j; break; }
-            int k0 = 0, b;
-            u64 mk;
-            if (p[0] != 0) {                                        // common case: the pivot sits in the first window word
-                b = __builtin_ctzll(p[0]);
-                mk = __ballot((C[0] >> b) & 1ULL);
-            } else {
-                k0 = -1;
-#pragma unroll
-                for (int k = WN - 1; k >= 1; --k) if (p[k] != 0) k0 = k;
-                if (k0 < 0) { kk = j; break; }
-                u64 pk = p[1], ck = C[1];
-#pragma unroll
-                for (int k = 2; k < WN; ++k) if (k == k0) { pk = p[k]; ck = C[k]; }
-                b = __builtin_ctzll(pk);
-                mk = __ballot((ck >> b) & 1ULL);
-            }
-            mk &= ~(1ULL << j);
-            todo &= todo - 1;
-            if (lane == j) { pw = w_lo + k0; pb = b; my_mask = mk; }
-            const u64 tj = readlane64(tv, j);
-            if ((mk >> lane) & 1ULL) {
-#pragma unroll
-                for (int k = 0; k < WN; ++k) C[k] ^= p[k];
-                tv ^= tj;
-            }
-        }
+        // narrow window (round 3): when every row of the block leads inside the first TWO words — a dense matrix, whose 64 pivots
+        // are 64 consecutive columns — the panel keeps two words per row instead of four: 4 v_readlane + 4 v_xor less per pivot.
+        // A row that cancels to zero inside the two words ends the block (as it does with four), so the result is unchanged.
+        const bool narrow = __ballot(valid && a != NOLEAD && !(a >= w_lo && a < w_lo + 2)) == 0ULL;
+        const int wn = narrow ? 2 : WN;
+        const u64 in_m = __ballot(valid && a != NOLEAD && a >= w_lo && a < w_lo + wn);
+        const u64 todo0 = (n_valid >= 64 ? ~0ULL : ((1ULL << n_valid) - 1ULL)) & ~zero_m;
+        if (narrow) panel_loop<2>(rows, Wc, i0, lane, valid, w_lo, in_m, todo0, kk, pw, pb, my_mask, tv);
+        else panel_loop<WN>(rows, Wc, i0, lane, valid, w_lo, in_m, todo0, kk, pw, pb, my_mask, tv);
     }
     // publish: only rows < kk belong to the block
     const u64 low = (kk >= 64) ? ~0ULL : ((1ULL << kk) - 1ULL);
