@@ -475,40 +475,47 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
             for (int e = 0; e < 16; ++e) tab[(g * 16 + e) * M4_TW + lane] = t[e];
         }
     }
-    if (PHASE == 3 && kk != 0) {
-        // the selectors of the next block's rows come from blocks 0..3 of this launch: wait for their flags (bounded), then read them
-        if (wave == 0) {
-            const int nr = (int)(ne - nb);
-            bool ok = true;
-            for (u32 spins = 0;; ++spins) {
-                const u32 v = lane < nr ? __hip_atomic_load(&fs.ready[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : fs.epoch;
-                if (__ballot(v == fs.epoch) == ~0ULL) break;
-                if (spins >= (1u << 22)) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            s_sel[lane] = (ok && lane < nr) ? __hip_atomic_load(&fs.sel[nb + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
-            if (lane == 0) { s_ok = ok ? 1 : 0; if (!ok) atomicOr(fs.fail, 1u); }
-        }
-    }
-    __syncthreads();
-    if (PHASE == 3 && kk != 0 && !s_ok) return;                      // flagged: the call fails loudly
     // ---- stream the rows: M4_U per wave and step, software pipelined (the loads of step i+1 are in flight while step i
     //      does its table look-ups: a wave only runs a handful of steps, so nothing else would hide the load latency) ----
     const i64 shift = ne - nb;
     const i64 step = M4_U * (M4_NT / 64);
     i64 rn[M4_U];
     u64 xn[M4_U], sn[M4_U];
-    auto fetch = [&](i64 v0) {
+    auto fetch = [&](i64 v0, bool with_sel) {
 #pragma unroll
         for (int u = 0; u < M4_U; ++u) {
             const i64 v = v0 + u < v_hi ? v0 + u : (v0 < v_hi ? v0 : v_lo);   // tail: surplus slots repeat a valid row, never stored
             rn[u] = P0 ? nb + v : (v < nb ? v : v + shift);
-            sn[u] = kk != 0 ? (PHASE == 3 ? s_sel[rn[u] - nb] : sel[rn[u]]) : 0ULL;
+            if (with_sel) sn[u] = kk != 0 ? (PHASE == 3 ? s_sel[rn[u] - nb] : sel[rn[u]]) : 0ULL;
             xn[u] = rows[rn[u] * Wc + wl];
         }
     };
     i64 v0 = v_lo + M4_U * wave;
-    if (v0 < v_hi) fetch(v0);
+    if (PHASE == 3) {
+        // the rows themselves do not depend on the selectors: their loads are issued before the wait
+        if (v0 < v_hi) fetch(v0, false);
+        if (kk != 0) {
+            // the selectors of the next block's rows come from blocks 0..3 of this launch: wait for their flags (bounded), then read them
+            if (wave == 0) {
+                const int nr = (int)(ne - nb);
+                bool ok = true;
+                for (u32 spins = 0;; ++spins) {
+                    const u32 v = lane < nr ? __hip_atomic_load(&fs.ready[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : fs.epoch;
+                    if (__ballot(v == fs.epoch) == ~0ULL) break;
+                    if (spins >= (1u << 22)) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                s_sel[lane] = (ok && lane < nr) ? __hip_atomic_load(&fs.sel[nb + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+                if (lane == 0) { s_ok = ok ? 1 : 0; if (!ok) atomicOr(fs.fail, 1u); }
+            }
+        }
+    }
+    __syncthreads();
+    if (PHASE == 3 && kk != 0 && !s_ok) return;                      // flagged: the call fails loudly
+    if (PHASE == 3) {
+#pragma unroll
+        for (int u = 0; u < M4_U; ++u) sn[u] = (kk != 0 && v0 < v_hi) ? s_sel[rn[u] - nb] : 0ULL;
+    } else if (v0 < v_hi) fetch(v0, true);
     for (; v0 < v_hi; v0 += step) {
         i64 r[M4_U];
         u64 x[M4_U];
@@ -519,7 +526,7 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
             slo[u] = __builtin_amdgcn_readfirstlane((u32)sn[u]);
             shi[u] = __builtin_amdgcn_readfirstlane((u32)(sn[u] >> 32));
         }
-        if (v0 + step < v_hi) fetch(v0 + step);                      // uniform
+        if (v0 + step < v_hi) fetch(v0 + step, true);                // uniform
 #pragma unroll
         for (int u = 0; u < M4_U; ++u) {
             const bool mine = (u == 0 || v0 + u < v_hi);
