@@ -1,0 +1,50 @@
+# randomised cross-check of the cleanup paths (run on the GPU box): default (lazy singles + fused output stage) against
+# SYMGPU_CLEANUP_LAZY=0 / SYMGPU_EMIT_FUSED=0 and, for small cases, the C oracle; planted duplicates, cancellations, tiny coefficients
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from symmer_amd import kernels, packing
+from oracle import oracle_c as oc
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+rng = np.random.default_rng(seed)
+bad = 0
+t0 = time.time()
+def dyadic(k):
+    return (rng.integers(-8, 9, k) + 1j * rng.integers(-8, 9, k)) / 8.0
+for case in range(n_cases):
+    n = int(rng.choice([1, 2, 3, 5, 17, 64, 65, 130, 1000]))
+    N = int(rng.choice([1, 2, 7, 63, 64, 65, 300, 1500, 5000])); M = int(rng.choice([1, 3, 40, 64, 257, 900]))
+    if N < M: N, M = M, N
+    dens = float(rng.choice([0.02, 0.3, 0.5]))
+    A = rng.random((N, 2 * n)) < dens; B = rng.random((M, 2 * n)) < dens
+    if rng.random() < 0.5:                                   # planted duplicate rows
+        A[rng.integers(0, N, max(1, N // 3))] = A[rng.integers(0, N, max(1, N // 3))]
+    a, b = dyadic(N), dyadic(M)
+    a[rng.random(N) < 0.1] = 1e-17
+    Ap, Bp = packing.pack_rows(A), packing.pack_rows(B)
+    thr = [1e-15, 0.0, None][int(rng.integers(0, 3))]
+    kind = int(rng.integers(0, 3))
+    outs = []
+    for lazy, fused in (('1', '1'), ('0', '1'), ('1', '0'), ('0', '0')):
+        os.environ['SYMGPU_CLEANUP_LAZY'] = lazy; os.environ['SYMGPU_EMIT_FUSED'] = fused
+        if kind == 0: outs.append(kernels.mul_cleanup(Ap, a, Bp, b, True, thr))
+        elif kind == 1: outs.append(kernels.mul_cleanup(Ap, a, Ap, a, True, thr))
+        else: outs.append(kernels.cleanup(np.concatenate([Ap, Ap[: N // 2]]), np.concatenate([a, -a[: N // 2]]), thr))
+    ok = all(np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]) for o in outs[1:])
+    why = '' if ok else 'GPU paths differ'
+    if N * M <= 400000:
+        if kind == 0: ref = oc.mul(Ap, a, Bp, b, thr)
+        elif kind == 1: ref = oc.mul(Ap, a, Ap, a, thr)
+        else: ref = oc.cleanup(np.concatenate([Ap, Ap[: N // 2]]), np.concatenate([a, -a[: N // 2]]), thr)
+        # a squared operator sums twin-first (exact for dyadic coefficients only): rows and order exact, sums to rounding
+        same_rows = outs[0][0].shape == ref[0].shape and np.array_equal(outs[0][0], ref[0])
+        if kind == 1: same_c = same_rows and np.allclose(outs[0][1], ref[1], rtol=1e-12, atol=1e-30)
+        else: same_c = same_rows and np.array_equal(outs[0][1], ref[1])
+        if not (same_rows and same_c):
+            ok = False; why += f' oracle differs (rows {same_rows})'
+    if not ok:
+        bad += 1
+        print(f'MISMATCH case {case}: n={n} N={N} M={M} dens={dens} thr={thr} kind={kind}: {why}', flush=True)
+print(f'stress cleanup: {n_cases} cases, {bad} mismatches, {time.time()-t0:.1f} s')
+sys.exit(1 if bad else 0)
