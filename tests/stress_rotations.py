@@ -1,5 +1,5 @@
 # stress (not a test): random rotations, one-launch kernel against the multi-launch paths, bit for bit; runs of Clifford rotations,
-# register chain against the multi-launch forms.  python3 tools/stress_rotations.py [cases] [seed]
+# register chain against the multi-launch forms.  python3 tests/stress_rotations.py [cases] [seed]
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
