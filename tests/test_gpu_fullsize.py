@@ -72,6 +72,44 @@ def test_cfg3_square_with_cleanup_consistency():
     dA.free(); out.free()
 
 
+def test_cfg3_round3_cleanup_equals_round2_flow_full_size(monkeypatch):
+    """BASELINE cfg3 at full size (10^4 terms squared, 10^8 pairs -> 2.5e7 terms): the round-3 cleanup (terms that merge with nothing
+    decided in index order before the sort, fused output stage) against the round-2 flow (every term filed from the sorted order,
+    batched list + stream stage; SYMGPU_CLEANUP_LAZY=0, SYMGPU_EMIT_FUSED=0): the same rows in the same order with the same
+    coefficients, compared chunk by chunk over the whole result — and the same again for the general pair path
+    (SYMGPU_CLEANUP_NOSQUARE=1: 10^8 keys) on a 4,000-term operator."""
+    lib = _lib.lib()
+
+    def square(op):
+        h = ctypes.c_void_p()
+        _lib.check(lib.symgpu_mul_cleanup_dev(op.handle, op.handle, 1, 1e-15, 1, ctypes.byref(h)))
+        return DeviceOp(h)
+
+    def same(x, y):
+        assert x.n_terms == y.n_terms and x.n_terms > 0
+        wq = x.info()[1]
+        step = 1 << 20
+        a = DeviceOp.alloc(step, wq, with_coeff=True); b = DeviceOp.alloc(step, wq, with_coeff=True)
+        for o in range(0, x.n_terms, step):
+            c = min(step, x.n_terms - o)
+            _lib.check(lib.symgpu_op_copy_rows(a.handle, 0, x.handle, o, c)); a.set_rows(c)
+            _lib.check(lib.symgpu_op_copy_rows(b.handle, 0, y.handle, o, c)); b.set_rows(c)
+            ra, ca = a.download(); rb, cb = b.download()
+            assert np.array_equal(ra, rb) and np.array_equal(ca, cb), o
+        a.free(); b.free()
+
+    for N, nosquare in ((10000, False), (4000, True)):
+        A = DeviceOp.random(N, 1000, 0.3, seed=4242 + N)
+        if nosquare: monkeypatch.setenv('SYMGPU_CLEANUP_NOSQUARE', '1')
+        new = square(A)
+        monkeypatch.setenv('SYMGPU_CLEANUP_LAZY', '0'); monkeypatch.setenv('SYMGPU_EMIT_FUSED', '0')
+        old = square(A)
+        monkeypatch.delenv('SYMGPU_CLEANUP_LAZY'); monkeypatch.delenv('SYMGPU_EMIT_FUSED')
+        if nosquare: monkeypatch.delenv('SYMGPU_CLEANUP_NOSQUARE')
+        same(new, old)
+        new.free(); old.free(); A.free()
+
+
 def test_cfg2_rotation_roundtrip():
     """1,000 qubits, 10^5 terms: R(-t) R(t) P == P (rows as a set, coefficients 1e-12); Clifford pi/2 then 3pi/2 == P exactly."""
     rng = np.random.default_rng(1236)
