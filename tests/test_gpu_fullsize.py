@@ -154,6 +154,23 @@ def test_cfg4_symmetry_generators_full_size():
     assert np.all(mask)
 
 
+def test_cfg4_elimination_schedules_agree_full_size(monkeypatch):
+    """BASELINE cfg4's matrix size (4000 x 54000, dense) and a sparse one of the same shape: the round-3 schedule (selectors inside
+    phase 0's launch, two-word panel window, full-row panel for sparse rows) against the separate-launch / four-word / windowed
+    schedules and the no-lookahead path — reduced matrix, pivots and reference row-XOR count identical."""
+    rng = np.random.default_rng(77)
+    for dens in (0.3, 0.0005):
+        m = rng.random((4000, 54000)) < dens
+        packed = packing.pack_bits(m)
+        ref = kernels.rref(packed, want_pivots=True)
+        for env in ({'SYMGPU_GF2_FUSED_SELECT': '0'}, {'SYMGPU_GF2_FULL_PANEL': '0'}, {'SYMGPU_GF2_LOOKAHEAD': '0'}):
+            for k, v in env.items(): monkeypatch.setenv(k, v)
+            got = kernels.rref(packed, want_pivots=True)
+            for k in env: monkeypatch.delenv(k)
+            assert np.array_equal(ref[0], got[0]) and ref[1] == got[1] and np.array_equal(ref[2], got[2]), (dens, env)
+        assert ref[1] > 0
+
+
 def test_cfg5_adjacency_slice_full_width():
     """2,000 qubits, 200,000 terms: a 4096-row block of the adjacency matrix against all terms — symmetric on the square
     sub-block, True on the diagonal, exact vs the C oracle on a 64 x 8192 corner, and byte count == bit-packed popcount."""
