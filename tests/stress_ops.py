@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import test_gpu_fuzz as F
+import test_gpu_parity as P
 from symmer_amd import kernels, packing
 from oracle import oracle_c as oc
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
@@ -12,6 +13,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 bad = 0
 t0 = time.time()
 fuzzers = [f for name, f in inspect.getmembers(F, inspect.isfunction) if name.startswith('test_fuzz') and list(inspect.signature(f).parameters) == ['seed']]
+fuzzers.append(P.test_rotation_chain_with_duplicates_and_tiny_terms)      # perform_rotations: Clifford runs, mixed angles, duplicates, tiny terms
 for seed in range(first, first + count):
     for f in fuzzers:
         try:
