@@ -39,6 +39,7 @@ struct BlockInfo {
     int pivb[WK];
     u64 mask[WK];             // block rows (bit r < kk, r != j) holding pivot j's column at time j
     u64 T[WK];                // new_row_r = XOR_{i in T[r]} old_row_i
+    int w_next;               // the largest pivot word of the block: where the NEXT block's window most likely starts (-1: no guess)
 };
 
 struct SweepState {
@@ -91,10 +92,16 @@ __device__ __forceinline__ int window_start(int a, bool valid, int jf) {
 // the row's leading word lies outside the window, or the row cancelled to zero inside it -> it opens the next block (re-windowed).
 template <int WNT>
 __device__ __forceinline__ void panel_loop(const u64 *__restrict__ rows, i64 Wc, i64 i0, int lane, bool valid, int w_lo, u64 in_m, u64 todo,
-                                           int &kk, int &pw, int &pb, u64 &my_mask, u64 &tv) {
+                                           int &kk, int &pw, int &pb, u64 &my_mask, u64 &tv, const u64 *spec, int w_spec, int &w_max) {
+    // spec: the window words loaded speculatively at w_spec (the previous block's guess), beside the leads instead of behind them
     u64 C[WNT];
+    if (w_spec == w_lo) {
 #pragma unroll
-    for (int k = 0; k < WNT; ++k) C[k] = (valid && (i64)w_lo + k < Wc) ? rows[(i0 + lane) * Wc + w_lo + k] : 0ULL;
+        for (int k = 0; k < WNT; ++k) C[k] = spec[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < WNT; ++k) C[k] = (valid && (i64)w_lo + k < Wc) ? rows[(i0 + lane) * Wc + w_lo + k] : 0ULL;
+    }
     while (todo) {
         const int j = __builtin_ctzll(todo);
         u64 p[WNT];
@@ -120,6 +127,7 @@ __device__ __forceinline__ void panel_loop(const u64 *__restrict__ rows, i64 Wc,
         mk &= ~(1ULL << j);
         todo &= todo - 1;
         if (lane == j) { pw = w_lo + k0; pb = b; my_mask = mk; }
+        w_max = w_lo + k0 > w_max ? w_lo + k0 : w_max;
         const u64 tj = readlane64(tv, j);
         if ((mk >> lane) & 1ULL) {
 #pragma unroll
@@ -131,8 +139,12 @@ __device__ __forceinline__ void panel_loop(const u64 *__restrict__ rows, i64 Wc,
 
 // the panel proper: ONE wavefront (lane = block row), `a` = this lane's leading word (lead[] semantics), block starts at i0
 __device__ __forceinline__ void panel_wave(const u64 *__restrict__ rows, i64 R, i64 Wc, i64 i0, int a, int lane, SweepState *__restrict__ st,
-                                           BlockInfo *__restrict__ info, i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count) {
-    if (i0 >= R) { if (lane == 0) { info->i0 = i0; info->kk = 0; } return; }
+                                           BlockInfo *__restrict__ info, i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count,
+                                           const u64 *spec = nullptr, int w_spec = -1) {
+    if (i0 >= R) { if (lane == 0) { info->i0 = i0; info->kk = 0; info->w_next = -1; } return; }
+    int w_max = -1;
+    u64 no_spec[WN] = {0, 0, 0, 0};
+    if (!spec) { spec = no_spec; w_spec = -1; }
     const bool valid = a >= 0;
     const int n_valid = __popcll(__ballot(valid));                 // rows i0 .. i0+n_valid-1 exist
     const u64 zero_m = __ballot(valid && a == NOLEAD);
@@ -151,8 +163,8 @@ __device__ __forceinline__ void panel_wave(const u64 *__restrict__ rows, i64 R, 
         const int wn = narrow ? 2 : WN;
         const u64 in_m = __ballot(valid && a != NOLEAD && a >= w_lo && a < w_lo + wn);
         const u64 todo0 = (n_valid >= 64 ? ~0ULL : ((1ULL << n_valid) - 1ULL)) & ~zero_m;
-        if (narrow) panel_loop<2>(rows, Wc, i0, lane, valid, w_lo, in_m, todo0, kk, pw, pb, my_mask, tv);
-        else panel_loop<WN>(rows, Wc, i0, lane, valid, w_lo, in_m, todo0, kk, pw, pb, my_mask, tv);
+        if (narrow) panel_loop<2>(rows, Wc, i0, lane, valid, w_lo, in_m, todo0, kk, pw, pb, my_mask, tv, spec, w_spec, w_max);
+        else panel_loop<WN>(rows, Wc, i0, lane, valid, w_lo, in_m, todo0, kk, pw, pb, my_mask, tv, spec, w_spec, w_max);
     }
     // publish: only rows < kk belong to the block
     const u64 low = (kk >= 64) ? ~0ULL : ((1ULL << kk) - 1ULL);
@@ -167,6 +179,7 @@ __device__ __forceinline__ void panel_wave(const u64 *__restrict__ rows, i64 R, 
     if (lane == 0) {
         info->i0 = i0;
         info->kk = kk;
+        info->w_next = w_max;                                        // w_max is wave-uniform (scalar running maximum)
         st->next_i0 = i0 + kk;
         if (c) atomicAdd(xor_count, c);
     }
@@ -231,6 +244,7 @@ __device__ __forceinline__ void panel_full(const u64 *__restrict__ rows, i64 R, 
         if (lane == 0) {
             info->i0 = i0;
             info->kk = n_valid;
+            info->w_next = -1;
             st->next_i0 = i0 + n_valid;
             if (c) atomicAdd(xor_count, c);
         }
@@ -422,7 +436,15 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
             // ---- panel workgroup; the leading words were collected by phase 0 (reset for the next block).  One wavefront on a 4-word
             //      window — or, when the window would end the block early and the rows fit, the whole workgroup on the full rows ----
             int a = -1;
-            if (wave == 0 && i0n + lane < R) a = lead[lane];
+            u64 spec[WN] = {0, 0, 0, 0};
+            const int w_spec = info->w_next;                         // the block that was just panelled guessed this block's window
+            if (wave == 0 && i0n + lane < R) {
+                a = lead[lane];
+                if (w_spec >= 0) {                                   // the window words at the guess: loaded beside the leads, not behind them
+#pragma unroll
+                    for (int k = 0; k < WN; ++k) spec[k] = (i64)w_spec + k < Wc ? rows[(i0n + lane) * Wc + w_spec + k] : 0ULL;
+                }
+            }
             if (wave == 0) {
                 bool full = false;
                 if (fs.full_panel && Wc <= FULL_WC && i0n < R) {
@@ -442,7 +464,7 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
             if (s_ok) {
                 if (wave != 0) a = 0;
                 panel_full(rows, R, Wc, i0n, a, tab, s_sel, st, info_next, pivots, xor_count);
-            } else if (wave == 0) panel_wave(rows, R, Wc, i0n, a, lane, st, info_next, pivots, xor_count);
+            } else if (wave == 0) panel_wave(rows, R, Wc, i0n, a, lane, st, info_next, pivots, xor_count, spec, w_spec);
             return;
         }
         --k;
