@@ -380,7 +380,7 @@ struct FusedSelect {
     u64 *sel;                                   // writable view of the selectors
     u64 *snap;
     u32 *rowcnt;
-    u32 *ready;                                 // [64] flags: == epoch when the row's selector has been published
+    u64 *ready;                                 // [64][2] granules {epoch 32 | half of the row's selector 32}: the data is the flag
     u32 epoch;
     u32 *fail;                                  // a tile workgroup gave up waiting
     int full_panel;                             // 1: the panel may switch to the full rows in LDS (panel_full)
@@ -417,9 +417,8 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
                 const u64 g = select_row(rows, Wc, r, lane, i0, kk, pw, pb, mj, Tj, fs.rowcnt);
                 if (lane == 0) {
                     if (k < SEL_PRI) {
-                        __hip_atomic_store(&fs.sel[r], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __hip_atomic_store(&fs.ready[r - nb], fs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&fs.ready[2 * (r - nb)], ((u64)fs.epoch << 32) | (u32)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&fs.ready[2 * (r - nb) + 1], ((u64)fs.epoch << 32) | (u32)(g >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     } else fs.sel[r] = g;
                 }
             }
@@ -521,13 +520,16 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
             if (wave == 0) {
                 const int nr = (int)(ne - nb);
                 bool ok = true;
+                u64 g0 = 0, g1 = 0;
                 for (u32 spins = 0;; ++spins) {
-                    const u32 v = lane < nr ? __hip_atomic_load(&fs.ready[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : fs.epoch;
-                    if (__ballot(v == fs.epoch) == ~0ULL) break;
+                    const u64 tagged = (u64)fs.epoch << 32;
+                    g0 = lane < nr ? __hip_atomic_load(&fs.ready[2 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tagged;
+                    g1 = lane < nr ? __hip_atomic_load(&fs.ready[2 * lane + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tagged;
+                    if (__ballot((u32)(g0 >> 32) == fs.epoch && (u32)(g1 >> 32) == fs.epoch) == ~0ULL) break;
                     if (spins >= (1u << 22)) { ok = false; break; }
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                s_sel[lane] = (ok && lane < nr) ? __hip_atomic_load(&fs.sel[nb + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+                s_sel[lane] = (ok && lane < nr) ? (((u64)(u32)g1 << 32) | (u32)g0) : 0ULL;
                 if (lane == 0) { s_ok = ok ? 1 : 0; if (!ok) atomicOr(fs.fail, 1u); }
             }
         }
@@ -658,8 +660,8 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     SG_TRY(rowcnt.alloc((size_t)R * 4));
     HIP_TRY(hipMemsetAsync(rowcnt.p, 0, (size_t)R * 4, st));
     HIP_TRY(hipMemsetAsync(count.p, 0, 16, st));
-    SG_TRY(ready.alloc(WK * sizeof(u32)));
-    HIP_TRY(hipMemsetAsync(ready.p, 0, WK * sizeof(u32), st));
+    SG_TRY(ready.alloc(2 * WK * sizeof(u64)));
+    HIP_TRY(hipMemsetAsync(ready.p, 0, 2 * WK * sizeof(u64), st));
     HIP_TRY(hipMemsetAsync(state.p, 0, sizeof(SweepState), st));
     HIP_TRY(hipMemsetAsync(info.p, 0, 2 * sizeof(BlockInfo), st));   // {i0 = 0, kk = 0}: "nothing swept yet, next block starts at row 0"
     constexpr int SW_ROWS = 16;                                     // rows per sweep workgroup, held in VGPRs
@@ -683,7 +685,7 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     // SYMGPU_GF2_FUSED_SELECT=0: the selector launch on its own in front of phase 0 (three launches per block instead of two)
     const bool fused_select = [] { const char *e = getenv("SYMGPU_GF2_FUSED_SELECT"); return !(e && e[0] == '0'); }();
     FusedSelect fs;
-    fs.sel = sel.as<u64>(); fs.snap = snap.as<u64>(); fs.rowcnt = rowcnt.as<u32>(); fs.ready = ready.as<u32>(); fs.epoch = 0;
+    fs.sel = sel.as<u64>(); fs.snap = snap.as<u64>(); fs.rowcnt = rowcnt.as<u32>(); fs.ready = ready.as<u64>(); fs.epoch = 0;
     fs.fail = reinterpret_cast<u32 *>(count.p) + 2;
     fs.full_panel = [] { const char *e = getenv("SYMGPU_GF2_FULL_PANEL"); return !(e && e[0] == '0'); }() ? 1 : 0;
     if (lookahead && m4r && (i64)m4_tiles * m4_chunks + 1 < ((i64)1 << 31)) {
