@@ -271,7 +271,7 @@ __device__ __forceinline__ u64 select_row(const u64 *__restrict__ rows, i64 Wc, 
     // sequential-time selector t_j = f_j ^ parity(f & mask_j & (2^j-1)): |t| row-XORs in the reference loop
     const bool tj = bit ^ (bool)(__popcll(f & mj) & 1);
     const u64 t = __ballot(tj);
-    if (lane == 0) rowcnt[r] += (u32)__popcll(t);                     // one wave per row: no atomics, summed at the end
+    if (lane == 0) atomicAdd(&rowcnt[r], (u32)__popcll(t));           // fire and forget (a load + store pair puts a round trip in front of the selector)
     u64 x = bit ? Tj : 0ULL;                                          // g = XOR_{j in f} T_j
     for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off);
     return x;
