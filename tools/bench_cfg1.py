@@ -18,3 +18,12 @@ if os.environ.get('PROFILE'):
     pr = cProfile.Profile(); pr.enable()
     for _ in range(20): run()
     pr.disable(); pstats.Stats(pr).sort_stats('cumulative').print_stats(14)
+import ctypes
+from symmer_amd import _lib
+def counter(i):
+    v = ctypes.c_int64(0); _lib.check(_lib.lib().symgpu_debug_counter(i, ctypes.byref(v))); return v.value
+c0 = counter(3); h0 = counter(0)
+ts = []
+for _ in range(10):
+    t0 = time.perf_counter(); run(); ts.append((time.perf_counter() - t0) * 1e3)
+print('per call ms:', ' '.join(f'{x:.2f}' for x in ts), '| hipMalloc calls', counter(3) - c0, '| hash reseeds', counter(0) - h0, flush=True)
