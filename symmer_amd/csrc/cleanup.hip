@@ -486,9 +486,9 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
     const i64 n_chunks = (T + 63) / 64;
     const i64 gw = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
     u32 dirty = 0;
-    if (dirtybits) {
-        if (gw >= (n_chunks + 31) / 32) return;
-        dirty = __builtin_amdgcn_readfirstlane(dirtybits[gw]);
+    if (dirtybits) {                                                // eight chunks per wavefront: a quarter of a bitmap word
+        if (gw * 8 >= n_chunks) return;
+        dirty = (__builtin_amdgcn_readfirstlane(dirtybits[gw >> 2]) >> (8 * (int)(gw & 3))) & 0xFFu;
         if (dirty == 0) return;
     }
 
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
     i64 c0, c1;
     if (dirtybits) {
         if (dirty == 0) break;
-        c0 = gw * 32 + __builtin_ctz(dirty);
+        c0 = gw * 8 + __builtin_ctz(dirty);
         dirty &= dirty - 1;
         c1 = c0 + 1;
         open = false;
@@ -787,6 +787,12 @@ __global__ __launch_bounds__(256) void k_fixup_work(u64 *__restrict__ keys, u32 
     }
 }
 
+__global__ __launch_bounds__(256) void k_count_bits(const u32 *__restrict__ bits, i64 n_words, u32 *__restrict__ total) {
+    u32 c = 0;
+    for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (i64)gridDim.x * blockDim.x) c += (u32)__popc(bits[w]);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, c);
+}
 __global__ void k_popc_words(const u32 *__restrict__ bits, i64 n_words, u32 *__restrict__ counts) {
     for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (i64)gridDim.x * blockDim.x) counts[w] = (u32)__popc(bits[w]);
 }
@@ -1139,7 +1145,11 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
     i64 Tk = T;                                                         // number of keys that are sorted (T index space stays)
     Scratch keys, keys2, idx, idx2, fixlist, collision, hI, hO, pair_coeff, markbits, sum_of, zpart, zcount, patchbits, e_lo, e_hi, dirtybits, sort_hist;
     // singles decided in index order, only merged terms filed from the sorted order (k_mark_singles); SYMGPU_CLEANUP_LAZY=0: every term filed
-    const bool lazy = [] { const char *e = getenv("SYMGPU_CLEANUP_LAZY"); return !(e && e[0] == '0'); }();
+    // Default: products only.  A plain cleanup is what follows `A + B` or a rotation — inputs full of repeated rows, where every chunk
+    // holds merged terms and the extra passes buy nothing (10^6 terms of 1,000 qubits, 2.7 copies of every row: 0.89 ms lazy against
+    // 0.55 ms filed); SYMGPU_CLEANUP_LAZY=1 forces the lazy flow for plain cleanups too (tests), 0 switches it off everywhere.
+    const int lazy_env = [] { const char *e = getenv("SYMGPU_CLEANUP_LAZY"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const bool lazy = lazy_env == 1 || (lazy_env == -1 && pair);
     const size_t bitmap_bytes = (size_t)((T + 63) / 64) * 8;         // whole 64-bit words: k_mark_singles stores one per wavefront
     SG_TRY(keys.alloc((size_t)T * 8));
     SG_TRY(keys2.alloc((size_t)T * 8));
@@ -1170,7 +1180,11 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         const int want = (lg + 5 + 7) / 8 * 8;   // ~1-3 % of the keys then share a prefix with another key: cheap local fix-up
         if (want < 64) nb = want;
     }
+    bool lazy_final = false;
     for (int attempt = 0; attempt < 6 && !ok; ++attempt) {
+        // the lazy flow pays off on big key sets (its passes are fixed costs, the scatter it avoids only hurts at scale)
+        const bool lazy_a = lazy && (lazy_env == 1 || Tk >= ((i64)1 << 22));
+        lazy_final = lazy_a;
         SG_TRY(ensure_hash_tables(seed));
         const int hash_bits = packed ? 64 - L.F() : 64;       // a packed key carries 64 - F >= 30 hash bits
         const int nbits = nb > hash_bits ? hash_bits : nb;
@@ -1184,7 +1198,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 ka.squared = squared ? 1 : 0;
                 SG_TRY(mul_keys_dev(inner, Ni, outer, No, W / 2, inner_is_left, ka));
                 u32 *first_hist = nullptr;
-                if (lazy) {                                          // the keys are still in index order
+                if (lazy_a) {                                          // the keys are still in index order
                     const i64 n_tiles = (Tk + SORT_TILE - 1) / SORT_TILE;
                     SG_TRY(sort_hist.alloc((size_t)n_tiles * 256 * sizeof(u32)));
                     first_hist = sort_hist.as<u32>();
@@ -1211,7 +1225,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             hipLaunchKernelGGL(k_iota_keys_plain, dim3(grid_for(T)), dim3(256), 0, st, idx.as<u32>(), T);
             KERNEL_CHECK();
         }
-        if (!packed && lazy) {
+        if (!packed && lazy_a) {
             hipLaunchKernelGGL(k_mark_singles<false>, dim3((unsigned)((T + SORT_TILE - 1) / SORT_TILE)), dim3(256), 0, st, (const u64 *)nullptr, coeff, T, L, (const double *)nullptr,
                                (const double *)nullptr, 0, thr, use_thr, markbits.as<u64>(), (u64 *)nullptr, (u64 *)nullptr, (u32 *)nullptr, 0, (i64)0);
             KERNEL_CHECK();
@@ -1225,7 +1239,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             const i64 n_ch = (Tk + 63) / 64;
             SG_TRY(fixlist.alloc((size_t)n_ch * 8 + 16));                         // one word of flags per 64 positions
             u32 *dirty_fx = nullptr;
-            if (lazy) {                                                           // the chunks with merged terms are found in the same pass
+            if (lazy_a) {                                                           // the chunks with merged terms are found in the same pass
                 const i64 n_dw = (n_ch + 31) / 32;
                 SG_TRY(dirtybits.alloc((size_t)n_dw * 4 + 16));
                 HIP_TRY(hipMemsetAsync(dirtybits.p, 0, (size_t)n_dw * 4 + 16, st));
@@ -1260,9 +1274,23 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             const u64 *nul = nullptr;
             const double *nud = nullptr;
             const i64 space = (squared && packed) ? Tk : T;               // index space of markbits / sum_of
-            if (lazy) HIP_TRY(hipMemsetAsync(patchbits.p, 0, (size_t)((space + 63) / 64) * 8, st));
+            // Adaptive: when many chunks hold merged terms — an input full of repeated rows: the followers' bitmap atomics of the lazy
+            // flow then cost more than the heads' scatter it saves (10^8 pairs with ~5 copies of every row: 6.2 ms lazy against 4.5 ms
+            // filed) — every term is filed from the sorted order after all; k_mark_singles' pass was wasted (one count read-back).
+            bool lazy_now = lazy_a;
+            if (lazy_a && merges_found && lazy_env != 1) {
+                u32 *dcount = collision.as<u32>() + 3;
+                hipLaunchKernelGGL(k_count_bits, dim3(grid_for((n_chunks + 31) / 32)), dim3(256), 0, st, dirtybits.as<u32>(), (n_chunks + 31) / 32, dcount);
+                KERNEL_CHECK();
+                u32 h_dirty = 0;
+                HIP_TRY(hipMemcpyAsync(&h_dirty, dcount, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if ((i64)h_dirty * 8 > n_chunks) lazy_now = false;
+            }
+            lazy_final = lazy_now;
+            if (lazy_now) HIP_TRY(hipMemsetAsync(patchbits.p, 0, (size_t)((space + 63) / 64) * 8, st));
             else HIP_TRY(hipMemsetAsync(markbits.p, 0, (size_t)((space + 31) / 32) * 4, st));
-            u32 *patch_p = lazy ? patchbits.as<u32>() : nullptr;
+            u32 *patch_p = lazy_now ? patchbits.as<u32>() : nullptr;
             const u32 *zero_len_p = nullptr;
             const bool zero_on = [] { const char *e = getenv("SYMGPU_CLEANUP_ZEROSEG"); return !(e && e[0] == '0'); }();
             if (squared && packed && zero_on) {
@@ -1272,14 +1300,14 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 SG_TRY(zcount.alloc((size_t)n_zb * 4 + 16));
                 u32 *zl = zcount.as<u32>() + n_zb;
                 hipLaunchKernelGGL(k_zero_partial, dim3((unsigned)n_zb), dim3(256), 0, st, ks, Tk, hI.as<u64>(), hO.as<u64>(), L, inner, W, ci,
-                                   zpart.as<double>(), zcount.as<u32>(), collision.as<u32>(), (u32)Ni, lazy ? markbits.as<u32>() : (u32 *)nullptr);
+                                   zpart.as<double>(), zcount.as<u32>(), collision.as<u32>(), (u32)Ni, lazy_now ? markbits.as<u32>() : (u32 *)nullptr);
                 hipLaunchKernelGGL(k_zero_close, dim3(1), dim3(64), 0, st, ks, zpart.as<double>(), zcount.as<u32>(), n_zb, L, (u32)Ni, thr, use_thr,
                                    markbits.as<u32>(), sum_of.as<double>(), zl, patch_p);
                 zero_len_p = zl;
             }
             const u32 *dirty_p = nullptr;
             dim3 gsl = gs;
-            if (lazy) {
+            if (lazy_now) {
                 // the chunks that hold a member of a segment of more than one element; k_heads_sums then works on those only
                 const i64 n_dw = (n_chunks + 31) / 32;
                 if (!merges_found) {
@@ -1291,7 +1319,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 KERNEL_CHECK();
                 }
                 dirty_p = dirtybits.as<u32>();
-                gsl = dim3((unsigned)((n_dw + 3) / 4));
+                gsl = dim3((unsigned)(((n_chunks + 7) / 8 + 3) / 4));
             }
             if (packed)
                 hipLaunchKernelGGL((k_heads_sums<true, true>), gsl, dim3(256), 0, st, ks, (const u32 *)nullptr, Tk, nul, W, inner, (u32)Ni, outer, G, nud,
@@ -1320,7 +1348,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
     }
     const bool tri = squared && packed;
     LazyEmit lz;
-    if (lazy) {
+    if (lazy_final) {
         lz.mode = packed ? 1 : 2; lz.squared = tri ? 1 : 0;
         lz.patchbits = patchbits.as<u32>(); lz.e_lo = e_lo.as<u32>(); lz.e_hi = e_hi.as<u32>();
         lz.ci = ci; lz.co = co; lz.coeff = coeff;
