@@ -653,6 +653,18 @@ def extras(_lib, kernels, DeviceOp):
         except Exception as exc:                                  # noqa: BLE001 - reported in the JSON line
             ex[fn.__name__] = {'error': f'{type(exc).__name__}: {exc}'}
 
+    def wake_gpu():
+        # the CPU baseline leg leaves the GPU idle for tens of seconds: its clocks are down when the (latency bound, sub-millisecond)
+        # small cases below start — 50 ms of row-stream work first
+        Aw = DeviceOp.random(20000, 1000, 0.3, seed=5); Bw = DeviceOp.random(256, 1000, 0.3, seed=6)
+        ow = DeviceOp.alloc(256 * 20000, 16, with_coeff=True)
+        for _ in range(250):
+            _lib.check(lib.symgpu_mul_allpairs_dev(Aw.handle, Bw.handle, 0, 256, 1, ow.handle))
+        kernels.sync()
+        ow.free(); Aw.free(); Bw.free()
+    section(wake_gpu)
+    ex.pop('wake_gpu', None) if 'wake_gpu' in ex and 'error' not in ex['wake_gpu'] else None
+
     def cfg1_api_mul():
         # the reference's own CPU-runnable case through the drop-in API, host buffers in / host result out
         rng1 = np.random.default_rng(1235)
