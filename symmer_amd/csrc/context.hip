@@ -128,7 +128,6 @@ int dev_alloc(size_t bytes, void **ptr) {
             return SYMGPU_OK;
         }
     }
-    ++g_counters[3];
     hipError_t e = hipMalloc(ptr, c);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -136,12 +135,29 @@ int dev_alloc(size_t bytes, void **ptr) {
         e = hipMalloc(ptr, c);
         if (e != hipSuccess) {
             (void)hipGetLastError();
+            // Last resort: a parked block of a LARGER class.  dev_cache_release cannot return arena blocks whose chunk still holds
+            // a live block (one long-lived handle pins its 4 GiB chunk), so their memory would otherwise be lost to this request.
+            // The block keeps its own class and goes back to it when freed.
+            std::lock_guard<std::mutex> lk(g_alloc_mu);
+            auto it = g_free.lower_bound(c);
+            if (it != g_free.end()) {
+                const size_t cls = it->first;
+                *ptr = it->second;
+                g_free.erase(it);
+                g_cached_bytes -= cls;
+                int chunk = -1;
+                auto pc = g_parked_chunk.find(*ptr);
+                if (pc != g_parked_chunk.end()) { chunk = pc->second; g_parked_chunk.erase(pc); ++g_chunks[chunk].live; }
+                g_live[*ptr] = LiveBlock{cls, chunk};
+                return SYMGPU_OK;
+            }
             set_error("device allocation of %zu bytes failed: %s", c, hipGetErrorString(e));
             *ptr = nullptr;
             return SYMGPU_E_NOMEM;
         }
     }
     std::lock_guard<std::mutex> lk(g_alloc_mu);
+    ++g_counters[3];
     g_live[*ptr] = LiveBlock{c, -1};
     return SYMGPU_OK;
 }

@@ -1216,6 +1216,34 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
     return SYMGPU_OK;
 }
 
+// The operator 0 * I (one identity row, coefficient 0): what the reference's cleanup() makes of an operator without terms (base.py:631-632)
+static int zero_identity_op(int Wq, symgpu_op_t *out) {
+    symgpu_op_t z = nullptr;
+    SG_TRY(symgpu_op_alloc(1, Wq, 1, &z));
+    hipStream_t st = ctx().stream;
+    hipError_t e = hipMemsetAsync(z->rows, 0, (size_t)2 * Wq * 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(z->coeff, 0, 16, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { symgpu_op_free(z); return hip_fail(e, "zero_identity_op", __FILE__, __LINE__); }
+    z->T = 1;
+    *out = z;
+    return SYMGPU_OK;
+}
+
+// does any row of `op` commute with the row q (host)?  Only asked when a non-Clifford rotation has left no term at all.
+static int any_row_commutes(symgpu_op_t op, const u64 *q_host, bool *any) {
+    symgpu_op_t q = nullptr;
+    SG_TRY(symgpu_op_upload(q_host, nullptr, 1, op->Wq, &q));
+    Scratch flags;
+    int rc = flags.alloc((size_t)op->T);
+    if (rc == SYMGPU_OK) rc = symgpu_commutes_dev(op, 0, op->T, q, flags.as<uint8_t>());
+    uint64_t sum = 0;
+    if (rc == SYMGPU_OK) rc = symgpu_dev_checksum_u8(flags.as<uint8_t>(), op->T, &sum);
+    symgpu_op_free(q);
+    *any = sum != 0;
+    return rc;
+}
+
 int symgpu_perform_rotations_dev(symgpu_op_t in, const uint64_t *q_rows_host, const double *cos_t, const double *sin_t, const int *ks_host, int64_t K,
                                  double thr, int clean, symgpu_op_t *out, uint8_t *acted, int64_t *n_done, int *clean_out) {
     SG_TRY(require_ctx());
@@ -1227,7 +1255,18 @@ int symgpu_perform_rotations_dev(symgpu_op_t in, const uint64_t *q_rows_host, co
     i64 step = 0;
     int rc = SYMGPU_OK;
     while (step < K && rc == SYMGPU_OK) {
-        if (clean && cur->T > 0 && cur->T <= ((i64)1 << 22) && ks_host[step] >= 0) {
+        if (cur->T == 0) {
+            // every rotation is the identity on an operator without terms (np.all of an empty mask, base.py:1130-1133) and the
+            // cleanup() that follows it returns 0 * I (base.py:631-632); the next step's cleanup() drops that term again
+            symgpu_op_t z = nullptr;
+            rc = zero_identity_op(in->Wq, &z);
+            if (rc != SYMGPU_OK) break;
+            replace(z);
+            clean = 0;
+            ++step;
+            continue;
+        }
+        if (clean && cur->T <= ((i64)1 << 22) && ks_host[step] >= 0) {
             // a run of Clifford rotations of a clean operator: no step drops or merges anything, so the reference's per-step cleanup()
             // is the identity and the whole run goes to the chain entry point
             i64 e = step;
@@ -1239,19 +1278,42 @@ int symgpu_perform_rotations_dev(symgpu_op_t in, const uint64_t *q_rows_host, co
             step = e;
             continue;
         }
-        if (cur->T > 0) {
-            symgpu_op_t res = nullptr;
-            int allc = 1;
-            rc = symgpu_rotate_single_dev(cur, q_rows_host + step * W, cos_t[step], sin_t[step], ks_host[step], thr, &res, &allc);
-            if (rc != SYMGPU_OK) break;
-            if (!allc) { if (acted) acted[step] = 1; replace(res); }
-            else if (res) symgpu_op_free(res);
+        symgpu_op_t res = nullptr;
+        int allc = 1;
+        rc = symgpu_rotate_single_dev(cur, q_rows_host + step * W, cos_t[step], sin_t[step], ks_host[step], thr, &res, &allc);
+        if (rc != SYMGPU_OK) break;
+        if (!allc && res && res->T == 0) {
+            // The rotation itself has left no term.  Clifford: the rows are vstack([cleaned product, commuting rows]) = none, and the
+            // cleanup() after it gives 0 * I.  Non-Clifford: the result is `commute_self + anticom_part` (base.py:1159-1161), an
+            // append + cleanup that yields 0 * I when BOTH parts hold no row (then the loop's cleanup() drops its term: no terms) and
+            // an operator without terms when commuting rows cancelled each other (then the loop's cleanup() gives 0 * I).
+            bool zero_identity = true;
+            if (ks_host[step] < 0) {
+                bool any = false;
+                rc = any_row_commutes(cur, q_rows_host + step * W, &any);
+                if (rc != SYMGPU_OK) { symgpu_op_free(res); break; }
+                zero_identity = any;
+            }
+            if (acted) acted[step] = 1;
+            if (zero_identity) {
+                symgpu_op_free(res);
+                res = nullptr;
+                rc = zero_identity_op(in->Wq, &res);
+                if (rc != SYMGPU_OK) break;
+                clean = 0;
+            } else {
+                clean = 1;                                          // no terms, and the cleanup() of this step has been applied
+            }
+            replace(res);
+            ++step;
+            continue;
         }
+        if (!allc) { if (acted) acted[step] = 1; replace(res); }
+        else if (res) symgpu_op_free(res);
         ++step;
-        if (cur->T == 0) break;                                     // the caller reproduces the reference's 0 * I alternation (base.py:631-632)
         if (!clean) {
             symgpu_op_t cleaned = nullptr;
-            rc = symgpu_cleanup_dev(cur, thr, 1, &cleaned);
+            rc = symgpu_cleanup_dev(cur, thr, 1, &cleaned);          // may leave no term (0 * I, or X + (-X) after an even multiple of pi/2)
             if (rc != SYMGPU_OK) break;
             replace(cleaned);
             clean = 1;
@@ -1334,11 +1396,23 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
         static const bool lds_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_clifford_chain_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                          128 * 1024) == hipSuccess;
         const bool reg_chain = clifford_chain_registers_applicable(T, Wq) && !getenv("SYMGPU_CHAIN_LOCAL_T");
+        // the register chain; if its one-launch sort timed out at a barrier the rows in `a`/`b` are garbage: restore `a` from the
+        // untouched input and run once more (the sort form is off by then, so the second run takes the multi-launch radix sort)
+        auto run_reg_chain = [&]() -> int {
+            int r = clifford_chain_registers(a, b, T, qs.as<u64>(), ks_host, K, &in_b);
+            if (r != CHAIN_RETRY) return r;
+            hipError_t e2 = hipMemcpyAsync(a->rows, in->rows, (size_t)T * W * 8, hipMemcpyDeviceToDevice, st);
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(a->coeff, in->coeff, (size_t)T * 16, hipMemcpyDeviceToDevice, st);
+            if (e2 != hipSuccess) return hip_fail(e2, "rotate_clifford_chain_dev: restore", __FILE__, __LINE__);
+            r = clifford_chain_registers(a, b, T, qs.as<u64>(), ks_host, K, &in_b);
+            if (r == CHAIN_RETRY) { set_error("rotate_clifford_chain: the one-launch sort timed out twice"); return SYMGPU_E_HIP; }
+            return r;
+        };
         if (e == hipSuccess && reg_chain) {
             // the whole run with the rows in registers and ONE sort of the accumulated partition bits per 40 rotations (rotate_chain.hip):
             // faster than every other form at every size (1 term: 0.5 us per rotation against 1.6 of the LDS-resident kernel, 128 terms:
             // 1.2 against 3.7, 10^5 terms: 5.3 against 22.9 of the two-launch form)
-            rc = clifford_chain_registers(a, b, T, qs.as<u64>(), ks_host, K, &in_b);
+            rc = run_reg_chain();
             if (rc != SYMGPU_OK) { symgpu_op_free(a); symgpu_op_free(b); return rc; }
         } else if (e == hipSuccess && lds_on && lds_attr && T <= local_t && T <= CHAIN_LDS_T && W <= 128 && lds_rows <= 128 * 1024) {
             // small operator, resident in LDS for the whole run
@@ -1353,7 +1427,7 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
             if (e == hipSuccess) e = hipMemcpyAsync(&in_b, which.p, 4, hipMemcpyDeviceToHost, st);
         } else if (e == hipSuccess && clifford_chain_registers_applicable(T, Wq)) {
             // (SYMGPU_CHAIN_LOCAL_T set and T above it: the tests' way to the register chain next to the single-workgroup kernels)
-            rc = clifford_chain_registers(a, b, T, qs.as<u64>(), ks_host, K, &in_b);
+            rc = run_reg_chain();
             if (rc != SYMGPU_OK) { symgpu_op_free(a); symgpu_op_free(b); return rc; }
         } else if (e == hipSuccess) {
             // large operator: the per-rotation kernels of the Clifford fast path, enqueued back to back — T is constant for a

@@ -257,10 +257,10 @@ int clifford_chain_registers(symgpu_op_t a, symgpu_op_t b, i64 T, const u64 *qs_
     HIP_TRY(hipStreamSynchronize(st));                                         // the scratch buffers go back to the allocator on return
     bool timed_out = false;
     SG_TRY(radix_sort_coop_check(&timed_out));
-    if (timed_out) {
-        set_error("rotate_clifford_chain: the one-launch sort gave up at a barrier (its workgroups were not co-resident); the form is now off, call again");
-        return SYMGPU_E_HIP;
-    }
+    // the one-launch sort gave up at a barrier (its workgroups were not co-resident, e.g. a shared GPU): radix_sort_coop_check has
+    // switched the form off for the process; the caller restores `a` from the untouched input and runs the chain again on the
+    // multi-launch sort
+    if (timed_out) return CHAIN_RETRY;
     return SYMGPU_OK;
 }
 

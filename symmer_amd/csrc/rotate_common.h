@@ -62,6 +62,7 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
                         int *all_commute, int *done);
 
 // rotate_chain.hip: a run of Clifford rotations of a clean operator with the rows in registers; *in_b: the result is in `b`
+constexpr int CHAIN_RETRY = 1;        // clifford_chain_registers: the one-launch sort timed out, buffers invalid, run again
 bool clifford_chain_registers_applicable(i64 T, int Wq);
 int clifford_chain_registers(symgpu_op_t a, symgpu_op_t b, i64 T, const u64 *qs_dev, const int *ks_host, i64 K, int *in_b);
 int rotate_resident_trace(u64 *out, int max_wgs, int *n_wgs);   // phase stamps of the last traced launch (SYMGPU_RES_TRACE=1)

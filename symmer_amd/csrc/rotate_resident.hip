@@ -824,7 +824,10 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     if (hc.dup != 0) {                                                             // verification failed (2), timed out (3), or no report at all (1)
         symgpu_op_free(res);
         ++g_counters[2];
-        if (hc.dup != 2) { c.res_disabled = true; c.res_epoch = 0; c.res_dirty = true; }   // time-out: arrival counts, table and notes are in an unknown state
+        if (hc.dup != 2) { c.res_disabled = true; c.res_epoch = 0; }               // time-out: arrival counts are in an unknown state
+        // code 2 too: every owner zeroes its slot and note in phase B, but that relies on every workgroup getting there; one memset on a
+        // path that is about to take the multi-launch kernels anyway makes the next launch independent of it
+        c.res_dirty = true;
         return SYMGPU_OK;
     }
     *done = 1;

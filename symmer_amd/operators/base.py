@@ -483,6 +483,10 @@ class PauliwordOp:
             res.free()
         finally:
             op.free()
+        if rows.shape[0] == 0 and kernels.rotation_args(angle, threshold)[2] < 0 and not np.any(self.commutes_termwise(Pword)):
+            # non-Clifford and nothing left: the reference returns `commute_self + anticom_part` (base.py:1159-1161), and the sum of
+            # two operators without terms is 0 * I (append, then cleanup(): base.py:631-632)
+            return PauliwordOp(np.zeros((1, 2 * self.n_qubits), dtype=bool), [0])
         return PauliwordOp._from_packed(rows, self.n_qubits, coeff)
 
     def perform_rotations(self, rotations: List[Tuple["PauliwordOp", float]]) -> "PauliwordOp":
@@ -525,26 +529,21 @@ class PauliwordOp:
         # strict threshold).  So the device cleanup runs until the operator is known to be in that state — i.e. once, after
         # the first rotation of a user-supplied operator — and is skipped for the rest of the chain; a run of Clifford rotations
         # of a clean operator is one call of the chain entry point (rows in registers, csrc/rotate_chain.hip).
+        # An operator without terms and 0 * I alternate under the reference's cleanup() (base.py:631-632, utils.py:275-278); the library
+        # call follows that state machine itself, including WHY an operator is empty (emptied by a rotation: cleanup() gives 0 * I;
+        # emptied by the cleanup: it stays without terms), so nothing is patched up here.
         clean = False
         try:
             step = 0
             while step < K:
-                if dev.n_terms > 0:
-                    res, n_done, acted, clean = kernels.perform_rotations_dev(dev, q_rows[step:], cos_t[step:], sin_t[step:], ks[step:], clean)
-                    for r in np.flatnonzero(acted[:n_done]):
-                        _warn_large_angle(angles[step + int(r)], 1e-18)
-                    if res is not None:
-                        dev.free()
-                        dev = res
-                    step += n_done
-                else:
-                    step += 1
-                if dev.n_terms == 0:
-                    # an operator without terms becomes 0*I under cleanup(), and 0*I loses its only term again under the
-                    # next one (base.py:631-632): the reference alternates between the two states
+                res, n_done, acted, clean = kernels.perform_rotations_dev(dev, q_rows[step:], cos_t[step:], sin_t[step:], ks[step:], clean)
+                for r in np.flatnonzero(acted[:n_done]):
+                    _warn_large_angle(angles[step + int(r)], 1e-18)
+                if res is not None:
                     dev.free()
-                    dev = kernels.DeviceOp.upload(np.zeros((1, 2 * wq), dtype='<u8'), np.zeros(1, dtype=complex))
-                    clean = False
+                    dev = res
+                assert n_done > 0, 'symgpu_perform_rotations_dev made no progress'
+                step += n_done
             rows, coeff = dev.download()
         finally:
             dev.free()

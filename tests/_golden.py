@@ -29,6 +29,17 @@ def known_single_qubit():
         return json.load(f)
 
 
+def rotate_empty_cases():
+    """tests/golden/rotate_empty.json (oracle/tools/gen_golden_rotate_empty.py): rotations that lose every term / start empty."""
+    with open(os.path.join(GOLDEN, 'rotate_empty.json')) as f:
+        doc = json.load(f)
+    n2 = 2 * int(doc['n_qubits'])
+    mat = lambda rows: np.array([[ch == '1' for ch in r] for r in rows], dtype=bool).reshape(-1, n2)
+    vec = lambda v: np.array([complex(re, im) for re, im in v], dtype=complex)
+    return [dict(kind=c['kind'], in_symp=mat(c['in_symp']), in_coeff=vec(c['in_coeff']), q=mat(c['q']), angles=c['angles'],
+                 out_symp=mat(c['out_symp']), out_coeff=vec(c['out_coeff']), same_object=c['same_object']) for c in doc['cases']]
+
+
 def as_bool(a):
     return np.asarray(a).astype(bool)
 

@@ -10,7 +10,7 @@ from symmer_amd.operators import (symplectic_cleanup, _rref_binary, rref_binary,
                                   mul_symplectic)
 from oracle import oracle_np as onp
 from oracle import oracle_c as oc
-from _golden import family, known, known_single_qubit, as_bool, unpackbits_matrix, assert_op_equal
+from _golden import family, known, known_single_qubit, as_bool, unpackbits_matrix, assert_op_equal, rotate_empty_cases
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-12
@@ -136,6 +136,21 @@ def test_rotate_duplicate_rows_and_threshold_golden(case, general, monkeypatch):
     clifford = abs(round(2 * ang / np.pi) - 2 * ang / np.pi) <= thr
     assert_op_equal(R.symp_matrix, R.coeff_vec, case['out_symp'], case['out_coeff'], exact=clifford, tol=TOL)
     assert (R is P) == bool(case['same_object'])
+
+
+def test_rotations_that_lose_every_term_golden():
+    """Reference outputs for rotations of operators that lose every term, have none, or are 0 * I: which of the two states a step
+    of perform_rotations ends in depends on where the terms were lost (rotation: cleanup() gives 0 * I; the loop's own cleanup:
+    no terms; non-Clifford ``commute_self + anticom_part``: base.py:1159-1161) — base.py:631-632, utils.py:275-278.  K = 1 .. 4."""
+    for c in rotate_empty_cases():
+        P = PauliwordOp(c['in_symp'], c['in_coeff'])
+        if c['kind'] == 'single':
+            R = P._rotate_by_single_Pword(PauliwordOp(c['q'][:1], [1]), c['angles'][0])
+            assert (R is P) == c['same_object'], c
+        else:
+            R = P.perform_rotations([(PauliwordOp(q.reshape(1, -1), [1]), a) for q, a in zip(c['q'], c['angles'])])
+        assert R.symp_matrix.shape == c['out_symp'].shape and np.array_equal(R.symp_matrix, c['out_symp']), c
+        assert np.allclose(R.coeff_vec, c['out_coeff'], rtol=0, atol=1e-15), c
 
 
 def test_rotation_chain_from_operator_with_duplicates():

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 from oracle import oracle_np as onp
 from oracle import oracle_c as oc
-from _golden import family, known, known_single_qubit, as_bool, unpackbits_matrix, assert_op_equal
+from _golden import family, known, known_single_qubit, as_bool, unpackbits_matrix, assert_op_equal, rotate_empty_cases
 
 
 def _n(symp):
@@ -142,3 +142,16 @@ def test_jordan_independence_and_reindex_golden(case):
         keys, vals = case['keys'].tolist(), case['vals'].tolist()
         old, new = (sorted(vals), vals) if int(case['as_list']) else (keys, vals)
         assert np.array_equal(onp.reindex(case['symp'].astype(bool), old, new), case['out'].astype(bool))
+
+
+def test_rotations_that_lose_every_term():
+    """The 0 * I / no-terms alternation of the reference's cleanup() under rotations (base.py:631-632, utils.py:275-278, :1159-1161)."""
+    cases = rotate_empty_cases()
+    assert len(cases) > 1000
+    for c in cases:
+        if c['kind'] == 'single':
+            rows, coeff = onp.rotate_by_single_pword(c['in_symp'], c['in_coeff'], c['q'][0], c['angles'][0])
+        else:
+            rows, coeff = onp.perform_rotations(c['in_symp'], c['in_coeff'], list(zip(c['q'], c['angles'])))
+        assert rows.shape == c['out_symp'].shape and np.array_equal(rows, c['out_symp']), c
+        assert np.allclose(coeff, c['out_coeff'], rtol=0, atol=1e-15), c
