@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void k_zero_partial(const u64 *__restrict__ ke
     }
     double re = 0.0, im = 0.0;
     u32 n = 0;
-    bool mism = false;
+    bool mism = false, offdiag = false;
     for (int j = 0; j < ZB / 256; ++j) {
         const i64 p = base + threadIdx.x + 256 * j;
         if (p >= Tk) break;
@@ -419,6 +419,7 @@ __global__ __launch_bounds__(256) void k_zero_partial(const u64 *__restrict__ ke
         if (i != o) {
             if (e & 1) { cr = 0.0; cim = 0.0; } else { cr = __dadd_rn(cr, cr); cim = __dadd_rn(cim, cim); }
             for (int w = 0; w < W; ++w) mism |= rows[(i64)i * W + w] != rows[(i64)o * W + w];      // identity row <=> equal factors
+            offdiag = true;
         }
         re = __dadd_rn(re, cr);
         im = __dadd_rn(im, cim);
@@ -430,6 +431,7 @@ __global__ __launch_bounds__(256) void k_zero_partial(const u64 *__restrict__ ke
     }
     s_re[threadIdx.x] = re; s_im[threadIdx.x] = im; s_n[threadIdx.x] = n;
     if (mism) atomicOr(collision, 1u);
+    if (offdiag) atomicOr(collision + 2, 1u);                          // a member that is not a diagonal pair: P holds duplicate rows
     __syncthreads();
     if (threadIdx.x == 0) {
         double r = 0.0, q = 0.0;
@@ -438,10 +440,46 @@ __global__ __launch_bounds__(256) void k_zero_partial(const u64 *__restrict__ ke
         part[2 * blockIdx.x] = r; part[2 * blockIdx.x + 1] = q; part_n[blockIdx.x] = c;
     }
 }
+// The identity coefficient of P * P exactly as the reference forms it when P has no duplicate rows: the N diagonal pairs are then the
+// only members of the identity segment, and np.add.at adds their coefficients c_i * c_i (the phase exponent of P_i * P_i is 0) to
+// 0.0 one after the other in index order (utils.py:273-274).  A sequential sum is sequential: ONE wavefront, 64 products per step
+// staged in LDS, lane 0 adds them in order (two independent chains, re and im).  ~12 cycles per term: 50 us at N = 10,000 — on the
+// side stream next to the key generation and the sort of the same call, which take milliseconds.
+__global__ __launch_bounds__(64) void k_diag_seq_sum(const double *__restrict__ cf, u32 N, double *__restrict__ out) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    __shared__ f64x2 s_p[2][64];
+    const int lane = threadIdx.x;
+    double re = 0.0, im = 0.0;
+    int buf = 0;
+    for (u32 base = 0; base < N; base += 64, buf ^= 1) {
+        const u32 i = base + lane;
+        if (i < N) {
+            const f64x2 c = reinterpret_cast<const f64x2 *>(cf)[i];
+            double pr, pi;
+            pair_coefficient(c.x, c.y, c.x, c.y, 0, pr, pi);
+            s_p[buf][lane] = f64x2{pr, pi};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0) {
+            const u32 m = N - base < 64u ? N - base : 64u;
+            if (m == 64u) {
+#pragma unroll
+                for (int k = 0; k < 64; ++k) { const f64x2 p = s_p[buf][k]; re = __dadd_rn(re, p.x); im = __dadd_rn(im, p.y); }
+            } else {
+                for (u32 k = 0; k < m; ++k) { const f64x2 p = s_p[buf][k]; re = __dadd_rn(re, p.x); im = __dadd_rn(im, p.y); }
+            }
+        }
+    }
+    if (lane == 0) { out[0] = re; out[1] = im; }
+}
+
 // blocks in order; files the identity term under the slot of the segment's first element and tells k_heads_sums where to start
 __global__ void k_zero_close(const u64 *__restrict__ keys, const double *__restrict__ part, const u32 *__restrict__ part_n, i64 n_blocks,
                              PackedLayout L, u32 Ni, double thr, int use_thr, u32 *__restrict__ markbits, double *__restrict__ sum_of,
-                             u32 *__restrict__ zero_len, u32 *__restrict__ patchbits) {
+                             u32 *__restrict__ zero_len, u32 *__restrict__ patchbits, const double *__restrict__ diag_seq,
+                             const u32 *__restrict__ offdiag) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double re = 0.0, im = 0.0;
     u64 len = 0;
@@ -452,6 +490,8 @@ __global__ void k_zero_close(const u64 *__restrict__ keys, const double *__restr
         len += c;
         if (c < (u32)ZB) break;
     }
+    // exactly the N diagonal pairs: the reference's sequential sum (k_diag_seq_sum) instead of the blocked one
+    if (diag_seq && len == (u64)Ni && *offdiag == 0u) { re = diag_seq[0]; im = diag_seq[1]; }
     *zero_len = (u32)len;
     if (len == 0) return;
     if (use_thr && !(hypot(re, im) > thr)) return;
@@ -1180,6 +1220,26 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         const int want = (lg + 5 + 7) / 8 * 8;   // ~1-3 % of the keys then share a prefix with another key: cheap local fix-up
         if (want < 64) nb = want;
     }
+    // P * P: the identity coefficient in the reference's own (sequential) order, see k_diag_seq_sum.  Large operators: on the side stream,
+    // joined just before k_zero_close reads it; small ones inline (two event operations cost more than the kernel).
+    Scratch diag_seq;
+    bool diag_side = false;
+    struct JoinSide {                                                  // whatever way the function is left: the main stream is ordered behind the side
+        bool &pending;                                                 // stream's kernel before its 16-byte result buffer goes back to the allocator
+        ~JoinSide() { if (pending) (void)hipStreamWaitEvent(ctx().stream, ctx().ev_join, 0); }
+    } join_side{diag_side};
+    if (squared) {
+        Context &c = ctx();
+        SG_TRY(diag_seq.alloc(16));
+        diag_side = Ni > 2048;
+        if (diag_side) {
+            HIP_TRY(hipEventRecord(c.ev_fork, st));
+            HIP_TRY(hipStreamWaitEvent(c.stream2, c.ev_fork, 0));
+        }
+        hipLaunchKernelGGL(k_diag_seq_sum, dim3(1), dim3(64), 0, diag_side ? c.stream2 : st, ci, (u32)Ni, diag_seq.as<double>());
+        KERNEL_CHECK();
+        if (diag_side) HIP_TRY(hipEventRecord(c.ev_join, c.stream2));
+    }
     bool lazy_final = false;
     for (int attempt = 0; attempt < 6 && !ok; ++attempt) {
         // the lazy flow pays off on big key sets (its passes are fixed costs, the scatter it avoids only hurts at scale)
@@ -1301,8 +1361,9 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 u32 *zl = zcount.as<u32>() + n_zb;
                 hipLaunchKernelGGL(k_zero_partial, dim3((unsigned)n_zb), dim3(256), 0, st, ks, Tk, hI.as<u64>(), hO.as<u64>(), L, inner, W, ci,
                                    zpart.as<double>(), zcount.as<u32>(), collision.as<u32>(), (u32)Ni, lazy_now ? markbits.as<u32>() : (u32 *)nullptr);
+                if (diag_side) { HIP_TRY(hipStreamWaitEvent(st, ctx().ev_join, 0)); diag_side = false; }
                 hipLaunchKernelGGL(k_zero_close, dim3(1), dim3(64), 0, st, ks, zpart.as<double>(), zcount.as<u32>(), n_zb, L, (u32)Ni, thr, use_thr,
-                                   markbits.as<u32>(), sum_of.as<double>(), zl, patch_p);
+                                   markbits.as<u32>(), sum_of.as<double>(), zl, patch_p, diag_seq.as<double>(), collision.as<u32>() + 2);
                 zero_len_p = zl;
             }
             const u32 *dirty_p = nullptr;

@@ -171,6 +171,157 @@ def test_cfg4_elimination_schedules_agree_full_size(monkeypatch):
         assert ref[1] > 0
 
 
+# ---- round 4: the ORACLE at the sizes where the size-gated device paths run ----------------------------
+def _cfg4_bench_operator(seed=1238):
+    """bench.py's cfg4 operator (cfg4_operator): 2,000 qubits, 50,000 terms, 32 planted symmetries, 16 Clifford rotations."""
+    rng = np.random.default_rng(seed)
+    symp = rng.random((50000, 4000)) < 0.3
+    symp[:, :32] = False
+    H = DeviceOp.upload(packing.pack_rows(symp), np.ones(50000, dtype=complex))
+    del symp
+    for _ in range(16):
+        q = packing.pack_rows((rng.random((1, 4000)) < 0.3))[0]
+        res, allc = kernels.rotate_single_dev(H, q, np.pi / 2)
+        if not allc:
+            H.free(); H = res
+    return H
+
+
+def test_cfg4_full_size_against_the_c_oracle():
+    """BASELINE cfg4 on the bench's own operator, against the C oracle (utils.py:292-315, independent_op.py:124-126):
+    (1) symmetry_kernel: the 32 generators (rows and order) and the reference-order row-XOR count;
+    (2) rref of the [4000 x 54000] matrix that symmetry_generators reduces: reduced matrix, pivot columns and XOR count — the device
+    runs its default blocked schedule (in-launch barrier, look-ahead panel), the oracle the reference's row-by-row loop."""
+    H = _cfg4_bench_operator()
+    h_rows = H.download(with_coeff=False)
+    H.free()
+    n, M = 2000, 50000
+    gen, n_xor = kernels.symmetry_kernel(h_rows, n)
+    egen, e_xor = oc.symmetry_generators(h_rows, n)
+    assert gen.shape == egen.shape == (32, 64) and np.array_equal(gen, egen)
+    assert n_xor == e_xor and 7_000_000 < n_xor < 9_000_000
+    # the matrix of independent_op.py:124: columns = [Z | X] of every term, then the identity; its transpose is row-reduced
+    symp = packing.unpack_rows(h_rows, n)
+    mat = np.hstack([np.hstack([symp[:, n:], symp[:, :n]]).T, np.eye(2 * n, dtype=bool)])
+    assert mat.shape == (4000, 54000)
+    packed = packing.pack_bits(mat)
+    del symp, mat
+    got = kernels.rref(packed, want_pivots=True)
+    exp = oc.rref(packed, want_pivots=True)
+    assert np.array_equal(got[0], exp[0]), 'reduced matrix differs from the oracle'
+    assert got[1] == exp[1] == n_xor, 'reference-order XOR count differs'
+    assert np.array_equal(got[2], exp[2]), 'pivot columns differ'
+
+
+def test_cfg2_full_size_rotations_against_the_oracle():
+    """BASELINE cfg2 on the bench's own operator (100,000 terms, 1,000 qubits) against the NumPy oracle of base.py:1090-1161: a
+    non-Clifford and a Clifford rotation on the one-launch kernel (rows resident in LDS), then a non-Clifford rotation of the
+    ~150,000-term result (the one-launch kernel's register-spill form, above its LDS capacity) — rows, row order, coefficients."""
+    from oracle import oracle_np as onp
+    n, N = 1000, 100000
+    rng = np.random.default_rng(1236)
+    P = DeviceOp.random(N, n, 0.3, seed=1236)
+    qs = [(rng.random(2 * n) < 0.3) for _ in range(3)]
+    qp = [packing.pack_rows(q.reshape(1, -1))[0] for q in qs]
+    clean = kernels.cleanup_dev(P)                                         # duplicate status known: the one-launch kernel takes it
+    P.free()
+    rows0, c0 = clean.download()
+    symp0 = packing.unpack_rows(rows0, n)
+    cnt = ctypes.c_int64(0)
+
+    def one_launch_count():
+        _lib.check(_lib.lib().symgpu_debug_counter(1, ctypes.addressof(cnt)))
+        return cnt.value
+
+    def check(dev_in, symp_in, c_in, q, qpk, ang, exact):
+        before = one_launch_count()
+        res, allc = kernels.rotate_single_dev(dev_in, qpk, ang)
+        assert not allc
+        took = one_launch_count() - before
+        r, c = res.download()
+        er, ec = onp.rotate_by_single_pword(symp_in, c_in, q, ang)
+        assert r.shape[0] == er.shape[0], (r.shape, er.shape)
+        assert np.array_equal(r, packing.pack_rows(er)), 'rows / row order differ from the oracle'
+        if exact:
+            assert np.array_equal(c, ec)
+        else:
+            assert np.allclose(c, ec, rtol=0, atol=1e-12)
+        return res, er, ec, took
+
+    res1, er1, ec1, took = check(clean, symp0, c0, qs[0], qp[0], 0.3, False)
+    assert took == 1, 'the one-launch rotation kernel did not run at BASELINE size'
+    assert 1.4 * N < res1.n_terms < 1.6 * N
+    res2, _, _, took = check(clean, symp0, c0, qs[1], qp[1], np.pi / 2, True)
+    assert took == 1
+    res2.free()
+    # second rotation, of the 1.5e5-term result: above the kernel's LDS capacity at 1,000 qubits (rows spill to registers)
+    res3, er3, _, took3 = check(res1, er1, ec1, qs[2], qp[2], -1.1, False)
+    assert took3 == 1, 'the register-spill form of the one-launch kernel did not take the 150,000-term operator'
+    assert res3.n_terms > 2.1 * N
+    for h in (res1, res3, clean):
+        h.free()
+    # and through the drop-in API (fresh upload, duplicate status unknown: the multi-launch path with its own duplicate check)
+    A = PauliwordOp._from_packed(rows0, n, c0)
+    R = A._rotate_by_single_Pword(PauliwordOp(qs[0].reshape(1, -1), [1]), 0.3)
+    assert np.array_equal(R.packed, packing.pack_rows(er1)) and np.allclose(R.coeff_vec, ec1, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize('shape', ['squared 3000', 'general 2500x2000', 'general 2000x2500'])
+def test_product_cleanup_over_the_lazy_gate_against_the_c_oracle(shape):
+    """Product + cleanup with more than 2^22 keys on the DEFAULT path (the lazy flow of cleanup.hip switches on there by itself;
+    round 3 only compared it with the forced gate or with the round-2 flow), 100 qubits, against the C oracle (utils.py:230-279):
+    a squared operator (4.5e6 keys of its 9e6 pairs) and general products in both operand orders (5e6 keys), dyadic coefficients:
+    rows, first-occurrence order and coefficients bit for bit."""
+    rng = np.random.default_rng(2200 + len(shape))
+    n = 100
+    if shape.startswith('squared'):
+        A = PauliwordOp(rng.random((3000, 2 * n)) < 0.3, dyadic(rng, 3000)); B = A
+    else:
+        na, nb = (2500, 2000) if shape.endswith('2500x2000') else (2000, 2500)
+        A = PauliwordOp(rng.random((na, 2 * n)) < 0.3, dyadic(rng, na)); B = PauliwordOp(rng.random((nb, 2 * n)) < 0.3, dyadic(rng, nb))
+    R = A * B
+    er, ec = oc.mul(A.packed, A.coeff_vec, B.packed, B.coeff_vec)
+    assert R.n_terms == er.shape[0] > (1 << 21)
+    assert np.array_equal(R.packed, er), 'rows / first-occurrence order differ from the oracle'
+    assert np.array_equal(R.coeff_vec, ec)
+
+
+@pytest.mark.parametrize('coeffs', ['gaussian', 'dyadic'])
+def test_cfg3_full_size_against_the_oracle(coeffs):
+    """BASELINE cfg3 at full size — a 10,000-term, 1,000-qubit operator squared (10^8 pairs) + cleanup — against the reference's
+    result assembled from the C oracle's 10^8 pair coefficients (tests/_expected.py, pinned to oracle_c.mul on the CPU: identity
+    first, then the pairs o < i in index order with the two twins' coefficients added; utils.py:230-279): the term count, EVERY
+    coefficient in output order bit for bit (Gaussian coefficients are all distinct, so that also fixes which pair every output
+    row is), every row of five 2^20-row chunks bit for bit, and the XOR of all rows."""
+    from _expected import squared_expected
+    rng = np.random.default_rng(1237)
+    n, N = 1000, 10000
+    rows = packing.pack_rows(rng.random((N, 2 * n)) < 0.3)
+    c = (rng.standard_normal(N) + 1j * rng.standard_normal(N)) if coeffs == 'gaussian' else dyadic(rng, N)
+    A = DeviceOp.upload(rows, c)
+    h = ctypes.c_void_p()
+    _lib.check(_lib.lib().symgpu_mul_cleanup_dev(A.handle, A.handle, 1, 1e-15, 1, ctypes.byref(h)))
+    R = DeviceOp(h)
+    o, i, ec = squared_expected(rows, c)
+    assert R.n_terms == ec.shape[0] and 2.4e7 < ec.shape[0] < 2.6e7
+    x, _ = R.checksum()
+    parity = (np.bincount(o[1:], minlength=N) + np.bincount(i[1:], minlength=N)) & 1          # the identity term contributes nothing
+    assert np.array_equal(x, np.bitwise_xor.reduce(rows[parity.astype(bool)], axis=0)), 'XOR of all output rows'
+    step = 1 << 20
+    part = DeviceOp.alloc(step, 16, with_coeff=True)
+    n_chunks = (R.n_terms + step - 1) // step
+    row_chunks = {0, 1, n_chunks // 2, n_chunks - 2, n_chunks - 1}
+    for k in range(n_chunks):
+        lo = k * step; cnt = min(step, R.n_terms - lo)
+        _lib.check(_lib.lib().symgpu_op_copy_rows(part.handle, 0, R.handle, lo, cnt)); part.set_rows(cnt)
+        gr, gc = part.download()
+        assert np.array_equal(gc, ec[lo:lo + cnt]), f'coefficients of chunk {k}'
+        if k in row_chunks:
+            assert np.array_equal(gr, rows[i[lo:lo + cnt]] ^ rows[o[lo:lo + cnt]]), f'rows of chunk {k}'
+    for hnd in (part, R, A):
+        hnd.free()
+
+
 def test_cfg5_adjacency_slice_full_width():
     """2,000 qubits, 200,000 terms: a 4096-row block of the adjacency matrix against all terms — symmetric on the square
     sub-block, True on the diagonal, exact vs the C oracle on a 64 x 8192 corner, and byte count == bit-packed popcount."""

@@ -155,3 +155,16 @@ def test_rotations_that_lose_every_term():
             rows, coeff = onp.perform_rotations(c['in_symp'], c['in_coeff'], list(zip(c['q'], c['angles'])))
         assert rows.shape == c['out_symp'].shape and np.array_equal(rows, c['out_symp']), c
         assert np.allclose(coeff, c['out_coeff'], rtol=0, atol=1e-15), c
+
+
+def test_squared_builder_equals_oracle_mul():
+    """tests/_expected.py (the expected P * P of the full-size cfg3 GPU test, assembled from the oracle's pair coefficients) is the
+    oracle's own product + cleanup: rows, row order and coefficients, dyadic and Gaussian."""
+    from _expected import squared_expected
+    rng = np.random.default_rng(404)
+    for n, N, gauss in ((1000, 900, False), (1000, 700, True), (130, 1200, False)):
+        A = onp.pack_rows(rng.random((N, 2 * n)) < 0.3)
+        c = (rng.standard_normal(N) + 1j * rng.standard_normal(N)) if gauss else (rng.integers(-8, 9, N) + 1j * rng.integers(-8, 9, N)) / 16.0
+        er, ec = oc.mul(A, c, A, c)
+        o, i, cc = squared_expected(A, c)
+        assert np.array_equal(A[i] ^ A[o], er) and np.array_equal(cc, ec)
