@@ -44,7 +44,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-TRAFFIC_PROFILE = 'r03_traffic.json'   # written by tools/pmc_product.sh from the rocprofv3 --pmc passes of this bench
+PROFILE_TAG = 'r04'                     # profiles/<tag>_*: the round whose rocprofv3 summaries belong to this bench.py
+TRAFFIC_PROFILE = f'{PROFILE_TAG}_traffic.json'   # written by tools/pmc_product.sh from the rocprofv3 --pmc passes of this bench
 
 
 def parse():
@@ -111,21 +112,39 @@ def main():
         assert world == 1, 'multi-rank run without a data plane'
         shard = right = DeviceOp.random(my_rows, n, 0.3, seed=99991 + rank)
     slab = max(1, min(args.slab_rows, M))
-    ring = [DeviceOp.alloc(slab * Ni, wq, with_coeff=True) for _ in range(2)]
-
-    def step():
-        if comm.gathers:
-            comm.allgather_op(shard, right, M)
-        k = 0
-        for o0 in range(0, M, slab):
-            o1 = min(M, o0 + slab)
-            _lib.check(lib.symgpu_mul_allpairs_dev(left.handle, right.handle, o0, o1, 1, ring[k & 1].handle))
-            k += 1
 
     def full_sync():
         # device-wide synchronisation == torch.cuda.synchronize(); torch's CUDA runtime is deliberately NOT initialised in
         # this process (PyTorch wheels bundle their own HIP runtime; the product uses the system one)
         _lib.check(lib.symgpu_device_sync())
+
+    def timed_product(left_op, n_left, slab_rows, steps, warmup):
+        """warmup + `steps` timed steps of (all-gather when world > 1) + the product of `left_op` against the whole right operand in
+        output slabs of `slab_rows` outer rows -> (max-over-ranks seconds, launches of the row kernel, their summed HIP-event ms)."""
+        ring = [DeviceOp.alloc(slab_rows * n_left, wq, with_coeff=True) for _ in range(2)]
+
+        def step():
+            if comm.gathers:
+                comm.allgather_op(shard, right, M)
+            k = 0
+            for o0 in range(0, M, slab_rows):
+                o1 = min(M, o0 + slab_rows)
+                _lib.check(lib.symgpu_mul_allpairs_dev(left_op.handle, right.handle, o0, o1, 1, ring[k & 1].handle))
+                k += 1
+        for _ in range(warmup):
+            step()
+        full_sync(); comm.barrier()
+        _lib.check(lib.symgpu_prof_enable(0, 1))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        full_sync(); comm.barrier()
+        dt_ = time.perf_counter() - t0
+        _lib.check(lib.symgpu_prof_enable(0, 0))
+        nl_, ms_ = prof_read(_lib, 0)
+        for r in ring:
+            r.free()
+        return comm.max_over_ranks(dt_), nl_, ms_
 
     if comm.gathers:
         # one gather outside the timed region, under a watchdog and agreed on by all ranks (a collective that hangs on one rank ends
@@ -136,24 +155,12 @@ def main():
         except parallel.CollectiveHang as exc:
             collective_hang(exc, args, rank, world)
         comm.verify_allgather(shard, right, M)
-    for _ in range(args.warmup):
-        step()
-    full_sync(); comm.barrier()
-    _lib.check(lib.symgpu_prof_enable(0, 1))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    full_sync(); comm.barrier()
-    dt = time.perf_counter() - t0
-    _lib.check(lib.symgpu_prof_enable(0, 0))
-    n_launch, tot_ms = ctypes.c_int64(0), ctypes.c_double(0)
-    _lib.check(lib.symgpu_prof_read(0, ctypes.addressof(n_launch), ctypes.addressof(tot_ms)))
-    dt = comm.max_over_ranks(dt)
+    dt, n_launch, tot_ms = timed_product(left, Ni, slab, args.steps, args.warmup)
 
     pairs_per_step_rank = Ni * M
     value = world * pairs_per_step_rank * args.steps / dt
-    launch_pairs = pairs_per_step_rank * args.steps / max(1, n_launch.value)
-    launch_ms = tot_ms.value / max(1, n_launch.value)
+    launch_pairs = pairs_per_step_rank * args.steps / max(1, n_launch)
+    launch_ms = tot_ms / max(1, n_launch)
     per_pair = 16 * wq                                   # the dominant kernel streams the rows (+ 1 phase byte per pair, not counted)
     fused_ok = os.environ.get('SYMGPU_PRODUCT_FUSED', '1') != '0' and wq & (wq - 1) == 0 and wq <= 64
     ROW_KERNEL = 'k_mul_rows_e' if fused_ok else 'k_mul_rows'
@@ -171,7 +178,7 @@ def main():
                      'note': 'one output row per block, grid.x a multiple of 8 so that every XCD keeps its eighth of the inner operand in L2; '
                              'the row stream also forms the phase sums (DPP + v_bcnt, VALU otherwise idle) and leaves 1 B/pair, '
                              'k_mul_coeff_expand streams the 16 B/pair coefficients after it (whole_step_GBps counts both kernels, 272 B/pair)', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'launches': n_launch.value, 'avg_launch_ms': launch_ms,
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'launches': n_launch, 'avg_launch_ms': launch_ms,
                      'algorithmic_bytes_per_launch': algo_bytes_launch,
                      'whole_step_GBps': pairs_per_step_rank * (16 * wq + 16) / (dt / args.steps) / 1e9},
     }
@@ -212,13 +219,25 @@ def main():
     # is running now (sha256 of product.hip recorded next to it); otherwise traffic stays null.
     traffic_from_profile(out['roofline'], TRAFFIC_PROFILE, ['product.hip'],
                          {'n_qubits': n, 'left_terms_per_gpu': Ni, 'right_terms': M, 'slab_rows': slab})
-    for r in ring:
-        r.free()
+    # STRONG scaling next to the weak line (world > 1): the same 10^5 x 10^5 product with the LEFT axis split over the ranks — 1/world of the
+    # left terms per GPU, world x as many outer rows per output slab, so that a launch still writes the same ~6.5 GB.
+    if world > 1:
+        try:
+            ni_s = (Ni + world - 1) // world
+            left_s = DeviceOp.random(ni_s, n, 0.3, seed=4321 + 7919 * rank)
+            dt_s, nl_s, ms_s = timed_product(left_s, ni_s, min(M, slab * world), args.steps, max(1, args.warmup))
+            left_s.free()
+            out['strong_scaling'] = {'scaling': 'strong', 'left_terms_per_gpu': ni_s, 'right_terms': M, 'slab_rows': min(M, slab * world),
+                                     'pairs_per_step': world * ni_s * M, 'value': world * ni_s * M * args.steps / dt_s, 'unit': 'pairs/s',
+                                     'ms_per_step': dt_s / args.steps * 1e3, 'row_kernel_avg_launch_ms': ms_s / max(1, nl_s),
+                                     'note': 'total work fixed at 1e5 x 1e5 terms; `value` of the contract line above is the weak-scaling figure'}
+        except Exception as exc:                                  # noqa: BLE001 - reported, never costs the headline line
+            out['strong_scaling'] = {'error': f'{type(exc).__name__}: {exc}'}
 
     # the secondary measurements must never cost the headline line: a failure is reported in place of the numbers
     if rank == 0 and world == 1 and not args.no_extras:
         try:
-            out['extras'] = extras(_lib, kernels, DeviceOp)
+            out['extras'] = extras(_lib, kernels, DeviceOp, comm, parallel, args, out)
         except Exception as exc:                                  # noqa: BLE001 - reported, not swallowed
             out['extras'] = {'error': f'{type(exc).__name__}: {exc}'}
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -336,7 +355,7 @@ def wl_mul_cleanup(args, comm, rank, world, _lib, DeviceOp, parallel):
                            'physical_write_floor_ms': n_out[0] * (row_bytes + 16) / (HBM_PEAK_GBS * 1e9) * 1e3,
                            'note': 'SURVEY 8d counts T (16Wq+16) B read + U_kept (16Wq+16) B written; the T product rows and pair coefficients '
                                    'never exist in memory here (keys only), so this figure is not HBM traffic'}}
-    traffic_from_profile(roof, 'r03_cfg3_traffic.json', ['cleanup.hip'], {'workload': 'mul_cleanup', 'n_qubits': n, 'terms': N})
+    traffic_from_profile(roof, f'{PROFILE_TAG}_cfg3_traffic.json', ['cleanup.hip'], {'workload': 'mul_cleanup', 'n_qubits': n, 'terms': N})
     out = contract_line(args, world, world * pairs * args.steps / dt, 'pairs/s', 'pauli_term_pairs_per_sec', dt, 'u64+c128',
                         {'workload': 'mul_cleanup_squared', 'n_qubits': n, 'terms': N, 'pairs_per_step': pairs, 'terms_out': n_out[0],
                          'call': 'P * P (symgpu_mul_cleanup_dev: fused product + cleanup, squared-operator path)',
@@ -400,7 +419,7 @@ def wl_rotation(args, comm, rank, world, _lib, DeviceOp, parallel):
             'events_pass': 'a second pass of the same steps right after the timed region (events inside every 27 us call would be part of it)',
             'note': 'one persistent launch per rotation, rows resident in LDS (one workgroup per CU); the launch is a chain of dependent phases '
                     '(rows in 7 us, join-table compare-and-swaps 3 us, two in-launch all-gathers, rows out 7 us), not a bandwidth-bound stream'}
-    traffic_from_profile(roof, 'r03_rotation_traffic.json', ['rotate_resident.hip'], {'workload': 'rotation', 'n_qubits': n, 'terms': N})
+    traffic_from_profile(roof, f'{PROFILE_TAG}_rotation_traffic.json', ['rotate_resident.hip'], {'workload': 'rotation', 'n_qubits': n, 'terms': N})
     out = contract_line(args, world, world * N * ROT * args.steps / dt, 'pairs/s', 'pauli_term_pairs_per_sec', dt, 'u64+c128',
                         {'workload': 'single_pauli_rotation_nonclifford', 'n_qubits': n, 'terms': N, 'terms_out': n_out[0], 'angle': 0.3,
                          'rotations_per_step': ROT, 'pairs_per_step': N * ROT, 'call': 'P._rotate_by_single_Pword(Q, 0.3) (symgpu_rotate_single_dev), one call per rotation',
@@ -425,7 +444,6 @@ def wl_rotation(args, comm, rank, world, _lib, DeviceOp, parallel):
             nl5, ms5 = prof_read(_lib, 5)
             res['k_cchain_reg_launches'] = nl5
             res['k_cchain_reg_us_per_rotation'] = ms5 * 1e3 / 200
-            res['run_algorithmic_GBps'] = 2 * Pc.n_terms * (16 * wq + 16) / res['run_of_200_seconds_per_rotation'] / 1e9
             Pc.free()
             return res
         out['clifford'] = guarded(clifford)
@@ -493,7 +511,7 @@ def wl_gf2(args, comm, rank, world, _lib, DeviceOp, parallel):
             'survey_8d_algorithmic_GBps': nx.value * 16 * wc / (dt / args.steps) / 1e9,
             'note': 'achieved = bytes one sweep launch moves (the 27 MB matrix read and written once) / its duration; the matrix lives in the '
                     'Infinity Cache, and the launch is as long as the single-wavefront panel of the next block that it hides'}
-    traffic_from_profile(roof, 'r03_gf2_traffic.json', ['gf2.hip'], {'workload': 'gf2', 'rows': 4000, 'cols': 54000})
+    traffic_from_profile(roof, f'{PROFILE_TAG}_gf2_traffic.json', ['gf2.hip'], {'workload': 'gf2', 'rows': 4000, 'cols': 54000})
     out = contract_line(args, world, world * nx.value * args.steps / dt, 'row-XORs/s', 'gf2_row_xors_per_sec', dt, 'u64',
                         {'workload': 'symmetry_generators_gf2', 'n_qubits': 2000, 'terms': 50000, 'matrix': [4000, 54000], 'row_xors_per_step': nx.value,
                          'generators_found': k.value, 'call': 'IndependentOp.symmetry_generators (symgpu_symmetry_kernel_dev)',
@@ -639,9 +657,12 @@ def timed(fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def extras(_lib, kernels, DeviceOp):
-    """Other BASELINE.json configs on one GPU (device-resident inputs, C-ABI level; cfg1 through the Python classes).  Every
-    section runs on its own: one that fails reports its error and the others still run."""
+def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
+    """The other BASELINE.json configs on the same GPU.  cfg2 / cfg3 / cfg4 / cfg5 run the SAME code as their `--workload` lines
+    (wl_rotation, wl_mul_cleanup, wl_gf2, adjacency) with a short timed region, and carry that line's `roofline` object (dominant
+    kernel, HIP-event duration, algorithmic or physical bytes, fraction of peak; never above 1: bytes that do not move are not
+    counted).  Every section runs on its own: one that fails reports its error and the others still run."""
+    import types
     lib = _lib.lib()
     from symmer_amd.operators import PauliwordOp
     from symmer_amd import packing
@@ -653,6 +674,13 @@ def extras(_lib, kernels, DeviceOp):
         except Exception as exc:                                  # noqa: BLE001 - reported in the JSON line
             ex[fn.__name__] = {'error': f'{type(exc).__name__}: {exc}'}
 
+    def workload_line(fn, steps, warmup=1, **kw):
+        a = types.SimpleNamespace(steps=steps, warmup=warmup, qubits=1000, no_cpu=True, no_extras=True, adj_terms=200000, adj_qubits=2000,
+                                  adj_slab_rows=0, gpus=1)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return fn(a, comm, 0, 1, _lib, DeviceOp, parallel)
+
     def wake_gpu():
         # the CPU baseline leg leaves the GPU idle for tens of seconds: its clocks are down when the (latency bound, sub-millisecond)
         # small cases below start — 50 ms of row-stream work first
@@ -663,7 +691,39 @@ def extras(_lib, kernels, DeviceOp):
         kernels.sync()
         ow.free(); Aw.free(); Bw.free()
     section(wake_gpu)
-    ex.pop('wake_gpu', None) if 'wake_gpu' in ex and 'error' not in ex['wake_gpu'] else None
+
+    def strong_scaling_shard():
+        # the per-rank shape of the 8-GPU STRONG-scaling run of the headline problem (1e5 x 1e5 terms in total): 12,500 left terms against all
+        # 1e5 right terms, 2,048 outer rows per output slab so that a launch writes the same 6.5 GB as the 256-row slab of the full left operand
+        n, Ni, M, slab = 1000, 12500, 100000, 2048
+        left = DeviceOp.random(Ni, n, 0.3, seed=4321); right = DeviceOp.random(M, n, 0.3, seed=99991)
+        ring = [DeviceOp.alloc(slab * Ni, 16, with_coeff=True) for _ in range(2)]
+
+        def step():
+            for k, o0 in enumerate(range(0, M, slab)):
+                _lib.check(lib.symgpu_mul_allpairs_dev(left.handle, right.handle, o0, min(M, o0 + slab), 1, ring[k & 1].handle))
+        step(); kernels.sync()
+        _lib.check(lib.symgpu_prof_enable(0, 1))
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        kernels.sync()
+        dt = (time.perf_counter() - t0) / 3
+        _lib.check(lib.symgpu_prof_enable(0, 0))
+        nl, ms = prof_read(_lib, 0)
+        kt = ms / max(1, nl) * 1e-3
+        launch_bytes = Ni * M * 3 / max(1, nl) * 256
+        full_ms = headline.get('ms_per_step')
+        ex['strong_scaling_shard'] = {
+            'left_terms': Ni, 'right_terms': M, 'slab_rows': slab, 'pairs_per_step': Ni * M, 'ms_per_step': dt * 1e3, 'pairs_per_s': Ni * M / dt,
+            'roofline': {'bound': 'hbm', 'kernel': headline['roofline']['kernel'], 'achieved': launch_bytes / kt / 1e9 if kt else None, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': launch_bytes / kt / 1e9 / HBM_PEAK_GBS if kt else None, 'traffic': None, 'launches': nl,
+                         'avg_launch_ms': kt * 1e3, 'algorithmic_bytes_per_launch': launch_bytes},
+            'predicted_8gpu_strong_speedup_before_allgather': (full_ms / (dt * 1e3)) if full_ms else None,
+            'note': 'one rank\'s share of the fixed 1e5 x 1e5 product on 8 GPUs, timed on one GPU; the all-gather of the 27 MB right operand '
+                    '(~0.1-0.3 ms over xGMI) comes on top of ms_per_step'}
+        for h in ring + [left, right]:
+            h.free()
 
     def cfg1_api_mul():
         # the reference's own CPU-runnable case through the drop-in API, host buffers in / host result out
@@ -685,29 +745,20 @@ def extras(_lib, kernels, DeviceOp):
                               'seconds': t, 'pairs_per_s': 250000 / t, 'terms_out': R1.n_terms}
 
     def cfg3_mul_cleanup():
-        # 1,000 qubits, 10,000 terms squared (1e8 pairs) + cleanup
-        A = DeviceOp.random(10000, 1000, 0.3, seed=1237)
-        n_out = [0]
-
-        def run():
-            h = ctypes.c_void_p()
-            _lib.check(lib.symgpu_mul_cleanup_dev(A.handle, A.handle, 1, 1e-15, 1, ctypes.byref(h)))
-            r = DeviceOp(h); n_out[0] = r.n_terms; r.free()
-        t = timed(run, 2)
-        # algorithmic bytes of product + cleanup = T (16 Wq + 16) read + U_kept (16 Wq + 16) written (the T product rows
-        # themselves never exist in memory here)
-        algo = (10**8 + n_out[0]) * 272
-        ex['cfg3_mul_cleanup'] = {'pairs': 10**8, 'seconds': t, 'pairs_per_s': 1e8 / t, 'terms_out': n_out[0],
-                                  'algorithmic_bytes': algo, 'algorithmic_GBps': algo / t / 1e9, 'frac_of_hbm_peak': algo / t / 1e9 / HBM_PEAK_GBS,
-                                  'physical_write_floor_s': n_out[0] * 272 / (HBM_PEAK_GBS * 1e9),
-                                  'note': 'squared operator: keys for the pairs with i >= o only (cleanup.hip)'}
-        A.free()
+        # 1,000 qubits, 10,000 terms squared (1e8 pairs) + cleanup: the `--workload mul_cleanup` line, 3 steps
+        line = workload_line(wl_mul_cleanup, 3)
+        ex['cfg3_mul_cleanup'] = {'pairs': 10**8, 'seconds': line['ms_per_step'] * 1e-3, 'pairs_per_s': line['value'], 'terms_out': line['config']['terms_out'],
+                                  'roofline': line['roofline'],
+                                  'note': 'squared operator: keys for the pairs with i >= o only (cleanup.hip); roofline = the output stage, the one kernel of the '
+                                          'step that moves the result\'s bytes (SURVEY 8d\'s T (16 Wq + 16) bytes of product rows never exist here)'}
 
     def cfg2_rotation():
-        # 1,000 qubits, 100,000 terms, chain of non-Clifford single-Pauli rotations, device resident
+        # 1,000 qubits, 100,000 terms: the `--workload rotation` line (100 non-Clifford rotations per step) + the per-call time seen by the host
+        line = workload_line(wl_rotation, 1, no_extras=False)
         rng = np.random.default_rng(1236)
         P = DeviceOp.random(100000, 1000, 0.3, seed=1236)
         qs = [packing.pack_rows((rng.random((1, 2000)) < 0.3))[0] for _ in range(8)]
+
         def chain4():
             terms, cur = [], P
             for q in qs[:4]:
@@ -721,34 +772,11 @@ def extras(_lib, kernels, DeviceOp):
             return terms
         chain4(); chain4()                                           # one-time costs: kernel modules, hash tables, the join tables of both paths
         t0 = time.perf_counter(); terms = chain4(); t_chain = time.perf_counter() - t0
-        t1 = timed(lambda: kernels.rotate_single_dev(P, qs[0], 0.3)[0].free(), 5)
-        # chain of 128 Clifford (pi/2) rotations with the operator device resident (term count stays 1e5)
-        cur = P
-        kernels.sync(); t0 = time.perf_counter()
-        n_rot = 0
-        for k in range(128):
-            res, allc = kernels.rotate_single_dev(cur, qs[k % 8], np.pi / 2)
-            if allc:
-                continue
-            if cur is not P:
-                cur.free()
-            cur = res; n_rot += 1
-        kernels.sync(); t_cl = (time.perf_counter() - t0) / max(1, n_rot)
-        if cur is not P:
-            cur.free()
-        # the same 128 rotations as ONE run (symgpu_rotate_clifford_chain_dev on the cleaned operator: no read-back between steps)
-        Pc = kernels.cleanup_dev(P)
-        q128 = np.vstack([qs[k % 8] for k in range(128)]); k128 = np.ones(128, dtype=np.int32)
-        kernels.rotate_clifford_chain_dev(Pc, q128[:4], k128[:4]).free(); kernels.sync()
-        t0 = time.perf_counter(); kernels.rotate_clifford_chain_dev(Pc, q128, k128).free(); kernels.sync()
-        t_run = (time.perf_counter() - t0) / 128
-        Pc.free()
-        ex['cfg2_rotation'] = {'terms_in': 100000, 'first_rotation_seconds': t1, 'term_pairs_per_s': 1e5 / t1,
-                               'algorithmic_GBps': (100000 + terms[0]) * 272 / t1 / 1e9,      # N (16 Wq + 16) read + N_out (...) written
-                               'chain4_seconds': t_chain, 'chain_terms': terms,
-                               'clifford_chain': {'rotations': n_rot, 'seconds_per_rotation': t_cl, 'term_pairs_per_s': 1e5 / t_cl,
-                                                  'as_one_run_seconds_per_rotation': t_run, 'as_one_run_term_pairs_per_s': 1e5 / t_run}}
+        t1 = timed(lambda: kernels.rotate_single_dev(P, qs[0], 0.3)[0].free(), 20)
         P.free()
+        ex['cfg2_rotation'] = {'terms_in': 100000, 'seconds_per_rotation': line['seconds_per_rotation'], 'term_pairs_per_s': line['value'],
+                               'first_rotation_seconds': t1, 'first_rotation_note': 'through kernels.rotate_single_dev (Python wrapper + handle free per call), 20 calls back to back',
+                               'roofline': line['roofline'], 'chain4_seconds': t_chain, 'chain_terms': terms, 'clifford': line.get('clifford')}
         # README claim 1 (a depth-2,000 Clifford circuit on 1,000 qubits "in one second"): 2,000 Clifford rotations of a 64-term,
         # 1,000-qubit observable through perform_rotations — one single-workgroup launch for the whole run (rotate.hip)
         rng_c = np.random.default_rng(1240)
@@ -760,65 +788,37 @@ def extras(_lib, kernels, DeviceOp):
             'seconds': t_circ, 'seconds_per_rotation': t_circ / 2000, 'terms_out': rot_obs.n_terms,
             'call': 'PauliwordOp.perform_rotations (Python API: upload, one chain launch, download)'}
 
-    def cfg5_commutation_slice():
-        # 2,000 qubits, 25,000 x 200,000 commutation block (one rank's share of the 8-GPU adjacency; `--workload adjacency` runs all of it)
+    def cfg5_adjacency():
+        # 2,000 qubits, 200,000 terms: the whole adjacency matrix on this GPU (`--workload adjacency`, 1 step) and ONE rank's share of the
+        # 8-GPU run, a 25,000 x 200,000 block, timed on its own
+        line = workload_line(adjacency, 1)
         C = DeviceOp.random(200000, 2000, 0.3, seed=1239)
         nrow = 25000
         buf = ctypes.c_void_p()
         _lib.check(lib.symgpu_dev_alloc(nrow * 200000, ctypes.byref(buf)))
+        _lib.check(lib.symgpu_commutes_dev(C.handle, 0, nrow, C.handle, buf)); kernels.sync()
         _lib.check(lib.symgpu_prof_enable(1, 1))
-        t = timed(lambda: _lib.check(lib.symgpu_commutes_dev(C.handle, 0, nrow, C.handle, buf)), 2)
-        nl, ms = ctypes.c_int64(0), ctypes.c_double(0)
-        _lib.check(lib.symgpu_prof_enable(1, 0)); _lib.check(lib.symgpu_prof_read(1, ctypes.addressof(nl), ctypes.addressof(ms)))
-        kt = ms.value / max(1, nl.value) * 1e-3
+        t = timed(lambda: _lib.check(lib.symgpu_commutes_dev(C.handle, 0, nrow, C.handle, buf)), 3)
+        _lib.check(lib.symgpu_prof_enable(1, 0))
+        nl, ms = prof_read(_lib, 1)
+        kt = ms / max(1, nl) * 1e-3
         pairs = nrow * 200000
-        # The slice runs on the Four-Russians kernel (commute_m4r.hip): per row of A, 8-bit k-block and 2048-column tile one
-        # 256-byte table entry is read from LDS, so the kernel's own roofline is the LDS read path (256 B/clk/CU, MI355X_MICROARCH.md
-        # LDS table: 256 CUs x 256 B x 2.4 GHz = 157 TB/s); HBM only sees the 1 B/pair np.bool_ output.
         n_kblocks = 2 * ((2000 + 7) // 8)                              # non-zero index bytes of a 2,000-qubit row (X and Z halves)
         col_tiles = (200000 // 64 + 31) // 32
         lds_bytes = nrow * n_kblocks * col_tiles * 256.0
-        ex['cfg5_commutation_slice'] = {'pairs': pairs, 'seconds': t, 'pairs_per_s': pairs / t, 'kernel': 'k_commutes_m4r', 'kernel_seconds': kt,
-                                        'kernel_pairs_per_s': pairs / kt if kt else None,
-                                        'hbm_GBps_at_1B_per_pair': pairs / kt / 1e9 if kt else None,
-                                        'lds_table_read_TBps': lds_bytes / kt / 1e12 if kt else None,
-                                        'lds_read_frac_of_157TBps': lds_bytes / kt / 157.3e12 if kt else None,
-                                        'register_tile_kernel_r01_pairs_per_s': 2.83e11}
+        full_s = line['ms_per_step'] * 1e-3
+        ex['cfg5_adjacency'] = {'pairs': 200000 ** 2, 'seconds': full_s, 'pairs_per_s': line['value'], 'roofline': line['roofline'],
+                                'rank_share_25000_rows': {'pairs': pairs, 'seconds': t, 'pairs_per_s': pairs / t, 'kernel': 'k_commutes_m4r', 'kernel_seconds': kt,
+                                                          'hbm_GBps_at_1B_per_pair': pairs / kt / 1e9 if kt else None,
+                                                          'lds_read_frac_of_157TBps': lds_bytes / kt / 157.3e12 if kt else None,
+                                                          'predicted_8gpu_strong_speedup_before_allgather': full_s / t}}
         _lib.check(lib.symgpu_dev_free(buf)); C.free()
 
     def cfg4_symmetry_kernel():
-        # GF(2) symmetry kernel, 2,000 qubits x 50,000 terms, 32 planted symmetries, Clifford-scrambled
-        rng = np.random.default_rng(1238)
-        symp = rng.random((50000, 4000)) < 0.3
-        symp[:, :32] = False
-        H = DeviceOp.upload(packing.pack_rows(symp), np.ones(50000, dtype=complex))
-        del symp
-        for _ in range(16):
-            q = packing.pack_rows((rng.random((1, 4000)) < 0.3))[0]
-            res, allc = kernels.rotate_single_dev(H, q, np.pi / 2)
-            if not allc:
-                H.free(); H = res
-        outg = np.zeros((4000, 64), dtype='<u8')
-        k, nx = ctypes.c_int64(0), ctypes.c_int64(0)
-
-        def run():
-            _lib.check(lib.symgpu_symmetry_kernel_dev(H.handle, 2000, outg.ctypes.data, 4000, ctypes.addressof(k), ctypes.addressof(nx)))
-        t = timed(run, 2)
-        wc = (50000 + 63) // 64 + 64
-        # physical traffic of the sweep launches (HIP events around every launch of the main sweep kernel): each pass reads and
-        # writes the whole 4000 x 846-word matrix once
-        _lib.check(lib.symgpu_prof_enable(2, 1))
-        run(); kernels.sync()
-        _lib.check(lib.symgpu_prof_enable(2, 0))
-        nl4, ms4 = ctypes.c_int64(0), ctypes.c_double(0)
-        _lib.check(lib.symgpu_prof_read(2, ctypes.addressof(nl4), ctypes.addressof(ms4)))
-        sweep_s = ms4.value / max(1, nl4.value) * 1e-3
-        ex['cfg4_symmetry_kernel'] = {'rows': 4000, 'cols': 54000, 'generators_found': k.value, 'row_xors': nx.value, 'seconds': t,
-                                      'row_xors_per_s': nx.value / t, 'algorithmic_GBps': nx.value * 16 * wc / t / 1e9,
-                                      'sweep_launches': nl4.value, 'sweep_avg_launch_us': sweep_s * 1e6,
-                                      'sweep_physical_GBps': 2 * 4000 * wc * 8 / sweep_s / 1e9 if sweep_s else None,
-                                      'sweep_frac_of_hbm_peak': 2 * 4000 * wc * 8 / sweep_s / 1e9 / HBM_PEAK_GBS if sweep_s else None}
-        H.free()
+        # GF(2) symmetry kernel, 2,000 qubits x 50,000 terms, 32 planted symmetries, Clifford-scrambled: the `--workload gf2` line, 3 steps
+        line = workload_line(wl_gf2, 3)
+        ex['cfg4_symmetry_kernel'] = {'rows': 4000, 'cols': 54000, 'generators_found': line['config']['generators_found'], 'row_xors': line['config']['row_xors_per_step'],
+                                      'seconds': line['ms_per_step'] * 1e-3, 'row_xors_per_s': line['value'], 'roofline': line['roofline']}
 
     def readme_claim1_clifford_circuit():
         # reference README.md:50-51: "expectation value of a 1,000-qubit Clifford circuit of depth 2,000" — CircuitSymmerlator: 2,000
@@ -877,7 +877,7 @@ def extras(_lib, kernels, DeviceOp):
                                             'seconds_operands_already_packed': t_dev, 'terms_out': R.n_terms,
                                             'call': 'PauliwordOp * PauliwordOp (Python API)'}
 
-    for fn in (cfg1_api_mul, cfg3_mul_cleanup, cfg2_rotation, cfg5_commutation_slice, cfg4_symmetry_kernel, readme_claim1_clifford_circuit, readme_claim3_square_1000q_500t, readme_claim4_wide_product):
+    for fn in (strong_scaling_shard, cfg1_api_mul, cfg3_mul_cleanup, cfg2_rotation, cfg5_adjacency, cfg4_symmetry_kernel, readme_claim1_clifford_circuit, readme_claim3_square_1000q_500t, readme_claim4_wide_product):
         section(fn)
     return ex
 
@@ -920,6 +920,11 @@ def cpu_baseline(n):
     M4 = rng.random((256, 54000)) < 0.5
     t0 = time.perf_counter(); _, nx = onp.rref_noswap(M4, count_xors=True); t = time.perf_counter() - t0
     other['cfg4_sample_rref'] = {'rows': 256, 'cols': 54000, 'row_xors': int(nx), 'seconds': t, 'row_xors_per_s': nx / t}
+    try:                                                              # the full 4000 x 54000 run of the same loop (~72 s), measured once by tools/cpu_cfg4_full.py
+        with open(os.path.join(ROOT, 'profiles', 'r03_cpu_cfg4_full.json')) as f:
+            other['cfg4_full_size_cached'] = json.load(f)
+    except (OSError, ValueError):
+        other['cfg4_full_size_cached'] = None
     model = 'unknown'
     try:
         with open('/proc/cpuinfo') as f:

@@ -1,7 +1,7 @@
-# Everything under profiles/ for one round (run on the GPU box): bash tools/prof_all.sh r03
+# Everything under profiles/ for one round (run on the GPU box): bash tools/prof_all.sh r04
 # -> gpurun_out/<tag>_profiles/: bench lines (un-profiled) of all five workloads, rocprofv3 kernel traces, PMC passes, traffic JSONs
 export TMPDIR=/tmp
-tag=${1:-r03}
+tag=${1:-r04}
 dst=gpurun_out/${tag}_profiles; rm -rf $dst; mkdir -p $dst
 # 1. the bench lines as the driver would see them
 timeout 900 python3 bench.py > $dst/${tag}_bench_n1.json 2> $dst/bench_n1.err
