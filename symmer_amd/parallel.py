@@ -487,13 +487,17 @@ class Communicator:
         # caller should finish its output and then leave through hard_exit_if_hung()
         self.needs_hard_exit = hung
 
-    def hard_exit_if_hung(self, status=0):
+    HUNG_EXIT_STATUS = 4
+
+    def hard_exit_if_hung(self, status=None):
         """Call after the last line of output: if a watchdog thread never came back from RCCL, end the process without running the
-        finalisers (library shutdown under a thread that is inside RCCL is not safe)."""
+        finalisers (library shutdown under a thread that is inside RCCL is not safe).  The exit status is NON-ZERO (4) by default:
+        a thread stuck inside RCCL means the run did not use the data plane it was asked to use (the JSON line says ``degraded``),
+        and a launcher that only reads exit codes must see that."""
         if getattr(self, 'needs_hard_exit', False):
             import sys
             sys.stdout.flush(); sys.stderr.flush()
-            os._exit(status)
+            os._exit(self.HUNG_EXIT_STATUS if status is None else status)
 
 
 def padded_random_shard(my_rows, ts, n_qubits, seed):

@@ -210,7 +210,7 @@ def _first_gather_worker(rank, world, port, q, mode):
         q.put((rank, ok, '' if ok else f'outcome={outcome} plane={comm.data_plane} degraded={comm.degraded}'))
         if comm.needs_hard_exit:
             q.close(); q.join_thread()
-            comm.hard_exit_if_hung(0)
+            comm.hard_exit_if_hung()                               # default status: non-zero (a launcher reading exit codes sees the degraded run)
     except Exception:                                         # pragma: no cover
         import traceback
         q.put((rank, False, traceback.format_exc()))
@@ -232,6 +232,10 @@ def test_first_gather_is_watched_and_agreed(mode):
         assert not p.is_alive(), 'a rank did not leave'
     for rank, ok, err in res:
         assert ok, f'rank {rank} failed ({mode}): {err}'
+    if mode == 'hang':
+        from symmer_amd import parallel
+        assert procs[1].exitcode == parallel.Communicator.HUNG_EXIT_STATUS != 0, 'a rank with a thread stuck inside RCCL must not exit with status 0'
+        assert procs[0].exitcode == 0
 
 
 def _mul_cleanup_worker(rank, world, port, q):
