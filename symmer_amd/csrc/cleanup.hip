@@ -312,6 +312,17 @@ __global__ __launch_bounds__(256) void k_mark_singles(const u64 *__restrict__ ke
                 else cf[j] = reinterpret_cast<const double2 *>(coeff)[sidx];
             }
         }
+        // the operand coefficients of all four chunks are fetched before the first one is used (gathers from the cache-resident tables:
+        // one after the other they were four dependent round trips per step, and the kernel was bound by them)
+        double2 ca[4], cb[4];
+        if (PACKED) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32 i = L.i(k[j]), o = L.o(k[j]);                // (lanes past the end hold key 0: term 0 of both tables)
+                ca[j] = reinterpret_cast<const double2 *>(ci)[i];
+                cb[j] = reinterpret_cast<const double2 *>(co)[o];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const i64 sidx = g0 + 64 * j + lane;
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(256) void k_mark_singles(const u64 *__restrict__ ke
                 if (hist) atomicAdd(&s_h[(u32)(k[j] >> hist_shift) & 255u], 1u);
                 const u32 i = L.i(k[j]), o = L.o(k[j]);
                 e = L.e(k[j]);
-                pair_coefficient(ci[2 * i], ci[2 * i + 1], co[2 * o], co[2 * o + 1], e, cx, cy);
+                pair_coefficient(ca[j].x, ca[j].y, cb[j].x, cb[j].y, e, cx, cy);
                 if (squared && i != o) {
                     if (e & 1) { cx = 0.0; cy = 0.0; }
                     else { cx = __dadd_rn(cx, cx); cy = __dadd_rn(cy, cy); }
@@ -1068,6 +1079,15 @@ int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
     return SYMGPU_OK;
 }
 
+// Reads every 16-byte chunk of a buffer and keeps nothing: run right before the output stage on the bitmaps it decodes (written two
+// gigabytes of traffic earlier, so out of the Infinity Cache again) — a saturated HBM WRITE stream tolerates cache hits, but every HBM
+// read mixed into it costs the DRAM a turn-around.
+__global__ __launch_bounds__(256) void k_touch(const u32x4 *__restrict__ p, i64 n16, u32 *__restrict__ sink) {
+    u32 acc = 0;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n16; i += (i64)gridDim.x * 256) { const u32x4 v = p[i]; acc |= v.x & v.y & v.z & v.w; }
+    if (acc == 0xDEADBEEFu) *sink = acc;                           // (never true for bitmaps of a real run; keeps the loads alive)
+}
+
 // T = size of the index space the kept terms are filed under (pair indices, or the slots of a squared operator: `tri`)
 int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, const u64 *rows, int W, const u64 *inner, i64 Ni,
                    const u64 *outer, symgpu_op_t *out, int Wq_out, bool tri, const LazyEmit &lz) {
@@ -1098,6 +1118,16 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
         if (fused) {
             const i64 n_w64 = (T + 63) / 64;
             const dim3 gfu((unsigned)((n_w64 + 4 * EF_NW - 1) / (4 * EF_NW)));
+            static const bool touch_on = [] { const char *e = getenv("SYMGPU_EMIT_TOUCH"); return !(e && e[0] == '0'); }();
+            if (touch_on) {
+                const i64 n16 = n_w64 / 2;                              // whole 16-byte chunks of a T-bit map
+                const void *maps[5] = {markbits_p, wordprefix.p, lz.mode ? (const void *)lz.patchbits : nullptr, lz.mode == 1 ? (const void *)lz.e_lo : nullptr,
+                                       lz.mode == 1 ? (const void *)lz.e_hi : nullptr};
+                for (int m = 0; m < 5; ++m)
+                    if (maps[m] && n16 > 0)
+                        hipLaunchKernelGGL(k_touch, dim3(grid_for(m == 1 ? 2 * n16 : n16)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(maps[m]), m == 1 ? 2 * n16 : n16,
+                                           total.as<u32>() + 2);
+            }
             ProfScope prof(3);
 #define LAUNCH_FUSED(P, TR) hipLaunchKernelGGL((k_emit_fused<P, TR>), gfu, dim3(256), 0, st, reinterpret_cast<const u64 *>(markbits_p), wordprefix.as<u32>(), T, sum_of_p, \
                                                (u32)(pair ? Ni : 1), Wq, wsh, reinterpret_cast<const u32x4 *>(rows), pin, pout, dst, res->coeff, lz)
@@ -1141,6 +1171,103 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
     res->dup_free = 1;                                          // merged: no two equal rows
     *out = res;
     return SYMGPU_OK;
+}
+
+// ---- products without repeated rows: the keys that COULD merge are few — find them after a partial sort, sort only them ---------------
+// The radix sort exists to bring equal keys together, but a product of operators without repeated rows merges next to nothing (cfg3:
+// the N diagonal pairs of P * P and nothing else), and the lazy flow has already decided every other term in index order
+// (k_mark_singles).  So the sort stops one 8-bit pass early: the keys are then ordered by `sorted` hash bits [lo, hi), a RUN of equal
+// bits holds ~Tk / 2^sorted keys (cfg3: 3) still in ascending index order (LSD passes are stable), and equal FULL keys can only sit in
+// one run.  k_find_suspects flags every key that has an equal full key (packed hash field first, then the 64-bit key rebuilt from the
+// operand hash tables) somewhere in its run — both partners — plus, conservatively, every key of a run too long to be seen whole
+// from its wavefront's window of three 64-key chunks and every key whose hash field is zero (the identity segment of a squared operator, N
+// keys in one run).  The flagged keys are compacted IN ARRAY ORDER (so equal keys stay in index order), sorted completely — a few
+// thousand keys instead of 5e7 — and handed to the unchanged segment machinery (fix-up, identity segment, k_heads_sums), which only
+// ever acts on segments of more than one key.  Inputs full of repeated rows flag most keys: the caller then finishes the last pass
+// on the whole array and carries on as before (the partial sort is the old sort's first passes, nothing is wasted but the flag pass).
+// cfg3: one scatter + one histogram pass over 5e7 keys (0.27 ms) and the 0.17 ms fix-up pass are replaced by one 0.08 ms read pass.
+constexpr int SUS_CPW = 8;                                             // chunks per wavefront of k_find_suspects
+constexpr int SUS_D = 12;                                              // a key is compared with the SUS_D keys before it
+__device__ __forceinline__ u32 wave_shr1(u32 v, u32 lane0) {            // lane L <- v[L - 1], lane 0 <- lane0 (DPP wave_shr:1, one VALU instruction)
+    return (u32)__builtin_amdgcn_update_dpp((int)lane0, (int)v, 0x138, 0xf, 0xf, false);
+}
+// Equal keys have equal run bits, so a key's partners are among its neighbours in the partially sorted array: the word w = key bits
+// [lo, lo + 32) (the run bits and the hash bits above them) of every key is compared with the SUS_D keys before it — one DPP shift of the
+// wavefront's 64 words per distance, the tail of the previous chunk shifted in at lane 0 — and an equal word (one lane in ~10^5) is
+// followed up with the hash field and then the full 64-bit keys rebuilt from the operand hash tables.  A partner further away than
+// SUS_D needs a run longer than SUS_D + 1 keys (P < 2e-6 per run at the 3 keys a run holds on average): every key of such a run is
+// flagged without looking — a position whose run bits equal those SUS_D positions before it flags itself and the SUS_D keys before it.
+__global__ __launch_bounds__(256) void k_find_suspects(const u64 *__restrict__ keys, i64 T, int lo, int run_bits, PackedLayout L, const u64 *__restrict__ hI,
+                                                        const u64 *__restrict__ hO, u64 *__restrict__ suspect64) {
+    const int lane = threadIdx.x & 63;
+    const i64 n_chunks = (T + 63) / 64;
+    const u32 rmask = run_bits >= 32 ? ~0u : ((1u << run_bits) - 1u);       // lo <= 32 and run_bits <= 32 (the caller's condition)
+    const int F = L.F();
+    // a wavefront walks SUS_CPW consecutive chunks and hands the words of the previous chunk on in registers; the loads are clamped and
+    // unconditional (a load under a branch is waited for at the branch's join, i.e. at once), one chunk ahead
+    const i64 c0 = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * SUS_CPW;
+    if (c0 >= n_chunks) return;
+    auto load = [&](i64 cc) -> u64 { i64 q = cc * 64 + lane; q = q < 0 ? 0 : (q < T ? q : T - 1); return keys[q]; };
+    u64 kp = load(c0 - 1), kc = load(c0);
+    for (i64 c = c0; c < c0 + SUS_CPW && c < n_chunks; ++c) {
+        const u64 kn = load(c + 1);
+        const i64 p = c * 64 + lane;
+        const bool vc = p < T;
+        // words past the end / before the start can equal nothing: all ones never occurs behind a valid key's word... it could, so validity
+        // is tracked in the compare instead: positions before 0 only exist for c == 0, where the previous chunk's words are forced to
+        // differ from every lane's (w ^ 0x80000000 of the lane itself)
+        const u32 wc = (u32)(kc >> lo);
+        u32 A = wc, P = c > 0 ? (u32)(kp >> lo) : (wc ^ 0x80000000u);
+        u64 partner_core = 0ULL, partner_prev = 0ULL, mine = __ballot(vc && (kc >> F) == 0ULL);
+#pragma unroll
+        for (int d = 1; d <= SUS_D; ++d) {
+            const u32 carry = (u32)__builtin_amdgcn_readlane((int)P, 63);
+            A = wave_shr1(A, carry);
+            P = wave_shr1(P, carry ^ 0x80000000u);                             // (lane 0 of the previous chunk's predecessor: unknown, made unequal)
+            const bool cand = vc && A == wc;
+            if (__ballot(cand)) {                                                // rare: fetch the partner's key, compare the hash field, then the full keys
+                const int src = lane - d;
+                const u64 ko_c = __shfl(kc, src & 63), ko_p = __shfl(kp, src & 63);
+                const u64 ko = src >= 0 ? ko_c : ko_p;
+                const bool pv = src >= 0 || c > 0;
+                const bool eq = cand && pv && (ko >> F) == (kc >> F) && L.full_key(hI, hO, ko) == L.full_key(hI, hO, kc);
+                const u64 m = __ballot(eq);
+                mine |= m;
+                partner_core |= m >> d;                                          // lane - d of this chunk ...
+                partner_prev |= m << (64 - d);                                   // ... or, for the lanes below d, lane - d + 64 of the previous one
+            }
+        }
+        // runs longer than SUS_D + 1: A now holds the words SUS_D positions back
+        {
+            const u64 S = __ballot(vc && ((A ^ wc) & rmask) == 0u && (lane >= SUS_D || c > 0));
+            if (S) {
+                u64 lc = S, lp = 0ULL;
+#pragma unroll
+                for (int j = 1; j <= SUS_D; ++j) { lc |= S >> j; lp |= S << (64 - j); }
+                mine |= lc;
+                partner_prev |= lp;
+            }
+        }
+        mine |= partner_core;
+        if (lane == 0) {
+            if (mine) atomicOr(reinterpret_cast<unsigned long long *>(suspect64 + c), (unsigned long long)mine);
+            if (partner_prev && c > 0) atomicOr(reinterpret_cast<unsigned long long *>(suspect64 + c - 1), (unsigned long long)partner_prev);
+        }
+        kp = kc; kc = kn;
+    }
+}
+__global__ void k_popc_words64(const u64 *__restrict__ bits, i64 n_words, u32 *__restrict__ counts) {
+    for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (i64)gridDim.x * blockDim.x) counts[w] = (u32)__popcll(bits[w]);
+}
+// flagged keys, in array order, to the front of `out`
+__global__ __launch_bounds__(256) void k_compact_suspects(const u64 *__restrict__ keys, const u64 *__restrict__ suspect64, const u32 *__restrict__ prefix,
+                                                           i64 n_chunks, u64 *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (i64 c = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); c < n_chunks; c += (i64)gridDim.x * 4) {
+        const u64 b = suspect64[c];
+        if (b == 0ULL) continue;                                                 // wave-uniform
+        if ((b >> lane) & 1ULL) out[(i64)prefix[c] + __popcll(b & ((1ULL << lane) - 1ULL))] = keys[c * 64 + lane];
+    }
 }
 
 // plain mode: rows/coeff of T terms.  pair mode (inner != null): T = Ni*No, term t = o*Ni + i is inner[i] ^ outer[o] with
@@ -1249,6 +1376,12 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         const int hash_bits = packed ? 64 - L.F() : 64;       // a packed key carries 64 - F >= 30 hash bits
         const int nbits = nb > hash_bits ? hash_bits : nb;
         bool in_tmp = false;
+        // what the stages after the sort see: `Tsort` keys ordered by their top `fix_bits` bits — all Tk keys, or (sus_active) only the keys
+        // that k_find_suspects flagged
+        i64 Tsort = Tk;
+        int fix_bits = nbits;
+        u64 *ks_sorted = nullptr;
+        bool sus_active = false, sus_coop = false;
         if (pair) {
             SG_TRY(hash_rows(inner, Ni, W, hI.as<u64>()));
             SG_TRY(hash_rows(outer, No, W, hO.as<u64>()));
@@ -1266,7 +1399,60 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                                        squared ? 1 : 0, thr, use_thr, markbits.as<u64>(), e_lo.as<u64>(), e_hi.as<u64>(), first_hist, 64 - nbits, n_tiles);
                     KERNEL_CHECK();
                 }
-                SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp, first_hist));
+                // products whose keys mostly merge with nothing: stop the sort one pass early and sort only the keys that have a partner
+                // (k_find_suspects).  Applies when a run of the partial order is short (<= 8 keys on average) and the operands are not
+                // one array used twice without the squared-operator compaction (then EVERY key has its twin).
+                const int n_pass = (nbits + 7) / 8;
+                int lgk = 0;
+                while (((i64)1 << lgk) < Tk) ++lgk;
+                const bool sus_env = [] { const char *e = getenv("SYMGPU_CLEANUP_SUSPECTS"); return !(e && e[0] == '0'); }();
+                const bool sus_try = lazy_a && sus_env && n_pass >= 2 && n_pass <= 5 && nbits >= 32 && lgk <= 8 * (n_pass - 1) + 2 && !(inner == outer && !squared);
+                if (!sus_try) {
+                    SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp, first_hist));
+                } else {
+                    const int lo = 64 - nbits, hi = lo + 8 * (n_pass - 1);
+                    SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, lo, hi, &in_tmp, first_hist));
+                    u64 *part = in_tmp ? keys2.as<u64>() : keys.as<u64>(), *spare = in_tmp ? keys.as<u64>() : keys2.as<u64>();
+                    const i64 n_sc = (Tk + 63) / 64;
+                    Scratch susbits, susprefix, sustotal;
+                    SG_TRY(susbits.alloc((size_t)n_sc * 8));
+                    SG_TRY(susprefix.alloc((size_t)n_sc * 4));
+                    SG_TRY(sustotal.alloc(16));
+                    HIP_TRY(hipMemsetAsync(susbits.p, 0, (size_t)n_sc * 8, st));
+                    hipLaunchKernelGGL(k_find_suspects, dim3((unsigned)((n_sc + 4 * SUS_CPW - 1) / (4 * SUS_CPW))), dim3(256), 0, st, part, Tk, lo, hi - lo, L, hI.as<u64>(),
+                                       hO.as<u64>(), susbits.as<u64>());
+                    hipLaunchKernelGGL(k_popc_words64, dim3(grid_for(n_sc)), dim3(256), 0, st, susbits.as<u64>(), n_sc, susprefix.as<u32>());
+                    KERNEL_CHECK();
+                    SG_TRY(exclusive_scan_u32(susprefix.as<u32>(), susprefix.as<u32>(), n_sc, sustotal.as<u32>()));
+                    u32 h_sus = 0;
+                    HIP_TRY(hipMemcpyAsync(&h_sus, sustotal.p, 4, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    if ((i64)h_sus * 16 > Tk || getenv("SYMGPU_CLEANUP_SUSPECTS_GIVEUP")) {
+                        // repeated rows all over: the last pass on the whole array after all (LSD: the order so far is its first passes)
+                        bool in_tmp2 = false;
+                        SG_TRY(radix_sort_keys_u64(part, spare, Tk, hi, 64, &in_tmp2));
+                        if (in_tmp2) in_tmp = !in_tmp;
+                    } else {
+                        sus_active = true;
+                        Tsort = h_sus;
+                        if (Tsort > 0) {
+                            hipLaunchKernelGGL(k_compact_suspects, dim3((unsigned)grid_for((n_sc + 3) / 4, 1, 1 << 16)), dim3(256), 0, st, part, susbits.as<u64>(),
+                                               susprefix.as<u32>(), n_sc, spare);
+                            KERNEL_CHECK();
+                            // the flagged keys, sorted completely (the same rule for the number of sorted bits, now for a few thousand keys);
+                            // `part` is not needed any more and serves as the sort's second buffer
+                            int lgs = 0;
+                            while (((i64)1 << lgs) < Tsort) ++lgs;
+                            const int want_s = (lgs + 5 + 7) / 8 * 8;
+                            fix_bits = want_s < hash_bits ? want_s : hash_bits;
+                            bool in_tmp_s = false, coop_done = false;
+                            SG_TRY(radix_sort_keys_u64_coop(spare, part, Tsort, 64 - fix_bits, 64, &in_tmp_s, &coop_done));
+                            sus_coop = coop_done;
+                            if (!coop_done) SG_TRY(radix_sort_keys_u64(spare, part, Tsort, 64 - fix_bits, 64, &in_tmp_s));
+                            ks_sorted = in_tmp_s ? part : spare;
+                        }
+                    }
+                }
             } else {
                 if (!idx.p) {
                     SG_TRY(idx.alloc((size_t)T * 4));
@@ -1291,12 +1477,12 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             KERNEL_CHECK();
         }
         if (!packed) SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), Tk, 64 - nbits, 64, &in_tmp));
-        ks = in_tmp ? keys2.as<u64>() : keys.as<u64>();
+        ks = ks_sorted ? ks_sorted : (in_tmp ? keys2.as<u64>() : keys.as<u64>());
         is = packed ? nullptr : (in_tmp ? idx2.as<u32>() : idx.as<u32>());
         HIP_TRY(hipMemsetAsync(collision.p, 0, 16, st));
         bool merges_found = false;                                     // lazy: dirtybits already filled by the fix-up passes
-        if (nbits < 64) {
-            const i64 n_ch = (Tk + 63) / 64;
+        if (fix_bits < 64 && Tsort > 0) {
+            const i64 n_ch = (Tsort + 63) / 64;
             SG_TRY(fixlist.alloc((size_t)n_ch * 8 + 16));                         // one word of flags per 64 positions
             u32 *dirty_fx = nullptr;
             if (lazy_a) {                                                           // the chunks with merged terms are found in the same pass
@@ -1306,23 +1492,26 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 dirty_fx = dirtybits.as<u32>();
                 merges_found = true;
             }
-            const dim3 gff((unsigned)grid_for((Tk + 255) / 256, 4, 8192));
+            const dim3 gff((unsigned)grid_for((Tsort + 255) / 256, 4, 8192));
             const dim3 gfw((unsigned)((n_ch + 255) / 256));
             if (packed) {
-                hipLaunchKernelGGL(k_fixup_find<true>, gff, dim3(256), 0, st, ks, Tk, 64 - nbits, hI.as<u64>(), hO.as<u64>(), L, inner == outer, fixlist.as<u64>(), dirty_fx);
-                hipLaunchKernelGGL(k_fixup_work<true>, gfw, dim3(256), 0, st, ks, (u32 *)nullptr, Tk, 64 - nbits, fixlist.as<u64>(), collision.as<u32>() + 1,
+                hipLaunchKernelGGL(k_fixup_find<true>, gff, dim3(256), 0, st, ks, Tsort, 64 - fix_bits, hI.as<u64>(), hO.as<u64>(), L, inner == outer, fixlist.as<u64>(), dirty_fx);
+                hipLaunchKernelGGL(k_fixup_work<true>, gfw, dim3(256), 0, st, ks, (u32 *)nullptr, Tsort, 64 - fix_bits, fixlist.as<u64>(), collision.as<u32>() + 1,
                                    hI.as<u64>(), hO.as<u64>(), L, inner == outer, dirty_fx);
             } else {
-                hipLaunchKernelGGL(k_fixup_find<false>, gff, dim3(256), 0, st, ks, Tk, 64 - nbits, (const u64 *)nullptr, (const u64 *)nullptr, L, false, fixlist.as<u64>(), dirty_fx);
-                hipLaunchKernelGGL(k_fixup_work<false>, gfw, dim3(256), 0, st, ks, is, Tk, 64 - nbits, fixlist.as<u64>(), collision.as<u32>() + 1,
+                hipLaunchKernelGGL(k_fixup_find<false>, gff, dim3(256), 0, st, ks, Tsort, 64 - fix_bits, (const u64 *)nullptr, (const u64 *)nullptr, L, false, fixlist.as<u64>(), dirty_fx);
+                hipLaunchKernelGGL(k_fixup_work<false>, gfw, dim3(256), 0, st, ks, is, Tsort, 64 - fix_bits, fixlist.as<u64>(), collision.as<u32>() + 1,
                                    (const u64 *)nullptr, (const u64 *)nullptr, L, false, dirty_fx);
             }
             KERNEL_CHECK();
         }
-        {
+        if (Tsort == 0) {
+            // nothing can merge (no key has a partner): every term is a single, decided by k_mark_singles
+            HIP_TRY(hipMemsetAsync(patchbits.p, 0, (size_t)((((squared && packed) ? Tk : T) + 63) / 64) * 8, st));
+        } else {
             int G = 1;                                   // lanes per verified candidate: one 16-byte chunk each
             while (G < W / 2 && G < 64) G <<= 1;
-            const i64 n_chunks = (Tk + 63) / 64;
+            const i64 n_chunks = (Tsort + 63) / 64;
             // The kernel is latency bound (dependent key load -> operand table gathers -> store per 64-position chunk; rocprofv3: 6 % of
             // the wave cycles issue, 53 % wait on memory), so it wants many short waves rather than few long ones: cfg3 6.39 / 6.16 /
             // 6.10 / 6.04 ms at 2^15 / 2^17 / 2^19 / 2^21 wavefronts (a wave also decodes the chunk after its range to close the
@@ -1338,7 +1527,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             // flow then cost more than the heads' scatter it saves (10^8 pairs with ~5 copies of every row: 6.2 ms lazy against 4.5 ms
             // filed) — every term is filed from the sorted order after all; k_mark_singles' pass was wasted (one count read-back).
             bool lazy_now = lazy_a;
-            if (lazy_a && merges_found && lazy_env != 1) {
+            if (lazy_a && merges_found && lazy_env != 1 && !sus_active) {       // (sus_active: the sorted keys ARE the merged terms)
                 u32 *dcount = collision.as<u32>() + 3;
                 hipLaunchKernelGGL(k_count_bits, dim3(grid_for((n_chunks + 31) / 32)), dim3(256), 0, st, dirtybits.as<u32>(), (n_chunks + 31) / 32, dcount);
                 KERNEL_CHECK();
@@ -1355,11 +1544,11 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             const bool zero_on = [] { const char *e = getenv("SYMGPU_CLEANUP_ZEROSEG"); return !(e && e[0] == '0'); }();
             if (squared && packed && zero_on) {
                 // the identity segment (the N diagonal pairs and whatever else multiplies to the identity) in parallel, see k_zero_partial
-                const i64 n_zb = (Tk + ZB - 1) / ZB;
+                const i64 n_zb = (Tsort + ZB - 1) / ZB;
                 SG_TRY(zpart.alloc((size_t)n_zb * 16));
                 SG_TRY(zcount.alloc((size_t)n_zb * 4 + 16));
                 u32 *zl = zcount.as<u32>() + n_zb;
-                hipLaunchKernelGGL(k_zero_partial, dim3((unsigned)n_zb), dim3(256), 0, st, ks, Tk, hI.as<u64>(), hO.as<u64>(), L, inner, W, ci,
+                hipLaunchKernelGGL(k_zero_partial, dim3((unsigned)n_zb), dim3(256), 0, st, ks, Tsort, hI.as<u64>(), hO.as<u64>(), L, inner, W, ci,
                                    zpart.as<double>(), zcount.as<u32>(), collision.as<u32>(), (u32)Ni, lazy_now ? markbits.as<u32>() : (u32 *)nullptr);
                 if (diag_side) { HIP_TRY(hipStreamWaitEvent(st, ctx().ev_join, 0)); diag_side = false; }
                 hipLaunchKernelGGL(k_zero_close, dim3(1), dim3(64), 0, st, ks, zpart.as<double>(), zcount.as<u32>(), n_zb, L, (u32)Ni, thr, use_thr,
@@ -1374,24 +1563,24 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 if (!merges_found) {
                 SG_TRY(dirtybits.alloc((size_t)n_dw * 4 + 16));
                 HIP_TRY(hipMemsetAsync(dirtybits.p, 0, (size_t)n_dw * 4 + 16, st));
-                const dim3 gf((unsigned)grid_for((Tk + 255) / 256, 4, 8192));
-                if (packed) hipLaunchKernelGGL(k_find_merges<true>, gf, dim3(256), 0, st, ks, Tk, zero_len_p, L, hI.as<u64>(), hO.as<u64>(), inner == outer ? 1 : 0, dirtybits.as<u32>());
-                else hipLaunchKernelGGL(k_find_merges<false>, gf, dim3(256), 0, st, ks, Tk, zero_len_p, L, nul, nul, 0, dirtybits.as<u32>());
+                const dim3 gf((unsigned)grid_for((Tsort + 255) / 256, 4, 8192));
+                if (packed) hipLaunchKernelGGL(k_find_merges<true>, gf, dim3(256), 0, st, ks, Tsort, zero_len_p, L, hI.as<u64>(), hO.as<u64>(), inner == outer ? 1 : 0, dirtybits.as<u32>());
+                else hipLaunchKernelGGL(k_find_merges<false>, gf, dim3(256), 0, st, ks, Tsort, zero_len_p, L, nul, nul, 0, dirtybits.as<u32>());
                 KERNEL_CHECK();
                 }
                 dirty_p = dirtybits.as<u32>();
                 gsl = dim3((unsigned)(((n_chunks + 7) / 8 + 3) / 4));
             }
             if (packed)
-                hipLaunchKernelGGL((k_heads_sums<true, true>), gsl, dim3(256), 0, st, ks, (const u32 *)nullptr, Tk, nul, W, inner, (u32)Ni, outer, G, nud,
+                hipLaunchKernelGGL((k_heads_sums<true, true>), gsl, dim3(256), 0, st, ks, (const u32 *)nullptr, Tsort, nul, W, inner, (u32)Ni, outer, G, nud,
                                    collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), L, ci, co, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0,
                                    zero_len_p, patch_p, dirty_p);
             else if (pair)
-                hipLaunchKernelGGL((k_heads_sums<true, false>), gsl, dim3(256), 0, st, ks, is, Tk, nul, W, inner, (u32)Ni, outer, G, coeff,
+                hipLaunchKernelGGL((k_heads_sums<true, false>), gsl, dim3(256), 0, st, ks, is, Tsort, nul, W, inner, (u32)Ni, outer, G, coeff,
                                    collision.as<u32>(), nul, nul, L, nud, nud, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0,
                                    (const u32 *)nullptr, patch_p, dirty_p);
             else
-                hipLaunchKernelGGL((k_heads_sums<false, false>), gsl, dim3(256), 0, st, ks, is, Tk, rows, W, nul, 1u, nul, G, coeff,
+                hipLaunchKernelGGL((k_heads_sums<false, false>), gsl, dim3(256), 0, st, ks, is, Tsort, rows, W, nul, 1u, nul, G, coeff,
                                    collision.as<u32>(), nul, nul, L, nud, nud, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0,
                                    (const u32 *)nullptr, patch_p, dirty_p);
         }
@@ -1399,6 +1588,11 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         u32 hflags[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(hflags, collision.p, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (sus_coop) {                                            // the one-launch sort of the flagged keys gave up at a barrier (GPU shared): its
+            bool timed_out = false;                                // output is garbage; the form is off now, the next attempt sorts with launches
+            SG_TRY(radix_sort_coop_check(&timed_out));
+            if (timed_out) continue;
+        }
         if (hflags[1]) { nb = 64; packed = false; squared = false; Tk = T; continue; }   // a long mixed prefix run: redo with a full 64-bit sort over all pairs, same seed
         ok = (hflags[0] == 0);
         if (!ok) { ++seed; ++g_hash_reseeds; }      // genuine 64-bit hash collision: reseed and retry

@@ -153,9 +153,36 @@ __global__ __launch_bounds__(256) void k_rs_hist(const u64 *__restrict__ keys, i
     tile_hist[(i64)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];   // digit-major
 }
 
+// Exclusive scan of the digit-major tile histograms, ONE launch per pass: block d scans row d (the counts of digit d over the tiles, in
+// tile order) in place and leaves the row's total in row_total[d]; the scatter kernel adds the exclusive scan of the 256 row totals
+// itself.  (The generic three-level exclusive_scan_u32 over all 256 * n_tiles counters was three launches and 36 us per pass at cfg3.)
+constexpr int RSS_ITEMS = 16;
+__global__ __launch_bounds__(256) void k_rs_scan_rows(u32 *__restrict__ tile_hist, i64 n_tiles, u32 *__restrict__ row_total) {
+    __shared__ u32 s_wave[4];
+    u32 *row = tile_hist + (i64)blockIdx.x * n_tiles;
+    u32 carry = 0;
+    for (i64 base = 0; base < n_tiles; base += 256 * RSS_ITEMS) {
+        const i64 b = base + (i64)threadIdx.x * RSS_ITEMS;
+        u32 v[RSS_ITEMS];
+        u32 sum = 0;
+#pragma unroll
+        for (int k = 0; k < RSS_ITEMS; ++k) { v[k] = b + k < n_tiles ? row[b + k] : 0u; sum += v[k]; }
+        u32 total;
+        u32 excl = carry + block_excl_scan_256(sum, s_wave, &total);
+#pragma unroll
+        for (int k = 0; k < RSS_ITEMS; ++k) {
+            if (b + k < n_tiles) row[b + k] = excl;
+            excl += v[k];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
+}
+
 template <bool HAS_VALS>
 __global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ keys, const u32 *__restrict__ vals, i64 n, int shift,
-                                                     i64 n_tiles, const u32 *__restrict__ tile_off /* scanned, digit-major */,
+                                                     i64 n_tiles, const u32 *__restrict__ tile_off /* scanned per digit row, digit-major */,
+                                                     const u32 *__restrict__ row_total /* [256]: keys per digit */,
                                                      u64 *__restrict__ out_keys, u32 *__restrict__ out_vals) {
     __shared__ u64 s_key[RS_TILE];
     __shared__ u32 s_val[HAS_VALS ? RS_TILE : 1];
@@ -174,7 +201,8 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ keys
     const i64 tile = (i64)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (tile >= n_tiles) return;
     const i64 tile_base = tile * RS_TILE;
-    const u32 gbase = tile_off[(i64)threadIdx.x * n_tiles + tile];            // issued first, stored to LDS behind the key loads
+    const u32 goff = tile_off[(i64)threadIdx.x * n_tiles + tile];             // issued first, stored to LDS behind the key loads
+    const u32 gtot = row_total[threadIdx.x];
     u64 key[RS_ITEMS];
     u32 val[RS_ITEMS];
     u32 pos[RS_ITEMS];
@@ -196,7 +224,10 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ keys
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
-    s_gbase[threadIdx.x] = gbase;
+    {   // global base of digit d for this tile = keys of smaller digits + keys of digit d in earlier tiles
+        u32 all;
+        s_gbase[threadIdx.x] = goff + block_excl_scan_256(gtot, s_wave, &all);
+    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
@@ -269,8 +300,9 @@ int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp,
     }
     hipStream_t st = ctx().stream;
     const i64 n_tiles = (n + RS_TILE - 1) / RS_TILE;
-    Scratch hist_own;
+    Scratch hist_own, row_total;
     if (!first_hist) SG_TRY(hist_own.alloc((size_t)n_tiles * 256 * sizeof(u32)));
+    SG_TRY(row_total.alloc(256 * sizeof(u32)));
     u32 *hist_p = first_hist ? first_hist : hist_own.as<u32>();
     u64 *ksrc = keys, *kdst = keys_tmp;
     u32 *vsrc = vals, *vdst = vals_tmp;
@@ -280,12 +312,13 @@ int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp,
             hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)n_tiles), dim3(256), 0, st, ksrc, n, shift, n_tiles, hist_p);
             KERNEL_CHECK();
         }
-        SG_TRY(exclusive_scan_u32(hist_p, hist_p, n_tiles * 256, nullptr));
+        hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, st, hist_p, n_tiles, row_total.as<u32>());
         if (vals)
-            hipLaunchKernelGGL(k_rs_scatter<true>, dim3((unsigned)((n_tiles + 7) / 8 * 8)), dim3(256), 0, st, ksrc, vsrc, n, shift, n_tiles, hist_p, kdst, vdst);
+            hipLaunchKernelGGL(k_rs_scatter<true>, dim3((unsigned)((n_tiles + 7) / 8 * 8)), dim3(256), 0, st, ksrc, vsrc, n, shift, n_tiles, hist_p,
+                               row_total.as<u32>(), kdst, vdst);
         else
             hipLaunchKernelGGL(k_rs_scatter<false>, dim3((unsigned)((n_tiles + 7) / 8 * 8)), dim3(256), 0, st, ksrc, (const u32 *)nullptr, n, shift, n_tiles,
-                               hist_p, kdst, (u32 *)nullptr);
+                               hist_p, row_total.as<u32>(), kdst, (u32 *)nullptr);
         KERNEL_CHECK();
         u64 *tk = ksrc; ksrc = kdst; kdst = tk;
         u32 *tv = vsrc; vsrc = vdst; vdst = tv;
