@@ -15,6 +15,7 @@
 //           input positions (qiskit `unordered_unique` order, utils.py:271) -> gather surviving rows.
 #include "common.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <vector>
 
 namespace symgpu {
@@ -869,7 +870,7 @@ static i64 emit_batch_words() {                                  // SYMGPU_EMIT_
 // where k_emit_meta takes a kept term's coefficient from: mode 0 = the filed sums only; 1 / 2 = filed sums for patched terms, the
 // operand tables (packed products) / the input coefficients (indexed operators) for all others (k_mark_singles)
 struct LazyEmit {
-    int mode = 0, squared = 0;
+    int mode = 0, squared = 0, no_one_outer = 0;
     const u32 *patchbits = nullptr, *e_lo = nullptr, *e_hi = nullptr;
     const double *ci = nullptr, *co = nullptr, *coeff = nullptr;
 };
@@ -971,32 +972,32 @@ __global__ __launch_bounds__(256) void k_emit_stream(const uint2 *__restrict__ m
 // step, into [prefix, prefix + K): consecutive wavefronts and workgroups write consecutive pieces (a workgroup's four words make
 // ~32 KB at n = 1000), so the chip still writes one moving window.  No list, no batches, no second launch: with the sums of the
 // singles no longer read back from HBM (k_mark_singles) nothing but the bitmaps is read beside the row stream.
-constexpr int EF_NW = 4;                                              // bitmap words per wavefront
-template <bool PAIR, bool TRI>
+// NW = bitmap words per wavefront (4: the dependent chain bitmap -> prefix -> phase / patch bits -> operand tables is paid once per 256
+// indices; a wavefront per word spent two thirds of its life in it: 4.5 TB/s), U = steps of 64 chunks in flight
+template <bool PAIR, bool TRI, int NW, int U>
 __global__ __launch_bounds__(256) void k_emit_fused(const u64 *__restrict__ markbits64, const u32 *__restrict__ wordprefix, i64 T, const double *__restrict__ sum_of,
                                                      u32 Ni, int Wq, int wsh, const u32x4 *__restrict__ rows, const u32x4 *__restrict__ inner,
                                                      const u32x4 *__restrict__ outer, u32x4 *__restrict__ out_rows, double *__restrict__ out_coeff, LazyEmit lz) {
-    __shared__ u32 s_i[4][64 * EF_NW], s_o[4][64 * EF_NW];
+    __shared__ u32 s_i[4][64 * NW], s_o[4][64 * NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const i64 w0 = ((i64)blockIdx.x * 4 + wave) * EF_NW;
+    const i64 w0 = ((i64)blockIdx.x * 4 + wave) * NW;
     if (w0 * 64 >= T) return;
-    // EF_NW words per wavefront: the dependent chain bitmap -> prefix -> phase / patch bits -> operand tables is paid once per 256
-    // indices (a wavefront per word spent two thirds of its life in it: 4.5 TB/s)
-    u64 bits[EF_NW];
-    u32 off[EF_NW + 1];
+    u64 bits[NW];
+    u32 off[NW + 1];
     off[0] = 0;
 #pragma unroll
-    for (int u = 0; u < EF_NW; ++u) {
+    for (int u = 0; u < NW; ++u) {
         const i64 w = w0 + u;
         bits[u] = w * 64 < T ? markbits64[w] : 0ULL;
         if (w * 64 < T && T - w * 64 < 64) bits[u] &= (1ULL << (T - w * 64)) - 1ULL;   // the bitmap's last word may be half written (32-bit words)
         off[u + 1] = off[u] + (u32)__popcll(bits[u]);
     }
-    const u32 K = off[EF_NW];
+    const u32 K = off[NW];
     if (K == 0) return;                                              // wave-uniform
     const i64 p_base = wordprefix[2 * w0];
+    u32 o_min = 0xFFFFFFFFu, o_max = 0u;                             // this lane's kept terms: range of their outer indices
 #pragma unroll
-    for (int u = 0; u < EF_NW; ++u) {
+    for (int u = 0; u < NW; ++u) {
         if ((bits[u] >> lane) & 1ULL) {
             const u32 rank = off[u] + (u32)__popcll(bits[u] & ((1ULL << lane) - 1ULL));
             const u32 t = (u32)((w0 + u) * 64 + lane);
@@ -1020,6 +1021,7 @@ __global__ __launch_bounds__(256) void k_emit_fused(const u64 *__restrict__ mark
             }
             reinterpret_cast<double2 *>(out_coeff)[p_base + rank] = cf;
             s_i[wave][rank] = ti; s_o[wave][rank] = to;
+            o_min = to < o_min ? to : o_min; o_max = to > o_max ? to : o_max;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1027,18 +1029,45 @@ __global__ __launch_bounds__(256) void k_emit_fused(const u64 *__restrict__ mark
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const u32 n_ch = K * (u32)Wq;
     u32x4 *dst = out_rows + p_base * Wq;
-    constexpr int EF_U = 4;                                           // steps of 64 chunks in flight
-    for (u32 f0 = 0; f0 < n_ch; f0 += 64 * EF_U) {
-        u32x4 v[EF_U];
+    // One outer row for the whole wavefront (a product's terms are ordered by their outer index, so 256 consecutive indices nearly always
+    // share it) and a row length that divides 64: the lane's chunk of that row is loop invariant — one gather and one list read per
+    // 16 bytes written instead of two each.
+    bool one_outer = false;
+    if (PAIR && wsh >= 0 && Wq <= 64 && !lz.no_one_outer) {
 #pragma unroll
-        for (int u = 0; u < EF_U; ++u) {
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const u32 a = (u32)__shfl_xor((int)o_min, sft), b = (u32)__shfl_xor((int)o_max, sft);
+            o_min = a < o_min ? a : o_min; o_max = b > o_max ? b : o_max;
+        }
+        one_outer = o_min == o_max;                                   // wave-uniform
+    }
+    if (one_outer) {
+        const u32x4 oc = outer[(i64)o_min * Wq + (lane & (Wq - 1))];
+        for (u32 f0 = 0; f0 < n_ch; f0 += 64 * U) {
+            u32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const u32 f = f0 + 64 * u + lane < n_ch ? f0 + 64 * u + lane : n_ch - 1;
+                const u32 r = f >> wsh;
+                v[u] = inner[(i64)s_i[wave][r] * Wq + (lane & (Wq - 1))] ^ oc;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (f0 + 64 * u + lane < n_ch) __builtin_nontemporal_store(v[u], dst + f0 + 64 * u + lane);
+        }
+        return;
+    }
+    for (u32 f0 = 0; f0 < n_ch; f0 += 64 * U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             const u32 f = f0 + 64 * u + lane < n_ch ? f0 + 64 * u + lane : n_ch - 1;
             const u32 r = wsh >= 0 ? f >> wsh : f / (u32)Wq;
             const u32 c = f - r * (u32)Wq;
             v[u] = PAIR ? (inner[(i64)s_i[wave][r] * Wq + c] ^ outer[(i64)s_o[wave][r] * Wq + c]) : rows[(i64)s_i[wave][r] * Wq + c];
         }
 #pragma unroll
-        for (int u = 0; u < EF_U; ++u)
+        for (int u = 0; u < U; ++u)
             if (f0 + 64 * u + lane < n_ch) __builtin_nontemporal_store(v[u], dst + f0 + 64 * u + lane);
     }
 }
@@ -1117,7 +1146,11 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
         const bool fused = Wq <= 64 && [] { const char *e = getenv("SYMGPU_EMIT_FUSED"); return !(e && e[0] == '0'); }();
         if (fused) {
             const i64 n_w64 = (T + 63) / 64;
-            const dim3 gfu((unsigned)((n_w64 + 4 * EF_NW - 1) / (4 * EF_NW)));
+            // wavefront shape: bitmap words per wavefront x 64-chunk steps in flight (SYMGPU_EMIT_SHAPE = "NW,U": experiments)
+            static const int shape = [] { const char *e = getenv("SYMGPU_EMIT_SHAPE"); int nw = 2, u = 4; if (e) sscanf(e, "%d,%d", &nw, &u); return nw * 16 + u; }();
+            const int NWs = shape / 16, Us = shape % 16;
+            const int NWr = (NWs == 1 || NWs == 4 || NWs == 8) ? NWs : 2;   // 2 words per wavefront, 4 steps in flight: 1.20 ms at cfg3 (4,4: 1.30; 1,4: 1.24; 2,8: 1.22)
+            const dim3 gfu((unsigned)((n_w64 + 4 * NWr - 1) / (4 * NWr)));
             static const bool touch_on = [] { const char *e = getenv("SYMGPU_EMIT_TOUCH"); return !(e && e[0] == '0'); }();
             if (touch_on) {
                 const i64 n16 = n_w64 / 2;                              // whole 16-byte chunks of a T-bit map
@@ -1129,9 +1162,14 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
                                            total.as<u32>() + 2);
             }
             ProfScope prof(3);
-#define LAUNCH_FUSED(P, TR) hipLaunchKernelGGL((k_emit_fused<P, TR>), gfu, dim3(256), 0, st, reinterpret_cast<const u64 *>(markbits_p), wordprefix.as<u32>(), T, sum_of_p, \
+#define LAUNCH_FUSED_S(P, TR, NWV, UV) hipLaunchKernelGGL((k_emit_fused<P, TR, NWV, UV>), gfu, dim3(256), 0, st, reinterpret_cast<const u64 *>(markbits_p), wordprefix.as<u32>(), T, sum_of_p, \
                                                (u32)(pair ? Ni : 1), Wq, wsh, reinterpret_cast<const u32x4 *>(rows), pin, pout, dst, res->coeff, lz)
+#define LAUNCH_FUSED_U(P, TR, NWV) do { if (Us == 8) LAUNCH_FUSED_S(P, TR, NWV, 8); else if (Us == 2) LAUNCH_FUSED_S(P, TR, NWV, 2); else LAUNCH_FUSED_S(P, TR, NWV, 4); } while (0)
+#define LAUNCH_FUSED(P, TR) do { if (NWr == 1) LAUNCH_FUSED_U(P, TR, 1); else if (NWr == 4) LAUNCH_FUSED_U(P, TR, 4); else if (NWr == 8) LAUNCH_FUSED_U(P, TR, 8); \
+                                 else LAUNCH_FUSED_U(P, TR, 2); } while (0)
             if (pair && tri) LAUNCH_FUSED(true, true); else if (pair) LAUNCH_FUSED(true, false); else LAUNCH_FUSED(false, false);
+#undef LAUNCH_FUSED_S
+#undef LAUNCH_FUSED_U
 #undef LAUNCH_FUSED
         } else {
         const int rc_env = [] { const char *e = getenv("SYMGPU_EMIT_RC"); return e ? atoi(e) : 2; }();     // chunks per lane: 1: 115, 2: 97, 4: 97 us per batch
@@ -1603,6 +1641,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
     }
     const bool tri = squared && packed;
     LazyEmit lz;
+    lz.no_one_outer = getenv("SYMGPU_EMIT_NO_ONE_OUTER") ? 1 : 0;
     if (lazy_final) {
         lz.mode = packed ? 1 : 2; lz.squared = tri ? 1 : 0;
         lz.patchbits = patchbits.as<u32>(); lz.e_lo = e_lo.as<u32>(); lz.e_hi = e_hi.as<u32>();
