@@ -137,10 +137,76 @@ __device__ __forceinline__ void panel_loop(const u64 *__restrict__ rows, i64 Wc,
     }
 }
 
+// The same loop on a TWO-word window, written for its DEPENDENT CHAIN (round 4: the panel is the critical path of every block — 64 pivots,
+// one after the other, 560 cycles each in the generic loop, nearly all of it pipeline latency between the vector and the scalar unit:
+// readlane -> scalar find -> vector test -> ballot -> scalar mask -> EXEC -> vector update -> readlane ...).  Here the chain of a pivot is
+// six v_readlane (issued together) -> branch-free scalar arithmetic (s_ff1 on the two window words, one-hot masks) -> ONE vector block:
+// the holders of the pivot column as an all-ones / zero word per lane (four and/or, compare, select) and the update as six v_bitop3
+// x ^= p & m — no EXEC-masked update, no ballot on the way to the next pivot.  Row j itself is kept out with EXEC (it holds the column it
+// pivots on); the holder mask for the records is the compare's VCC, filed into lane j afterwards (off the chain).
+__device__ __forceinline__ void panel_loop_narrow(const u64 *__restrict__ rows, i64 Wc, i64 i0, int lane, bool valid, int w_lo, u64 in_m, u64 todo,
+                                                  int &kk, int &pw, int &pb, u64 &my_mask, u64 &tv, const u64 *spec, int w_spec, int &w_max) {
+    u64 C[2];
+    if (w_spec == w_lo) { C[0] = spec[0]; C[1] = spec[1]; }
+    else {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) C[k] = (valid && (i64)w_lo + k < Wc) ? rows[(i0 + lane) * Wc + w_lo + k] : 0ULL;
+    }
+    u32 c0 = (u32)C[0], c1 = (u32)(C[0] >> 32), c2 = (u32)C[1], c3 = (u32)(C[1] >> 32), t0 = (u32)tv, t1 = (u32)(tv >> 32);
+    u32 pw_v = (u32)pw, pb_v = (u32)pb, mlo_v = (u32)my_mask, mhi_v = (u32)(my_mask >> 32);
+    const int w_lo_s = __builtin_amdgcn_readfirstlane(w_lo);
+    while (todo) {
+        const int j = __builtin_ctzll(todo);
+        const u32 p0 = __builtin_amdgcn_readlane(c0, j), p1 = __builtin_amdgcn_readlane(c1, j), p2 = __builtin_amdgcn_readlane(c2, j),
+                  p3 = __builtin_amdgcn_readlane(c3, j), q0 = __builtin_amdgcn_readlane(t0, j), q1 = __builtin_amdgcn_readlane(t1, j);
+        const u64 P0 = ((u64)p1 << 32) | p0, P1 = ((u64)p3 << 32) | p2;
+        // (rare exits, one test: the row leads outside the window, or it cancelled to zero inside it)
+        if (!((in_m >> j) & 1ULL) || (P0 | P1) == 0ULL) { kk = j; break; }
+        const int hiw = P0 == 0ULL ? 1 : 0;                                     // the pivot sits in the second window word
+        const int b = __builtin_ctzll(hiw ? P1 : P0);
+        const u64 oh = 1ULL << b, M0 = hiw ? 0ULL : oh, M1 = hiw ? oh : 0ULL;   // one-hot over the window
+        const u64 onej = 1ULL << j;
+        u64 mk;
+        u32 t;
+        asm volatile("s_andn2_b64 exec, -1, %[onej]\n\t"
+                     "v_and_b32 %[t], %[m0], %[c0]\n\t"
+                     "v_and_or_b32 %[t], %[c1], %[m1], %[t]\n\t"
+                     "v_and_or_b32 %[t], %[c2], %[m2], %[t]\n\t"
+                     "v_and_or_b32 %[t], %[c3], %[m3], %[t]\n\t"
+                     "v_cmp_ne_u32 vcc, 0, %[t]\n\t"
+                     "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"
+                     "v_bitop3_b32 %[c0], %[c0], %[p0], %[t] bitop3:0x78\n\t"
+                     "v_bitop3_b32 %[c1], %[c1], %[p1], %[t] bitop3:0x78\n\t"
+                     "v_bitop3_b32 %[c2], %[c2], %[p2], %[t] bitop3:0x78\n\t"
+                     "v_bitop3_b32 %[c3], %[c3], %[p3], %[t] bitop3:0x78\n\t"
+                     "v_bitop3_b32 %[t0], %[t0], %[q0], %[t] bitop3:0x78\n\t"
+                     "v_bitop3_b32 %[t1], %[t1], %[q1], %[t] bitop3:0x78\n\t"
+                     "s_mov_b64 %[mk], vcc\n\t"
+                     "s_mov_b64 exec, -1"
+                     : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3), [t0] "+v"(t0), [t1] "+v"(t1), [t] "=&v"(t), [mk] "=&s"(mk)
+                     : [onej] "s"(onej), [m0] "s"((u32)M0), [m1] "s"((u32)(M0 >> 32)), [m2] "s"((u32)M1), [m3] "s"((u32)(M1 >> 32)),
+                       [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [p3] "s"(p3), [q0] "s"(q0), [q1] "s"(q1)
+                     : "vcc");
+        todo &= todo - 1;
+        const int wabs = w_lo_s + hiw;
+        w_max = wabs > w_max ? wabs : w_max;
+        // the pivot's records into lane j (EXEC = {j}); nothing of the next pivot depends on them
+        asm volatile("s_mov_b64 exec, %[onej]\n\t"
+                     "v_mov_b32 %[pw], %[vw]\n\t"
+                     "v_mov_b32 %[pb], %[vb]\n\t"
+                     "v_mov_b32 %[ml], %[vl]\n\t"
+                     "v_mov_b32 %[mh], %[vh]\n\t"
+                     "s_mov_b64 exec, -1"
+                     : [pw] "+v"(pw_v), [pb] "+v"(pb_v), [ml] "+v"(mlo_v), [mh] "+v"(mhi_v)
+                     : [onej] "s"(onej), [vw] "s"(wabs), [vb] "s"(b), [vl] "s"((u32)mk), [vh] "s"((u32)(mk >> 32)));
+    }
+    pw = (int)pw_v; pb = (int)pb_v; my_mask = ((u64)mhi_v << 32) | mlo_v; tv = ((u64)t1 << 32) | t0;
+}
+
 // the panel proper: ONE wavefront (lane = block row), `a` = this lane's leading word (lead[] semantics), block starts at i0
 __device__ __forceinline__ void panel_wave(const u64 *__restrict__ rows, i64 R, i64 Wc, i64 i0, int a, int lane, SweepState *__restrict__ st,
                                            BlockInfo *__restrict__ info, i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count,
-                                           const u64 *spec = nullptr, int w_spec = -1) {
+                                           const u64 *spec = nullptr, int w_spec = -1, int lean = 1) {
     if (i0 >= R) { if (lane == 0) { info->i0 = i0; info->kk = 0; info->w_next = -1; } return; }
     int w_max = -1;
     u64 no_spec[WN] = {0, 0, 0, 0};
@@ -163,7 +229,9 @@ __device__ __forceinline__ void panel_wave(const u64 *__restrict__ rows, i64 R, 
         const int wn = narrow ? 2 : WN;
         const u64 in_m = __ballot(valid && a != NOLEAD && a >= w_lo && a < w_lo + wn);
         const u64 todo0 = (n_valid >= 64 ? ~0ULL : ((1ULL << n_valid) - 1ULL)) & ~zero_m;
-        if (narrow) panel_loop<2>(rows, Wc, i0, lane, valid, w_lo, in_m, todo0, kk, pw, pb, my_mask, tv, spec, w_spec, w_max);
+        static_assert(WN >= 2, "narrow window");
+        if (narrow && lean) panel_loop_narrow(rows, Wc, i0, lane, valid, w_lo, in_m, todo0, kk, pw, pb, my_mask, tv, spec, w_spec, w_max);
+        else if (narrow) panel_loop<2>(rows, Wc, i0, lane, valid, w_lo, in_m, todo0, kk, pw, pb, my_mask, tv, spec, w_spec, w_max);
         else panel_loop<WN>(rows, Wc, i0, lane, valid, w_lo, in_m, todo0, kk, pw, pb, my_mask, tv, spec, w_spec, w_max);
     }
     // publish: only rows < kk belong to the block
@@ -252,9 +320,9 @@ __device__ __forceinline__ void panel_full(const u64 *__restrict__ rows, i64 R, 
 }
 
 __global__ __launch_bounds__(64) void k_wpanel(const u64 *__restrict__ rows, i64 R, i64 Wc, SweepState *__restrict__ st, const int *__restrict__ lead,
-                                                BlockInfo *__restrict__ info, i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count) {
+                                                BlockInfo *__restrict__ info, i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count, int lean) {
     const i64 i0 = st->next_i0;
-    panel_wave(rows, R, Wc, i0, i0 < R ? lead[threadIdx.x] : -1, threadIdx.x, st, info, pivots, xor_count);
+    panel_wave(rows, R, Wc, i0, i0 < R ? lead[threadIdx.x] : -1, threadIdx.x, st, info, pivots, xor_count, nullptr, -1, lean);
 }
 
 // selectors of all rows (in terms of the OLD block rows), reference-order XOR count, snapshot of the old block rows.
@@ -384,6 +452,7 @@ struct FusedSelect {
     u32 epoch;
     u32 *fail;                                  // a tile workgroup gave up waiting
     int full_panel;                             // 1: the panel may switch to the full rows in LDS (panel_full)
+    int lean_panel;                             // 1: two-word windows run panel_loop_narrow (0: the generic loop; tests)
 };
 template <int PHASE>
 __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64 R, i64 Wc, const BlockInfo *__restrict__ info,
@@ -463,7 +532,7 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
             if (s_ok) {
                 if (wave != 0) a = 0;
                 panel_full(rows, R, Wc, i0n, a, tab, s_sel, st, info_next, pivots, xor_count);
-            } else if (wave == 0) panel_wave(rows, R, Wc, i0n, a, lane, st, info_next, pivots, xor_count, spec, w_spec);
+            } else if (wave == 0) panel_wave(rows, R, Wc, i0n, a, lane, st, info_next, pivots, xor_count, spec, w_spec, fs.lean_panel);
             return;
         }
         --k;
@@ -479,6 +548,25 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
     const i64 w = (i64)tile * M4_TW + lane;
     const bool live = w < Wc;
     const i64 wl = live ? w : Wc - 1;
+    // ---- stream the rows: M4_U per wave and step, software pipelined (the loads of step i+1 are in flight while step i
+    //      does its table look-ups: a wave only runs a handful of steps, so nothing else would hide the load latency) ----
+    const i64 shift = ne - nb;
+    const i64 step = M4_U * (M4_NT / 64);
+    i64 rn[M4_U];
+    u64 xn[M4_U], sn[M4_U];
+    auto fetch = [&](i64 v0, bool with_sel) {
+#pragma unroll
+        for (int u = 0; u < M4_U; ++u) {
+            const i64 v = v0 + u < v_hi ? v0 + u : (v0 < v_hi ? v0 : v_lo);   // tail: surplus slots repeat a valid row, never stored
+            rn[u] = P0 ? nb + v : (v < nb ? v : v + shift);
+            if (with_sel) sn[u] = kk != 0 ? (PHASE == 3 ? s_sel[rn[u] - nb] : sel[rn[u]]) : 0ULL;
+            xn[u] = rows[rn[u] * Wc + wl];
+        }
+    };
+    i64 v0 = v_lo + M4_U * wave;
+    // phases 1 / 2: the first rows and their selectors are on their way while the tables are built (round 4: the loads used to start behind
+    // the table build and its barrier, 2-3 us of every 15 us launch with nothing in flight)
+    if (PHASE != 3 && v0 < v_hi) fetch(v0, true);
     // ---- tabulate the XOR combinations of the old block rows ----
     if (kk != 0) {
         for (int g = wave; g < 16; g += M4_NT / 64) {
@@ -496,22 +584,6 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
             for (int e = 0; e < 16; ++e) tab[(g * 16 + e) * M4_TW + lane] = t[e];
         }
     }
-    // ---- stream the rows: M4_U per wave and step, software pipelined (the loads of step i+1 are in flight while step i
-    //      does its table look-ups: a wave only runs a handful of steps, so nothing else would hide the load latency) ----
-    const i64 shift = ne - nb;
-    const i64 step = M4_U * (M4_NT / 64);
-    i64 rn[M4_U];
-    u64 xn[M4_U], sn[M4_U];
-    auto fetch = [&](i64 v0, bool with_sel) {
-#pragma unroll
-        for (int u = 0; u < M4_U; ++u) {
-            const i64 v = v0 + u < v_hi ? v0 + u : (v0 < v_hi ? v0 : v_lo);   // tail: surplus slots repeat a valid row, never stored
-            rn[u] = P0 ? nb + v : (v < nb ? v : v + shift);
-            if (with_sel) sn[u] = kk != 0 ? (PHASE == 3 ? s_sel[rn[u] - nb] : sel[rn[u]]) : 0ULL;
-            xn[u] = rows[rn[u] * Wc + wl];
-        }
-    };
-    i64 v0 = v_lo + M4_U * wave;
     if (PHASE == 3) {
         // the rows themselves do not depend on the selectors: their loads are issued before the wait
         if (v0 < v_hi) fetch(v0, false);
@@ -539,7 +611,7 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
     if (PHASE == 3) {
 #pragma unroll
         for (int u = 0; u < M4_U; ++u) sn[u] = (kk != 0 && v0 < v_hi) ? s_sel[rn[u] - nb] : 0ULL;
-    } else if (v0 < v_hi) fetch(v0, true);
+    }
     for (; v0 < v_hi; v0 += step) {
         i64 r[M4_U];
         u64 x[M4_U];
@@ -688,6 +760,7 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     fs.sel = sel.as<u64>(); fs.snap = snap.as<u64>(); fs.rowcnt = rowcnt.as<u32>(); fs.ready = ready.as<u64>(); fs.epoch = 0;
     fs.fail = reinterpret_cast<u32 *>(count.p) + 2;
     fs.full_panel = [] { const char *e = getenv("SYMGPU_GF2_FULL_PANEL"); return !(e && e[0] == '0'); }() ? 1 : 0;
+    fs.lean_panel = [] { const char *e = getenv("SYMGPU_GF2_LEAN_PANEL"); return !(e && e[0] == '0'); }() ? 1 : 0;
     if (lookahead && m4r && (i64)m4_tiles * m4_chunks + 1 < ((i64)1 << 31)) {
         // Pipeline, three launches per block: select(b) -> phase 0: sweep of the rows of block b+1 + their leading words ->
         // phase 1: panel of block b+1 (-> the other info buffer) inside the sweep of all remaining rows.  The very first
@@ -742,7 +815,7 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
         for (i64 it = 0; it < n_iter; ++it) {
             hipLaunchKernelGGL(k_lead, dim3(WK / 4), dim3(256), 0, st, rows, R, Wc, state.as<SweepState>(), lead.as<int>());
             hipLaunchKernelGGL(k_wpanel, dim3(1), dim3(64), 0, st, rows, R, Wc, state.as<SweepState>(), lead.as<int>(), binfo,
-                               piv.as<i64>(), count.as<unsigned long long>());
+                               piv.as<i64>(), count.as<unsigned long long>(), fs.lean_panel);
             hipLaunchKernelGGL(k_select, dim3(gsel), dim3(256), 0, st, rows, R, Wc, binfo, sel.as<u64>(), snap.as<u64>(),
                                rowcnt.as<u32>());
             ProfScope prof(2);
