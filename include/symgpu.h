@@ -170,6 +170,21 @@ int symgpu_symmetry_kernel(const uint64_t *H, int64_t M, int n_qubits, int Wq,
 int symgpu_symmetry_kernel_dev(symgpu_op_t H, int n_qubits, uint64_t *out, int64_t capacity, int64_t *k,
                                int64_t *xor_count);
 
+/* ---- f3 / f4: the callers next to the hot path, device side -----------------------------------------------------------
+ * symgpu_project_dev   S3Projection._perform_projection (symmer/projection/base.py:44-84) on an operator that has already been taken
+ *   through the stabiliser rotations: terms that anticommute with any of the k fixed (single-qubit) stabiliser rows vanish; the others
+ *   are multiplied by (-1)^|row & neg_mask| (neg_mask: the symplectic positions of the stabilisers with eigenvalue -1, i.e. the product
+ *   of eigenvalues over the occupied stabilised positions, :68-71); the qubits not listed in keep_qubits (ascending) are deleted and equal
+ *   terms merged with the cleanup's semantics (:82).  stab_rows [k][2*Wq], neg_mask [2*Wq], keep_qubits [n_keep >= 1]: host arrays.
+ * symgpu_noncontextual_dev   PauliwordOp.is_noncontextual (base.py:1074-1088, check_adjmat_noncontextual utils.py:567-589): 1 iff the
+ *   terms that do not commute with every term split into disjoint cliques of the commutation graph.
+ * symgpu_state_inner_dev   QuantumState bra * ket (base.py:1808-1815): sum over the basis rows present in both CLEANED states of
+ *   c_a * c_b, added in the order of a's rows (pass the state with fewer terms as a, as the reference does).  out: double[2]. */
+int symgpu_project_dev(symgpu_op_t op, const uint64_t *stab_rows, int k, const uint64_t *neg_mask, const int *keep_qubits, int n_keep,
+                       int n_qubits, double thr, int use_thr, symgpu_op_t *out, int64_t *n_survived /* may be NULL: terms that commute with every stabiliser */);
+int symgpu_noncontextual_dev(symgpu_op_t op, int *is_noncontextual);
+int symgpu_state_inner_dev(symgpu_op_t a, symgpu_op_t b, double *out);
+
 /* ---- e: multi-GPU (one process per GPU; RCCL over xGMI) ------------------------------------------- */
 #define SYMGPU_UNIQUE_ID_BYTES 128
 int symgpu_comm_available(void);                                                /* librccl loadable? (no device, no collective) */

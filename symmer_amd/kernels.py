@@ -278,3 +278,38 @@ def symmetry_kernel(h_rows, n_qubits):
     check(_lib.lib().symgpu_symmetry_kernel(addr(h_rows), h_rows.shape[0], int(n_qubits), wq, addr(out), 2 * n_qubits,
                                             ctypes.addressof(k), ctypes.addressof(count)))
     return out[:k.value].copy(), count.value
+
+
+# ---- f3 / f4: projection, noncontextuality test, state inner product -------------------------------------------------
+def project_dev(op, stab_rows, eigenvalues, keep_qubits, n_qubits, zero_threshold=1e-15):
+    """``S3Projection._perform_projection`` (projection/base.py:44-84) on a device operator: ``stab_rows`` uint64[k, 2*Wq] the fixed
+    single-qubit stabilisers, ``eigenvalues`` int[k] their sector, ``keep_qubits`` the ascending indices of the qubits that stay.
+    Returns (cleaned projected DeviceOp, number of terms that commuted with every stabiliser)."""
+    stab_rows = np.ascontiguousarray(stab_rows, dtype='<u8').reshape(-1, stab_rows.shape[-1]) if len(stab_rows) else np.zeros((0, 2), dtype='<u8')
+    k = stab_rows.shape[0]
+    wq = op.info()[1]
+    neg = np.zeros(2 * wq, dtype='<u8')
+    for row, ev in zip(stab_rows, np.asarray(eigenvalues).ravel()):
+        if ev == -1:
+            neg |= row                                             # (projection/base.py:69: the column index list has one entry per stabiliser)
+    keep = np.ascontiguousarray(keep_qubits, dtype=np.int32)
+    thr, use = _thr_args(zero_threshold)
+    out = ctypes.c_void_p()
+    n_surv = c_i64(0)
+    check(_lib.lib().symgpu_project_dev(op.handle, addr(stab_rows) if k else None, k, addr(neg), addr(keep), keep.shape[0], int(n_qubits), thr, use,
+                                        ctypes.byref(out), ctypes.addressof(n_surv)))
+    return DeviceOp(out), n_surv.value
+
+
+def noncontextual_dev(op):
+    res = c_int(0)
+    check(_lib.lib().symgpu_noncontextual_dev(op.handle, ctypes.addressof(res)))
+    return bool(res.value)
+
+
+def state_inner_dev(a, b):
+    """Inner product of two CLEANED device states (operators whose X blocks are the basis strings): sum of c_a * c_b over the rows present
+    in both, added in the order of ``a``."""
+    out = np.zeros(2, dtype=np.float64)
+    check(_lib.lib().symgpu_state_inner_dev(a.handle, b.handle, addr(out)))
+    return complex(out[0], out[1])

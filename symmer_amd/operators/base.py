@@ -383,10 +383,16 @@ class PauliwordOp:
 
     @cached_property
     def is_noncontextual(self) -> bool:
-        """base.py:1074-1088: O(M^2) test on the adjacency matrix (computed on the device)."""
+        """base.py:1074-1088 / utils.py:567-589, all of it on the device (csrc/project.hip): bit-packed adjacency rows, the rows of the
+        terms that do not commute with everything restricted to those terms, unique rows by the cleanup kernels, disjointness of the
+        unique rows as a popcount identity — the M x M matrix never exists as bytes and never leaves the GPU."""
         if self.n_terms < 4:
             return True
-        return check_adjmat_noncontextual(self.adjacency_matrix)
+        dev = kernels.DeviceOp.upload(self.packed)
+        try:
+            return kernels.noncontextual_dev(dev)
+        finally:
+            dev.free()
 
     # ---- graph glue on the device-computed adjacency matrix (reference base.py:985-1364; networkx, host) ------------
     def qubitwise_commutes_termwise(self, PwordOp: "PauliwordOp") -> np.ndarray:

@@ -94,12 +94,19 @@ class QuantumState:
         assert self.vec_type == 'bra', 'Cannot multiply a ket from the right'
         if isinstance(mul_obj, QuantumState):
             assert mul_obj.vec_type == 'ket', 'Cannot multiply a bra with another bra'
+            # base.py:1808-1815: the state with fewer terms is the left one; both are cleaned (to_dictionary, :2104), then the coefficients
+            # of the basis strings they share are multiplied and added in the left state's order — here a hash join of the packed
+            # basis rows on the device (csrc/project.hip), the products added in that same order
             left, right = (self, mul_obj) if self.state_op.n_terms < mul_obj.n_terms else (mul_obj, self)
-            right_dict = right.to_dictionary
-            inner_product = 0
-            for bstring, left_coeff in left.to_dictionary.items():
-                inner_product += left_coeff * right_dict.get(bstring, 0)
-            return inner_product
+            from .. import kernels
+            ups = [kernels.DeviceOp.upload(s.state_op.packed, s.state_op.coeff_vec) for s in (left, right)]
+            cleaned = []
+            try:
+                cleaned = [kernels.cleanup_dev(u) for u in ups]
+                return kernels.state_inner_dev(cleaned[0], cleaned[1])
+            finally:
+                for h in ups + cleaned:
+                    h.free()
         if isinstance(mul_obj, PauliwordOp):
             new_state_op = self.state_op * mul_obj
             coeff = new_state_op.coeff_vec * ((-1j) ** new_state_op.Y_count)

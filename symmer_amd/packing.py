@@ -55,3 +55,11 @@ def unpack_rows(packed, n_qubits):
     out[:, :n_qubits] = unpack_bits(packed[:, :wq], n_qubits)
     out[:, n_qubits:] = unpack_bits(packed[:, wq:], n_qubits)
     return out
+
+
+def popcount_rows(packed):
+    """uint64[T, W] -> int64[T]: set bits per row."""
+    packed = np.ascontiguousarray(packed, dtype='<u8')
+    if packed.shape[0] == 0:
+        return np.zeros(0, dtype=np.int64)
+    return np.bitwise_count(packed).sum(axis=1, dtype=np.int64)

@@ -5,6 +5,7 @@ duplicate cleanup) runs on the MI355X through ``PauliwordOp``; the index bookkee
 from typing import List, Union
 import numpy as np
 from ..operators import PauliwordOp, IndependentOp
+from .. import kernels, packing
 
 
 class S3Projection:
@@ -21,18 +22,33 @@ class S3Projection:
         assert self.rotated_flag, 'The operator has not been rotated - intended for use with perform_projection method'
         self.rotated_flag = False
         fixed = self.rotated_stabilizers
-        survives = np.all(operator.commutes_termwise(fixed), axis=1)                  # device commutation kernel
-        terms, weights = operator.symp_matrix[survives], operator.coeff_vec[survives]
-        # symplectic column of each single-qubit stabiliser and its eigenvalue; an occupied column contributes the
-        # eigenvalue (the reference's product treats an eigenvalue 0 like an unoccupied column: factor 1)
-        columns = np.nonzero(fixed.symp_matrix)[1]
-        eigenvalues = np.asarray(fixed.coeff_vec)
-        factors = np.where(terms[:, columns] & (eigenvalues != 0), eigenvalues, 1)
-        weights = weights * np.prod(factors, axis=1)
-        keep_columns = np.concatenate([self.free_qubit_indices, self.free_qubit_indices + operator.n_qubits])
-        if keep_columns.size == 0:
-            return PauliwordOp(np.zeros((1, 0), dtype=bool), [np.sum(weights)])        # every qubit stabilised: a scalar
-        return PauliwordOp(terms[:, keep_columns], weights).cleanup()                  # device cleanup merges equal terms
+        n = operator.n_qubits
+        keep = np.asarray(self.free_qubit_indices, dtype=np.int64)
+        if keep.size == 0:
+            # every qubit stabilised: a scalar (projection/base.py:83-84) — the surviving weights times their signs, from the packed rows
+            survives = np.all(operator.commutes_termwise(fixed), axis=1)
+            neg = np.zeros(operator.packed.shape[1], dtype='<u8')
+            for row, ev in zip(fixed.packed, np.asarray(fixed.coeff_vec)):
+                if ev == -1:
+                    neg |= row
+            odd = (packing.popcount_rows(operator.packed[survives] & neg) & 1).astype(bool)
+            weights = np.where(odd, -operator.coeff_vec[survives], operator.coeff_vec[survives])
+            return PauliwordOp(np.zeros((1, 0), dtype=bool), [np.sum(weights)])
+        # the whole step on the device, on packed rows (csrc/project.hip): anticommutation with the fixed stabilisers, eigenvalue signs, deletion
+        # of the stabilised qubits and the final merge of equal terms — no one-byte-per-bit matrix, no operator round trip through the host
+        dev = kernels.DeviceOp.upload(operator.packed, operator.coeff_vec)
+        try:
+            res, n_survived = kernels.project_dev(dev, fixed.packed, np.asarray(fixed.coeff_vec), keep, n)
+        finally:
+            dev.free()
+        try:
+            rows, weights = res.download()
+        finally:
+            res.free()
+        if n_survived == 0:
+            # nothing commutes with the stabilisers: the reference's cleanup() of an operator without terms is 0 * I (base.py:631-632)
+            return PauliwordOp(np.zeros((1, 2 * keep.size), dtype=bool), [0])
+        return PauliwordOp._from_packed(rows, int(keep.size), weights)
 
     def perform_projection(self, operator: PauliwordOp, ref_state: Union[List[int], np.ndarray] = None,
                            sector: Union[List[int], np.ndarray] = None) -> PauliwordOp:

@@ -568,6 +568,77 @@ def test_qubit_tapering_golden(case):
     assert out.n_qubits == H.n_qubits - T.n_taper
 
 
+def test_f3_f4_device_paths_vs_host_restatements():
+    """SURVEY 8f rows f3 / f4 on the device (csrc/project.hip) against NumPy restatements of the reference lines, random inputs:
+    projection (projection/base.py:60-84), noncontextuality test (utils.py:567-589 on the oracle's adjacency matrix), bra * ket
+    (base.py:1808-1815) — and none of them builds the one-byte-per-bit matrix of its operand."""
+    from symmer_amd.projection.base import S3Projection
+    from symmer_amd.operators.utils import check_adjmat_noncontextual
+    from symmer_amd import QuantumState
+    rng = np.random.default_rng(808)
+    # ---- projection: random operator, stabilisers = single-qubit Z / X on chosen qubits with random sector
+    for n, T, stab_q in ((70, 400, [3, 64, 69]), (10, 50, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]), (130, 300, [5]), (6, 40, [1, 4])):
+        symp = rng.random((T, 2 * n)) < 0.3
+        symp = np.vstack([symp, symp[: T // 4]])                                        # duplicates that only differ on stabilised qubits appear too
+        symp[T:, stab_q[0]] ^= True
+        coeff = dyadic(rng, symp.shape[0])
+        stab = np.zeros((len(stab_q), 2 * n), dtype=bool)
+        kinds = rng.integers(0, 2, len(stab_q))
+        for s, (q, kd) in enumerate(zip(stab_q, kinds)):
+            stab[s, q + (n if kd else 0)] = True                                       # kd 1: Z_q, 0: X_q
+        eig = rng.choice([-1, 1], len(stab_q))
+        op = PauliwordOp._from_packed(packing.pack_rows(symp), n, coeff)
+        proj = S3Projection(IndependentOp(stab, eig))
+        proj.rotated_stabilizers = PauliwordOp(stab, eig)
+        proj.free_qubit_indices = np.setdiff1d(np.arange(n), stab_q)
+        proj.rotated_flag = True
+        out = proj._perform_projection(op)
+        assert op._symp is None, 'the projection expanded its operand'
+        # the reference's lines on bool matrices
+        commutes = onp.commutes_termwise(symp, stab)
+        keep_rows = np.all(commutes, axis=1)
+        cols = np.nonzero(stab)[1]
+        ev = symp[keep_rows][:, cols] * eig
+        ev[ev == 0] = 1
+        w = coeff[keep_rows] * np.prod(ev, axis=1)
+        free = proj.free_qubit_indices
+        if free.size:
+            er, ec = onp.cleanup_op(symp[keep_rows][:, np.hstack([free, free + n])], w) if keep_rows.any() else (np.zeros((1, 2 * free.size), dtype=bool), np.zeros(1, dtype=complex))
+            assert_op_equal(out.symp_matrix, out.coeff_vec, er, ec)
+        else:
+            assert out.n_qubits == 0 and out.coeff_vec[0] == np.sum(w)
+    # ---- noncontextuality: random (contextual), clique-structured (noncontextual), all commuting
+    def host_answer(symp):
+        return check_adjmat_noncontextual(onp.commutes_termwise(symp, symp))
+    cases = [rng.random((300, 2 * 40)) < 0.3, rng.random((5, 2 * 3)) < 0.5]
+    zs = np.zeros((200, 2 * 50), dtype=bool); zs[:, 50:] = rng.random((200, 50)) < 0.4
+    cases.append(zs)                                                                     # Z strings only: everything commutes
+    # two anticommuting cliques on disjoint... noncontextual set: universally commuting Z's plus {X0 A_i} and {Z0 B_i} style cliques
+    nc = np.zeros((60, 2 * 30), dtype=bool)
+    nc[:20, 30 + 1:] = rng.random((20, 29)) < 0.5                                        # Z on qubits 1..29: commute with all below
+    nc[20:40, 30 + 1:] = rng.random((20, 29)) < 0.5; nc[20:40, 0] = True                 # X0 * Z-string: clique 1
+    nc[40:, 30 + 1:] = rng.random((20, 29)) < 0.5; nc[40:, 30] = True                    # Z0 * Z-string: clique 2 (anticommutes with clique 1)
+    cases.append(nc)
+    for symp in cases:
+        op = PauliwordOp._from_packed(packing.pack_rows(symp), symp.shape[1] // 2, np.ones(symp.shape[0]))
+        assert op.is_noncontextual == host_answer(symp)
+        assert op._symp is None and 'adjacency_matrix' not in op.__dict__, 'the noncontextuality test built a host matrix'
+    assert host_answer(nc) and not host_answer(cases[0])
+    # ---- bra * ket: states with shared and unshared basis strings, duplicates inside a state, complex amplitudes
+    for nq, Na, Nb in ((70, 300, 500), (5, 20, 30), (130, 1000, 40)):
+        base = rng.integers(0, 2, (Na + Nb, nq))
+        a_m = np.vstack([base[:Na], base[: Na // 3]]); b_m = np.vstack([base[Na // 2:], base[Na // 2: Na // 2 + 7]])
+        a_c = dyadic(rng, a_m.shape[0]); b_c = dyadic(rng, b_m.shape[0])
+        bra = QuantumState(a_m, a_c, vec_type='bra'); ket = QuantumState(b_m, b_c)
+        got = bra * ket
+        left, right = (bra, ket) if bra.state_op.n_terms < ket.n_terms else (ket, bra)
+        rd = right.to_dictionary
+        expect = 0
+        for bstring, lc in left.to_dictionary.items():
+            expect += lc * rd.get(bstring, 0)
+        assert got == expect                                                             # dyadic amplitudes: bit for bit, same order of additions
+
+
 def test_independent_op_rotations_and_sector():
     """tests/test_operators/test_independent_op.py:77-109 (rotation onto single-qubit Z / X, sector assignment)."""
     k = known()
