@@ -127,6 +127,13 @@ int symgpu_mul_cleanup(const uint64_t *inner, const double *ci, int64_t Ni,
                        uint64_t *out_rows, double *out_coeff, int64_t capacity, int64_t *n_out);
 int symgpu_mul_cleanup_dev(symgpu_op_t inner, symgpu_op_t outer, int inner_is_left, double thr, int use_thr,
                            symgpu_op_t *out);
+/* The same two device calls with the FIRST-OCCURRENCE INDEX of every output term kept on the result (read it with symgpu_op_first_index):
+ * the position of the first input row of a plain cleanup, (o << 32) | i of a product's first pair (o: outer index, i: inner index; the
+ * reference's pair index is o * Ni + i, base.py:783-792).  A caller that cleans ONE product in parts — symmer_amd/parallel.py, the
+ * hash-partitioned multi-GPU cleanup — merges the parts in the reference's first-occurrence order with it (utils.py:271). */
+int symgpu_cleanup_indexed_dev(symgpu_op_t in, double thr, int use_thr, symgpu_op_t *out);
+int symgpu_mul_cleanup_indexed_dev(symgpu_op_t inner, symgpu_op_t outer, int inner_is_left, double thr, int use_thr, symgpu_op_t *out);
+int symgpu_op_first_index(symgpu_op_t op, uint64_t *first_host, int64_t capacity_rows);
 
 /* ---- a7: _rotate_by_single_Pword (base.py:1090-1161), one fused pass ------------------------------
  * clifford_k < 0: non-Clifford: cleanup([commuting, cos*anticommuting, -i*sin*(anticommuting*Q)], thr)

@@ -877,7 +877,7 @@ struct LazyEmit {
 template <bool PAIR, bool TRI>
 __global__ __launch_bounds__(256) void k_emit_meta(const u32 *__restrict__ markbits, const u32 *__restrict__ wordprefix, i64 w_begin, i64 w_end,
                                                     const double *__restrict__ sum_of, int wpw, u32 Ni,
-                                                    uint2 *__restrict__ meta, double *__restrict__ out_coeff, LazyEmit lz) {
+                                                    uint2 *__restrict__ meta, double *__restrict__ out_coeff, LazyEmit lz, u64 *__restrict__ out_first) {
     __shared__ unsigned short s_list[4][2048];                       // offsets inside the chunk (< 2048)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned short *list = s_list[wave];
@@ -926,6 +926,7 @@ __global__ __launch_bounds__(256) void k_emit_meta(const u32 *__restrict__ markb
             }
             reinterpret_cast<double2 *>(out_coeff)[(i64)p_base + k] = cf;
             meta[(p_base - P0) + k] = make_uint2(ti, to);
+            if (out_first) out_first[(i64)p_base + k] = PAIR ? (((u64)to << 32) | ti) : (u64)t;
         }
         __builtin_amdgcn_wave_barrier();                             // the list is rewritten by the next chunk
     }
@@ -977,7 +978,8 @@ __global__ __launch_bounds__(256) void k_emit_stream(const uint2 *__restrict__ m
 template <bool PAIR, bool TRI, int NW, int U>
 __global__ __launch_bounds__(256) void k_emit_fused(const u64 *__restrict__ markbits64, const u32 *__restrict__ wordprefix, i64 T, const double *__restrict__ sum_of,
                                                      u32 Ni, int Wq, int wsh, const u32x4 *__restrict__ rows, const u32x4 *__restrict__ inner,
-                                                     const u32x4 *__restrict__ outer, u32x4 *__restrict__ out_rows, double *__restrict__ out_coeff, LazyEmit lz) {
+                                                     const u32x4 *__restrict__ outer, u32x4 *__restrict__ out_rows, double *__restrict__ out_coeff, LazyEmit lz,
+                                                     u64 *__restrict__ out_first) {
     __shared__ u32 s_i[4][64 * NW], s_o[4][64 * NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const i64 w0 = ((i64)blockIdx.x * 4 + wave) * NW;
@@ -1020,6 +1022,7 @@ __global__ __launch_bounds__(256) void k_emit_fused(const u64 *__restrict__ mark
                 cf.x = __dadd_rn(0.0, c0.x); cf.y = __dadd_rn(0.0, c0.y);
             }
             reinterpret_cast<double2 *>(out_coeff)[p_base + rank] = cf;
+            if (out_first) out_first[p_base + rank] = PAIR ? (((u64)to << 32) | ti) : (u64)t;
             s_i[wave][rank] = ti; s_o[wave][rank] = to;
             o_min = to < o_min ? to : o_min; o_max = to > o_max ? to : o_max;
         }
@@ -1119,7 +1122,7 @@ __global__ __launch_bounds__(256) void k_touch(const u32x4 *__restrict__ p, i64 
 
 // T = size of the index space the kept terms are filed under (pair indices, or the slots of a squared operator: `tri`)
 int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, const u64 *rows, int W, const u64 *inner, i64 Ni,
-                   const u64 *outer, symgpu_op_t *out, int Wq_out, bool tri, const LazyEmit &lz) {
+                   const u64 *outer, symgpu_op_t *out, int Wq_out, bool tri, const LazyEmit &lz, bool want_first) {
     hipStream_t st = ctx().stream;
     const i64 n_words = (T + 31) / 32;
     Scratch wordprefix;
@@ -1136,6 +1139,10 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
     symgpu_op_t res = nullptr;
     SG_TRY(symgpu_op_alloc(n_out > 0 ? n_out : 1, Wq_out, 1, &res));
     res->T = n_out;
+    if (want_first) {
+        const int rcf = dev_alloc((size_t)(n_out > 0 ? n_out : 1) * 8, (void **)&res->first);
+        if (rcf != SYMGPU_OK) { symgpu_op_free(res); return rcf; }
+    }
     if (n_out > 0) {
         const int Wq = W / 2;
         const int wsh = (Wq & (Wq - 1)) == 0 ? __builtin_ctz((unsigned)Wq) : -1;
@@ -1163,7 +1170,7 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
             }
             ProfScope prof(3);
 #define LAUNCH_FUSED_S(P, TR, NWV, UV) hipLaunchKernelGGL((k_emit_fused<P, TR, NWV, UV>), gfu, dim3(256), 0, st, reinterpret_cast<const u64 *>(markbits_p), wordprefix.as<u32>(), T, sum_of_p, \
-                                               (u32)(pair ? Ni : 1), Wq, wsh, reinterpret_cast<const u32x4 *>(rows), pin, pout, dst, res->coeff, lz)
+                                               (u32)(pair ? Ni : 1), Wq, wsh, reinterpret_cast<const u32x4 *>(rows), pin, pout, dst, res->coeff, lz, res->first)
 #define LAUNCH_FUSED_U(P, TR, NWV) do { if (Us == 8) LAUNCH_FUSED_S(P, TR, NWV, 8); else if (Us == 2) LAUNCH_FUSED_S(P, TR, NWV, 2); else LAUNCH_FUSED_S(P, TR, NWV, 4); } while (0)
 #define LAUNCH_FUSED(P, TR) do { if (NWr == 1) LAUNCH_FUSED_U(P, TR, 1); else if (NWr == 4) LAUNCH_FUSED_U(P, TR, 4); else if (NWr == 8) LAUNCH_FUSED_U(P, TR, 8); \
                                  else LAUNCH_FUSED_U(P, TR, 2); } while (0)
@@ -1186,7 +1193,7 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
             i64 ge = ((w1 - w0 + wpw - 1) / wpw + 3) / 4;
             if (ge > 16384) ge = 16384;
 #define LAUNCH_META(P, TR) hipLaunchKernelGGL((k_emit_meta<P, TR>), dim3((unsigned)ge), dim3(256), 0, st, markbits_p, wordprefix.as<u32>(), w0, w1, sum_of_p, wpw, \
-                                              (u32)(pair ? Ni : 1), meta.as<uint2>(), res->coeff, lz)
+                                              (u32)(pair ? Ni : 1), meta.as<uint2>(), res->coeff, lz, res->first)
             if (pair && tri) LAUNCH_META(true, true); else if (pair) LAUNCH_META(true, false); else LAUNCH_META(false, false);
 #undef LAUNCH_META
             const u32 *p_begin = wordprefix.as<u32>() + w0;
@@ -1311,7 +1318,7 @@ __global__ __launch_bounds__(256) void k_compact_suspects(const u64 *__restrict_
 // plain mode: rows/coeff of T terms.  pair mode (inner != null): T = Ni*No, term t = o*Ni + i is inner[i] ^ outer[o] with
 // coefficient ci[i] * co[o] * i^e (product.hip); coeff is unused.  *out is a fresh operator with the cleaned result.
 int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *inner, i64 Ni, const u64 *outer, i64 No,
-                 double thr, int use_thr, symgpu_op_t *out, int Wq_out, const double *ci, const double *co, int inner_is_left) {
+                 double thr, int use_thr, symgpu_op_t *out, int Wq_out, const double *ci, const double *co, int inner_is_left, bool want_first) {
     hipStream_t st = ctx().stream;
     const bool pair = inner != nullptr;
     if (T >= ((i64)1 << 32) - 1) {
@@ -1647,7 +1654,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         lz.patchbits = patchbits.as<u32>(); lz.e_lo = e_lo.as<u32>(); lz.e_hi = e_hi.as<u32>();
         lz.ci = ci; lz.co = co; lz.coeff = coeff;
     }
-    return cleanup_finish(markbits.as<u32>(), sum_of.as<double>(), tri ? Tk : T, pair, rows, W, inner, Ni, outer, out, Wq_out, tri, lz);
+    return cleanup_finish(markbits.as<u32>(), sum_of.as<double>(), tri ? Tk : T, pair, rows, W, inner, Ni, outer, out, Wq_out, tri, lz, want_first);
 }
 
 }  // namespace symgpu
@@ -1674,6 +1681,40 @@ int symgpu_mul_cleanup_dev(symgpu_op_t inner, symgpu_op_t outer, int inner_is_le
     SG_REQUIRE(No == 0 || Ni < ((i64)1 << 32) / No, "mul_cleanup_dev: Ni*No must stay below 2^32 (tile the outer operand)");
     return cleanup_core(nullptr, nullptr, T, 2 * inner->Wq, inner->rows, Ni, outer->rows, No, thr, use_thr, out, inner->Wq, inner->coeff, outer->coeff,
                         inner_is_left);
+}
+
+// The same two calls, with the first-occurrence index of every output term kept on the result (symgpu_op_first_index): what a caller needs
+// to merge cleaned partial results of ONE product in the reference's order (symmer_amd/parallel.py: hash-partitioned multi-GPU cleanup).
+int symgpu_cleanup_indexed_dev(symgpu_op_t in, double thr, int use_thr, symgpu_op_t *out) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(in && out, "cleanup_indexed_dev: null handle");
+    SG_REQUIRE(in->coeff || in->T == 0, "cleanup_indexed_dev: operator has no coefficients");
+    return cleanup_core(in->rows, in->coeff, in->T, 2 * in->Wq, nullptr, 0, nullptr, 0, thr, use_thr, out, in->Wq, nullptr, nullptr, 1, true);
+}
+
+int symgpu_mul_cleanup_indexed_dev(symgpu_op_t inner, symgpu_op_t outer, int inner_is_left, double thr, int use_thr, symgpu_op_t *out) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(inner && outer && out, "mul_cleanup_indexed_dev: null handle");
+    SG_REQUIRE(inner->Wq == outer->Wq, "mul_cleanup_indexed_dev: operands must share Wq");
+    const i64 Ni = inner->T, No = outer->T;
+    const i64 T = Ni * No;
+    if (T == 0) return cleanup_core(nullptr, nullptr, 0, 2 * inner->Wq, nullptr, 0, nullptr, 0, thr, use_thr, out, inner->Wq, nullptr, nullptr, 1, true);
+    SG_REQUIRE(inner->coeff && outer->coeff, "mul_cleanup_indexed_dev: operands have no coefficients");
+    SG_REQUIRE(Ni < ((i64)1 << 32) / No, "mul_cleanup_indexed_dev: Ni*No must stay below 2^32 (tile the outer operand)");
+    return cleanup_core(nullptr, nullptr, T, 2 * inner->Wq, inner->rows, Ni, outer->rows, No, thr, use_thr, out, inner->Wq, inner->coeff, outer->coeff,
+                        inner_is_left, true);
+}
+
+int symgpu_op_first_index(symgpu_op_t op, uint64_t *first_host, int64_t capacity) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(op && (first_host || op->T == 0), "op_first_index: null argument");
+    SG_REQUIRE(op->first || op->T == 0, "op_first_index: the operator does not come from an *_indexed cleanup");
+    if (capacity < op->T) { set_error("op_first_index: capacity %lld < %lld rows", (long long)capacity, (long long)op->T); return SYMGPU_E_CAPACITY; }
+    if (op->T > 0) {
+        HIP_TRY(hipMemcpyAsync(first_host, op->first, (size_t)op->T * 8, hipMemcpyDeviceToHost, ctx().stream));
+        HIP_TRY(hipStreamSynchronize(ctx().stream));
+    }
+    return SYMGPU_OK;
 }
 
 static int finish_to_host(symgpu_op_t res, uint64_t *out_rows, double *out_coeff, int64_t capacity, int64_t *n_out) {

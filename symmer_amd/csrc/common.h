@@ -127,6 +127,9 @@ struct symgpu_op_s {
     // valid while yc_T == T.  Dropped by op_invalidate.
     int *yc = nullptr;
     i64 yc_T = -1;
+    // first[t] (optional; results of the *_indexed cleanups): the input index under which output term t was filed — its first occurrence:
+    // the position of a plain cleanup's input row, (o << 32) | i of a product's pair.  Dropped by op_invalidate.
+    u64 *first = nullptr;
 };
 
 namespace symgpu {
@@ -209,7 +212,8 @@ u64 host_row_hash(const u64 *row, int W);                       // the same hash
 int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W,          // plain mode (pair mode if inner != null)
                  const u64 *inner, i64 Ni, const u64 *outer, i64 No,
                  double thr, int use_thr, symgpu_op_t *out, int Wq_out,
-                 const double *ci = nullptr, const double *co = nullptr, int inner_is_left = 1);   // pair mode: operand coefficients
+                 const double *ci = nullptr, const double *co = nullptr, int inner_is_left = 1,    // pair mode: operand coefficients
+                 bool want_first = false);                                                          // the result carries symgpu_op_s::first
 
 // gf2.hip
 int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host);

@@ -53,6 +53,7 @@ void op_invalidate(symgpu_op_s *op) {
     op->bt_pad = 0; op->bt_T = -1;
     if (op->yc) { dev_free(op->yc); op->yc = nullptr; }
     op->yc_T = -1;
+    if (op->first) { dev_free(op->first); op->first = nullptr; }
 }
 
 int op_ycount(symgpu_op_s *op, const int **out) {

@@ -313,3 +313,52 @@ def state_inner_dev(a, b):
     out = np.zeros(2, dtype=np.float64)
     check(_lib.lib().symgpu_state_inner_dev(a.handle, b.handle, addr(out)))
     return complex(out[0], out[1])
+
+
+# ---- cleanups that also return the first-occurrence index of every output term (hash-partitioned multi-GPU cleanup, parallel.py) ----
+def _first_index(op):
+    t = op.n_terms
+    first = np.zeros(t, dtype='<u8')
+    check(_lib.lib().symgpu_op_first_index(op.handle, addr(first), t))
+    return first
+
+
+def mul_cleanup_indexed(inner, ci, outer, co, inner_is_left=True, zero_threshold=None):
+    """Fused product + cleanup -> (rows, coeff, i_first, o_first): ``inner[i_first[t]] ^ outer[o_first[t]]`` is output row t, and
+    ``o_first * Ni + i_first`` is the pair index of its first occurrence (base.py:783-792, utils.py:271)."""
+    inner, outer, ci, co = _rows(inner), _rows(outer), _coeff(ci), _coeff(co)
+    if inner.shape[0] == 0 or outer.shape[0] == 0:
+        z = np.zeros(0, dtype=np.int64)
+        return np.empty((0, inner.shape[1]), dtype='<u8'), np.empty(0, dtype=np.complex128), z, z
+    thr, use = _thr_args(zero_threshold)
+    a = DeviceOp.upload(inner, ci)
+    b = DeviceOp.upload(outer, co)
+    out = ctypes.c_void_p()
+    try:
+        check(_lib.lib().symgpu_mul_cleanup_indexed_dev(a.handle, b.handle, 1 if inner_is_left else 0, thr, use, ctypes.byref(out)))
+        res = DeviceOp(out)
+        rows, coeff = res.download()
+        first = _first_index(res)
+        res.free()
+    finally:
+        a.free(); b.free()
+    return rows, coeff, (first & 0xFFFFFFFF).astype(np.int64), (first >> 32).astype(np.int64)
+
+
+def cleanup_indexed(rows, coeff, zero_threshold=1e-15):
+    """First-occurrence cleanup -> (rows, coeff, first): ``first[t]`` is the position of output term t's first input row."""
+    rows, coeff = _rows(rows), _coeff(coeff)
+    if rows.shape[0] == 0:
+        return rows.copy(), coeff.copy(), np.zeros(0, dtype=np.int64)
+    thr, use = _thr_args(zero_threshold)
+    op = DeviceOp.upload(rows, coeff)
+    out = ctypes.c_void_p()
+    try:
+        check(_lib.lib().symgpu_cleanup_indexed_dev(op.handle, thr, use, ctypes.byref(out)))
+        res = DeviceOp(out)
+        r, c = res.download()
+        first = _first_index(res).astype(np.int64)
+        res.free()
+    finally:
+        op.free()
+    return r, c, first

@@ -397,6 +397,18 @@ class Communicator:
         cat.free()
         return res
 
+    def mul_cleanup_hash_partitioned(self, inner_full, outer_full, inner_is_left=True, zero_threshold=1e-15, stats=None):
+        """Fused product + cleanup of two device operators that are COMPLETE on every rank (after :meth:`allgather_op`), the pairs partitioned
+        over the ranks by the GF(2)-linear class of their product row (:func:`hash_partitioned_mul_cleanup`): all duplicates of a row meet
+        on one rank — also the twins (i, o) / (o, i) of a squared operator, which the contiguous split of :meth:`mul_cleanup_sharded` leaves
+        on different ranks — no key and no partial product crosses the wire, only each rank's share of the final result.  Returns a DeviceOp
+        (the result is replicated).  This version stages the sub-operands and the result through host arrays (the operands are small; the
+        result share is what travels anyway); the per-rank device work is the indexed fused product + cleanup (``symgpu_mul_cleanup_indexed_dev``)."""
+        from . import kernels
+        ir, ic = inner_full.download(); orows, oc_ = outer_full.download()
+        rows, coeff = hash_partitioned_mul_cleanup(ir, ic, orows, oc_, self, inner_is_left, zero_threshold, stats=stats)
+        return kernels.DeviceOp.upload(rows, coeff) if rows.shape[0] else kernels.DeviceOp.alloc(1, inner_full.info()[1], with_coeff=True)
+
     def verify_allgather(self, shard, full, n_rows_total):
         """Self-check of the RCCL data plane (call once, outside any timed region): gather the same shards a second time through
         host memory over the control plane and compare them with the device result of ``allgather_op`` — rows and coefficients,
@@ -560,3 +572,105 @@ def sharded_mul_cleanup(inner_rows, inner_coeff, outer_rows_local, outer_coeff_l
     cat_r = np.concatenate([all_r[r, :counts[r]] for r in range(comm.world)], axis=0)
     cat_c = np.concatenate([all_c[r, :counts[r]] for r in range(comm.world)])
     return cleanup_kernel(cat_r, cat_c, zero_threshold)
+
+
+# ---- cleanup across GPUs by HASH PARTITION ("cleanup across GPUs") -----------------------------------
+# sharded_mul_cleanup above splits the OUTER index in contiguous blocks: every rank cleans its own slab, gathers every other rank's cleaned
+# slab and cleans the concatenation again.  That is right for products whose duplicates sit close together, but the twins (i, o) / (o, i)
+# of a squared operator live on different ranks, nothing merges locally, and every rank receives and re-cleans (nearly) the whole product.
+#
+# Here the PAIRS are partitioned by a GF(2)-LINEAR class of their product row: cls(row) = parities of the row under a few fixed random
+# masks, so cls(inner[i] ^ outer[o]) = cls(inner[i]) ^ cls(outer[o]) — the owner of a pair, (cls_i ^ cls_o) mod G, is known from the two
+# operand tables alone, equal product rows always have the same owner, and the pairs of one owner are a union of full sub-products
+# (inner rows of class a) x (outer rows whose class XOR a maps to the owner).  No key is generated for a pair that another rank owns and
+# NOTHING is exchanged before the result: every duplicate of a row meets its partners on its owner, which applies the threshold there.
+# What does cross the wire is each rank's share of the FINAL result (rows, coefficients and the pair index of each row's first
+# occurrence), all-gathered and put in the reference's first-occurrence order (utils.py:271) by that index.
+# Precondition: both operands complete on every rank (the all-gather of the right operand that the product path performs anyway).
+# Sums associate per sub-product (in pair order inside it, the sub-products' sums then in order of their first pair): bit-exact for
+# dyadic coefficients, <= 1e-16 relative otherwise — the same statement as for the tiled kernels.mul_cleanup.
+def linear_row_classes(rows, n_bits, seed=0x51A55E5):
+    """GF(2)-linear class in [0, 2^n_bits) of every packed row: bit k = parity of the row under the k-th fixed random mask."""
+    rows = np.ascontiguousarray(rows, dtype='<u8')
+    rng = np.random.default_rng(seed)
+    masks = rng.integers(0, 1 << 63, size=(n_bits, rows.shape[1]), dtype=np.uint64) ^ (rng.integers(0, 2, size=(n_bits, rows.shape[1]), dtype=np.uint64) << np.uint64(63))
+    cls = np.zeros(rows.shape[0], dtype=np.int64)
+    for k in range(n_bits):
+        par = np.bitwise_count(rows & masks[k][None, :]).sum(axis=1, dtype=np.int64) & 1
+        cls |= par << k
+    return cls
+
+
+def hash_partition_local(inner_rows, inner_coeff, outer_rows, outer_coeff, rank, world, inner_is_left=True, zero_threshold=1e-15,
+                         mul_kernel=None, cleanup_kernel=None, stats=None):
+    """Rank ``rank``'s share of the cleaned product: the terms whose product row's linear class maps to this rank — complete (every duplicate
+    of such a row is among this rank's pairs), thresholded, in first-occurrence order, with the pair index ``o * Ni + i`` of each term's
+    first occurrence.  No communication.  -> (rows, coeff, first_pair_index)."""
+    if mul_kernel is None or cleanup_kernel is None:
+        from . import kernels
+        mul_kernel = mul_kernel or (lambda a, ca, b, cb, left: kernels.mul_cleanup_indexed(a, ca, b, cb, left, None))
+        cleanup_kernel = cleanup_kernel or kernels.cleanup_indexed
+    inner_rows = np.ascontiguousarray(inner_rows, dtype='<u8'); outer_rows = np.ascontiguousarray(outer_rows, dtype='<u8')
+    inner_coeff = np.ascontiguousarray(inner_coeff, dtype=np.complex128); outer_coeff = np.ascontiguousarray(outer_coeff, dtype=np.complex128)
+    Ni, No, W = inner_rows.shape[0], outer_rows.shape[0], inner_rows.shape[1]
+    G = world
+    n_bits = 1
+    while (1 << n_bits) < G:
+        n_bits += 1
+    if G & (G - 1):
+        n_bits += 2                                                # a class count that is not a multiple of G: four times as many classes even the shares out
+    n_cls = 1 << n_bits
+    cls_i = linear_row_classes(inner_rows, n_bits); cls_o = linear_row_classes(outer_rows, n_bits)
+    parts_r, parts_c, parts_g = [], [], []
+    pairs_owned = 0
+    for a in range(n_cls):
+        ia = np.flatnonzero(cls_i == a)                                                    # ascending: local pair order = global pair order restricted
+        oa = np.flatnonzero(((cls_o ^ a) % G) == rank)
+        if ia.size == 0 or oa.size == 0:
+            continue
+        pairs_owned += ia.size * oa.size
+        r, c, i_f, o_f = mul_kernel(inner_rows[ia], inner_coeff[ia], outer_rows[oa], outer_coeff[oa], inner_is_left)
+        parts_r.append(r); parts_c.append(c)
+        parts_g.append(oa[np.asarray(o_f, dtype=np.int64)] * Ni + ia[np.asarray(i_f, dtype=np.int64)])   # pair index of the first occurrence (base.py:783-792)
+    if parts_r:
+        rows = np.concatenate(parts_r, axis=0); coeff = np.concatenate(parts_c); g = np.concatenate(parts_g)
+        order = np.argsort(g, kind='stable')
+        rows, coeff, g = np.ascontiguousarray(rows[order]), coeff[order], g[order]
+        rows, coeff, first = cleanup_kernel(rows, coeff, zero_threshold)                   # duplicates across this rank's sub-products; the threshold: final
+        g = g[np.asarray(first, dtype=np.int64)]
+    else:
+        rows, coeff, g = np.zeros((0, W), dtype='<u8'), np.zeros(0, dtype=np.complex128), np.zeros(0, dtype=np.int64)
+    if stats is not None:
+        stats.update(pairs_owned=int(pairs_owned), pairs_total=int(Ni) * int(No), keys_exchanged=0,
+                     bytes_sent=int(rows.nbytes + coeff.nbytes + g.nbytes) if G > 1 else 0)
+    return np.ascontiguousarray(rows, dtype='<u8'), np.ascontiguousarray(coeff), g
+
+
+def hash_partitioned_mul_cleanup(inner_rows, inner_coeff, outer_rows, outer_coeff, comm, inner_is_left=True, zero_threshold=1e-15,
+                                 mul_kernel=None, cleanup_kernel=None, stats=None):
+    """``inner * outer`` (or ``outer * inner``) + cleanup with the PAIRS partitioned over the ranks by the linear class of their product
+    row.  Host arrays in, the cleaned product (rows, coeff) out, identical on every rank and equal to the single-process result.
+    ``mul_kernel(inner, ci, outer, co, inner_is_left) -> (rows, coeff, i_first, o_first)`` = fused product + cleanup WITHOUT threshold plus the
+    first pair of every output row (default ``kernels.mul_cleanup_indexed``); ``cleanup_kernel(rows, coeff, thr) -> (rows, coeff, first)``
+    (default ``kernels.cleanup_indexed``).  The CPU tests inject checkers built on the oracle.  ``stats`` (dict, optional) receives
+    ``pairs_owned``, ``pairs_total``, ``keys_exchanged`` (always 0) and ``bytes_sent`` of this rank."""
+    G = comm.world
+    rows, coeff, g = hash_partition_local(inner_rows, inner_coeff, outer_rows, outer_coeff, comm.rank, G, inner_is_left, zero_threshold,
+                                          mul_kernel, cleanup_kernel, stats)
+    if G == 1:
+        return rows, coeff
+    W = rows.shape[1]
+    # the result: every rank's share, all-gathered and ordered by first pair index
+    counts = np.frombuffer(comm._allgather_bytes(np.int64(rows.shape[0]).tobytes()), dtype=np.int64)
+    ts = max(1, int(counts.max()))
+    pad_r = np.zeros((ts, W), dtype='<u8'); pad_r[:rows.shape[0]] = rows
+    pad_c = np.zeros(ts, dtype=np.complex128); pad_c[:coeff.shape[0]] = coeff
+    pad_g = np.zeros(ts, dtype=np.int64); pad_g[:g.shape[0]] = g
+    all_r = np.frombuffer(comm._allgather_bytes(pad_r.tobytes()), dtype='<u8').reshape(G, ts, W)
+    all_c = np.frombuffer(comm._allgather_bytes(pad_c.tobytes()), dtype=np.complex128).reshape(G, ts)
+    all_g = np.frombuffer(comm._allgather_bytes(pad_g.tobytes()), dtype=np.int64).reshape(G, ts)
+    cat_r = np.concatenate([all_r[r, :counts[r]] for r in range(G)], axis=0)
+    cat_c = np.concatenate([all_c[r, :counts[r]] for r in range(G)])
+    cat_g = np.concatenate([all_g[r, :counts[r]] for r in range(G)])
+    order = np.argsort(cat_g, kind='stable')
+    return np.ascontiguousarray(cat_r[order]), np.ascontiguousarray(cat_c[order])

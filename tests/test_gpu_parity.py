@@ -700,6 +700,52 @@ def test_quantum_state_golden(case):
     assert psi + psi == psi * 2 and (psi - psi).n_terms == 0
 
 
+def test_indexed_cleanups_and_hash_partitioned_shares():
+    """The cleanups that return first-occurrence indices (symgpu_*_indexed_dev) against the oracle, and the hash-partitioned multi-GPU cleanup
+    (parallel.hash_partition_local) with the DEVICE kernels: the shares of G = 1, 2, 3, 4, 8 ranks, computed one after the other on this GPU
+    and merged by first pair index, equal the single-process oracle result — squared operators (twins on one rank), general products in both
+    operand orders, repeated rows, through and below the size gates of the lazy cleanup flow."""
+    from symmer_amd import parallel
+    rng = np.random.default_rng(606)
+    for n, Ni, No in ((100, 700, 400), (1000, 2100, 2100), (40, 300, 5)):
+        A = onp.pack_rows(rng.random((Ni, 2 * n)) < 0.3); B = onp.pack_rows(rng.random((No, 2 * n)) < 0.3)
+        A[Ni // 2: Ni // 2 + 20] = A[:20]; B[No // 2:] = B[: No - No // 2]            # repeated rows in both operands
+        a = dyadic(rng, Ni); b = dyadic(rng, No)
+        # indexed product + cleanup: rows / sums as the plain call, indices = first occurrence in pair order
+        r, c, i_f, o_f = kernels.mul_cleanup_indexed(A, a, B, b, True, None)
+        pr, pc = oc.mul_allpairs(A, a, B, b, True)
+        er, ec = oc.cleanup(pr, pc, None)
+        assert np.array_equal(r, er) and np.array_equal(c, ec)
+        assert np.array_equal(A[i_f] ^ B[o_f], r)
+        g = o_f * Ni + i_f
+        assert np.all(np.diff(g) > 0), 'first occurrences must come in pair order'
+        first_np, _ = onp.first_occurrence_unique(np.ascontiguousarray(pr).view(np.uint8).reshape(pr.shape[0], -1))
+        assert np.array_equal(g, first_np)
+        # indexed plain cleanup
+        stack = np.vstack([A, A[::3], B]); sc = np.hstack([a, a[::3], b])
+        r2, c2, f2 = kernels.cleanup_indexed(stack, sc, 1e-15)
+        e2r, e2c = oc.cleanup(stack, sc, 1e-15)
+        assert np.array_equal(r2, e2r) and np.array_equal(c2, e2c) and np.array_equal(stack[f2], r2) and np.all(np.diff(f2) > 0)
+        for X, x, Y, y, left in ((A, a, B, b, True), (A, a, A, a, True), (B, b, A, a, False)):
+            if X.shape[0] * Y.shape[0] > 3_000_000:
+                continue
+            pr, pc = oc.mul_allpairs(X, x, Y, y, left)
+            er, ec = oc.cleanup(pr, pc, 1e-15)
+            for G in (1, 2, 3, 4, 8):
+                shares, owned = [], 0
+                for rank in range(G):
+                    st = {}
+                    shares.append(parallel.hash_partition_local(X, x, Y, y, rank, G, left, 1e-15, stats=st))
+                    owned += st['pairs_owned']
+                    assert st['keys_exchanged'] == 0
+                assert owned == X.shape[0] * Y.shape[0], 'every pair has exactly one owner'
+                gg = np.concatenate([s_[2] for s_ in shares])
+                assert np.unique(gg).size == gg.size, 'a term came out of two ranks'
+                order = np.argsort(gg, kind='stable')
+                rows = np.concatenate([s_[0] for s_ in shares], axis=0)[order]; coeff = np.concatenate([s_[1] for s_ in shares])[order]
+                assert np.array_equal(rows, er) and np.array_equal(coeff, ec), (n, G, left)
+
+
 def test_mul_cleanup_tiled_over_outer_operand():
     """Products beyond the 32-bit pair-index limit are tiled over the outer operand; forced here with a tiny tile."""
     rng = np.random.default_rng(8)

@@ -265,6 +265,33 @@ def _mul_cleanup_worker(rank, world, port, q):
                                                        cleanup_kernel=lambda r, c, thr: oc.cleanup(r, c, thr))
             er, ec = oc.mul(A, a, B, b)
             ok = ok and np.array_equal(rows, er) and np.array_equal(coeff, ec)
+            # ---- the same product with the PAIRS partitioned by the linear class of their product row: both operands
+            #      complete on every rank, nothing exchanged but each rank's share of the result.  Checker kernels on the oracle:
+            #      first-occurrence unique with indices (utils.py:271) + np.add.at sums (:273-274)
+            def indexed_cleanup(r, c, thr):
+                first, inv = onp.first_occurrence_unique(np.ascontiguousarray(r).view(np.uint8).reshape(r.shape[0], -1))
+                sums = np.zeros(first.shape[0], dtype=complex)
+                np.add.at(sums, inv, c)
+                keep = np.ones(first.shape[0], dtype=bool) if thr is None else np.abs(sums) > thr
+                return r[first][keep], sums[keep], first[keep]
+
+            def indexed_mul(inner, ci, outer, co, left):
+                r, c = oc.mul_allpairs(inner, ci, outer, co, left)
+                rr, cc, first = indexed_cleanup(r, c, None)
+                return rr, cc, first % inner.shape[0], first // inner.shape[0]
+            for (X, x, Y, y, left) in ((A, a, B, b, True), (A, a, A, a, True), (B, b, A, a, False)):
+                st = {}
+                rows, coeff = parallel.hash_partitioned_mul_cleanup(X, x, Y, y, comm, left, 1e-15, mul_kernel=indexed_mul, cleanup_kernel=indexed_cleanup, stats=st)
+                rr, cc = oc.mul_allpairs(X, x, Y, y, left)
+                er, ec = oc.cleanup(rr, cc, 1e-15)
+                ok = ok and np.array_equal(rows, er) and np.array_equal(coeff, ec)
+                # every pair has exactly one owner, and what a rank sends is its share of the RESULT — no key, no partial product row
+                owned = np.frombuffer(comm._allgather_bytes(np.int64(st['pairs_owned']).tobytes()), dtype=np.int64)
+                ok = ok and int(owned.sum()) == st['pairs_total'] == X.shape[0] * Y.shape[0]
+                sent = np.frombuffer(comm._allgather_bytes(np.int64(st['bytes_sent']).tobytes()), dtype=np.int64)
+                ok = ok and int(sent.sum()) == er.shape[0] * (er.shape[1] * 8 + 16 + 8)
+                # (no key and no partial product is exchanged at all: the bytes a rank sends are exactly its kept terms — row, coefficient,
+                # first pair index — i.e. the result is the only traffic, 1/G of it per rank on average)
         comm.close()
         q.put((rank, bool(ok), ''))
     except Exception:                                         # pragma: no cover
