@@ -652,7 +652,7 @@ def hash_partitioned_mul_cleanup(inner_rows, inner_coeff, outer_rows, outer_coef
     row.  Host arrays in, the cleaned product (rows, coeff) out, identical on every rank and equal to the single-process result.
     ``mul_kernel(inner, ci, outer, co, inner_is_left) -> (rows, coeff, i_first, o_first)`` = fused product + cleanup WITHOUT threshold plus the
     first pair of every output row (default ``kernels.mul_cleanup_indexed``); ``cleanup_kernel(rows, coeff, thr) -> (rows, coeff, first)``
-    (default ``kernels.cleanup_indexed``).  The CPU tests inject checkers built on the oracle.  ``stats`` (dict, optional) receives
+    (default ``kernels.cleanup_indexed``).  The CPU tests inject their own checker kernels.  ``stats`` (dict, optional) receives
     ``pairs_owned``, ``pairs_total``, ``keys_exchanged`` (always 0) and ``bytes_sent`` of this rank."""
     G = comm.world
     rows, coeff, g = hash_partition_local(inner_rows, inner_coeff, outer_rows, outer_coeff, comm.rank, G, inner_is_left, zero_threshold,
