@@ -286,6 +286,26 @@ def test_product_cleanup_over_the_lazy_gate_against_the_c_oracle(shape):
     assert np.array_equal(R.coeff_vec, ec)
 
 
+@pytest.mark.parametrize('mode', ['default', 'full sort', 'give up', 'repeated rows'])
+def test_cleanup_flagged_key_flow_switches(mode, monkeypatch):
+    """Round 4's cleanup of products (partial sort, k_find_suspects, only the flagged keys sorted completely) against the C oracle above
+    the 2^22-key gate: the default, the full sort of all keys (SYMGPU_CLEANUP_SUSPECTS=0), the flow giving up after the flag pass and
+    finishing the last radix pass on the whole array (forced, and reached by itself on operands full of repeated rows, where nearly
+    every key has a partner)."""
+    rng = np.random.default_rng(4404)
+    n, na, nb = 100, 2600, 2100
+    if mode == 'full sort': monkeypatch.setenv('SYMGPU_CLEANUP_SUSPECTS', '0')
+    if mode == 'give up': monkeypatch.setenv('SYMGPU_CLEANUP_SUSPECTS_GIVEUP', '1')
+    sa = rng.random((na, 2 * n)) < 0.3; sb = rng.random((nb, 2 * n)) < 0.3
+    if mode == 'repeated rows':
+        sa = sa[rng.integers(0, 400, na)]; sb = sb[rng.integers(0, 300, nb)]          # 400 x 300 distinct products, each ~45 times
+    A = PauliwordOp(sa, dyadic(rng, na)); B = PauliwordOp(sb, dyadic(rng, nb))
+    for X, Y in ((A, B), (A, A)):
+        R = X * Y
+        er, ec = oc.mul(X.packed, X.coeff_vec, Y.packed, Y.coeff_vec)
+        assert np.array_equal(R.packed, er) and np.array_equal(R.coeff_vec, ec), mode
+
+
 @pytest.mark.parametrize('coeffs', ['gaussian', 'dyadic'])
 def test_cfg3_full_size_against_the_oracle(coeffs):
     """BASELINE cfg3 at full size — a 10,000-term, 1,000-qubit operator squared (10^8 pairs) + cleanup — against the reference's
