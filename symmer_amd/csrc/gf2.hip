@@ -696,8 +696,12 @@ __global__ __launch_bounds__(256) void k_rref_small(u64 *__restrict__ rows, int 
 }
 
 // ---- in-place reduction of a device matrix -------------------------------------------------------
-int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
+// fused_select: launch A carries the selectors of the next block's rows to its tile workgroups through in-launch flags (one launch less per
+// block).  *timed_out: a tile workgroup gave up waiting (its workgroups were not co-resident) — the matrix is then partly updated: the caller
+// restores it and runs the schedule with separate launches.
+static int rref_dev_impl(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host, bool fused_select_allowed, bool *timed_out) {
     hipStream_t st = ctx().stream;
+    *timed_out = false;
     if (xor_count) *xor_count = 0;
     if (R <= 0 || Wc <= 0) return SYMGPU_OK;
     if (Wc >= ((i64)1 << 31) - 64) { set_error("rref: Wc too large"); return SYMGPU_E_INVALID; }
@@ -755,7 +759,7 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     if (m4_chunks < 1) m4_chunks = 1;
     const bool lookahead = !(env_la && env_la[0] == '0');
     // SYMGPU_GF2_FUSED_SELECT=0: the selector launch on its own in front of phase 0 (three launches per block instead of two)
-    const bool fused_select = [] { const char *e = getenv("SYMGPU_GF2_FUSED_SELECT"); return !(e && e[0] == '0'); }();
+    const bool fused_select = fused_select_allowed;
     FusedSelect fs;
     fs.sel = sel.as<u64>(); fs.snap = snap.as<u64>(); fs.rowcnt = rowcnt.as<u32>(); fs.ready = ready.as<u64>(); fs.epoch = 0;
     fs.fail = reinterpret_cast<u32 *>(count.p) + 2;
@@ -840,11 +844,39 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     if (pivots_host) HIP_TRY(hipMemcpyAsync(pivots_host, piv.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (getenv("SYMGPU_GF2_DEBUG")) fprintf(stderr, "rref %lld x %lld words: full-row panels %u\n", (long long)R, (long long)Wc, (u32)(hb[1] >> 32));
-    if ((u32)hb[1] != 0) {
-        set_error("rref: a phase-0 workgroup timed out waiting for the selectors of its rows (SYMGPU_GF2_FUSED_SELECT=0 separates the launches)");
-        return SYMGPU_E_HIP;
-    }
+    if ((u32)hb[1] != 0) { *timed_out = true; return SYMGPU_OK; }
     if (xor_count) *xor_count = (i64)hb[0];
+    return SYMGPU_OK;
+}
+
+static bool g_gf2_fused_off = false;         // a launch-A wait timed out once: the process keeps to the separate-launch schedule
+
+int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
+    hipStream_t st = ctx().stream;
+    if (xor_count) *xor_count = 0;
+    if (R <= 0 || Wc <= 0) return SYMGPU_OK;
+    const bool env_fused = [] { const char *e = getenv("SYMGPU_GF2_FUSED_SELECT"); return !(e && e[0] == '0'); }();
+    const bool inject = getenv("SYMGPU_GF2_INJECT_TIMEOUT") != nullptr;      // tests: pretend the first attempt timed out
+    const bool fused = env_fused && !g_gf2_fused_off;
+    // The fused schedule waits inside a launch for flags of other workgroups (bounded, ~1 s).  Should that wait ever give up, the matrix
+    // is half updated in place — so a copy of the input is kept (2 x 27 MB at 5 TB/s = 11 us of a 2 ms call at cfg4) and the reduction is
+    // redone from it with separate launches; the fused form stays off for the rest of the process.
+    Scratch orig;
+    const bool big = R > SMALL_R || Wc > SMALL_WC;
+    if (fused && big) {
+        SG_TRY(orig.alloc((size_t)R * Wc * 8));
+        HIP_TRY(hipMemcpyAsync(orig.p, rows, (size_t)R * Wc * 8, hipMemcpyDeviceToDevice, st));
+    }
+    bool timed_out = false;
+    SG_TRY(rref_dev_impl(rows, R, Wc, xor_count, pivots_host, fused, &timed_out));
+    if (inject && fused && big) timed_out = true;
+    if (!timed_out) return SYMGPU_OK;
+    if (!orig.p) { set_error("rref: an in-launch wait timed out on a schedule that has none (internal error)"); return SYMGPU_E_HIP; }
+    g_gf2_fused_off = !inject;
+    HIP_TRY(hipMemcpyAsync(rows, orig.p, (size_t)R * Wc * 8, hipMemcpyDeviceToDevice, st));
+    if (xor_count) *xor_count = 0;
+    SG_TRY(rref_dev_impl(rows, R, Wc, xor_count, pivots_host, false, &timed_out));
+    if (timed_out) { set_error("rref: time-out on the separate-launch schedule (internal error)"); return SYMGPU_E_HIP; }
     return SYMGPU_OK;
 }
 

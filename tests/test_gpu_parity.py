@@ -447,6 +447,22 @@ def test_rref_vs_oracle(R, C, dens):
     assert np.array_equal(red, ered) and n_xor == en_xor and np.array_equal(piv, epiv)
 
 
+def test_rref_recovers_from_an_in_launch_time_out(monkeypatch):
+    """The fused GF(2) schedule waits inside a launch for flags of other workgroups; should that wait give up (workgroups not co-resident)
+    the half-updated matrix is restored from the copy taken at entry and reduced with separate launches (robustness).  The
+    time-out is injected after the first attempt: reduced matrix, pivots and reference row-XOR count must still be the oracle's."""
+    rng = np.random.default_rng(321)
+    m = rng.random((900, 5000)) < 0.4
+    p = packing.pack_bits(m)
+    monkeypatch.setenv('SYMGPU_GF2_INJECT_TIMEOUT', '1')
+    red, n_xor, piv = kernels.rref(p, want_pivots=True)
+    ered, en_xor, epiv = oc.rref(p, want_pivots=True)
+    assert np.array_equal(red, ered) and n_xor == en_xor and np.array_equal(piv, epiv)
+    monkeypatch.delenv('SYMGPU_GF2_INJECT_TIMEOUT')
+    red2, n2 = kernels.rref(p)
+    assert np.array_equal(red2, ered) and n2 == en_xor
+
+
 def test_rref_wide_rows_global_panel():
     """rows wider than the LDS budget take the global-memory panel path"""
     rng = np.random.default_rng(9)
