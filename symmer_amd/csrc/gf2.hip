@@ -339,7 +339,7 @@ __device__ __forceinline__ u64 select_row(const u64 *__restrict__ rows, i64 Wc, 
     // sequential-time selector t_j = f_j ^ parity(f & mask_j & (2^j-1)): |t| row-XORs in the reference loop
     const bool tj = bit ^ (bool)(__popcll(f & mj) & 1);
     const u64 t = __ballot(tj);
-    if (lane == 0) atomicAdd(&rowcnt[r], (u32)__popcll(t));           // fire and forget (a load + store pair puts a round trip in front of the selector)
+    if (lane == 0 && rowcnt) atomicAdd(&rowcnt[r], (u32)__popcll(t));  // fire and forget (a load + store pair puts a round trip in front of the selector)
     u64 x = bit ? Tj : 0ULL;                                          // g = XOR_{j in f} T_j
     for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off);
     return x;
@@ -643,6 +643,219 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
     }
 }
 
+// ---- ONE launch per block (round 4) --------------------------------------------------------------------------------------------------
+// Launch A of the two-launch schedule (selectors of every row for the block just panelled, update of the next block's 64 rows, their
+// leading words, snapshot of the block's old rows) only exists because the selectors of a row must be read before ANY column tile of that
+// row is updated.  Here it becomes the TAIL of the launch that panels the block: workgroup 0 panels block k+1 while the tile workgroups sweep
+// block k over all other rows (as phase 1); then every tile workgroup arrives at a counter, waits until all of them and the panel have
+// (everything block k writes is in memory, the pivots of block k+1 are known, nobody writes a row any more), and the tail runs:
+//   1. selectors of ALL rows for block k+1 — one wavefront per row, the rows shared out over the tile workgroups (sel[] is rewritten: its old
+//      contents were consumed before the counter);
+//   2. the n_tiles workgroups of chunk 0: selectors of the 64 rows after block k+1 once more into LDS (they are about to overwrite the pivot words
+//      they are read from: a second, small counter separates every workgroup's reads from everybody's writes), tables of block k+1 from
+//      its rows (written out as the snapshot the next launch builds its tables from), update of those 64 rows, their leading words.
+// The next launch starts exactly where launch B of the two-launch schedule starts.  Two in-launch waits, both bounded; a time-out raises the
+// same flag as launch A's and rref_dev restores the matrix and falls back to separate launches.  Slower than the two launches it replaces
+// (see rref_dev_impl): kept behind SYMGPU_GF2_MERGED=1.
+struct MergedSync { u32 *ctr; u32 epoch; u32 n_wg; };                  // ctr[0]: tile workgroups past their sweep, ctr[1]: panel done (epoch), ctr[2]: chunk-0 workgroups past their selector reads
+typedef int32_t i32;
+__device__ __forceinline__ bool merged_wait(const u32 *p, u32 target, bool at_least) {
+    for (u32 spins = 0;; ++spins) {
+        const u32 v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (at_least ? (i32)(v - target) >= 0 : v == target) return true;
+        if (spins >= (1u << 22)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__global__ __launch_bounds__(M4_NT) void k_gf2_merged(u64 *__restrict__ rows, i64 R, i64 Wc, const BlockInfo *__restrict__ info, u64 *__restrict__ sel,
+                                                       u64 *__restrict__ snap, int n_tiles, int n_chunks, BlockInfo *__restrict__ info_next,
+                                                       SweepState *__restrict__ st, i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count,
+                                                       int *__restrict__ lead, FusedSelect fs, MergedSync ms) {
+    extern __shared__ u64 tab[];                                    // [16 groups][16 entries][64 words]
+    __shared__ u64 s_sel[WK];
+    __shared__ int s_ok;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = info->kk;
+    const i64 i0n = info->i0 + kk;                                  // first row of the next block
+    const i64 nb = i0n < R ? i0n : R, ne = i0n + WK < R ? i0n + WK : R;
+    if (blockIdx.x == 0) {
+        // ---- panel workgroup (as phase 1 of k_sweep_m4r) ----
+        int a = -1;
+        u64 spec[WN] = {0, 0, 0, 0};
+        const int w_spec = info->w_next;
+        if (wave == 0 && i0n + lane < R) {
+            a = lead[lane];
+            if (w_spec >= 0) {
+#pragma unroll
+                for (int k = 0; k < WN; ++k) spec[k] = (i64)w_spec + k < Wc ? rows[(i0n + lane) * Wc + w_spec + k] : 0ULL;
+            }
+        }
+        if (wave == 0) {
+            bool full = false;
+            if (fs.full_panel && Wc <= FULL_WC && i0n < R) {
+                const bool valid = a >= 0;
+                const u64 fin_m = __ballot(valid && a != NOLEAD);
+                if (fin_m != 0) {
+                    const int w_lo = window_start(a, valid, __builtin_ctzll(fin_m));
+                    const u64 bad = __ballot(valid && a != NOLEAD && !(a >= w_lo && a < w_lo + WN));
+                    const int n_valid = __popcll(__ballot(valid));
+                    full = bad != 0 && __builtin_ctzll(bad) < (n_valid < 32 ? n_valid : 32);
+                }
+            }
+            if (lane == 0) { s_ok = full ? 1 : 0; if (full) atomicAdd(fs.fail + 1, 1u); }
+            if (i0n + lane < R) lead[lane] = NOLEAD;
+        }
+        __syncthreads();
+        if (s_ok) {
+            if (wave != 0) a = 0;
+            panel_full(rows, R, Wc, i0n, a, tab, s_sel, st, info_next, pivots, xor_count);
+        } else if (wave == 0) panel_wave(rows, R, Wc, i0n, a, lane, st, info_next, pivots, xor_count, spec, w_spec, fs.lean_panel);
+        // publish: the block's info is in memory before the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&ms.ctr[1], ms.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    const int k = blockIdx.x - 1;
+    const int tile = k % n_tiles, chunk = k / n_tiles;
+    const i64 w = (i64)tile * M4_TW + lane;
+    const bool live = w < Wc;
+    const i64 wl = live ? w : Wc - 1;
+    const i64 step = M4_U * (M4_NT / 64);
+    // one pass of "rows ^= table look-ups under their selectors" over the virtual rows [v_lo, v_hi): PRI = the 64 rows after the block
+    // (selectors from LDS, leading words recorded), otherwise all rows but those of [x_b, x_e) (selectors from sel[])
+    auto sweep_rows = [&](i64 v_lo, i64 v_hi, bool pri, i64 x_b, i64 x_e, bool have_table) {
+        i64 rn[M4_U];
+        u64 xn[M4_U], sn[M4_U];
+        const i64 shift = x_e - x_b;
+        auto fetch = [&](i64 v0) {
+#pragma unroll
+            for (int u = 0; u < M4_U; ++u) {
+                const i64 v = v0 + u < v_hi ? v0 + u : (v0 < v_hi ? v0 : v_lo);
+                rn[u] = pri ? x_b + v : (v < x_b ? v : v + shift);
+                sn[u] = have_table ? (pri ? s_sel[rn[u] - x_b] : sel[rn[u]]) : 0ULL;
+                xn[u] = rows[rn[u] * Wc + wl];
+            }
+        };
+        i64 v0 = v_lo + M4_U * wave;
+        if (v0 < v_hi) fetch(v0);
+        for (; v0 < v_hi; v0 += step) {
+            i64 r[M4_U];
+            u64 x[M4_U];
+            u32 slo[M4_U], shi[M4_U];
+#pragma unroll
+            for (int u = 0; u < M4_U; ++u) {
+                r[u] = rn[u]; x[u] = xn[u];
+                slo[u] = __builtin_amdgcn_readfirstlane((u32)sn[u]);
+                shi[u] = __builtin_amdgcn_readfirstlane((u32)(sn[u] >> 32));
+            }
+            if (v0 + step < v_hi) fetch(v0 + step);
+#pragma unroll
+            for (int u = 0; u < M4_U; ++u) {
+                const bool mine = (u == 0 || v0 + u < v_hi);
+                if ((slo[u] | shi[u]) != 0u) {
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const u32 e = ((g < 8 ? slo[u] : shi[u]) >> (4 * (g & 7))) & 15u;
+                        x[u] ^= tab[(g * 16 + (int)e) * M4_TW + lane];
+                    }
+                    if (live && mine) rows[r[u] * Wc + w] = x[u];
+                }
+                if (pri && mine) {
+                    const u64 nz = __ballot(live && x[u] != 0);
+                    if (nz && lane == 0) atomicMin(&lead[r[u] - x_b], tile * M4_TW + (int)__builtin_ctzll(nz));
+                }
+            }
+        }
+    };
+    // tables of the XOR combinations of a block's old rows (src: the snapshot, or the rows themselves + snapshot written on the way)
+    auto build_table = [&](const u64 *src, i64 src_stride_rows_base, int kkb, u64 *snap_out) {
+        for (int g = wave; g < 16; g += M4_NT / 64) {
+            u64 sv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sv[i] = (4 * g + i < kkb) ? src[(src_stride_rows_base + 4 * g + i) * Wc + wl] : 0ULL;
+                if (snap_out && live && 4 * g + i < kkb) snap_out[(i64)(4 * g + i) * Wc + w] = sv[i];
+            }
+            u64 t[16];
+            t[0] = 0; t[1] = sv[0]; t[2] = sv[1]; t[3] = sv[0] ^ sv[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[4 + e] = t[e] ^ sv[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[8 + e] = t[e] ^ sv[3];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tab[(g * 16 + e) * M4_TW + lane] = t[e];
+        }
+    };
+    // ---- the sweep of block k over all rows but the next block's (phase 1) ----
+    if (kk != 0) {
+        const i64 n_rows = R - (ne - nb);
+        const i64 per = (n_rows + n_chunks - 1) / n_chunks;
+        const i64 v_lo = (i64)chunk * per, v_hi = v_lo + per < n_rows ? v_lo + per : n_rows;
+        if (v_lo < v_hi) {
+            build_table(snap, 0, kk, nullptr);
+            __syncthreads();
+            sweep_rows(v_lo, v_hi, false, nb, ne, true);
+        }
+    }
+    // ---- everything this workgroup writes for block k is in memory; wait for the others and for the panel ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        atomicAdd(&ms.ctr[0], 1u);
+        bool ok = merged_wait(&ms.ctr[0], ms.epoch * ms.n_wg, true) && merged_wait(&ms.ctr[1], ms.epoch, false);
+        if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        else atomicOr(fs.fail, 1u);
+        s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    // ---- tail 1: selectors of all rows for the block that was just panelled ----
+    const int kk2 = info_next->kk;
+    const i64 i02 = info_next->i0;
+    const int pw2 = info_next->pivw[lane], pb2 = info_next->pivb[lane];
+    const u64 mj2 = info_next->mask[lane] & ((1ULL << lane) - 1ULL);
+    const u64 T2 = info_next->T[lane];
+    const i64 nb2 = i02 + kk2 < R ? i02 + kk2 : R, ne2 = i02 + kk2 + WK < R ? i02 + kk2 + WK : R;
+    if (kk2 != 0) {
+        // (the 64 rows after the new block are left to tail 2: the chunk-0 workgroups overwrite their pivot words, and their selectors in
+        // sel[] are never read — the next launch's sweep skips those rows)
+        for (i64 r = (i64)k * (M4_NT / 64) + wave; r < R; r += (i64)ms.n_wg * (M4_NT / 64)) {
+            if (r >= nb2 && r < ne2) continue;                       // wave-uniform
+            const u64 g = select_row(rows, Wc, r, lane, i02, kk2, pw2, pb2, mj2, T2, fs.rowcnt);
+            if (lane == 0) sel[r] = g;
+        }
+    }
+    if (chunk != 0) return;
+    // ---- tail 2 (one workgroup per column tile): the 64 rows after the new block ----
+    if (kk2 != 0) {
+        for (i64 r = nb2 + wave; r < ne2; r += M4_NT / 64) {
+            const u64 g = select_row(rows, Wc, r, lane, i02, kk2, pw2, pb2, mj2, T2, tile == 0 ? fs.rowcnt : nullptr);   // counted once
+            if (lane == 0) s_sel[r - nb2] = g;
+        }
+    }
+    // every chunk-0 workgroup has READ the pivot words of those rows before any of them writes one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&ms.ctr[2], 1u);
+        const bool ok = merged_wait(&ms.ctr[2], ms.epoch * (u32)n_tiles, true);
+        if (!ok) atomicOr(fs.fail, 1u);
+        s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_ok || kk2 == 0) return;
+    build_table(rows, i02, kk2, snap);                              // + the snapshot the next launch builds its tables from
+    __syncthreads();
+    sweep_rows(0, ne2 - nb2, true, nb2, ne2, true);
+}
+
 // ---- small matrices: the whole reduction in ONE workgroup -------------------------------------------------------------
 // R <= 64 rows and Wc <= 64 words (32 KiB of LDS): the reference loop verbatim — for every row in order: leftmost set column,
 // flags of the rows holding it (one ballot), XOR — without the 3 launches per block of the blocked path.  Stabiliser sets,
@@ -765,6 +978,19 @@ static int rref_dev_impl(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_h
     fs.fail = reinterpret_cast<u32 *>(count.p) + 2;
     fs.full_panel = [] { const char *e = getenv("SYMGPU_GF2_FULL_PANEL"); return !(e && e[0] == '0'); }() ? 1 : 0;
     fs.lean_panel = [] { const char *e = getenv("SYMGPU_GF2_LEAN_PANEL"); return !(e && e[0] == '0'); }() ? 1 : 0;
+    // one launch per block: needs every tile workgroup and the panel co-resident (<= one per CU) and the in-launch waits allowed
+    static const bool merged_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gf2_merged), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess;
+    // MEASURED AND NOT THE DEFAULT (cfg4, round 4): 37.9 us per block against 9.7 + 14.3 us for the two launches — the grid-wide wait has to
+    // write the sweep's 27 MB back from the XCDs' L2s (release) before the tail may read other workgroups' rows, which a kernel boundary does
+    // in 2-4 us and an in-launch release + acquire + counter does in ~10, and the tail's two dependent steps (selectors, then 64 rows) run on
+    // a chip that is otherwise idle.  SYMGPU_GF2_MERGED=1 selects it (tests keep it exercised).
+    const bool merged_env = [] { const char *e = getenv("SYMGPU_GF2_MERGED"); return e && e[0] == '1'; }();
+    const bool merged = fused_select && merged_env && merged_attr && lookahead && m4r && m4_tiles * m4_chunks + 1 <= ctx().num_cu;
+    Scratch msync;
+    if (merged) {
+        SG_TRY(msync.alloc(64));
+        HIP_TRY(hipMemsetAsync(msync.p, 0, 64, st));
+    }
     if (lookahead && m4r && (i64)m4_tiles * m4_chunks + 1 < ((i64)1 << 31)) {
         // Pipeline, three launches per block: select(b) -> phase 0: sweep of the rows of block b+1 + their leading words ->
         // phase 1: panel of block b+1 (-> the other info buffer) inside the sweep of all remaining rows.  The very first
@@ -784,6 +1010,19 @@ static int rref_dev_impl(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_h
             for (i64 k = 0; k < n_iter; ++k, ++it) {
                 BlockInfo *cur = binfo + ((it + 1) & 1), *next = binfo + (it & 1);      // cur: block it-1 (to sweep), next: block it (to panel)
                 fs.epoch = (u32)(it + 1);
+                if (merged) {
+                    // one launch per block (k_gf2_merged); the very first iteration still needs the leading words of rows 0..63: launch A once
+                    if (it == 0)
+                        hipLaunchKernelGGL(k_sweep_m4r<3>, dim3((unsigned)(SEL_PRI + m4_tiles + (R + 15) / 16)), dim3(M4_NT), M4_LDS, st, rows, R, Wc, cur, sel.as<u64>(),
+                                           snap.as<u64>(), m4_tiles, 1, next, state.as<SweepState>(), piv.as<i64>(), count.as<unsigned long long>(), lead.as<int>(), fs);
+                    MergedSync ms;
+                    ms.ctr = msync.as<u32>(); ms.epoch = (u32)(it + 1); ms.n_wg = (u32)(m4_tiles * m4_chunks);
+                    ProfScope prof(2);
+                    hipLaunchKernelGGL(k_gf2_merged, dim3((unsigned)(m4_tiles * m4_chunks + 1)), dim3(M4_NT), M4_LDS, st, rows, R, Wc, cur, sel.as<u64>(), snap.as<u64>(),
+                                       m4_tiles, m4_chunks, next, state.as<SweepState>(), piv.as<i64>(), count.as<unsigned long long>(), lead.as<int>(), fs, ms);
+                    KERNEL_CHECK();
+                    continue;
+                }
                 if (fused_select) {
                     // selectors of block it-1 and phase 0 in one grid (the very first iteration has no block to select for: kk == 0)
                     const unsigned g3 = (unsigned)(SEL_PRI + m4_tiles + (R + 15) / 16);

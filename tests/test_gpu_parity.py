@@ -435,8 +435,11 @@ def test_cleanup_vs_oracle(T, n, dup):
         assert np.array_equal(r, er) and np.array_equal(c, ec)
 
 
+@pytest.mark.parametrize('merged', [False, True])
 @pytest.mark.parametrize('R,C,dens', [(1000, 3000, 0.5), (300, 20000, 0.01), (2000, 500, 0.5), (33, 64, 0.5), (700, 700, 0.003)])
-def test_rref_vs_oracle(R, C, dens):
+def test_rref_vs_oracle(R, C, dens, merged, monkeypatch):
+    if merged:
+        monkeypatch.setenv('SYMGPU_GF2_MERGED', '1')             # one launch per block (k_gf2_merged): measured slower, kept switchable
     rng = np.random.default_rng(500 + R)
     m = rng.random((R, C)) < dens
     m[R // 3] = False
