@@ -3,11 +3,6 @@
 export TMPDIR=/tmp
 tag=${1:-r04}
 dst=gpurun_out/${tag}_profiles; rm -rf $dst; mkdir -p $dst
-# 1. the bench lines as the driver would see them
-timeout 900 python3 bench.py > $dst/${tag}_bench_n1.json 2> $dst/bench_n1.err
-for wl in rotation mul_cleanup gf2 adjacency; do
-  timeout 900 python3 bench.py --workload $wl > $dst/${tag}_${wl}_n1.json 2> $dst/${wl}_n1.err
-done
 # 2. product: PMC + kernel trace (+ traffic JSON tied to product.hip)
 bash tools/pmc_product.sh $tag > $dst/pmc_product.log 2>&1
 cp gpurun_out/$tag/${tag}_traffic.json gpurun_out/$tag/${tag}_product_pmc.txt gpurun_out/$tag/${tag}_bench_n1_kernel_trace.txt gpurun_out/$tag/${tag}_bench_n1_under_rocprof.json $dst/ 2>/dev/null
@@ -25,4 +20,11 @@ python3 profiles/summarize_rocpd.py --pmc $dst/adjpmc/p_results.db | grep -E "co
 timeout 600 rocprofv3 --kernel-trace --stats -d $dst/chain -o t -- python3 tools/bench_chain3.py > $dst/chain.out 2> $dst/chain.log
 { grep chain $dst/chain.out; python3 profiles/summarize_rocpd.py $dst/chain/t_results.db | grep -E "calls|cchain_reg|rs_coop|permute|cchain_flags|cchain_move" ; } > $dst/${tag}_clifford_run_kernel_trace.txt
 rm -rf $dst/adj $dst/adjpmc $dst/chain
+# the traffic JSONs of THIS source go where bench.py looks for them (on the box's copy of the tree), then:
+cp $dst/${tag}_*traffic.json profiles/ 2>/dev/null
+# 5. the bench lines as the driver would see them (un-profiled; their `traffic` comes from the JSONs just written)
+timeout 900 python3 bench.py > $dst/${tag}_bench_n1.json 2> $dst/bench_n1.err
+for wl in rotation mul_cleanup gf2 adjacency; do
+  timeout 900 python3 bench.py --workload $wl > $dst/${tag}_${wl}_n1.json 2> $dst/${wl}_n1.err
+done
 ls -la $dst | head -50
