@@ -998,28 +998,62 @@ __global__ __launch_bounds__(256) void k_emit_fused(const u64 *__restrict__ mark
     if (K == 0) return;                                              // wave-uniform
     const i64 p_base = wordprefix[2 * w0];
     u32 o_min = 0xFFFFFFFFu, o_max = 0u;                             // this lane's kept terms: range of their outer indices
+    // Nothing the coefficients need depends on the bitmap's CONTENT: the pair (i, o) of an index, its patch / phase-exponent bits and its
+    // operands' coefficients are addressed by the index alone.  They are therefore fetched for all NW x 64 indices at once, next to the
+    // bitmap words and the prefix — one memory round trip per wavefront instead of two dependent ones (the prologue alone took 0.25 ms of the
+    // stage's 1.19 at cfg3 and did not overlap the row stream).
+    u32 ti_[NW], to_[NW], pw_[NW], el_[NW], eh_[NW];
+    double2 ca_[NW], cb_[NW], cs_[NW];
+    // The pair of the wavefront's FIRST index costs a square root (triangular slots) or a division; every other index of the wavefront is a
+    // few additions away: consecutive indices walk along a row of the (o, i) plane and step to the next row when i reaches Ni (the per-index
+    // tri_pair of all NW x 64 indices was most of the prologue's 0.25 ms: ~150 instructions each).
+    u32 o_first = 0, i_first = 0;
+    if (PAIR) {
+        const u32 t0 = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(w0 * 64));
+        if (TRI) tri_pair(t0, Ni, o_first, i_first);
+        else { o_first = t0 / Ni; i_first = t0 - o_first * Ni; }
+        o_first = (u32)__builtin_amdgcn_readfirstlane((int)o_first); i_first = (u32)__builtin_amdgcn_readfirstlane((int)i_first);
+    }
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+        const i64 tt = (w0 + u) * 64 + lane;
+        const u32 t = (u32)(tt < T ? tt : T - 1);                     // clamped: the surplus lanes of the last word load valid addresses
+        ti_[u] = t; to_[u] = 0;
+        if (PAIR) {
+            u32 o = o_first;
+            u64 i = (u64)i_first + (t - (u32)(w0 * 64));
+            // row o holds the indices i in [TRI ? o : 0, Ni): step rows while i runs past the end (0 or 1 steps except in the last short rows)
+            while (i >= Ni) { i -= Ni; ++o; if (TRI) i += o; }
+            to_[u] = o; ti_[u] = (u32)i;
+        }
+        pw_[u] = lz.mode != 0 ? lz.patchbits[t >> 5] : 0xFFFFFFFFu;
+        if (lz.mode == 1) {
+            el_[u] = lz.e_lo[t >> 5]; eh_[u] = lz.e_hi[t >> 5];
+            ca_[u] = reinterpret_cast<const double2 *>(lz.ci)[ti_[u]];
+            cb_[u] = reinterpret_cast<const double2 *>(lz.co)[to_[u]];
+        } else if (lz.mode == 2) {
+            cs_[u] = reinterpret_cast<const double2 *>(lz.coeff)[t];
+        }
+    }
 #pragma unroll
     for (int u = 0; u < NW; ++u) {
         if ((bits[u] >> lane) & 1ULL) {
             const u32 rank = off[u] + (u32)__popcll(bits[u] & ((1ULL << lane) - 1ULL));
             const u32 t = (u32)((w0 + u) * 64 + lane);
-            u32 ti = t, to = 0;
-            if (PAIR && TRI) tri_pair(t, Ni, to, ti);
-            else if (PAIR) { to = t / Ni; ti = t - to * Ni; }
+            const u32 ti = ti_[u], to = to_[u];
             double2 cf;
-            if (lz.mode == 0 || ((lz.patchbits[t >> 5] >> (t & 31u)) & 1u)) cf = reinterpret_cast<const double2 *>(sum_of)[t];
+            if (lz.mode == 0 || ((pw_[u] >> (t & 31u)) & 1u)) cf = reinterpret_cast<const double2 *>(sum_of)[t];
             else if (lz.mode == 1) {                                  // a single of a packed product: c_i * c_o * i^e from the operand tables
-                const int e = (int)(((lz.e_lo[t >> 5] >> (t & 31u)) & 1u) | (((lz.e_hi[t >> 5] >> (t & 31u)) & 1u) << 1));
+                const int e = (int)(((el_[u] >> (t & 31u)) & 1u) | (((eh_[u] >> (t & 31u)) & 1u) << 1));
                 double cx, cy;
-                pair_coefficient(lz.ci[2 * ti], lz.ci[2 * ti + 1], lz.co[2 * to], lz.co[2 * to + 1], e, cx, cy);
+                pair_coefficient(ca_[u].x, ca_[u].y, cb_[u].x, cb_[u].y, e, cx, cy);
                 if (lz.squared && ti != to) {
                     if (e & 1) { cx = 0.0; cy = 0.0; }
                     else { cx = __dadd_rn(cx, cx); cy = __dadd_rn(cy, cy); }
                 }
                 cf.x = __dadd_rn(0.0, cx); cf.y = __dadd_rn(0.0, cy);
             } else {                                                  // a single of an indexed operator: 0.0 + its own coefficient
-                const double2 c0 = reinterpret_cast<const double2 *>(lz.coeff)[t];
-                cf.x = __dadd_rn(0.0, c0.x); cf.y = __dadd_rn(0.0, c0.y);
+                cf.x = __dadd_rn(0.0, cs_[u].x); cf.y = __dadd_rn(0.0, cs_[u].y);
             }
             reinterpret_cast<double2 *>(out_coeff)[p_base + rank] = cf;
             if (out_first) out_first[p_base + rank] = PAIR ? (((u64)to << 32) | ti) : (u64)t;
@@ -1036,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_emit_fused(const u64 *__restrict__ mark
     // share it) and a row length that divides 64: the lane's chunk of that row is loop invariant — one gather and one list read per
     // 16 bytes written instead of two each.
     bool one_outer = false;
-    if (PAIR && wsh >= 0 && Wq <= 64 && !lz.no_one_outer) {
+    if (PAIR && wsh >= 0 && Wq <= 64 && lz.no_one_outer == 0) {
 #pragma unroll
         for (int sft = 32; sft > 0; sft >>= 1) {
             const u32 a = (u32)__shfl_xor((int)o_min, sft), b = (u32)__shfl_xor((int)o_max, sft);
