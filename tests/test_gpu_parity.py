@@ -658,6 +658,57 @@ def test_f3_f4_device_paths_vs_host_restatements():
         assert got == expect                                                             # dyadic amplitudes: bit for bit, same order of additions
 
 
+def test_f3_f4_entry_point_edge_cases():
+    """C-ABI edge cases of csrc/project.hip and of the indexed cleanups: empty operands, no stabilisers, nothing survives, no shared basis
+    string, threshold on the indexed product, wrong Wq."""
+    from symmer_amd import _lib
+    rng = np.random.default_rng(99)
+    n = 70
+    symp = rng.random((50, 2 * n)) < 0.3
+    op = kernels.DeviceOp.upload(packing.pack_rows(symp), dyadic(rng, 50))
+    # no stabilisers: everything survives, qubits 0..9 kept
+    res, n_s = kernels.project_dev(op, np.zeros((0, 4), dtype='<u8'), np.zeros(0, dtype=int), np.arange(10), n)
+    r, c = res.download(); res.free()
+    er, ec = onp.cleanup_op(symp[:, np.hstack([np.arange(10), n + np.arange(10)])], op.download()[1])
+    assert n_s == 50 and np.array_equal(packing.unpack_rows(r, 10), er) and np.array_equal(c, ec)
+    # a stabiliser nothing commutes with... X_0 and Z_0 together remove every term that touches qubit 0 in either block; force all to touch it
+    symp2 = symp.copy(); symp2[:, 0] = True; symp2[:, n] = False                      # X on qubit 0: anticommutes with Z_0
+    op2 = kernels.DeviceOp.upload(packing.pack_rows(symp2), dyadic(rng, 50))
+    z0 = np.zeros((1, 2 * n), dtype=bool); z0[0, n] = True
+    res, n_s = kernels.project_dev(op2, packing.pack_rows(z0), np.array([1]), np.arange(1, n), n)
+    assert n_s == 0 and res.n_terms == 0
+    res.free(); op2.free()
+    # empty operator
+    empty = kernels.DeviceOp.upload(np.zeros((0, 2), dtype='<u8'), np.zeros(0, dtype=complex))          # 2 qubits, no terms
+    res, n_s = kernels.project_dev(empty, packing.pack_rows(np.array([[False, False, True, False]])), np.array([1]), np.arange(1, 2), 2)
+    assert n_s == 0 and res.n_terms == 0
+    res.free()
+    assert kernels.noncontextual_dev(empty) is True
+    empty.free()
+    with pytest.raises(_lib.SymgpuError):
+        kernels.project_dev(op, np.zeros((0, 4), dtype='<u8'), np.zeros(0, dtype=int), np.arange(10), 200)       # n_qubits does not match Wq
+    one = kernels.DeviceOp.upload(packing.pack_rows(symp[:1]))
+    assert kernels.noncontextual_dev(one) is True
+    one.free(); op.free()
+    # states without a common basis string, and a state against itself
+    a = kernels.cleanup_dev(kernels.DeviceOp.upload(packing.pack_rows(np.hstack([np.eye(8, dtype=bool), np.zeros((8, 8), dtype=bool)])), dyadic(rng, 8)))
+    b_rows = np.hstack([~np.eye(8, dtype=bool), np.zeros((8, 8), dtype=bool)])
+    b = kernels.cleanup_dev(kernels.DeviceOp.upload(packing.pack_rows(b_rows), dyadic(rng, 8)))
+    assert kernels.state_inner_dev(a, b) == 0
+    ra, ca = a.download()
+    assert kernels.state_inner_dev(a, a) == sum((x * x for x in ca), 0)
+    raw = kernels.DeviceOp.upload(ra, ca)
+    with pytest.raises(_lib.SymgpuError):
+        kernels.state_inner_dev(raw, a)                                                # not from a cleanup: refused
+    for h in (a, b, raw):
+        h.free()
+    # indexed product with a threshold: kept terms only, indices still those of the first pairs
+    A = onp.pack_rows(rng.random((40, 2 * 5)) < 0.4); ca = dyadic(rng, 40)
+    r, c, i_f, o_f = kernels.mul_cleanup_indexed(A, ca, A, ca, True, 1e-15)
+    er, ec = oc.mul(A, ca, A, ca)
+    assert np.array_equal(r, er) and np.array_equal(c, ec) and np.array_equal(A[i_f] ^ A[o_f], r) and np.all(np.diff(o_f * 40 + i_f) > 0)
+
+
 def test_independent_op_rotations_and_sector():
     """tests/test_operators/test_independent_op.py:77-109 (rotation onto single-qubit Z / X, sector assignment)."""
     k = known()
