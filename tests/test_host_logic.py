@@ -193,3 +193,48 @@ def test_circuit_rotation_string_last_write_wins_and_negative_indices():
         C.get_rotation_string('X', [70])
     with pytest.raises(AssertionError):
         C.get_rotation_string('X', [-71])
+
+
+def test_hash_partition_classes_are_linear_and_shares_partition_the_product():
+    """symmer_amd/parallel.py, hash-partitioned multi-GPU cleanup (no GPU: checker kernels built on the oracle): the row class is GF(2)-linear
+    (class of a product row = XOR of the operands' classes), every pair has exactly one owner for any world size, and the shares of
+    G = 1 .. 8 ranks merged by first pair index are the single-process result — rows, order and sums (dyadic: bit for bit)."""
+    from symmer_amd import parallel
+    from oracle import oracle_c as oc, oracle_np as onp
+    rng = np.random.default_rng(11)
+    n, Ni, No = 70, 90, 57
+    A = onp.pack_rows(rng.random((Ni, 2 * n)) < 0.3); B = onp.pack_rows(rng.random((No, 2 * n)) < 0.3)
+    A[40:50] = A[:10]; B[30:35] = B[:5]
+    a = (rng.integers(-8, 9, Ni) + 1j * rng.integers(-8, 9, Ni)) / 16.0; b = (rng.integers(-8, 9, No) + 1j * rng.integers(-8, 9, No)) / 16.0
+    for bits in (1, 3, 5):
+        ca, cb = parallel.linear_row_classes(A, bits), parallel.linear_row_classes(B, bits)
+        prod = (A[:, None, :] ^ B[None, :, :]).reshape(-1, A.shape[1])
+        assert np.array_equal(parallel.linear_row_classes(prod, bits), (ca[:, None] ^ cb[None, :]).ravel())
+        assert ca.max() < (1 << bits)
+
+    def indexed_cleanup(r, c, thr):
+        first, inv = onp.first_occurrence_unique(np.ascontiguousarray(r).view(np.uint8).reshape(r.shape[0], -1))
+        sums = np.zeros(first.shape[0], dtype=complex)
+        np.add.at(sums, inv, c)
+        keep = np.ones(first.shape[0], dtype=bool) if thr is None else np.abs(sums) > thr
+        return r[first][keep], sums[keep], first[keep]
+
+    def indexed_mul(inner, ci, outer, co, left):
+        r, c = oc.mul_allpairs(inner, ci, outer, co, left)
+        rr, cc, first = indexed_cleanup(r, c, None)
+        return rr, cc, first % inner.shape[0], first // inner.shape[0]
+    for X, x, Y, y, left in ((A, a, B, b, True), (A, a, A, a, True), (B, b, A, a, False)):
+        pr, pc = oc.mul_allpairs(X, x, Y, y, left)
+        er, ec = oc.cleanup(pr, pc, 1e-15)
+        for G in range(1, 9):
+            shares, owned = [], 0
+            for rank in range(G):
+                st = {}
+                shares.append(parallel.hash_partition_local(X, x, Y, y, rank, G, left, 1e-15, indexed_mul, indexed_cleanup, st))
+                owned += st['pairs_owned']
+            assert owned == X.shape[0] * Y.shape[0]
+            g = np.concatenate([s[2] for s in shares])
+            order = np.argsort(g, kind='stable')
+            assert np.unique(g).size == g.size
+            assert np.array_equal(np.concatenate([s[0] for s in shares], axis=0)[order], er)
+            assert np.array_equal(np.concatenate([s[1] for s in shares])[order], ec)
