@@ -134,6 +134,16 @@ int symgpu_mul_cleanup_dev(symgpu_op_t inner, symgpu_op_t outer, int inner_is_le
 int symgpu_cleanup_indexed_dev(symgpu_op_t in, double thr, int use_thr, symgpu_op_t *out);
 int symgpu_mul_cleanup_indexed_dev(symgpu_op_t inner, symgpu_op_t outer, int inner_is_left, double thr, int use_thr, symgpu_op_t *out);
 int symgpu_op_first_index(symgpu_op_t op, uint64_t *first_host, int64_t capacity_rows);
+/* Device side of the hash-partitioned multi-GPU cleanup (symmer_amd/parallel.py): out = op[idx] (rows + coefficients); the indices of an
+ * indexed product of two gathered sub-operands rewritten to pair indices of the complete operands (o_global * Ni_global + i_global); an index
+ * array attached to an operator (the shares received from other ranks); and the merge of indexed operators: concatenated, ordered by index
+ * (keys below 2^key_bits; 0 = 64), then — do_cleanup — rows that several parts share merged at their smallest index with the cleanup's
+ * semantics and threshold.  The result carries its indices again (ascending). */
+int symgpu_op_gather(symgpu_op_t op, const int64_t *idx_host, int64_t n, symgpu_op_t *out);
+int symgpu_part_global_index(symgpu_op_t part, const int64_t *inner_idx_host, int64_t n_inner, const int64_t *outer_idx_host, int64_t n_outer,
+                             int64_t Ni_global);
+int symgpu_op_set_first_index(symgpu_op_t op, const uint64_t *first_host);
+int symgpu_merge_indexed_dev(const symgpu_op_t *parts, int n_parts, int key_bits, int do_cleanup, double thr, int use_thr, symgpu_op_t *out);
 
 /* ---- a7: _rotate_by_single_Pword (base.py:1090-1161), one fused pass ------------------------------
  * clifford_k < 0: non-Clifford: cleanup([commuting, cos*anticommuting, -i*sin*(anticommuting*Q)], thr)

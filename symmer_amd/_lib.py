@@ -72,6 +72,10 @@ SIGNATURES = {
     'symgpu_cleanup_indexed_dev': [P, c_dbl, c_int, PP],
     'symgpu_mul_cleanup_indexed_dev': [P, P, c_int, c_dbl, c_int, PP],
     'symgpu_op_first_index': [P, P, c_i64],
+    'symgpu_op_gather': [P, P, c_i64, PP],
+    'symgpu_part_global_index': [P, P, c_i64, P, c_i64, c_i64],
+    'symgpu_op_set_first_index': [P, P],
+    'symgpu_merge_indexed_dev': [P, c_int, c_int, c_int, c_dbl, c_int, PP],
     'symgpu_rotate_single': [P, P, c_i64, c_int, P, c_dbl, c_dbl, c_int, c_dbl, P, P, c_i64, P, P],
     'symgpu_rotate_single_dev': [P, P, c_dbl, c_dbl, c_int, c_dbl, PP, P],
     'symgpu_rotate_clifford_chain_dev': [P, P, P, c_i64, PP],

@@ -362,3 +362,42 @@ def cleanup_indexed(rows, coeff, zero_threshold=1e-15):
     finally:
         op.free()
     return r, c, first
+
+
+# ---- device-resident pieces of the hash-partitioned multi-GPU cleanup (csrc/partition.hip) -----------------------------------------
+def op_gather(op, idx):
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    out = ctypes.c_void_p()
+    check(_lib.lib().symgpu_op_gather(op.handle, addr(idx), idx.shape[0], ctypes.byref(out)))
+    return DeviceOp(out)
+
+
+def mul_cleanup_indexed_dev(inner, outer, inner_is_left=True, zero_threshold=None):
+    thr, use = _thr_args(zero_threshold)
+    out = ctypes.c_void_p()
+    check(_lib.lib().symgpu_mul_cleanup_indexed_dev(inner.handle, outer.handle, 1 if inner_is_left else 0, thr, use, ctypes.byref(out)))
+    return DeviceOp(out)
+
+
+def part_global_index(part, inner_idx, outer_idx, ni_global):
+    inner_idx = np.ascontiguousarray(inner_idx, dtype=np.int64); outer_idx = np.ascontiguousarray(outer_idx, dtype=np.int64)
+    check(_lib.lib().symgpu_part_global_index(part.handle, addr(inner_idx), inner_idx.shape[0], addr(outer_idx), outer_idx.shape[0], int(ni_global)))
+
+
+def merge_indexed_dev(parts, key_bits=0, do_cleanup=True, zero_threshold=1e-15):
+    """Indexed device operators -> one, ordered by index; ``do_cleanup``: shared rows merged at their smallest index + threshold."""
+    arr = (ctypes.c_void_p * len(parts))(*[p.handle for p in parts])
+    thr, use = _thr_args(zero_threshold)
+    out = ctypes.c_void_p()
+    check(_lib.lib().symgpu_merge_indexed_dev(ctypes.addressof(arr), len(parts), int(key_bits), 1 if do_cleanup else 0, thr, use, ctypes.byref(out)))
+    return DeviceOp(out)
+
+
+def op_first_index(op):
+    return _first_index(op)
+
+
+def op_set_first_index(op, first):
+    first = np.ascontiguousarray(first, dtype='<u8')
+    assert first.shape[0] == op.n_terms
+    check(_lib.lib().symgpu_op_set_first_index(op.handle, addr(first)))

@@ -397,17 +397,44 @@ class Communicator:
         cat.free()
         return res
 
-    def mul_cleanup_hash_partitioned(self, inner_full, outer_full, inner_is_left=True, zero_threshold=1e-15, stats=None):
+    def mul_cleanup_hash_partitioned(self, inner_full, outer_full, inner_is_left=True, zero_threshold=1e-15, stats=None, gather=True):
         """Fused product + cleanup of two device operators that are COMPLETE on every rank (after :meth:`allgather_op`), the pairs partitioned
-        over the ranks by the GF(2)-linear class of their product row (:func:`hash_partitioned_mul_cleanup`): all duplicates of a row meet
-        on one rank — also the twins (i, o) / (o, i) of a squared operator, which the contiguous split of :meth:`mul_cleanup_sharded` leaves
-        on different ranks — no key and no partial product crosses the wire, only each rank's share of the final result.  Returns a DeviceOp
-        (the result is replicated).  This version stages the sub-operands and the result through host arrays (the operands are small; the
-        result share is what travels anyway); the per-rank device work is the indexed fused product + cleanup (``symgpu_mul_cleanup_indexed_dev``)."""
-        from . import kernels
-        ir, ic = inner_full.download(); orows, oc_ = outer_full.download()
-        rows, coeff = hash_partitioned_mul_cleanup(ir, ic, orows, oc_, self, inner_is_left, zero_threshold, stats=stats)
-        return kernels.DeviceOp.upload(rows, coeff) if rows.shape[0] else kernels.DeviceOp.alloc(1, inner_full.info()[1], with_coeff=True)
+        over the ranks by the GF(2)-linear class of their product row (:func:`hash_partition_local_dev`): all duplicates of a row meet on one
+        rank — also the twins (i, o) / (o, i) of a squared operator, which the contiguous split of :meth:`mul_cleanup_sharded` leaves on
+        different ranks — no key and no partial product crosses the wire.  The rank's share is computed, ordered and merged on the device.
+        ``gather=False`` returns this rank's share (a DeviceOp carrying the pair index of each term's first occurrence: the result stays
+        sharded); otherwise the shares are all-gathered (rows and coefficients through :meth:`allgather_op`, the 8-byte indices over the
+        control plane) and ordered by pair index on every rank: the replicated result in the reference's first-occurrence order."""
+        from . import _lib, kernels
+        share = hash_partition_local_dev(inner_full, outer_full, self.rank, self.world, inner_is_left, zero_threshold, stats)
+        if not gather or not self.gathers:
+            return share
+        n_loc, wq, _ = share.info()
+        counts = np.frombuffer(self._allgather_bytes(np.int64(n_loc).tobytes()), dtype=np.int64)
+        ts = max(1, int(counts.max()))
+        g_loc = np.zeros(ts, dtype='<u8'); g_loc[:n_loc] = kernels.op_first_index(share)
+        all_g = np.frombuffer(self._allgather_bytes(g_loc.tobytes()), dtype='<u8').reshape(self.world, ts)
+        shard = kernels.DeviceOp.alloc(ts, wq, with_coeff=True)
+        _lib.check(_lib.lib().symgpu_op_copy_rows(shard.handle, 0, share.handle, 0, n_loc))
+        shard.set_rows(n_loc)
+        share.free()
+        full = kernels.DeviceOp.alloc(ts * self.world, wq, with_coeff=True)
+        self.allgather_op(shard, full, ts * self.world)
+        shard.free()
+        parts = []
+        try:
+            for r in range(self.world):
+                part = kernels.DeviceOp.alloc(max(1, int(counts[r])), wq, with_coeff=True)
+                _lib.check(_lib.lib().symgpu_op_copy_rows(part.handle, 0, full.handle, r * ts, int(counts[r])))
+                part.set_rows(int(counts[r]))
+                kernels.op_set_first_index(part, all_g[r, :counts[r]])
+                parts.append(part)
+            full.free()
+            key_bits = max(1, int(inner_full.n_terms * outer_full.n_terms - 1).bit_length())
+            return kernels.merge_indexed_dev(parts, key_bits, False)
+        finally:
+            for p in parts:
+                p.free()
 
     def verify_allgather(self, shard, full, n_rows_total):
         """Self-check of the RCCL data plane (call once, outside any timed region): gather the same shards a second time through
@@ -644,6 +671,55 @@ def hash_partition_local(inner_rows, inner_coeff, outer_rows, outer_coeff, rank,
         stats.update(pairs_owned=int(pairs_owned), pairs_total=int(Ni) * int(No), keys_exchanged=0,
                      bytes_sent=int(rows.nbytes + coeff.nbytes + g.nbytes) if G > 1 else 0)
     return np.ascontiguousarray(rows, dtype='<u8'), np.ascontiguousarray(coeff), g
+
+
+def hash_partition_local_dev(inner, outer, rank, world, inner_is_left=True, zero_threshold=1e-15, stats=None, classes=None):
+    """:func:`hash_partition_local` with the operands and every intermediate on the DEVICE (``csrc/partition.hip``): ``inner`` / ``outer`` are
+    complete DeviceOps; sub-operands are gathered on the device, each sub-product is one indexed fused product + cleanup, the parts are ordered
+    by pair index and merged there.  Only the operands' rows visit the host once, for their class bits (``classes`` = (cls_i, cls_o) skips
+    that).  Returns a DeviceOp that carries the pair index of every term's first occurrence (``kernels.op_first_index``)."""
+    from . import kernels
+    Ni, wq, _ = inner.info()
+    No = outer.info()[0]
+    G = world
+    n_bits = 1
+    while (1 << n_bits) < G:
+        n_bits += 1
+    if G & (G - 1):
+        n_bits += 2
+    if classes is None:
+        cls_i = linear_row_classes(inner.download(with_coeff=False), n_bits)
+        cls_o = cls_i if outer is inner else linear_row_classes(outer.download(with_coeff=False), n_bits)
+    else:
+        cls_i, cls_o = classes
+    parts, pairs_owned = [], 0
+    try:
+        for a in range(1 << n_bits):
+            ia = np.flatnonzero(cls_i == a)
+            oa = np.flatnonzero(((cls_o ^ a) % G) == rank)
+            if ia.size == 0 or oa.size == 0:
+                continue
+            pairs_owned += ia.size * oa.size
+            sub_i = kernels.op_gather(inner, ia); sub_o = kernels.op_gather(outer, oa)
+            try:
+                part = kernels.mul_cleanup_indexed_dev(sub_i, sub_o, inner_is_left, None)
+            finally:
+                sub_i.free(); sub_o.free()
+            kernels.part_global_index(part, ia, oa, Ni)
+            parts.append(part)
+        key_bits = max(1, int(Ni * No - 1).bit_length())
+        if parts:
+            res = kernels.merge_indexed_dev(parts, key_bits, True, zero_threshold)
+        else:
+            res = kernels.DeviceOp.alloc(1, wq, with_coeff=True)
+            kernels.op_set_first_index(res, np.zeros(0, dtype='<u8'))
+    finally:
+        for p in parts:
+            p.free()
+    if stats is not None:
+        stats.update(pairs_owned=int(pairs_owned), pairs_total=int(Ni) * int(No), keys_exchanged=0,
+                     bytes_sent=int(res.n_terms * (16 * wq + 16 + 8)) if G > 1 else 0)
+    return res
 
 
 def hash_partitioned_mul_cleanup(inner_rows, inner_coeff, outer_rows, outer_coeff, comm, inner_is_left=True, zero_threshold=1e-15,

@@ -59,6 +59,19 @@ er, ec = oc.mul(A2, a2, B2, b2)
 assert np.array_equal(rr, er) and np.array_equal(rc, ec), 'sharded product + cleanup differs from the oracle'
 for h in (inner, outer, res):
     h.free()
+# the same product, and the squared operator, with the PAIRS partitioned by the linear class of their product row (both operands complete on
+# every rank, the share computed / merged on the device, shares all-gathered and ordered by pair index): the replicated result is the oracle's
+innerf = DeviceOp.upload(A2, a2); outerf = DeviceOp.upload(B2, b2)
+for X, Y, ex in ((innerf, outerf, (A2, a2, B2, b2)), (innerf, innerf, (A2, a2, A2, a2))):
+    st = {}
+    res = comm.mul_cleanup_hash_partitioned(X, Y, True, 1e-15, stats=st)
+    rr, rc = res.download()
+    pr, pc = oc.mul_allpairs(*ex, True)
+    er, ec = oc.cleanup(pr, pc, 1e-15)
+    assert np.array_equal(rr, er) and np.array_equal(rc, ec), 'hash-partitioned product + cleanup differs from the oracle'
+    assert st['keys_exchanged'] == 0 and 0 < st['pairs_owned'] < st['pairs_total']
+    res.free()
+innerf.free(); outerf.free()
 comm.barrier()
 plane = comm.data_plane
 comm.close()

@@ -816,6 +816,41 @@ def test_indexed_cleanups_and_hash_partitioned_shares():
                 assert np.array_equal(rows, er) and np.array_equal(coeff, ec), (n, G, left)
 
 
+def test_hash_partitioned_shares_device_resident():
+    """The device-resident share computation (csrc/partition.hip: gather of sub-operands, indexed fused product + cleanup, pair indices, merge by
+    index) for G = 1, 2, 3, 8: the shares merged by pair index on the device (symgpu_merge_indexed_dev without cleanup) are the oracle's result,
+    also above the 2^22-key gate of the lazy cleanup flow (squared 3,000-term operator) and with Gaussian coefficients within 1e-12."""
+    from symmer_amd import parallel
+    from symmer_amd.kernels import DeviceOp
+    rng = np.random.default_rng(707)
+    for n, Ni, No, gauss in ((100, 700, 400, False), (1000, 900, 900, False), (100, 3000, 3000, False), (70, 500, 300, True)):
+        A = onp.pack_rows(rng.random((Ni, 2 * n)) < 0.3); B = onp.pack_rows(rng.random((No, 2 * n)) < 0.3)
+        if Ni < 2000:
+            A[Ni // 2: Ni // 2 + 20] = A[:20]; B[No // 2:] = B[: No - No // 2]
+        a = (rng.standard_normal(Ni) + 1j * rng.standard_normal(Ni)) if gauss else dyadic(rng, Ni)
+        b = (rng.standard_normal(No) + 1j * rng.standard_normal(No)) if gauss else dyadic(rng, No)
+        dA, dB = DeviceOp.upload(A, a), DeviceOp.upload(B, b)
+        for X, Y, ex, left in ((dA, dB, (A, a, B, b), True), (dA, dA, (A, a, A, a), True), (dB, dA, (B, b, A, a), False)):
+            if Ni >= 3000 and X is not Y:
+                continue
+            pr, pc = oc.mul_allpairs(*ex, left)
+            er, ec = oc.cleanup(pr, pc, 1e-15)
+            for G in ((1, 2, 3, 8) if Ni < 3000 else (2,)):
+                shares = [parallel.hash_partition_local_dev(X, Y, rank, G, left, 1e-15) for rank in range(G)]
+                key_bits = int(ex[0].shape[0] * ex[2].shape[0] - 1).bit_length()
+                merged = kernels.merge_indexed_dev(shares, key_bits, False)
+                rows, coeff = merged.download()
+                g = kernels.op_first_index(merged)
+                assert np.all(np.diff(g.astype(np.int64)) > 0)
+                if gauss:
+                    assert_op_equal(onp.unpack_rows(rows, n), coeff, onp.unpack_rows(er, n), ec, exact=False, tol=TOL)
+                else:
+                    assert np.array_equal(rows, er) and np.array_equal(coeff, ec), (n, G, left)
+                for h in shares + [merged]:
+                    h.free()
+        dA.free(); dB.free()
+
+
 def test_mul_cleanup_tiled_over_outer_operand():
     """Products beyond the 32-bit pair-index limit are tiled over the outer operand; forced here with a tiny tile."""
     rng = np.random.default_rng(8)
