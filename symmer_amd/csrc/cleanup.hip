@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void k_mark_singles(const u64 *__restrict__ ke
     }
     if (hist) {
         __syncthreads();
-        hist[(i64)threadIdx.x * n_tiles + blockIdx.x] = s_h[threadIdx.x];     // digit-major, as k_rs_hist files it
+        hist[(i64)blockIdx.x * 256 + threadIdx.x] = s_h[threadIdx.x];         // tile-major, as k_rs_hist files it
     }
 }
 

@@ -70,6 +70,7 @@ struct Context {
     u32 *sort_state = nullptr;     // one-launch radix sort (sort.hip): barrier counter, time-out flag, tile histograms
     u32 sort_bar_base = 0;
     bool sort_coop_disabled = false;
+    u32 *sort_scan_ticket = nullptr;   // radix sort: "last workgroup finishes the scan" ticket, zero between launches
     bool res_disabled = false;     // a barrier timed out once (workgroups not co-resident): the process keeps to the multi-launch paths
 };
 Context &ctx();
@@ -144,8 +145,8 @@ void op_invalidate(symgpu_op_s *op);
 
 // sort.hip
 int exclusive_scan_u32(const u32 *in, u32 *out, i64 n, u32 *total_dev /* may be null: device u32 */);
-// first_hist (optional, device, 256 * ceil(n / SORT_TILE) u32): the digit-major tile histograms of the FIRST pass
-// (hist[digit * n_tiles + tile] = keys of tile `tile` whose bits [begin_bit, begin_bit + 8) equal `digit`), formed by a kernel of the
+// first_hist (optional, device, 256 * ceil(n / SORT_TILE) u32): the TILE-major ([tile][256]) tile histograms of the FIRST pass
+// (hist[tile * 256 + digit] = keys of tile `tile` whose bits [begin_bit, begin_bit + 8) equal `digit`), formed by a kernel of the
 // caller's that reads the keys anyway; the buffer then serves the later passes
 constexpr int SORT_TILE = 4096;
 int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp, i64 n, int begin_bit, int end_bit,

@@ -150,38 +150,58 @@ __global__ __launch_bounds__(256) void k_rs_hist(const u64 *__restrict__ keys, i
     for (int k = 0; k < RS_ITEMS; ++k)
         if (base + k * 256 + threadIdx.x < n) atomicAdd(&h[(kk[k] >> shift) & 255], 1u);
     __syncthreads();
-    tile_hist[(i64)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];   // digit-major
+    tile_hist[(i64)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];       // tile-major: one coalesced KB per tile, here and in the scatter
 }
 
-// Exclusive scan of the digit-major tile histograms, ONE launch per pass: block d scans row d (the counts of digit d over the tiles, in
-// tile order) in place and leaves the row's total in row_total[d]; the scatter kernel adds the exclusive scan of the 256 row totals
-// itself.  (The generic three-level exclusive_scan_u32 over all 256 * n_tiles counters was three launches and 36 us per pass at cfg3.)
-constexpr int RSS_ITEMS = 16;
-__global__ __launch_bounds__(256) void k_rs_scan_rows(u32 *__restrict__ tile_hist, i64 n_tiles, u32 *__restrict__ row_total) {
-    __shared__ u32 s_wave[4];
-    u32 *row = tile_hist + (i64)blockIdx.x * n_tiles;
-    u32 carry = 0;
-    for (i64 base = 0; base < n_tiles; base += 256 * RSS_ITEMS) {
-        const i64 b = base + (i64)threadIdx.x * RSS_ITEMS;
-        u32 v[RSS_ITEMS];
-        u32 sum = 0;
+// Exclusive scan of the tile histograms over the tiles, per digit, ONE launch per pass.  The histograms are TILE-major (256 counters of a
+// tile side by side: every access of k_rs_hist, of this kernel and of the scatter is a coalesced KB; the digit-major layout of rounds 2-3
+// made the scatter gather its 256 offsets from 256 different lines).  Workgroup c scans a chunk of `chunk_len` tiles in place (thread d
+// walks column d, sixteen rows in flight) and files the chunk's totals write-through; the LAST workgroup to finish (ticket) turns the
+// chunk totals into chunk_excl[c][d] and row_total[d].  The scatter adds tile_off[tile][d] + chunk_excl[tile / chunk_len][d].
+constexpr int RSC_MAX_CHUNKS = 128;
+constexpr int RSC_MIN_LEN = 16;
+__global__ __launch_bounds__(256) void k_rs_scan_cols(u32 *__restrict__ tile_hist, i64 n_tiles, i64 chunk_len, u32 *__restrict__ chunk_tot,
+                                                       u32 *__restrict__ chunk_excl, u32 *__restrict__ row_total, u32 *__restrict__ ticket) {
+    __shared__ u32 s_last;
+    const int d = threadIdx.x;
+    const i64 t0 = (i64)blockIdx.x * chunk_len, t1 = t0 + chunk_len < n_tiles ? t0 + chunk_len : n_tiles;
+    u32 run = 0;
+    for (i64 t = t0; t < t1; t += 16) {
+        u32 v[16];
 #pragma unroll
-        for (int k = 0; k < RSS_ITEMS; ++k) { v[k] = b + k < n_tiles ? row[b + k] : 0u; sum += v[k]; }
-        u32 total;
-        u32 excl = carry + block_excl_scan_256(sum, s_wave, &total);
+        for (int k = 0; k < 16; ++k) v[k] = t + k < t1 ? tile_hist[(t + k) * 256 + d] : 0u;
 #pragma unroll
-        for (int k = 0; k < RSS_ITEMS; ++k) {
-            if (b + k < n_tiles) row[b + k] = excl;
-            excl += v[k];
+        for (int k = 0; k < 16; ++k) {
+            if (t + k < t1) tile_hist[(t + k) * 256 + d] = run;
+            run += v[k];
         }
-        carry += total;
     }
-    if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
+    __hip_atomic_store(chunk_tot + (i64)blockIdx.x * 256 + d, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the write-through stores have left before the ticket is taken
+    __syncthreads();
+    if (d == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    u32 acc = 0;
+    for (int c = 0; c < (int)gridDim.x; c += 32) {
+        u32 v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            v[k] = c + k < (int)gridDim.x ? __hip_atomic_load(chunk_tot + (i64)(c + k) * 256 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if (c + k < (int)gridDim.x) chunk_excl[(i64)(c + k) * 256 + d] = acc;
+            acc += v[k];
+        }
+    }
+    row_total[d] = acc;
+    if (d == 0) *ticket = 0;                                           // for the next pass (stream order)
 }
 
 template <bool HAS_VALS>
 __global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ keys, const u32 *__restrict__ vals, i64 n, int shift,
-                                                     i64 n_tiles, const u32 *__restrict__ tile_off /* scanned per digit row, digit-major */,
+                                                     i64 n_tiles, const u32 *__restrict__ tile_off /* [tile][256], scanned inside its chunk */,
+                                                     const u32 *__restrict__ chunk_excl /* [chunk][256] */, i64 chunk_len,
                                                      const u32 *__restrict__ row_total /* [256]: keys per digit */,
                                                      u64 *__restrict__ out_keys, u32 *__restrict__ out_vals) {
     __shared__ u64 s_key[RS_TILE];
@@ -201,7 +221,7 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ keys
     const i64 tile = (i64)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (tile >= n_tiles) return;
     const i64 tile_base = tile * RS_TILE;
-    const u32 goff = tile_off[(i64)threadIdx.x * n_tiles + tile];             // issued first, stored to LDS behind the key loads
+    const u32 goff = tile_off[tile * 256 + threadIdx.x] + chunk_excl[tile / chunk_len * 256 + threadIdx.x];     // issued first, used behind the key loads
     const u32 gtot = row_total[threadIdx.x];
     u64 key[RS_ITEMS];
     u32 val[RS_ITEMS];
@@ -300,9 +320,17 @@ int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp,
     }
     hipStream_t st = ctx().stream;
     const i64 n_tiles = (n + RS_TILE - 1) / RS_TILE;
-    Scratch hist_own, row_total;
+    Context &c = ctx();
+    if (!c.sort_scan_ticket) {
+        HIP_TRY(hipMalloc((void **)&c.sort_scan_ticket, 256));
+        HIP_TRY(hipMemsetAsync(c.sort_scan_ticket, 0, 256, st));
+    }
+    const i64 chunk_len = (n_tiles + RSC_MAX_CHUNKS - 1) / RSC_MAX_CHUNKS > RSC_MIN_LEN ? (n_tiles + RSC_MAX_CHUNKS - 1) / RSC_MAX_CHUNKS : RSC_MIN_LEN;
+    const unsigned n_chunks = (unsigned)((n_tiles + chunk_len - 1) / chunk_len);
+    Scratch hist_own, scan;                                            // scan: row_total[256] | chunk_tot[n_chunks][256] | chunk_excl[n_chunks][256]
     if (!first_hist) SG_TRY(hist_own.alloc((size_t)n_tiles * 256 * sizeof(u32)));
-    SG_TRY(row_total.alloc(256 * sizeof(u32)));
+    SG_TRY(scan.alloc((size_t)(1 + 2 * n_chunks) * 256 * sizeof(u32)));
+    u32 *row_total = scan.as<u32>(), *chunk_tot = row_total + 256, *chunk_excl = chunk_tot + (size_t)n_chunks * 256;
     u32 *hist_p = first_hist ? first_hist : hist_own.as<u32>();
     u64 *ksrc = keys, *kdst = keys_tmp;
     u32 *vsrc = vals, *vdst = vals_tmp;
@@ -312,13 +340,13 @@ int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp,
             hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)n_tiles), dim3(256), 0, st, ksrc, n, shift, n_tiles, hist_p);
             KERNEL_CHECK();
         }
-        hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, st, hist_p, n_tiles, row_total.as<u32>());
+        hipLaunchKernelGGL(k_rs_scan_cols, dim3(n_chunks), dim3(256), 0, st, hist_p, n_tiles, chunk_len, chunk_tot, chunk_excl, row_total, c.sort_scan_ticket);
         if (vals)
-            hipLaunchKernelGGL(k_rs_scatter<true>, dim3((unsigned)((n_tiles + 7) / 8 * 8)), dim3(256), 0, st, ksrc, vsrc, n, shift, n_tiles, hist_p,
-                               row_total.as<u32>(), kdst, vdst);
+            hipLaunchKernelGGL(k_rs_scatter<true>, dim3((unsigned)((n_tiles + 7) / 8 * 8)), dim3(256), 0, st, ksrc, vsrc, n, shift, n_tiles, hist_p, chunk_excl,
+                               chunk_len, row_total, kdst, vdst);
         else
             hipLaunchKernelGGL(k_rs_scatter<false>, dim3((unsigned)((n_tiles + 7) / 8 * 8)), dim3(256), 0, st, ksrc, (const u32 *)nullptr, n, shift, n_tiles,
-                               hist_p, row_total.as<u32>(), kdst, (u32 *)nullptr);
+                               hist_p, chunk_excl, chunk_len, row_total, kdst, (u32 *)nullptr);
         KERNEL_CHECK();
         u64 *tk = ksrc; ksrc = kdst; kdst = tk;
         u32 *tv = vsrc; vsrc = vdst; vdst = tv;
