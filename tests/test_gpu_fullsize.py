@@ -163,7 +163,7 @@ def test_cfg4_elimination_schedules_agree_full_size(monkeypatch):
         m = rng.random((4000, 54000)) < dens
         packed = packing.pack_bits(m)
         ref = kernels.rref(packed, want_pivots=True)
-        for env in ({'SYMGPU_GF2_FUSED_SELECT': '0'}, {'SYMGPU_GF2_FULL_PANEL': '0'}, {'SYMGPU_GF2_LOOKAHEAD': '0'}):
+        for env in ({'SYMGPU_GF2_SPEC': '1'}, {'SYMGPU_GF2_FUSED_SELECT': '0'}, {'SYMGPU_GF2_FULL_PANEL': '0'}, {'SYMGPU_GF2_LOOKAHEAD': '0'}):
             for k, v in env.items(): monkeypatch.setenv(k, v)
             got = kernels.rref(packed, want_pivots=True)
             for k in env: monkeypatch.delenv(k)

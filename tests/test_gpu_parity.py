@@ -1023,7 +1023,7 @@ def test_rotate_golden_general_path(case, monkeypatch):
     test_rotate_golden(case)
 
 
-@pytest.mark.parametrize('env', [{'SYMGPU_GF2_LOOKAHEAD': '0'}, {'SYMGPU_GF2_M4R': '0'}, {'SYMGPU_GF2_FUSED_SELECT': '0'},
+@pytest.mark.parametrize('env', [{'SYMGPU_GF2_SPEC': '1'}, {'SYMGPU_GF2_LOOKAHEAD': '0'}, {'SYMGPU_GF2_M4R': '0'}, {'SYMGPU_GF2_FUSED_SELECT': '0'},
                                  {'SYMGPU_GF2_FUSED_SELECT': '0', 'SYMGPU_GF2_SMALL': '0'}, {'SYMGPU_GF2_SMALL': '0'}])
 @pytest.mark.parametrize('case', family('gf2')[::4])
 def test_gf2_golden_other_sweep_paths(case, env, monkeypatch):
