@@ -80,23 +80,93 @@ __global__ void k_store_total(const u32 *__restrict__ last_in, const u32 *__rest
     *total = *last_in + *last_out;
 }
 
+// Two launches for up to 2^23 elements (every caller but the very largest): (1) block sums, the LAST workgroup to finish scans them
+// (ticket; the sums travel write-through) and files the total, (2) every block scans its 2,048 elements on top of its offset.  The
+// recursive form below (block scan, scan of the sums, add, plus a copy and a store for the total) was five or six launches of 4-6 us each
+// around a few hundred KB of data.
+constexpr int SCAN2_MAX_BLOCKS = 4096;
+__global__ __launch_bounds__(256) void k_scan_sums(const u32 *__restrict__ in, i64 n, u32 *__restrict__ block_sums, u32 *__restrict__ total, u32 *__restrict__ ticket) {
+    __shared__ u32 s_wave[4];
+    __shared__ u32 s_last;
+    const i64 base = (i64)blockIdx.x * SCAN_BLOCK + (i64)threadIdx.x * SCAN_ITEMS;
+    u32 sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) sum += (base + k < n) ? in[base + k] : 0u;
+    u32 tot;
+    (void)block_excl_scan_256(sum, s_wave, &tot);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(block_sums + blockIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // exclusive scan of the block sums in place: sixteen per thread
+    constexpr int PER = SCAN2_MAX_BLOCKS / 256;
+    u32 v[PER], mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int b = threadIdx.x * PER + k;
+        v[k] = b < (int)gridDim.x ? __hip_atomic_load(block_sums + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        mine += v[k];
+    }
+    u32 all;
+    u32 excl = block_excl_scan_256(mine, s_wave, &all);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int b = threadIdx.x * PER + k;
+        if (b < (int)gridDim.x) block_sums[b] = excl;
+        excl += v[k];
+    }
+    if (threadIdx.x == 0) { if (total) *total = all; *ticket = 0; }
+}
+__global__ __launch_bounds__(256) void k_scan_final(const u32 *__restrict__ in, u32 *__restrict__ out, i64 n, const u32 *__restrict__ block_offsets) {
+    __shared__ u32 s_wave[4];
+    const i64 base = (i64)blockIdx.x * SCAN_BLOCK + (i64)threadIdx.x * SCAN_ITEMS;
+    const u32 off = block_offsets[blockIdx.x];
+    u32 v[SCAN_ITEMS];
+    u32 sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        sum += v[k];
+    }
+    u32 total;
+    u32 excl = off + block_excl_scan_256(sum, s_wave, &total);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = excl;
+        excl += v[k];
+    }
+}
+
 // out may alias in.  total_dev (optional, device) receives the sum of all n inputs.
 int exclusive_scan_u32(const u32 *in, u32 *out, i64 n, u32 *total_dev) {
-    hipStream_t st = ctx().stream;
+    Context &c = ctx();
+    hipStream_t st = c.stream;
     if (n <= 0) {
         if (total_dev) HIP_TRY(hipMemsetAsync(total_dev, 0, sizeof(u32), st));
         return SYMGPU_OK;
     }
     const i64 nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (nb <= SCAN2_MAX_BLOCKS) {
+        if (!c.sort_scan_ticket) {
+            HIP_TRY(hipMalloc((void **)&c.sort_scan_ticket, 256));
+            HIP_TRY(hipMemsetAsync(c.sort_scan_ticket, 0, 256, st));
+        }
+        Scratch sums;
+        SG_TRY(sums.alloc((size_t)nb * sizeof(u32)));
+        hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(256), 0, st, in, n, sums.as<u32>(), total_dev, c.sort_scan_ticket + 1);
+        hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(256), 0, st, in, out, n, sums.as<u32>());
+        KERNEL_CHECK();
+        return SYMGPU_OK;
+    }
     Scratch last;   // keep in[n-1] before it is overwritten (aliasing) to form the total
     if (total_dev) {
         SG_TRY(last.alloc(sizeof(u32)));
         HIP_TRY(hipMemcpyAsync(last.p, in + (n - 1), sizeof(u32), hipMemcpyDeviceToDevice, st));
     }
-    if (nb == 1) {
-        hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(256), 0, st, in, out, n, (u32 *)nullptr);
-        KERNEL_CHECK();
-    } else {
+    {
         Scratch sums;
         SG_TRY(sums.alloc((size_t)nb * sizeof(u32)));
         hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(256), 0, st, in, out, n, sums.as<u32>());
