@@ -51,8 +51,8 @@ TRAFFIC_PROFILE = f'{PROFILE_TAG}_traffic.json'   # written by tools/pmc_product
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default 3; the millisecond-scale workloads mul_cleanup / gf2: 20 / 10)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed steps before them (default 1; mul_cleanup / gf2: 3 / 2)')
     ap.add_argument('--qubits', type=int, default=1000)
     ap.add_argument('--left-terms', type=int, default=100000, help='left terms PER GPU')
     ap.add_argument('--right-terms', type=int, default=100000)
@@ -66,7 +66,12 @@ def parse():
     ap.add_argument('--adj-slab-rows', type=int, default=0, help='adjacency: rows per launch / output slab (0: as many as a quarter of the free HBM holds)')
     ap.add_argument('--no-extras', action='store_true')
     ap.add_argument('--no-cpu', action='store_true')
-    return ap.parse_args()
+    args = ap.parse_args()
+    # a millisecond-scale step needs more than three of them for a stable figure (clocks, allocator): mul_cleanup 20 + 3, gf2 10 + 2
+    d_steps, d_warm = {'mul_cleanup': (20, 3), 'gf2': (10, 2)}.get(args.workload, (3, 1))
+    if args.steps is None: args.steps = d_steps
+    if args.warmup is None: args.warmup = d_warm
+    return args
 
 
 def main():
@@ -745,8 +750,8 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
                               'seconds': t, 'pairs_per_s': 250000 / t, 'terms_out': R1.n_terms}
 
     def cfg3_mul_cleanup():
-        # 1,000 qubits, 10,000 terms squared (1e8 pairs) + cleanup: the `--workload mul_cleanup` line, 3 steps
-        line = workload_line(wl_mul_cleanup, 3)
+        # 1,000 qubits, 10,000 terms squared (1e8 pairs) + cleanup: the `--workload mul_cleanup` line, 20 steps
+        line = workload_line(wl_mul_cleanup, 20, 3)
         ex['cfg3_mul_cleanup'] = {'pairs': 10**8, 'seconds': line['ms_per_step'] * 1e-3, 'pairs_per_s': line['value'], 'terms_out': line['config']['terms_out'],
                                   'roofline': line['roofline'],
                                   'note': 'squared operator: keys for the pairs with i >= o only (cleanup.hip); roofline = the output stage, the one kernel of the '
@@ -815,8 +820,8 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
         _lib.check(lib.symgpu_dev_free(buf)); C.free()
 
     def cfg4_symmetry_kernel():
-        # GF(2) symmetry kernel, 2,000 qubits x 50,000 terms, 32 planted symmetries, Clifford-scrambled: the `--workload gf2` line, 3 steps
-        line = workload_line(wl_gf2, 3)
+        # GF(2) symmetry kernel, 2,000 qubits x 50,000 terms, 32 planted symmetries, Clifford-scrambled: the `--workload gf2` line, 10 steps
+        line = workload_line(wl_gf2, 10, 2)
         ex['cfg4_symmetry_kernel'] = {'rows': 4000, 'cols': 54000, 'generators_found': line['config']['generators_found'], 'row_xors': line['config']['row_xors_per_step'],
                                       'seconds': line['ms_per_step'] * 1e-3, 'row_xors_per_s': line['value'], 'roofline': line['roofline']}
 
