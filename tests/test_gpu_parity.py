@@ -902,6 +902,13 @@ def test_cleanup_lazy_and_fused_switches(n, N, M, monkeypatch):
             assert np.array_equal(got[0], want_c[0]) and np.array_equal(got[1], want_c[1]), (lazy, fused, 'cleanup')
     monkeypatch.delenv('SYMGPU_CLEANUP_LAZY')
     monkeypatch.delenv('SYMGPU_EMIT_FUSED')
+    # the prefix sums behind the output positions: two launches up to 2^23 elements, the recursive form above it (forced here)
+    monkeypatch.setenv('SYMGPU_SCAN_RECURSIVE', '1')
+    got = kernels.mul_cleanup(A.packed, A.coeff_vec, B.packed, B.coeff_vec, True, 1e-15)
+    assert np.array_equal(got[0], want_ab[0]) and np.array_equal(got[1], want_ab[1]), 'recursive scan'
+    got = kernels.cleanup(stacked_rows, stacked_coeff, 1e-15)
+    assert np.array_equal(got[0], want_c[0]) and np.array_equal(got[1], want_c[1]), 'recursive scan, cleanup'
+    monkeypatch.delenv('SYMGPU_SCAN_RECURSIVE')
 
 
 def test_mul_cleanup_unpacked_fallback_path(monkeypatch):
