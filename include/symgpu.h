@@ -58,7 +58,11 @@ int symgpu_prof_read(int kernel_class, int64_t *n_launches, double *total_ms);
  * guard behind symplectic_cleanup, operators/utils.py:230-279; expected 0 outside the tests, which weaken the hash on purpose);
  * 1: rotations completed by the one-launch LDS-resident kernel; 2: calls of that kernel that reported a failed row verification or a
  * barrier time-out (the multi-launch path then recomputes); 3: device allocations that were not served from the allocator's arena;
- * 4-6: host nanoseconds spent by the one-launch rotation in preparation, in the launch call and waiting for the kernel's status word */
+ * 4-6: host nanoseconds spent by the one-launch rotation in preparation, in the launch call and waiting for the kernel's status word;
+ * 7 / 8: payload bytes copied host -> device / device -> host by this library (operators, coefficients, index arrays, result matrices; not the
+ * few-byte counts and flags a call reads back); 9 / 10: operator uploads / downloads (calls that moved a whole operator or its coefficients).
+ * The drop-in classes keep their operands on the device between calls; the tests assert through 7-10 that a multi-step workflow
+ * (symmer/projection/base.py:44-124, rotate -> project -> cleanup) moves its operator once in and once out. */
 int symgpu_debug_counter(int which, int64_t *value);
 /* tuning aid: with SYMGPU_RES_TRACE=1 every workgroup of the one-launch rotation kernel stamps the 100 MHz wall clock at its phase
  * boundaries; this copies the stamps of the last traced launch, 16 words per workgroup */
@@ -81,6 +85,19 @@ int symgpu_op_write(symgpu_op_t op, int64_t row_offset, const uint64_t *rows, co
 /* device-to-device: rows (and coefficients, if both have them) src[src_offset .. +count) -> dst[dst_offset ..); stream ordered */
 int symgpu_op_copy_rows(symgpu_op_t dst, int64_t dst_offset, symgpu_op_t src, int64_t src_offset, int64_t count);
 int symgpu_op_random(int64_t T, int n_qubits, double density, uint64_t seed, symgpu_op_t *out); /* synthetic input, generated on device */
+/* Handle-level primitives behind the device-resident drop-in classes (no reference counterpart: the reference keeps NumPy arrays):
+ *  clone       rows (+ coefficients) copied device to device into a new handle
+ *  set_coeff   the T coefficients replaced from a host array (allocated if the operator had none); rows and their cached layouts stay
+ *  scale       in place c <- (conjugate_first ? conj(c) : c) * (re + i im)   (multiply_by_constant base.py:750-762, dagger :1366-1376)
+ *  ycount      PauliwordOp.Y_count (base.py:604-615) of a resident operator -> int64[T] on the host
+ *  upload_bool / download_bool   the reference layout itself (np.bool_ [T][2n], X columns then Z columns, base.py:42-74) <-> packed rows,
+ *              packed / unpacked ON THE DEVICE: np.packbits on the host runs at ~1.5 GB/s of bools, PCIe + a ballot kernel at >10 GB/s */
+int symgpu_op_clone(symgpu_op_t in, symgpu_op_t *out);
+int symgpu_op_set_coeff(symgpu_op_t op, const double *coeff_host);
+int symgpu_op_scale(symgpu_op_t op, double re, double im, int conjugate_first);
+int symgpu_op_ycount(symgpu_op_t op, int64_t *out_host);
+int symgpu_op_upload_bool(const uint8_t *symp /* [T][2n] */, const double *coeff /* may be NULL */, int64_t T, int n_qubits, symgpu_op_t *out);
+int symgpu_op_download_bool(symgpu_op_t op, int n_qubits, uint8_t *symp_out /* [capacity_rows][2n] */, int64_t capacity_rows);
 /* XOR-fold of all packed rows (2*Wq words) and plain sum of coefficients: size-independent checksums */
 int symgpu_op_checksum(symgpu_op_t op, uint64_t *xor_words /* [2*Wq] */, double *coeff_sum /* [2] */);
 /* number of set bits in all packed rows: sum_{i,o} |a_i ^ b_o| of a product slab follows from the operands' bit-column counts in O(N + M) */

@@ -51,6 +51,12 @@ SIGNATURES = {
     'symgpu_op_write': [P, c_i64, P, P, c_i64],
     'symgpu_op_random': [c_i64, c_int, c_dbl, c_u64, PP],
     'symgpu_op_checksum': [P, P, P],
+    'symgpu_op_clone': [P, PP],
+    'symgpu_op_set_coeff': [P, P],
+    'symgpu_op_scale': [P, c_dbl, c_dbl, c_int],
+    'symgpu_op_ycount': [P, P],
+    'symgpu_op_upload_bool': [P, P, c_i64, c_int, PP],
+    'symgpu_op_download_bool': [P, c_int, P, c_i64],
     'symgpu_ycount': [P, c_i64, c_int, P],
     'symgpu_commutes': [P, c_i64, P, c_i64, c_int, P],
     'symgpu_commutes_dev': [P, c_i64, c_i64, P, P],

@@ -1746,6 +1746,7 @@ int symgpu_op_first_index(symgpu_op_t op, uint64_t *first_host, int64_t capacity
     if (capacity < op->T) { set_error("op_first_index: capacity %lld < %lld rows", (long long)capacity, (long long)op->T); return SYMGPU_E_CAPACITY; }
     if (op->T > 0) {
         HIP_TRY(hipMemcpyAsync(first_host, op->first, (size_t)op->T * 8, hipMemcpyDeviceToHost, ctx().stream));
+        count_d2h((size_t)op->T * 8);
         HIP_TRY(hipStreamSynchronize(ctx().stream));
     }
     return SYMGPU_OK;

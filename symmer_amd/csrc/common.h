@@ -74,7 +74,10 @@ struct Context {
     bool res_disabled = false;     // a barrier timed out once (workgroups not co-resident): the process keeps to the multi-launch paths
 };
 Context &ctx();
-extern i64 g_counters[8];                  // debug counters (symgpu_debug_counter): [1] one-launch rotations, [2] their failures, [3] hipMalloc calls of dev_alloc
+extern i64 g_counters[16];                 // debug counters (symgpu_debug_counter): [1] one-launch rotations, [2] their failures, [3] hipMalloc calls of dev_alloc,
+                                           // [7] / [8] payload bytes host -> device / device -> host, [9] / [10] operator uploads / downloads (calls)
+inline void count_h2d(size_t bytes) { g_counters[7] += (i64)bytes; }
+inline void count_d2h(size_t bytes) { g_counters[8] += (i64)bytes; }
 int require_ctx();
 
 // per-launch event timing of one kernel class (bench.py roofline leg)

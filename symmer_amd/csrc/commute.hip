@@ -239,6 +239,7 @@ int symgpu_ycount(const uint64_t *rows, int64_t T, int Wq, int64_t *out) {
     SG_TRY(d.alloc((size_t)T * 2 * Wq * sizeof(u64)));
     SG_TRY(o.alloc((size_t)T * sizeof(int)));
     HIP_TRY(hipMemcpyAsync(d.p, rows, (size_t)T * 2 * Wq * sizeof(u64), hipMemcpyHostToDevice, ctx().stream));
+    count_h2d((size_t)T * 2 * Wq * sizeof(u64)); count_d2h((size_t)T * sizeof(int));
     SG_TRY(ycount_dev(d.as<u64>(), T, Wq, o.as<int>()));
     int *h = (int *)malloc((size_t)T * sizeof(int));
     if (!h) { set_error("host allocation failed"); return SYMGPU_E_NOMEM; }
@@ -275,10 +276,12 @@ int symgpu_commutes(const uint64_t *A, int64_t N, const uint64_t *B, int64_t M, 
     Scratch da, db, dout;
     SG_TRY(da.alloc((size_t)N * rb));
     HIP_TRY(hipMemcpyAsync(da.p, A, (size_t)N * rb, hipMemcpyHostToDevice, ctx().stream));
+    count_h2d((size_t)N * rb); count_d2h((size_t)N * (size_t)M);
     const u64 *pb = da.as<u64>();
     if (!(B == A && M == N)) {
         SG_TRY(db.alloc((size_t)M * rb));
         HIP_TRY(hipMemcpyAsync(db.p, B, (size_t)M * rb, hipMemcpyHostToDevice, ctx().stream));
+        count_h2d((size_t)M * rb);
         pb = db.as<u64>();
     }
     SG_TRY(dout.alloc((size_t)N * (size_t)M));

@@ -29,7 +29,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
 }
 
 static Context g_ctx;
-i64 g_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // symgpu_debug_counter 1..6 (0 is g_hash_reseeds, cleanup.hip)
+i64 g_counters[16] = {0};   // symgpu_debug_counter 1..10 (0 is g_hash_reseeds, cleanup.hip)
 Context &ctx() { return g_ctx; }
 
 int require_ctx() {
@@ -311,6 +311,44 @@ __global__ void k_random_op(u64 *__restrict__ rows, double *__restrict__ coeff, 
     }
 }
 
+// coefficients in place: c <- (conjugate_first ? conj(c) : c) * (re + i im), plain IEEE products (no contraction: NumPy's complex multiply)
+__global__ __launch_bounds__(256) void k_scale_coeff(double *__restrict__ c, i64 T, double re, double im, int conjugate_first) {
+    const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    double2 v = reinterpret_cast<double2 *>(c)[t];
+    if (conjugate_first) v.y = -v.y;
+    double2 o;
+    o.x = __dsub_rn(__dmul_rn(v.x, re), __dmul_rn(v.y, im));
+    o.y = __dadd_rn(__dmul_rn(v.x, im), __dmul_rn(v.y, re));
+    reinterpret_cast<double2 *>(c)[t] = o;
+}
+
+// reference layout (np.bool_ [T][2n], X columns then Z columns, base.py:42-74) <-> packed rows: one wavefront per (term, word); lane l owns
+// qubit 64 w + l, so the packed word IS the wavefront's ballot (and a word's 64 bytes are one coalesced store on the way back)
+__global__ __launch_bounds__(256) void k_pack_bool(const uint8_t *__restrict__ symp, i64 T, int n, int Wq, u64 *__restrict__ rows) {
+    const int lane = threadIdx.x & 63;
+    const i64 n_words = T * 2 * Wq;
+    for (i64 idx = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); idx < n_words; idx += (i64)gridDim.x * 4) {
+        const i64 t = idx / (2 * Wq);
+        const int w = (int)(idx % (2 * Wq));
+        const int half = w >= Wq, q = (half ? w - Wq : w) * 64 + lane;
+        const bool bit = q < n && symp[t * 2 * n + (half ? n : 0) + q] != 0;
+        const u64 word = __ballot(bit);
+        if (lane == 0) rows[idx] = word;
+    }
+}
+__global__ __launch_bounds__(256) void k_unpack_bool(const u64 *__restrict__ rows, i64 T, int n, int Wq, uint8_t *__restrict__ symp) {
+    const int lane = threadIdx.x & 63;
+    const i64 n_words = T * 2 * Wq;
+    for (i64 idx = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); idx < n_words; idx += (i64)gridDim.x * 4) {
+        const i64 t = idx / (2 * Wq);
+        const int w = (int)(idx % (2 * Wq));
+        const int half = w >= Wq, q = (half ? w - Wq : w) * 64 + lane;
+        const u64 word = rows[idx];
+        if (q < n) symp[t * 2 * n + (half ? n : 0) + q] = (uint8_t)((word >> lane) & 1);
+    }
+}
+
 // on-box bandwidth ceilings for the roofline (one 16-byte store / load+store per thread, one-shot grid)
 typedef unsigned int u32x4p __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_probe_fill(u32x4p *out, i64 n, u32 v) {
@@ -516,7 +554,7 @@ int symgpu_prof_enable(int kernel_class, int on) {
 }
 
 int symgpu_debug_counter(int which, int64_t *value) {
-    SG_REQUIRE(value && which >= 0 && which <= 6, "debug_counter: 0 = row-hash reseeds, 1 = rotations done by the one-launch kernel, 2 = its failures (verification / time-out), 3 = device allocations that went to hipMalloc, 4-6 = host nanoseconds of the one-launch rotation (preparation, launch call, wait)");
+    SG_REQUIRE(value && which >= 0 && which <= 10, "debug_counter: 0 = row-hash reseeds, 1 = rotations done by the one-launch kernel, 2 = its failures (verification / time-out), 3 = device allocations that went to hipMalloc, 4-6 = host nanoseconds of the one-launch rotation (preparation, launch call, wait), 7 / 8 = payload bytes host -> device / device -> host, 9 / 10 = operator uploads / downloads");
     *value = which == 0 ? g_hash_reseeds : g_counters[which];
     return SYMGPU_OK;
 }
@@ -551,6 +589,7 @@ int symgpu_dev_download(const void *dev, void *host, int64_t bytes) {
     prefault_host(host, (size_t)bytes);
     HIP_TRY(hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx().stream));
     HIP_TRY(hipStreamSynchronize(ctx().stream));
+    count_d2h((size_t)bytes);
     return SYMGPU_OK;
 }
 
@@ -559,6 +598,7 @@ int symgpu_dev_upload(void *dev, const void *host, int64_t bytes) {
     SG_REQUIRE(dev && host && bytes >= 0, "dev_upload");
     HIP_TRY(hipMemcpyAsync(dev, host, (size_t)bytes, hipMemcpyHostToDevice, ctx().stream));
     HIP_TRY(hipStreamSynchronize(ctx().stream));
+    count_h2d((size_t)bytes);
     return SYMGPU_OK;
 }
 
@@ -635,6 +675,8 @@ int symgpu_op_write(symgpu_op_t op, int64_t row_offset, const uint64_t *rows, co
         if (coeff && op->coeff)
             HIP_TRY(hipMemcpyAsync(op->coeff + 2 * (size_t)row_offset, coeff, (size_t)count * 16, hipMemcpyHostToDevice, ctx().stream));
         HIP_TRY(hipStreamSynchronize(ctx().stream));
+        count_h2d((size_t)count * W * 8 + ((coeff && op->coeff) ? (size_t)count * 16 : 0));
+        ++g_counters[9];
     }
     op_invalidate(op);
     if (row_offset + count > op->T) op->T = row_offset + count;
@@ -668,6 +710,8 @@ int symgpu_op_upload(const uint64_t *rows, const double *coeff, int64_t T, int W
         if (e == hipSuccess && coeff) e = hipMemcpyAsync(op->coeff, coeff, (size_t)T * 2 * sizeof(double), hipMemcpyHostToDevice, ctx().stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);   // host buffers are not retained past the call
         if (e != hipSuccess) { symgpu_op_free(op); return hip_fail(e, "op_upload memcpy", __FILE__, __LINE__); }
+        count_h2d((size_t)T * 2 * Wq * sizeof(u64) + (coeff ? (size_t)T * 16 : 0));
+        ++g_counters[9];
     }
     *out = op;
     return SYMGPU_OK;
@@ -684,14 +728,128 @@ int symgpu_op_download(symgpu_op_t op, uint64_t *rows, double *coeff, int64_t ca
         if (rows) {
             prefault_host(rows, (size_t)op->T * 2 * op->Wq * sizeof(u64));
             HIP_TRY(hipMemcpyAsync(rows, op->rows, (size_t)op->T * 2 * op->Wq * sizeof(u64), hipMemcpyDeviceToHost, ctx().stream));
+            count_d2h((size_t)op->T * 2 * op->Wq * sizeof(u64));
         }
         if (coeff) {
             SG_REQUIRE(op->coeff, "op_download: operator has no coefficients");
             prefault_host(coeff, (size_t)op->T * 2 * sizeof(double));
             HIP_TRY(hipMemcpyAsync(coeff, op->coeff, (size_t)op->T * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+            count_d2h((size_t)op->T * 16);
         }
+        if (rows || coeff) ++g_counters[10];
     }
     HIP_TRY(hipStreamSynchronize(ctx().stream));
+    return SYMGPU_OK;
+}
+
+// ---- handle-level primitives behind the device-resident drop-in classes (symmer_amd/operators/base.py) -----------------------------------
+int symgpu_op_clone(symgpu_op_t in, symgpu_op_t *out) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(in && out, "op_clone: null argument");
+    symgpu_op_t op = nullptr;
+    SG_TRY(symgpu_op_alloc(in->T, in->Wq, in->coeff != nullptr, &op));
+    op->T = in->T;
+    if (in->T > 0) {
+        hipError_t e = hipMemcpyAsync(op->rows, in->rows, (size_t)in->T * 2 * in->Wq * sizeof(u64), hipMemcpyDeviceToDevice, ctx().stream);
+        if (e == hipSuccess && in->coeff) e = hipMemcpyAsync(op->coeff, in->coeff, (size_t)in->T * 16, hipMemcpyDeviceToDevice, ctx().stream);
+        if (e != hipSuccess) { symgpu_op_free(op); return hip_fail(e, "op_clone memcpy", __FILE__, __LINE__); }
+    }
+    op->dup_free = in->dup_free;          // the rows are the same rows
+    *out = op;
+    return SYMGPU_OK;
+}
+
+int symgpu_op_set_coeff(symgpu_op_t op, const double *coeff_host) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(op && (coeff_host || op->T == 0), "op_set_coeff: null argument");
+    if (!op->coeff) SG_TRY(dev_alloc((size_t)(op->capacity > 0 ? op->capacity : 1) * 16, (void **)&op->coeff));
+    if (op->T > 0) {
+        HIP_TRY(hipMemcpyAsync(op->coeff, coeff_host, (size_t)op->T * 16, hipMemcpyHostToDevice, ctx().stream));
+        HIP_TRY(hipStreamSynchronize(ctx().stream));              // host buffers are not retained past the call
+        count_h2d((size_t)op->T * 16);
+        ++g_counters[9];
+    }
+    return SYMGPU_OK;                                             // the rows did not change: per-handle caches stay
+}
+
+int symgpu_op_scale(symgpu_op_t op, double re, double im, int conjugate_first) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(op && (op->coeff || op->T == 0), "op_scale: operator has no coefficients");
+    if (op->T > 0) {
+        hipLaunchKernelGGL(k_scale_coeff, dim3((unsigned)((op->T + 255) / 256)), dim3(256), 0, ctx().stream, op->coeff, op->T, re, im, conjugate_first);
+        KERNEL_CHECK();
+    }
+    return SYMGPU_OK;
+}
+
+int symgpu_op_ycount(symgpu_op_t op, int64_t *out_host) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(op && (out_host || op->T == 0), "op_ycount: null argument");
+    if (op->T == 0) return SYMGPU_OK;
+    const int *yc = nullptr;
+    SG_TRY(op_ycount(op, &yc));
+    int *h = (int *)malloc((size_t)op->T * sizeof(int));
+    if (!h) { set_error("host allocation failed"); return SYMGPU_E_NOMEM; }
+    hipError_t e = hipMemcpyAsync(h, yc, (size_t)op->T * sizeof(int), hipMemcpyDeviceToHost, ctx().stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
+    if (e != hipSuccess) { free(h); return hip_fail(e, "op_ycount download", __FILE__, __LINE__); }
+    count_d2h((size_t)op->T * sizeof(int));
+    for (i64 t = 0; t < op->T; ++t) out_host[t] = h[t];
+    free(h);
+    return SYMGPU_OK;
+}
+
+int symgpu_op_upload_bool(const uint8_t *symp, const double *coeff, int64_t T, int n_qubits, symgpu_op_t *out) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(out && T >= 0 && n_qubits >= 1 && (symp || T == 0), "op_upload_bool");
+    const int Wq = (n_qubits + 63) / 64;
+    symgpu_op_t op = nullptr;
+    SG_TRY(symgpu_op_alloc(T, Wq, coeff != nullptr, &op));
+    op->T = T;
+    if (T > 0) {
+        const size_t nb = (size_t)T * 2 * n_qubits;
+        Scratch stage;
+        int rc = stage.alloc(nb);
+        if (rc != SYMGPU_OK) { symgpu_op_free(op); return rc; }
+        hipError_t e = hipMemcpyAsync(stage.p, symp, nb, hipMemcpyHostToDevice, ctx().stream);
+        if (e == hipSuccess && coeff) e = hipMemcpyAsync(op->coeff, coeff, (size_t)T * 16, hipMemcpyHostToDevice, ctx().stream);
+        if (e == hipSuccess) {
+            // one wavefront per (row, word): lane l reads the byte of qubit 64 w + l, the ballot is the packed word
+            const i64 n_words = T * 2 * Wq;
+            const unsigned grid = (unsigned)((n_words + 3) / 4 < 65536 * 16 ? (n_words + 3) / 4 : 65536 * 16);
+            hipLaunchKernelGGL(k_pack_bool, dim3(grid), dim3(256), 0, ctx().stream, stage.as<uint8_t>(), T, n_qubits, Wq, op->rows);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);   // host buffers are not retained past the call (and the staging buffer goes)
+        if (e != hipSuccess) { symgpu_op_free(op); return hip_fail(e, "op_upload_bool", __FILE__, __LINE__); }
+        count_h2d(nb + (coeff ? (size_t)T * 16 : 0));
+        ++g_counters[9];
+    }
+    *out = op;
+    return SYMGPU_OK;
+}
+
+int symgpu_op_download_bool(symgpu_op_t op, int n_qubits, uint8_t *symp_out, int64_t capacity_rows) {
+    SG_TRY(require_ctx());
+    SG_REQUIRE(op && n_qubits >= 1 && (n_qubits + 63) / 64 == op->Wq, "op_download_bool: qubit count does not match the packed width");
+    if (capacity_rows < op->T) {
+        set_error("op_download_bool: capacity %lld < %lld rows", (long long)capacity_rows, (long long)op->T);
+        return SYMGPU_E_CAPACITY;
+    }
+    if (op->T == 0) return SYMGPU_OK;
+    SG_REQUIRE(symp_out, "op_download_bool: null output");
+    const size_t nb = (size_t)op->T * 2 * n_qubits;
+    Scratch stage;
+    SG_TRY(stage.alloc(nb));
+    const i64 n_words = op->T * 2 * op->Wq;
+    const unsigned grid = (unsigned)((n_words + 3) / 4 < 65536 * 16 ? (n_words + 3) / 4 : 65536 * 16);
+    hipLaunchKernelGGL(k_unpack_bool, dim3(grid), dim3(256), 0, ctx().stream, op->rows, op->T, n_qubits, op->Wq, stage.as<uint8_t>());
+    KERNEL_CHECK();
+    prefault_host(symp_out, nb);
+    HIP_TRY(hipMemcpyAsync(symp_out, stage.p, nb, hipMemcpyDeviceToHost, ctx().stream));
+    HIP_TRY(hipStreamSynchronize(ctx().stream));
+    count_d2h(nb);
+    ++g_counters[10];
     return SYMGPU_OK;
 }
 

@@ -1673,6 +1673,7 @@ int symgpu_rref(uint64_t *rows, int64_t R, int64_t Wc, int64_t *xor_count, int64
     Scratch d;
     SG_TRY(d.alloc((size_t)R * Wc * 8));
     HIP_TRY(hipMemcpyAsync(d.p, rows, (size_t)R * Wc * 8, hipMemcpyHostToDevice, ctx().stream));
+    count_h2d((size_t)R * Wc * 8); count_d2h((size_t)R * Wc * 8);
     SG_TRY(rref_dev(d.as<u64>(), R, Wc, xor_count, pivots));
     HIP_TRY(hipMemcpyAsync(rows, d.p, (size_t)R * Wc * 8, hipMemcpyDeviceToHost, ctx().stream));
     HIP_TRY(hipStreamSynchronize(ctx().stream));
@@ -1717,6 +1718,7 @@ int symgpu_symmetry_kernel_dev(symgpu_op_t H, int n_qubits, uint64_t *out, int64
                        flag.as<u32>(), kcount, gens.as<u64>());
     KERNEL_CHECK();
     HIP_TRY(hipMemcpyAsync(out, gens.p, (size_t)kcount * W * 8, hipMemcpyDeviceToHost, st));
+    count_d2h((size_t)kcount * W * 8);
     HIP_TRY(hipStreamSynchronize(st));
     return SYMGPU_OK;
 }

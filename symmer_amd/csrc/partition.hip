@@ -116,6 +116,7 @@ int symgpu_op_set_first_index(symgpu_op_t op, const uint64_t *first_host) {
     if (!op->first) SG_TRY(dev_alloc((size_t)(op->capacity > 0 ? op->capacity : 1) * 8, (void **)&op->first));
     if (op->T > 0) {
         HIP_TRY(hipMemcpyAsync(op->first, first_host, (size_t)op->T * 8, hipMemcpyHostToDevice, ctx().stream));
+        count_h2d((size_t)op->T * 8);
         HIP_TRY(hipStreamSynchronize(ctx().stream));
     }
     return SYMGPU_OK;

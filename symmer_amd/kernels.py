@@ -25,10 +25,17 @@ def _coeff(c):
 
 
 class DeviceOp:
-    """Owner of a device-resident operator handle (``symgpu_op_t``)."""
+    """Owner of a device-resident operator handle (``symgpu_op_t``).  ``shared`` is set once a handle is attached to more than one
+    Python object (``copy()``): the in-place primitives (``set_coeff``, ``scale``) then work on a clone."""
 
     def __init__(self, handle):
         self.handle = handle
+        self.shared = False
+
+    def __deepcopy__(self, memo):
+        # a handle is never duplicated by value (two owners of one symgpu_op_t would free it twice): copies share the object
+        self.shared = True
+        return self
 
     @classmethod
     def upload(cls, rows, coeff=None):
@@ -38,6 +45,16 @@ class DeviceOp:
             assert coeff.shape[0] == rows.shape[0]
         h = ctypes.c_void_p()
         check(_lib.lib().symgpu_op_upload(addr(rows), addr(coeff), rows.shape[0], rows.shape[1] // 2, ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def upload_bool(cls, symp_matrix, coeff=None):
+        """The reference layout itself (bool[T, 2n]) -> packed rows, packed on the device (``symgpu_op_upload_bool``)."""
+        symp = np.ascontiguousarray(symp_matrix, dtype=np.bool_)
+        assert symp.ndim == 2 and symp.shape[1] % 2 == 0 and symp.shape[1] >= 2
+        coeff = None if coeff is None else _coeff(coeff)
+        h = ctypes.c_void_p()
+        check(_lib.lib().symgpu_op_upload_bool(addr(symp), addr(coeff), symp.shape[0], symp.shape[1] // 2, ctypes.byref(h)))
         return cls(h)
 
     @classmethod
@@ -71,6 +88,38 @@ class DeviceOp:
         check(_lib.lib().symgpu_op_download(self.handle, addr(rows), addr(coeff), t))
         return (rows, coeff) if with_coeff else rows
 
+    def download_coeff(self):
+        t = self.info()[0]
+        coeff = np.empty(t, dtype=np.complex128)
+        check(_lib.lib().symgpu_op_download(self.handle, None, addr(coeff), t))
+        return coeff
+
+    def download_bool(self, n_qubits):
+        """bool[T, 2n] in the reference layout, unpacked on the device (``symgpu_op_download_bool``)."""
+        t = self.info()[0]
+        out = np.empty((t, 2 * int(n_qubits)), dtype=np.bool_)
+        check(_lib.lib().symgpu_op_download_bool(self.handle, int(n_qubits), addr(out), t))
+        return out
+
+    def clone(self):
+        h = ctypes.c_void_p()
+        check(_lib.lib().symgpu_op_clone(self.handle, ctypes.byref(h)))
+        return DeviceOp(h)
+
+    def set_coeff(self, coeff):
+        coeff = _coeff(coeff)
+        assert coeff.shape[0] == self.info()[0]
+        check(_lib.lib().symgpu_op_set_coeff(self.handle, addr(coeff)))
+
+    def scale(self, const, conjugate_first=False):
+        const = complex(const)
+        check(_lib.lib().symgpu_op_scale(self.handle, const.real, const.imag, 1 if conjugate_first else 0))
+
+    def ycount(self):
+        out = np.zeros(self.info()[0], dtype=np.int64)
+        check(_lib.lib().symgpu_op_ycount(self.handle, addr(out)))
+        return out
+
     def checksum(self, with_coeff=True):
         _, wq, _ = self.info()
         x = np.zeros(2 * wq, dtype='<u8')
@@ -88,6 +137,38 @@ class DeviceOp:
             self.free()
         except Exception:
             pass
+
+
+def concat_dev(parts, with_coeff=True):
+    """Device operators stacked in order into a new one (device-to-device copies)."""
+    sizes = [p.info() for p in parts]
+    wq = sizes[0][1]
+    out = DeviceOp.alloc(sum(t for t, _, _ in sizes), wq, with_coeff)
+    at = 0
+    for p, (t, w, _) in zip(parts, sizes):
+        assert w == wq, 'operands packed with different Wq'
+        if t:
+            check(_lib.lib().symgpu_op_copy_rows(out.handle, at, p.handle, 0, t))
+        at += t
+    return out
+
+
+def slice_dev(op, begin, end, with_coeff=True):
+    """Rows [begin, end) of a device operator as a new one."""
+    out = DeviceOp.alloc(end - begin, op.info()[1], with_coeff)
+    if end > begin:
+        check(_lib.lib().symgpu_op_copy_rows(out.handle, 0, op.handle, int(begin), int(end - begin)))
+    return out
+
+
+def transfer_counters():
+    """(bytes host -> device, bytes device -> host, operator uploads, operator downloads) since the library was loaded."""
+    v = c_i64(0)
+    out = []
+    for which in (7, 8, 9, 10):
+        check(_lib.lib().symgpu_debug_counter(which, ctypes.addressof(v)))
+        out.append(v.value)
+    return tuple(out)
 
 
 def sync():
@@ -110,6 +191,22 @@ def commutes(a_rows, b_rows):
     if n and m:
         same = a_rows is b_rows
         check(_lib.lib().symgpu_commutes(addr(a_rows), n, addr(a_rows if same else b_rows), m, a_rows.shape[1] // 2, addr(out)))
+    return out.view(np.bool_)
+
+
+def commutes_handles(a, b):
+    """bool[N, M] for two device operators (rows only are used): the table is computed into device memory and read back once."""
+    (n, wq, _), (m, wq_b, _) = a.info(), b.info()
+    assert wq == wq_b, 'operands packed with different Wq'
+    out = np.empty((n, m), dtype=np.uint8)
+    if n and m:
+        buf = ctypes.c_void_p()
+        check(_lib.lib().symgpu_dev_alloc(n * m, ctypes.byref(buf)))
+        try:
+            check(_lib.lib().symgpu_commutes_dev(a.handle, 0, n, b.handle, buf))
+            check(_lib.lib().symgpu_dev_download(buf, addr(out), n * m))
+        finally:
+            _lib.lib().symgpu_dev_free(buf)
     return out.view(np.bool_)
 
 
@@ -149,44 +246,55 @@ def cleanup(rows, coeff, zero_threshold=1e-15):
 MAX_PAIRS_PER_CALL = 1 << 31      # one device call sorts 32-bit pair indices; larger products are tiled over the outer operand
 
 
-def mul_cleanup(inner, ci, outer, co, inner_is_left=True, zero_threshold=1e-15, max_pairs=None):
-    """Fused product + cleanup; the product rows are never materialised.  Products with more than ``max_pairs`` pairs are
-    tiled over the outer (slow) index: every slab is cleaned on the device, the concatenation of the cleaned slabs is
-    cleaned once more (same first-occurrence order; coefficient sums associate per slab, i.e. within 1e-16 relative)."""
-    same = outer is inner and co is ci                          # P * P: one device operand serves both factors, which lets the
-    inner, outer, ci, co = _rows(inner), _rows(outer), _coeff(ci), _coeff(co)    # library sort half of the pairs (cleanup.hip)
-    assert inner.shape[1] == outer.shape[1]
-    ni, no = inner.shape[0], outer.shape[0]
-    if ni == 0 or no == 0:
-        return np.empty((0, inner.shape[1]), dtype='<u8'), np.empty(0, dtype=np.complex128)
+def mul_cleanup_handles(a, b, inner_is_left=True, zero_threshold=1e-15, max_pairs=None):
+    """Fused product + cleanup of two device operators (``a`` inner, ``b`` outer; ``a is b`` squares) -> new DeviceOp; the product rows are
+    never materialised.  Products with more than ``max_pairs`` pairs are tiled over the outer (slow) index: every slab is cleaned on the
+    device, the concatenation of the cleaned slabs is cleaned once more (same first-occurrence order; coefficient sums associate per slab,
+    i.e. within 1e-16 relative).  Nothing returns to the host."""
+    ni, no = a.info()[0], b.info()[0]
     thr, use = _thr_args(zero_threshold)
     max_pairs = MAX_PAIRS_PER_CALL if max_pairs is None else int(max_pairs)
+    out = ctypes.c_void_p()
+    if ni * no <= max_pairs:
+        check(_lib.lib().symgpu_mul_cleanup_dev(a.handle, b.handle, 1 if inner_is_left else 0, thr, use, ctypes.byref(out)))
+        return DeviceOp(out)
+    slab = max(1, max_pairs // ni)
+    parts = []
+    for o0 in range(0, no, slab):
+        piece = slice_dev(b, o0, min(no, o0 + slab))
+        part = ctypes.c_void_p()
+        # partial sums must not be thresholded: a term may only cancel across slabs
+        check(_lib.lib().symgpu_mul_cleanup_dev(a.handle, piece.handle, 1 if inner_is_left else 0, 0.0, 0, ctypes.byref(part)))
+        piece.free()
+        parts.append(DeviceOp(part))
+    stacked = concat_dev(parts)
+    for p in parts:
+        p.free()
+    check(_lib.lib().symgpu_cleanup_dev(stacked.handle, thr, use, ctypes.byref(out)))
+    stacked.free()
+    return DeviceOp(out)
+
+
+def mul_cleanup(inner, ci, outer, co, inner_is_left=True, zero_threshold=1e-15, max_pairs=None):
+    """Host arrays in, host arrays out around :func:`mul_cleanup_handles` (``outer is inner``: one device operand serves both factors,
+    which lets the library sort half of the pairs, cleanup.hip)."""
+    same = outer is inner and co is ci
+    inner, outer, ci, co = _rows(inner), _rows(outer), _coeff(ci), _coeff(co)
+    assert inner.shape[1] == outer.shape[1]
+    if inner.shape[0] == 0 or outer.shape[0] == 0:
+        return np.empty((0, inner.shape[1]), dtype='<u8'), np.empty(0, dtype=np.complex128)
     a = DeviceOp.upload(inner, ci)
+    b = a if same else DeviceOp.upload(outer, co)
     try:
-        if ni * no <= max_pairs:
-            b = a if same else DeviceOp.upload(outer, co)
-            out = ctypes.c_void_p()
-            try:
-                check(_lib.lib().symgpu_mul_cleanup_dev(a.handle, b.handle, 1 if inner_is_left else 0, thr, use, ctypes.byref(out)))
-                return DeviceOp(out).download()
-            finally:
-                if b is not a:
-                    b.free()
-        slab = max(1, max_pairs // ni)
-        parts_r, parts_c = [], []
-        for o0 in range(0, no, slab):
-            b = DeviceOp.upload(outer[o0:o0 + slab], co[o0:o0 + slab])
-            out = ctypes.c_void_p()
-            try:
-                # partial sums must not be thresholded: a term may only cancel across slabs
-                check(_lib.lib().symgpu_mul_cleanup_dev(a.handle, b.handle, 1 if inner_is_left else 0, 0.0, 0, ctypes.byref(out)))
-                r, c = DeviceOp(out).download()
-            finally:
-                b.free()
-            parts_r.append(r); parts_c.append(c)
-        return cleanup(np.vstack(parts_r), np.hstack(parts_c), zero_threshold)
+        res = mul_cleanup_handles(a, b, inner_is_left, zero_threshold, max_pairs)
+        try:
+            return res.download()
+        finally:
+            res.free()
     finally:
         a.free()
+        if b is not a:
+            b.free()
 
 
 def rotation_args(angle, threshold=1e-18):
@@ -237,7 +345,7 @@ def rotate_clifford_chain_dev(op, q_rows, ks):
 def perform_rotations_dev(op, q_rows, cos_t, sin_t, ks, clean, zero_threshold=1e-15):
     """``perform_rotations`` on a device operator in one library call (``symgpu_perform_rotations_dev``): returns
     (new DeviceOp or None if nothing changed, rotations done, uint8 flags of the single rotations that acted, clean flag).
-    Fewer rotations done than given: the operator has lost all its terms (the caller handles the reference's 0*I alternation)."""
+    The call processes all K rotations, also through the states "no terms" and "0 * I" (it follows the reference's alternation itself)."""
     q_rows = np.ascontiguousarray(q_rows, dtype='<u8')
     cos_t, sin_t = np.ascontiguousarray(cos_t, dtype=np.float64), np.ascontiguousarray(sin_t, dtype=np.float64)
     ks = np.ascontiguousarray(ks, dtype=np.int32)
@@ -280,6 +388,15 @@ def symmetry_kernel(h_rows, n_qubits):
     return out[:k.value].copy(), count.value
 
 
+def symmetry_kernel_handle(op, n_qubits):
+    """The same on a device-resident operator (``symgpu_symmetry_kernel_dev``): only the generators come back."""
+    wq = op.info()[1]
+    out = np.zeros((2 * n_qubits, 2 * wq), dtype='<u8')
+    k, count = c_i64(0), c_i64(0)
+    check(_lib.lib().symgpu_symmetry_kernel_dev(op.handle, int(n_qubits), addr(out), 2 * n_qubits, ctypes.addressof(k), ctypes.addressof(count)))
+    return out[:k.value].copy(), count.value
+
+
 # ---- f3 / f4 (SURVEY 8f): projection, noncontextuality test, state inner product -------------------------------------------------
 def project_dev(op, stab_rows, eigenvalues, keep_qubits, n_qubits, zero_threshold=1e-15):
     """``S3Projection._perform_projection`` (projection/base.py:44-84) on a device operator: ``stab_rows`` uint64[k, 2*Wq] the fixed
@@ -289,7 +406,11 @@ def project_dev(op, stab_rows, eigenvalues, keep_qubits, n_qubits, zero_threshol
     k = stab_rows.shape[0]
     wq = op.info()[1]
     neg = np.zeros(2 * wq, dtype='<u8')
-    for row, ev in zip(stab_rows, np.asarray(eigenvalues).ravel()):
+    eigenvalues = np.asarray(eigenvalues).ravel()
+    # the reference multiplies by the eigenvalue itself (projection/base.py:68-71); the sign-mask form below is that product only for
+    # eigenvalues in {-1, 0, +1} — anything else (a sector entry like -1.0000000000000002) must not be read as +1 in silence
+    assert np.all(np.isin(eigenvalues, (-1, 0, 1))), f'stabiliser eigenvalues must be -1, 0 or +1, got {eigenvalues}'
+    for row, ev in zip(stab_rows, eigenvalues):
         if ev == -1:
             neg |= row                                             # (projection/base.py:69: the column index list has one entry per stabiliser)
     keep = np.ascontiguousarray(keep_qubits, dtype=np.int32)

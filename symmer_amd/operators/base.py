@@ -46,18 +46,29 @@ class PauliwordOp:
         assert len(symp_matrix.shape) == 2, 'symplectic matrix must be 2 dimensional only'
         self._symp = symp_matrix
         self.n_qubits = symp_matrix.shape[1] // 2
-        self.coeff_vec = np.asarray(coeff_vec, dtype=complex)
+        self._coeff = np.asarray(coeff_vec, dtype=complex)
         self.n_terms = symp_matrix.shape[0]
-        assert self.n_terms == len(self.coeff_vec), 'coeff list and Pauliwords not same length'
+        assert self.n_terms == len(self._coeff), 'coeff list and Pauliwords not same length'
         self._packed_cache = None
+        self._dev = None                 # kernels.DeviceOp: the operator resident on the GPU (rows + coefficients)
+        self._dev_coeff_valid = False    # the handle's coefficients are this operator's coefficients
+        self._coeff_exposed = True       # the host coefficient array is (or may be) in the caller's hands: it can change behind our back
 
-    # ---- the two layouts: reference bool matrix (host glue) and packed rows (the C-ABI operand) -----------
+    # ---- three layouts of one operator: the reference's bool matrix, packed rows on the host, packed rows on the device --------------
+    # Results of device kernels STAY on the device (`_dev`) and come to the host when somebody asks for `symp_matrix`, `packed` or
+    # `coeff_vec`; operands are uploaded once and the handle is kept, so a multi-step caller (rotate -> project -> cleanup,
+    # symmer/projection/base.py:44-124) moves its operator over PCIe once in and once out.  `symp_matrix` is treated as immutable, as
+    # in the reference; `coeff_vec` is not (`op.coeff_vec *= -1`, `op.coeff_vec[i] = x` are reference idioms): once the host array has
+    # been handed out, the device copy of the coefficients is refreshed (16 bytes per term) before every device call.
     @property
     def symp_matrix(self) -> np.ndarray:
-        """bool[T, 2n] = [X | Z] as in the reference.  Results of device kernels arrive packed and are only expanded
-        to one byte per bit when somebody asks (a 2.5e7-term, 1000-qubit product is 6 GB packed but 50 GB as bools)."""
+        """bool[T, 2n] = [X | Z] as in the reference; expanded to one byte per bit only when somebody asks (a 2.5e7-term, 1000-qubit
+        product is 6 GB packed but 50 GB as bools) — on the device when the operator is resident there."""
         if self._symp is None:
-            self._symp = packing.unpack_rows(self._packed_cache, self.n_qubits)
+            if self._packed_cache is None and self._dev is not None and self.n_qubits > 0:
+                self._symp = self._dev.download_bool(self.n_qubits)
+            else:
+                self._symp = packing.unpack_rows(self.packed, self.n_qubits)
         return self._symp
 
     @property
@@ -70,10 +81,64 @@ class PauliwordOp:
 
     @property
     def packed(self) -> np.ndarray:
-        """uint64[T, 2*Wq] rows of the C-ABI; cached (``symp_matrix`` is treated as immutable, as in the reference)."""
+        """uint64[T, 2*Wq] rows of the C-ABI on the host; cached."""
         if self._packed_cache is None:
-            self._packed_cache = packing.pack_rows(self._symp)
+            if self._symp is not None:
+                self._packed_cache = packing.pack_rows(self._symp)
+            elif self._coeff is None:
+                self._packed_cache, self._coeff = self._dev.download()          # one transfer for both halves of the operator
+            else:
+                self._packed_cache = self._dev.download(with_coeff=False)
         return self._packed_cache
+
+    @property
+    def coeff_vec(self) -> np.ndarray:
+        """complex128[T] (whatever was assigned, for subclasses that keep ints).  Handing the array out ends our knowledge of its
+        contents: see the note above."""
+        self._coeff_exposed = True
+        return self._c()
+
+    @coeff_vec.setter
+    def coeff_vec(self, value) -> None:
+        self._coeff = value if isinstance(value, np.ndarray) else np.asarray(value)
+        self._coeff_exposed = True
+        self._dev_coeff_valid = False
+
+    def _c(self) -> np.ndarray:
+        """The coefficients for READING inside this package (never mutated, never passed on by reference)."""
+        if self._coeff is None:
+            self._coeff = self._dev.download_coeff()
+        return self._coeff
+
+    _UPLOAD_BOOL_MIN_BYTES = 1 << 20
+
+    def _device(self, rows_only: bool = False) -> "kernels.DeviceOp":
+        """The operator as a device handle: uploaded on first use, kept for the life of the object.  ``rows_only``: the caller reads
+        the rows only (commutation, Y counts, GF(2) kernels), so stale device coefficients need no refresh."""
+        assert self.n_qubits > 0, 'a 0-qubit operator has no packed rows'
+        if self._dev is None:
+            coeff = np.asarray(self._c(), dtype=complex)
+            if self._packed_cache is None and self._symp.size >= self._UPLOAD_BOOL_MIN_BYTES and self._symp.flags.c_contiguous:
+                self._dev = kernels.DeviceOp.upload_bool(self._symp, coeff)       # packed by a ballot kernel: 10x np.packbits
+            else:
+                self._dev = kernels.DeviceOp.upload(self.packed, coeff)
+            self._dev_coeff_valid = True
+        elif not rows_only and (self._coeff_exposed or not self._dev_coeff_valid) and self._coeff is not None:
+            if self._dev.shared:
+                self._dev = self._dev.clone()
+            self._dev.set_coeff(np.asarray(self._coeff, dtype=complex))
+            self._dev_coeff_valid = True
+        return self._dev
+
+    @classmethod
+    def _from_device(cls, dev: "kernels.DeviceOp", n_qubits: int) -> "PauliwordOp":
+        """A kernel's result, left where it is."""
+        op = cls.__new__(cls)
+        op._symp = op._packed_cache = op._coeff = None
+        op._dev, op._dev_coeff_valid, op._coeff_exposed = dev, True, False
+        op.n_qubits = n_qubits
+        op.n_terms = dev.n_terms
+        return op
 
     @classmethod
     def _from_packed(cls, packed: np.ndarray, n_qubits: int, coeff_vec) -> "PauliwordOp":
@@ -84,20 +149,33 @@ class PauliwordOp:
         op._packed_cache = packed
         op.n_qubits = n_qubits
         op.n_terms = packed.shape[0]
-        op.coeff_vec = np.asarray(coeff_vec, dtype=complex)
-        assert op.n_terms == len(op.coeff_vec), 'coeff list and Pauliwords not same length'
+        op._coeff = np.asarray(coeff_vec, dtype=complex)
+        op._dev, op._dev_coeff_valid, op._coeff_exposed = None, False, True
+        assert op.n_terms == len(op._coeff), 'coeff list and Pauliwords not same length'
         return op
 
+    def _host_has_rows(self) -> bool:
+        return self._symp is not None or self._packed_cache is not None
+
     def _derive(self, index=None, coeff_vec=None) -> "PauliwordOp":
-        """Row selection / new coefficients without touching layouts that have not been materialised."""
+        """Row selection / new coefficients without touching layouts that have not been materialised: an operator that lives on the
+        device only is indexed THERE (``symgpu_op_gather``)."""
+        if index is not None and not self._host_has_rows() and self._dev is not None:
+            assert coeff_vec is None
+            picked = np.arange(self.n_terms)[index].astype(np.int64).reshape(-1)
+            return PauliwordOp._from_device(kernels.op_gather(self._device(), picked), self.n_qubits)
         op = PauliwordOp.__new__(PauliwordOp)
         op._symp = None if self._symp is None else (self._symp if index is None else self._symp[index])
         op._packed_cache = None if self._packed_cache is None else (self._packed_cache if index is None else
                                                                     np.ascontiguousarray(self._packed_cache[index]))
         op.n_qubits = self.n_qubits
-        coeff = self.coeff_vec if coeff_vec is None else coeff_vec
-        op.coeff_vec = np.asarray(coeff if index is None or coeff_vec is not None else coeff[index], dtype=complex)
-        op.n_terms = len(op.coeff_vec)
+        coeff = self._c() if coeff_vec is None else coeff_vec
+        op._coeff = np.array(coeff if index is None or coeff_vec is not None else coeff[index], dtype=complex)   # a copy: never an alias of ours
+        op.n_terms = len(op._coeff)
+        op._dev, op._dev_coeff_valid, op._coeff_exposed = None, False, False
+        if index is None and self._dev is not None:
+            op._dev = self._dev                                   # same rows: the handle is shared, its coefficients are not ours
+            self._dev.shared = True
         return op
 
     # ---- constructors --------------------------------------------------------------------------------
@@ -142,8 +220,8 @@ class PauliwordOp:
     def __str__(self) -> str:
         fmt = f' .{self.sigfig}f'
         if self.n_qubits == 0:
-            return format(self.coeff_vec[0], fmt)                 # a bare scalar
-        return ' +\n'.join(f'{format(c, fmt)} {symplectic_to_string(row)}' for row, c in zip(self.symp_matrix, self.coeff_vec))
+            return format(self._c()[0], fmt)                      # a bare scalar
+        return ' +\n'.join(f'{format(c, fmt)} {symplectic_to_string(row)}' for row, c in zip(self.symp_matrix, self._c()))
 
     def __repr__(self) -> str:
         return str(self)
@@ -163,7 +241,7 @@ class PauliwordOp:
     # the orderings of the reference's ``sort`` (base.py:455-492) as a table: name -> term order for key='decreasing'.  The same
     # NumPy sorts on the same score vectors as the reference, so ties fall the same way.
     _ORDERINGS = {
-        'magnitude': lambda P: np.argsort(-abs(P.coeff_vec)),
+        'magnitude': lambda P: np.argsort(-abs(P._c())),
         'lex': lambda P: np.lexsort(P.symp_matrix.T) if P.n_terms else np.zeros(0, dtype=int),    # last column = primary key
         'weight': lambda P: np.argsort(-P.symp_matrix.sum(axis=1, dtype=int)),
         'support': lambda P: P._support_order(),
@@ -195,7 +273,7 @@ class PauliwordOp:
         assert len(unmapped) == 0, f'Assignment conflict: indices {unmapped} cannot be mapped.'
         perm = np.arange(self.n_qubits)
         perm[list(old_indices)] = list(new_indices)
-        return PauliwordOp(np.hstack([self.X_block[:, perm], self.Z_block[:, perm]]), self.coeff_vec)
+        return PauliwordOp(np.hstack([self.X_block[:, perm], self.Z_block[:, perm]]), self._c().copy())
 
     def set_processing_method(self, method):
         """base.py:76-80 selects mp / ray / single_thread for the reference's host fan-out; the device path has no such pool."""
@@ -205,9 +283,9 @@ class PauliwordOp:
     def to_dataframe(self):
         """base.py:1419-1434."""
         import pandas as pd
-        frame = pd.DataFrame.from_dict({'Pauli terms': list(self.to_dictionary.keys()), 'Coefficients (real)': self.coeff_vec.real})
-        if np.any(self.coeff_vec.imag):
-            frame['Coefficients (imaginary)'] = self.coeff_vec.imag
+        frame = pd.DataFrame.from_dict({'Pauli terms': list(self.to_dictionary.keys()), 'Coefficients (real)': self._c().real})
+        if np.any(self._c().imag):
+            frame['Coefficients (imaginary)'] = self._c().imag
         return frame
 
     def conjugate_op(self, R: "PauliwordOp") -> "PauliwordOp":
@@ -239,18 +317,17 @@ class PauliwordOp:
         """base.py:604-615: per-term count of Pauli Y (popcount of X & Z on the packed rows, on device)."""
         if self.n_terms == 0 or self.n_qubits == 0:
             return np.zeros(self.n_terms, dtype=np.int64)
-        return kernels.ycount(self.packed)
+        return self._device(rows_only=True).ycount()
 
     # ---- a5 ----------------------------------------------------------------------------------------------
     def cleanup(self, zero_threshold: float = 1e-15) -> "PauliwordOp":
         """base.py:617-638.  Edge cases as the reference: no terms -> one identity row with coefficient 0;
         0 qubits -> the scalar term (the reference raises there, SURVEY §8a'; we return the sum)."""
         if self.n_qubits == 0:
-            return PauliwordOp(np.zeros((1, 0), dtype=bool), [np.sum(self.coeff_vec)])
+            return PauliwordOp(np.zeros((1, 0), dtype=bool), [np.sum(self._c())])
         if self.n_terms == 0:
-            return PauliwordOp(np.zeros((1, self.symp_matrix.shape[1]), dtype=bool), [0])
-        rows, coeff = kernels.cleanup(self.packed, self.coeff_vec, zero_threshold)
-        return PauliwordOp._from_packed(rows, self.n_qubits, coeff)
+            return PauliwordOp(np.zeros((1, 2 * self.n_qubits), dtype=bool), [0])
+        return PauliwordOp._from_device(kernels.cleanup_dev(self._device(), zero_threshold), self.n_qubits)
 
     def __eq__(self, Pword: "PauliwordOp") -> bool:
         """base.py:640-662: cleanup + lexicographic sort on both sides, exact rows, ``np.allclose`` coefficients."""
@@ -261,14 +338,17 @@ class PauliwordOp:
         if check_1.n_terms != check_2.n_terms:
             return False
         return bool(not np.sum(np.logical_xor(check_1.symp_matrix, check_2.symp_matrix)) and
-                    np.allclose(check_1.coeff_vec, check_2.coeff_vec))
+                    np.allclose(check_1._c(), check_2._c()))
 
     def __hash__(self) -> int:
         return hash(tuple(self.to_dictionary.items()))
 
     def append(self, PwordOp: "PauliwordOp") -> "PauliwordOp":
         assert self.n_qubits == PwordOp.n_qubits, 'Pauliwords defined for different number of qubits'
-        coeff = np.hstack((self.coeff_vec, PwordOp.coeff_vec))
+        if self.n_qubits and (self._dev is not None or PwordOp._dev is not None) and self.n_terms and PwordOp.n_terms:
+            # an operand already lives on the device: stacked there (device-to-device), nothing comes back
+            return PauliwordOp._from_device(kernels.concat_dev([self._device(), PwordOp._device()]), self.n_qubits)
+        coeff = np.hstack((self._c(), PwordOp._c()))
         if (self._symp is None or PwordOp._symp is None) and self.n_qubits:
             return PauliwordOp._from_packed(np.vstack((self.packed, PwordOp.packed)), self.n_qubits, coeff)
         return PauliwordOp(np.vstack((self.symp_matrix, PwordOp.symp_matrix)), coeff)
@@ -282,19 +362,35 @@ class PauliwordOp:
         return self + add_obj
 
     def __sub__(self, PwordOp: "PauliwordOp") -> "PauliwordOp":
-        op_copy = PwordOp.copy()
-        op_copy.coeff_vec *= -1
-        return self + op_copy
+        return self + PwordOp.multiply_by_constant(-1)        # base.py:742-748 negates a copy's coefficients: the same values
+
+    def _scaled(self, const: complex, conjugate_first: bool = False) -> "PauliwordOp":
+        """coefficients -> (conj?) * const with the rows untouched; on the device when the coefficients live there only."""
+        if self._dev is not None and self._coeff is None:
+            scaled = self._dev.clone()
+            scaled.scale(const, conjugate_first)
+            return PauliwordOp._from_device(scaled, self.n_qubits)
+        coeff = self._c().conjugate() if conjugate_first else self._c()
+        return self._derive(coeff_vec=coeff if (conjugate_first and const == 1) else coeff * const)
 
     def multiply_by_constant(self, const: complex) -> "PauliwordOp":
-        return self._derive(coeff_vec=self.coeff_vec * const)
+        return self._scaled(const)
 
     # ---- a3 / a4 -----------------------------------------------------------------------------------------
+    def _product(self, other: "PauliwordOp", self_is_inner: bool, zero_threshold: float) -> "PauliwordOp":
+        """Fused product + cleanup ``self * other`` on resident operands; the result stays resident.  ``self_is_inner``: self's terms
+        are the fast index of the reference's pair order (base.py:783-792)."""
+        if self.n_terms == 0 or other.n_terms == 0:
+            return PauliwordOp._from_packed(np.empty((0, 2 * packing.words_per_block(self.n_qubits)), dtype='<u8'), self.n_qubits, [])
+        a = self._device()
+        b = a if other is self else other._device()
+        inner, outer = (a, b) if self_is_inner else (b, a)
+        return PauliwordOp._from_device(kernels.mul_cleanup_handles(inner, outer, self_is_inner, zero_threshold), self.n_qubits)
+
     def _multiply_by_operator(self, PwordOp: "PauliwordOp", zero_threshold: float = 1e-15) -> "PauliwordOp":
         """base.py:764-794: ``self`` is the inner (fast) index and the LEFT factor; fused product + cleanup on device."""
         assert self.n_qubits == PwordOp.n_qubits, 'PauliwordOps defined for different number of qubits'
-        rows, coeff = kernels.mul_cleanup(self.packed, self.coeff_vec, PwordOp.packed, PwordOp.coeff_vec, True, zero_threshold)
-        return PauliwordOp._from_packed(rows, self.n_qubits, coeff)
+        return self._product(PwordOp, True, zero_threshold)
 
     def __mul__(self, mul_obj, zero_threshold: float = 1e-15) -> "PauliwordOp":
         """base.py:821-859.  The operand with fewer terms is the outer index; the reference does that through
@@ -311,14 +407,10 @@ class PauliwordOp:
             other = mul_obj
         assert isinstance(other, PauliwordOp), f'cannot multiply PauliwordOp by {type(mul_obj)}'
         assert self.n_qubits == other.n_qubits, 'PauliwordOps defined for different number of qubits'
-        if self.n_terms < other.n_terms:
-            rows, coeff = kernels.mul_cleanup(other.packed, other.coeff_vec, self.packed, self.coeff_vec, False, zero_threshold)
-        else:
-            rows, coeff = kernels.mul_cleanup(self.packed, self.coeff_vec, other.packed, other.coeff_vec, True, zero_threshold)
-        out = PauliwordOp._from_packed(rows, self.n_qubits, coeff)
+        out = self._product(other, self.n_terms >= other.n_terms, zero_threshold)
         if is_state:
             # identities were mapped to Z: II == ZZ as states, so fold i^Y into the coefficients and merge again (base.py:854-857)
-            return QuantumState(out.X_block.astype(int), out.coeff_vec * (1j ** out.Y_count)).cleanup()
+            return QuantumState(out.X_block.astype(int), out._c() * (1j ** out.Y_count)).cleanup()
         return out
 
     def expval(self, psi) -> complex:
@@ -327,7 +419,7 @@ class PauliwordOp:
         if self.n_terms > psi.n_terms and psi.n_terms > 10:
             return (psi.dagger * self * psi).real
         expvals = np.array([single_term_expval(P, psi) for P in self]) if self.n_terms > 1 else np.array(single_term_expval(self, psi))
-        return np.sum(expvals * self.coeff_vec).real
+        return np.sum(expvals * self._c()).real
 
     def __rmul__(self, const):
         if isinstance(const, Number):
@@ -372,7 +464,10 @@ class PauliwordOp:
         assert self.n_qubits == PwordOp.n_qubits, 'Pauliwords defined for different number of qubits'
         if self.n_qubits == 0:
             return np.ones((self.n_terms, PwordOp.n_terms), dtype=bool)
-        return kernels.commutes(self.packed, self.packed if PwordOp is self else PwordOp.packed)
+        if self.n_terms == 0 or PwordOp.n_terms == 0:
+            return np.empty((self.n_terms, PwordOp.n_terms), dtype=bool)
+        a = self._device(rows_only=True)
+        return kernels.commutes_handles(a, a if PwordOp is self else PwordOp._device(rows_only=True))
 
     def anticommutes_termwise(self, PwordOp: "PauliwordOp") -> np.ndarray:
         return ~self.commutes_termwise(PwordOp)
@@ -388,11 +483,7 @@ class PauliwordOp:
         unique rows as a popcount identity — the M x M matrix never exists as bytes and never leaves the GPU."""
         if self.n_terms < 4:
             return True
-        dev = kernels.DeviceOp.upload(self.packed)
-        try:
-            return kernels.noncontextual_dev(dev)
-        finally:
-            dev.free()
+        return kernels.noncontextual_dev(self._device(rows_only=True))
 
     # ---- graph glue on the device-computed adjacency matrix (reference base.py:985-1364; networkx, host) ------------
     def qubitwise_commutes_termwise(self, PwordOp: "PauliwordOp") -> np.ndarray:
@@ -461,7 +552,7 @@ class PauliwordOp:
 
     def commutes(self, PwordOp: "PauliwordOp") -> bool:
         commutator = self.commutator(PwordOp).cleanup()
-        return bool(commutator.n_terms == 0 or np.all(commutator.coeff_vec[0] == 0))
+        return bool(commutator.n_terms == 0 or np.all(commutator._c()[0] == 0))
 
     # ---- a7 ----------------------------------------------------------------------------------------------
     def _rotate_by_single_Pword(self, Pword: "PauliwordOp", angle: float = None, threshold: float = 1e-18
@@ -475,25 +566,19 @@ class PauliwordOp:
         angle = angle.real
         assert Pword.n_terms == 1, 'Only rotation by single Pauliword allowed here'
         assert Pword.n_qubits == self.n_qubits, 'Pauliwords defined for different number of qubits'
-        if Pword.coeff_vec[0] != 1:
-            warnings.warn(f'Pword coefficient {Pword.coeff_vec[0]: .8f} has been set to 1')
+        if Pword._c()[0] != 1:
+            warnings.warn(f'Pword coefficient {Pword._c()[0]: .8f} has been set to 1')
         if self.n_terms == 0:
             return self
-        op = kernels.DeviceOp.upload(self.packed, self.coeff_vec)
-        try:
-            res, all_commute = kernels.rotate_single_dev(op, Pword.packed[0], angle, clifford_threshold=threshold)
-            if all_commute:
-                return self                                     # identity action: the SAME object (base.py:1131-1133)
-            _warn_large_angle(angle, threshold)                 # only on the non-Clifford, non-commuting branch (base.py:1156-1157)
-            rows, coeff = res.download()
-            res.free()
-        finally:
-            op.free()
-        if rows.shape[0] == 0 and kernels.rotation_args(angle, threshold)[2] < 0 and not np.any(self.commutes_termwise(Pword)):
+        res, all_commute = kernels.rotate_single_dev(self._device(), Pword.packed[0], angle, clifford_threshold=threshold)
+        if all_commute:
+            return self                                         # identity action: the SAME object (base.py:1131-1133)
+        _warn_large_angle(angle, threshold)                     # only on the non-Clifford, non-commuting branch (base.py:1156-1157)
+        if res.n_terms == 0 and kernels.rotation_args(angle, threshold)[2] < 0 and not np.any(self.commutes_termwise(Pword)):
             # non-Clifford and nothing left: the reference returns `commute_self + anticom_part` (base.py:1159-1161), and the sum of
             # two operators without terms is 0 * I (append, then cleanup(): base.py:631-632)
             return PauliwordOp(np.zeros((1, 2 * self.n_qubits), dtype=bool), [0])
-        return PauliwordOp._from_packed(rows, self.n_qubits, coeff)
+        return PauliwordOp._from_device(res, self.n_qubits)     # the result stays on the device until somebody reads it
 
     def perform_rotations(self, rotations: List[Tuple["PauliwordOp", float]]) -> "PauliwordOp":
         """base.py:1163-1186: rotations applied left to right, each followed by ``cleanup()``; the operator stays
@@ -520,15 +605,15 @@ class PauliwordOp:
             assert pauli_rotation.n_qubits == self.n_qubits, 'Pauliwords defined for different number of qubits'
             if angle is None:
                 angle = np.pi / 2
-            if pauli_rotation.coeff_vec[0] != 1:
-                warnings.warn(f'Pword coefficient {pauli_rotation.coeff_vec[0]: .8f} has been set to 1')
+            if pauli_rotation._c()[0] != 1:
+                warnings.warn(f'Pword coefficient {pauli_rotation._c()[0]: .8f} has been set to 1')
             if getattr(angle, 'imag', 0) != 0:
                 warnings.warn('Complex component in angle: this will be ignored.')
             angle = float(np.real(angle))
             angles.append(angle)
             q_rows[r] = pauli_rotation.packed[0]
             cos_t[r], sin_t[r], ks[r] = kernels.rotation_args(angle)
-        dev = kernels.DeviceOp.upload(self.packed, self.coeff_vec)
+        dev = start = self._device()                             # resident already, or uploaded once and kept
         # The reference calls ``.cleanup()`` after every rotation (base.py:1185).  On an operator that has no duplicate rows and
         # no coefficient with |c| <= 1e-15 that cleanup is the identity, and the rotation kernels preserve both properties
         # (a rotated row P*Q can only coincide with an input row, which the kernels merge themselves; they also apply the
@@ -539,40 +624,39 @@ class PauliwordOp:
         # call follows that state machine itself, including WHY an operator is empty (emptied by a rotation: cleanup() gives 0 * I;
         # emptied by the cleanup: it stays without terms), so nothing is patched up here.
         clean = False
-        try:
-            step = 0
-            while step < K:
-                res, n_done, acted, clean = kernels.perform_rotations_dev(dev, q_rows[step:], cos_t[step:], sin_t[step:], ks[step:], clean)
-                for r in np.flatnonzero(acted[:n_done]):
-                    _warn_large_angle(angles[step + int(r)], 1e-18)
-                if res is not None:
-                    dev.free()
-                    dev = res
-                assert n_done > 0, 'symgpu_perform_rotations_dev made no progress'
-                step += n_done
-            rows, coeff = dev.download()
-        finally:
-            dev.free()
-        if rows.shape[0] == 0:
+        step = 0
+        while step < K:
+            res, n_done, acted, clean = kernels.perform_rotations_dev(dev, q_rows[step:], cos_t[step:], sin_t[step:], ks[step:], clean)
+            for r in np.flatnonzero(acted[:n_done]):
+                _warn_large_angle(angles[step + int(r)], 1e-18)
+            if res is not None:
+                if dev is not start:
+                    dev.free()                                  # an intermediate of this chain; `start` belongs to self
+                dev = res
+            assert n_done > 0, 'symgpu_perform_rotations_dev made no progress'
+            step += n_done
+        if dev is start:
+            start.shared = True                                 # nothing acted and the operator was clean: a new object on the same rows
+        if dev.n_terms == 0:
             # cleanup() of an operator whose terms all cancelled has shape (0, 2n) (test_base.py:124-130)
             return PauliwordOp(np.zeros((0, 2 * self.n_qubits), dtype=bool), [])
-        return PauliwordOp._from_packed(rows, self.n_qubits, coeff)
+        return PauliwordOp._from_device(dev, self.n_qubits)
 
     def tensor(self, right_op: "PauliwordOp") -> "PauliwordOp":
         id_r = np.zeros([right_op.n_terms, self.n_qubits], dtype=bool)
         id_l = np.zeros([self.n_terms, right_op.n_qubits], dtype=bool)
-        left = PauliwordOp(np.hstack([self.X_block, id_l, self.Z_block, id_l]), self.coeff_vec)
-        right = PauliwordOp(np.hstack([id_r, right_op.X_block, id_r, right_op.Z_block]), right_op.coeff_vec)
+        left = PauliwordOp(np.hstack([self.X_block, id_l, self.Z_block, id_l]), self._c().copy())
+        right = PauliwordOp(np.hstack([id_r, right_op.X_block, id_r, right_op.Z_block]), right_op._c().copy())
         return left * right
 
     @cached_property
     def dagger(self) -> "PauliwordOp":
-        return self._derive(coeff_vec=self.coeff_vec.conjugate())
+        return self._scaled(1, conjugate_first=True)
 
     @cached_property
     def to_dictionary(self) -> Dict[str, complex]:
         op = self.cleanup()
-        return {symplectic_to_string(v): c for v, c in zip(op.symp_matrix, op.coeff_vec)}
+        return {symplectic_to_string(v): c for v, c in zip(op.symp_matrix, op._c())}
 
     # ---- a10 / f2: GF(2) generator routines (same device kernel as a8) ----------------------------------------
     @cached_property

@@ -57,7 +57,7 @@ class IndependentOp(PauliwordOp):
         sweep, ``csrc/gf2.hip``) and reads the same rows out, in the same order."""
         n = PwordOp.n_qubits
         if PwordOp.n_terms and n:
-            packed_generators, _ = kernels.symmetry_kernel(PwordOp.packed, n)
+            packed_generators, _ = kernels.symmetry_kernel_handle(PwordOp._device(rows_only=True), n)
             found = packing.unpack_rows(packed_generators, n)
         else:
             found = np.eye(2 * n, dtype=bool)                     # nothing constrains the kernel

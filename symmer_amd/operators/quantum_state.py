@@ -99,13 +99,11 @@ class QuantumState:
             # basis rows on the device (csrc/project.hip), the products added in that same order
             left, right = (self, mul_obj) if self.state_op.n_terms < mul_obj.n_terms else (mul_obj, self)
             from .. import kernels
-            ups = [kernels.DeviceOp.upload(s.state_op.packed, s.state_op.coeff_vec) for s in (left, right)]
-            cleaned = []
+            cleaned = [kernels.cleanup_dev(s.state_op._device()) for s in (left, right)]
             try:
-                cleaned = [kernels.cleanup_dev(u) for u in ups]
                 return kernels.state_inner_dev(cleaned[0], cleaned[1])
             finally:
-                for h in ups + cleaned:
+                for h in cleaned:
                     h.free()
         if isinstance(mul_obj, PauliwordOp):
             new_state_op = self.state_op * mul_obj

@@ -31,24 +31,18 @@ class S3Projection:
             for row, ev in zip(fixed.packed, np.asarray(fixed.coeff_vec)):
                 if ev == -1:
                     neg |= row
+            assert np.all(np.isin(np.asarray(fixed.coeff_vec), (-1, 0, 1))), 'stabiliser eigenvalues must be -1, 0 or +1'
             odd = (packing.popcount_rows(operator.packed[survives] & neg) & 1).astype(bool)
-            weights = np.where(odd, -operator.coeff_vec[survives], operator.coeff_vec[survives])
+            weights = np.where(odd, -operator._c()[survives], operator._c()[survives])
             return PauliwordOp(np.zeros((1, 0), dtype=bool), [np.sum(weights)])
         # the whole step on the device, on packed rows (csrc/project.hip): anticommutation with the fixed stabilisers, eigenvalue signs, deletion
         # of the stabilised qubits and the final merge of equal terms — no one-byte-per-bit matrix, no operator round trip through the host
-        dev = kernels.DeviceOp.upload(operator.packed, operator.coeff_vec)
-        try:
-            res, n_survived = kernels.project_dev(dev, fixed.packed, np.asarray(fixed.coeff_vec), keep, n)
-        finally:
-            dev.free()
-        try:
-            rows, weights = res.download()
-        finally:
-            res.free()
+        # (the operator arrives resident from perform_rotations and the projected operator stays resident: no round trip)
+        res, n_survived = kernels.project_dev(operator._device(), fixed.packed, np.asarray(fixed.coeff_vec), keep, n)
         if n_survived == 0:
             # nothing commutes with the stabilisers: the reference's cleanup() of an operator without terms is 0 * I (base.py:631-632)
             return PauliwordOp(np.zeros((1, 2 * keep.size), dtype=bool), [0])
-        return PauliwordOp._from_packed(rows, int(keep.size), weights)
+        return PauliwordOp._from_device(res, int(keep.size))
 
     def perform_projection(self, operator: PauliwordOp, ref_state: Union[List[int], np.ndarray] = None,
                            sector: Union[List[int], np.ndarray] = None) -> PauliwordOp:
