@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bench.py — headline benchmark of the symplectic hot path on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W     (N>1: launched by torch.distributed.run,
@@ -44,7 +43,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-PROFILE_TAG = 'r04'                     # profiles/<tag>_*: the round whose rocprofv3 summaries belong to this bench.py
+PROFILE_TAG = 'r05'                     # profiles/<tag>_*: the round whose rocprofv3 summaries belong to this bench.py
 TRAFFIC_PROFILE = f'{PROFILE_TAG}_traffic.json'   # written by tools/pmc_product.sh from the rocprofv3 --pmc passes of this bench
 
 
@@ -66,6 +65,8 @@ def parse():
     ap.add_argument('--adj-slab-rows', type=int, default=0, help='adjacency: rows per launch / output slab (0: as many as a quarter of the free HBM holds)')
     ap.add_argument('--no-extras', action='store_true')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-api', action='store_true', help='skip the `api` objects (the reference\'s call spelling timed on the drop-in classes)')
+    ap.add_argument('--cpu-full', action='store_true', help='gf2: time the CPU restatement on the full 4000 x 54000 matrix (~70 s) instead of citing the cached run')
     args = ap.parse_args()
     # a millisecond-scale step needs more than three of them for a stable figure (clocks, allocator): mul_cleanup 20 + 3, gf2 10 + 2
     d_steps, d_warm = {'mul_cleanup': (20, 3), 'gf2': (10, 2)}.get(args.workload, (3, 1))
@@ -97,6 +98,7 @@ def main():
             collective_hang(exc, args, rank, world)
         comm.close()
         if rank == 0:
+            out['degraded_kernels'] = _lib.degraded()     # fast paths that gave up in this process (in-kernel wait timed out): [] on a healthy box
             print(json.dumps(out))
         comm.hard_exit_if_hung()
         return
@@ -252,6 +254,7 @@ def main():
             out['cpu_baseline'] = {'error': f'{type(exc).__name__}: {exc}'}
     comm.close()
     if rank == 0:
+        out['degraded_kernels'] = _lib.degraded()         # fast paths that gave up in this process (in-kernel wait timed out): [] on a healthy box
         print(json.dumps(out))
     comm.hard_exit_if_hung()
 
@@ -354,8 +357,8 @@ def wl_mul_cleanup(args, comm, rank, world, _lib, DeviceOp, parallel):
             'frac': launch_bytes / kt / 1e9 / HBM_PEAK_GBS if kt else None, 'traffic': None, 'launches': nl, 'avg_launch_ms': kt * 1e3,
             'algorithmic_bytes_per_launch': launch_bytes,
             'note': 'output stage of the cleanup in one launch: 16*Wq + 16 bytes per kept row, written once (non-temporal stores), rows '
-                    'gathered from the L2-resident operand; the other long kernels of the step are the 4 passes of the radix sort '
-                    '(8 B keys: scatter 0.17 ms + histogram 0.09 ms each) and the key generation — profiles/r03_cfg3_kernel_trace.txt',
+                    'gathered from the L2-resident operand; the other kernels of the step are key generation, the partial radix sort (3 of 4 '
+                    f'8-bit passes), the marking of single keys and the suspect search — profiles/{PROFILE_TAG}_cfg3_kernel_trace.txt',
             'whole_step': {'survey_8d_algorithmic_bytes': algo_step, 'algorithmic_GBps': algo_step / (dt / args.steps) / 1e9,
                            'physical_write_floor_ms': n_out[0] * (row_bytes + 16) / (HBM_PEAK_GBS * 1e9) * 1e3,
                            'note': 'SURVEY 8d counts T (16Wq+16) B read + U_kept (16Wq+16) B written; the T product rows and pair coefficients '
@@ -366,6 +369,11 @@ def wl_mul_cleanup(args, comm, rank, world, _lib, DeviceOp, parallel):
                          'call': 'P * P (symgpu_mul_cleanup_dev: fused product + cleanup, squared-operator path)',
                          'parallelism': f'{world} independent replicas' if world > 1 else 'single GPU'}, roof, comm)
     A.free()
+    if rank == 0 and not getattr(args, 'no_api', False):
+        # reference spelling: P = PauliwordOp.random(n, N); P * P   (base.py:821 -> :764 -> utils.py:230)
+        out['api'] = guarded(lambda: api_block('P * P', lambda: host_operator(N, n, 1237), lambda P: P * P, lambda R: (R.packed, R.coeff_vec), 5,
+                                               dt / args.steps, note='b reads the result as packed rows + coefficients (6.8 GB); its symp_matrix '
+                                               'would be 50 GB of bools'))
     if rank == 0 and not args.no_cpu:
         out['cpu_baseline'] = guarded(lambda: cpu_mul_cleanup(n))
     return out
@@ -453,6 +461,17 @@ def wl_rotation(args, comm, rank, world, _lib, DeviceOp, parallel):
             return res
         out['clifford'] = guarded(clifford)
     P.free()
+    if rank == 0 and not getattr(args, 'no_api', False):
+        from symmer_amd import PauliwordOp
+        Qs = [PauliwordOp(packing.unpack_rows(q.reshape(1, -1), n), [1]) for q in qs]
+        out['api'] = guarded(lambda: api_block('P._rotate_by_single_Pword(Q, 0.3)', lambda: host_operator(N, n, 1236),
+                                               lambda Pa: Pa._rotate_by_single_Pword(Qs[0], 0.3), lambda R: (R.packed, R.coeff_vec), 20,
+                                               dt / (args.steps * ROT)))
+        out['api_perform_rotations'] = guarded(lambda: api_block('P.perform_rotations([(Q_k, pi/2)] * 100)', lambda: host_operator(N, n, 1236),
+                                                                 lambda Pa: Pa.perform_rotations([(Qs[k % 8], np.pi / 2) for k in range(100)]),
+                                                                 lambda R: (R.packed, R.coeff_vec), 5, None,
+                                                                 note='100 Clifford rotations in one call (a chain of 100 non-Clifford rotations by random Paulis '
+                                                                      'grows the operator 1.5x per step)'))
     if rank == 0 and not args.no_cpu:
         out['cpu_baseline'] = guarded(lambda: cpu_rotation(n, N))
     return out
@@ -521,9 +540,17 @@ def wl_gf2(args, comm, rank, world, _lib, DeviceOp, parallel):
                         {'workload': 'symmetry_generators_gf2', 'n_qubits': 2000, 'terms': 50000, 'matrix': [4000, 54000], 'row_xors_per_step': nx.value,
                          'generators_found': k.value, 'call': 'IndependentOp.symmetry_generators (symgpu_symmetry_kernel_dev)',
                          'parallelism': f'{world} independent replicas' if world > 1 else 'single GPU'}, roof, comm)
+    if rank == 0 and not getattr(args, 'no_api', False):
+        from symmer_amd import PauliwordOp, IndependentOp
+
+        def make():
+            return PauliwordOp(H.download_bool(2000), H.download_coeff())
+        out['api'] = guarded(lambda: api_block('IndependentOp.symmetry_generators(H, commuting_override=True)', make,
+                                               lambda Ha: IndependentOp.symmetry_generators(Ha, commuting_override=True),
+                                               lambda G: (G.symp_matrix, G.coeff_vec), 5, dt / args.steps))
     H.free()
     if rank == 0 and not args.no_cpu:
-        out['cpu_baseline'] = guarded(cpu_gf2)
+        out['cpu_baseline'] = guarded(lambda: cpu_gf2(getattr(args, 'cpu_full', False)))
     return out
 
 
@@ -532,6 +559,45 @@ def guarded(fn):
         return fn()
     except Exception as exc:                                      # noqa: BLE001 - reported in the JSON line
         return {'error': f'{type(exc).__name__}: {exc}'}
+
+
+# ---- `api`: the reference's own call spelling (SURVEY 8d "API call timed per config") on the drop-in classes -----------------------
+def host_operator(n_terms, n_qubits, seed):
+    """A caller's operator as the reference holds it: NumPy arrays in the reference layout (bool [T, 2n], complex128 [T]) handed to the
+    constructor.  The bits come from the library's device generator and are brought to the host (np.random.choice, which
+    PauliwordOp.random uses, needs 40 s for cfg2's 2e8 bits); nothing of the operator is on the device when this returns."""
+    from symmer_amd import PauliwordOp
+    from symmer_amd.kernels import DeviceOp
+    d = DeviceOp.random(n_terms, n_qubits, 0.3, seed=seed)
+    symp, coeff = d.download_bool(n_qubits), d.download_coeff()
+    d.free()
+    return PauliwordOp(symp, coeff)
+
+
+def api_block(spelling, make, call, fetch, reps, c_abi_seconds, note=None):
+    """first_call: fresh host operands -> result object (includes their one-time upload; operands of 1 MiB and more go up in the
+    reference layout and are packed by a device kernel).  (a) steady state, operands resident (they stay resident behind the drop-in
+    classes): host objects in -> result object out, the result left on the device.  (b) = (a) + the result's host arrays read."""
+    from symmer_amd import kernels
+    pc = time.perf_counter
+    obj = make()
+    t0 = pc(); r = call(obj); kernels.sync(); first = pc() - t0
+    del r
+    ta, tb = [], []
+    for _ in range(reps):                                             # (a) and (b) in loops of their own: a 40 MB read-back between two 30 us
+        t0 = pc(); r = call(obj); kernels.sync(); ta.append(pc() - t0)  # calls leaves the GPU idle for milliseconds, and the next call pays for it
+        del r
+    for _ in range(reps):
+        t0 = pc(); r = call(obj); fetch(r); tb.append(pc() - t0)
+        del r
+    med = lambda v: sorted(v)[len(v) // 2]
+    out = {'call': spelling, 'first_call_seconds': first, 'a_result_object_seconds': med(ta), 'b_host_arrays_out_seconds': med(tb),
+           'c_abi_seconds': c_abi_seconds, 'a_over_c_abi': med(ta) / c_abi_seconds if c_abi_seconds else None, 'reps': reps,
+           'legend': 'first_call: fresh host arrays in (upload included); a: operands resident, result object out (left on the GPU); '
+                     'b: a + result host arrays out; c_abi: the device-resident C-ABI step of this line'}
+    if note:
+        out['note'] = note
+    return out
 
 
 def cpu_mul_cleanup(n):
@@ -555,12 +621,18 @@ def cpu_rotation(n, N):
             'sample': f'one rotation of {N} terms on {n} qubits at full size, NumPy restatement of base.py:1090-1161 (commutes -> split -> multiply -> cleanups)'}
 
 
-def cpu_gf2():
+def cpu_gf2(full=False):
     """cfg4: the row-XOR rate of the reference's loop depends on the row length and the row count, so SURVEY 8d asks for the full
-    4000 x 54000 matrix (~10 minutes).  The full-size figure is measured once by tools/cpu_cfg4_full.py and cached in
-    profiles/r03_cpu_cfg4_full.json (labelled with host and date); the live leg is a bounded sample with the full row LENGTH."""
+    4000 x 54000 matrix (72 s on the box's EPYC 9575F).  The default leg is a bounded sample with the full row LENGTH and cites the
+    full-size run of tools/cpu_cfg4_full.py cached in profiles/r03_cpu_cfg4_full.json (labelled with host and date); `--cpu-full`
+    times the full matrix in this run instead."""
     from oracle import oracle_np as onp
     rng = np.random.default_rng(1234)
+    if full:
+        M4 = rng.random((4000, 54000)) < 0.5
+        t0 = time.perf_counter(); _, nx = onp.rref_noswap(M4, count_xors=True); t = time.perf_counter() - t0
+        return {'value': nx / t, 'unit': 'row-XORs/s', 'cores': 1, 'kind': 'port', 'cpu_model': cpu_model(), 'host_cores': os.cpu_count(), 'seconds': t,
+                'sample': f'_rref_binary of the full 4000 x 54000 matrix ({int(nx)} row-XORs), NumPy restatement of utils.py:292-315, timed in this run'}
     M4 = rng.random((384, 54000)) < 0.5
     t0 = time.perf_counter(); _, nx = onp.rref_noswap(M4, count_xors=True); t = time.perf_counter() - t0
     out = {'value': nx / t, 'unit': 'row-XORs/s', 'cores': 1, 'kind': 'port', 'cpu_model': cpu_model(), 'host_cores': os.cpu_count(), 'seconds': t,
@@ -648,7 +720,48 @@ def adjacency(args, comm, rank, world, _lib, DeviceOp, parallel):
         out['degraded'] = comm.degraded
     for p in ring:
         _lib.check(lib.symgpu_dev_free(p))
+    traffic_from_profile(out['roofline'], f'{PROFILE_TAG}_adjacency_traffic.json', ['commute_m4r.hip'], {'workload': 'adjacency', 'n_qubits': n, 'terms': T})
+    if rank == 0 and world == 1 and not getattr(args, 'no_api', False):
+        out['api'] = guarded(lambda: api_adjacency(n, T, dt / args.steps))
+    if rank == 0 and not args.no_cpu:
+        out['cpu_baseline'] = guarded(lambda: cpu_adjacency(n))
     return out
+
+
+def api_adjacency(n, T, c_abi_seconds):
+    """`P.commutes_termwise(P)` (base.py:938-971) returns a NumPy bool [T, T]: 40 GB of host memory at cfg5, written by one D2H copy
+    behind the 40 ms kernel.  Timed at full size when the host has the memory for it, and always on one rank's 25,000-row share."""
+    avail = 0
+    try:
+        with open('/proc/meminfo') as f:
+            for line in f:
+                if line.startswith('MemAvailable'):
+                    avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    P = host_operator(T, n, 555)
+    res = {}
+    rows = min(25000, T)
+    Ps = P[:rows]
+    res['rank_share'] = api_block(f'Ps = P[:{rows}]; Ps.commutes_termwise(P)', lambda: (Ps, P), lambda ops: ops[0].commutes_termwise(ops[1]), lambda C: C, 3,
+                                  c_abi_seconds * rows / T, note='the result IS a host array: a = b; c_abi scaled to the share')
+    if avail > 3 * T * T:
+        res['full'] = api_block('P.commutes_termwise(P)', lambda: P, lambda Pa: Pa.commutes_termwise(Pa), lambda C: C, 2, c_abi_seconds,
+                                note=f'{T * T / 1e9:.0f} GB np.bool_ result on the host (MemAvailable {avail / 1e9:.0f} GB): a = b')
+    else:
+        res['full'] = {'skipped': f'host MemAvailable {avail / 1e9:.0f} GB < 3 x the {T * T / 1e9:.0f} GB result'}
+    return res
+
+
+def cpu_adjacency(n):
+    """cfg5 cannot be materialised by the reference algorithm (320 GB of float64 temporaries): a 2,000 x 20,000 block of the 2,000-qubit
+    commutation table, float64 dot % 2 as the reference (utils.py:63-78)."""
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(1234)
+    C5 = rng.random((20000, 2 * n)) < 0.3
+    t0 = time.perf_counter(); onp.commutes_termwise(C5[:2000], C5); t = time.perf_counter() - t0
+    return {'value': 4e7 / t, 'unit': 'pairs/s', 'cores': 'BLAS default threads', 'kind': 'port', 'cpu_model': cpu_model(), 'host_cores': os.cpu_count(), 'seconds': t,
+            'sample': f'P[:2000].commutes_termwise(P) of a 20,000-term, {n}-qubit operator (4e7 pairs), NumPy restatement of base.py:938-971 (float64 dot % 2)'}
 
 
 def timed(fn, reps):
@@ -681,7 +794,7 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
 
     def workload_line(fn, steps, warmup=1, **kw):
         a = types.SimpleNamespace(steps=steps, warmup=warmup, qubits=1000, no_cpu=True, no_extras=True, adj_terms=200000, adj_qubits=2000,
-                                  adj_slab_rows=0, gpus=1)
+                                  adj_slab_rows=0, gpus=1, no_api=getattr(args, 'no_api', False), cpu_full=False)
         for k, v in kw.items():
             setattr(a, k, v)
         return fn(a, comm, 0, 1, _lib, DeviceOp, parallel)
@@ -734,26 +847,26 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
         # the reference's own CPU-runnable case through the drop-in API, host buffers in / host result out
         rng1 = np.random.default_rng(1235)
         P1 = PauliwordOp(rng1.random((500, 200)) < 0.3, rng1.standard_normal(500) + 1j * rng1.standard_normal(500))
+        symp1, c1 = P1.symp_matrix, P1.coeff_vec.copy()
         for _ in range(4):                                          # the first calls of a process load the code objects of a dozen kernels
-            P1._packed_cache = None
-            (P1 * P1)
+            (PauliwordOp(symp1, c1.copy()) * PauliwordOp(symp1, c1.copy()))
         ts = []
         for _ in range(5):
-            P1._packed_cache = None
             t0 = time.perf_counter()
-            R1 = P1 * P1
+            Pf = PauliwordOp(symp1, c1.copy())                      # a fresh operand every time: pack + upload + product/cleanup + download
+            R1 = Pf * Pf
+            rows_out, coeff_out = R1.symp_matrix, R1.coeff_vec
             ts.append(time.perf_counter() - t0)
         t = sorted(ts)[2]                                            # median of five: a sub-millisecond call through Python catches the odd GC pause
-        if os.environ.get('BENCH_DEBUG_CFG1'):
-            print('cfg1 per call ms:', ' '.join(f'{x * 1e3:.2f}' for x in ts), file=sys.stderr, flush=True)
-        ex['cfg1_api_mul'] = {'call': 'PauliwordOp * PauliwordOp (pack + upload + fused product/cleanup + download; median of 5 calls)', 'pairs': 250000,
-                              'seconds': t, 'pairs_per_s': 250000 / t, 'terms_out': R1.n_terms}
+        ex['cfg1_api_mul'] = {'call': 'P = PauliwordOp(symp, coeff); R = P * P; R.symp_matrix, R.coeff_vec (fresh host arrays in, host arrays out; median of 5)', 'pairs': 250000,
+                              'seconds': t, 'pairs_per_s': 250000 / t, 'terms_out': R1.n_terms,
+                              'api': api_block('P * P', lambda: PauliwordOp(symp1, c1.copy()), lambda P: P * P, lambda R: (R.symp_matrix, R.coeff_vec), 5, None)}
 
     def cfg3_mul_cleanup():
         # 1,000 qubits, 10,000 terms squared (1e8 pairs) + cleanup: the `--workload mul_cleanup` line, 20 steps
         line = workload_line(wl_mul_cleanup, 20, 3)
         ex['cfg3_mul_cleanup'] = {'pairs': 10**8, 'seconds': line['ms_per_step'] * 1e-3, 'pairs_per_s': line['value'], 'terms_out': line['config']['terms_out'],
-                                  'roofline': line['roofline'],
+                                  'roofline': line['roofline'], 'api': line.get('api'),
                                   'note': 'squared operator: keys for the pairs with i >= o only (cleanup.hip); roofline = the output stage, the one kernel of the '
                                           'step that moves the result\'s bytes (SURVEY 8d\'s T (16 Wq + 16) bytes of product rows never exist here)'}
 
@@ -781,7 +894,7 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
         P.free()
         ex['cfg2_rotation'] = {'terms_in': 100000, 'seconds_per_rotation': line['seconds_per_rotation'], 'term_pairs_per_s': line['value'],
                                'first_rotation_seconds': t1, 'first_rotation_note': 'through kernels.rotate_single_dev (Python wrapper + handle free per call), 20 calls back to back',
-                               'roofline': line['roofline'], 'chain4_seconds': t_chain, 'chain_terms': terms, 'clifford': line.get('clifford')}
+                               'roofline': line['roofline'], 'api': line.get('api'), 'api_perform_rotations': line.get('api_perform_rotations'), 'chain4_seconds': t_chain, 'chain_terms': terms, 'clifford': line.get('clifford')}
         # README claim 1 (a depth-2,000 Clifford circuit on 1,000 qubits "in one second"): 2,000 Clifford rotations of a 64-term,
         # 1,000-qubit observable through perform_rotations — one single-workgroup launch for the whole run (rotate.hip)
         rng_c = np.random.default_rng(1240)
@@ -812,7 +925,7 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
         col_tiles = (200000 // 64 + 31) // 32
         lds_bytes = nrow * n_kblocks * col_tiles * 256.0
         full_s = line['ms_per_step'] * 1e-3
-        ex['cfg5_adjacency'] = {'pairs': 200000 ** 2, 'seconds': full_s, 'pairs_per_s': line['value'], 'roofline': line['roofline'],
+        ex['cfg5_adjacency'] = {'pairs': 200000 ** 2, 'seconds': full_s, 'pairs_per_s': line['value'], 'roofline': line['roofline'], 'api': line.get('api'),
                                 'rank_share_25000_rows': {'pairs': pairs, 'seconds': t, 'pairs_per_s': pairs / t, 'kernel': 'k_commutes_m4r', 'kernel_seconds': kt,
                                                           'hbm_GBps_at_1B_per_pair': pairs / kt / 1e9 if kt else None,
                                                           'lds_read_frac_of_157TBps': lds_bytes / kt / 157.3e12 if kt else None,
@@ -823,7 +936,7 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
         # GF(2) symmetry kernel, 2,000 qubits x 50,000 terms, 32 planted symmetries, Clifford-scrambled: the `--workload gf2` line, 10 steps
         line = workload_line(wl_gf2, 10, 2)
         ex['cfg4_symmetry_kernel'] = {'rows': 4000, 'cols': 54000, 'generators_found': line['config']['generators_found'], 'row_xors': line['config']['row_xors_per_step'],
-                                      'seconds': line['ms_per_step'] * 1e-3, 'row_xors_per_s': line['value'], 'roofline': line['roofline']}
+                                      'seconds': line['ms_per_step'] * 1e-3, 'row_xors_per_s': line['value'], 'roofline': line['roofline'], 'api': line.get('api')}
 
     def readme_claim1_clifford_circuit():
         # reference README.md:50-51: "expectation value of a 1,000-qubit Clifford circuit of depth 2,000" — CircuitSymmerlator: 2,000
@@ -857,14 +970,16 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
         # 8.3 s for the reference code in the survey container) — through the drop-in API, host arrays in and out
         rng3 = np.random.default_rng(1241)
         P3 = PauliwordOp(rng3.random((500, 2000)) < 0.3, rng3.standard_normal(500) + 1j * rng3.standard_normal(500))
+        symp3, c3 = P3.symp_matrix, P3.coeff_vec.copy()
         (P3 * P3)
         t0 = time.perf_counter()
         for _ in range(5):
-            P3._packed_cache = None
-            R3 = P3 * P3
+            Pf = PauliwordOp(symp3, c3.copy())
+            R3 = Pf * Pf
+            rows_out, coeff_out = R3.packed, R3.coeff_vec
         t = (time.perf_counter() - t0) / 5
         ex['readme_claim3_square_1000q_500t'] = {'pairs': 250000, 'seconds': t, 'pairs_per_s': 250000 / t, 'terms_out': R3.n_terms,
-                                                 'call': 'PauliwordOp * PauliwordOp (Python API: pack + upload + fused product/cleanup + download)'}
+                                                 'call': 'P = PauliwordOp(symp, coeff); R = P * P; R.packed, R.coeff_vec (fresh host arrays in, packed host arrays out)'}
 
     def readme_claim4_wide_product():
         # reference README.md:54: "multiply two 100,000,000-qubit Pauli terms" (in one second on a laptop).  Through the drop-in API:
@@ -875,11 +990,11 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
         bits = lambda: np.unpackbits(rngw.integers(0, 256, 2 * nq // 8, dtype=np.uint8)).astype(bool).reshape(1, -1)
         A = PauliwordOp(bits(), [1.0]); B = PauliwordOp(bits(), [1.0])
         (A * B)
-        A._packed_cache = None; B._packed_cache = None
-        t0 = time.perf_counter(); R = A * B; t_all = time.perf_counter() - t0
-        t0 = time.perf_counter(); R = A * B; t_dev = time.perf_counter() - t0
+        A2 = PauliwordOp(A.symp_matrix, [1.0]); B2 = PauliwordOp(B.symp_matrix, [1.0])
+        t0 = time.perf_counter(); R = A2 * B2; row_out = R.packed; t_all = time.perf_counter() - t0
+        t0 = time.perf_counter(); R = A2 * B2; kernels.sync(); t_dev = time.perf_counter() - t0
         ex['readme_claim4_wide_product'] = {'n_qubits': nq, 'terms': '1 x 1', 'seconds_host_bool_arrays_in': t_all,
-                                            'seconds_operands_already_packed': t_dev, 'terms_out': R.n_terms,
+                                            'seconds_operands_resident': t_dev, 'terms_out': R.n_terms,
                                             'call': 'PauliwordOp * PauliwordOp (Python API)'}
 
     for fn in (strong_scaling_shard, cfg1_api_mul, cfg3_mul_cleanup, cfg2_rotation, cfg5_adjacency, cfg4_symmetry_kernel, readme_claim1_clifford_circuit, readme_claim3_square_1000q_500t, readme_claim4_wide_product):

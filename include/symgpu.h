@@ -64,7 +64,11 @@ int symgpu_prof_read(int kernel_class, int64_t *n_launches, double *total_ms);
  * The drop-in classes keep their operands on the device between calls; the tests assert through 7-10 that a multi-step workflow
  * (symmer/projection/base.py:44-124, rotate -> project -> cleanup) moves its operator once in and once out. */
 int symgpu_debug_counter(int which, int64_t *value);
-/* tuning aid: with SYMGPU_RES_TRACE=1 every workgroup of the one-launch rotation kernel stamps the 100 MHz wall clock at its phase
+/* Fast paths that gave up in this process and were replaced by a slower, equally exact form — the one-launch rotation, the one-launch
+ * radix sort, the fused selector launch of the GF(2) elimination: their in-kernel waits assume co-resident workgroups and are bounded, so
+ * a shared or partitioned GPU turns them off.  Each is announced once on stderr; this returns the list ("" = nothing degraded). */
+int symgpu_degraded(char *buf, int len);
+/* tuning aid (library built with `make TUNING=1`): with SYMGPU_RES_TRACE=1 every workgroup of the one-launch rotation kernel stamps the 100 MHz wall clock at its phase
  * boundaries; this copies the stamps of the last traced launch, 16 words per workgroup */
 int symgpu_debug_rotation_trace(uint64_t *out, int max_workgroups, int *n_workgroups);
 
@@ -184,9 +188,10 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
 /* perform_rotations (base.py:1163-1186) on a device-resident operator in ONE call: rotations r = 0 .. K-1 (q_rows[r][2*Wq], cos_t[r], sin_t[r],
  * ks[r] = clifford_k as for symgpu_rotate_single_dev) applied in order, each followed by the reference's cleanup() — which is the identity once the
  * operator is clean (`clean` != 0 on entry says it already is), so it runs once; runs of Clifford rotations of a clean operator go through the chain
- * entry point.  acted[r] (may be NULL; zeroed by the caller) is set where a single rotation changed the operator.  Returns early with *n_done < K when
- * the operator has lost all its terms after rotation *n_done - 1 (the reference then alternates between 0 * I and the empty operator, which the
- * caller reproduces).  *out = NULL: nothing changed, keep using `in` (which is never freed here). */
+ * entry point.  acted[r] (may be NULL; zeroed by the caller) is set where a single rotation changed the operator.  The call always processes all K
+ * rotations (*n_done == K on success): an operator that loses all its terms is taken through the reference's alternation between "no terms" and
+ * 0 * I (cleanup() of an empty operator, base.py:631-632, utils.py:275-278) INSIDE the call — the caller must not apply it again — and *clean_out
+ * reflects the state after the last rotation.  *out = NULL: nothing changed, keep using `in` (which is never freed here). */
 int symgpu_perform_rotations_dev(symgpu_op_t in, const uint64_t *q_rows_host, const double *cos_t, const double *sin_t, const int *ks_host, int64_t K,
                                  double thr, int clean, symgpu_op_t *out, uint8_t *acted, int64_t *n_done, int *clean_out);
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     'symgpu_prof_read': [c_int, P, P],
     'symgpu_debug_counter': [c_int, P],
     'symgpu_debug_rotation_trace': [P, c_int, P],
+    'symgpu_degraded': [P, c_int],
     'symgpu_membw_probe': [c_i64, P, P],
     'symgpu_op_upload': [P, P, c_i64, c_int, PP],
     'symgpu_op_alloc': [c_i64, c_int, c_int, PP],
@@ -134,6 +135,14 @@ def last_error():
 def check(rc):
     if rc != OK:
         raise SymgpuError(rc, last_error())
+
+
+def degraded():
+    """Fast paths the library has switched off in this process (in-kernel wait timed out / attribute refused), as a list of sentences."""
+    buf = ctypes.create_string_buffer(2048)
+    check(load().symgpu_degraded(ctypes.addressof(buf), 2048))
+    text = buf.value.decode('utf-8', 'replace')
+    return [t for t in text.split('; ') if t]
 
 
 def device_count():

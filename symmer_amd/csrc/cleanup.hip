@@ -864,7 +864,7 @@ __global__ void k_popc_words(const u32 *__restrict__ bits, i64 n_words, u32 *__r
 // it is read (3.8 TB/s).  A batch's list is 32 MB at most, written by one kernel and read by the next.
 // TRI (PAIR only): the index space is the compacted slot order of a squared operator (tri_slot / tri_pair).
 static i64 emit_batch_words() {                                  // SYMGPU_EMIT_BATCH = log2(bitmap words per batch), default 17 (4M indices)
-    const i64 w = [] { const char *e = getenv("SYMGPU_EMIT_BATCH"); const int l = e ? atoi(e) : 17; return (i64)1 << (l >= 6 && l <= 26 ? l : 17); }();
+    const i64 w = [] { const char *e = SG_TUNE("SYMGPU_EMIT_BATCH"); const int l = e ? atoi(e) : 17; return (i64)1 << (l >= 6 && l <= 26 ? l : 17); }();
     return w;
 }
 // where k_emit_meta takes a kept term's coefficient from: mode 0 = the filed sums only; 1 / 2 = filed sums for patched terms, the
@@ -1188,11 +1188,11 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
         if (fused) {
             const i64 n_w64 = (T + 63) / 64;
             // wavefront shape: bitmap words per wavefront x 64-chunk steps in flight (SYMGPU_EMIT_SHAPE = "NW,U": experiments)
-            static const int shape = [] { const char *e = getenv("SYMGPU_EMIT_SHAPE"); int nw = 2, u = 4; if (e) sscanf(e, "%d,%d", &nw, &u); return nw * 16 + u; }();
+            static const int shape = [] { const char *e = SG_TUNE("SYMGPU_EMIT_SHAPE"); int nw = 2, u = 4; if (e) sscanf(e, "%d,%d", &nw, &u); return nw * 16 + u; }();
             const int NWs = shape / 16, Us = shape % 16;
             const int NWr = (NWs == 1 || NWs == 4 || NWs == 8) ? NWs : 2;   // 2 words per wavefront, 4 steps in flight: 1.20 ms at cfg3 (4,4: 1.30; 1,4: 1.24; 2,8: 1.22)
             const dim3 gfu((unsigned)((n_w64 + 4 * NWr - 1) / (4 * NWr)));
-            static const bool touch_on = [] { const char *e = getenv("SYMGPU_EMIT_TOUCH"); return !(e && e[0] == '0'); }();
+            static const bool touch_on = [] { const char *e = SG_TUNE("SYMGPU_EMIT_TOUCH"); return !(e && e[0] == '0'); }();
             if (touch_on) {
                 const i64 n16 = n_w64 / 2;                              // whole 16-byte chunks of a T-bit map
                 const void *maps[5] = {markbits_p, wordprefix.p, lz.mode ? (const void *)lz.patchbits : nullptr, lz.mode == 1 ? (const void *)lz.e_lo : nullptr,
@@ -1213,7 +1213,7 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
 #undef LAUNCH_FUSED_U
 #undef LAUNCH_FUSED
         } else {
-        const int rc_env = [] { const char *e = getenv("SYMGPU_EMIT_RC"); return e ? atoi(e) : 2; }();     // chunks per lane: 1: 115, 2: 97, 4: 97 us per batch
+        const int rc_env = [] { const char *e = SG_TUNE("SYMGPU_EMIT_RC"); return e ? atoi(e) : 2; }();     // chunks per lane: 1: 115, 2: 97, 4: 97 us per batch
         const int RCs = rc_env == 1 || rc_env == 4 ? rc_env : 2;
         const i64 EMIT_BATCH_WORDS = emit_batch_words();
         const i64 bw = n_words < EMIT_BATCH_WORDS ? n_words : EMIT_BATCH_WORDS;
@@ -1484,7 +1484,9 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 const int n_pass = (nbits + 7) / 8;
                 int lgk = 0;
                 while (((i64)1 << lgk) < Tk) ++lgk;
+                // SYMGPU_CLEANUP_SUSPECTS: 0 = complete sort of all keys; 2 = tests: behave as if most keys were flagged (the last pass is finished on the whole array)
                 const bool sus_env = [] { const char *e = getenv("SYMGPU_CLEANUP_SUSPECTS"); return !(e && e[0] == '0'); }();
+                const bool sus_giveup = [] { const char *e = getenv("SYMGPU_CLEANUP_SUSPECTS"); return e && e[0] == '2'; }();
                 const bool sus_try = lazy_a && sus_env && n_pass >= 2 && n_pass <= 5 && nbits >= 32 && lgk <= 8 * (n_pass - 1) + 2 && !(inner == outer && !squared);
                 if (!sus_try) {
                     SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp, first_hist));
@@ -1506,7 +1508,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     u32 h_sus = 0;
                     HIP_TRY(hipMemcpyAsync(&h_sus, sustotal.p, 4, hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipStreamSynchronize(st));
-                    if ((i64)h_sus * 16 > Tk || getenv("SYMGPU_CLEANUP_SUSPECTS_GIVEUP")) {
+                    if ((i64)h_sus * 16 > Tk || sus_giveup) {
                         // repeated rows all over: the last pass on the whole array after all (LSD: the order so far is its first passes)
                         bool in_tmp2 = false;
                         SG_TRY(radix_sort_keys_u64(part, spare, Tk, hi, 64, &in_tmp2));
@@ -1595,7 +1597,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             // the wave cycles issue, 53 % wait on memory), so it wants many short waves rather than few long ones: cfg3 6.39 / 6.16 /
             // 6.10 / 6.04 ms at 2^15 / 2^17 / 2^19 / 2^21 wavefronts (a wave also decodes the chunk after its range to close the
             // segment it carries, so one chunk per wave reads the keys twice — still the fastest).
-            const i64 HS_WAVES = [] { const char *e = getenv("SYMGPU_HS_WAVES"); return e ? atoll(e) : (i64)1 << 21; }();
+            const i64 HS_WAVES = [] { const char *e = SG_TUNE("SYMGPU_HS_WAVES"); return e ? atoll(e) : (i64)1 << 21; }();
             const i64 cpw = (n_chunks + HS_WAVES - 1) / HS_WAVES;     // <= HS_WAVES wavefronts, each on a contiguous range of chunks
             const i64 n_waves = (n_chunks + cpw - 1) / cpw;
             const dim3 gs((unsigned)((n_waves + 3) / 4));
@@ -1620,7 +1622,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             else HIP_TRY(hipMemsetAsync(markbits.p, 0, (size_t)((space + 31) / 32) * 4, st));
             u32 *patch_p = lazy_now ? patchbits.as<u32>() : nullptr;
             const u32 *zero_len_p = nullptr;
-            const bool zero_on = [] { const char *e = getenv("SYMGPU_CLEANUP_ZEROSEG"); return !(e && e[0] == '0'); }();
+            const bool zero_on = [] { const char *e = SG_TUNE("SYMGPU_CLEANUP_ZEROSEG"); return !(e && e[0] == '0'); }();
             if (squared && packed && zero_on) {
                 // the identity segment (the N diagonal pairs and whatever else multiplies to the identity) in parallel, see k_zero_partial
                 const i64 n_zb = (Tsort + ZB - 1) / ZB;
@@ -1682,7 +1684,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
     }
     const bool tri = squared && packed;
     LazyEmit lz;
-    lz.no_one_outer = getenv("SYMGPU_EMIT_NO_ONE_OUTER") ? 1 : 0;
+    lz.no_one_outer = SG_TUNE("SYMGPU_EMIT_NO_ONE_OUTER") ? 1 : 0;
     if (lazy_final) {
         lz.mode = packed ? 1 : 2; lz.squared = tri ? 1 : 0;
         lz.patchbits = patchbits.as<u32>(); lz.e_lo = e_lo.as<u32>(); lz.e_hi = e_hi.as<u32>();

@@ -38,6 +38,16 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 #define KERNEL_CHECK() HIP_TRY(hipGetLastError())
 
+// Environment switches.  The RUNTIME switches (one table: DESIGN.md, "Environment switches") are read with getenv where they act, on every
+// call: each selects a path the library also takes by itself (a size limit, a refused attribute, a time-out), so that the tests can force it
+// on inputs of any size.  Everything else — tuning knobs and variants that were measured slower — is compiled out of the default build:
+// `make TUNING=1` (-DSYMGPU_TUNING) makes SG_TUNE read the environment again.
+#ifdef SYMGPU_TUNING
+#define SG_TUNE(name) getenv(name)
+#else
+#define SG_TUNE(name) (static_cast<const char *>(nullptr))
+#endif
+
 // ---- context ---------------------------------------------------------------------------------
 struct Context {
     bool ready = false;
@@ -79,6 +89,9 @@ extern i64 g_counters[16];                 // debug counters (symgpu_debug_count
 inline void count_h2d(size_t bytes) { g_counters[7] += (i64)bytes; }
 inline void count_d2h(size_t bytes) { g_counters[8] += (i64)bytes; }
 int require_ctx();
+// A fast path gave up in this process (an in-kernel wait timed out because the workgroups were not co-resident — a shared or partitioned
+// GPU —, or the runtime refused an LDS attribute) and a slower form has taken over: said ONCE on stderr and kept for symgpu_degraded().
+void note_degraded(const char *what);
 
 // per-launch event timing of one kernel class (bench.py roofline leg)
 struct ProfScope {

@@ -418,7 +418,7 @@ int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *
     KERNEL_CHECK();
     // np.bool_ output: expanded by the kernel's own epilogue when rows can be written with aligned 16-byte stores, otherwise
     // bit-packed rows to scratch + a separate expansion with byte stores
-    const bool fused_bytes = out && (M % 16 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && !getenv("SYMGPU_M4R_UNFUSED");
+    const bool fused_bytes = out && (M % 16 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && !SG_TUNE("SYMGPU_M4R_UNFUSED");
     void *dst = out_bits;
     i64 stride = Mw;
     if (fused_bytes) {

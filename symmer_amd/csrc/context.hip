@@ -32,6 +32,16 @@ static Context g_ctx;
 i64 g_counters[16] = {0};   // symgpu_debug_counter 1..10 (0 is g_hash_reseeds, cleanup.hip)
 Context &ctx() { return g_ctx; }
 
+static std::mutex g_deg_mu;
+static std::string g_degraded;
+void note_degraded(const char *what) {
+    std::lock_guard<std::mutex> lk(g_deg_mu);
+    if (g_degraded.find(what) != std::string::npos) return;
+    if (!g_degraded.empty()) g_degraded += "; ";
+    g_degraded += what;
+    fprintf(stderr, "symgpu: warning: %s (results are unaffected; symgpu_degraded() lists what was switched off)\n", what);
+}
+
 int require_ctx() {
     if (!g_ctx.ready) {
         set_error("symgpu_init() has not been called (or no HIP device)");
@@ -437,7 +447,7 @@ int symgpu_init(int device) {
         size_t f = 0, t = 0;
         if (hipMemGetInfo(&f, &t) == hipSuccess && t / 2 > g_cache_limit) g_cache_limit = t / 2;
     }
-    if (const char *e = getenv("SYMGPU_ARENA")) g_arena_on = !(e[0] == '0');       // 0: every size class straight from hipMalloc (round 2's allocator)
+    if (const char *e = SG_TUNE("SYMGPU_ARENA")) g_arena_on = !(e[0] == '0');       // 0: every size class straight from hipMalloc (round 2's allocator)
     c.ready = true;
     return SYMGPU_OK;
 }
@@ -556,6 +566,13 @@ int symgpu_prof_enable(int kernel_class, int on) {
 int symgpu_debug_counter(int which, int64_t *value) {
     SG_REQUIRE(value && which >= 0 && which <= 10, "debug_counter: 0 = row-hash reseeds, 1 = rotations done by the one-launch kernel, 2 = its failures (verification / time-out), 3 = device allocations that went to hipMalloc, 4-6 = host nanoseconds of the one-launch rotation (preparation, launch call, wait), 7 / 8 = payload bytes host -> device / device -> host, 9 / 10 = operator uploads / downloads");
     *value = which == 0 ? g_hash_reseeds : g_counters[which];
+    return SYMGPU_OK;
+}
+
+int symgpu_degraded(char *buf, int len) {
+    if (!buf || len <= 0) return SYMGPU_E_INVALID;
+    std::lock_guard<std::mutex> lk(g_deg_mu);
+    snprintf(buf, (size_t)len, "%s", g_degraded.c_str());
     return SYMGPU_OK;
 }
 

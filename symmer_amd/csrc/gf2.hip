@@ -32,7 +32,6 @@ namespace symgpu {
 constexpr int WK = 64;        // max rows per block = lanes of the panel wave
 constexpr int WN = 4;         // window width in 64-bit words
 constexpr int NOLEAD = 0x7fffffff;
-constexpr int SPEC_W = 8;     // words of the closed-column frontier (k_gf2_spec)
 
 struct BlockInfo {
     i64 i0;                   // first row of the block
@@ -648,610 +647,6 @@ __global__ __launch_bounds__(M4_NT) void k_sweep_m4r(u64 *__restrict__ rows, i64
     }
 }
 
-// ---- ONE launch per block (round 4) --------------------------------------------------------------------------------------------------
-// Launch A of the two-launch schedule (selectors of every row for the block just panelled, update of the next block's 64 rows, their
-// leading words, snapshot of the block's old rows) only exists because the selectors of a row must be read before ANY column tile of that
-// row is updated.  Here it becomes the TAIL of the launch that panels the block: workgroup 0 panels block k+1 while the tile workgroups sweep
-// block k over all other rows (as phase 1); then every tile workgroup arrives at a counter, waits until all of them and the panel have
-// (everything block k writes is in memory, the pivots of block k+1 are known, nobody writes a row any more), and the tail runs:
-//   1. selectors of ALL rows for block k+1 — one wavefront per row, the rows shared out over the tile workgroups (sel[] is rewritten: its old
-//      contents were consumed before the counter);
-//   2. the n_tiles workgroups of chunk 0: selectors of the 64 rows after block k+1 once more into LDS (they are about to overwrite the pivot words
-//      they are read from: a second, small counter separates every workgroup's reads from everybody's writes), tables of block k+1 from
-//      its rows (written out as the snapshot the next launch builds its tables from), update of those 64 rows, their leading words.
-// The next launch starts exactly where launch B of the two-launch schedule starts.  Two in-launch waits, both bounded; a time-out raises the
-// same flag as launch A's and rref_dev restores the matrix and falls back to separate launches.  Slower than the two launches it replaces
-// (see rref_dev_impl): kept behind SYMGPU_GF2_MERGED=1.
-struct MergedSync { u32 *ctr; u32 epoch; u32 n_wg; };                  // ctr[0]: tile workgroups past their sweep, ctr[1]: panel done (epoch), ctr[2]: chunk-0 workgroups past their selector reads
-typedef int32_t i32;
-__device__ __forceinline__ bool merged_wait(const u32 *p, u32 target, bool at_least) {
-    for (u32 spins = 0;; ++spins) {
-        const u32 v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (at_least ? (i32)(v - target) >= 0 : v == target) return true;
-        if (spins >= (1u << 22)) return false;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-__global__ __launch_bounds__(M4_NT) void k_gf2_merged(u64 *__restrict__ rows, i64 R, i64 Wc, const BlockInfo *__restrict__ info, u64 *__restrict__ sel,
-                                                       u64 *__restrict__ snap, int n_tiles, int n_chunks, BlockInfo *__restrict__ info_next,
-                                                       SweepState *__restrict__ st, i64 *__restrict__ pivots, unsigned long long *__restrict__ xor_count,
-                                                       int *__restrict__ lead, FusedSelect fs, MergedSync ms) {
-    extern __shared__ u64 tab[];                                    // [16 groups][16 entries][64 words]
-    __shared__ u64 s_sel[WK];
-    __shared__ int s_ok;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int kk = info->kk;
-    const i64 i0n = info->i0 + kk;                                  // first row of the next block
-    const i64 nb = i0n < R ? i0n : R, ne = i0n + WK < R ? i0n + WK : R;
-    if (blockIdx.x == 0) {
-        // ---- panel workgroup (as phase 1 of k_sweep_m4r) ----
-        int a = -1;
-        u64 spec[WN] = {0, 0, 0, 0};
-        const int w_spec = info->w_next;
-        if (wave == 0 && i0n + lane < R) {
-            a = lead[lane];
-            if (w_spec >= 0) {
-#pragma unroll
-                for (int k = 0; k < WN; ++k) spec[k] = (i64)w_spec + k < Wc ? rows[(i0n + lane) * Wc + w_spec + k] : 0ULL;
-            }
-        }
-        if (wave == 0) {
-            bool full = false;
-            if (fs.full_panel && Wc <= FULL_WC && i0n < R) {
-                const bool valid = a >= 0;
-                const u64 fin_m = __ballot(valid && a != NOLEAD);
-                if (fin_m != 0) {
-                    const int w_lo = window_start(a, valid, __builtin_ctzll(fin_m));
-                    const u64 bad = __ballot(valid && a != NOLEAD && !(a >= w_lo && a < w_lo + WN));
-                    const int n_valid = __popcll(__ballot(valid));
-                    full = bad != 0 && __builtin_ctzll(bad) < (n_valid < 32 ? n_valid : 32);
-                }
-            }
-            if (lane == 0) { s_ok = full ? 1 : 0; if (full) atomicAdd(fs.fail + 1, 1u); }
-            if (i0n + lane < R) lead[lane] = NOLEAD;
-        }
-        __syncthreads();
-        if (s_ok) {
-            if (wave != 0) a = 0;
-            panel_full(rows, R, Wc, i0n, a, tab, s_sel, st, info_next, pivots, xor_count);
-        } else if (wave == 0) panel_wave(rows, R, Wc, i0n, a, lane, st, info_next, pivots, xor_count, spec, w_spec, fs.lean_panel);
-        // publish: the block's info is in memory before the flag
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&ms.ctr[1], ms.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
-    const int k = blockIdx.x - 1;
-    const int tile = k % n_tiles, chunk = k / n_tiles;
-    const i64 w = (i64)tile * M4_TW + lane;
-    const bool live = w < Wc;
-    const i64 wl = live ? w : Wc - 1;
-    const i64 step = M4_U * (M4_NT / 64);
-    // one pass of "rows ^= table look-ups under their selectors" over the virtual rows [v_lo, v_hi): PRI = the 64 rows after the block
-    // (selectors from LDS, leading words recorded), otherwise all rows but those of [x_b, x_e) (selectors from sel[])
-    auto sweep_rows = [&](i64 v_lo, i64 v_hi, bool pri, i64 x_b, i64 x_e, bool have_table) {
-        i64 rn[M4_U];
-        u64 xn[M4_U], sn[M4_U];
-        const i64 shift = x_e - x_b;
-        auto fetch = [&](i64 v0) {
-#pragma unroll
-            for (int u = 0; u < M4_U; ++u) {
-                const i64 v = v0 + u < v_hi ? v0 + u : (v0 < v_hi ? v0 : v_lo);
-                rn[u] = pri ? x_b + v : (v < x_b ? v : v + shift);
-                sn[u] = have_table ? (pri ? s_sel[rn[u] - x_b] : sel[rn[u]]) : 0ULL;
-                xn[u] = rows[rn[u] * Wc + wl];
-            }
-        };
-        i64 v0 = v_lo + M4_U * wave;
-        if (v0 < v_hi) fetch(v0);
-        for (; v0 < v_hi; v0 += step) {
-            i64 r[M4_U];
-            u64 x[M4_U];
-            u32 slo[M4_U], shi[M4_U];
-#pragma unroll
-            for (int u = 0; u < M4_U; ++u) {
-                r[u] = rn[u]; x[u] = xn[u];
-                slo[u] = __builtin_amdgcn_readfirstlane((u32)sn[u]);
-                shi[u] = __builtin_amdgcn_readfirstlane((u32)(sn[u] >> 32));
-            }
-            if (v0 + step < v_hi) fetch(v0 + step);
-#pragma unroll
-            for (int u = 0; u < M4_U; ++u) {
-                const bool mine = (u == 0 || v0 + u < v_hi);
-                if ((slo[u] | shi[u]) != 0u) {
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        const u32 e = ((g < 8 ? slo[u] : shi[u]) >> (4 * (g & 7))) & 15u;
-                        x[u] ^= tab[(g * 16 + (int)e) * M4_TW + lane];
-                    }
-                    if (live && mine) rows[r[u] * Wc + w] = x[u];
-                }
-                if (pri && mine) {
-                    const u64 nz = __ballot(live && x[u] != 0);
-                    if (nz && lane == 0) atomicMin(&lead[r[u] - x_b], tile * M4_TW + (int)__builtin_ctzll(nz));
-                }
-            }
-        }
-    };
-    // tables of the XOR combinations of a block's old rows (src: the snapshot, or the rows themselves + snapshot written on the way)
-    auto build_table = [&](const u64 *src, i64 src_stride_rows_base, int kkb, u64 *snap_out) {
-        for (int g = wave; g < 16; g += M4_NT / 64) {
-            u64 sv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sv[i] = (4 * g + i < kkb) ? src[(src_stride_rows_base + 4 * g + i) * Wc + wl] : 0ULL;
-                if (snap_out && live && 4 * g + i < kkb) snap_out[(i64)(4 * g + i) * Wc + w] = sv[i];
-            }
-            u64 t[16];
-            t[0] = 0; t[1] = sv[0]; t[2] = sv[1]; t[3] = sv[0] ^ sv[1];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t[4 + e] = t[e] ^ sv[2];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t[8 + e] = t[e] ^ sv[3];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) tab[(g * 16 + e) * M4_TW + lane] = t[e];
-        }
-    };
-    // ---- the sweep of block k over all rows but the next block's (phase 1) ----
-    if (kk != 0) {
-        const i64 n_rows = R - (ne - nb);
-        const i64 per = (n_rows + n_chunks - 1) / n_chunks;
-        const i64 v_lo = (i64)chunk * per, v_hi = v_lo + per < n_rows ? v_lo + per : n_rows;
-        if (v_lo < v_hi) {
-            build_table(snap, 0, kk, nullptr);
-            __syncthreads();
-            sweep_rows(v_lo, v_hi, false, nb, ne, true);
-        }
-    }
-    // ---- everything this workgroup writes for block k is in memory; wait for the others and for the panel ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        atomicAdd(&ms.ctr[0], 1u);
-        bool ok = merged_wait(&ms.ctr[0], ms.epoch * ms.n_wg, true) && merged_wait(&ms.ctr[1], ms.epoch, false);
-        if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        else atomicOr(fs.fail, 1u);
-        s_ok = ok ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_ok) return;
-    // ---- tail 1: selectors of all rows for the block that was just panelled ----
-    const int kk2 = info_next->kk;
-    const i64 i02 = info_next->i0;
-    const int pw2 = info_next->pivw[lane], pb2 = info_next->pivb[lane];
-    const u64 mj2 = info_next->mask[lane] & ((1ULL << lane) - 1ULL);
-    const u64 T2 = info_next->T[lane];
-    const i64 nb2 = i02 + kk2 < R ? i02 + kk2 : R, ne2 = i02 + kk2 + WK < R ? i02 + kk2 + WK : R;
-    if (kk2 != 0) {
-        // (the 64 rows after the new block are left to tail 2: the chunk-0 workgroups overwrite their pivot words, and their selectors in
-        // sel[] are never read — the next launch's sweep skips those rows)
-        for (i64 r = (i64)k * (M4_NT / 64) + wave; r < R; r += (i64)ms.n_wg * (M4_NT / 64)) {
-            if (r >= nb2 && r < ne2) continue;                       // wave-uniform
-            const u64 g = select_row(rows, Wc, r, lane, i02, kk2, pw2, pb2, mj2, T2, fs.rowcnt);
-            if (lane == 0) sel[r] = g;
-        }
-    }
-    if (chunk != 0) return;
-    // ---- tail 2 (one workgroup per column tile): the 64 rows after the new block ----
-    if (kk2 != 0) {
-        for (i64 r = nb2 + wave; r < ne2; r += M4_NT / 64) {
-            const u64 g = select_row(rows, Wc, r, lane, i02, kk2, pw2, pb2, mj2, T2, tile == 0 ? fs.rowcnt : nullptr);   // counted once
-            if (lane == 0) s_sel[r - nb2] = g;
-        }
-    }
-    // every chunk-0 workgroup has READ the pivot words of those rows before any of them writes one
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&ms.ctr[2], 1u);
-        const bool ok = merged_wait(&ms.ctr[2], ms.epoch * (u32)n_tiles, true);
-        if (!ok) atomicOr(fs.fail, 1u);
-        s_ok = ok ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_ok || kk2 == 0) return;
-    build_table(rows, i02, kk2, snap);                              // + the snapshot the next launch builds its tables from
-    __syncthreads();
-    sweep_rows(0, ne2 - nb2, true, nb2, ne2, true);
-}
-
-// ---- ONE launch per block and NO in-launch wait (round 4): the column-window schedule ------------------------------------------------
-// What made launch A necessary: (1) the selector of a row must be read from the row's bits at the block's pivot columns before any column
-// tile of the row is rewritten, (2) the next block's panel needs that block's 64 rows up to date (window + leading words).  Both are
-// answered from a COLUMN WINDOW instead: every launch files, for ALL rows, the CWW words starting at the first word column that is not
-// closed yet (closed = each of its 64 columns is the pivot column of a panelled block, or certified dead) as they are after the launch's
-// update — twelve 8-byte stores per row from the tile workgroup that owns those words.  In the next launch
-//   * every tile workgroup computes the selectors of its rows itself from that window (the pivots of a block panelled from the window lie
-//     inside it by construction) — no selector launch, no sel[] array;
-//   * the panel workgroup forms the next block's 64 candidate rows AS THEY WILL BE after this launch's sweep on those twelve words
-//     (win_r = window_r ^ XOR_{j in g(r)} window_{old row j}): left of the window every unprocessed row is zero (closed columns), so a
-//     row's leading word is its first non-zero window word, and the panel runs at once — beside the sweep, as before;
-//   * the old block rows the tables are built from were filed by the previous launch as well (snap, the 64 candidate rows).
-// Rows the window says nothing about: a candidate no old row goes into (g = 0) is unchanged by this launch, and its true leading word was
-// filed by the previous one (leadkey: an atomic max per row and column tile over the 128 rows that can become candidates); a candidate
-// that changes and is zero on the window is UNKNOWN and ends the block in front of it.  A block that starts with a row that leads outside
-// the window (a "far" block: dependent rows lead in the identity columns) is panelled from the matrix itself — only unchanged rows can
-// belong to it — and because its pivot columns are not in the column window, the next launch is a SELECTOR launch (mode F1: sel[] of all
-// rows read from the matrix, nothing else) and the one after sweeps with sel[] (F2).  If even the first candidate is unknown, the next
-// launch sweeps nothing (IDLE) and panels from the matrix with everything known.  The launches are generic steps: what a step does is read
-// from a control block the previous step wrote (double buffered by launch parity), so the host just enqueues steps.
-// Hole columns (left behind the pivots, never to be led in: dependent on the closed ones) would pin the window: the tile workgroup that owns
-// the first unclosed word ORs, over all unprocessed rows, its bits that are not pivot columns yet; what stays zero is dead for good and
-// the next panel closes it.
-constexpr int CWW = 12;
-enum { SPEC_N = 0, SPEC_F1 = 1, SPEC_F2 = 2, SPEC_IDLE = 3, SPEC_DONE = 4 };
-struct SpecCtrl { u32 ep, mode, blk, pad; };                        // launch L reads ctrl[L & 1] and writes ctrl[(L + 1) & 1]
-struct SpecState {                                                  // data epoch e reads st[e & 1], its panel writes st[(e + 1) & 1]
-    i64 next_i0;                                                    // first row that is not a block row yet
-    int closed_base;                                                // word columns [0, closed_base) are closed; cm[k]: closed columns of word closed_base + k
-    int pad;
-    u64 cm[SPEC_W];
-};
-struct SpecShared {
-    SpecCtrl ctrl[2];
-    u32 broken;                                                     // != 0: handed back to the two-launch schedule (too many far blocks)
-    u32 n_far;
-    i64 handoff_i0;                                                 // first row that is not reduced (nothing is pending)
-    unsigned long long n_spec, n_idle;                              // statistics
-    u64 alive[2], alive_hm[2];                                      // per data parity: candidate hole columns (hm) and those seen set (alive)
-    int alive_w[2];                                                 //                  the word they belong to
-    int colbase[2];                                                 //                  first word of the column window the epoch files
-    u64 tstamp[16];                                                 // SYMGPU_GF2_DEBUG
-};
-struct SpecArgs {
-    SpecState *st;                                                  // [2]
-    SpecShared *sh;
-    BlockInfo *binfo;                                               // [2]
-    u64 *colwin;                                                    // [2][R][CWW]
-    u64 *snap;                                                      // [2][WK][Wc]
-    u64 *leadkey;                                                   // [R]: (epoch << 32) | (0xffffffff - leading word) where the epoch left the row non-zero
-    u64 *sel;                                                       // [R]: far blocks
-    u32 *rowcnt;
-    u32 launch;                                                     // from 1
-    int lean_panel;
-};
-// g = f * T without a cross-lane reduction: lane i holds column i of T (Tt), g_i = parity(f & Tt_i), g = ballot — a handful of VALU
-// instructions per row instead of twelve ds_bpermute
-__device__ __forceinline__ u64 transpose_T(u64 Tj, int lane) {
-    u64 tt = 0;
-#pragma unroll 8
-    for (int i = 0; i < 64; ++i) {
-        const u64 col = __ballot((Tj >> i) & 1ULL);
-        if (lane == i) tt = col;
-    }
-    return tt;
-}
-// selector of row r in terms of the old block rows from its pivot-column bit (lane j <-> pivot j); the row's share of the XOR count
-__device__ __forceinline__ u64 select_from_bit(bool bit, int lane, i64 r, i64 i0, int kk, u64 mj, u64 Tj, u64 Tt, u32 *__restrict__ rowcnt) {
-    if (r >= i0 && r < i0 + kk) return readlane64(Tj, (int)(r - i0)) ^ (1ULL << (r - i0));
-    const u64 f = __ballot(bit);
-    if (rowcnt) {
-        const bool tj = bit ^ (bool)(__popcll(f & mj) & 1);
-        const u64 t = __ballot(tj);
-        if (lane == 0) atomicAdd(&rowcnt[r], (u32)__popcll(t));
-    }
-    return __ballot(__popcll(f & Tt) & 1);
-}
-__global__ __launch_bounds__(M4_NT) void k_gf2_spec(u64 *__restrict__ rows, i64 R, i64 Wc, int n_tiles, int n_chunks, i64 *__restrict__ pivots,
-                                                     unsigned long long *__restrict__ xor_count, SpecArgs sa) {
-    extern __shared__ u64 tab[];                                    // tile workgroups: [16 groups][16 entries][64 words]; panel: staging
-    __shared__ u64 s_g[WK];
-    __shared__ int s_lead[WK];
-    __shared__ u64 s_cm[SPEC_W];
-    __shared__ int s_flag;
-    SpecShared *__restrict__ sh = sa.sh;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // ---- everything a step needs to know, loaded together (one round trip, not a chain) ----
-    const SpecCtrl c = sh->ctrl[sa.launch & 1u];
-    SpecCtrl *__restrict__ c_out = &sh->ctrl[(sa.launch + 1u) & 1u];
-    const u32 broken = sh->broken;
-    const u32 ep = c.ep, mode = c.mode;
-    const int pc = (int)(ep & 1u), pp = pc ^ 1;                     // parity of what this epoch files / of what the previous one filed
-    const SpecState *__restrict__ s_in = sa.st + pc;
-    SpecState *__restrict__ s_out = sa.st + pp;
-    const BlockInfo *__restrict__ info = sa.binfo + ((c.blk + 1u) & 1u);
-    BlockInfo *__restrict__ info_next = sa.binfo + (c.blk & 1u);
-    const int kk_info = info->kk;
-    const i64 i0 = info->i0;
-    const i64 i0n = s_in->next_i0;                                  // candidates of the next block: [i0n, i0n + 64)
-    const int cbp = sh->colbase[pp];                                // first word of the previous epoch's column window
-    u64 cmv[SPEC_W];
-#pragma unroll
-    for (int q = 0; q < SPEC_W; ++q) cmv[q] = s_in->cm[q];
-    const int closed_base = s_in->closed_base;
-    int pw = info->pivw[lane], pb = info->pivb[lane];              // lane j <-> pivot j of the block to sweep
-    u64 mj = info->mask[lane] & ((1ULL << lane) - 1ULL), Tj = info->T[lane];
-    if (broken != 0u || mode == SPEC_DONE) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *c_out = c;
-        return;
-    }
-    const int kk = mode == SPEC_IDLE ? 0 : kk_info;
-    if (kk == 0) { pw = -1; pb = 0; mj = 0; Tj = 0; }
-    // first word column that is not closed (this epoch's column window starts there) and the closed columns of that word
-    int cw_now = closed_base;
-    u64 cw_mask = ~0ULL;
-    {
-        bool open = false;
-#pragma unroll
-        for (int q = 0; q < SPEC_W; ++q) {
-            if (!open && cmv[q] != ~0ULL) { open = true; cw_mask = cmv[q]; }
-            if (!open) ++cw_now;
-        }
-    }
-    if (mode == SPEC_F1) {
-        // ---- selector step: sel[] of every row for a block whose pivot columns are outside the column window ----
-        const i64 n_wave = (i64)gridDim.x * (M4_NT / 64);
-        for (i64 r = (i64)blockIdx.x * (M4_NT / 64) + wave; r < R; r += n_wave) {
-            const u64 g = select_row(rows, Wc, r, lane, i0, kk, pw, pb, mj, Tj, sa.rowcnt);
-            if (lane == 0) sa.sel[r] = g;
-        }
-        if (blockIdx.x == 0 && threadIdx.x == 0) { SpecCtrl o = c; o.mode = SPEC_F2; *c_out = o; }
-        return;
-    }
-    const bool from_sel = mode == SPEC_F2;
-    const u64 *__restrict__ CWp = sa.colwin + (size_t)pp * (size_t)R * CWW;
-    u64 *__restrict__ CWn = sa.colwin + (size_t)pc * (size_t)R * CWW;
-    const u64 *__restrict__ snp = sa.snap + (size_t)pp * (size_t)WK * Wc;
-    u64 *__restrict__ snn = sa.snap + (size_t)pc * (size_t)WK * Wc;
-    const int pwr = (!from_sel && lane < kk && pw >= 0) ? pw - cbp : -1;     // the pivot's word inside the previous column window
-    if (blockIdx.x == 0) {
-        // ================= panel workgroup =================
-        u64 *s_old = tab, *s_win = tab + WK * CWW, *s_raw = tab + 2 * WK * CWW;     // [64][CWW] each
-        const bool stamp = sa.launch == 20u && threadIdx.x == 0;
-        if (stamp) sh->tstamp[0] = wall_clock64();
-        const bool direct = mode == SPEC_IDLE;                      // nothing is swept in this launch: the matrix itself is the truth
-        const int base = direct ? cw_now : cbp;                     // first word of the window the candidates are looked at through
-        const int nr = (int)(R - i0n < WK ? (R - i0n > 0 ? R - i0n : 0) : WK);
-        // 1. the candidates' own window words, the old block rows' window words; selectors and filed leading words of the candidates —
-        //    four candidates per wavefront, their loads issued together
-        for (int x = threadIdx.x; x < WK * CWW; x += M4_NT) {
-            const int r = x / CWW, q = x - r * CWW;
-            u64 raw = 0, old = 0;
-            const bool inside = (i64)base + q < Wc;                 // (words past the end of the rows were never filed)
-            if (r < nr && inside) raw = direct ? rows[(i0n + r) * Wc + base + q] : CWp[(i0n + r) * CWW + q];
-            if (r < kk && inside) old = CWp[(i0 + r) * CWW + q];
-            s_raw[x] = raw; s_old[x] = old;
-        }
-        {
-            u64 cbw[4], lk[4], sg[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = wave * 4 + u;
-                cbw[u] = (r < nr && pwr >= 0) ? CWp[(i0n + r) * CWW + pwr] : 0ULL;
-                lk[u] = r < nr ? sa.leadkey[i0n + r] : 0ULL;
-                sg[u] = (r < nr && from_sel && kk != 0) ? sa.sel[i0n + r] : 0ULL;
-            }
-            const u64 Tt = (kk != 0 && !from_sel) ? transpose_T(Tj, lane) : 0ULL;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = wave * 4 + u;
-                u64 g = sg[u];
-                if (r < nr && kk != 0 && !from_sel) g = select_from_bit(pwr >= 0 && ((cbw[u] >> pb) & 1ULL), lane, i0n + r, i0, kk, mj, Tj, Tt, nullptr);
-                // the row's true leading word where it is known without the window: filed by the previous epoch and still true (g == 0)
-                int tl = -2;                                        // -2: not known
-                if (r < nr && direct) {
-                    int fw = NOLEAD;
-                    for (i64 x0 = 0; x0 < Wc; x0 += 64) {
-                        const i64 x = x0 + lane;
-                        const u64 nz = __ballot(x < Wc && rows[(i0n + r) * Wc + x] != 0ULL);
-                        if (nz) { fw = (int)(x0 + __builtin_ctzll(nz)); break; }
-                    }
-                    tl = fw;
-                } else if (r < nr && g == 0ULL) tl = (u32)(lk[u] >> 32) == ep - 1u ? (int)(0xffffffffu - (u32)lk[u]) : NOLEAD;
-                if (lane == 0 && r < WK) { s_g[r] = g; s_lead[r] = tl; }
-            }
-        }
-        __syncthreads();
-        // 2. the candidates as the sweep of this launch leaves them, on the window words
-        for (int x = threadIdx.x; x < WK * CWW; x += M4_NT) {
-            const int r = x / CWW, q = x - r * CWW;
-            u64 v = s_raw[x], g = s_g[r];
-            while (g) { const int j = __builtin_ctzll(g); g &= g - 1; v ^= s_old[j * CWW + q]; }
-            s_win[x] = v;
-        }
-        __syncthreads();
-        if (wave != 0) return;
-        if (stamp) sh->tstamp[1] = wall_clock64();
-        // 3. leading words, decision, panel
-        const bool valid = lane < nr;
-        const int q0 = cw_now - base;                               // words in front of it are closed: zero in every unprocessed row
-        const int UNKNOWN = 0x7ffffff0;
-        int a = -1;
-        if (valid) {
-            const int tl = s_lead[lane];
-            a = tl != -2 ? tl : UNKNOWN;
-            if (tl == -2) for (int q = CWW - 1; q >= 0; --q) if (q >= q0 && s_win[lane * CWW + q] != 0ULL) a = base + q;
-        }
-        if (nr == 0) {                                              // no row left: this launch's sweep is the last thing that happens
-            if (lane == 0) {
-                SpecCtrl o = c; o.ep = ep + 1u; o.mode = SPEC_DONE; *c_out = o;
-                info_next->i0 = i0n; info_next->kk = 0; info_next->w_next = -1;
-            }
-            return;
-        }
-        const u64 fin_m = __ballot(valid && a != NOLEAD);
-        int w_lo = -1;                                              // the panel's window start (-1: a block of zero rows)
-        bool stuck = false, far = false;
-        if (fin_m != 0ULL) {
-            const int jf = __builtin_ctzll(fin_m);
-            if (__builtin_amdgcn_readlane(a, jf) == UNKNOWN) stuck = true;
-            else {
-                w_lo = window_start(a, valid, jf);
-                far = w_lo < base || w_lo + WN > base + CWW;
-            }
-        }
-        int kkn = 0, pwn = -1, pbn = 0;                             // the block panelled in this step (none when stuck)
-        if (stuck) {
-            // nothing is known about the first row: the next step sweeps nothing and looks at the matrix itself
-            if (lane == 0) {
-                SpecCtrl o = c; o.ep = ep + 1u; o.mode = SPEC_IDLE; *c_out = o;
-                s_out->next_i0 = i0n;
-                atomicAdd(&sh->n_idle, 1ULL);
-            }
-        } else if (far && sh->n_far >= 64u && sh->n_far * 2u > c.blk) {
-            // mostly far blocks (sparse rows): the two-launch schedule with its full-row panels does these better; nothing is pending after
-            // this launch's sweep
-            if (lane == 0) {
-                sh->handoff_i0 = i0n;
-                SpecCtrl o = c; o.ep = ep + 1u; o.mode = SPEC_DONE; *c_out = o;
-                __hip_atomic_store(&sh->broken, sa.launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
-        } else {
-            const bool from_win = fin_m != 0ULL && !far;
-            u64 spec[WN] = {0, 0, 0, 0};
-            if (valid && from_win) {
-#pragma unroll
-                for (int q = 0; q < WN; ++q) spec[q] = s_win[lane * CWW + (w_lo - base) + q];
-            }
-            // a far block is read from the matrix: rows that change in this launch cannot belong to it (they lead near the frontier, far
-            // from its window, so the panel's window test ends the block in front of them anyway; made explicit)
-            if (far && !direct && valid && s_g[lane] != 0ULL && a != NOLEAD) a = UNKNOWN;
-            if (stamp) sh->tstamp[2] = wall_clock64();
-            panel_wave(rows, R, Wc, i0n, a, lane, reinterpret_cast<SweepState *>(s_out), info_next, pivots, xor_count, from_win ? spec : nullptr, from_win ? w_lo : -1,
-                       sa.lean_panel, &kkn, &pwn, &pbn);
-            if (stamp) { sh->tstamp[3] = wall_clock64(); sh->tstamp[8] = (u64)kkn; }
-            // the next step: the block's pivots inside the column window this launch files -> N, else selectors from the matrix first
-            const bool outside = __ballot(lane < kkn && pwn >= 0 && (pwn < cw_now || pwn >= cw_now + CWW)) != 0ULL;
-            if (lane == 0) {
-                SpecCtrl o = c;
-                o.ep = ep + 1u; o.mode = outside ? SPEC_F1 : SPEC_N; o.blk = c.blk + 1u;
-                *c_out = o;
-                if (outside) atomicAdd(&sh->n_far, 1u); else atomicAdd(&sh->n_spec, 1ULL);
-            }
-        }
-        // 4. the closed-column frontier after this step: carried over, holes certified dead by the previous epoch, words that filled up
-        //    shifted out, this block's pivot columns filed
-        if (lane == 0) {
-            u64 cm2[SPEC_W];
-#pragma unroll
-            for (int q = 0; q < SPEC_W; ++q) cm2[q] = cmv[q];
-            const u64 dead = sh->alive_hm[pp] & ~sh->alive[pp];
-            const int aw = sh->alive_w[pp];
-            if (dead != 0ULL && aw >= closed_base && aw < closed_base + SPEC_W) {
-#pragma unroll
-                for (int q = 0; q < SPEC_W; ++q) if (q == aw - closed_base) cm2[q] |= dead;
-            }
-            sh->alive[pp] = 0ULL; sh->alive_hm[pp] = 0ULL;
-            int full = 0;
-#pragma unroll
-            for (int q = 0; q < SPEC_W; ++q) { if (cm2[q] != ~0ULL) break; ++full; }
-#pragma unroll
-            for (int q = 0; q < SPEC_W; ++q) {
-                u64 v = 0;
-#pragma unroll
-                for (int q2 = 0; q2 < SPEC_W; ++q2) if (q2 == q + full) v = cm2[q2];
-                s_cm[q] = v;
-            }
-            s_flag = closed_base + full;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int nb2 = s_flag;
-        if (lane < kkn && pwn >= nb2 && pwn < nb2 + SPEC_W) atomicOr((unsigned long long *)&s_cm[pwn - nb2], 1ULL << pbn);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < SPEC_W) s_out->cm[lane] = s_cm[lane];
-        if (lane == 0) s_out->closed_base = nb2;
-        if (stamp) sh->tstamp[4] = wall_clock64();
-        return;
-    }
-    // ================= tile workgroups: sweep of the current block over their rows =================
-    const int k = (int)blockIdx.x - 1;
-    const bool tstamp = sa.launch == 20u && threadIdx.x == 0 && (k == 0 || k == (int)gridDim.x - 2);
-    const int tso = k == 0 ? 5 : 10;
-    if (tstamp) sh->tstamp[tso] = wall_clock64();
-    const int tile = k % n_tiles, chunk = k / n_tiles;
-    const i64 per = (R + n_chunks - 1) / n_chunks;
-    const i64 v_lo = (i64)chunk * per, v_hi = v_lo + per < R ? v_lo + per : R;
-    if (v_lo >= v_hi) return;
-    const i64 w = (i64)tile * M4_TW + lane;
-    const bool live = w < Wc;
-    const i64 wl = live ? w : Wc - 1;
-    // what this tile files besides the rows (all wave-uniform tests): the column window, the hole candidates of the first unclosed word
-    const u64 hm = ~cw_mask;
-    const bool tile_cw = (i64)tile * M4_TW < (i64)cw_now + CWW && (i64)tile * M4_TW + M4_TW > (i64)cw_now;
-    const bool tile_hole = hm != 0ULL && (i64)tile * M4_TW <= (i64)cw_now && (i64)cw_now < (i64)tile * M4_TW + M4_TW;
-    const bool hole_lane = live && w == (i64)cw_now;
-    const i64 qn = w - (i64)cw_now;                                 // this lane's word inside the column window this epoch files
-    const bool cw_lane = live && qn >= 0 && qn < CWW;
-    if (k == 0 && threadIdx.x == 0) { sh->colbase[pc] = cw_now; sh->alive_w[pc] = cw_now; sh->alive_hm[pc] = hm; }
-    u32 *const rowcnt = (tile == 0 && !from_sel) ? sa.rowcnt : nullptr;
-    const i64 step = M4_U * (M4_NT / 64);
-    i64 rn[M4_U];
-    u64 xn[M4_U], cn[M4_U];
-    auto fetch = [&](i64 v0) {
-#pragma unroll
-        for (int u = 0; u < M4_U; ++u) {
-            rn[u] = v0 + u < v_hi ? v0 + u : (v0 < v_hi ? v0 : v_lo);   // tail: surplus slots repeat a valid row, never stored
-            xn[u] = rows[rn[u] * Wc + wl];
-            cn[u] = from_sel ? (kk != 0 ? sa.sel[rn[u]] : 0ULL) : (pwr >= 0 ? CWp[rn[u] * CWW + pwr] : 0ULL);
-        }
-    };
-    i64 v0 = v_lo + M4_U * wave;
-    if (v0 < v_hi) fetch(v0);
-    const u64 Tt = (kk != 0 && !from_sel) ? transpose_T(Tj, lane) : 0ULL;
-    if (kk != 0) {
-        for (int g = wave; g < 16; g += M4_NT / 64) {
-            u64 sv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sv[i] = (4 * g + i < kk) ? snp[(i64)(4 * g + i) * Wc + wl] : 0ULL;
-            u64 t[16];
-            t[0] = 0; t[1] = sv[0]; t[2] = sv[1]; t[3] = sv[0] ^ sv[1];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t[4 + e] = t[e] ^ sv[2];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t[8 + e] = t[e] ^ sv[3];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) tab[(g * 16 + e) * M4_TW + lane] = t[e];
-        }
-    }
-    __syncthreads();
-    if (tstamp) sh->tstamp[tso + 1] = wall_clock64();
-    u64 alive_acc = 0;
-    for (; v0 < v_hi; v0 += step) {
-        i64 r[M4_U];
-        u64 x[M4_U], cb[M4_U];
-#pragma unroll
-        for (int u = 0; u < M4_U; ++u) { r[u] = rn[u]; x[u] = xn[u]; cb[u] = cn[u]; }
-        if (v0 + step < v_hi) fetch(v0 + step);                      // uniform
-#pragma unroll
-        for (int u = 0; u < M4_U; ++u) {
-            const bool mine = (u == 0 || v0 + u < v_hi);
-            u64 g = 0;
-            if (kk != 0) g = from_sel ? cb[u] : select_from_bit(pwr >= 0 && ((cb[u] >> pb) & 1ULL), lane, r[u], i0, kk, mj, Tj, Tt, mine ? rowcnt : nullptr);
-            const u32 slo = __builtin_amdgcn_readfirstlane((u32)g), shi = __builtin_amdgcn_readfirstlane((u32)(g >> 32));
-            if ((slo | shi) != 0u) {                                 // uniform; untouched rows are not rewritten
-#pragma unroll
-                for (int gg = 0; gg < 16; ++gg) {
-                    const u32 e = ((gg < 8 ? slo : shi) >> (4 * (gg & 7))) & 15u;
-                    x[u] ^= tab[(gg * 16 + (int)e) * M4_TW + lane];
-                }
-                if (live && mine) rows[r[u] * Wc + w] = x[u];
-            }
-            if (mine) {
-                const i64 ru = __builtin_amdgcn_readfirstlane((u32)r[u]) | ((i64)__builtin_amdgcn_readfirstlane((u32)(r[u] >> 32)) << 32);
-                if (tile_cw && cw_lane) CWn[ru * CWW + qn] = x[u];
-                if (ru >= i0n && ru < i0n + 2 * WK) {                // the rows that can be candidates of the next step: true leading word; old rows
-                    const u64 nzb = __ballot(live && x[u] != 0ULL);
-                    if (nzb != 0ULL && lane == 0)
-                        atomicMax((unsigned long long *)&sa.leadkey[ru], ((u64)ep << 32) | (u64)(0xffffffffu - (u32)(tile * M4_TW + (int)__builtin_ctzll(nzb))));
-                    if (ru < i0n + WK && live) snn[(ru - i0n) * Wc + w] = x[u];
-                }
-                if (tile_hole && hole_lane && ru >= i0n) alive_acc |= x[u] & hm;
-            }
-        }
-    }
-    if (tile_hole && alive_acc != 0ULL) atomicOr((unsigned long long *)&sh->alive[pc], alive_acc);
-    if (tstamp) sh->tstamp[tso + 2] = wall_clock64();
-}
-
 // ---- small matrices: the whole reduction in ONE workgroup -------------------------------------------------------------
 // R <= 64 rows and Wc <= 64 words (32 KiB of LDS): the reference loop verbatim — for every row in order: leftmost set column,
 // flags of the rows holding it (one ballot), XOR — without the 3 launches per block of the blocked path.  Stabiliser sets,
@@ -1360,7 +755,7 @@ static int rref_dev_impl(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_h
                hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess &&
                hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess;
     }();
-    const char *env_m4r = getenv("SYMGPU_GF2_M4R"), *env_la = getenv("SYMGPU_GF2_LOOKAHEAD");   // read per call: the tests switch paths
+    const char *env_m4r = getenv("SYMGPU_GF2_M4R"), *env_la = SG_TUNE("SYMGPU_GF2_LOOKAHEAD");   // read per call: the tests switch paths
     const bool m4r = m4r_attr && !(env_m4r && env_m4r[0] == '0'), m4r_plain = m4r;
     const int m4_tiles = (int)((Wc + M4_TW - 1) / M4_TW);
     int m4_chunks = 256 / m4_tiles;                              // one workgroup per CU: about one round of workgroups
@@ -1372,48 +767,8 @@ static int rref_dev_impl(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_h
     FusedSelect fs;
     fs.sel = sel.as<u64>(); fs.snap = snap.as<u64>(); fs.rowcnt = rowcnt.as<u32>(); fs.ready = ready.as<u64>(); fs.epoch = 0;
     fs.fail = reinterpret_cast<u32 *>(count.p) + 2;
-    fs.full_panel = [] { const char *e = getenv("SYMGPU_GF2_FULL_PANEL"); return !(e && e[0] == '0'); }() ? 1 : 0;
-    fs.lean_panel = [] { const char *e = getenv("SYMGPU_GF2_LEAN_PANEL"); return !(e && e[0] == '0'); }() ? 1 : 0;
-    // one launch per block: needs every tile workgroup and the panel co-resident (<= one per CU) and the in-launch waits allowed
-    static const bool merged_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gf2_merged), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess;
-    // MEASURED AND NOT THE DEFAULT (cfg4, round 4): 37.9 us per block against 9.7 + 14.3 us for the two launches — the grid-wide wait has to
-    // write the sweep's 27 MB back from the XCDs' L2s (release) before the tail may read other workgroups' rows, which a kernel boundary does
-    // in 2-4 us and an in-launch release + acquire + counter does in ~10, and the tail's two dependent steps (selectors, then 64 rows) run on
-    // a chip that is otherwise idle.  SYMGPU_GF2_MERGED=1 selects it (tests keep it exercised).
-    const bool merged_env = [] { const char *e = getenv("SYMGPU_GF2_MERGED"); return e && e[0] == '1'; }();
-    const bool merged = fused_select && merged_env && merged_attr && lookahead && m4r && m4_tiles * m4_chunks + 1 <= ctx().num_cu;
-    // the speculative-window schedule (k_gf2_spec): one launch per block, no in-launch wait; SYMGPU_GF2_SPEC=0 keeps to the two launches
-    static const bool spec_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gf2_spec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess;
-    // MEASURED AND NOT THE DEFAULT (cfg4, round 4): a step takes 24 us — the panel still waits for the selectors of its 64 candidates and
-    // their updated window (two memory round trips and two LDS stages, 9.6 us in front of the panel's 12), exactly what launch A cost, and
-    // far / unknown first rows add steps (87 launches for 73 blocks): 2.4 ms against 2.0.  SYMGPU_GF2_SPEC=1 selects it (tests keep it exercised).
-    const bool spec_env = [] { const char *e = getenv("SYMGPU_GF2_SPEC"); return e && e[0] == '1'; }();
-    bool spec_sched = spec_env && spec_attr && fused_select && !merged && lookahead && m4r && R * CWW < ((i64)1 << 40);
-    Scratch spec_st, spec_sh, spec_cw, spec_snap, spec_lk;
-    SpecArgs sa;
-    memset(&sa, 0, sizeof(sa));
-    sa.rowcnt = rowcnt.as<u32>(); sa.lean_panel = fs.lean_panel; sa.binfo = binfo; sa.sel = sel.as<u64>();
-    if (spec_sched) {
-        SG_TRY(spec_st.alloc(2 * sizeof(SpecState)));
-        SG_TRY(spec_sh.alloc(sizeof(SpecShared)));
-        SG_TRY(spec_cw.alloc((size_t)2 * R * CWW * sizeof(u64)));
-        SG_TRY(spec_snap.alloc((size_t)2 * WK * Wc * sizeof(u64)));
-        SG_TRY(spec_lk.alloc((size_t)R * sizeof(u64)));
-        HIP_TRY(hipMemsetAsync(spec_lk.p, 0, (size_t)R * sizeof(u64), st));
-        HIP_TRY(hipMemsetAsync(spec_st.p, 0, 2 * sizeof(SpecState), st));
-        SpecShared h0;
-        memset(&h0, 0, sizeof(h0));
-        h0.ctrl[1].ep = 1; h0.ctrl[1].mode = SPEC_IDLE; h0.ctrl[1].blk = 0;     // launch 1: nothing to sweep, panel from the matrix
-        HIP_TRY(hipMemcpyAsync(spec_sh.p, &h0, sizeof(h0), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));                           // (stack buffer)
-        sa.st = spec_st.as<SpecState>(); sa.sh = spec_sh.as<SpecShared>(); sa.colwin = spec_cw.as<u64>(); sa.snap = spec_snap.as<u64>();
-        sa.leadkey = spec_lk.as<u64>();
-    }
-    Scratch msync;
-    if (merged) {
-        SG_TRY(msync.alloc(64));
-        HIP_TRY(hipMemsetAsync(msync.p, 0, 64, st));
-    }
+    fs.full_panel = [] { const char *e = SG_TUNE("SYMGPU_GF2_FULL_PANEL"); return !(e && e[0] == '0'); }() ? 1 : 0;
+    fs.lean_panel = [] { const char *e = SG_TUNE("SYMGPU_GF2_LEAN_PANEL"); return !(e && e[0] == '0'); }() ? 1 : 0;
     if (lookahead && m4r && (i64)m4_tiles * m4_chunks + 1 < ((i64)1 << 31)) {
         // Pipeline, three launches per block: select(b) -> phase 0: sweep of the rows of block b+1 + their leading words ->
         // phase 1: panel of block b+1 (-> the other info buffer) inside the sweep of all remaining rows.  The very first
@@ -1427,79 +782,12 @@ static int rref_dev_impl(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_h
         }
         i64 it = 0, done = 0, prev = -1;
         bool finished = false;
-        if (spec_sched) {
-            // the column-window schedule: generic steps, the device decides what each one does (k_gf2_spec)
-            const bool dbg = getenv("SYMGPU_GF2_DEBUG") != nullptr;
-            u32 launch = 0;
-            i64 spec_done = 0;
-            for (int batch = 0;; ++batch) {
-                i64 n_steps = (R - spec_done + WK - 1) / WK + 2;
-                if (batch == 0 && n_steps > 12) n_steps = 12;         // a short first batch: a matrix the schedule hands back shows at once
-                if (n_steps > 4096) n_steps = 4096;
-                for (i64 k = 0; k < n_steps; ++k) {
-                    sa.launch = ++launch;
-                    ProfScope prof(2);
-                    hipLaunchKernelGGL(k_gf2_spec, dim3((unsigned)(m4_tiles * m4_chunks + 1)), dim3(M4_NT), M4_LDS, st, rows, R, Wc, m4_tiles, m4_chunks, piv.as<i64>(),
-                                       count.as<unsigned long long>(), sa);
-                    KERNEL_CHECK();
-                }
-                SpecShared hsh;
-                SpecState hst[2];
-                HIP_TRY(hipMemcpyAsync(&hsh, spec_sh.p, sizeof(hsh), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipMemcpyAsync(hst, spec_st.p, sizeof(hst), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                const SpecCtrl cc = hsh.ctrl[(launch + 1u) & 1u];
-                const i64 reached = hst[cc.ep & 1u].next_i0;
-                if (dbg) {
-                    const u64 t0 = hsh.tstamp[0];
-                    fprintf(stderr, "rref steps: %u launches, %llu blocks from the column window, %u far, %llu idle steps, row %lld, mode %u%s\n", launch, hsh.n_spec, hsh.n_far,
-                            hsh.n_idle, (long long)reached, cc.mode, hsh.broken ? " (handed back to the two-launch schedule)" : "");
-                    if (launch >= 20u && t0)
-                        fprintf(stderr, "  launch 20 (10 ns ticks from the panel's start): staged %lld, decided %lld, panelled %lld (kk %llu), frontier %lld; tile wg 0: start %lld tables %lld done %lld; last: start %lld tables %lld done %lld\n",
-                                (long long)(hsh.tstamp[1] - t0), (long long)(hsh.tstamp[2] - t0), (long long)(hsh.tstamp[3] - t0), (unsigned long long)hsh.tstamp[8],
-                                (long long)(hsh.tstamp[4] - t0), (long long)(hsh.tstamp[5] - t0), (long long)(hsh.tstamp[6] - t0), (long long)(hsh.tstamp[7] - t0),
-                                (long long)(hsh.tstamp[10] - t0), (long long)(hsh.tstamp[11] - t0), (long long)(hsh.tstamp[12] - t0));
-                }
-                if (hsh.broken != 0u) {
-                    // everything in front of row handoff_i0 is reduced and swept, nothing is pending: the state the two-launch schedule starts
-                    // from (an empty "current" block at that row)
-                    BlockInfo hb;
-                    memset(&hb, 0, sizeof(hb));
-                    hb.i0 = hsh.handoff_i0; hb.kk = 0; hb.w_next = -1;
-                    HIP_TRY(hipMemcpyAsync(binfo, &hb, sizeof(hb), hipMemcpyHostToDevice, st));
-                    HIP_TRY(hipMemcpyAsync(binfo + 1, &hb, sizeof(hb), hipMemcpyHostToDevice, st));
-                    SweepState hs0;
-                    hs0.next_i0 = hsh.handoff_i0;
-                    HIP_TRY(hipMemcpyAsync(state.p, &hs0, sizeof(hs0), hipMemcpyHostToDevice, st));
-                    HIP_TRY(hipStreamSynchronize(st));               // (stack buffers)
-                    done = hsh.handoff_i0;
-                    prev = hsh.handoff_i0 - 1;
-                    break;
-                }
-                if (cc.mode == SPEC_DONE) { finished = true; break; }
-                if (batch > 0 && reached <= spec_done && n_steps >= 4) { set_error("rref: no progress (internal error, column-window schedule)"); return SYMGPU_E_INVALID; }
-                spec_done = reached;
-            }
-        }
         while (!finished) {
             i64 n_iter = (R - done + WK - 1) / WK + 1;
             if (n_iter > 4096) n_iter = 4096;
             for (i64 k = 0; k < n_iter; ++k, ++it) {
                 BlockInfo *cur = binfo + ((it + 1) & 1), *next = binfo + (it & 1);      // cur: block it-1 (to sweep), next: block it (to panel)
                 fs.epoch = (u32)(it + 1);
-                if (merged) {
-                    // one launch per block (k_gf2_merged); the very first iteration still needs the leading words of rows 0..63: launch A once
-                    if (it == 0)
-                        hipLaunchKernelGGL(k_sweep_m4r<3>, dim3((unsigned)(SEL_PRI + m4_tiles + (R + 15) / 16)), dim3(M4_NT), M4_LDS, st, rows, R, Wc, cur, sel.as<u64>(),
-                                           snap.as<u64>(), m4_tiles, 1, next, state.as<SweepState>(), piv.as<i64>(), count.as<unsigned long long>(), lead.as<int>(), fs);
-                    MergedSync ms;
-                    ms.ctr = msync.as<u32>(); ms.epoch = (u32)(it + 1); ms.n_wg = (u32)(m4_tiles * m4_chunks);
-                    ProfScope prof(2);
-                    hipLaunchKernelGGL(k_gf2_merged, dim3((unsigned)(m4_tiles * m4_chunks + 1)), dim3(M4_NT), M4_LDS, st, rows, R, Wc, cur, sel.as<u64>(), snap.as<u64>(),
-                                       m4_tiles, m4_chunks, next, state.as<SweepState>(), piv.as<i64>(), count.as<unsigned long long>(), lead.as<int>(), fs, ms);
-                    KERNEL_CHECK();
-                    continue;
-                }
                 if (fused_select) {
                     // selectors of block it-1 and phase 0 in one grid (the very first iteration has no block to select for: kk == 0)
                     const unsigned g3 = (unsigned)(SEL_PRI + m4_tiles + (R + 15) / 16);
@@ -1559,7 +847,7 @@ static int rref_dev_impl(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_h
     HIP_TRY(hipMemcpyAsync(hb, count.p, 16, hipMemcpyDeviceToHost, st));
     if (pivots_host) HIP_TRY(hipMemcpyAsync(pivots_host, piv.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (getenv("SYMGPU_GF2_DEBUG")) fprintf(stderr, "rref %lld x %lld words: full-row panels %u\n", (long long)R, (long long)Wc, (u32)(hb[1] >> 32));
+    if (SG_TUNE("SYMGPU_GF2_DEBUG")) fprintf(stderr, "rref %lld x %lld words: full-row panels %u\n", (long long)R, (long long)Wc, (u32)(hb[1] >> 32));
     if ((u32)hb[1] != 0) { *timed_out = true; return SYMGPU_OK; }
     if (xor_count) *xor_count = (i64)hb[0];
     return SYMGPU_OK;
@@ -1572,23 +860,31 @@ int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host) {
     if (xor_count) *xor_count = 0;
     if (R <= 0 || Wc <= 0) return SYMGPU_OK;
     const bool env_fused = [] { const char *e = getenv("SYMGPU_GF2_FUSED_SELECT"); return !(e && e[0] == '0'); }();
-    const bool inject = getenv("SYMGPU_GF2_INJECT_TIMEOUT") != nullptr;      // tests: pretend the first attempt timed out
+    const bool inject = [] { const char *e = getenv("SYMGPU_GF2_FUSED_SELECT"); return e && e[0] == '2'; }();      // 2 = tests: pretend the first attempt timed out
     const bool fused = env_fused && !g_gf2_fused_off;
     // The fused schedule waits inside a launch for flags of other workgroups (bounded, ~1 s).  Should that wait ever give up, the matrix
     // is half updated in place — so a copy of the input is kept (2 x 27 MB at 5 TB/s = 11 us of a 2 ms call at cfg4) and the reduction is
     // redone from it with separate launches; the fused form stays off for the rest of the process.
     Scratch orig;
     const bool big = R > SMALL_R || Wc > SMALL_WC;
+    bool fused_now = fused;
     if (fused && big) {
-        SG_TRY(orig.alloc((size_t)R * Wc * 8));
-        HIP_TRY(hipMemcpyAsync(orig.p, rows, (size_t)R * Wc * 8, hipMemcpyDeviceToDevice, st));
+        if (orig.alloc((size_t)R * Wc * 8) != SYMGPU_OK) {
+            // no room for the safety copy (a matrix near the memory limit): the separate-launch schedule needs none and has no wait to time out
+            orig.p = nullptr;
+            set_error("");
+            fused_now = false;
+        } else {
+            HIP_TRY(hipMemcpyAsync(orig.p, rows, (size_t)R * Wc * 8, hipMemcpyDeviceToDevice, st));
+        }
     }
     bool timed_out = false;
-    SG_TRY(rref_dev_impl(rows, R, Wc, xor_count, pivots_host, fused, &timed_out));
-    if (inject && fused && big) timed_out = true;
+    SG_TRY(rref_dev_impl(rows, R, Wc, xor_count, pivots_host, fused_now, &timed_out));
+    if (inject && fused_now && big) timed_out = true;
     if (!timed_out) return SYMGPU_OK;
     if (!orig.p) { set_error("rref: an in-launch wait timed out on a schedule that has none (internal error)"); return SYMGPU_E_HIP; }
     g_gf2_fused_off = !inject;
+    if (!inject) note_degraded("GF(2) fused selector launch off: an in-kernel wait timed out (workgroups not co-resident?); the elimination takes three launches per block");
     HIP_TRY(hipMemcpyAsync(rows, orig.p, (size_t)R * Wc * 8, hipMemcpyDeviceToDevice, st));
     if (xor_count) *xor_count = 0;
     SG_TRY(rref_dev_impl(rows, R, Wc, xor_count, pivots_host, false, &timed_out));

@@ -331,7 +331,7 @@ static RowsVariant g_rv;
 static const RowsVariant &rows_variant() {
     if (!g_rv.parsed) {
         g_rv.parsed = true;
-        const char *e = getenv("SYMGPU_ROWS_VARIANT");
+        const char *e = SG_TUNE("SYMGPU_ROWS_VARIANT");
         if (e) {
             int a = 0, b2 = 0, c = 0, d = 256, p8 = 1;
             const int got = sscanf(e, "%d,%d,%d,%d,%d", &a, &b2, &c, &d, &p8);
@@ -539,7 +539,7 @@ int symgpu_mul_allpairs_dev(symgpu_op_t inner, symgpu_op_t outer, int64_t o_begi
         i64 Ipad = 0;
         SG_TRY(op_wordmajor(inner, 64 * PJ, &It, &Ipad));          // cached across slabs of the same inner operand
         Scratch ot;
-        const bool overlap = [] { const char *e = getenv("SYMGPU_PRODUCT_OVERLAP"); return e && e[0] == '1'; }();
+        const bool overlap = [] { const char *e = SG_TUNE("SYMGPU_PRODUCT_OVERLAP"); return e && e[0] == '1'; }();
         if (overlap) {
             HIP_TRY(hipEventRecord(c.ev_fork, c.stream));
             HIP_TRY(hipStreamWaitEvent(c.stream2, c.ev_fork, 0));

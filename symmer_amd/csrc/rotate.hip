@@ -618,7 +618,7 @@ static int analyze_rows(symgpu_op_t in, u64 *q_dev, u32 *anti, uint8_t *ph, cons
     while (G < Wq && G < 64) G <<= 1;
     const int rpb = 256 / G;
     // word kernel: grid-stride over <= 1024 blocks (uncapped measured 20.6 / 14.2 us against 22.4 / 10.8 us with / without the insert)
-    const i64 cap = [] { const char *e = getenv("SYMGPU_ROT_ANALYZE_CAP"); return e ? atoll(e) : (i64)1024; }();
+    const i64 cap = [] { const char *e = SG_TUNE("SYMGPU_ROT_ANALYZE_CAP"); return e ? atoll(e) : (i64)1024; }();
     i64 g = (T + rpb - 1) / rpb;
     if (g > cap) g = cap;
     const JoinTable none = {nullptr, 0, 0, nullptr};
@@ -629,7 +629,7 @@ static int analyze_rows(symgpu_op_t in, u64 *q_dev, u32 *anti, uint8_t *ph, cons
 #define LAUNCH_AN(H, I, HT, HO, HI, J) do { if (by_arg) hipLaunchKernelGGL((k_rot_analyze<H, I, true>), dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q_dev, anti, ph, HT, HO, HI, J, qa); \
                                            else hipLaunchKernelGGL((k_rot_analyze<H, I, false>), dim3((unsigned)g), dim3(256), 0, st, in->rows, T, Wq, G, q_dev, anti, ph, HT, HO, HI, J, qa); } while (0)
     const bool have_hash = jt && in->hash && in->hash_seed == ctx().hash_seed;
-    const bool chunks_on = [] { const char *e = getenv("SYMGPU_ROT_CHUNKS"); return !(e && e[0] == '0'); }();
+    const bool chunks_on = [] { const char *e = SG_TUNE("SYMGPU_ROT_CHUNKS"); return !(e && e[0] == '0'); }();
     if (chunks_on && (!jt || have_hash) && Wq <= 64 && (Wq & (Wq - 1)) == 0) {
         // one 16-byte chunk per lane (k_rot_analyze_chunks); rows of other lengths and the launch that also hashes keep the word kernel
         const u32x4 *pr = reinterpret_cast<const u32x4 *>(in->rows);
@@ -1392,7 +1392,7 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
             if (local_t > CHAIN_TMAX) local_t = CHAIN_TMAX;
         }
         const size_t lds_rows = (size_t)2 * T * W * 8;
-        const bool lds_on = [] { const char *e3 = getenv("SYMGPU_CHAIN_LDS"); return !(e3 && e3[0] == '0'); }();
+        const bool lds_on = [] { const char *e3 = SG_TUNE("SYMGPU_CHAIN_LDS"); return !(e3 && e3[0] == '0'); }();
         static const bool lds_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_clifford_chain_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                          128 * 1024) == hipSuccess;
         const bool reg_chain = clifford_chain_registers_applicable(T, Wq) && !getenv("SYMGPU_CHAIN_LOCAL_T");
@@ -1445,8 +1445,8 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
             if (rc == SYMGPU_OK) rc = blk.alloc((size_t)n_blk * 16);
             if (rc != SYMGPU_OK) { symgpu_op_free(a); symgpu_op_free(b); return rc; }
             symgpu_op_t cur = a, nxt = b;
-            const bool two_on = [] { const char *e2 = getenv("SYMGPU_CHAIN_TWO"); return !(e2 && e2[0] == '0'); }();
-            if (two_on && Wq <= 64 && (Wq & (Wq - 1)) == 0 && T <= (getenv("SYMGPU_CHAIN_TWO_T") ? atoll(getenv("SYMGPU_CHAIN_TWO_T")) : CHAIN_TWO_T)) {
+            const bool two_on = [] { const char *e2 = SG_TUNE("SYMGPU_CHAIN_TWO"); return !(e2 && e2[0] == '0'); }();
+            if (two_on && Wq <= 64 && (Wq & (Wq - 1)) == 0 && T <= (SG_TUNE("SYMGPU_CHAIN_TWO_T") ? atoll(SG_TUNE("SYMGPU_CHAIN_TWO_T")) : CHAIN_TWO_T)) {
                 // two launches per rotation (k_cchain_flags / k_cchain_move)
                 Scratch af, nc, cnts;
                 const int n_cnt = (int)((T + 1023) / 1024);

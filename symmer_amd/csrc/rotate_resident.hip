@@ -651,7 +651,7 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     *done = 0;
     Context &c = ctx();
     const i64 t_enter = host_ns();
-    if (const char *e = getenv("SYMGPU_ROT_RESIDENT")) {                          // read on every call: 0 = off, 2 = on again after a failure
+    if (const char *e = getenv("SYMGPU_ROT_RESIDENT")) {                          // read on every call: 0 = off, 2 = on again after a failure, 3 = tests: inject a time-out
         if (e[0] == '0') return SYMGPU_OK;
         if (e[0] == '2') c.res_disabled = false;
     }
@@ -682,7 +682,11 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(res_kernel(m == 1, wq)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS_MAX) != hipSuccess) return false;
         return true;
     }();
-    if (!attr_ok) { (void)hipGetLastError(); c.res_disabled = true; return SYMGPU_OK; }
+    if (!attr_ok) {
+        (void)hipGetLastError(); c.res_disabled = true;
+        note_degraded("one-launch rotation (k_rot_resident) off: the runtime refused its LDS size; rotations take the multi-launch kernels");
+        return SYMGPU_OK;
+    }
     hipStream_t st = c.stream;
     if (!clifford && !have_hash) {
         // a duplicate-free operator without cached hashes (straight from a cleanup): hash its rows once, on the handle
@@ -721,7 +725,7 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
         // join table (>= 4 slots per row) and partner notes: all-zero between launches — the kernel zeroes what it used; after a
         // launch that did not complete (res_dirty) they are cleared here
         size_t cap = 4096;
-        static const int slots_per_row = [] { const char *e = getenv("SYMGPU_RES_SLOTS"); const int v = e ? atoi(e) : 4; return v >= 2 && v <= 64 ? v : 4; }();
+        static const int slots_per_row = [] { const char *e = SG_TUNE("SYMGPU_RES_SLOTS"); const int v = e ? atoi(e) : 4; return v >= 2 && v <= 64 ? v : 4; }();
         while ((i64)cap < (i64)slots_per_row * T) cap <<= 1;
         if (cap > c.res_table_cap) {
             if (c.res_table) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(c.res_table); c.res_table = nullptr; c.res_table_cap = 0; }
@@ -748,9 +752,9 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     a.finished = a.fail + 2; a.finish_target = finished_base + (u32)G;
     finished_base += (u32)G;
     a.epoch = c.res_epoch;
-    { const char *e = getenv("SYMGPU_RES_INJECT"); a.inject = (e && e[0] == '1') ? 1 : 0; }
+    { const char *e = getenv("SYMGPU_ROT_RESIDENT"); a.inject = (e && e[0] == '3') ? 1 : 0; }                      // 3 = tests: the kernel reports a failed verification
     a.trace = nullptr;
-    if (const char *e = getenv("SYMGPU_RES_TRACE")) if (e[0] == '1') {
+    if (const char *e = SG_TUNE("SYMGPU_RES_TRACE")) if (e[0] == '1') {
         if (!g_res_trace) { HIP_TRY(hipMalloc((void **)&g_res_trace, (size_t)RES_MAX_WG * 16 * 8)); }
         HIP_TRY(hipMemsetAsync(g_res_trace, 0, (size_t)RES_MAX_WG * 16 * 8, st));
         a.trace = g_res_trace;
@@ -763,6 +767,7 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     volatile u64 *host_words = reinterpret_cast<u64 *>(hcnt) + 5;
     if (*host_late != 0) {                                                        // a launch failed AFTER it had reported its counts
         c.res_disabled = true; c.res_epoch = 0; c.res_dirty = true;
+        note_degraded("one-launch rotation (k_rot_resident) off: a launch failed after reporting; rotations take the multi-launch kernels");
         *host_late = 0;
         set_error("rotate resident: a previous launch failed after it had reported success; its result is invalid");
         return SYMGPU_E_HIP;
@@ -824,7 +829,10 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     if (hc.dup != 0) {                                                             // verification failed (2), timed out (3), or no report at all (1)
         symgpu_op_free(res);
         ++g_counters[2];
-        if (hc.dup != 2) { c.res_disabled = true; c.res_epoch = 0; }               // time-out: arrival counts are in an unknown state
+        if (hc.dup != 2) {                                                         // time-out: arrival counts are in an unknown state
+            c.res_disabled = true; c.res_epoch = 0;
+            note_degraded("one-launch rotation (k_rot_resident) off: an in-kernel wait timed out (workgroups not co-resident?); rotations take the multi-launch kernels");
+        }
         // code 2 too: every owner zeroes its slot and note in phase B, but that relies on every workgroup getting there; one memset on a
         // path that is about to take the multi-launch kernels anyway makes the next launch independent of it
         c.res_dirty = true;

@@ -566,7 +566,7 @@ int radix_sort_keys_u64_coop(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int
     if (n <= 1) { *done = true; return SYMGPU_OK; }
     const i64 n_tiles = (n + RS_TILE - 1) / RS_TILE;
     if (n_tiles > COOP_MAX_TILES) return SYMGPU_OK;
-    if (const char *e = getenv("SYMGPU_SORT_COOP")) if (e[0] == '0') return SYMGPU_OK;
+    if (const char *e = SG_TUNE("SYMGPU_SORT_COOP")) if (e[0] == '0') return SYMGPU_OK;
     Context &c = ctx();
     if (c.sort_coop_disabled) return SYMGPU_OK;
     hipStream_t st = c.stream;
@@ -602,6 +602,7 @@ int radix_sort_coop_check(bool *timed_out) {
     if (flag) {
         *timed_out = true;
         c.sort_coop_disabled = true;
+        note_degraded("one-launch radix sort (k_rs_coop) off: an in-kernel barrier timed out (workgroups not co-resident?); sorts take one launch per pass");
     }
     return SYMGPU_OK;
 }

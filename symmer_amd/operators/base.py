@@ -5,6 +5,7 @@ routines.  The data-parallel work runs in hand-written HIP kernels (``libsymgpu.
 glue only.  Out of scope (not on the path): ``from_matrix``, ``to_sparse_matrix``, graph colouring,
 openfermion/qiskit converters, ``QuantumState``.
 """
+import sys
 import warnings
 from copy import deepcopy
 from functools import reduce, cached_property
@@ -51,15 +52,15 @@ class PauliwordOp:
         assert self.n_terms == len(self._coeff), 'coeff list and Pauliwords not same length'
         self._packed_cache = None
         self._dev = None                 # kernels.DeviceOp: the operator resident on the GPU (rows + coefficients)
-        self._dev_coeff_valid = False    # the handle's coefficients are this operator's coefficients
-        self._coeff_exposed = True       # the host coefficient array is (or may be) in the caller's hands: it can change behind our back
+        self._dev_coeff_valid = False    # the handle's coefficients are this operator's coefficients AND nobody outside can change them
 
     # ---- three layouts of one operator: the reference's bool matrix, packed rows on the host, packed rows on the device --------------
     # Results of device kernels STAY on the device (`_dev`) and come to the host when somebody asks for `symp_matrix`, `packed` or
     # `coeff_vec`; operands are uploaded once and the handle is kept, so a multi-step caller (rotate -> project -> cleanup,
     # symmer/projection/base.py:44-124) moves its operator over PCIe once in and once out.  `symp_matrix` is treated as immutable, as
-    # in the reference; `coeff_vec` is not (`op.coeff_vec *= -1`, `op.coeff_vec[i] = x` are reference idioms): once the host array has
-    # been handed out, the device copy of the coefficients is refreshed (16 bytes per term) before every device call.
+    # in the reference; `coeff_vec` is not (`op.coeff_vec *= -1`, `op.coeff_vec[i] = x` are reference idioms, and the constructor
+    # aliases the caller's array as the reference's np.asarray does): while anybody outside holds the host array — seen from its
+    # reference count — the device copy of the coefficients is refreshed (16 bytes per term) before every device call.
     @property
     def symp_matrix(self) -> np.ndarray:
         """bool[T, 2n] = [X | Z] as in the reference; expanded to one byte per bit only when somebody asks (a 2.5e7-term, 1000-qubit
@@ -95,14 +96,20 @@ class PauliwordOp:
     def coeff_vec(self) -> np.ndarray:
         """complex128[T] (whatever was assigned, for subclasses that keep ints).  Handing the array out ends our knowledge of its
         contents: see the note above."""
-        self._coeff_exposed = True
+        self._dev_coeff_valid = False
         return self._c()
 
     @coeff_vec.setter
     def coeff_vec(self, value) -> None:
         self._coeff = value if isinstance(value, np.ndarray) else np.asarray(value)
-        self._coeff_exposed = True
         self._dev_coeff_valid = False
+
+    def _coeff_is_private(self) -> bool:
+        """Nobody but this object can reach the host coefficient array: it owns its memory and the only references to it are our
+        attribute, the local below and getrefcount's argument (every view, memoryview or alias a caller may write through holds a
+        reference to the owning array).  CPython reference counting; a False negative only costs a 16 B/term upload."""
+        c = self._coeff
+        return isinstance(c, np.ndarray) and c.base is None and sys.getrefcount(c) <= 3
 
     def _c(self) -> np.ndarray:
         """The coefficients for READING inside this package (never mutated, never passed on by reference)."""
@@ -122,12 +129,13 @@ class PauliwordOp:
                 self._dev = kernels.DeviceOp.upload_bool(self._symp, coeff)       # packed by a ballot kernel: 10x np.packbits
             else:
                 self._dev = kernels.DeviceOp.upload(self.packed, coeff)
-            self._dev_coeff_valid = True
-        elif not rows_only and (self._coeff_exposed or not self._dev_coeff_valid) and self._coeff is not None:
+            del coeff                                             # (a second reference to the array would read as "somebody holds it")
+            self._dev_coeff_valid = self._coeff_is_private()
+        elif not rows_only and not self._dev_coeff_valid and self._coeff is not None:
             if self._dev.shared:
                 self._dev = self._dev.clone()
             self._dev.set_coeff(np.asarray(self._coeff, dtype=complex))
-            self._dev_coeff_valid = True
+            self._dev_coeff_valid = self._coeff_is_private()
         return self._dev
 
     @classmethod
@@ -135,7 +143,7 @@ class PauliwordOp:
         """A kernel's result, left where it is."""
         op = cls.__new__(cls)
         op._symp = op._packed_cache = op._coeff = None
-        op._dev, op._dev_coeff_valid, op._coeff_exposed = dev, True, False
+        op._dev, op._dev_coeff_valid = dev, True
         op.n_qubits = n_qubits
         op.n_terms = dev.n_terms
         return op
@@ -150,7 +158,7 @@ class PauliwordOp:
         op.n_qubits = n_qubits
         op.n_terms = packed.shape[0]
         op._coeff = np.asarray(coeff_vec, dtype=complex)
-        op._dev, op._dev_coeff_valid, op._coeff_exposed = None, False, True
+        op._dev, op._dev_coeff_valid = None, False
         assert op.n_terms == len(op._coeff), 'coeff list and Pauliwords not same length'
         return op
 
@@ -159,8 +167,8 @@ class PauliwordOp:
 
     def _derive(self, index=None, coeff_vec=None) -> "PauliwordOp":
         """Row selection / new coefficients without touching layouts that have not been materialised: an operator that lives on the
-        device only is indexed THERE (``symgpu_op_gather``)."""
-        if index is not None and not self._host_has_rows() and self._dev is not None:
+        device only — or is resident and large — is indexed THERE (``symgpu_op_gather``), so the selection needs no upload of its own."""
+        if index is not None and self._dev is not None and (not self._host_has_rows() or self.n_terms * self.n_qubits >= (1 << 22)):
             assert coeff_vec is None
             picked = np.arange(self.n_terms)[index].astype(np.int64).reshape(-1)
             return PauliwordOp._from_device(kernels.op_gather(self._device(), picked), self.n_qubits)
@@ -172,7 +180,7 @@ class PauliwordOp:
         coeff = self._c() if coeff_vec is None else coeff_vec
         op._coeff = np.array(coeff if index is None or coeff_vec is not None else coeff[index], dtype=complex)   # a copy: never an alias of ours
         op.n_terms = len(op._coeff)
-        op._dev, op._dev_coeff_valid, op._coeff_exposed = None, False, False
+        op._dev, op._dev_coeff_valid = None, False
         if index is None and self._dev is not None:
             op._dev = self._dev                                   # same rows: the handle is shared, its coefficients are not ours
             self._dev.shared = True

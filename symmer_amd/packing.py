@@ -62,4 +62,9 @@ def popcount_rows(packed):
     packed = np.ascontiguousarray(packed, dtype='<u8')
     if packed.shape[0] == 0:
         return np.zeros(0, dtype=np.int64)
-    return np.bitwise_count(packed).sum(axis=1, dtype=np.int64)
+    if hasattr(np, 'bitwise_count'):                                      # NumPy >= 2.0
+        return np.bitwise_count(packed).sum(axis=1, dtype=np.int64)
+    return _POP8[packed.view(np.uint8)].reshape(packed.shape[0], -1).sum(axis=1, dtype=np.int64)   # NumPy 1.x: byte table
+
+
+_POP8 = np.array([bin(v).count('1') for v in range(256)], dtype=np.uint8)

@@ -20,6 +20,7 @@ step); callers report the degraded data plane (``Communicator.degraded``).  Noth
 import os
 import ctypes
 import numpy as np
+from . import packing
 
 
 def shard_bounds(n_rows, world):
@@ -623,7 +624,7 @@ def linear_row_classes(rows, n_bits, seed=0x51A55E5):
     masks = rng.integers(0, 1 << 63, size=(n_bits, rows.shape[1]), dtype=np.uint64) ^ (rng.integers(0, 2, size=(n_bits, rows.shape[1]), dtype=np.uint64) << np.uint64(63))
     cls = np.zeros(rows.shape[0], dtype=np.int64)
     for k in range(n_bits):
-        par = np.bitwise_count(rows & masks[k][None, :]).sum(axis=1, dtype=np.int64) & 1
+        par = packing.popcount_rows(rows & masks[k][None, :]) & 1
         cls |= par << k
     return cls
 
@@ -673,12 +674,15 @@ def hash_partition_local(inner_rows, inner_coeff, outer_rows, outer_coeff, rank,
     return np.ascontiguousarray(rows, dtype='<u8'), np.ascontiguousarray(coeff), g
 
 
-def hash_partition_local_dev(inner, outer, rank, world, inner_is_left=True, zero_threshold=1e-15, stats=None, classes=None):
+def hash_partition_local_dev(inner, outer, rank, world, inner_is_left=True, zero_threshold=1e-15, stats=None, classes=None, max_pairs=None):
     """:func:`hash_partition_local` with the operands and every intermediate on the DEVICE (``csrc/partition.hip``): ``inner`` / ``outer`` are
     complete DeviceOps; sub-operands are gathered on the device, each sub-product is one indexed fused product + cleanup, the parts are ordered
     by pair index and merged there.  Only the operands' rows visit the host once, for their class bits (``classes`` = (cls_i, cls_o) skips
-    that).  Returns a DeviceOp that carries the pair index of every term's first occurrence (``kernels.op_first_index``)."""
+    that).  Returns a DeviceOp that carries the pair index of every term's first occurrence (``kernels.op_first_index``).
+    One indexed product call handles fewer than 2^32 pairs (``symgpu_mul_cleanup_indexed_dev``): a sub-product beyond ``max_pairs`` is cut
+    along its OUTER index into pieces below it — the pieces are further parts of the same merge, which orders everything by pair index."""
     from . import kernels
+    max_pairs = int(max_pairs) if max_pairs else (1 << 31)
     Ni, wq, _ = inner.info()
     No = outer.info()[0]
     G = world
@@ -700,13 +704,20 @@ def hash_partition_local_dev(inner, outer, rank, world, inner_is_left=True, zero
             if ia.size == 0 or oa.size == 0:
                 continue
             pairs_owned += ia.size * oa.size
-            sub_i = kernels.op_gather(inner, ia); sub_o = kernels.op_gather(outer, oa)
+            sub_i = kernels.op_gather(inner, ia)
             try:
-                part = kernels.mul_cleanup_indexed_dev(sub_i, sub_o, inner_is_left, None)
+                step = max(1, max_pairs // int(ia.size))                                   # outer rows per call: ia.size * step <= max_pairs < 2^32
+                for o0 in range(0, int(oa.size), step):
+                    oc = oa[o0:o0 + step]
+                    sub_o = kernels.op_gather(outer, oc)
+                    try:
+                        part = kernels.mul_cleanup_indexed_dev(sub_i, sub_o, inner_is_left, None)
+                    finally:
+                        sub_o.free()
+                    kernels.part_global_index(part, ia, oc, Ni)
+                    parts.append(part)
             finally:
-                sub_i.free(); sub_o.free()
-            kernels.part_global_index(part, ia, oa, Ni)
-            parts.append(part)
+                sub_i.free()
         key_bits = max(1, int(Ni * No - 1).bit_length())
         if parts:
             res = kernels.merge_indexed_dev(parts, key_bits, True, zero_threshold)

@@ -1,6 +1,6 @@
 # fresh process: the one-launch rotation kernel must report what it cannot do exactly, and the caller must still get the right result.
 #   weakhash: SYMGPU_HASH_WEAK_ODD=1 keeps 4 bits of the row hash -> distinct rows with equal hashes -> verification failure (code 2)
-#   timeout : SYMGPU_RES_INJECT=1 lets one workgroup leave without a word -> the all-gather times out (code 3), the path is switched off
+#   timeout : SYMGPU_ROT_RESIDENT=3 lets one workgroup leave without a word -> the all-gather times out (code 3), the path is switched off
 import os, sys, ctypes
 mode = sys.argv[1]
 if mode == 'weakhash':
@@ -32,7 +32,7 @@ first, _ = kernels.rotate_single_dev(op, qp, 0.7)               # multi-launch p
 first.free()
 assert counter(1) == 0 and counter(2) == 0
 if mode == 'timeout':
-    os.environ['SYMGPU_RES_INJECT'] = '1'
+    os.environ['SYMGPU_ROT_RESIDENT'] = '3'
 res, allc = kernels.rotate_single_dev(op, qp, 0.3)
 assert counter(2) == 1 and counter(1) == 0, (counter(1), counter(2))
 rows, coeff = res.download()
@@ -40,7 +40,9 @@ er, ec = onp.rotate_by_single_pword(symp, c, q, 0.3)
 kd, ko = np.abs(coeff) > 1e-12, np.abs(ec) > 1e-12
 assert np.array_equal(rows[kd], packing.pack_rows(er)[ko]) and np.allclose(coeff[kd], ec[ko], rtol=0, atol=1e-12)
 if mode == 'timeout':
-    os.environ.pop('SYMGPU_RES_INJECT')
+    from symmer_amd import _lib as _l
+    assert any('k_rot_resident' in t for t in _l.degraded()), _l.degraded()     # a lost fast path is visible (stderr once + symgpu_degraded)
+    os.environ.pop('SYMGPU_ROT_RESIDENT')
     r2, _ = kernels.rotate_single_dev(op, qp, 0.3)             # switched off after a time-out: multi-launch path, no new attempt
     assert counter(2) == 1 and counter(1) == 0
     os.environ['SYMGPU_ROT_RESIDENT'] = '2'                     # ... until it is asked for again

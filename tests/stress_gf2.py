@@ -11,8 +11,7 @@ n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 rng = np.random.default_rng(seed)
 bad = 0
 t0 = time.time()
-ENVS = [{}, {'SYMGPU_GF2_SPEC': '1'}, {'SYMGPU_GF2_FULL_PANEL': '0'}, {'SYMGPU_GF2_FUSED_SELECT': '0'}, {'SYMGPU_GF2_LOOKAHEAD': '0'}, {'SYMGPU_GF2_SMALL': '0'},
-        {'SYMGPU_GF2_FULL_PANEL': '0', 'SYMGPU_GF2_FUSED_SELECT': '0', 'SYMGPU_GF2_SMALL': '0'}]
+ENVS = [{}, {'SYMGPU_GF2_FUSED_SELECT': '0'}, {'SYMGPU_GF2_M4R': '0'}, {'SYMGPU_GF2_SMALL': '0'}, {'SYMGPU_GF2_FUSED_SELECT': '0', 'SYMGPU_GF2_SMALL': '0'}]
 for case in range(n_cases):
     R = int(rng.choice([1, 2, 63, 64, 65, 100, 129, 300, 700, 1500, 2500]))
     C = int(rng.choice([1, 5, 64, 65, 200, 700, 3000, 9000, 16384, 16400, 30000]))
@@ -38,7 +37,7 @@ for case in range(n_cases):
     packed = packing.pack_bits(m)
     outs = []
     for env in ENVS:
-        for k in ('SYMGPU_GF2_SPEC', 'SYMGPU_GF2_FULL_PANEL', 'SYMGPU_GF2_FUSED_SELECT', 'SYMGPU_GF2_LOOKAHEAD', 'SYMGPU_GF2_SMALL'): os.environ.pop(k, None)
+        for k in ('SYMGPU_GF2_FUSED_SELECT', 'SYMGPU_GF2_M4R', 'SYMGPU_GF2_SMALL'): os.environ.pop(k, None)
         os.environ.update(env)
         outs.append(kernels.rref(packed, want_pivots=True))
     ok = all(np.array_equal(outs[0][0], o[0]) and outs[0][1] == o[1] and np.array_equal(outs[0][2], o[2]) for o in outs[1:])

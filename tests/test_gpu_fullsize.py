@@ -155,15 +155,15 @@ def test_cfg4_symmetry_generators_full_size():
 
 
 def test_cfg4_elimination_schedules_agree_full_size(monkeypatch):
-    """BASELINE cfg4's matrix size (4000 x 54000, dense) and a sparse one of the same shape: the round-3 schedule (selectors inside
-    phase 0's launch, two-word panel window, full-row panel for sparse rows) against the separate-launch / four-word / windowed
-    schedules and the no-lookahead path — reduced matrix, pivots and reference row-XOR count identical."""
+    """BASELINE cfg4's matrix size (4000 x 54000, dense) and a sparse one of the same shape: the default schedule (selectors inside
+    phase 0's launch, two-word panel window, full-row panel for sparse rows) against its two fall-backs, the separate-launch schedule
+    (after a time-out) and the flag-per-row sweep (LDS attribute refused) — reduced matrix, pivots and reference row-XOR count identical."""
     rng = np.random.default_rng(77)
     for dens in (0.3, 0.0005):
         m = rng.random((4000, 54000)) < dens
         packed = packing.pack_bits(m)
         ref = kernels.rref(packed, want_pivots=True)
-        for env in ({'SYMGPU_GF2_SPEC': '1'}, {'SYMGPU_GF2_FUSED_SELECT': '0'}, {'SYMGPU_GF2_FULL_PANEL': '0'}, {'SYMGPU_GF2_LOOKAHEAD': '0'}):
+        for env in ({'SYMGPU_GF2_FUSED_SELECT': '0'}, {'SYMGPU_GF2_M4R': '0'}):
             for k, v in env.items(): monkeypatch.setenv(k, v)
             got = kernels.rref(packed, want_pivots=True)
             for k in env: monkeypatch.delenv(k)
@@ -295,7 +295,7 @@ def test_cleanup_flagged_key_flow_switches(mode, monkeypatch):
     rng = np.random.default_rng(4404)
     n, na, nb = 100, 2600, 2100
     if mode == 'full sort': monkeypatch.setenv('SYMGPU_CLEANUP_SUSPECTS', '0')
-    if mode == 'give up': monkeypatch.setenv('SYMGPU_CLEANUP_SUSPECTS_GIVEUP', '1')
+    if mode == 'give up': monkeypatch.setenv('SYMGPU_CLEANUP_SUSPECTS', '2')
     sa = rng.random((na, 2 * n)) < 0.3; sb = rng.random((nb, 2 * n)) < 0.3
     if mode == 'repeated rows':
         sa = sa[rng.integers(0, 400, na)]; sb = sb[rng.integers(0, 300, nb)]          # 400 x 300 distinct products, each ~45 times

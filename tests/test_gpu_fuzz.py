@@ -106,10 +106,8 @@ def test_fuzz_round2_paths(seed, monkeypatch):
     a, b = _rows(rng, N, n), _rows(rng, M, n)
     monkeypatch.setenv('SYMGPU_COMMUTE_M4R', '1')
     monkeypatch.setenv('SYMGPU_M4R_R', str(rng.choice([16, 24, 40, 48, 116])))
-    if seed % 2:
-        monkeypatch.setenv('SYMGPU_M4R_UNFUSED', '1')
     assert np.array_equal(kernels.commutes(a, b), oc.commutes(a, b))
-    for var in ('SYMGPU_COMMUTE_M4R', 'SYMGPU_M4R_R', 'SYMGPU_M4R_UNFUSED'):
+    for var in ('SYMGPU_COMMUTE_M4R', 'SYMGPU_M4R_R'):
         monkeypatch.delenv(var, raising=False)
     # (2) squared operator (duplicate-heavy every third seed): shortcut == general pair path == oracle
     T = int(rng.integers(1, 260))

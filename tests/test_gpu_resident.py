@@ -54,11 +54,21 @@ def test_square_then_multiply_moves_every_operand_once():
     r1, c1 = oc.mul(P.packed, P.coeff_vec, P.packed, P.coeff_vec)
     er, ec = oc.mul(r1, c1, Q.packed, Q.coeff_vec)
     assert np.array_equal(rows, er) and np.array_equal(coeff, ec)
-    with Traffic() as t:                                                  # the operands are resident now: nothing goes up again but P's
-        R2 = P * Q                                                        # and Q's coefficients (their host arrays are the caller's)
+    with Traffic() as t:                                                  # the operands are resident now: nothing goes up again but P's and
+        R2 = P * Q                                                        # Q's coefficients (their host arrays were handed out two lines above)
     assert t.h2d == 16 * (P.n_terms + Q.n_terms) and t.d2h == 0
+    with Traffic() as t:                                                  # nobody holds those arrays any more (reference counts): nothing moves
+        R3 = P * Q
+    assert t.h2d == 0 and t.d2h == 0
     er, ec = oc.mul(P.packed, P.coeff_vec, Q.packed, Q.coeff_vec)
-    assert np.array_equal(R2.packed, er) and np.array_equal(R2.coeff_vec, ec)
+    for R in (R2, R3):
+        assert np.array_equal(R.packed, er) and np.array_equal(R.coeff_vec, ec)
+    held = P.coeff_vec                                                    # a caller keeps the array ...
+    P * Q
+    held[0] = 3.0                                                         # ... and writes through it later: seen by the next call
+    R4 = P * Q
+    er, ec = oc.mul(P.packed, held, Q.packed, Q.coeff_vec)
+    assert np.array_equal(R4.packed, er) and np.array_equal(R4.coeff_vec, ec)
 
 
 def planted_symmetry_operator(rng, n, T, k):

@@ -184,8 +184,7 @@ def test_every_chain_form_gives_the_same_run_in_one_process(n, T, K, monkeypatch
     up.free()
     qs = packing.pack_rows(rng.random((K, 2 * n)) < 0.3)
     ks = rng.integers(0, 4, K).astype(np.int32)
-    forms = [{}, {'SYMGPU_CHAIN_REG': '0'}, {'SYMGPU_CHAIN_REG': '0', 'SYMGPU_CHAIN_LDS': '0'}, {'SYMGPU_CHAIN_REG': '0', 'SYMGPU_CHAIN_LOCAL_T': '0'},
-             {'SYMGPU_CHAIN_REG': '0', 'SYMGPU_CHAIN_LOCAL_T': '0', 'SYMGPU_CHAIN_TWO': '0'}, {'SYMGPU_CHAIN_LOCAL_T': '0'}]
+    forms = [{}, {'SYMGPU_CHAIN_REG': '0'}, {'SYMGPU_CHAIN_REG': '0', 'SYMGPU_CHAIN_LOCAL_T': '0'}, {'SYMGPU_CHAIN_LOCAL_T': '0'}]
     results = []
     for env in forms:
         for k, v in env.items():
