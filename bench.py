@@ -782,7 +782,7 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
     counted).  Every section runs on its own: one that fails reports its error and the others still run."""
     import types
     lib = _lib.lib()
-    from symmer_amd.operators import PauliwordOp
+    from symmer_amd.operators import PauliwordOp, check_independent
     from symmer_amd import packing
     ex = {}
 
@@ -938,6 +938,24 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
         ex['cfg4_symmetry_kernel'] = {'rows': 4000, 'cols': 54000, 'generators_found': line['config']['generators_found'], 'row_xors': line['config']['row_xors_per_step'],
                                       'seconds': line['ms_per_step'] * 1e-3, 'row_xors_per_s': line['value'], 'roofline': line['roofline'], 'api': line.get('api')}
 
+    def f2_generator_reconstruction():
+        # SURVEY 8f row f2 at cfg4's operator size: 50,000 terms on 2,000 qubits reconstructed in 60 independent generators
+        # (PauliwordOp.generator_reconstruction, base.py:523-560) and the generators of a 20,000-term operator (base.py:1436-1456)
+        n2, T2, g2 = 2000, 50000, 60
+        Mop = host_operator(T2, n2, 4004)
+        Gop = host_operator(g2, n2, 4005)
+        Mop.generator_reconstruction(Gop)
+        t_rec = timed(lambda: Mop.generator_reconstruction(Gop), 3)
+        t_ci = timed(lambda: check_independent(Gop), 5)
+        sub = Mop[:20000]
+        sub._device()
+        t0 = time.perf_counter(); gens = PauliwordOp._from_device(kernels.generators_dev(sub._device()), n2); kernels.sync(); t_gen = time.perf_counter() - t0
+        ex['f2_generator_reconstruction'] = {'terms': T2, 'n_qubits': n2, 'generators': g2, 'matrix': [2 * n2, g2 + T2],
+                                             'seconds_generator_reconstruction': t_rec, 'seconds_check_independent': t_ci,
+                                             'generators_of_20000_terms': {'seconds': t_gen, 'rank': gens.n_terms},
+                                             'call': 'M.generator_reconstruction(G) -> (int64 [50000, 60], bool [50000]) on the host; operands resident, '
+                                                     'transposed stack built / reduced / read out on the device (csrc/genrec.hip)'}
+
     def readme_claim1_clifford_circuit():
         # reference README.md:50-51: "expectation value of a 1,000-qubit Clifford circuit of depth 2,000" — CircuitSymmerlator: 2,000
         # random H / S / CX gates (4,000 single-Pauli rotations), a 64-term observable, evaluate() = <0| U^+ O U |0>
@@ -997,7 +1015,7 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
                                             'seconds_operands_resident': t_dev, 'terms_out': R.n_terms,
                                             'call': 'PauliwordOp * PauliwordOp (Python API)'}
 
-    for fn in (strong_scaling_shard, cfg1_api_mul, cfg3_mul_cleanup, cfg2_rotation, cfg5_adjacency, cfg4_symmetry_kernel, readme_claim1_clifford_circuit, readme_claim3_square_1000q_500t, readme_claim4_wide_product):
+    for fn in (strong_scaling_shard, cfg1_api_mul, cfg3_mul_cleanup, cfg2_rotation, cfg5_adjacency, cfg4_symmetry_kernel, f2_generator_reconstruction, readme_claim1_clifford_circuit, readme_claim3_square_1000q_500t, readme_claim4_wide_product):
         section(fn)
     return ex
 

@@ -209,6 +209,19 @@ int symgpu_symmetry_kernel(const uint64_t *H, int64_t M, int n_qubits, int Wq,
 int symgpu_symmetry_kernel_dev(symgpu_op_t H, int n_qubits, uint64_t *out, int64_t capacity, int64_t *k,
                                int64_t *xor_count);
 
+/* ---- f2: generator routines on packed rows, device side (csrc/genrec.hip) ------------------------------------------------
+ * symgpu_op_gf2_rank   rank over GF(2) of the operator's symplectic rows = number of non-zero rows of _rref_binary(symp_matrix)
+ *   (utils.py:292-315); check_independent (utils.py:504-519) is `rank == T`.
+ * symgpu_generators_dev   PauliwordOp.generators (base.py:1436-1456): the non-zero rows of _rref_binary(symp_matrix), in row order, with
+ *   coefficient 1 — a new resident operator.
+ * symgpu_generator_reconstruction_dev   PauliwordOp.generator_reconstruction (base.py:523-560): reduced = cref_binary(vstack([G, M]))
+ *   (utils.py:349-359); recon_host int64 [T][g] = reduced[g:, :g] (the reference returns .astype(int)), mask_host uint8 [T] =
+ *   all(~reduced[g:, g:], axis=1).  g = G's terms (1 <= g <= 2n), T = M's terms (>= 1).  The transposed stack is built bit-packed on the
+ *   device, reduced by the blocked elimination and read out in pivot order: no one-byte-per-bit matrix on either side. */
+int symgpu_op_gf2_rank(symgpu_op_t op, int64_t *rank);
+int symgpu_generators_dev(symgpu_op_t op, symgpu_op_t *out);
+int symgpu_generator_reconstruction_dev(symgpu_op_t G, symgpu_op_t M, int n_qubits, int64_t *recon_host, uint8_t *mask_host);
+
 /* ---- f3 / f4: the callers next to the hot path, device side -----------------------------------------------------------
  * symgpu_project_dev   S3Projection._perform_projection (symmer/projection/base.py:44-84) on an operator that has already been taken
  *   through the stabiliser rotations: terms that anticommute with any of the k fixed (single-qubit) stabiliser rows vanish; the others

@@ -335,3 +335,49 @@ def lex_order(symp):
     if symp.shape[0] == 0:
         return np.zeros(0, dtype=np.int64)
     return np.lexsort(symp.T)
+
+
+def check_adjmat_noncontextual(adjmat):
+    """utils.py:567-589: terms that do not commute with every term must split into cliques — the unique rows of the adjacency matrix
+    restricted to those terms have to be disjoint."""
+    adjmat = np.asarray(adjmat, dtype=bool)
+    non_universal = np.where(~np.all(adjmat, axis=1))[0]
+    unique_rows = np.unique(adjmat[non_universal, :][:, non_universal], axis=0)
+    return bool(np.all(np.count_nonzero(unique_rows, axis=0) == 1))
+
+
+def is_noncontextual(symp):
+    """base.py:1074-1088: fewer than four terms are always noncontextual, otherwise the test on the adjacency matrix."""
+    symp = np.asarray(symp, dtype=bool)
+    if symp.shape[0] < 4:
+        return True
+    return check_adjmat_noncontextual(commutes_termwise(symp, symp))
+
+
+def sort_order(symp, coeff, by='magnitude', key='decreasing'):
+    """Term order of ``PauliwordOp.sort`` (base.py:455-492): the same NumPy sorts on the same score vectors."""
+    symp = np.asarray(symp, dtype=bool)
+    n = symp.shape[1] // 2
+    X, Z = symp[:, :n].astype(int), symp[:, n:].astype(int)
+    if by == 'magnitude':
+        order = np.argsort(-abs(np.asarray(coeff)))
+    elif by == 'lex':
+        order = np.lexsort(symp.T)
+    elif by == 'weight':
+        order = np.argsort(-np.sum(symp.astype(int), axis=1))
+    elif by == 'support':
+        occ = np.ascontiguousarray(np.logical_or(symp[:, :n], symp[:, n:]))
+        order = np.argsort(occ.view(np.dtype((np.void, occ.dtype.itemsize * occ.shape[1]))).ravel())[::-1]
+    elif by == 'Z':
+        order = np.argsort(np.sum((n + 1) * X + Z, axis=1))
+    elif by == 'X':
+        order = np.argsort(np.sum(X + (n + 1) * Z, axis=1))
+    elif by == 'Y':
+        order = np.argsort(np.sum(abs(X - Z), axis=1))
+    else:
+        raise ValueError('Only permitted sort by values are magnitude, weight, X, Y or Z')
+    if key == 'increasing':
+        order = order[::-1]
+    elif key != 'decreasing':
+        raise ValueError('Only permitted sort by values are increasing or decreasing')
+    return order

@@ -91,6 +91,9 @@ SIGNATURES = {
     'symgpu_rref_dev': [P, c_i64, c_i64, P, P],
     'symgpu_symmetry_kernel': [P, c_i64, c_int, c_int, P, c_i64, P, P],
     'symgpu_symmetry_kernel_dev': [P, c_int, P, c_i64, P, P],
+    'symgpu_op_gf2_rank': [P, P],
+    'symgpu_generators_dev': [P, PP],
+    'symgpu_generator_reconstruction_dev': [P, P, c_int, P, P],
     'symgpu_project_dev': [P, P, c_int, P, P, c_int, c_int, c_dbl, c_int, PP, P],
     'symgpu_noncontextual_dev': [P, P],
     'symgpu_state_inner_dev': [P, P, P],

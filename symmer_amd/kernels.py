@@ -397,6 +397,30 @@ def symmetry_kernel_handle(op, n_qubits):
     return out[:k.value].copy(), count.value
 
 
+# ---- f2: generator routines on resident operators (csrc/genrec.hip) -----------------------------------------------------
+def gf2_rank_dev(op):
+    """Rank over GF(2) of the operator's symplectic rows (= non-zero rows of ``_rref_binary``, utils.py:292-315)."""
+    r = c_i64(0)
+    check(_lib.lib().symgpu_op_gf2_rank(op.handle, ctypes.addressof(r)))
+    return r.value
+
+
+def generators_dev(op):
+    """``PauliwordOp.generators`` (base.py:1436-1456) -> new DeviceOp: non-zero rows of ``_rref_binary(symp_matrix)``, coefficients 1."""
+    out = ctypes.c_void_p()
+    check(_lib.lib().symgpu_generators_dev(op.handle, ctypes.byref(out)))
+    return DeviceOp(out)
+
+
+def generator_reconstruction_dev(gens, op, n_qubits):
+    """``PauliwordOp.generator_reconstruction`` (base.py:523-560) of ``op`` in ``gens`` -> (int64[T, g], bool[T])."""
+    g, t = gens.info()[0], op.info()[0]
+    recon = np.empty((t, g), dtype=np.int64)
+    mask = np.empty(t, dtype=np.uint8)
+    check(_lib.lib().symgpu_generator_reconstruction_dev(gens.handle, op.handle, int(n_qubits), addr(recon), addr(mask)))
+    return recon, mask.view(np.bool_)
+
+
 # ---- f3 / f4 (SURVEY 8f): projection, noncontextuality test, state inner product -------------------------------------------------
 def project_dev(op, stab_rows, eigenvalues, keep_qubits, n_qubits, zero_threshold=1e-15):
     """``S3Projection._perform_projection`` (projection/base.py:44-84) on a device operator: ``stab_rows`` uint64[k, 2*Wq] the fixed

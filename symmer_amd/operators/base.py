@@ -669,10 +669,14 @@ class PauliwordOp:
     # ---- a10 / f2: GF(2) generator routines (same device kernel as a8) ----------------------------------------
     @cached_property
     def generators(self) -> "PauliwordOp":
-        """base.py:1436-1456: non-zero rows of ``_rref_binary(symp_matrix)``."""
-        row_red = _rref_binary(self.symp_matrix)
-        non_zero_rows = row_red[np.sum(row_red, axis=1).astype(bool)]
-        gens = PauliwordOp(non_zero_rows, np.ones(non_zero_rows.shape[0], dtype=complex))
+        """base.py:1436-1456: non-zero rows of ``_rref_binary(symp_matrix)`` — the packed rows are reduced on the device as they are (the
+        column order x_0 .. x_{n-1}, z_0 .. z_{n-1} is the packed bit order; padding bits never become pivots): no bool matrix."""
+        if self.n_terms == 0 or self.n_qubits == 0:
+            row_red = _rref_binary(self.symp_matrix)
+            non_zero_rows = row_red[np.sum(row_red, axis=1).astype(bool)]
+            gens = PauliwordOp(non_zero_rows, np.ones(non_zero_rows.shape[0], dtype=complex))
+        else:
+            gens = PauliwordOp._from_device(kernels.generators_dev(self._device(rows_only=True)), self.n_qubits)
         assert check_independent(gens), 'generators are not independent'
         assert gens.n_terms <= 2 * self.n_qubits, 'cannot have an independent generating set of size greaterthan 2 time num qubits'
         return gens
@@ -682,6 +686,10 @@ class PauliwordOp:
         if not override_independence_check:
             assert check_independent(generators), 'Supplied generators are algebraically dependent'
         dim = generators.n_terms
-        reduced = cref_binary(np.vstack([generators.symp_matrix, self.symp_matrix]))
-        mask = np.all(~reduced[dim:, dim:], axis=1)
-        return reduced[dim:, :dim].astype(int), mask
+        assert self.n_qubits == generators.n_qubits, 'Pauliwords defined for different number of qubits'
+        if dim == 0 or self.n_terms == 0 or self.n_qubits == 0 or dim > 2 * self.n_qubits:
+            reduced = cref_binary(np.vstack([generators.symp_matrix, self.symp_matrix]))     # degenerate shapes: host glue around the device rref
+            mask = np.all(~reduced[dim:, dim:], axis=1)
+            return reduced[dim:, :dim].astype(int), mask
+        # the transposed stack is built, reduced and read out in pivot order on the device (csrc/genrec.hip): neither operand is expanded
+        return kernels.generator_reconstruction_dev(generators._device(rows_only=True), self._device(rows_only=True), self.n_qubits)

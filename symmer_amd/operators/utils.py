@@ -117,8 +117,10 @@ def check_independent(operators) -> bool:
         return False
     if operators.n_terms == 0:
         return True
-    red = _rref_binary(operators.symp_matrix)
-    return bool(~np.any(np.all(~red, axis=1)))
+    if operators.n_qubits == 0:
+        return False                                               # a term without qubits is a zero row
+    # no zero row in _rref_binary(symp_matrix) <=> full row rank; the rank comes from the packed rows on the device (csrc/genrec.hip)
+    return kernels.gf2_rank_dev(operators._device(rows_only=True)) == operators.n_terms
 
 
 # ---- f4: noncontextuality test on the device-computed adjacency matrix (reference utils.py:567-589) --------------

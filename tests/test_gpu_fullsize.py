@@ -561,3 +561,39 @@ def test_bench_workloads_of_the_other_baseline_configs(workload, metric, kernel)
         assert d['config']['terms'] == 100000 and 1.4e5 < d['config']['terms_out'] <= 1.5e5 and r['launches'] == 100
     if workload == 'gf2':
         assert d['config']['generators_found'] == 32 and d['config']['matrix'] == [4000, 54000] and 7e6 < d['config']['row_xors_per_step'] < 9e6
+
+
+def test_f2_generator_reconstruction_full_size_against_the_c_oracle():
+    """SURVEY 8f row f2 at cfg4's operator size: 50,000 terms on 2,000 qubits reconstructed in 60 independent generators — the device builds
+    the transposed [4000 x 50,060] stack bit-packed, reduces it and reads (R, mask) out in pivot order (csrc/genrec.hip).  Expected values: the
+    reference's lines (base.py:552-560, utils.py:317-359) on the C oracle's _rref_binary of the same packed matrix.  Neither operand is ever
+    expanded to one byte per bit on the product's side.  Then PauliwordOp.generators of a 20,000-term operator against the C oracle's rref."""
+    rng = np.random.default_rng(4004)
+    n, T, g = 2000, 50000, 60
+    gens = rng.random((g, 2 * n)) < 0.3
+    combos = rng.random((T, g)) < 0.2
+    inside = (combos.astype(np.float32) @ gens.astype(np.float32)) % 2 == 1
+    symp = np.where((np.arange(T) % 2 == 0)[:, None], inside, rng.random((T, 2 * n)) < 0.3)          # even terms in the span, odd terms outside
+    del inside
+    G = PauliwordOp._from_packed(packing.pack_rows(gens), n, np.ones(g))
+    M = PauliwordOp._from_packed(packing.pack_rows(symp), n, np.ones(T))
+    R, mask = M.generator_reconstruction(G)
+    assert G._symp is None and M._symp is None, 'an operand was expanded to one byte per bit'
+    assert R.shape == (T, g) and R.dtype == np.int64 and mask.shape == (T,)
+    # the reference's lines, with the C oracle's _rref_binary
+    stack_t = packing.pack_bits(np.vstack([gens, symp]).T)                                           # [4000, ceil(50060 / 64)]
+    red, _, piv = oc.rref(stack_t, want_pivots=True)
+    has = np.flatnonzero(piv >= 0)
+    order = np.concatenate([has[np.argsort(piv[has], kind='stable')], np.flatnonzero(piv < 0)])
+    reduced = packing.unpack_bits(red[order], g + T).T                                               # cref_binary(vstack([G, M]))
+    assert np.array_equal(R, reduced[g:, :g].astype(int))
+    assert np.array_equal(mask, np.all(~reduced[g:, g:], axis=1))
+    assert np.array_equal(mask, np.arange(T) % 2 == 0), 'exactly the terms built from the generators are reconstructed'
+    assert np.array_equal(R[mask], combos[mask].astype(int)), 'independent generators: the reconstruction is the combination the term was built from'
+    del reduced, red, stack_t
+    # generators of a tall operator: 20,000 terms, rank 2n = 4,000
+    sub = M[:20000]
+    gen_op = sub.generators
+    ered, _, epiv = oc.rref(packing.pack_rows(symp[:20000]), want_pivots=True)
+    assert gen_op.n_terms == int((epiv >= 0).sum()) == 4000
+    assert np.array_equal(gen_op.packed, ered[epiv >= 0])

@@ -168,3 +168,22 @@ def test_squared_builder_equals_oracle_mul():
         er, ec = oc.mul(A, c, A, c)
         o, i, cc = squared_expected(A, c)
         assert np.array_equal(A[i] ^ A[o], er) and np.array_equal(cc, ec)
+
+
+@pytest.mark.parametrize('case', family('noncontextual'))
+def test_noncontextual_golden(case):
+    """tests/golden/noncontextual.npz (oracle/tools/gen_golden_noncontextual.py): the reference's is_noncontextual (base.py:1074-1088)
+    and check_adjmat_noncontextual (utils.py:567-589) on random, clique-structured, all-commuting, duplicate-row and tiny operators."""
+    symp = as_bool(case['symp'])
+    assert onp.is_noncontextual(symp) == bool(case['is_noncontextual'])
+    assert onp.check_adjmat_noncontextual(onp.commutes_termwise(symp, symp)) == bool(case['adjmat_noncontextual'])
+
+
+@pytest.mark.parametrize('case', [c for c in family('api_glue') if int(c['kind']) == 0])
+def test_sort_orders_golden(case):
+    """tests/golden/api_glue.npz: the oracle's restatement of sort (base.py:455-492) reproduces the reference's term orders."""
+    symp, coeff = as_bool(case['in_symp']), case['in_coeff']
+    for by in ('magnitude', 'lex', 'weight', 'support', 'Z', 'X', 'Y'):
+        for key in ('decreasing', 'increasing'):
+            order = onp.sort_order(symp, coeff, by, key)
+            assert np.array_equal(symp[order], as_bool(case[f'sort_{by}_{key}_symp'])) and np.array_equal(coeff[order], case[f'sort_{by}_{key}_coeff']), (by, key)
