@@ -64,6 +64,8 @@ def parse():
     ap.add_argument('--adj-qubits', type=int, default=2000)
     ap.add_argument('--adj-slab-rows', type=int, default=0, help='adjacency: rows per launch / output slab (0: as many as a quarter of the free HBM holds)')
     ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--single-process', action='store_true', help='drive all --gpus devices from THIS process (symgpu_init_all + grouped RCCL all-gather); '
+                    'the default whenever --gpus > 1 and no launcher has set WORLD_SIZE')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-api', action='store_true', help='skip the `api` objects (the reference\'s call spelling timed on the drop-in classes)')
     ap.add_argument('--cpu-full', action='store_true', help='gf2: time the CPU restatement on the full 4000 x 54000 matrix (~70 s) instead of citing the cached run')
@@ -82,6 +84,11 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if world == 1 and (args.single_process or (args.gpus > 1 and 'WORLD_SIZE' not in os.environ)):
+        # no launcher: ONE process drives all devices — same workload, same contract line
+        out = single_process_product(args)
+        print(json.dumps(out))
+        return
 
     from symmer_amd import _lib, kernels
     from symmer_amd.kernels import DeviceOp
@@ -257,6 +264,89 @@ def main():
         out['degraded_kernels'] = _lib.degraded()         # fast paths that gave up in this process (in-kernel wait timed out): [] on a healthy box
         print(json.dumps(out))
     comm.hard_exit_if_hung()
+
+
+def single_process_product(args):
+    """The north-star product with `--gpus N` devices driven by ONE process (symmer_amd/multi.py's HipBackend: symgpu_init_all, one stream
+    per device, ncclCommInitAll, the per-device all-gathers of a step issued from this thread as one RCCL group).  Per step and device: the
+    grouped all-gather of the right operand's 1/N shards, then the product of the device's own 1e5 left terms against all right terms in
+    output slabs; the launches of a slab go to every device before the next slab starts, so the devices run side by side.  Weak scaling,
+    `value` = all devices' pairs / wall time between two all-device synchronisations."""
+    from symmer_amd import _lib, multi, parallel
+    from symmer_amd.kernels import DeviceOp
+    G = max(1, args.gpus)
+    if G == 1:
+        os.environ.setdefault('SYMGPU_FORCE_COMM', '1')             # one device: still through ncclCommInitAll and the grouped all-gather
+    if _lib.device_count() < G:
+        return {'metric': 'pauli_term_pairs_per_sec', 'value': None, 'unit': 'pairs/s', 'n_gpus': G, 'steps': args.steps, 'warmup': args.warmup,
+                'error': f'--gpus {G} in one process but only {_lib.device_count()} device(s) visible', 'config': {'workload': 'allpairs_product'}}
+    be = multi.HipBackend(G)
+    lib = _lib.load()
+    n, Ni, M = args.qubits, args.left_terms, args.right_terms
+    wq = (n + 63) // 64
+    ts, bounds = parallel.shard_bounds(M, G)
+    slab = max(1, min(args.slab_rows, M))
+    lefts, shards, fulls, rings = [], [], [], []
+    for d in range(G):
+        be.use(d)
+        lefts.append(DeviceOp.random(Ni, n, 0.3, seed=1234 + 7919 * d))
+        sh = DeviceOp.random(ts, n, 0.3, seed=99991 + d); sh.set_rows(bounds[d][1] - bounds[d][0])
+        shards.append(sh)
+        fulls.append(DeviceOp.alloc(ts * G, wq, with_coeff=True))
+        rings.append([DeviceOp.alloc(slab * Ni, wq, with_coeff=True) for _ in range(2)])
+
+    def sync_all():
+        for d in range(G):
+            be.use(d)
+            _lib.check(lib.symgpu_device_sync())
+
+    def step():
+        be.allgather(shards, fulls, M)
+        k = 0
+        for o0 in range(0, M, slab):
+            o1 = min(M, o0 + slab)
+            for d in range(G):
+                _lib.check(lib.symgpu_mul_allpairs_dev(lefts[d].handle, fulls[d].handle, o0, o1, 1, rings[d][k & 1].handle))   # runs on the handles' device
+            k += 1
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    for d in range(G):
+        be.use(d); _lib.check(lib.symgpu_prof_enable(0, 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    n_launch, tot_ms = 0, 0.0
+    for d in range(G):
+        be.use(d); _lib.check(lib.symgpu_prof_enable(0, 0))
+        nl, ms = prof_read(_lib, 0)
+        n_launch += nl; tot_ms += ms
+    launch_ms = tot_ms / max(1, n_launch)
+    launch_pairs = G * Ni * M * args.steps / max(1, n_launch)
+    achieved = launch_pairs * 16 * wq / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    out = {'metric': 'pauli_term_pairs_per_sec', 'value': G * Ni * M * args.steps / dt, 'unit': 'pairs/s', 'n_gpus': G, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u64',
+           'data': 'synthetic',
+           'config': {'workload': 'allpairs_product', 'n_qubits': n, 'left_terms_per_gpu': Ni, 'right_terms': M, 'pairs_per_step': G * Ni * M,
+                      'bytes_per_pair': 16 * wq + 16, 'slab_rows': slab,
+                      'parallelism': f'ONE process driving {G} device(s): left-axis shard, grouped all-gather of right rows '
+                                     f'({"rccl (ncclCommInitAll + ncclGroupStart/End)" if be.degraded is None else "host-staged"})'},
+           'roofline': {'bound': 'hbm', 'kernel': 'k_mul_rows_e', 'bytes_per_pair': 16 * wq, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'launches': n_launch, 'avg_launch_ms': launch_ms,
+                        'algorithmic_bytes_per_launch': launch_pairs * 16 * wq, 'note': 'per-launch HIP events on every device\'s own stream, averaged over the devices',
+                        'whole_step_GBps_per_gpu': Ni * M * (16 * wq + 16) / (dt / args.steps) / 1e9},
+           'degraded_kernels': _lib.degraded()}
+    if be.degraded:
+        out['degraded'] = be.degraded
+    traffic_from_profile(out['roofline'], TRAFFIC_PROFILE, ['product.hip'], {'n_qubits': n, 'left_terms_per_gpu': Ni, 'right_terms': M, 'slab_rows': slab})
+    if not args.no_cpu:
+        try:
+            out['cpu_baseline'] = cpu_baseline(n)
+        except Exception as exc:                                      # noqa: BLE001
+            out['cpu_baseline'] = {'error': f'{type(exc).__name__}: {exc}'}
+    return out
 
 
 def collective_hang(exc, args, rank, world):

@@ -14,8 +14,9 @@
  *  - GF(2) matrices: R rows of Wc uint64 words, same bit rule; "leftmost column" = lowest set bit of the
  *    first non-zero word.
  *  - coefficients: complex128 as interleaved double[2] (re, im).
- *  - one context per process (one process per GPU); calls are serialised on one HIP stream; a handle is
- *    single-owner.  Multi-GPU = one process per device + symgpu_comm_* (RCCL over xGMI).
+ *  - one context per DEVICE; calls on a device are serialised on its HIP stream; a handle is single-owner and belongs to
+ *    the device it was created on.  Multi-GPU = one process per device (symgpu_init + symgpu_comm_*, RCCL over xGMI) or one
+ *    process driving several devices (symgpu_init_all + symgpu_set_device + symgpu_comm_init_all).
  */
 #ifndef SYMGPU_H
 #define SYMGPU_H
@@ -37,8 +38,19 @@ extern "C" {
 typedef struct symgpu_op_s *symgpu_op_t; /* device-resident operator: packed rows (+ optional coefficients) */
 
 /* ---- context -------------------------------------------------------------------------------- */
-int symgpu_init(int device);              /* select device, create stream; idempotent for the same device */
-int symgpu_shutdown(void);
+#define SYMGPU_MAX_DEVICES 16
+int symgpu_init(int device);              /* create the device's context (stream, allocator) if needed and make it the calling thread's current device */
+/* Single-process multi-device mode ("one host process ... driving <= 8 devices — no MPI launcher needed"): contexts for devices
+ * 0 .. n-1 (n <= 0: all visible), peer access between them.  A host thread has a CURRENT device (symgpu_set_device; initially the first
+ * device initialised): uploads, allocations and every call without a handle go there.  A call that takes handles runs on the handles'
+ * device whatever the current one is, and refuses handles of different devices (SYMGPU_E_INVALID) — symgpu_op_copy_rows is the one call
+ * that crosses devices (peer copy over xGMI).  Each device has its own stream; calls on different devices overlap, so one thread can
+ * launch a block of an all-pairs kernel on every device and then collect the results. */
+int symgpu_init_all(int n_devices);
+int symgpu_set_device(int device);
+int symgpu_current_device(int *device);
+int symgpu_n_initialised(int *n);          /* number of devices with a context in this process */
+int symgpu_shutdown(void);                 /* all devices */
 const char *symgpu_last_error(void);
 int symgpu_device_count(int *n);          /* does not initialise a device */
 int symgpu_sync(void);                    /* wait for the library stream */
@@ -250,6 +262,11 @@ int symgpu_comm_abandon(void);
  * (capacity >= nranks * shard rows); rank r's rows land at [r*T_shard, (r+1)*T_shard). */
 int symgpu_comm_allgather_op(symgpu_op_t shard, symgpu_op_t full);
 int symgpu_comm_barrier(void);
+/* The same all-gather for ONE process that drives n devices (symgpu_init_all): one communicator per device (ncclCommInitAll); shards[d] and
+ * fulls[d] live on device d, every shard has the same capacity Ts, device d's rows land at [d * Ts, (d + 1) * Ts) of every full operator.
+ * The n all-gathers are enqueued from the calling thread as one RCCL group (ncclGroupStart / ncclGroupEnd), each on its device's stream. */
+int symgpu_comm_init_all(int n_devices);
+int symgpu_comm_allgather_ops(const symgpu_op_t *shards, const symgpu_op_t *fulls, int n);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,10 @@ PP = ctypes.POINTER(ctypes.c_void_p)
 SIGNATURES = {
     'symgpu_init': [c_int],
     'symgpu_shutdown': [],
+    'symgpu_init_all': [c_int],
+    'symgpu_set_device': [c_int],
+    'symgpu_current_device': [P],
+    'symgpu_n_initialised': [P],
     'symgpu_device_count': [P],
     'symgpu_sync': [],
     'symgpu_device_sync': [],
@@ -104,6 +108,8 @@ SIGNATURES = {
     'symgpu_comm_abandon': [],
     'symgpu_comm_allgather_op': [P, P],
     'symgpu_comm_barrier': [],
+    'symgpu_comm_init_all': [c_int],
+    'symgpu_comm_allgather_ops': [P, P, c_int],
 }
 
 _lib = None
@@ -170,6 +176,17 @@ def init(device=None):
     check(lib.symgpu_init(device % n))
     _initialised_device = device % n
     return _initialised_device
+
+
+def set_device(device):
+    """Make ``device`` the calling thread's current device (its context is created on first use)."""
+    check(load().symgpu_set_device(int(device)))
+
+
+def current_device():
+    d = c_int(-1)
+    check(load().symgpu_current_device(ctypes.addressof(d)))
+    return d.value
 
 
 def lib():

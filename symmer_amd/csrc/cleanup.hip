@@ -30,7 +30,6 @@ static u64 host_splitmix64(u64 &s) {
 }
 
 i64 g_hash_reseeds = 0;                // statistics (symgpu_debug_counter 0)
-static std::vector<u64> g_host_tab;   // host copy of the device tables (to hash single rows, e.g. a rotation's Q)
 // k_hash_rows_long: columns of M^(2^j), M = the xorshift step of the per-lane Horner scheme (a linear map on GF(2)^64), j < 32
 static u64 host_xorshift_step(u64 h) { h ^= h << 13; h ^= h >> 7; h ^= h << 17; return h; }
 static int ensure_xs_pow() {
@@ -76,12 +75,13 @@ int ensure_hash_tables(u64 seed) {
     HIP_TRY(hipMemcpyAsync(c.hash_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, c.stream));
     HIP_TRY(hipStreamSynchronize(c.stream));   // tab is a host temporary
     c.hash_seed = seed;
-    g_host_tab = tab;
+    c.host_hash_tab = tab;
     return SYMGPU_OK;
 }
 
 // host evaluation of the same linear hash h1 as k_hash_rows (per-lane Horner over 64-word blocks, XOR over lanes)
 u64 host_row_hash(const u64 *row, int W) {
+    const std::vector<u64> &tab = ctx().host_hash_tab;
     const int n_blk = (W + 63) / 64;
     u64 h = 0;
     for (int g = 0; g < 64; ++g) {
@@ -91,7 +91,7 @@ u64 host_row_hash(const u64 *row, int W) {
             u64 a1 = 0;
             if (w < W) {
                 const u64 x = row[w];
-                for (int k = 0; k < 8; ++k) a1 ^= g_host_tab[((size_t)k * 256 + ((x >> (8 * k)) & 255)) * 2];
+                for (int k = 0; k < 8; ++k) a1 ^= tab[((size_t)k * 256 + ((x >> (8 * k)) & 255)) * 2];
             }
             hg ^= hg << 13; hg ^= hg >> 7; hg ^= hg << 17;
             const int r = g & 63;
@@ -1700,14 +1700,14 @@ using namespace symgpu;
 extern "C" {
 
 int symgpu_cleanup_dev(symgpu_op_t in, double thr, int use_thr, symgpu_op_t *out) {
-    SG_TRY(require_ctx());
+    SG_ENTER(in);
     SG_REQUIRE(in && out, "cleanup_dev: null handle");
     SG_REQUIRE(in->coeff || in->T == 0, "cleanup_dev: operator has no coefficients");
     return cleanup_core(in->rows, in->coeff, in->T, 2 * in->Wq, nullptr, 0, nullptr, 0, thr, use_thr, out, in->Wq, nullptr, nullptr, 1);
 }
 
 int symgpu_mul_cleanup_dev(symgpu_op_t inner, symgpu_op_t outer, int inner_is_left, double thr, int use_thr, symgpu_op_t *out) {
-    SG_TRY(require_ctx());
+    SG_ENTER(inner, outer);
     SG_REQUIRE(inner && outer && out, "mul_cleanup_dev: null handle");
     SG_REQUIRE(inner->Wq == outer->Wq, "mul_cleanup_dev: operands must share Wq");
     const i64 Ni = inner->T, No = outer->T;
@@ -1722,14 +1722,14 @@ int symgpu_mul_cleanup_dev(symgpu_op_t inner, symgpu_op_t outer, int inner_is_le
 // The same two calls, with the first-occurrence index of every output term kept on the result (symgpu_op_first_index): what a caller needs
 // to merge cleaned partial results of ONE product in the reference's order (symmer_amd/parallel.py: hash-partitioned multi-GPU cleanup).
 int symgpu_cleanup_indexed_dev(symgpu_op_t in, double thr, int use_thr, symgpu_op_t *out) {
-    SG_TRY(require_ctx());
+    SG_ENTER(in);
     SG_REQUIRE(in && out, "cleanup_indexed_dev: null handle");
     SG_REQUIRE(in->coeff || in->T == 0, "cleanup_indexed_dev: operator has no coefficients");
     return cleanup_core(in->rows, in->coeff, in->T, 2 * in->Wq, nullptr, 0, nullptr, 0, thr, use_thr, out, in->Wq, nullptr, nullptr, 1, true);
 }
 
 int symgpu_mul_cleanup_indexed_dev(symgpu_op_t inner, symgpu_op_t outer, int inner_is_left, double thr, int use_thr, symgpu_op_t *out) {
-    SG_TRY(require_ctx());
+    SG_ENTER(inner, outer);
     SG_REQUIRE(inner && outer && out, "mul_cleanup_indexed_dev: null handle");
     SG_REQUIRE(inner->Wq == outer->Wq, "mul_cleanup_indexed_dev: operands must share Wq");
     const i64 Ni = inner->T, No = outer->T;
@@ -1742,7 +1742,7 @@ int symgpu_mul_cleanup_indexed_dev(symgpu_op_t inner, symgpu_op_t outer, int inn
 }
 
 int symgpu_op_first_index(symgpu_op_t op, uint64_t *first_host, int64_t capacity) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     SG_REQUIRE(op && (first_host || op->T == 0), "op_first_index: null argument");
     SG_REQUIRE(op->first || op->T == 0, "op_first_index: the operator does not come from an *_indexed cleanup");
     if (capacity < op->T) { set_error("op_first_index: capacity %lld < %lld rows", (long long)capacity, (long long)op->T); return SYMGPU_E_CAPACITY; }

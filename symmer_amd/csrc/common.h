@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
+#include <vector>
 #include "../../include/symgpu.h"
 
 typedef uint64_t u64;
@@ -60,6 +61,7 @@ struct Context {
     // linear-hash tables (cleanup): 8 byte positions x 256 values x {h1,h2}; reseeded on collision
     u64 *hash_tab = nullptr;       // device, [8][256][2]
     u64 hash_seed = 0;
+    std::vector<u64> host_hash_tab;  // host copy of hash_tab (to hash single rows, e.g. a rotation's Q, with the SAME device's tables)
     u64 *xs_pow = nullptr;         // device, [32][64]: columns of M^(2^j), M = the hash's xorshift step (k_hash_rows_long, cleanup.hip)
     // rotation hash join (rotate.hip): persistent open-addressing table of [tag 32 | generation 10 | row index + 1 : 22] entries.
     // An entry of another generation is empty, so the table is cleared once per 1023 rotations instead of once per rotation.
@@ -82,13 +84,38 @@ struct Context {
     bool sort_coop_disabled = false;
     u32 *sort_scan_ticket = nullptr;   // radix sort: "last workgroup finishes the scan" ticket, zero between launches
     bool res_disabled = false;     // a barrier timed out once (workgroups not co-resident): the process keeps to the multi-launch paths
+    u32 res_finished_base = 0, res_host_tag = 0;   // one-launch rotation: arrival counter base of the next launch, tag of its report
 };
-Context &ctx();
+Context &ctx();                            // the calling thread's current device's context
+Context *ctx_of_device(int device);
+void select_device(int device);            // this thread's current device (no HIP call; require_ctx binds the runtime)
+int selected_device();
+void forget_bound_device();                // after a library (RCCL) may have changed the thread's HIP device behind our back
+// hipFuncSetAttribute acts on the CURRENT device's copy of a kernel, so "set once" means once per device: evaluates `expr` (-> bool) the
+// first time the enclosing code runs on a device and remembers the answer for that device (the statics belong to the call site)
+#define SG_DEVICE_ONCE(expr)                                                                          \
+    ([&]() -> bool {                                                                                  \
+        static u32 _done = 0, _ok = 0;                                                                \
+        const u32 _bit = 1u << symgpu::ctx().device;                                                  \
+        if (!(_done & _bit)) { _done |= _bit; if (expr) _ok |= _bit; }                                \
+        return (_ok & _bit) != 0;                                                                     \
+    }())
 extern i64 g_counters[16];                 // debug counters (symgpu_debug_counter): [1] one-launch rotations, [2] their failures, [3] hipMalloc calls of dev_alloc,
                                            // [7] / [8] payload bytes host -> device / device -> host, [9] / [10] operator uploads / downloads (calls)
 inline void count_h2d(size_t bytes) { g_counters[7] += (i64)bytes; }
 inline void count_d2h(size_t bytes) { g_counters[8] += (i64)bytes; }
 int require_ctx();
+// A call that is handed operator handles runs on THEIR device for its duration (and refuses handles of different devices); the
+// thread's own selection comes back when the scope ends.
+struct DeviceScope {
+    int saved = -1;
+    bool active = false;
+    int enter(const struct ::symgpu_op_s *a, const struct ::symgpu_op_s *b = nullptr, const struct ::symgpu_op_s *c = nullptr);
+    ~DeviceScope();
+};
+#define SG_ENTER(...)                   \
+    symgpu::DeviceScope _dev_scope;     \
+    SG_TRY(_dev_scope.enter(__VA_ARGS__))
 // A fast path gave up in this process (an in-kernel wait timed out because the workgroups were not co-resident — a shared or partitioned
 // GPU —, or the runtime refused an LDS attribute) and a slower form has taken over: said ONCE on stderr and kept for symgpu_degraded().
 void note_degraded(const char *what);
@@ -122,6 +149,7 @@ struct Scratch {
 
 // ---- device-resident operator ------------------------------------------------------------------
 struct symgpu_op_s {
+    int device = 0;          // the device whose memory holds the operator (set by symgpu_op_alloc)
     u64 *rows = nullptr;     // [capacity][2*Wq] row-major packed
     double *coeff = nullptr; // [capacity][2] or null
     i64 T = 0, capacity = 0;
@@ -136,6 +164,7 @@ struct symgpu_op_s {
     // for free (h(P ^ Q) = h(P) ^ h(Q)), so a chain of rotations hashes the operator once.  Dropped by op_invalidate.
     u64 *hash = nullptr;
     u64 hash_seed = 0;
+    std::vector<u64> host_hash_tab;  // host copy of hash_tab (to hash single rows, e.g. a rotation's Q, with the SAME device's tables)
     // cached bit-major copy of rows[0..T) for the Four-Russians commutation kernel (commute_m4r.hip): bt[c][jw], bt_pad words per
     // bit-row; valid while bt_T == T.  An adjacency matrix computed slab by slab transposes its right operand once.
     u64 *bt = nullptr;

@@ -252,7 +252,7 @@ int symgpu_ycount(const uint64_t *rows, int64_t T, int Wq, int64_t *out) {
 }
 
 int symgpu_commutes_dev(symgpu_op_t A, int64_t a_begin, int64_t a_end, symgpu_op_t B, uint8_t *out_dev) {
-    SG_TRY(require_ctx());
+    SG_ENTER(A, B);
     SG_REQUIRE(A && B && A->Wq == B->Wq, "commutes_dev: operands must share Wq");
     SG_REQUIRE(0 <= a_begin && a_begin <= a_end && a_end <= A->T, "commutes_dev: bad row range");
     SG_REQUIRE(out_dev || a_end == a_begin || B->T == 0, "commutes_dev: null output");
@@ -260,7 +260,7 @@ int symgpu_commutes_dev(symgpu_op_t A, int64_t a_begin, int64_t a_end, symgpu_op
 }
 
 int symgpu_commutes_bits_dev(symgpu_op_t A, int64_t a_begin, int64_t a_end, symgpu_op_t B, uint64_t *out_bits_dev) {
-    SG_TRY(require_ctx());
+    SG_ENTER(A, B);
     SG_REQUIRE(A && B && A->Wq == B->Wq, "commutes_bits_dev: operands must share Wq");
     SG_REQUIRE(0 <= a_begin && a_begin <= a_end && a_end <= A->T, "commutes_bits_dev: bad row range");
     SG_REQUIRE(out_bits_dev || a_end == a_begin || B->T == 0, "commutes_bits_dev: null output");

@@ -339,8 +339,8 @@ template <int R, int WAVES, int LOOK, bool BYTES>
 static int launch_m4r(const uint8_t *A8, i64 Npad, i64 N, const u64 *BT, i64 Mw_pad, int Wq, const u32 *klist, const u32 *nk, void *out, i64 stride,
                       i64 M) {
     constexpr int lds = mk_lds_bytes(4 * WAVES * R);
-    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_commutes_m4r<R, WAVES, LOOK, BYTES>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  lds) == hipSuccess;
+    const bool attr = SG_DEVICE_ONCE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_commutes_m4r<R, WAVES, LOOK, BYTES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         lds) == hipSuccess);
     if (!attr) { set_error("commutes_m4r: %d bytes of LDS refused", lds); return SYMGPU_E_HIP; }
     const i64 gx = Npad / (4 * WAVES * R), gy = Mw_pad / MK_TILE_W;
     // blockIdx.x (fast) walks the row blocks: workgroups that run together share the BT column tile in L2

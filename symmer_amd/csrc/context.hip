@@ -28,9 +28,20 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     return e == hipErrorOutOfMemory ? SYMGPU_E_NOMEM : SYMGPU_E_HIP;
 }
 
-static Context g_ctx;
+// One context per DEVICE, all of them in this process (round 5: single-process multi-device mode, SURVEY 8b "one host process ... driving
+// <= 8 devices").  A host thread has a CURRENT device — the one it last selected with symgpu_set_device / symgpu_init, else the
+// first device initialised in the process — and everything that is not handed a handle works on it.  A call that IS handed a handle runs
+// on the handle's device for its duration (DeviceScope).
+static Context g_ctxs[SYMGPU_MAX_DEVICES];
+static int g_default_dev = -1;                    // the first device initialised in this process
+static thread_local int t_cur_dev = -1;           // this thread's selection (-1: the default)
+static thread_local int t_bound_dev = -1;         // the device hipSetDevice was last called with on this thread
 i64 g_counters[16] = {0};   // symgpu_debug_counter 1..10 (0 is g_hash_reseeds, cleanup.hip)
-Context &ctx() { return g_ctx; }
+static int cur_index() { return t_cur_dev >= 0 ? t_cur_dev : (g_default_dev >= 0 ? g_default_dev : 0); }
+Context &ctx() { return g_ctxs[cur_index()]; }
+Context *ctx_of_device(int device) { return device >= 0 && device < SYMGPU_MAX_DEVICES ? &g_ctxs[device] : nullptr; }
+void select_device(int device) { t_cur_dev = device; }
+int selected_device() { return t_cur_dev; }
 
 static std::mutex g_deg_mu;
 static std::string g_degraded;
@@ -43,20 +54,37 @@ void note_degraded(const char *what) {
 }
 
 int require_ctx() {
-    if (!g_ctx.ready) {
-        set_error("symgpu_init() has not been called (or no HIP device)");
+    Context &c = ctx();
+    if (!c.ready) {
+        set_error("symgpu_init() has not been called for this device (or no HIP device)");
         return SYMGPU_E_NODEVICE;
     }
     // HIP's current device is per host thread and starts at 0: a thread other than the one that called symgpu_init (e.g. the
-    // watchdog thread of symmer_amd/parallel.py) must be bound to the context's device before it touches the runtime, or a
-    // rank > 0 would create its RCCL communicator on device 0
-    static thread_local int bound = -1;
-    if (bound != g_ctx.device) {
-        HIP_TRY(hipSetDevice(g_ctx.device));
-        bound = g_ctx.device;
+    // watchdog thread of symmer_amd/parallel.py), or one that has moved on to another context, must be bound to the context's device
+    // before it touches the runtime
+    if (t_bound_dev != c.device) {
+        HIP_TRY(hipSetDevice(c.device));
+        t_bound_dev = c.device;
     }
     return SYMGPU_OK;
 }
+void forget_bound_device() { t_bound_dev = -1; }
+
+int DeviceScope::enter(const symgpu_op_s *a, const symgpu_op_s *b, const symgpu_op_s *c) {
+    saved = t_cur_dev;
+    active = true;
+    const symgpu_op_s *first = a ? a : (b ? b : c);
+    if (first) {
+        if ((b && b->device != first->device) || (c && c->device != first->device)) {
+            set_error("operands live on different devices (%d and %d): copy one over with symgpu_op_copy_rows first", first->device,
+                      (b && b->device != first->device) ? b->device : c->device);
+            return SYMGPU_E_INVALID;
+        }
+        t_cur_dev = first->device;
+    }
+    return require_ctx();
+}
+DeviceScope::~DeviceScope() { if (active) t_cur_dev = saved; }
 
 // ---- cached allocator ------------------------------------------------------------------------------------------------------
 // Size classes (power-of-two-ish), freed blocks parked per class until shutdown / release.  A class that has no parked block is
@@ -65,17 +93,27 @@ int require_ctx() {
 // every later pass costs (round 2 needed a warm-up pass in the bench for that).  Carved blocks are never returned to the runtime
 // one by one; a chunk is released as a whole when none of its blocks is in use (dev_cache_release).
 static std::mutex g_alloc_mu;
-static std::multimap<size_t, void *> g_free;      // size class -> parked block
-struct LiveBlock { size_t cls; int chunk; };      // chunk: index into g_chunks, -1 = its own hipMalloc
-static std::map<void *, LiveBlock> g_live;        // block in use -> class / origin
-static std::map<void *, int> g_parked_chunk;      // parked block -> origin (only arena blocks)
+struct LiveBlock { size_t cls; int chunk; int dev; };   // chunk: index into the device's chunks, -1 = its own hipMalloc
+static std::map<void *, LiveBlock> g_live;        // block in use -> class / origin (device pointers are unique across the devices)
 struct Chunk { char *base; size_t size, used; i64 live; };
-static std::vector<Chunk> g_chunks;
-static size_t g_cached_bytes = 0;
-static size_t g_cache_limit = (size_t)64 << 30;       // parked blocks: at most 64 GiB, raised to half of the device memory at init
-                                                        // (hipMalloc / hipFree of multi-GB blocks cost ~10 ms per GB)
+struct DevAlloc {                                 // the allocator's state of ONE device
+    std::multimap<size_t, void *> free_;          // size class -> parked block
+    std::map<void *, int> parked_chunk;           // parked block -> origin (only arena blocks)
+    std::vector<Chunk> chunks;
+    size_t cached_bytes = 0;
+    size_t cache_limit = (size_t)64 << 30;        // parked blocks: at most 64 GiB, raised to half of the device memory at init
+                                                  // (hipMalloc / hipFree of multi-GB blocks cost ~10 ms per GB)
+    bool arena_on = true;
+};
+static DevAlloc g_alloc[SYMGPU_MAX_DEVICES];
 static const size_t ARENA_CHUNK = (size_t)4 << 30, ARENA_MAX_BLOCK = (size_t)1 << 30;
-static bool g_arena_on = true;
+// the names the allocator below was written with, now the CURRENT device's state
+#define g_free (g_alloc[cur_index()].free_)
+#define g_parked_chunk (g_alloc[cur_index()].parked_chunk)
+#define g_chunks (g_alloc[cur_index()].chunks)
+#define g_cached_bytes (g_alloc[cur_index()].cached_bytes)
+#define g_cache_limit (g_alloc[cur_index()].cache_limit)
+#define g_arena_on (g_alloc[cur_index()].arena_on)
 
 static size_t size_class(size_t b) {
     if (b < 256) b = 256;
@@ -128,13 +166,13 @@ int dev_alloc(size_t bytes, void **ptr) {
             int chunk = -1;
             auto pc = g_parked_chunk.find(*ptr);
             if (pc != g_parked_chunk.end()) { chunk = pc->second; g_parked_chunk.erase(pc); ++g_chunks[chunk].live; }
-            g_live[*ptr] = LiveBlock{c, chunk};
+            g_live[*ptr] = LiveBlock{c, chunk, cur_index()};
             return SYMGPU_OK;
         }
         int chunk = -1;
         if (void *p = arena_carve(c, &chunk)) {
             *ptr = p;
-            g_live[p] = LiveBlock{c, chunk};
+            g_live[p] = LiveBlock{c, chunk, cur_index()};
             return SYMGPU_OK;
         }
     }
@@ -158,7 +196,7 @@ int dev_alloc(size_t bytes, void **ptr) {
                 int chunk = -1;
                 auto pc = g_parked_chunk.find(*ptr);
                 if (pc != g_parked_chunk.end()) { chunk = pc->second; g_parked_chunk.erase(pc); ++g_chunks[chunk].live; }
-                g_live[*ptr] = LiveBlock{cls, chunk};
+                g_live[*ptr] = LiveBlock{cls, chunk, cur_index()};
                 return SYMGPU_OK;
             }
             set_error("device allocation of %zu bytes failed: %s", c, hipGetErrorString(e));
@@ -168,7 +206,7 @@ int dev_alloc(size_t bytes, void **ptr) {
     }
     std::lock_guard<std::mutex> lk(g_alloc_mu);
     ++g_counters[3];
-    g_live[*ptr] = LiveBlock{c, -1};
+    g_live[*ptr] = LiveBlock{c, -1, cur_index()};
     return SYMGPU_OK;
 }
 
@@ -182,24 +220,25 @@ int dev_free(void *ptr) {
     }
     const LiveBlock blk = it->second;
     g_live.erase(it);
+    DevAlloc &A = g_alloc[blk.dev];                    // the OWNING device's lists (a handle may be dropped while another device is current)
     if (blk.chunk >= 0) {                              // arena block: parked, whatever the limit says (it cannot go back on its own)
-        --g_chunks[blk.chunk].live;
-        g_parked_chunk[ptr] = blk.chunk;
-        g_free.insert({blk.cls, ptr});
-        g_cached_bytes += blk.cls;
-    } else if (g_cached_bytes + blk.cls > g_cache_limit) {
-        // stream-ordered safety: everything runs on one stream, but hipFree synchronises anyway
+        --A.chunks[blk.chunk].live;
+        A.parked_chunk[ptr] = blk.chunk;
+        A.free_.insert({blk.cls, ptr});
+        A.cached_bytes += blk.cls;
+    } else if (A.cached_bytes + blk.cls > A.cache_limit) {
+        // stream-ordered safety: everything runs on one stream per device, but hipFree synchronises anyway
         (void)hipFree(ptr);
     } else {
-        g_free.insert({blk.cls, ptr});
-        g_cached_bytes += blk.cls;
+        A.free_.insert({blk.cls, ptr});
+        A.cached_bytes += blk.cls;
     }
     return SYMGPU_OK;
 }
 
 void dev_cache_release() {
     std::lock_guard<std::mutex> lk(g_alloc_mu);
-    if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
+    if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
     for (auto it = g_free.begin(); it != g_free.end();) {
         auto pc = g_parked_chunk.find(it->second);
         if (pc == g_parked_chunk.end()) {              // its own hipMalloc
@@ -220,17 +259,18 @@ void dev_cache_release() {
 
 // ---- per-launch profiling ---------------------------------------------------------------------------
 struct ProfClass { bool on = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
-static ProfClass g_prof[SYMGPU_PROF_CLASSES];
+static ProfClass g_prof_all[SYMGPU_MAX_DEVICES][SYMGPU_PROF_CLASSES];
+#define g_prof (g_prof_all[cur_index()])
 
 ProfScope::ProfScope(int kernel_class) : cls(kernel_class), on(false) {
     if (cls < 0 || cls >= SYMGPU_PROF_CLASSES || !g_prof[cls].on) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { (void)hipGetLastError(); return; }
     on = true;
-    (void)hipEventRecord(a, g_ctx.stream);
+    (void)hipEventRecord(a, ctx().stream);
 }
 ProfScope::~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(b, g_ctx.stream);
+    (void)hipEventRecord(b, ctx().stream);
     g_prof[cls].ev.push_back({a, b});
 }
 
@@ -414,13 +454,7 @@ int symgpu_device_count(int *n) {
     return SYMGPU_OK;
 }
 
-int symgpu_init(int device) {
-    Context &c = ctx();
-    if (c.ready) {
-        if (c.device == device) return SYMGPU_OK;
-        set_error("symgpu_init: already initialised on device %d", c.device);
-        return SYMGPU_E_INVALID;
-    }
+static int init_device(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -428,11 +462,14 @@ int symgpu_init(int device) {
         set_error("no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
         return SYMGPU_E_NODEVICE;
     }
-    if (device < 0 || device >= n) {
-        set_error("device %d out of range (have %d)", device, n);
+    if (device < 0 || device >= n || device >= SYMGPU_MAX_DEVICES) {
+        set_error("device %d out of range (have %d, at most %d per process)", device, n, SYMGPU_MAX_DEVICES);
         return SYMGPU_E_INVALID;
     }
+    Context &c = g_ctxs[device];
+    if (c.ready) return SYMGPU_OK;
     HIP_TRY(hipSetDevice(device));
+    t_bound_dev = device;
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
@@ -445,22 +482,81 @@ int symgpu_init(int device) {
     c.device = device;
     {
         size_t f = 0, t = 0;
-        if (hipMemGetInfo(&f, &t) == hipSuccess && t / 2 > g_cache_limit) g_cache_limit = t / 2;
+        if (hipMemGetInfo(&f, &t) == hipSuccess && t / 2 > g_alloc[device].cache_limit) g_alloc[device].cache_limit = t / 2;
     }
-    if (const char *e = SG_TUNE("SYMGPU_ARENA")) g_arena_on = !(e[0] == '0');       // 0: every size class straight from hipMalloc (round 2's allocator)
+    if (const char *e = SG_TUNE("SYMGPU_ARENA")) g_alloc[device].arena_on = !(e[0] == '0');       // 0: every size class straight from hipMalloc (round 2's allocator)
     c.ready = true;
+    if (g_default_dev < 0) g_default_dev = device;
     return SYMGPU_OK;
 }
 
-int symgpu_shutdown(void) {
-    Context &c = ctx();
-    if (!c.ready) return SYMGPU_OK;
+int symgpu_init(int device) {
+    // creates the device's context if it does not exist yet and makes the device this thread's current one (one process per GPU: the
+    // only call a rank makes; single-process multi-device: symgpu_init_all, then symgpu_set_device)
+    SG_TRY(init_device(device));
+    t_cur_dev = device;
+    return require_ctx();
+}
+
+int symgpu_init_all(int n_devices) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return SYMGPU_E_NODEVICE;
+    }
+    if (n_devices <= 0 || n_devices > n) n_devices = n;
+    if (n_devices > SYMGPU_MAX_DEVICES) n_devices = SYMGPU_MAX_DEVICES;
+    for (int d = 0; d < n_devices; ++d) SG_TRY(init_device(d));
+    // peer access both ways between every pair: symgpu_op_copy_rows between devices and RCCL's transports use it (xGMI)
+    for (int a = 0; a < n_devices; ++a) {
+        HIP_TRY(hipSetDevice(a));
+        for (int b = 0; b < n_devices; ++b) {
+            if (a == b) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(b, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
+        }
+    }
+    t_bound_dev = -1;
+    if (t_cur_dev < 0) t_cur_dev = g_default_dev;
+    return require_ctx();
+}
+
+int symgpu_set_device(int device) {
+    SG_TRY(init_device(device));
+    t_cur_dev = device;
+    return require_ctx();
+}
+
+int symgpu_current_device(int *device) {
+    SG_REQUIRE(device, "current_device: null argument");
+    *device = ctx().ready ? ctx().device : -1;
+    return SYMGPU_OK;
+}
+
+int symgpu_n_initialised(int *n) {
+    SG_REQUIRE(n, "n_initialised: null argument");
+    int k = 0;
+    for (int d = 0; d < SYMGPU_MAX_DEVICES; ++d) k += g_ctxs[d].ready ? 1 : 0;
+    *n = k;
+    return SYMGPU_OK;
+}
+
+static void shutdown_device(int device) {
+    Context &c = g_ctxs[device];
+    if (!c.ready) return;
+    const int saved = t_cur_dev;
+    t_cur_dev = device;
+    if (hipSetDevice(device) == hipSuccess) t_bound_dev = device;
     (void)hipStreamSynchronize(c.stream);
     if (c.rot_table) { dev_free(c.rot_table); c.rot_table = nullptr; c.rot_table_cap = 0; c.rot_gen = 0; }
     dev_cache_release();
     if (c.hash_tab) { (void)hipFree(c.hash_tab); c.hash_tab = nullptr; }
     if (c.xs_pow) { (void)hipFree(c.xs_pow); c.xs_pow = nullptr; }
-    if (c.rot_table) { dev_free(c.rot_table); c.rot_table = nullptr; c.rot_table_cap = 0; c.rot_gen = 0; }
     if (c.rot_flags) { (void)hipFree(c.rot_flags); c.rot_flags = nullptr; }
     if (c.rot_partner) { (void)hipFree(c.rot_partner); c.rot_partner = nullptr; c.rot_partner_cap = 0; }
     if (c.sort_state) { (void)hipFree(c.sort_state); c.sort_state = nullptr; c.sort_bar_base = 0; }
@@ -475,8 +571,15 @@ int symgpu_shutdown(void) {
     (void)hipEventDestroy(c.ev_join);
     (void)hipStreamDestroy(c.stream2);
     (void)hipStreamDestroy(c.stream);
-    c.ready = false;
-    c.device = -1;
+    c = Context();
+    t_cur_dev = saved;
+}
+
+int symgpu_shutdown(void) {
+    for (int d = 0; d < SYMGPU_MAX_DEVICES; ++d) shutdown_device(d);
+    g_default_dev = -1;
+    t_cur_dev = -1;
+    t_bound_dev = -1;
     return SYMGPU_OK;
 }
 
@@ -652,6 +755,7 @@ int symgpu_op_alloc(int64_t capacity_rows, int Wq, int with_coeff, symgpu_op_t *
     SG_TRY(require_ctx());
     SG_REQUIRE(out && capacity_rows >= 0 && Wq >= 1, "op_alloc");
     symgpu_op_s *op = new symgpu_op_s();
+    op->device = ctx().device;
     op->Wq = Wq;
     op->capacity = capacity_rows;
     op->T = 0;
@@ -683,7 +787,7 @@ int symgpu_op_set_rows(symgpu_op_t op, int64_t T) {
 }
 
 int symgpu_op_write(symgpu_op_t op, int64_t row_offset, const uint64_t *rows, const double *coeff, int64_t count) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     SG_REQUIRE(op && row_offset >= 0 && count >= 0 && row_offset + count <= op->capacity, "op_write: row range exceeds the capacity");
     SG_REQUIRE(count == 0 || rows, "op_write: null rows");
     const size_t W = (size_t)2 * op->Wq;
@@ -701,12 +805,20 @@ int symgpu_op_write(symgpu_op_t op, int64_t row_offset, const uint64_t *rows, co
 }
 
 int symgpu_op_copy_rows(symgpu_op_t dst, int64_t dst_offset, symgpu_op_t src, int64_t src_offset, int64_t count) {
-    SG_TRY(require_ctx());
     SG_REQUIRE(dst && src && dst != src && dst->Wq == src->Wq, "op_copy_rows: handles");
+    SG_ENTER(dst);                                                     // runs on the destination's device
     SG_REQUIRE(count >= 0 && dst_offset >= 0 && src_offset >= 0 && dst_offset + count <= dst->capacity && src_offset + count <= src->T,
                "op_copy_rows: row range");
     const size_t W = (size_t)2 * dst->Wq;
-    if (count > 0) {
+    if (count > 0 && src->device != dst->device) {
+        // the one call that crosses devices: a peer copy (xGMI) on the destination's stream, after the source's stream has drained
+        Context *sc = ctx_of_device(src->device);
+        SG_REQUIRE(sc && sc->ready, "op_copy_rows: the source's device has no context");
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        HIP_TRY(hipMemcpyPeerAsync(dst->rows + (size_t)dst_offset * W, dst->device, src->rows + (size_t)src_offset * W, src->device, (size_t)count * W * 8, ctx().stream));
+        if (dst->coeff && src->coeff)
+            HIP_TRY(hipMemcpyPeerAsync(dst->coeff + 2 * (size_t)dst_offset, dst->device, src->coeff + 2 * (size_t)src_offset, src->device, (size_t)count * 16, ctx().stream));
+    } else if (count > 0) {
         HIP_TRY(hipMemcpyAsync(dst->rows + (size_t)dst_offset * W, src->rows + (size_t)src_offset * W, (size_t)count * W * 8, hipMemcpyDeviceToDevice, ctx().stream));
         if (dst->coeff && src->coeff)
             HIP_TRY(hipMemcpyAsync(dst->coeff + 2 * (size_t)dst_offset, src->coeff + 2 * (size_t)src_offset, (size_t)count * 16, hipMemcpyDeviceToDevice, ctx().stream));
@@ -735,7 +847,7 @@ int symgpu_op_upload(const uint64_t *rows, const double *coeff, int64_t T, int W
 }
 
 int symgpu_op_download(symgpu_op_t op, uint64_t *rows, double *coeff, int64_t capacity_rows) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     SG_REQUIRE(op, "op_download: null handle");
     if (capacity_rows < op->T) {
         set_error("op_download: capacity %lld < %lld rows", (long long)capacity_rows, (long long)op->T);
@@ -761,7 +873,7 @@ int symgpu_op_download(symgpu_op_t op, uint64_t *rows, double *coeff, int64_t ca
 
 // ---- handle-level primitives behind the device-resident drop-in classes (symmer_amd/operators/base.py) -----------------------------------
 int symgpu_op_clone(symgpu_op_t in, symgpu_op_t *out) {
-    SG_TRY(require_ctx());
+    SG_ENTER(in);
     SG_REQUIRE(in && out, "op_clone: null argument");
     symgpu_op_t op = nullptr;
     SG_TRY(symgpu_op_alloc(in->T, in->Wq, in->coeff != nullptr, &op));
@@ -777,7 +889,7 @@ int symgpu_op_clone(symgpu_op_t in, symgpu_op_t *out) {
 }
 
 int symgpu_op_set_coeff(symgpu_op_t op, const double *coeff_host) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     SG_REQUIRE(op && (coeff_host || op->T == 0), "op_set_coeff: null argument");
     if (!op->coeff) SG_TRY(dev_alloc((size_t)(op->capacity > 0 ? op->capacity : 1) * 16, (void **)&op->coeff));
     if (op->T > 0) {
@@ -790,7 +902,7 @@ int symgpu_op_set_coeff(symgpu_op_t op, const double *coeff_host) {
 }
 
 int symgpu_op_scale(symgpu_op_t op, double re, double im, int conjugate_first) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     SG_REQUIRE(op && (op->coeff || op->T == 0), "op_scale: operator has no coefficients");
     if (op->T > 0) {
         hipLaunchKernelGGL(k_scale_coeff, dim3((unsigned)((op->T + 255) / 256)), dim3(256), 0, ctx().stream, op->coeff, op->T, re, im, conjugate_first);
@@ -800,7 +912,7 @@ int symgpu_op_scale(symgpu_op_t op, double re, double im, int conjugate_first) {
 }
 
 int symgpu_op_ycount(symgpu_op_t op, int64_t *out_host) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     SG_REQUIRE(op && (out_host || op->T == 0), "op_ycount: null argument");
     if (op->T == 0) return SYMGPU_OK;
     const int *yc = nullptr;
@@ -847,7 +959,7 @@ int symgpu_op_upload_bool(const uint8_t *symp, const double *coeff, int64_t T, i
 }
 
 int symgpu_op_download_bool(symgpu_op_t op, int n_qubits, uint8_t *symp_out, int64_t capacity_rows) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     SG_REQUIRE(op && n_qubits >= 1 && (n_qubits + 63) / 64 == op->Wq, "op_download_bool: qubit count does not match the packed width");
     if (capacity_rows < op->T) {
         set_error("op_download_bool: capacity %lld < %lld rows", (long long)capacity_rows, (long long)op->T);
@@ -896,14 +1008,14 @@ int symgpu_op_random(int64_t T, int n_qubits, double density, uint64_t seed, sym
 }
 
 int symgpu_op_popcount(symgpu_op_t op, uint64_t *sum) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     SG_REQUIRE(op && sum, "op_popcount: null argument");
     if (op->T == 0) { *sum = 0; return SYMGPU_OK; }
     return symgpu_dev_popcount_u64(op->rows, op->T * 2 * op->Wq, sum);
 }
 
 int symgpu_op_checksum(symgpu_op_t op, uint64_t *xor_words, double *coeff_sum) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     SG_REQUIRE(op, "op_checksum: null handle");
     int W = 2 * op->Wq;
     Scratch acc;

@@ -98,7 +98,7 @@ using namespace symgpu;
 extern "C" {
 
 int symgpu_op_gf2_rank(symgpu_op_t op, int64_t *rank) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     SG_REQUIRE(op && rank, "op_gf2_rank: null argument");
     *rank = 0;
     if (op->T == 0) return SYMGPU_OK;
@@ -112,7 +112,7 @@ int symgpu_op_gf2_rank(symgpu_op_t op, int64_t *rank) {
 }
 
 int symgpu_generators_dev(symgpu_op_t op, symgpu_op_t *out) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     SG_REQUIRE(op && out, "generators_dev: null argument");
     const int W = 2 * op->Wq;
     hipStream_t st = ctx().stream;
@@ -143,7 +143,7 @@ int symgpu_generators_dev(symgpu_op_t op, symgpu_op_t *out) {
 }
 
 int symgpu_generator_reconstruction_dev(symgpu_op_t G, symgpu_op_t M, int n_qubits, int64_t *recon_host, uint8_t *mask_host) {
-    SG_TRY(require_ctx());
+    SG_ENTER(G, M);
     SG_REQUIRE(G && M && n_qubits >= 1, "generator_reconstruction_dev: null argument");
     SG_REQUIRE(G->Wq == M->Wq && (n_qubits + 63) / 64 == G->Wq, "generator_reconstruction_dev: operands must share the qubit count");
     const i64 g = G->T, T = M->T;

@@ -711,8 +711,8 @@ static int rref_dev_impl(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_h
     if (Wc >= ((i64)1 << 31) - 64) { set_error("rref: Wc too large"); return SYMGPU_E_INVALID; }
     {   // one-workgroup path for small matrices (SYMGPU_GF2_SMALL=0 disables it: tests)
         const char *env_small = getenv("SYMGPU_GF2_SMALL");
-        static const bool small_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rref_small), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                           SMALL_R * SMALL_WC * 8) == hipSuccess;
+        const bool small_attr = SG_DEVICE_ONCE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rref_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                   SMALL_R * SMALL_WC * 8) == hipSuccess);
         if (R <= SMALL_R && Wc <= SMALL_WC && small_attr && !(env_small && env_small[0] == '0')) {
             Scratch piv, count;
             SG_TRY(piv.alloc((size_t)R * 8));
@@ -749,12 +749,11 @@ static int rref_dev_impl(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_h
     const unsigned gsel = (unsigned)((R + 3) / 4);
     BlockInfo *binfo = info.as<BlockInfo>();
     // Four-Russians sweep (128 KiB of LDS per workgroup) unless disabled or refused by the runtime
-    static const bool m4r_attr = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess;
-    }();
+    const bool m4r_attr = SG_DEVICE_ONCE(
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_m4r<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M4_LDS) == hipSuccess);
     const char *env_m4r = getenv("SYMGPU_GF2_M4R"), *env_la = SG_TUNE("SYMGPU_GF2_LOOKAHEAD");   // read per call: the tests switch paths
     const bool m4r = m4r_attr && !(env_m4r && env_m4r[0] == '0'), m4r_plain = m4r;
     const int m4_tiles = (int)((Wc + M4_TW - 1) / M4_TW);
@@ -977,7 +976,7 @@ int symgpu_rref(uint64_t *rows, int64_t R, int64_t Wc, int64_t *xor_count, int64
 }
 
 int symgpu_symmetry_kernel_dev(symgpu_op_t H, int n_qubits, uint64_t *out, int64_t capacity, int64_t *k, int64_t *xor_count) {
-    SG_TRY(require_ctx());
+    SG_ENTER(H);
     SG_REQUIRE(H && k && n_qubits >= 1, "symmetry_kernel_dev");
     SG_REQUIRE((n_qubits + 63) / 64 == H->Wq, "symmetry_kernel_dev: n_qubits does not match Wq");
     hipStream_t st = ctx().stream;

@@ -69,7 +69,7 @@ using namespace symgpu;
 extern "C" {
 
 int symgpu_op_gather(symgpu_op_t op, const int64_t *idx_host, int64_t n, symgpu_op_t *out) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     SG_REQUIRE(op && out && n >= 0 && (idx_host || n == 0), "op_gather: arguments");
     for (i64 r = 0; r < n; ++r) SG_REQUIRE(idx_host[r] >= 0 && idx_host[r] < op->T, "op_gather: index out of range");
     hipStream_t st = ctx().stream;
@@ -94,7 +94,7 @@ int symgpu_op_gather(symgpu_op_t op, const int64_t *idx_host, int64_t n, symgpu_
 }
 
 int symgpu_part_global_index(symgpu_op_t part, const int64_t *inner_idx_host, int64_t n_inner, const int64_t *outer_idx_host, int64_t n_outer, int64_t Ni_global) {
-    SG_TRY(require_ctx());
+    SG_ENTER(part);
     SG_REQUIRE(part && inner_idx_host && outer_idx_host && n_inner >= 1 && n_outer >= 1 && Ni_global >= 1, "part_global_index: arguments");
     SG_REQUIRE(part->first || part->T == 0, "part_global_index: the operator does not come from symgpu_mul_cleanup_indexed_dev");
     if (part->T == 0) return SYMGPU_OK;
@@ -111,7 +111,7 @@ int symgpu_part_global_index(symgpu_op_t part, const int64_t *inner_idx_host, in
 }
 
 int symgpu_op_set_first_index(symgpu_op_t op, const uint64_t *first_host) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     SG_REQUIRE(op && (first_host || op->T == 0), "op_set_first_index: arguments");
     if (!op->first) SG_TRY(dev_alloc((size_t)(op->capacity > 0 ? op->capacity : 1) * 8, (void **)&op->first));
     if (op->T > 0) {
@@ -123,7 +123,7 @@ int symgpu_op_set_first_index(symgpu_op_t op, const uint64_t *first_host) {
 }
 
 int symgpu_merge_indexed_dev(const symgpu_op_t *parts, int n_parts, int key_bits, int do_cleanup, double thr, int use_thr, symgpu_op_t *out) {
-    SG_TRY(require_ctx());
+    SG_ENTER((parts && n_parts > 0) ? parts[0] : nullptr);
     SG_REQUIRE(parts && out && n_parts >= 1 && key_bits >= 0 && key_bits <= 64, "merge_indexed_dev: arguments");
     const int sort_bits = key_bits == 0 ? 64 : (key_bits + 7) / 8 * 8;
     hipStream_t st = ctx().stream;

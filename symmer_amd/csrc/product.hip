@@ -500,7 +500,7 @@ extern "C" {
 
 int symgpu_mul_allpairs_dev(symgpu_op_t inner, symgpu_op_t outer, int64_t o_begin, int64_t o_end, int inner_is_left,
                             symgpu_op_t out) {
-    SG_TRY(require_ctx());
+    SG_ENTER(inner, outer, out);
     SG_REQUIRE(inner && outer && out, "mul_allpairs_dev: null handle");
     SG_REQUIRE(inner->Wq == outer->Wq && out->Wq == inner->Wq, "mul_allpairs_dev: operands must share Wq");
     SG_REQUIRE(0 <= o_begin && o_begin <= o_end && o_end <= outer->T, "mul_allpairs_dev: bad outer range");

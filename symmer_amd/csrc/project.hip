@@ -160,7 +160,7 @@ extern "C" {
 
 int symgpu_project_dev(symgpu_op_t op, const uint64_t *stab_rows, int k, const uint64_t *neg_mask, const int *keep_qubits, int n_keep, int n_qubits,
                        double thr, int use_thr, symgpu_op_t *out, int64_t *n_survived) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     if (n_survived) *n_survived = 0;
     SG_REQUIRE(op && out && k >= 0 && n_keep >= 1 && n_qubits >= 1 && neg_mask && keep_qubits && (k == 0 || stab_rows), "project_dev: arguments");
     SG_REQUIRE((n_qubits + 63) / 64 == op->Wq, "project_dev: n_qubits does not match the operator's Wq");
@@ -215,7 +215,7 @@ int symgpu_project_dev(symgpu_op_t op, const uint64_t *stab_rows, int k, const u
 }
 
 int symgpu_noncontextual_dev(symgpu_op_t op, int *is_noncontextual) {
-    SG_TRY(require_ctx());
+    SG_ENTER(op);
     SG_REQUIRE(op && is_noncontextual, "noncontextual_dev: null argument");
     hipStream_t st = ctx().stream;
     const i64 T = op->T;
@@ -259,7 +259,7 @@ int symgpu_noncontextual_dev(symgpu_op_t op, int *is_noncontextual) {
 }
 
 int symgpu_state_inner_dev(symgpu_op_t a, symgpu_op_t b, double *out) {
-    SG_TRY(require_ctx());
+    SG_ENTER(a, b);
     SG_REQUIRE(a && b && out && a->Wq == b->Wq, "state_inner_dev: arguments");
     SG_REQUIRE((a->coeff || a->T == 0) && (b->coeff || b->T == 0), "state_inner_dev: states have no coefficients");
     SG_REQUIRE(a->dup_free && b->dup_free, "state_inner_dev: both states must come from a cleanup (to_dictionary cleans them, base.py:2104)");

@@ -1071,7 +1071,7 @@ extern "C" {
 
 int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double cos_t, double sin_t, int clifford_k, double thr,
                              symgpu_op_t *out, int *all_commute) {
-    SG_TRY(require_ctx());
+    SG_ENTER(in);
     SG_REQUIRE(in && q_row_host && out && all_commute, "rotate_single_dev: null argument");
     SG_REQUIRE(in->coeff || in->T == 0, "rotate_single_dev: operator has no coefficients");
     hipStream_t st = ctx().stream;
@@ -1246,7 +1246,7 @@ static int any_row_commutes(symgpu_op_t op, const u64 *q_host, bool *any) {
 
 int symgpu_perform_rotations_dev(symgpu_op_t in, const uint64_t *q_rows_host, const double *cos_t, const double *sin_t, const int *ks_host, int64_t K,
                                  double thr, int clean, symgpu_op_t *out, uint8_t *acted, int64_t *n_done, int *clean_out) {
-    SG_TRY(require_ctx());
+    SG_ENTER(in);
     SG_REQUIRE(in && out && n_done && clean_out && K >= 0 && (K == 0 || (q_rows_host && cos_t && sin_t && ks_host)), "perform_rotations_dev: null argument");
     const int W = 2 * in->Wq;
     symgpu_op_t cur = in;                                            // borrowed while cur == in, owned otherwise
@@ -1356,7 +1356,7 @@ int symgpu_rotate_single(const uint64_t *rows, const double *coeff, int64_t N, i
 }
 
 int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host, const int *ks_host, int64_t K, symgpu_op_t *out) {
-    SG_TRY(require_ctx());
+    SG_ENTER(in);
     SG_REQUIRE(in && out && K >= 0 && (K == 0 || (q_rows_host && ks_host)), "rotate_clifford_chain_dev: null argument");
     SG_REQUIRE(in->coeff || in->T == 0, "rotate_clifford_chain_dev: operator has no coefficients");
     SG_REQUIRE(in->dup_free, "rotate_clifford_chain_dev: the operator must come from a cleanup (no duplicate rows, |c| > threshold)");
@@ -1393,8 +1393,8 @@ int symgpu_rotate_clifford_chain_dev(symgpu_op_t in, const uint64_t *q_rows_host
         }
         const size_t lds_rows = (size_t)2 * T * W * 8;
         const bool lds_on = [] { const char *e3 = SG_TUNE("SYMGPU_CHAIN_LDS"); return !(e3 && e3[0] == '0'); }();
-        static const bool lds_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_clifford_chain_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                         128 * 1024) == hipSuccess;
+        const bool lds_attr = SG_DEVICE_ONCE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_clifford_chain_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                 128 * 1024) == hipSuccess);
         const bool reg_chain = clifford_chain_registers_applicable(T, Wq) && !getenv("SYMGPU_CHAIN_LOCAL_T");
         // the register chain; if its one-launch sort timed out at a barrier the rows in `a`/`b` are garbage: restore `a` from the
         // untouched input and run once more (the sort form is off by then, so the second run takes the multi-launch radix sort)

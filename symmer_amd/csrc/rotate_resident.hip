@@ -676,12 +676,12 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     ResLayout L = res_layout((int)R, Wq, 0);
     if ((size_t)L.total > RES_LDS_MAX && pow2) { nreg = 2; L = res_layout((int)R, Wq, nreg); }
     if ((size_t)L.total > RES_LDS_MAX) return SYMGPU_OK;
-    static const bool attr_ok = [] {
+    const bool attr_ok = SG_DEVICE_ONCE(([] {
         for (int m = 0; m < 2; ++m)
             for (int wq : {1, 2, 4, 8, 16, 32, 3})
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(res_kernel(m == 1, wq)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS_MAX) != hipSuccess) return false;
         return true;
-    }();
+    }()));
     if (!attr_ok) {
         (void)hipGetLastError(); c.res_disabled = true;
         note_degraded("one-launch rotation (k_rot_resident) off: the runtime refused its LDS size; rotations take the multi-launch kernels");
@@ -698,7 +698,7 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
         have_hash = true;
     }
     constexpr size_t state_words = 2 * RES_MAX_WG + 2;                            // granules, {fail[0], fail[1]}, {finished, published}
-    static u32 finished_base = 0;
+    u32 &finished_base = c.res_finished_base;                                    // (per device: the counters live in the device's res_state)
     if (!c.res_state) {
         HIP_TRY(hipMalloc((void **)&c.res_state, state_words * 8));
         c.res_epoch = 0;
@@ -772,7 +772,7 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
         set_error("rotate resident: a previous launch failed after it had reported success; its result is invalid");
         return SYMGPU_E_HIP;
     }
-    static u32 host_tag = 0;
+    u32 &host_tag = c.res_host_tag;
     host_tag = host_tag >= 65535 ? 1 : host_tag + 1;
     a.host_late = reinterpret_cast<u32 *>(hcnt_dev) + 8; a.host_words = reinterpret_cast<u64 *>(hcnt_dev) + 5; a.host_tag = host_tag;
     a.published = a.fail + 3;

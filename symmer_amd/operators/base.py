@@ -14,7 +14,7 @@ from typing import Dict, List, Tuple, Union
 
 import numpy as np
 
-from .. import kernels, packing
+from .. import kernels, multi, packing
 from .utils import (string_to_symplectic, symplectic_to_string, random_symplectic_matrix, check_independent,
                     cref_binary, _rref_binary, check_adjmat_noncontextual, check_jordan_independent)
 
@@ -137,6 +137,13 @@ class PauliwordOp:
             self._dev.set_coeff(np.asarray(self._coeff, dtype=complex))
             self._dev_coeff_valid = self._coeff_is_private()
         return self._dev
+
+    def _multi_source(self, with_coeff: bool = True):
+        """The operator as symmer_amd.multi takes it: the resident handle if there is one (shards then travel device to device), else
+        the host arrays."""
+        if self._dev is not None:
+            return self._device(rows_only=not with_coeff)
+        return (self.packed, np.asarray(self._c(), dtype=complex) if with_coeff else None)
 
     @classmethod
     def _from_device(cls, dev: "kernels.DeviceOp", n_qubits: int) -> "PauliwordOp":
@@ -390,6 +397,12 @@ class PauliwordOp:
         are the fast index of the reference's pair order (base.py:783-792)."""
         if self.n_terms == 0 or other.n_terms == 0:
             return PauliwordOp._from_packed(np.empty((0, 2 * packing.words_per_block(self.n_qubits)), dtype='<u8'), self.n_qubits, [])
+        if self.n_terms * other.n_terms >= multi.MIN_PAIRS_PRODUCT and multi.group() is not None:
+            # more than one MI355X in this process: the outer index in contiguous blocks over the devices (symmer_amd/multi.py)
+            inner, outer = (self, other) if self_is_inner else (other, self)
+            res = multi.group().mul_cleanup(inner._multi_source(), None if other is self else outer._multi_source(), self_is_inner, zero_threshold,
+                                            same=other is self)
+            return PauliwordOp._from_device(res, self.n_qubits)
         a = self._device()
         b = a if other is self else other._device()
         inner, outer = (a, b) if self_is_inner else (b, a)
@@ -474,6 +487,10 @@ class PauliwordOp:
             return np.ones((self.n_terms, PwordOp.n_terms), dtype=bool)
         if self.n_terms == 0 or PwordOp.n_terms == 0:
             return np.empty((self.n_terms, PwordOp.n_terms), dtype=bool)
+        if self.n_terms * PwordOp.n_terms >= multi.MIN_PAIRS_COMMUTES and multi.group() is not None:
+            # more than one MI355X in this process: the left term axis in contiguous blocks over the devices, the right operand all-gathered
+            # over xGMI, the blocks of the table read back over every device's own PCIe link (symmer_amd/multi.py)
+            return multi.group().commutes(self._multi_source(False), None if PwordOp is self else PwordOp._multi_source(False))
         a = self._device(rows_only=True)
         return kernels.commutes_handles(a, a if PwordOp is self else PwordOp._device(rows_only=True))
 

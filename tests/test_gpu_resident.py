@@ -215,3 +215,57 @@ def test_rotation_results_are_resident_and_chain():
     assert_op_equal(cur.symp_matrix, cur.coeff_vec, es, ec, exact=False, tol=1e-12)
     es, ec = onp.perform_rotations(P.symp_matrix, P.coeff_vec, list(zip(qs, (0.3, np.pi / 2, -1.1))))
     assert_op_equal(chained.symp_matrix, chained.coeff_vec, es, ec, exact=False, tol=1e-12)
+
+
+# ---------------------------------------------------------------- single-process multi-device mode (symmer_amd/multi.py), one device ----
+def test_device_group_on_one_device_runs_the_grouped_rccl_path(monkeypatch):
+    """The pool has one GPU per box: DeviceGroup over HipBackend(1) with SYMGPU_FORCE_COMM=1 goes through symgpu_init_all, ncclCommInitAll
+    with one communicator, the grouped all-gather (symgpu_comm_allgather_ops) and the same block kernels as n devices would; the block
+    arithmetic for 2 .. 8 devices is covered on the CPU by tests/test_multi_device.py.  Host sources and resident sources."""
+    from symmer_amd import multi, _lib
+    monkeypatch.setenv('SYMGPU_FORCE_COMM', '1')
+    be = multi.HipBackend(1)
+    assert be.n == 1 and be.degraded is None, be.degraded
+    grp = multi.DeviceGroup(be)
+    rng = np.random.default_rng(507)
+    n, N, M = 130, 700, 333
+    A = packing.pack_rows(rng.random((N, 2 * n)) < 0.3); B = packing.pack_rows(rng.random((M, 2 * n)) < 0.3)
+    a, b = dyadic(rng, N), dyadic(rng, M)
+    assert np.array_equal(grp.commutes((A, None), (B, None)), oc.commutes(A, B))
+    assert np.array_equal(grp.commutes((A, None)), oc.commutes(A, A))
+    dA, dB = kernels.DeviceOp.upload(A, a), kernels.DeviceOp.upload(B, b)
+    assert np.array_equal(grp.commutes(dA, dB), oc.commutes(A, B))
+    for src_a, src_b in (((A, a), (B, b)), (dA, dB)):
+        for left in (True, False):
+            res = grp.mul_cleanup(src_a, src_b, left, 1e-15)
+            pr, pc = oc.mul_allpairs(A, a, B, b, left)
+            er, ec = oc.cleanup(pr, pc, 1e-15)
+            rows, coeff = res.download()
+            assert np.array_equal(rows, er) and np.array_equal(coeff, ec)
+    res = grp.mul_cleanup(dA, None, True, 1e-15, same=True)
+    er, ec = oc.mul(A, a, A, a)
+    rows, coeff = res.download()
+    assert np.array_equal(rows, er) and np.array_equal(coeff, ec)
+    _lib.check(_lib.load().symgpu_comm_destroy())
+
+
+def test_current_device_and_handle_devices():
+    """symgpu_set_device / symgpu_current_device; a device that does not exist is refused; a handle keeps working whatever the thread's
+    current device is (calls run on the handle's device)."""
+    import threading
+    from symmer_amd import _lib
+    _lib.set_device(0)
+    assert _lib.current_device() == 0
+    with pytest.raises(_lib.SymgpuError):
+        _lib.set_device(_lib.device_count())                            # one past the last device
+    assert _lib.current_device() == 0
+    rng = np.random.default_rng(508)
+    rows = packing.pack_rows(rng.random((50, 140)) < 0.3)
+    op = kernels.DeviceOp.upload(rows, dyadic(rng, 50))
+    seen = {}
+
+    def other_thread():                                                 # a fresh thread starts on the process' default device
+        seen['dev'] = _lib.current_device()
+        seen['rows'] = op.download(with_coeff=False)
+    th = threading.Thread(target=other_thread); th.start(); th.join()
+    assert seen['dev'] == 0 and np.array_equal(seen['rows'], rows)
