@@ -788,7 +788,7 @@ def adjacency(args, comm, rank, world, _lib, DeviceOp, parallel):
     _lib.check(lib.symgpu_prof_read(1, ctypes.addressof(nl), ctypes.addressof(ms)))
     kt = ms.value / max(1, nl.value) * 1e-3
     pairs = T * T
-    n_kblocks = 2 * ((n + 7) // 8)
+    n_kblocks = m4r_groups(n)
     launch_rows = (b1 - b0) * args.steps / max(1, nl.value)
     lds_bytes = launch_rows * n_kblocks * (((T + 63) // 64 + 31) // 32) * 256.0
     out = {'metric': 'pauli_term_pairs_per_sec', 'value': pairs * args.steps / dt, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
@@ -802,7 +802,8 @@ def adjacency(args, comm, rank, world, _lib, DeviceOp, parallel):
            'roofline': {'bound': 'hbm', 'kernel': 'k_commutes_m4r', 'achieved': launch_rows * T / kt / 1e9 if kt else None, 'peak': HBM_PEAK_GBS,
                         'unit': 'GB/s', 'frac': launch_rows * T / kt / 1e9 / HBM_PEAK_GBS if kt else None, 'traffic': None,
                         'launches': nl.value, 'avg_launch_ms': kt * 1e3,
-                        'note': 'not HBM-bound: Four-Russians GF(2) product, one 256-byte LDS table entry per row, 8-bit k-block and 2048-column tile',
+                        'note': 'not HBM-bound: Four-Russians GF(2) product, one 256-byte LDS table entry per row, 7-bit group and 2048-column tile; two '
+                                'tables per step folded with v_bitop3 (csrc/commute_m4r7.hip)',
                         'lds': {'achieved_GBps': lds_bytes / kt / 1e9 if kt else None, 'peak_GBps': 157286.4,
                                 'frac': lds_bytes / kt / 1e9 / 157286.4 if kt else None,
                                 'peak_source': '256 CUs x 256 B/clk (ds_read_b128) x 2.4 GHz, MI355X_MICROARCH.md LDS table'}}}
@@ -816,6 +817,14 @@ def adjacency(args, comm, rank, world, _lib, DeviceOp, parallel):
     if rank == 0 and not args.no_cpu:
         out['cpu_baseline'] = guarded(lambda: cpu_adjacency(n))
     return out
+
+
+def m4r_groups(n):
+    """Non-zero 7-bit groups of a packed n-qubit row (X bits 0 .. n-1, Z bits 64 Wq .. 64 Wq + n-1): the table look-ups of one row and one
+    2048-column tile in csrc/commute_m4r7.hip, padded to whole pairs (a step reads two tables)."""
+    wq = (n + 63) // 64
+    groups = {b // 7 for b in range(n)} | {(64 * wq + b) // 7 for b in range(n)}
+    return len(groups) + (len(groups) & 1)
 
 
 def api_adjacency(n, T, c_abi_seconds):
@@ -1011,7 +1020,7 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
         nl, ms = prof_read(_lib, 1)
         kt = ms / max(1, nl) * 1e-3
         pairs = nrow * 200000
-        n_kblocks = 2 * ((2000 + 7) // 8)                              # non-zero index bytes of a 2,000-qubit row (X and Z halves)
+        n_kblocks = m4r_groups(2000)                                   # non-zero 7-bit groups of a 2,000-qubit row (X and Z halves)
         col_tiles = (200000 // 64 + 31) // 32
         lds_bytes = nrow * n_kblocks * col_tiles * 256.0
         full_s = line['ms_per_step'] * 1e-3

@@ -987,9 +987,9 @@ def test_commutes_both_kernels(n, N, M, dens, force, monkeypatch):
 
 
 @pytest.mark.parametrize('M', [4208, 4200])
-@pytest.mark.parametrize('r', ['16', '24', '40', '48', '116'])
+@pytest.mark.parametrize('r', ['16', '24', '40', '48'])
 def test_commutes_m4r_tile_heights(r, M, monkeypatch):
-    """Every instantiation of the Four-Russians kernel (rows per 16-lane slot; '116' = 16 waves x 16 rows) on a shape that
+    """Every instantiation of the Four-Russians kernel (rows per 16-lane slot; two 7-bit tables per step, csrc/commute_m4r7.hip) on a shape that
     leaves partial row and column tiles; M = 4208 takes the fused byte-expanding epilogue (16-byte stores), M = 4200 the
     bit-packed rows + separate expansion."""
     monkeypatch.setenv('SYMGPU_COMMUTE_M4R', '1'); monkeypatch.setenv('SYMGPU_M4R_R', r)

@@ -4,6 +4,7 @@
 //   MODE 1: reads + per-row accumulators (4 v_xor per read into acc[R][4]) + v_perm address (the real inner loop)
 //   MODE 2: as 1 but the address comes from a precomputed VGPR (no v_perm)
 //   MODE 3: ds_write_b64 table build only (16 entries per lane per iteration)
+//   MODE 8: TWO 32 KiB tables (7-bit groups) read per row and folded with v_bitop3 XOR3: 2 ds_read_b128 + 2 v_perm + 4 v_bitop3 per row (3 VALU per read)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
@@ -24,7 +25,7 @@ __global__ __launch_bounds__(512) void k(u64 *out, const u32 *idx_in, int iters)
     u64 acc[R][2];
     for (int j = 0; j < R; ++j) acc[j][0] = acc[j][1] = 0;
     u64x2 one = {0, 0};
-    if (MODE >= 4) {
+    if (MODE >= 4 && MODE != 8) {
         // pure store rate, values precomputed: MODE 4 = 16 x ds_write_b64 (entry stride 256 B), 5 = 8 x ds_write_b128 (16 lanes per entry),
         // 6 = 8 x ds_write_b128 with both halves... , 7 = 16 x b64 but only even waves write (half the waves)
         u64 e[16];
@@ -55,6 +56,46 @@ __global__ __launch_bounds__(512) void k(u64 *out, const u32 *idx_in, int iters)
             __syncthreads();
         }
         out[blockIdx.x * 512 + threadIdx.x] = e + lds[threadIdx.x];
+        return;
+    }
+    if (MODE == 8) {
+        u32 idx2[R / 4];
+        for (int q = 0; q < R / 4; ++q) idx2[q] = idx_in[4096 + (threadIdx.x >> 4) * (R / 4) + q] & 0x7f7f7f7fu;
+        for (int q = 0; q < R / 4; ++q) idx[q] &= 0x7f7f7f7fu;
+        for (int it = 0; it < iters; ++it) {
+            const u32 b = base | ((it & 1) << 16);
+            auto readA = [&](int j) -> u64x2 {
+                const u32 addr = __builtin_amdgcn_perm(idx[j / 4], b, 0x0c020000u | ((4u + (j % 4)) << 8));
+                return *reinterpret_cast<const lds_u64x2 *>((uintptr_t)addr);
+            };
+            auto readB = [&](int j) -> u64x2 {
+                const u32 addr = __builtin_amdgcn_perm(idx2[j / 4], b, 0x0c020000u | ((4u + (j % 4)) << 8));
+                return *reinterpret_cast<const lds_u64x2 *>((uintptr_t)addr + 32768);
+            };
+            u64x2 va[LOOK], vb[LOOK];
+#pragma unroll
+            for (int q = 0; q < LOOK; ++q) { va[q] = readA(q); vb[q] = readB(q); }
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const u64x2 a = va[j % LOOK], c = vb[j % LOOK];
+                const u32 l0 = __builtin_amdgcn_bitop3_b32((u32)acc[j][0], (u32)a.x, (u32)c.x, 0x96);
+                const u32 h0 = __builtin_amdgcn_bitop3_b32((u32)(acc[j][0] >> 32), (u32)(a.x >> 32), (u32)(c.x >> 32), 0x96);
+                const u32 l1 = __builtin_amdgcn_bitop3_b32((u32)acc[j][1], (u32)a.y, (u32)c.y, 0x96);
+                const u32 h1 = __builtin_amdgcn_bitop3_b32((u32)(acc[j][1] >> 32), (u32)(a.y >> 32), (u32)(c.y >> 32), 0x96);
+                acc[j][0] = ((u64)h0 << 32) | l0;
+                acc[j][1] = ((u64)h1 << 32) | l1;
+                asm volatile("" : "+v"(acc[j][0]), "+v"(acc[j][1]));
+                if (j + LOOK < R) { va[j % LOOK] = readA(j + LOOK); vb[j % LOOK] = readB(j + LOOK); }
+            }
+#pragma unroll
+            for (int q = 0; q < LOOK; ++q) { __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+#pragma unroll
+            for (int j = 0; j < R - LOOK; ++j) { __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x002, 4 * LOOK, 0);
+        }
+        u64 r = 0;
+        for (int j = 0; j < R; ++j) r ^= acc[j][0] ^ acc[j][1];
+        out[blockIdx.x * 512 + threadIdx.x] = r;
         return;
     }
     for (int it = 0; it < iters; ++it) {
@@ -94,12 +135,12 @@ template <int MODE, int R, int LOOK> void run(const char *name, u64 *out, u32 *i
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double per_iter_us = ms * 1e3 / iters / (blocks / 256.0);
-    const double instr = MODE >= 3 ? (MODE == 5 ? 8 * 8 : (MODE == 7 ? 4 * 16 : 8 * 16)) : 8.0 * R;
+    const double instr = MODE == 8 ? 16.0 * R : (MODE >= 3 ? (MODE == 5 ? 8 * 8 : (MODE == 7 ? 4 * 16 : 8 * 16)) : 8.0 * R);
     printf("%-44s %8.3f ms  %.3f us per iteration per CU  = %.0f cycles @2.3GHz, %.2f cycles per DS wave-instr\n", name, ms, per_iter_us, per_iter_us * 2300,
            per_iter_us * 2300 / instr);
 }
 int main() {
-    u64 *out; u32 *idx; hipMalloc(&out, 1024 * 512 * 8); hipMalloc(&idx, 1 << 16);
+    u64 *out; u32 *idx; hipMalloc(&out, 1024 * 512 * 8); hipMalloc(&idx, 1 << 16);   // idx: 16384 dwords (MODE 8 reads a second set from +4096)
     u32 *h = (u32 *)malloc(1 << 16); for (int i = 0; i < (1 << 14); ++i) h[i] = (u32)rand() * 2654435761u;
     hipMemcpy(idx, h, 1 << 16, hipMemcpyHostToDevice);
     run<0, 40, 8>("reads only, R=40 LOOK=8", out, idx);
@@ -109,6 +150,10 @@ int main() {
     run<1, 48, 6>("reads + 4 xor + perm, R=48 LOOK=6", out, idx);
     run<2, 40, 8>("reads + 4 xor (addr without perm), R=40", out, idx);
     run<1, 16, 8>("reads + 4 xor + perm, R=16 LOOK=8", out, idx);
+    run<8, 48, 3>("2 tables, xor3: R=48, 3 pairs in flight", out, idx);
+    run<8, 48, 4>("2 tables, xor3: R=48, 4 pairs in flight", out, idx);
+    run<8, 40, 4>("2 tables, xor3: R=40, 4 pairs in flight", out, idx);
+    run<8, 40, 6>("2 tables, xor3: R=40, 6 pairs in flight", out, idx);
     run<3, 16, 8>("table build: 16 x ds_write_b64 per lane", out, idx);
     run<4, 16, 8>("64 KiB: 16 x ds_write_b64 per lane, no VALU", out, idx);
     run<5, 16, 8>("64 KiB: 8 x ds_write_b128 per lane, no VALU", out, idx);
