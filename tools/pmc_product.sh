@@ -3,7 +3,7 @@
 # --pmc), then a kernel-trace pass of the same command.  Writes profiles/<tag>_traffic.json (read by bench.py, tied to the
 # sha256 of product.hip), profiles/<tag>_product_pmc.txt and profiles/<tag>_bench_n1_kernel_trace.txt into gpurun_out/<tag>/.
 export TMPDIR=/tmp
-tag=${1:-r04}
+tag=${1:-r05}
 out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
 cmd="bench.py --steps 2 --warmup 1 --no-extras --no-cpu"
 timeout 900 rocprofv3 --pmc WRITE_SIZE -d $out/w -o w -- python3 $cmd > $out/w.log 2>&1

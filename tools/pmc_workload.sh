@@ -5,7 +5,7 @@
 #   <tag>_<short>_traffic.json  (read by bench.py; tied to the sha256 of the kernel source), <tag>_<short>_pmc.txt, <tag>_<short>_kernel_trace.txt,
 #   <tag>_<short>_n1.json (the bench line under the profiler)
 export TMPDIR=/tmp
-tag=${1:-r04}; wl=${2:-rotation}
+tag=${1:-r05}; wl=${2:-rotation}
 case $wl in
   mul_cleanup) short=cfg3; like='%k_emit_fused%'; srcs="cleanup.hip";;
   rotation)    short=rotation; like='%k_rot_resident%'; srcs="rotate_resident.hip";;
