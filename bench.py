@@ -811,7 +811,7 @@ def adjacency(args, comm, rank, world, _lib, DeviceOp, parallel):
         out['degraded'] = comm.degraded
     for p in ring:
         _lib.check(lib.symgpu_dev_free(p))
-    traffic_from_profile(out['roofline'], f'{PROFILE_TAG}_adjacency_traffic.json', ['commute_m4r.hip'], {'workload': 'adjacency', 'n_qubits': n, 'terms': T})
+    traffic_from_profile(out['roofline'], f'{PROFILE_TAG}_adjacency_traffic.json', ['commute_m4r.hip', 'commute_m4r7.hip'], {'workload': 'adjacency', 'n_qubits': n, 'terms': T})
     if rank == 0 and world == 1 and not getattr(args, 'no_api', False):
         out['api'] = guarded(lambda: api_adjacency(n, T, dt / args.steps))
     if rank == 0 and not args.no_cpu:

@@ -10,7 +10,7 @@ case $wl in
   mul_cleanup) short=cfg3; like='%k_emit_fused%'; srcs="cleanup.hip";;
   rotation)    short=rotation; like='%k_rot_resident%'; srcs="rotate_resident.hip";;
   gf2)         short=gf2; like='%k_sweep_m4r<1>%'; srcs="gf2.hip";;
-  adjacency)   short=adjacency; like='%k_commutes_m4r%'; srcs="commute_m4r.hip";;
+  adjacency)   short=adjacency; like='%k_commutes_m4r%'; srcs="commute_m4r.hip commute_m4r7.hip";;
   *) echo "unknown workload $wl"; exit 2;;
 esac
 out=gpurun_out/${tag}_$wl; rm -rf $out; mkdir -p $out

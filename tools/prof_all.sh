@@ -15,11 +15,12 @@ done
 # 4. adjacency: kernel trace + LDS counters; run of Clifford rotations: kernel trace
 timeout 600 rocprofv3 --kernel-trace --stats -d $dst/adj -o t -- python3 bench.py --workload adjacency --steps 2 --warmup 1 --no-api --no-cpu > $dst/adj_under_rocprof.json 2> $dst/adj.log
 python3 profiles/summarize_rocpd.py $dst/adj/t_results.db | head -14 > $dst/${tag}_adjacency_kernel_trace.txt
-timeout 600 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_BUSY_CYCLES -d $dst/adjpmc -o p -- python3 bench.py --workload adjacency --steps 1 --warmup 0 --no-api --no-cpu > /dev/null 2> $dst/adjpmc.log
-python3 profiles/summarize_rocpd.py --pmc $dst/adjpmc/p_results.db | grep -E "counter|k_commutes_m4r" > $dst/${tag}_adjacency_lds_pmc.txt
+timeout 600 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU -d $dst/adjpmc -o p -- python3 bench.py --workload adjacency --steps 1 --warmup 0 --no-api --no-cpu > /dev/null 2> $dst/adjpmc.log
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_BUSY_CYCLES -d $dst/adjpmc2 -o p -- python3 bench.py --workload adjacency --steps 1 --warmup 0 --no-api --no-cpu > /dev/null 2> $dst/adjpmc2.log
+python3 profiles/summarize_rocpd.py --pmc $dst/adjpmc/p_results.db --pmc $dst/adjpmc2/p_results.db | grep -E "counter|k_commutes_m4r" > $dst/${tag}_adjacency_lds_pmc.txt
 timeout 600 rocprofv3 --kernel-trace --stats -d $dst/chain -o t -- python3 tools/bench_chain3.py > $dst/chain.out 2> $dst/chain.log
 { grep chain $dst/chain.out; python3 profiles/summarize_rocpd.py $dst/chain/t_results.db | grep -E "calls|cchain_reg|rs_coop|permute|cchain_flags|cchain_move" ; } > $dst/${tag}_clifford_run_kernel_trace.txt
-rm -rf $dst/adj $dst/adjpmc $dst/chain
+rm -rf $dst/adj $dst/adjpmc $dst/adjpmc2 $dst/chain
 # the traffic JSONs of THIS source go where bench.py looks for them (on the box's copy of the tree), then:
 cp $dst/${tag}_*traffic.json profiles/ 2>/dev/null
 # 5. the bench lines as the driver would see them (un-profiled; their `traffic` comes from the JSONs just written)
