@@ -14,7 +14,9 @@
 // behind a workgroup barrier, twice per step at R = 48), which the depth of the read window does not change (2 / 3 / 4 pairs: 37.4 / 36.1 /
 // 36.4 ms).  Measured and dropped this round: look-ups and the next table's build as one interleaved instruction stream (8-bit kernel, R = 40:
 // 45.8 against 44.7 ms — the LDS pipe serves reads and writes from one queue, the interleaved writes delay the reads the folds wait for) and
-// a staggered start of the first workgroup of every CU so that the 3 MB tile epilogues do not meet in the memory system (35.9 / 35.8 ms).
+// a staggered start of the first workgroup of every CU so that the 3 MB tile epilogues do not meet in the memory system (35.9 / 35.8 ms);
+// the index dwords in a rolling window of their own (read 2 LOOKP + 1 rows ahead inside the stream: one pass over all rows at R = 48 and one
+// round trip less per step, but 38.3 against 36.5 ms — the index reads queue in front of the table reads the folds wait for).
 //
 // Layouts prepared per call:
 //   A7[g][i]   bits [7g, 7g + 7) of packed row i (values 0..127), group-major, i zero padded to Npad; one more all-zero group at index
