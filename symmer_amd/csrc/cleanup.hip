@@ -1155,21 +1155,35 @@ __global__ __launch_bounds__(256) void k_touch(const u32x4 *__restrict__ p, i64 
 }
 
 // T = size of the index space the kept terms are filed under (pair indices, or the slots of a squared operator: `tri`)
-int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, const u64 *rows, int W, const u64 *inner, i64 Ni,
-                   const u64 *outer, symgpu_op_t *out, int Wq_out, bool tri, const LazyEmit &lz, bool want_first) {
+// word prefix of the kept-term bitmap (the output slot of every 32 indices' first kept term) + the number of kept terms, on the device
+static int emit_prefix(const u32 *markbits_p, i64 T, Scratch &wordprefix, Scratch &total) {
     hipStream_t st = ctx().stream;
     const i64 n_words = (T + 31) / 32;
-    Scratch wordprefix;
     SG_TRY(wordprefix.alloc((size_t)n_words * 4));
     hipLaunchKernelGGL(k_popc_words, dim3(grid_for(n_words)), dim3(256), 0, st, markbits_p, n_words, wordprefix.as<u32>());
     KERNEL_CHECK();
-    Scratch total;
-    SG_TRY(total.alloc(16));
-    SG_TRY(exclusive_scan_u32(wordprefix.as<u32>(), wordprefix.as<u32>(), n_words, total.as<u32>()));
-    u32 n_out32 = 0;
-    HIP_TRY(hipMemcpyAsync(&n_out32, total.p, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const i64 n_out = n_out32;
+    SG_TRY(total.alloc(32));                                       // [0] the count, [2] k_touch's sink, [4..5] cleanup_core's status words ride along
+    return exclusive_scan_u32(wordprefix.as<u32>(), wordprefix.as<u32>(), n_words, total.as<u32>());
+}
+
+// pre (optional): the prefix was formed and the count read back by the caller (cleanup_core reads it with its own status words: one host
+// round trip instead of two)
+struct EmitPrefix { Scratch wordprefix, total; i64 n_out = -1; };
+int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, const u64 *rows, int W, const u64 *inner, i64 Ni,
+                   const u64 *outer, symgpu_op_t *out, int Wq_out, bool tri, const LazyEmit &lz, bool want_first, EmitPrefix *pre = nullptr) {
+    hipStream_t st = ctx().stream;
+    const i64 n_words = (T + 31) / 32;
+    EmitPrefix own;
+    if (!pre || pre->n_out < 0) {
+        pre = &own;
+        SG_TRY(emit_prefix(markbits_p, T, own.wordprefix, own.total));
+        u32 n_out32 = 0;
+        HIP_TRY(hipMemcpyAsync(&n_out32, own.total.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        own.n_out = n_out32;
+    }
+    Scratch &wordprefix = pre->wordprefix, &total = pre->total;
+    const i64 n_out = pre->n_out;
     symgpu_op_t res = nullptr;
     SG_TRY(symgpu_op_alloc(n_out > 0 ? n_out : 1, Wq_out, 1, &res));
     res->T = n_out;
@@ -1341,11 +1355,20 @@ __global__ void k_popc_words64(const u64 *__restrict__ bits, i64 n_words, u32 *_
 // flagged keys, in array order, to the front of `out`
 __global__ __launch_bounds__(256) void k_compact_suspects(const u64 *__restrict__ keys, const u64 *__restrict__ suspect64, const u32 *__restrict__ prefix,
                                                            i64 n_chunks, u64 *__restrict__ out) {
+    // a lane per flag word (one coalesced load for 4,096 keys), then the few words that have a flag set one after the other with the whole
+    // wavefront (a product without repeated rows flags a few thousand of 5e7 keys: a wavefront per word spent 41 us reading zeros)
     const int lane = threadIdx.x & 63;
-    for (i64 c = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); c < n_chunks; c += (i64)gridDim.x * 4) {
-        const u64 b = suspect64[c];
-        if (b == 0ULL) continue;                                                 // wave-uniform
-        if ((b >> lane) & 1ULL) out[(i64)prefix[c] + __popcll(b & ((1ULL << lane) - 1ULL))] = keys[c * 64 + lane];
+    for (i64 base = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; base < n_chunks; base += (i64)gridDim.x * 256) {
+        const i64 mine = base + lane;
+        const u64 b = mine < n_chunks ? suspect64[mine] : 0ULL;
+        u64 nz = __ballot(b != 0ULL);
+        while (nz) {                                                             // wave-uniform
+            const int l = __builtin_ctzll(nz);
+            nz &= nz - 1;
+            const u64 bb = __shfl(b, l);
+            const i64 c = base + l;
+            if ((bb >> lane) & 1ULL) out[(i64)prefix[c] + __popcll(bb & ((1ULL << lane) - 1ULL))] = keys[c * 64 + lane];
+        }
     }
 }
 
@@ -1447,6 +1470,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         if (diag_side) HIP_TRY(hipEventRecord(c.ev_join, c.stream2));
     }
     bool lazy_final = false;
+    EmitPrefix pre;
     for (int attempt = 0; attempt < 6 && !ok; ++attempt) {
         // the lazy flow pays off on big key sets (its passes are fixed costs, the scatter it avoids only hurts at scale)
         const bool lazy_a = lazy && (lazy_env == 1 || Tk >= ((i64)1 << 22));
@@ -1517,7 +1541,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                         sus_active = true;
                         Tsort = h_sus;
                         if (Tsort > 0) {
-                            hipLaunchKernelGGL(k_compact_suspects, dim3((unsigned)grid_for((n_sc + 3) / 4, 1, 1 << 16)), dim3(256), 0, st, part, susbits.as<u64>(),
+                            hipLaunchKernelGGL(k_compact_suspects, dim3((unsigned)grid_for((n_sc + 255) / 256, 1, 1 << 16)), dim3(256), 0, st, part, susbits.as<u64>(),
                                                susprefix.as<u32>(), n_sc, spare);
                             KERNEL_CHECK();
                             // the flagged keys, sorted completely (the same rule for the number of sorted bits, now for a few thousand keys);
@@ -1666,9 +1690,17 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                                    (const u32 *)nullptr, patch_p, dirty_p);
         }
         KERNEL_CHECK();
-        u32 hflags[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(hflags, collision.p, 8, hipMemcpyDeviceToHost, st));
+        // the output stage's prefix over the kept-term bitmap is formed BEFORE this attempt's status words are read: the count of kept terms
+        // comes back with them (an attempt that has to be repeated throws the prefix away)
+        pre.n_out = -1;
+        SG_TRY(emit_prefix(markbits.as<u32>(), (squared && packed) ? Tk : T, pre.wordprefix, pre.total));
+        // (ONE copy to the host: a small device-to-host copy into pageable memory is a blocking round trip of 20-35 us each)
+        u32 hback[6] = {0, 0, 0, 0, 0, 0};                           // (a pinned destination was measured: no faster)
+        HIP_TRY(hipMemcpyAsync(pre.total.as<u32>() + 4, collision.p, 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(hback, pre.total.p, 24, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        const u32 hflags[2] = {hback[4], hback[5]};
+        pre.n_out = hback[0];
         if (sus_coop) {                                            // the one-launch sort of the flagged keys gave up at a barrier (GPU shared): its
             bool timed_out = false;                                // output is garbage; the form is off now, the next attempt sorts with launches
             SG_TRY(radix_sort_coop_check(&timed_out));
@@ -1690,7 +1722,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         lz.patchbits = patchbits.as<u32>(); lz.e_lo = e_lo.as<u32>(); lz.e_hi = e_hi.as<u32>();
         lz.ci = ci; lz.co = co; lz.coeff = coeff;
     }
-    return cleanup_finish(markbits.as<u32>(), sum_of.as<double>(), tri ? Tk : T, pair, rows, W, inner, Ni, outer, out, Wq_out, tri, lz, want_first);
+    return cleanup_finish(markbits.as<u32>(), sum_of.as<double>(), tri ? Tk : T, pair, rows, W, inner, Ni, outer, out, Wq_out, tri, lz, want_first, &pre);
 }
 
 }  // namespace symgpu

@@ -70,6 +70,8 @@ int require_ctx() {
 }
 void forget_bound_device() { t_bound_dev = -1; }
 
+
+
 int DeviceScope::enter(const symgpu_op_s *a, const symgpu_op_s *b, const symgpu_op_s *c) {
     saved = t_cur_dev;
     active = true;

@@ -131,3 +131,47 @@ def test_bench_eight_ranks_rank_arithmetic():
         assert doc['n_gpus'] == 8 and doc['config']['pairs_per_step'] == pairs and doc['value'] > 0
         if _n_gpus() < 8:
             assert 'host-staged' in doc.get('degraded', '')
+
+
+# ---------------------------------------------------------------- one process, several devices (symmer_amd/multi.py) ----
+@pytest.mark.timeout(600)
+def test_single_process_device_group_on_all_devices():
+    """DeviceGroup over HipBackend on every visible device (symgpu_init_all, ncclCommInitAll, grouped all-gather, peer copies, one download
+    thread per device) against the C oracle.  Needs two devices; the pool's boxes have one (tests/test_gpu_resident.py runs the same code with
+    one device, tests/test_multi_device.py the block arithmetic for 8)."""
+    if _n_gpus() < 2:
+        pytest.skip('one process driving several devices needs several devices; this box has one')
+    import numpy as np
+    from symmer_amd import multi, packing, _lib
+    from oracle import oracle_c as oc
+    G = min(8, _n_gpus())
+    be = multi.HipBackend(G)
+    grp = multi.DeviceGroup(be)
+    rng = np.random.default_rng(77)
+    n, N, M = 300, 5000, 3100
+    A = packing.pack_rows(rng.random((N, 2 * n)) < 0.3); B = packing.pack_rows(rng.random((M, 2 * n)) < 0.3)
+    a = (rng.integers(-8, 9, N) + 1j * rng.integers(-8, 9, N)) / 16.0; b = (rng.integers(-8, 9, M) + 1j * rng.integers(-8, 9, M)) / 16.0
+    assert np.array_equal(grp.commutes((A, None), (B, None)), oc.commutes(A, B))
+    assert np.array_equal(grp.commutes((A, None)), oc.commutes(A, A))
+    res = grp.mul_cleanup((A[:900], a[:900]), (B[:400], b[:400]), True, 1e-15)
+    pr, pc = oc.mul_allpairs(A[:900], a[:900], B[:400], b[:400], True)
+    er, ec = oc.cleanup(pr, pc, 1e-15)
+    rows, coeff = res.download()
+    assert np.array_equal(rows, er) and np.array_equal(coeff, ec)
+    assert be.degraded is None, be.degraded
+    _lib.check(_lib.load().symgpu_comm_destroy())
+
+
+@pytest.mark.timeout(900)
+def test_bench_single_process_line():
+    """`bench.py --gpus N` WITHOUT a launcher: one process drives the devices and prints the contract line (N = the visible devices, at most 2
+    here; with one device the same path runs through ncclCommInitAll with one communicator)."""
+    import subprocess, sys
+    n = min(2, _n_gpus())
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--single-process', '--steps', '1', '--warmup', '1', '--left-terms', '20000',
+                        '--right-terms', '20000', '--no-extras', '--no-cpu'], capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    doc = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    assert doc['n_gpus'] == n and doc['config']['pairs_per_step'] == n * 20000 * 20000 and doc['value'] > 0
+    assert 'ONE process' in doc['config']['parallelism'] and doc['degraded_kernels'] == []
