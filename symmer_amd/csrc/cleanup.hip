@@ -21,6 +21,7 @@
 namespace symgpu {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
 static u64 host_splitmix64(u64 &s) {
     u64 z = (s += 0x9e3779b97f4a7c15ULL);
@@ -1269,84 +1270,272 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
 // ---- products without repeated rows: the keys that COULD merge are few — find them after a partial sort, sort only them ---------------
 // The radix sort exists to bring equal keys together, but a product of operators without repeated rows merges next to nothing (cfg3:
 // the N diagonal pairs of P * P and nothing else), and the lazy flow has already decided every other term in index order
-// (k_mark_singles).  So the sort stops one 8-bit pass early: the keys are then ordered by `sorted` hash bits [lo, hi), a RUN of equal
-// bits holds ~Tk / 2^sorted keys (cfg3: 3) still in ascending index order (LSD passes are stable), and equal FULL keys can only sit in
-// one run.  k_find_suspects flags every key that has an equal full key (packed hash field first, then the 64-bit key rebuilt from the
-// operand hash tables) somewhere in its run — both partners — plus, conservatively, every key of a run too long to be seen whole
-// from its wavefront's window of three 64-key chunks and every key whose hash field is zero (the identity segment of a squared operator, N
-// keys in one run).  The flagged keys are compacted IN ARRAY ORDER (so equal keys stay in index order), sorted completely — a few
-// thousand keys instead of 5e7 — and handed to the unchanged segment machinery (fix-up, identity segment, k_heads_sums), which only
-// ever acts on segments of more than one key.  Inputs full of repeated rows flag most keys: the caller then finishes the last pass
-// on the whole array and carries on as before (the partial sort is the old sort's first passes, nothing is wasted but the flag pass).
-// cfg3: one scatter + one histogram pass over 5e7 keys (0.27 ms) and the 0.17 ms fix-up pass are replaced by one 0.08 ms read pass.
-constexpr int SUS_CPW = 8;                                             // chunks per wavefront of k_find_suspects
-constexpr int SUS_D = 12;                                              // a key is compared with the SUS_D keys before it
+// (k_mark_singles).  So the sort stops early: after `run_bits` / 8 passes the keys are ordered by hash bits [lo, lo + run_bits), a RUN of
+// equal bits holds ~Tk / 2^run_bits keys still in ascending index order (LSD passes are stable), and equal FULL keys can only sit in
+// one run.  k_find_suspects flags every key that has an equal full key somewhere in its run — both partners — plus every key whose hash
+// field is zero (the identity segment of a squared operator, N keys in one run).  The flagged keys are compacted IN ARRAY ORDER (so equal
+// keys stay in index order), sorted completely — a few thousand keys instead of 5e7 — and handed to the unchanged segment machinery
+// (fix-up, identity segment, k_heads_sums), which only ever acts on segments of more than one key.  Inputs full of repeated rows flag
+// most keys: the caller then finishes the remaining passes on the whole array and carries on as before (the partial sort is the old
+// sort's first passes, nothing is wasted but the flag pass).
+// Round 4 stopped ONE pass early (runs of 3 keys, each key compared with its 12 predecessors in registers).  Round 5 stops when a run
+// holds <= 1,024 keys on average (cfg3: two passes of four, runs of 763) and finds the partners inside a run through LDS: one scatter,
+// one histogram and one scan pass over 5e7 keys less (0.27 ms), for a flag pass of the same cost.
+//
+// A workgroup owns the runs that START in its tile of 4,096 positions: it skips the head of the tile that continues the previous tile's
+// run and reads on past the end of the tile until its last run ends (the neighbour skips exactly those keys).  The words w = key bits
+// [lo, lo + 32) of the owned keys go through a pair of LDS bitmaps (2^17 bits each, index = multiplicative hash of w): `seen`, and `dup`
+// for a bit that was already set.  Every key whose `dup` bit is set — the keys that have a partner, plus ~4 % chance hits — is listed, the
+// listed words are compared all against all (a hundred or two per workgroup), and an equal word is followed up with the hash field and
+// then the full 64-bit keys rebuilt from the operand hash tables, exactly the test the segment machinery makes.  A list that overflows
+// flags every key the workgroup owns; a run longer than SUS_MAX_EXT extension steps raises `giveup` (the caller finishes the sort).
+constexpr int SUS_TILE = 4096;
+constexpr int SUS_BLOOM = 16;                                          // log2 bits per bitmap: 8 KB each
+constexpr int SUS_CAND = 512;
+constexpr int SUS_MAX_EXT = 64;                                        // steps of 1,024 keys a workgroup reads past its tile
+constexpr int SUS_WAVES = 8;                                           // 512 threads: eight keys of the tile and two of an extension step per lane
+constexpr int SUS_ROWS = SUS_TILE / (64 * SUS_WAVES), SUS_XROWS = 1024 / (64 * SUS_WAVES);
+constexpr int SUS_RUN_BITS = 16;                                       // the caller's partial sort: key bits [32, 48)
 __device__ __forceinline__ u32 wave_shr1(u32 v, u32 lane0) {            // lane L <- v[L - 1], lane 0 <- lane0 (DPP wave_shr:1, one VALU instruction)
     return (u32)__builtin_amdgcn_update_dpp((int)lane0, (int)v, 0x138, 0xf, 0xf, false);
 }
-// Equal keys have equal run bits, so a key's partners are among its neighbours in the partially sorted array: the word w = key bits
-// [lo, lo + 32) (the run bits and the hash bits above them) of every key is compared with the SUS_D keys before it — one DPP shift of the
-// wavefront's 64 words per distance, the tail of the previous chunk shifted in at lane 0 — and an equal word (one lane in ~10^5) is
-// followed up with the hash field and then the full 64-bit keys rebuilt from the operand hash tables.  A partner further away than
-// SUS_D needs a run longer than SUS_D + 1 keys (P < 2e-6 per run at the 3 keys a run holds on average): every key of such a run is
-// flagged without looking — a position whose run bits equal those SUS_D positions before it flags itself and the SUS_D keys before it.
-__global__ __launch_bounds__(256) void k_find_suspects(const u64 *__restrict__ keys, i64 T, int lo, int run_bits, PackedLayout L, const u64 *__restrict__ hI,
-                                                        const u64 *__restrict__ hO, u64 *__restrict__ suspect64) {
-    const int lane = threadIdx.x & 63;
-    const i64 n_chunks = (T + 63) / 64;
-    const u32 rmask = run_bits >= 32 ? ~0u : ((1u << run_bits) - 1u);       // lo <= 32 and run_bits <= 32 (the caller's condition)
+// w = the upper half of a key: run bits v below, sixteen more hash bits u above.  Inside a workgroup's range v takes a handful of consecutive
+// values, so the two slots of a word are u and (u / 8, v mod 8): words that share both are equal (up to eight runs), and a key that is
+// listed without a partner needs a chance hit in each (~1 % of the keys; with one slot 7 %, and the all-against-all comparison of
+// the listed keys then costs more than everything else)
+__device__ __forceinline__ u32 sus_slot(u32 w) { return w >> 16; }
+__device__ __forceinline__ u32 sus_slot2(u32 w) { return (w >> 19) | ((w & 7u) << 13); }
+static_assert(SUS_BLOOM == 16 && SUS_RUN_BITS == 16, "sus_slot / sus_slot2 are written for these");
+__global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_find_suspects(const u64 *__restrict__ keys, i64 T, PackedLayout L, const u64 *__restrict__ hI,
+                                                                   const u64 *__restrict__ hO, u64 *__restrict__ suspect64, u32 *__restrict__ giveup) {
+    constexpr int NT = 64 * SUS_WAVES;
+    __shared__ u32 s_seen[1 << (SUS_BLOOM - 5)], s_dup[1 << (SUS_BLOOM - 5)];
+    __shared__ __attribute__((aligned(16))) u32 s_cw[SUS_CAND];
+    __shared__ u64 s_ck[SUS_CAND];
+    __shared__ u32 s_cpos[SUS_CAND];
+    __shared__ u32 s_start, s_end[2], s_nc;                             // s_end by step parity: a wavefront is at most one barrier ahead
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 lt_mask = (1ULL << lane) - 1ULL;
+    const i64 t0 = (i64)blockIdx.x * SUS_TILE;
+    const u64 *kt = keys + t0;
+    const u32 n_rel = T - t0 < (i64)0x7fffffff ? (u32)(T - t0) : 0x7fffffffu;          // positions from t0 on, as far as this workgroup could ever reach
+    const u32 t1_rel = n_rel < (u32)SUS_TILE ? n_rel : (u32)SUS_TILE;
+    const u32 rmask = (1u << SUS_RUN_BITS) - 1u;
     const int F = L.F();
-    // a wavefront walks SUS_CPW consecutive chunks and hands the words of the previous chunk on in registers; the loads are clamped and
-    // unconditional (a load under a branch is waited for at the branch's join, i.e. at once), one chunk ahead
-    const i64 c0 = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * SUS_CPW;
-    if (c0 >= n_chunks) return;
-    auto load = [&](i64 cc) -> u64 { i64 q = cc * 64 + lane; q = q < 0 ? 0 : (q < T ? q : T - 1); return keys[q]; };
-    u64 kp = load(c0 - 1), kc = load(c0);
-    for (i64 c = c0; c < c0 + SUS_CPW && c < n_chunks; ++c) {
-        const u64 kn = load(c + 1);
-        const i64 p = c * 64 + lane;
-        const bool vc = p < T;
-        // words past the end / before the start can equal nothing: all ones never occurs behind a valid key's word... it could, so validity
-        // is tracked in the compare instead: positions before 0 only exist for c == 0, where the previous chunk's words are forced to
-        // differ from every lane's (w ^ 0x80000000 of the lane itself)
-        const u32 wc = (u32)(kc >> lo);
-        u32 A = wc, P = c > 0 ? (u32)(kp >> lo) : (wc ^ 0x80000000u);
-        u64 partner_core = 0ULL, partner_prev = 0ULL, mine = __ballot(vc && (kc >> F) == 0ULL);
+    typedef unsigned long long ull;
+    auto at = [&](u32 rel) -> u64 { return kt[rel < n_rel ? rel : n_rel - 1]; };      // clamped, unconditional
+    auto hash0 = [&](u64 k) -> bool { return (k >> F) == 0ULL; };                      // the identity segment
+    // the tile — a wavefront holds 512 consecutive keys — and the first 1,024 keys behind it (a run of 763 keys on average ends there):
+    // all loads in flight together
+    constexpr int NK = SUS_ROWS + SUS_XROWS;
+    u64 key[NK];
+    const u32 wrel = (u32)wave * (64 * SUS_ROWS), xrel = (u32)SUS_TILE + (u32)wave * (64 * SUS_XROWS);
+    auto rel_of = [&](int r) -> u32 { return (r < SUS_ROWS ? wrel + r * 64 : xrel + (r - SUS_ROWS) * 64) + lane; };
 #pragma unroll
-        for (int d = 1; d <= SUS_D; ++d) {
-            const u32 carry = (u32)__builtin_amdgcn_readlane((int)P, 63);
-            A = wave_shr1(A, carry);
-            P = wave_shr1(P, carry ^ 0x80000000u);                             // (lane 0 of the previous chunk's predecessor: unknown, made unequal)
-            const bool cand = vc && A == wc;
-            if (__ballot(cand)) {                                                // rare: fetch the partner's key, compare the hash field, then the full keys
-                const int src = lane - d;
-                const u64 ko_c = __shfl(kc, src & 63), ko_p = __shfl(kp, src & 63);
-                const u64 ko = src >= 0 ? ko_c : ko_p;
-                const bool pv = src >= 0 || c > 0;
-                const bool eq = cand && pv && (ko >> F) == (kc >> F) && L.full_key(hI, hO, ko) == L.full_key(hI, hO, kc);
-                const u64 m = __ballot(eq);
-                mine |= m;
-                partner_core |= m >> d;                                          // lane - d of this chunk ...
-                partner_prev |= m << (64 - d);                                   // ... or, for the lanes below d, lane - d + 64 of the previous one
+    for (int r = 0; r < NK; ++r) key[r] = at(rel_of(r));
+    const u64 kprev = (t0 > 0 || wrel > 0) ? keys[t0 + wrel - 1] : 0ULL;
+    const u64 kpe = at(xrel - 1);
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < (1 << (SUS_BLOOM - 5)) / (4 * NT); ++k) {
+            reinterpret_cast<u32x4 *>(s_seen)[k * NT + threadIdx.x] = z;
+            reinterpret_cast<u32x4 *>(s_dup)[k * NT + threadIdx.x] = z;
+        }
+    }
+    if (threadIdx.x == 0) { s_start = ~0u; s_end[0] = ~0u; s_end[1] = ~0u; s_nc = 0u; }
+    __syncthreads();
+    // first position of the tile where a run starts, and first one behind the tile
+    {
+        u32 carry = (u32)(kprev >> 32) & rmask;
+        u32 first_b = ~0u, first_e = ~0u;
+#pragma unroll
+        for (int r = 0; r < NK; ++r) {
+            if (r == SUS_ROWS) carry = (u32)(kpe >> 32) & rmask;
+            const u32 v = (u32)(key[r] >> 32) & rmask;
+            const u32 pv = wave_shr1(v, carry);
+            carry = (u32)__builtin_amdgcn_readlane((int)v, 63);
+            const u32 rel = rel_of(r);
+            if (r < SUS_ROWS) {
+                const u64 bm = __ballot(rel < t1_rel && (v != pv || (t0 == 0 && rel == 0)));
+                if (bm && first_b == ~0u) first_b = rel - lane + (u32)__builtin_ctzll(bm);
+            } else {
+                const u64 bm = __ballot(rel < n_rel && v != pv);
+                if (bm && first_e == ~0u) first_e = rel - lane + (u32)__builtin_ctzll(bm);
             }
         }
-        // runs longer than SUS_D + 1: A now holds the words SUS_D positions back
-        {
-            const u64 S = __ballot(vc && ((A ^ wc) & rmask) == 0u && (lane >= SUS_D || c > 0));
-            if (S) {
-                u64 lc = S, lp = 0ULL;
+        if (lane == 0 && first_b != ~0u) atomicMin(&s_start, first_b);
+        if (lane == 0 && first_e != ~0u) atomicMin(&s_end[0], first_e);
+    }
+    __syncthreads();
+    const u32 s_rel = s_start;
+    if (s_rel == ~0u) return;                                           // the whole tile continues a run that started earlier (block-uniform)
+    // the end of the last run that starts in the tile: in the first 1,024 keys behind it, or (rare) further on, in steps of 1,024 keys
+    u32 e_rel = t1_rel;
+    bool closed = n_rel <= (u32)SUS_TILE;
+    if (!closed) {
+        const u32 end_now = s_end[0];
+        const u32 step_end = (u32)SUS_TILE + 1024u;
+        if (end_now != ~0u) { e_rel = end_now; closed = true; }
+        else if (step_end >= n_rel) { e_rel = n_rel; closed = true; }
+        else e_rel = step_end;
+    }
+    auto flag_chunk = [&](u64 m, i64 chunk) {
+        if (lane == 0 && m) atomicOr(reinterpret_cast<ull *>(suspect64 + chunk), (ull)m);
+    };
+    // `seen` bits of a lane's keys back to back (a lane that owns nothing ORs a zero), then the `dup` bits
+    {
+        u32 ins = 0;                                                    // bit r = key r of this lane goes into the bitmaps
 #pragma unroll
-                for (int j = 1; j <= SUS_D; ++j) { lc |= S >> j; lp |= S << (64 - j); }
-                mine |= lc;
-                partner_prev |= lp;
+        for (int r = 0; r < NK; ++r) {
+            const u32 rel = rel_of(r);
+            const bool own = rel >= s_rel && rel < e_rel;
+            const bool zh = own && hash0(key[r]);
+            flag_chunk(__ballot(zh), (t0 + rel - lane) / 64);
+            ins |= ((own && !zh) ? 1u : 0u) << r;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                                   // five keys at a time: ten atomics with return in flight
+            constexpr int HB = NK / 2;
+            u32 old[HB], old2[HB];
+#pragma unroll
+            for (int q = 0; q < HB; ++q) {
+                const int r = h * HB + q;
+                const u32 w = (u32)(key[r] >> 32), slot = sus_slot(w), slot2 = sus_slot2(w), in = (ins >> r) & 1u;
+                old[q] = atomicOr(&s_seen[slot >> 5], in << (slot & 31));
+                old2[q] = atomicOr(&s_seen[slot2 >> 5], in << (slot2 & 31));
+            }
+#pragma unroll
+            for (int q = 0; q < HB; ++q) {
+                const int r = h * HB + q;
+                const u32 w = (u32)(key[r] >> 32), slot = sus_slot(w), slot2 = sus_slot2(w), in = (ins >> r) & 1u;
+                atomicOr(&s_dup[slot >> 5], old[q] & (in << (slot & 31)));
+                atomicOr(&s_dup[slot2 >> 5], old2[q] & (in << (slot2 & 31)));
             }
         }
-        mine |= partner_core;
-        if (lane == 0) {
-            if (mine) atomicOr(reinterpret_cast<unsigned long long *>(suspect64 + c), (unsigned long long)mine);
-            if (partner_prev && c > 0) atomicOr(reinterpret_cast<unsigned long long *>(suspect64 + c - 1), (unsigned long long)partner_prev);
+    }
+    for (int step = 1; !closed; ++step) {
+        if (step == SUS_MAX_EXT) {                                      // block-uniform
+            if (threadIdx.x == 0) atomicOr(giveup, 1u);
+            return;
         }
-        kp = kc; kc = kn;
+        const u32 q0 = xrel + (u32)step * 1024u;
+        u64 kq[SUS_XROWS];
+#pragma unroll
+        for (int r = 0; r < SUS_XROWS; ++r) kq[r] = at(q0 + r * 64 + lane);
+        const u64 kp = at(q0 - 1);
+        u32 carry = (u32)(kp >> 32) & rmask, first_e = ~0u;
+#pragma unroll
+        for (int r = 0; r < SUS_XROWS; ++r) {
+            const u32 rel = q0 + r * 64 + lane;
+            const u32 v = (u32)(kq[r] >> 32) & rmask;
+            const u32 pv = wave_shr1(v, carry);
+            carry = (u32)__builtin_amdgcn_readlane((int)v, 63);
+            const u64 bm = __ballot(rel < n_rel && v != pv);
+            if (bm && first_e == ~0u) first_e = q0 + r * 64 + (u32)__builtin_ctzll(bm);
+        }
+        if (lane == 0 && first_e != ~0u) atomicMin(&s_end[step & 1], first_e);
+        __syncthreads();
+        const u32 end_now = s_end[step & 1];
+        const u32 step_end = (u32)SUS_TILE + (u32)(step + 1) * 1024u;
+        if (end_now != ~0u) { e_rel = end_now; closed = true; }
+        else if (step_end >= n_rel) { e_rel = n_rel; closed = true; }
+        else e_rel = step_end;
+#pragma unroll
+        for (int r = 0; r < SUS_XROWS; ++r) {
+            const u32 rel = q0 + r * 64 + lane;
+            const bool own = rel < e_rel;
+            const bool zh = own && hash0(kq[r]);
+            flag_chunk(__ballot(zh), (t0 + q0) / 64 + r);
+            const u32 w = (u32)(kq[r] >> 32), slot = sus_slot(w), slot2 = sus_slot2(w);
+            const u32 bit = (own && !zh) ? 1u << (slot & 31) : 0u, bit2 = (own && !zh) ? 1u << (slot2 & 31) : 0u;
+            const u32 old = atomicOr(&s_seen[slot >> 5], bit), old2 = atomicOr(&s_seen[slot2 >> 5], bit2);
+            atomicOr(&s_dup[slot >> 5], old & bit);
+            atomicOr(&s_dup[slot2 >> 5], old2 & bit2);
+        }
+    }
+    __syncthreads();
+    // the owned keys whose two bits were both set twice: one counter update per wavefront
+    auto listed = [&](u32 rel, u64 k) -> bool {
+        const u32 w = (u32)(k >> 32), slot = sus_slot(w), slot2 = sus_slot2(w);
+        return rel >= s_rel && rel < e_rel && ((s_dup[slot >> 5] >> (slot & 31)) & (s_dup[slot2 >> 5] >> (slot2 & 31)) & 1u) && !hash0(k);
+    };
+    {
+        u64 m[NK];
+        u32 total = 0;
+#pragma unroll
+        for (int r = 0; r < NK; ++r) {
+            m[r] = __ballot(listed(rel_of(r), key[r]));
+            total += (u32)__popcll(m[r]);
+        }
+        if (total) {                                                    // wave-uniform
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&s_nc, total);
+            base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+            for (int r = 0; r < NK; ++r) {
+                const u32 n = base + (u32)__popcll(m[r] & lt_mask);
+                if (((m[r] >> lane) & 1ULL) && n < (u32)SUS_CAND) { s_cpos[n] = rel_of(r); s_ck[n] = key[r]; s_cw[n] = (u32)(key[r] >> 32); }
+                base += (u32)__popcll(m[r]);
+            }
+        }
+    }
+    for (u32 rel = (u32)SUS_TILE + 1024u + threadIdx.x; rel < e_rel; rel += NT) {      // (the steps that were not kept in registers)
+        const u64 k = kt[rel];
+        if (listed(rel, k)) {
+            const u32 n = atomicAdd(&s_nc, 1u);
+            if (n < (u32)SUS_CAND) { s_cpos[n] = rel; s_ck[n] = k; s_cw[n] = (u32)(k >> 32); }
+        }
+    }
+    __syncthreads();
+    const u32 nc = s_nc;
+    if (nc > (u32)SUS_CAND) {                                           // (repeated rows all over: the caller gives the partial sort up anyway)
+        for (u32 rel = s_rel + threadIdx.x; rel < e_rel; rel += NT)
+            atomicOr(reinterpret_cast<ull *>(suspect64 + ((t0 + rel) >> 6)), 1ULL << ((t0 + rel) & 63));
+        return;
+    }
+    // listed keys all against all by their words (a broadcast 16-byte read serves four) — no memory access in the loop: a lane that
+    // followed an equal word up with loads made the whole wavefront wait for every such lane in turn (a run of 763 keys holds four pairs
+    // with equal 32-bit words), and that was two thirds of the kernel.  One partner: the rest of the hash field, then the 64-bit keys
+    // rebuilt from the operand hash tables decide, all lanes at once (a run holds 0.02 triples of equal words on average: 3,000 keys of
+    // 5e7, and flagged without looking they cost the fix-up pass of the flagged keys 0.15 ms); more than two: flagged without looking.
+    // (two lanes per listed key, each on half of the list: the tail of a workgroup is a handful of lanes at work)
+    const u32 nc4 = (nc + 3u) & ~3u, half = ((nc4 / 4 + 1) / 2) * 4;
+    for (u32 a0 = 0; a0 < nc; a0 += NT / 2) {
+        const u32 a = a0 + threadIdx.x / 2, part = threadIdx.x & 1u;
+        const bool live = a < nc;
+        const u32 wa = live ? s_cw[a] : 0u;
+        u32 n_eq = 0, first = 0, last = 0;
+        const u32 b0 = part ? half : 0u, b1 = part ? nc : (half < nc ? half : nc);
+#pragma unroll 4
+        for (u32 b = b0; b < b1; b += 4) {
+            const u32x4 w = *reinterpret_cast<const u32x4 *>(&s_cw[b]);
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j)
+                if (live && w[j] == wa && b + j != a && b + j < b1) {
+                    if (n_eq == 0) first = b + j;
+                    last = b + j;
+                    ++n_eq;
+                }
+        }
+        {   // both halves together: with up to two partners (first, last) are all of them
+            const u32 n_o = (u32)__shfl_xor((int)n_eq, 1), f_o = (u32)__shfl_xor((int)first, 1), l_o = (u32)__shfl_xor((int)last, 1);
+            const u32 n_lo = part ? n_o : n_eq, f_lo = part ? f_o : first, l_lo = part ? l_o : last;
+            const u32 n_hi = part ? n_eq : n_o, f_hi = part ? first : f_o, l_hi = part ? last : l_o;
+            first = n_lo ? f_lo : f_hi;
+            last = n_hi ? l_hi : l_lo;
+            n_eq = n_lo + n_hi;
+        }
+        bool hit = n_eq > 2;                                            // (four equal 32-bit words in one run: flagged without looking)
+        if (n_eq >= 1 && n_eq <= 2 && part == 0) {
+            const u64 ka = s_ck[a], kb = s_ck[first], kc = s_ck[last];
+            const u64 fa = L.full_key(hI, hO, ka);
+            hit = (((ka ^ kb) >> F) == 0ULL && fa == L.full_key(hI, hO, kb)) || (((ka ^ kc) >> F) == 0ULL && fa == L.full_key(hI, hO, kc));
+        }
+        if (hit && part == 0) {
+            const i64 p = t0 + s_cpos[a];
+            atomicOr(reinterpret_cast<ull *>(suspect64 + (p >> 6)), 1ULL << (p & 63));
+        }
     }
 }
 __global__ void k_popc_words64(const u64 *__restrict__ bits, i64 n_words, u32 *__restrict__ counts) {
@@ -1505,34 +1694,35 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 // products whose keys mostly merge with nothing: stop the sort one pass early and sort only the keys that have a partner
                 // (k_find_suspects).  Applies when a run of the partial order is short (<= 8 keys on average) and the operands are not
                 // one array used twice without the squared-operator compaction (then EVERY key has its twin).
-                const int n_pass = (nbits + 7) / 8;
-                int lgk = 0;
-                while (((i64)1 << lgk) < Tk) ++lgk;
-                // SYMGPU_CLEANUP_SUSPECTS: 0 = complete sort of all keys; 2 = tests: behave as if most keys were flagged (the last pass is finished on the whole array)
+                // SYMGPU_CLEANUP_SUSPECTS: 0 = complete sort of all keys; 2 = tests: behave as if most keys were flagged (the remaining passes are finished on the whole array)
                 const bool sus_env = [] { const char *e = getenv("SYMGPU_CLEANUP_SUSPECTS"); return !(e && e[0] == '0'); }();
                 const bool sus_giveup = [] { const char *e = getenv("SYMGPU_CLEANUP_SUSPECTS"); return e && e[0] == '2'; }();
-                const bool sus_try = lazy_a && sus_env && n_pass >= 2 && n_pass <= 5 && nbits >= 32 && lgk <= 8 * (n_pass - 1) + 2 && !(inner == outer && !squared);
+                // two passes before the flag pass, on key bits [32, 48): a run then holds <= 1,024 keys on average
+                const int sus_pass = SUS_RUN_BITS / 8;
+                const bool sus_try = lazy_a && sus_env && nbits == 32 && (Tk >> SUS_RUN_BITS) <= 1024 && !(inner == outer && !squared);
                 if (!sus_try) {
                     SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp, first_hist));
                 } else {
-                    const int lo = 64 - nbits, hi = lo + 8 * (n_pass - 1);
+                    const int lo = 64 - nbits, hi = lo + 8 * sus_pass;
                     SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, lo, hi, &in_tmp, first_hist));
                     u64 *part = in_tmp ? keys2.as<u64>() : keys.as<u64>(), *spare = in_tmp ? keys.as<u64>() : keys2.as<u64>();
                     const i64 n_sc = (Tk + 63) / 64;
                     Scratch susbits, susprefix, sustotal;
                     SG_TRY(susbits.alloc((size_t)n_sc * 8));
                     SG_TRY(susprefix.alloc((size_t)n_sc * 4));
-                    SG_TRY(sustotal.alloc(16));
+                    SG_TRY(sustotal.alloc(16));                            // [0] flagged keys, [1] a run too long for the flag pass
                     HIP_TRY(hipMemsetAsync(susbits.p, 0, (size_t)n_sc * 8, st));
-                    hipLaunchKernelGGL(k_find_suspects, dim3((unsigned)((n_sc + 4 * SUS_CPW - 1) / (4 * SUS_CPW))), dim3(256), 0, st, part, Tk, lo, hi - lo, L, hI.as<u64>(),
-                                       hO.as<u64>(), susbits.as<u64>());
+                    HIP_TRY(hipMemsetAsync(sustotal.p, 0, 16, st));
+                    hipLaunchKernelGGL(k_find_suspects, dim3((unsigned)((Tk + SUS_TILE - 1) / SUS_TILE)), dim3(64 * SUS_WAVES), 0, st, part, Tk, L, hI.as<u64>(),
+                                       hO.as<u64>(), susbits.as<u64>(), sustotal.as<u32>() + 1);
                     hipLaunchKernelGGL(k_popc_words64, dim3(grid_for(n_sc)), dim3(256), 0, st, susbits.as<u64>(), n_sc, susprefix.as<u32>());
                     KERNEL_CHECK();
                     SG_TRY(exclusive_scan_u32(susprefix.as<u32>(), susprefix.as<u32>(), n_sc, sustotal.as<u32>()));
-                    u32 h_sus = 0;
-                    HIP_TRY(hipMemcpyAsync(&h_sus, sustotal.p, 4, hipMemcpyDeviceToHost, st));
+                    u32 h_sus2[4] = {0, 0, 0, 0};
+                    HIP_TRY(hipMemcpyAsync(h_sus2, sustotal.p, 16, hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipStreamSynchronize(st));
-                    if ((i64)h_sus * 16 > Tk || sus_giveup) {
+                    const u32 h_sus = h_sus2[0];
+                    if ((i64)h_sus * 16 > Tk || sus_giveup || h_sus2[1]) {
                         // repeated rows all over: the last pass on the whole array after all (LSD: the order so far is its first passes)
                         bool in_tmp2 = false;
                         SG_TRY(radix_sort_keys_u64(part, spare, Tk, hi, 64, &in_tmp2));
