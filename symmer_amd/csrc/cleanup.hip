@@ -1149,9 +1149,12 @@ int hash_rows(const u64 *rows, i64 T, int W, u64 *out1) {
 // Reads every 16-byte chunk of a buffer and keeps nothing: run right before the output stage on the bitmaps it decodes (written two
 // gigabytes of traffic earlier, so out of the Infinity Cache again) — a saturated HBM WRITE stream tolerates cache hits, but every HBM
 // read mixed into it costs the DRAM a turn-around.
-__global__ __launch_bounds__(256) void k_touch(const u32x4 *__restrict__ p, i64 n16, u32 *__restrict__ sink) {
+struct TouchMaps { const u32x4 *p[5]; i64 n16[5]; };
+__global__ __launch_bounds__(256) void k_touch(TouchMaps tm, u32 *__restrict__ sink) {
     u32 acc = 0;
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n16; i += (i64)gridDim.x * 256) { const u32x4 v = p[i]; acc |= v.x & v.y & v.z & v.w; }
+#pragma unroll
+    for (int m = 0; m < 5; ++m)
+        for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < tm.n16[m]; i += (i64)gridDim.x * 256) { const u32x4 v = tm.p[m][i]; acc |= v.x & v.y & v.z & v.w; }
     if (acc == 0xDEADBEEFu) *sink = acc;                           // (never true for bitmaps of a real run; keeps the loads alive)
 }
 
@@ -1169,7 +1172,24 @@ static int emit_prefix(const u32 *markbits_p, i64 T, Scratch &wordprefix, Scratc
 
 // pre (optional): the prefix was formed and the count read back by the caller (cleanup_core reads it with its own status words: one host
 // round trip instead of two)
-struct EmitPrefix { Scratch wordprefix, total; i64 n_out = -1; };
+struct EmitPrefix { Scratch wordprefix, total; i64 n_out = -1; bool touched = false; };
+// one launch over the bitmaps the fused output stage decodes (five launches of 2 us each sat 6 us apart behind the host's read-back)
+static bool emit_is_fused(int Wq) { return Wq <= 64 && [] { const char *e = getenv("SYMGPU_EMIT_FUSED"); return !(e && e[0] == '0'); }(); }
+static int emit_touch(const u32 *markbits_p, i64 T, const LazyEmit &lz, EmitPrefix &pre) {
+    const i64 n16 = (T + 63) / 64 / 2;                              // whole 16-byte chunks of a T-bit map
+    pre.touched = true;
+    if (n16 <= 0) return SYMGPU_OK;
+    TouchMaps tm;
+    const void *maps[5] = {markbits_p, pre.wordprefix.p, lz.mode ? (const void *)lz.patchbits : nullptr, lz.mode == 1 ? (const void *)lz.e_lo : nullptr,
+                           lz.mode == 1 ? (const void *)lz.e_hi : nullptr};
+    for (int m = 0; m < 5; ++m) {
+        tm.p[m] = reinterpret_cast<const u32x4 *>(maps[m]);
+        tm.n16[m] = maps[m] ? (m == 1 ? 2 * n16 : n16) : 0;
+    }
+    hipLaunchKernelGGL(k_touch, dim3(grid_for(2 * n16)), dim3(256), 0, ctx().stream, tm, pre.total.as<u32>() + 2);
+    KERNEL_CHECK();
+    return SYMGPU_OK;
+}
 int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, const u64 *rows, int W, const u64 *inner, i64 Ni,
                    const u64 *outer, symgpu_op_t *out, int Wq_out, bool tri, const LazyEmit &lz, bool want_first, EmitPrefix *pre = nullptr) {
     hipStream_t st = ctx().stream;
@@ -1179,8 +1199,7 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
         pre = &own;
         SG_TRY(emit_prefix(markbits_p, T, own.wordprefix, own.total));
         u32 n_out32 = 0;
-        HIP_TRY(hipMemcpyAsync(&n_out32, own.total.p, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        SG_TRY(read_back_words(own.total.as<u32>(), 1, nullptr, 0, &n_out32));
         own.n_out = n_out32;
     }
     Scratch &wordprefix = pre->wordprefix, &total = pre->total;
@@ -1199,7 +1218,7 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
         u32x4 *dst = reinterpret_cast<u32x4 *>(res->rows);
         // (rows of more than 64 chunks keep the batched stage: there every workgroup of the grid shares the chunks of a row, here a
         // wavefront streams its own rows alone — two 10^8-qubit terms: 2.9 ms against 8.5 ms)
-        const bool fused = Wq <= 64 && [] { const char *e = getenv("SYMGPU_EMIT_FUSED"); return !(e && e[0] == '0'); }();
+        const bool fused = emit_is_fused(Wq);
         if (fused) {
             const i64 n_w64 = (T + 63) / 64;
             // wavefront shape: bitmap words per wavefront x 64-chunk steps in flight (SYMGPU_EMIT_SHAPE = "NW,U": experiments)
@@ -1208,15 +1227,7 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
             const int NWr = (NWs == 1 || NWs == 4 || NWs == 8) ? NWs : 2;   // 2 words per wavefront, 4 steps in flight: 1.20 ms at cfg3 (4,4: 1.30; 1,4: 1.24; 2,8: 1.22)
             const dim3 gfu((unsigned)((n_w64 + 4 * NWr - 1) / (4 * NWr)));
             static const bool touch_on = [] { const char *e = SG_TUNE("SYMGPU_EMIT_TOUCH"); return !(e && e[0] == '0'); }();
-            if (touch_on) {
-                const i64 n16 = n_w64 / 2;                              // whole 16-byte chunks of a T-bit map
-                const void *maps[5] = {markbits_p, wordprefix.p, lz.mode ? (const void *)lz.patchbits : nullptr, lz.mode == 1 ? (const void *)lz.e_lo : nullptr,
-                                       lz.mode == 1 ? (const void *)lz.e_hi : nullptr};
-                for (int m = 0; m < 5; ++m)
-                    if (maps[m] && n16 > 0)
-                        hipLaunchKernelGGL(k_touch, dim3(grid_for(m == 1 ? 2 * n16 : n16)), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(maps[m]), m == 1 ? 2 * n16 : n16,
-                                           total.as<u32>() + 2);
-            }
+            if (touch_on && !pre->touched) SG_TRY(emit_touch(markbits_p, T, lz, *pre));
             ProfScope prof(3);
 #define LAUNCH_FUSED_S(P, TR, NWV, UV) hipLaunchKernelGGL((k_emit_fused<P, TR, NWV, UV>), gfu, dim3(256), 0, st, reinterpret_cast<const u64 *>(markbits_p), wordprefix.as<u32>(), T, sum_of_p, \
                                                (u32)(pair ? Ni : 1), Wq, wsh, reinterpret_cast<const u32x4 *>(rows), pin, pout, dst, res->coeff, lz, res->first)
@@ -1718,9 +1729,17 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     hipLaunchKernelGGL(k_popc_words64, dim3(grid_for(n_sc)), dim3(256), 0, st, susbits.as<u64>(), n_sc, susprefix.as<u32>());
                     KERNEL_CHECK();
                     SG_TRY(exclusive_scan_u32(susprefix.as<u32>(), susprefix.as<u32>(), n_sc, sustotal.as<u32>()));
-                    u32 h_sus2[4] = {0, 0, 0, 0};
-                    HIP_TRY(hipMemcpyAsync(h_sus2, sustotal.p, 16, hipMemcpyDeviceToHost, st));
-                    HIP_TRY(hipStreamSynchronize(st));
+                    // the compaction does not need the count: it is queued behind the count's way home and runs while the host waits for it (in
+                    // the rare give-up case its output is simply overwritten)
+                    u32 h_sus2[2] = {0, 0};
+                    {
+                        ReadBack rb;
+                        SG_TRY(read_back_post(sustotal.as<u32>(), 2, nullptr, 0, &rb));
+                        hipLaunchKernelGGL(k_compact_suspects, dim3((unsigned)grid_for((n_sc + 255) / 256, 1, 1 << 16)), dim3(256), 0, st, part, susbits.as<u64>(),
+                                           susprefix.as<u32>(), n_sc, spare);
+                        KERNEL_CHECK();
+                        SG_TRY(read_back_wait(&rb, h_sus2));
+                    }
                     const u32 h_sus = h_sus2[0];
                     if ((i64)h_sus * 16 > Tk || sus_giveup || h_sus2[1]) {
                         // repeated rows all over: the last pass on the whole array after all (LSD: the order so far is its first passes)
@@ -1731,9 +1750,6 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                         sus_active = true;
                         Tsort = h_sus;
                         if (Tsort > 0) {
-                            hipLaunchKernelGGL(k_compact_suspects, dim3((unsigned)grid_for((n_sc + 255) / 256, 1, 1 << 16)), dim3(256), 0, st, part, susbits.as<u64>(),
-                                               susprefix.as<u32>(), n_sc, spare);
-                            KERNEL_CHECK();
                             // the flagged keys, sorted completely (the same rule for the number of sorted bits, now for a few thousand keys);
                             // `part` is not needed any more and serves as the sort's second buffer
                             int lgs = 0;
@@ -1827,8 +1843,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 hipLaunchKernelGGL(k_count_bits, dim3(grid_for((n_chunks + 31) / 32)), dim3(256), 0, st, dirtybits.as<u32>(), (n_chunks + 31) / 32, dcount);
                 KERNEL_CHECK();
                 u32 h_dirty = 0;
-                HIP_TRY(hipMemcpyAsync(&h_dirty, dcount, 4, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
+                SG_TRY(read_back_words(dcount, 1, nullptr, 0, &h_dirty));
                 if ((i64)h_dirty * 8 > n_chunks) lazy_now = false;
             }
             lazy_final = lazy_now;
@@ -1884,16 +1899,24 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         // comes back with them (an attempt that has to be repeated throws the prefix away)
         pre.n_out = -1;
         SG_TRY(emit_prefix(markbits.as<u32>(), (squared && packed) ? Tk : T, pre.wordprefix, pre.total));
-        // (ONE copy to the host: a small device-to-host copy into pageable memory is a blocking round trip of 20-35 us each)
-        u32 hback[6] = {0, 0, 0, 0, 0, 0};                           // (a pinned destination was measured: no faster)
-        HIP_TRY(hipMemcpyAsync(pre.total.as<u32>() + 4, collision.p, 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(hback, pre.total.p, 24, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        pre.touched = false;
+        if (emit_is_fused(W / 2) && !SG_TUNE("SYMGPU_EMIT_TOUCH")) {      // (the output stage's bitmaps back into the cache: queued ahead of the read-back, not behind it)
+            LazyEmit lzt;
+            if (lazy_final) { lzt.mode = packed ? 1 : 2; lzt.patchbits = patchbits.as<u32>(); lzt.e_lo = e_lo.as<u32>(); lzt.e_hi = e_hi.as<u32>(); }
+            SG_TRY(emit_touch(markbits.as<u32>(), (squared && packed) ? Tk : T, lzt, pre));
+        }
+        // (ONE trip to the host for the count and the status words)
+        u32 hback[6] = {0, 0, 0, 0, 0, 0};
+        {
+            u32 hb[4] = {0, 0, 0, 0};
+            SG_TRY(read_back_words(pre.total.as<u32>(), 1, collision.as<u32>(), 2, hb, sus_coop ? radix_sort_coop_flag() : nullptr));
+            hback[0] = hb[0]; hback[4] = hb[1]; hback[5] = hb[2]; hback[1] = hb[3];
+        }
         const u32 hflags[2] = {hback[4], hback[5]};
         pre.n_out = hback[0];
         if (sus_coop) {                                            // the one-launch sort of the flagged keys gave up at a barrier (GPU shared): its
             bool timed_out = false;                                // output is garbage; the form is off now, the next attempt sorts with launches
-            SG_TRY(radix_sort_coop_check(&timed_out));
+            radix_sort_coop_note(hback[1], &timed_out);
             if (timed_out) continue;
         }
         if (hflags[1]) { nb = 64; packed = false; squared = false; Tk = T; continue; }   // a long mixed prefix run: redo with a full 64-bit sort over all pairs, same seed

@@ -57,6 +57,9 @@ struct Context {
     hipStream_t stream2 = nullptr;           // side stream: VALU-bound coefficient kernel overlaps the HBM-bound row stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    u32 *mail_host = nullptr, *mail_dev = nullptr;   // 64 bytes of mapped, coherent host memory: word 0 = sequence number, words 1.. = the few
+    u32 mail_seq = 0;                                // status words / counts a call reads back in the middle of its work (read_back_words)
+    bool mail_failed = false;
     int num_cu = 256;
     // linear-hash tables (cleanup): 8 byte positions x 256 values x {h1,h2}; reseeded on collision
     u64 *hash_tab = nullptr;       // device, [8][256][2]
@@ -188,6 +191,12 @@ int op_wordmajor(symgpu_op_s *op, i64 mult, const u64 **out, i64 *pad);
 int op_ycount(symgpu_op_s *op, const int **out);
 void op_invalidate(symgpu_op_s *op);
 
+// the n_a + n_b <= 8 device words a[0..n_a) ++ b[0..n_b) to the host, behind everything queued on the stream so far (context.hip)
+int read_back_words(const u32 *a, int n_a, const u32 *b, int n_b, u32 *host_out, const u32 *c1 = nullptr);
+struct ReadBack { int n; u32 seq; u32 plain[8]; };
+int read_back_post(const u32 *a, int n_a, const u32 *b, int n_b, ReadBack *rb, const u32 *c1 = nullptr /* one more word */);   // ... more work may be queued before the wait
+int read_back_wait(ReadBack *rb, u32 *host_out);
+
 // sort.hip
 int exclusive_scan_u32(const u32 *in, u32 *out, i64 n, u32 *total_dev /* may be null: device u32 */);
 // first_hist (optional, device, 256 * ceil(n / SORT_TILE) u32): the TILE-major ([tile][256]) tile histograms of the FIRST pass
@@ -199,6 +208,8 @@ int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp,
 int radix_sort_keys_u64(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, u32 *first_hist = nullptr);
 // the same as one persistent launch (up to 2^19 keys); *done = false: not applicable, use the multi-launch form
 int radix_sort_keys_u64_coop(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done);
+const u32 *radix_sort_coop_flag();
+void radix_sort_coop_note(u32 flag, bool *timed_out);
 int radix_sort_coop_check(bool *timed_out);     // after a stream synchronisation: did a one-launch sort give up (output invalid)?
 
 // commute.hip

@@ -1,6 +1,7 @@
 // context.hip — context, error text, cached device allocator, operator handles, timers, checksums.
 #include "common.h"
 #include <thread>
+#include <chrono>
 #include <sys/mman.h>
 #include <stdint.h>
 #include <vector>
@@ -439,6 +440,88 @@ void prefault_host(void *dst, size_t bytes) {
     for (auto &w : workers) w.join();
 }
 
+// ---- a few words back to the host in the middle of a call ---------------------------------------------------------------------------
+// hipMemcpyAsync of a few bytes + hipStreamSynchronize costs two host round trips on this runtime (the stream is drained, THEN a blit
+// kernel is queued, then drained again: 35 + 25 us of idle GPU per read-back, rocprofv3 timeline of cfg3).  Instead a one-wavefront kernel
+// at the end of the queue stores the words into mapped, coherent host memory and a sequence number behind them (system-scope release);
+// the host polls the sequence number.  Nothing else of the runtime is involved; after 2 s without an answer (a kernel fault upstream)
+// the stream is synchronised the ordinary way and its error reported.
+__global__ void k_mail_words(const u32 *__restrict__ a, int n_a, const u32 *__restrict__ b, int n_b, const u32 *__restrict__ c1, u32 *__restrict__ mail, u32 seq) {
+    const int t = threadIdx.x;
+    if (t < n_a) __hip_atomic_store(mail + 1 + t, a[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (t < n_a + n_b) __hip_atomic_store(mail + 1 + t, b[t - n_a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (t == n_a + n_b && c1) __hip_atomic_store(mail + 1 + t, *c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __builtin_amdgcn_s_barrier();
+    if (t == 0) __hip_atomic_store(mail, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static bool mail_ready() {
+    Context &c = ctx();
+    static const bool plain = [] { const char *e = getenv("SYMGPU_READBACK_PLAIN"); return e && e[0] == '1'; }();
+    if (plain) return false;
+    if (!c.mail_host && !c.mail_failed) {
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            memset(h, 0, 64);
+            c.mail_host = static_cast<u32 *>(h);
+            c.mail_dev = static_cast<u32 *>(d);
+        } else {
+            (void)hipGetLastError();
+            if (h) (void)hipHostFree(h);
+            c.mail_failed = true;
+            note_degraded("read-back through mapped host memory unavailable: every mid-call read-back is a copy + stream synchronisation");
+        }
+    }
+    return c.mail_host != nullptr;
+}
+// post: queue the words' way home (more work may be queued behind it before the wait); wait: poll, copy out.  One read-back in flight per
+// context.
+int read_back_post(const u32 *a, int n_a, const u32 *b, int n_b, ReadBack *rb, const u32 *c1) {
+    Context &c = ctx();
+    rb->n = n_a + n_b + (c1 ? 1 : 0); rb->seq = 0;
+    if (rb->n > 8) { set_error("read_back: %d words", rb->n); return SYMGPU_E_INVALID; }
+    if (!mail_ready()) {                                                // the copies are queued here, the synchronisation is the wait
+        if (n_a) HIP_TRY(hipMemcpyAsync(rb->plain, a, (size_t)n_a * 4, hipMemcpyDeviceToHost, c.stream));
+        if (n_b) HIP_TRY(hipMemcpyAsync(rb->plain + n_a, b, (size_t)n_b * 4, hipMemcpyDeviceToHost, c.stream));
+        if (c1) HIP_TRY(hipMemcpyAsync(rb->plain + n_a + n_b, c1, 4, hipMemcpyDeviceToHost, c.stream));
+        return SYMGPU_OK;
+    }
+    ++c.mail_seq;
+    if (c.mail_seq == 0) ++c.mail_seq;                                  // never 0
+    rb->seq = c.mail_seq;
+    hipLaunchKernelGGL(k_mail_words, dim3(1), dim3(64), 0, c.stream, a, n_a, b, n_b, c1, c.mail_dev, rb->seq);
+    KERNEL_CHECK();
+    return SYMGPU_OK;
+}
+int read_back_wait(ReadBack *rb, u32 *host_out) {
+    Context &c = ctx();
+    const int n = rb->n;
+    if (rb->seq == 0) {
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        for (int k = 0; k < n; ++k) host_out[k] = rb->plain[k];
+        count_d2h((size_t)n * 4);
+        return SYMGPU_OK;
+    }
+    volatile u32 *mail = c.mail_host;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (u64 spin = 0;; ++spin) {
+        if (__atomic_load_n(&mail[0], __ATOMIC_ACQUIRE) == rb->seq) break;
+        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            HIP_TRY(hipStreamSynchronize(c.stream));                    // reports a fault upstream; otherwise the words are there now
+            if (__atomic_load_n(&mail[0], __ATOMIC_ACQUIRE) != rb->seq) { set_error("read_back: no answer from the device"); return SYMGPU_E_HIP; }
+            break;
+        }
+    }
+    for (int k = 0; k < n; ++k) host_out[k] = mail[1 + k];
+    count_d2h((size_t)n * 4);
+    return SYMGPU_OK;
+}
+int read_back_words(const u32 *a, int n_a, const u32 *b, int n_b, u32 *host_out, const u32 *c1) {
+    ReadBack rb;
+    SG_TRY(read_back_post(a, n_a, b, n_b, &rb, c1));
+    return read_back_wait(&rb, host_out);
+}
+
 }  // namespace symgpu
 
 using namespace symgpu;
@@ -569,6 +652,7 @@ static void shutdown_device(int device) {
     (void)hipEventDestroy(c.ev0);
     (void)hipEventDestroy(c.ev1);
     (void)hipStreamSynchronize(c.stream2);
+    if (c.mail_host) { (void)hipHostFree(c.mail_host); c.mail_host = nullptr; c.mail_dev = nullptr; }
     (void)hipEventDestroy(c.ev_fork);
     (void)hipEventDestroy(c.ev_join);
     (void)hipStreamDestroy(c.stream2);

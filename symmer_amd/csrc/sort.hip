@@ -593,17 +593,26 @@ int radix_sort_keys_u64_coop(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int
 
 // After the stream has been synchronised: did a one-launch sort since the last check give up at a barrier?  Then its output is garbage;
 // the form is switched off for the rest of the process and the caller reports the failure.
-int radix_sort_coop_check(bool *timed_out) {
+// the device word a one-launch sort raises when it gives up (null: no such sort has run), and what to do with its value once it is on the
+// host — for callers that read it back together with their own status words
+const u32 *radix_sort_coop_flag() {
     Context &c = ctx();
+    return (!c.sort_state || c.sort_coop_disabled) ? nullptr : c.sort_state + 1;
+}
+void radix_sort_coop_note(u32 flag, bool *timed_out) {
     *timed_out = false;
-    if (!c.sort_state || c.sort_coop_disabled) return SYMGPU_OK;
+    if (!flag) return;
+    *timed_out = true;
+    ctx().sort_coop_disabled = true;
+    note_degraded("one-launch radix sort (k_rs_coop) off: an in-kernel barrier timed out (workgroups not co-resident?); sorts take one launch per pass");
+}
+int radix_sort_coop_check(bool *timed_out) {
+    *timed_out = false;
+    const u32 *p = radix_sort_coop_flag();
+    if (!p) return SYMGPU_OK;
     u32 flag = 0;
-    HIP_TRY(hipMemcpy(&flag, c.sort_state + 1, 4, hipMemcpyDeviceToHost));
-    if (flag) {
-        *timed_out = true;
-        c.sort_coop_disabled = true;
-        note_degraded("one-launch radix sort (k_rs_coop) off: an in-kernel barrier timed out (workgroups not co-resident?); sorts take one launch per pass");
-    }
+    HIP_TRY(hipMemcpy(&flag, p, 4, hipMemcpyDeviceToHost));
+    radix_sort_coop_note(flag, timed_out);
     return SYMGPU_OK;
 }
 
