@@ -499,7 +499,6 @@ int read_back_wait(ReadBack *rb, u32 *host_out) {
     if (rb->seq == 0) {
         HIP_TRY(hipStreamSynchronize(c.stream));
         for (int k = 0; k < n; ++k) host_out[k] = rb->plain[k];
-        count_d2h((size_t)n * 4);
         return SYMGPU_OK;
     }
     volatile u32 *mail = c.mail_host;
@@ -513,7 +512,6 @@ int read_back_wait(ReadBack *rb, u32 *host_out) {
         }
     }
     for (int k = 0; k < n; ++k) host_out[k] = mail[1 + k];
-    count_d2h((size_t)n * 4);
     return SYMGPU_OK;
 }
 int read_back_words(const u32 *a, int n_a, const u32 *b, int n_b, u32 *host_out, const u32 *c1) {

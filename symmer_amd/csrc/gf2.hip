@@ -32,6 +32,7 @@ namespace symgpu {
 constexpr int WK = 64;        // max rows per block = lanes of the panel wave
 constexpr int WN = 4;         // window width in 64-bit words
 constexpr int NOLEAD = 0x7fffffff;
+__global__ void k_fill_nolead(int *__restrict__ lead) { lead[threadIdx.x] = NOLEAD; }
 
 struct BlockInfo {
     i64 i0;                   // first row of the block
@@ -773,12 +774,7 @@ static int rref_dev_impl(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_h
         // phase 1: panel of block b+1 (-> the other info buffer) inside the sweep of all remaining rows.  The very first
         // iteration has nothing to sweep (zeroed info): it only collects the leading words of rows 0..63 and panels block 0.
         // `it` keeps counting across batches.
-        {
-            int h_lead[WK];
-            for (int k = 0; k < WK; ++k) h_lead[k] = NOLEAD;
-            HIP_TRY(hipMemcpyAsync(lead.p, h_lead, sizeof(h_lead), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));                      // h_lead is a stack buffer
-        }
+        hipLaunchKernelGGL(k_fill_nolead, dim3(1), dim3(WK), 0, st, lead.as<int>());
         i64 it = 0, done = 0, prev = -1;
         bool finished = false;
         while (!finished) {
@@ -806,8 +802,12 @@ static int rref_dev_impl(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_h
             }
             // the block that has been panelled but not swept yet: kk == 0 means the matrix is exhausted
             struct { i64 i0; int kk; } pending;
-            HIP_TRY(hipMemcpyAsync(&pending, binfo + ((it + 1) & 1), sizeof(pending), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            {
+                u32 w[3] = {0, 0, 0};                                   // (i0 low, i0 high, kk: the head of a BlockInfo)
+                SG_TRY(read_back_words(reinterpret_cast<const u32 *>(binfo + ((it + 1) & 1)), 3, nullptr, 0, w));
+                pending.i0 = (i64)(((u64)w[1] << 32) | w[0]);
+                pending.kk = (int)w[2];
+            }
             if (pending.kk == 0) finished = true;
             else if (pending.i0 <= prev) { set_error("rref: no progress (internal error)"); return SYMGPU_E_INVALID; }
             prev = pending.i0;
@@ -834,8 +834,11 @@ static int rref_dev_impl(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_h
             KERNEL_CHECK();
         }
         SweepState hs;
-        HIP_TRY(hipMemcpyAsync(&hs, state.p, sizeof(hs), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        {
+            u32 w[2] = {0, 0};
+            SG_TRY(read_back_words(state.as<u32>(), 2, nullptr, 0, w));
+            hs.next_i0 = (i64)(((u64)w[1] << 32) | w[0]);
+        }
         if (hs.next_i0 <= done) { set_error("rref: no progress (internal error)"); return SYMGPU_E_INVALID; }
         done = hs.next_i0;
     }
@@ -843,9 +846,16 @@ static int rref_dev_impl(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_h
     hipLaunchKernelGGL(k_sum_u32, dim3(256), dim3(256), 0, st, rowcnt.as<u32>(), R, count.as<unsigned long long>());
     KERNEL_CHECK();
     unsigned long long hb[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(hb, count.p, 16, hipMemcpyDeviceToHost, st));
-    if (pivots_host) HIP_TRY(hipMemcpyAsync(pivots_host, piv.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (pivots_host) {
+        HIP_TRY(hipMemcpyAsync(hb, count.p, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(pivots_host, piv.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else {
+        u32 w[4] = {0, 0, 0, 0};
+        SG_TRY(read_back_words(reinterpret_cast<const u32 *>(count.p), 4, nullptr, 0, w));
+        hb[0] = ((unsigned long long)w[1] << 32) | w[0];
+        hb[1] = ((unsigned long long)w[3] << 32) | w[2];
+    }
     if (SG_TUNE("SYMGPU_GF2_DEBUG")) fprintf(stderr, "rref %lld x %lld words: full-row panels %u\n", (long long)R, (long long)Wc, (u32)(hb[1] >> 32));
     if ((u32)hb[1] != 0) { *timed_out = true; return SYMGPU_OK; }
     if (xor_count) *xor_count = (i64)hb[0];
@@ -999,8 +1009,7 @@ int symgpu_symmetry_kernel_dev(symgpu_op_t H, int n_qubits, uint64_t *out, int64
     KERNEL_CHECK();
     SG_TRY(exclusive_scan_u32(flag.as<u32>(), flag.as<u32>(), R, total.as<u32>()));
     u32 kcount = 0;
-    HIP_TRY(hipMemcpyAsync(&kcount, total.p, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    SG_TRY(read_back_words(total.as<u32>(), 1, nullptr, 0, &kcount));
     *k = kcount;
     if ((i64)kcount > capacity) {
         set_error("symmetry_kernel: capacity %lld < %u generators", (long long)capacity, kcount);

@@ -9,6 +9,7 @@
 //   symgpu_state_inner_dev    QuantumState bra * ket (base.py:1808-1815): a hash join of the packed basis rows of two cleaned states,
 //                             products added in the left state's order (the reference's Python loop order).
 #include "common.h"
+#include <string.h>
 #include "rotate_common.h"
 #include <stdlib.h>
 #include <vector>
@@ -197,8 +198,7 @@ int symgpu_project_dev(symgpu_op_t op, const uint64_t *stab_rows, int k, const u
     KERNEL_CHECK();
     SG_TRY(exclusive_scan_u32(survive.as<u32>(), pos.as<u32>(), T, total.as<u32>()));
     u32 n_s = 0;
-    HIP_TRY(hipMemcpyAsync(&n_s, total.p, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));                               // also: src / stab_rows / neg_mask are host temporaries of the caller
+    SG_TRY(read_back_words(total.as<u32>(), 1, nullptr, 0, &n_s));   // also: src / stab_rows / neg_mask are host temporaries of the caller (their copies are ahead in the stream)
     if (n_survived) *n_survived = n_s;
     if (n_s == 0) {
         SG_TRY(symgpu_op_alloc(1, Wq_out, 1, out));
@@ -237,8 +237,7 @@ int symgpu_noncontextual_dev(symgpu_op_t op, int *is_noncontextual) {
     KERNEL_CHECK();
     SG_TRY(exclusive_scan_u32(flag.as<u32>(), pos.as<u32>(), T, total.as<u32>()));
     u32 n_nu = 0;
-    HIP_TRY(hipMemcpyAsync(&n_nu, total.p, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    SG_TRY(read_back_words(total.as<u32>(), 1, nullptr, 0, &n_nu));
     if (n_nu == 0) return SYMGPU_OK;                                 // everything commutes with everything
     SG_TRY(c_rows.alloc((size_t)n_nu * W2 * 8));
     SG_TRY(c_coeff.alloc((size_t)n_nu * 16));
@@ -286,8 +285,9 @@ int symgpu_state_inner_dev(symgpu_op_t a, symgpu_op_t b, double *out) {
                        table.as<u64>(), (u32)(cap - 1), prod.as<double>());
     hipLaunchKernelGGL(k_seq_sum, dim3(1), dim3(64), 0, st, prod.as<double>(), Na, res.as<double>());
     KERNEL_CHECK();
-    HIP_TRY(hipMemcpyAsync(out, res.p, 16, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    u32 w[4] = {0, 0, 0, 0};
+    SG_TRY(read_back_words(res.as<u32>(), 4, nullptr, 0, w));
+    memcpy(out, w, 16);
     return SYMGPU_OK;
 }
 

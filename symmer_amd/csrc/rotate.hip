@@ -1126,8 +1126,7 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
             SG_TRY(analyze_rows(in, q.as<u64>(), anti.as<u32>(), ph.as<uint8_t>(), &jt, q_pending ? q_row_host : nullptr));
             q_pending = false;
             u32 hflag = 0;
-            HIP_TRY(hipMemcpyAsync(&hflag, jt.flags, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            SG_TRY(read_back_words(jt.flags, 1, nullptr, 0, &hflag));
             has_dup = hflag == jt.gen;
             if (!has_dup) in->dup_free = 1;
         } else {
@@ -1154,8 +1153,7 @@ int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double 
     KERNEL_CHECK();
     SG_TRY(exclusive_scan_u32(cpos.as<u32>(), cpos.as<u32>(), T, tot + 1));        // positions among commuting rows
     u32 h[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h, tot, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    SG_TRY(read_back_words(tot, 2, nullptr, 0, h));
     const i64 n_sel = h[0], n_comm = h[1];
     if (n_comm == T) return SYMGPU_OK;        // every term commutes: identity action (base.py:1131-1133)
     *all_commute = 0;
