@@ -30,6 +30,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32 xor_and(u32 acc, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(acc, b, c, 0x78); }   // a ^ (b & c)
 __device__ __forceinline__ u32 to_vgpr(u32 s) { u32 v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
 __device__ __forceinline__ u32 and_xor(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x60); }     // a & (b ^ c)
+__device__ __forceinline__ u32 bcnt_acc(u32 x, u32 acc) { u32 r; asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc)); return r; }   // popc(x) + acc
 
 constexpr int PO = 8;   // outer terms per wave (SGPR operand)
 constexpr int PJ = 4;   // inner terms per lane: i = ibase + 64*b + lane
@@ -55,14 +56,14 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
     if (ibase >= Ipad) return;                                         // surplus block of the grid padded to a multiple of 8 (below)
     if (KM == 2 && ibase + 64 * PJ - 1 < o0 + ka.o_base) return;       // tile strictly below the diagonal: no pair with i >= o
 
-    u32 cnt[PO][PJ], flo[PO][PJ], fhi[PO][PJ];
+    u32 cnt[PO][PJ], flip[PO][PJ];
     u32 yi[PJ];
     int yo[PO];
 #pragma unroll
     for (int a = 0; a < PO; ++a) {
         yo[a] = 0;
 #pragma unroll
-        for (int b = 0; b < PJ; ++b) cnt[a][b] = flo[a][b] = fhi[a][b] = 0;
+        for (int b = 0; b < PJ; ++b) cnt[a][b] = flip[a][b] = 0;
     }
 #pragma unroll
     for (int b = 0; b < PJ; ++b) yi[b] = 0;
@@ -70,42 +71,57 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
     const u64 *pox = Ot + o0, *poz = Ot + (i64)Wq * Opad + o0;
     const u64 *pix = It + ibase + lane, *piz = It + (i64)Wq * Ipad + ibase + lane;
 
+    // The words of step w + 1 are fetched before the arithmetic of step w (round 5: the loads used to be waited for right where they
+    // were issued, four wavefronts per SIMD could not cover that, and the kernel ran at half its VALU rate — 0.32 ms for the 5e7 keys
+    // of cfg3).  One parity accumulator for both halves of a word frees the registers the second set of operand words needs.
+    u64 xi[PJ], zi[PJ], xo[PO], zo[PO];
+#pragma unroll
+    for (int b = 0; b < PJ; ++b) { xi[b] = pix[64 * b]; zi[b] = piz[64 * b]; }
+#pragma unroll
+    for (int a = 0; a < PO; ++a) { xo[a] = pox[a]; zo[a] = poz[a]; }   // wave-uniform -> s_load
     for (int w = 0; w < Wq; ++w) {
-        u64 xi[PJ], zi[PJ];
+        const int wn = w + 1 < Wq ? w + 1 : w;
+        u64 xin[PJ], zin[PJ], xon[PO], zon[PO];
 #pragma unroll
         for (int b = 0; b < PJ; ++b) {
-            xi[b] = pix[(i64)w * Ipad + 64 * b];
-            zi[b] = piz[(i64)w * Ipad + 64 * b];
-            yi[b] += __popcll(xi[b] & zi[b]);
+            xin[b] = pix[(i64)wn * Ipad + 64 * b];
+            zin[b] = piz[(i64)wn * Ipad + 64 * b];
         }
-        u64 xo[PO], zo[PO];
 #pragma unroll
         for (int a = 0; a < PO; ++a) {
-            xo[a] = pox[(i64)w * Opad + a];   // wave-uniform -> s_load
-            zo[a] = poz[(i64)w * Opad + a];
-            yo[a] += __popcll(xo[a] & zo[a]);
+            xon[a] = pox[(i64)wn * Opad + a];
+            zon[a] = poz[(i64)wn * Opad + a];
         }
+#pragma unroll
+        for (int b = 0; b < PJ; ++b) yi[b] += __popcll(xi[b] & zi[b]);
+#pragma unroll
+        for (int a = 0; a < PO; ++a) yo[a] += __popcll(xo[a] & zo[a]);
 #pragma unroll
         for (int a = 0; a < PO; ++a) {
             // SGPR sources cost ~40 % VALU issue rate on gfx950 (tools/ubench_bitop.hip): copy the uniform words to VGPRs once
-            const u32 xol = to_vgpr((u32)xo[a]), xoh = to_vgpr((u32)(xo[a] >> 32));
+            // (the words that only feed a two-operand v_xor stay scalar: an SGPR source is free there)
+            const u32 xol = INNER_LEFT ? (u32)xo[a] : to_vgpr((u32)xo[a]), xoh = INNER_LEFT ? (u32)(xo[a] >> 32) : to_vgpr((u32)(xo[a] >> 32));
             const u32 zol = to_vgpr((u32)zo[a]), zoh = to_vgpr((u32)(zo[a] >> 32));
 #pragma unroll
             for (int b = 0; b < PJ; ++b) {
                 const u32 xil = (u32)xi[b], xih = (u32)(xi[b] >> 32), zil = (u32)zi[b], zih = (u32)(zi[b] >> 32);
-                // Y_out += |(xi^xo) & (zi^zo)|
-                cnt[a][b] += __popc(and_xor(xil ^ xol, zil, zol));
-                cnt[a][b] += __popc(and_xor(xih ^ xoh, zih, zoh));
+                // Y_out += |(xi^xo) & (zi^zo)|   (v_bcnt with its accumulator operand: the compiler adds two counts with a third instruction)
+                cnt[a][b] = bcnt_acc(and_xor(xil ^ xol, zil, zol), cnt[a][b]);
+                cnt[a][b] = bcnt_acc(and_xor(xih ^ xoh, zih, zoh), cnt[a][b]);
                 // flip ^= x_left & z_right
                 if (INNER_LEFT) {
-                    flo[a][b] = xor_and(flo[a][b], xil, zol);
-                    fhi[a][b] = xor_and(fhi[a][b], xih, zoh);
+                    flip[a][b] = xor_and(flip[a][b], xil, zol);
+                    flip[a][b] = xor_and(flip[a][b], xih, zoh);
                 } else {
-                    flo[a][b] = xor_and(flo[a][b], zil, xol);
-                    fhi[a][b] = xor_and(fhi[a][b], zih, xoh);
+                    flip[a][b] = xor_and(flip[a][b], zil, xol);
+                    flip[a][b] = xor_and(flip[a][b], zih, xoh);
                 }
             }
         }
+#pragma unroll
+        for (int b = 0; b < PJ; ++b) { xi[b] = xin[b]; zi[b] = zin[b]; }
+#pragma unroll
+        for (int a = 0; a < PO; ++a) { xo[a] = xon[a]; zo[a] = zon[a]; }
     }
 
     // Epilogue.  The stores of a full 8-outer-term tile are issued unconditionally back to back: a conditional store per
@@ -130,7 +146,7 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
 #pragma unroll
             for (int b = 0; b < PJ; ++b) {
                 const i64 i = ibase + 64 * b + lane;
-                const u64 e = (3u * (yi[b] + (u32)yo[a]) + cnt[a][b] + 2u * (__popc(flo[a][b] ^ fhi[a][b]) & 1u)) & 3u;
+                const u64 e = (3u * (yi[b] + (u32)yo[a]) + cnt[a][b] + 2u * (__popc(flip[a][b]) & 1u)) & 3u;
                 if (i < Ni && i >= o) dst[i] = ((ka.hI[i] ^ ho[a]) & hmask) | (e << (ka.bi + ka.bo)) | ((u64)o << ka.bi) | (u64)i;
             }
         }
@@ -147,7 +163,7 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
             u64 key[PO];
 #pragma unroll
             for (int a = 0; a < PO; ++a) {
-                const u64 e = (3u * (yi[b] + (u32)yo[a]) + cnt[a][b] + 2u * (__popc(flo[a][b] ^ fhi[a][b]) & 1u)) & 3u;
+                const u64 e = (3u * (yi[b] + (u32)yo[a]) + cnt[a][b] + 2u * (__popc(flip[a][b]) & 1u)) & 3u;
                 key[a] = ((hi ^ ho[a]) & hmask) | (e << (ka.bi + ka.bo)) | ((u64)(o0 + a + ka.o_base) << ka.bi) | (u64)i;
             }
             u64 *dst = ka.keys + o0 * Ni + i;
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
         double2 v[PO];
 #pragma unroll
         for (int a = 0; a < PO; ++a) {
-            const int e = (int)((3u * (yi[b] + (u32)yo[a]) + cnt[a][b] + 2u * (__popc(flo[a][b] ^ fhi[a][b]) & 1u)) & 3u);
+            const int e = (int)((3u * (yi[b] + (u32)yo[a]) + cnt[a][b] + 2u * (__popc(flip[a][b]) & 1u)) & 3u);
             pair_coefficient(ar, ai, cor[a], coi[a], e, v[a].x, v[a].y);
         }
         double2 *dst = reinterpret_cast<double2 *>(out) + o0 * Ni + i;
