@@ -290,13 +290,33 @@ __device__ __forceinline__ void tri_pair(u32 p, u32 N, u32 &o, u32 &i) {
 // PACKED: keys[s] is the packed key of index s (pair index, or slot of a squared operator); otherwise coeff[s].
 // One workgroup per tile of SORT_TILE indices (= the radix sort's tile).  hist != null (packed keys): the same pass forms the digit
 // histograms of the sort's first pass, which reads these very keys in this very order (one HBM pass over the keys less).
+// smallest max(|re|, |im|) over the terms of an operand (0 if a component is not a number), as the bit pattern of a non-negative double
+// (ordered like the unsigned integer): *slot starts as all ones
+__global__ __launch_bounds__(256) void k_coeff_floor(const double *__restrict__ c, i64 n, unsigned long long *__restrict__ slot) {
+    double m = __builtin_inf();
+    for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < n; t += (i64)gridDim.x * 256) {
+        const double2 v = reinterpret_cast<const double2 *>(c)[t];
+        const double a = fabs(v.x), b = fabs(v.y);
+        const double mx = (a == a && b == b) ? (a > b ? a : b) : 0.0;
+        m = mx < m ? mx : m;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(m, d); m = o < m ? o : m; }
+    if ((threadIdx.x & 63) == 0) atomicMin(slot, (unsigned long long)__double_as_longlong(m));
+}
+// floor_i / floor_o (packed keys; null: none): k_coeff_floor of the two operands.  |c_i c_o| >= floor_i * floor_o, the larger component of
+// the computed product is at least 0.7 of that, so when half of it exceeds thr every pair of non-zero weight is kept WHATEVER its
+// coefficient: the two table gathers, the complex product and the comparison (50 of the kernel's 70 instructions per key) are skipped
+// — the decision is the same, it is just not computed (cfg3: 0.19 -> see DESIGN 3.3).
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_mark_singles(const u64 *__restrict__ keys, const double *__restrict__ coeff, i64 space, PackedLayout L,
                                                        const double *__restrict__ ci, const double *__restrict__ co, int squared, double thr, int use_thr,
                                                        u64 *__restrict__ markbits64, u64 *__restrict__ e_lo64, u64 *__restrict__ e_hi64,
-                                                       u32 *__restrict__ hist, int hist_shift, i64 n_tiles) {
+                                                       u32 *__restrict__ hist, int hist_shift, i64 n_tiles, const double *__restrict__ floor_i,
+                                                       const double *__restrict__ floor_o) {
     __shared__ u32 s_h[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool all_kept = PACKED && (!use_thr || (floor_i && floor_o && 0.5 * floor_i[0] * floor_o[0] > thr));   // block-uniform
     if (hist) { s_h[threadIdx.x] = 0; __syncthreads(); }
     const i64 tile_base = (i64)blockIdx.x * SORT_TILE;
 #pragma unroll 1
@@ -317,7 +337,7 @@ __global__ __launch_bounds__(256) void k_mark_singles(const u64 *__restrict__ ke
         // the operand coefficients of all four chunks are fetched before the first one is used (gathers from the cache-resident tables:
         // one after the other they were four dependent round trips per step, and the kernel was bound by them)
         double2 ca[4], cb[4];
-        if (PACKED) {
+        if (PACKED && !all_kept) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const u32 i = L.i(k[j]), o = L.o(k[j]);                // (lanes past the end hold key 0: term 0 of both tables)
@@ -332,6 +352,13 @@ __global__ __launch_bounds__(256) void k_mark_singles(const u64 *__restrict__ ke
             const bool valid = sidx < space;
             double cx = cf[j].x, cy = cf[j].y;
             int e = 0;
+            bool keep;
+            if (PACKED && all_kept) {
+                if (valid && hist) atomicAdd(&s_h[(u32)(k[j] >> hist_shift) & 255u], 1u);
+                e = L.e(k[j]);
+                // the weight-0 pairs of a squared operator (anticommuting, off the diagonal) are exact zeros: kept only without a threshold
+                keep = valid && !(use_thr && squared && (e & 1) && L.i(k[j]) != L.o(k[j]) && !(0.0 > thr));
+            } else {
             if (PACKED && valid) {
                 if (hist) atomicAdd(&s_h[(u32)(k[j] >> hist_shift) & 255u], 1u);
                 const u32 i = L.i(k[j]), o = L.o(k[j]);
@@ -345,7 +372,8 @@ __global__ __launch_bounds__(256) void k_mark_singles(const u64 *__restrict__ ke
             // strict |c| > thr: a component that alone exceeds thr decides it (hypot is faithfully rounded and >= either component)
             // (and an exact zero — every anticommuting pair of a squared operator — needs no hypot either)
             const bool zero = cx == 0.0 && cy == 0.0;
-            const bool keep = valid && (!use_thr || (zero ? 0.0 > thr : (fabs(cx) > thr || fabs(cy) > thr || hypot(__dadd_rn(0.0, cx), __dadd_rn(0.0, cy)) > thr)));
+            keep = valid && (!use_thr || (zero ? 0.0 > thr : (fabs(cx) > thr || fabs(cy) > thr || hypot(__dadd_rn(0.0, cx), __dadd_rn(0.0, cy)) > thr)));
+            }
             const u64 mk = __ballot(keep);
             const i64 chunk = (g0 + 64 * j) / 64;
             if (PACKED) {
@@ -1612,7 +1640,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         if (e && e[0] == '1') squared = false;
     }
     i64 Tk = T;                                                         // number of keys that are sorted (T index space stays)
-    Scratch keys, keys2, idx, idx2, fixlist, collision, hI, hO, pair_coeff, markbits, sum_of, zpart, zcount, patchbits, e_lo, e_hi, dirtybits, sort_hist;
+    Scratch keys, keys2, idx, idx2, fixlist, collision, hI, hO, pair_coeff, markbits, sum_of, zpart, zcount, patchbits, e_lo, e_hi, dirtybits, sort_hist, cfloor;
     // singles decided in index order, only merged terms filed from the sorted order (k_mark_singles); SYMGPU_CLEANUP_LAZY=0: every term filed
     // Default: products only.  A plain cleanup is what follows `A + B` or a rotation — inputs full of repeated rows, where every chunk
     // holds merged terms and the extra passes buy nothing (10^6 terms of 1,000 qubits, 2.7 copies of every row: 0.89 ms lazy against
@@ -1698,8 +1726,16 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     const i64 n_tiles = (Tk + SORT_TILE - 1) / SORT_TILE;
                     SG_TRY(sort_hist.alloc((size_t)n_tiles * 256 * sizeof(u32)));
                     first_hist = sort_hist.as<u32>();
+                    // how small the operands' coefficients get: decides whether k_mark_singles has to look at them at all
+                    SG_TRY(cfloor.alloc(16));
+                    HIP_TRY(hipMemsetAsync(cfloor.p, 0xFF, 16, st));
+                    hipLaunchKernelGGL(k_coeff_floor, dim3(grid_for(Ni, 256, 256)), dim3(256), 0, st, ci, Ni, cfloor.as<unsigned long long>());
+                    if (co != ci || No != Ni)
+                        hipLaunchKernelGGL(k_coeff_floor, dim3(grid_for(No, 256, 256)), dim3(256), 0, st, co, No, cfloor.as<unsigned long long>() + 1);
+                    const double *fl_i = cfloor.as<double>(), *fl_o = (co != ci || No != Ni) ? cfloor.as<double>() + 1 : cfloor.as<double>();
+                    if (getenv("SYMGPU_CLEANUP_NOFLOOR")) fl_i = fl_o = nullptr;     // tests: every coefficient looked at
                     hipLaunchKernelGGL(k_mark_singles<true>, dim3((unsigned)n_tiles), dim3(256), 0, st, keys.as<u64>(), (const double *)nullptr, Tk, L, ci, co,
-                                       squared ? 1 : 0, thr, use_thr, markbits.as<u64>(), e_lo.as<u64>(), e_hi.as<u64>(), first_hist, 64 - nbits, n_tiles);
+                                       squared ? 1 : 0, thr, use_thr, markbits.as<u64>(), e_lo.as<u64>(), e_hi.as<u64>(), first_hist, 64 - nbits, n_tiles, fl_i, fl_o);
                     KERNEL_CHECK();
                 }
                 // products whose keys mostly merge with nothing: stop the sort one pass early and sort only the keys that have a partner
@@ -1784,7 +1820,8 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         }
         if (!packed && lazy_a) {
             hipLaunchKernelGGL(k_mark_singles<false>, dim3((unsigned)((T + SORT_TILE - 1) / SORT_TILE)), dim3(256), 0, st, (const u64 *)nullptr, coeff, T, L, (const double *)nullptr,
-                               (const double *)nullptr, 0, thr, use_thr, markbits.as<u64>(), (u64 *)nullptr, (u64 *)nullptr, (u32 *)nullptr, 0, (i64)0);
+                               (const double *)nullptr, 0, thr, use_thr, markbits.as<u64>(), (u64 *)nullptr, (u64 *)nullptr, (u32 *)nullptr, 0, (i64)0, (const double *)nullptr,
+                               (const double *)nullptr);
             KERNEL_CHECK();
         }
         if (!packed) SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), Tk, 64 - nbits, 64, &in_tmp));

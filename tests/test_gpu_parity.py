@@ -412,6 +412,33 @@ def test_squared_operator_path_equals_general_pair_path(n, N, monkeypatch):
     assert_op_equal(fast.symp_matrix, fast.coeff_vec, slow.symp_matrix, slow.coeff_vec, exact=False, tol=TOL * per_row)
 
 
+@pytest.mark.parametrize('planted', [False, True])
+def test_singles_kept_without_looking_equals_looking(planted, monkeypatch):
+    """k_mark_singles skips the coefficient arithmetic when the operands' smallest coefficients prove that every pair of non-zero weight
+    clears the threshold (k_coeff_floor); SYMGPU_CLEANUP_NOFLOOR=1 makes it look at every coefficient.  Same bits either way — with O(1)
+    coefficients (shortcut taken) and with planted tiny ones whose products fall under the threshold (shortcut refused by itself)."""
+    rng = np.random.default_rng(4242 + planted)
+    n, N, M = 64, 900, 700
+    ca = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    cb = rng.standard_normal(M) + 1j * rng.standard_normal(M)
+    if planted:
+        ca[rng.integers(0, N, 40)] *= 1e-9
+        cb[rng.integers(0, M, 40)] *= 1e-9
+    A = PauliwordOp(rng.random((N, 2 * n)) < 0.3, ca)
+    B = PauliwordOp(rng.random((M, 2 * n)) < 0.3, cb)
+    monkeypatch.setenv('SYMGPU_CLEANUP_LAZY', '1')                      # the flow with k_mark_singles at this size
+    for X, Y in ((A, A), (A, B)):
+        for thr in (1e-15, 1e-12, None):
+            fast = kernels.mul_cleanup(X.packed, X.coeff_vec, Y.packed, Y.coeff_vec, True, thr)
+            monkeypatch.setenv('SYMGPU_CLEANUP_NOFLOOR', '1')
+            slow = kernels.mul_cleanup(X.packed, X.coeff_vec, Y.packed, Y.coeff_vec, True, thr)
+            monkeypatch.delenv('SYMGPU_CLEANUP_NOFLOOR')
+            assert np.array_equal(fast[0], slow[0]) and np.array_equal(fast[1].view(np.uint64), slow[1].view(np.uint64))
+        erows, ecoeff = onp.mul(X.symp_matrix, X.coeff_vec, Y.symp_matrix, Y.coeff_vec)
+        R = X * Y
+        assert_op_equal(R.symp_matrix, R.coeff_vec, erows, ecoeff, exact=False)
+
+
 def test_mul_cleanup_gaussian_tolerance():
     rng = np.random.default_rng(11)
     n, N = 100, 300
