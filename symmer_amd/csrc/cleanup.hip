@@ -292,7 +292,9 @@ __device__ __forceinline__ void tri_pair(u32 p, u32 N, u32 &o, u32 &i) {
 // histograms of the sort's first pass, which reads these very keys in this very order (one HBM pass over the keys less).
 // smallest max(|re|, |im|) over the terms of an operand (0 if a component is not a number), as the bit pattern of a non-negative double
 // (ordered like the unsigned integer): *slot starts as all ones
-__global__ __launch_bounds__(256) void k_coeff_floor(const double *__restrict__ c, i64 n, unsigned long long *__restrict__ slot) {
+__global__ __launch_bounds__(256) void k_coeff_floor(const double *__restrict__ c, i64 n, unsigned long long *__restrict__ slot, int one_block) {
+    __shared__ unsigned long long s_min;
+    if (one_block) { if (threadIdx.x == 0) s_min = ~0ULL; __syncthreads(); }
     double m = __builtin_inf();
     for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < n; t += (i64)gridDim.x * 256) {
         const double2 v = reinterpret_cast<const double2 *>(c)[t];
@@ -302,7 +304,8 @@ __global__ __launch_bounds__(256) void k_coeff_floor(const double *__restrict__ 
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(m, d); m = o < m ? o : m; }
-    if ((threadIdx.x & 63) == 0) atomicMin(slot, (unsigned long long)__double_as_longlong(m));
+    if ((threadIdx.x & 63) == 0) atomicMin(one_block ? &s_min : slot, (unsigned long long)__double_as_longlong(m));
+    if (one_block) { __syncthreads(); if (threadIdx.x == 0) *slot = s_min; }
 }
 // floor_i / floor_o (packed keys; null: none): k_coeff_floor of the two operands.  |c_i c_o| >= floor_i * floor_o, the larger component of
 // the computed product is at least 0.7 of that, so when half of it exceeds thr every pair of non-zero weight is kept WHATEVER its
@@ -1606,6 +1609,8 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                  double thr, int use_thr, symgpu_op_t *out, int Wq_out, const double *ci, const double *co, int inner_is_left, bool want_first) {
     hipStream_t st = ctx().stream;
     const bool pair = inner != nullptr;
+    const bool same_rows = pair && outer == inner && No == Ni;
+    const u64 *hO_p = nullptr;
     if (T >= ((i64)1 << 32) - 1) {
         set_error("cleanup: %lld terms exceed the 2^32-2 limit of the 32-bit index sort", (long long)T);
         return SYMGPU_E_INVALID;
@@ -1659,7 +1664,8 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
     SG_TRY(collision.alloc(16));
     if (pair) {
         SG_TRY(hI.alloc((size_t)Ni * 8));
-        SG_TRY(hO.alloc((size_t)No * 8));
+        if (!same_rows) SG_TRY(hO.alloc((size_t)No * 8));
+        hO_p = same_rows ? hI.as<u64>() : hO.as<u64>();
     } else {
         SG_TRY(idx.alloc((size_t)T * 4));
         SG_TRY(idx2.alloc((size_t)T * 4));
@@ -1715,10 +1721,10 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         bool sus_active = false, sus_coop = false;
         if (pair) {
             SG_TRY(hash_rows(inner, Ni, W, hI.as<u64>()));
-            SG_TRY(hash_rows(outer, No, W, hO.as<u64>()));
+            if (!same_rows) SG_TRY(hash_rows(outer, No, W, hO.as<u64>()));     // (one operand used twice: hO_p is hI)
             if (packed) {
                 PairKeyArgs ka;
-                ka.hI = hI.as<u64>(); ka.hO = hO.as<u64>(); ka.keys = keys.as<u64>(); ka.bi = L.bi; ka.bo = L.bo; ka.o_base = 0;
+                ka.hI = hI.as<u64>(); ka.hO = hO_p; ka.keys = keys.as<u64>(); ka.bi = L.bi; ka.bo = L.bo; ka.o_base = 0;
                 ka.squared = squared ? 1 : 0;
                 SG_TRY(mul_keys_dev(inner, Ni, outer, No, W / 2, inner_is_left, ka));
                 u32 *first_hist = nullptr;
@@ -1728,10 +1734,12 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     first_hist = sort_hist.as<u32>();
                     // how small the operands' coefficients get: decides whether k_mark_singles has to look at them at all
                     SG_TRY(cfloor.alloc(16));
-                    HIP_TRY(hipMemsetAsync(cfloor.p, 0xFF, 16, st));
-                    hipLaunchKernelGGL(k_coeff_floor, dim3(grid_for(Ni, 256, 256)), dim3(256), 0, st, ci, Ni, cfloor.as<unsigned long long>());
+                    const bool one_block = Ni <= 65536 && No <= 65536;       // a single workgroup stores its minimum: nothing to initialise
+                    if (!one_block) HIP_TRY(hipMemsetAsync(cfloor.p, 0xFF, 16, st));
+                    hipLaunchKernelGGL(k_coeff_floor, dim3(one_block ? 1 : grid_for(Ni, 256, 256)), dim3(256), 0, st, ci, Ni, cfloor.as<unsigned long long>(), one_block ? 1 : 0);
                     if (co != ci || No != Ni)
-                        hipLaunchKernelGGL(k_coeff_floor, dim3(grid_for(No, 256, 256)), dim3(256), 0, st, co, No, cfloor.as<unsigned long long>() + 1);
+                        hipLaunchKernelGGL(k_coeff_floor, dim3(one_block ? 1 : grid_for(No, 256, 256)), dim3(256), 0, st, co, No, cfloor.as<unsigned long long>() + 1,
+                                           one_block ? 1 : 0);
                     const double *fl_i = cfloor.as<double>(), *fl_o = (co != ci || No != Ni) ? cfloor.as<double>() + 1 : cfloor.as<double>();
                     if (getenv("SYMGPU_CLEANUP_NOFLOOR")) fl_i = fl_o = nullptr;     // tests: every coefficient looked at
                     hipLaunchKernelGGL(k_mark_singles<true>, dim3((unsigned)n_tiles), dim3(256), 0, st, keys.as<u64>(), (const double *)nullptr, Tk, L, ci, co,
@@ -1754,23 +1762,22 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, lo, hi, &in_tmp, first_hist));
                     u64 *part = in_tmp ? keys2.as<u64>() : keys.as<u64>(), *spare = in_tmp ? keys.as<u64>() : keys2.as<u64>();
                     const i64 n_sc = (Tk + 63) / 64;
-                    Scratch susbits, susprefix, sustotal;
-                    SG_TRY(susbits.alloc((size_t)n_sc * 8));
+                    Scratch susbits, susprefix;
+                    SG_TRY(susbits.alloc((size_t)n_sc * 8 + 16));
                     SG_TRY(susprefix.alloc((size_t)n_sc * 4));
-                    SG_TRY(sustotal.alloc(16));                            // [0] flagged keys, [1] a run too long for the flag pass
-                    HIP_TRY(hipMemsetAsync(susbits.p, 0, (size_t)n_sc * 8, st));
-                    HIP_TRY(hipMemsetAsync(sustotal.p, 0, 16, st));
+                    u32 *sustotal = susbits.as<u32>() + 2 * n_sc;          // [0] flagged keys, [1] a run too long for the flag pass (one memset with the flags)
+                    HIP_TRY(hipMemsetAsync(susbits.p, 0, (size_t)n_sc * 8 + 16, st));
                     hipLaunchKernelGGL(k_find_suspects, dim3((unsigned)((Tk + SUS_TILE - 1) / SUS_TILE)), dim3(64 * SUS_WAVES), 0, st, part, Tk, L, hI.as<u64>(),
-                                       hO.as<u64>(), susbits.as<u64>(), sustotal.as<u32>() + 1);
+                                       hO_p, susbits.as<u64>(), sustotal + 1);
                     hipLaunchKernelGGL(k_popc_words64, dim3(grid_for(n_sc)), dim3(256), 0, st, susbits.as<u64>(), n_sc, susprefix.as<u32>());
                     KERNEL_CHECK();
-                    SG_TRY(exclusive_scan_u32(susprefix.as<u32>(), susprefix.as<u32>(), n_sc, sustotal.as<u32>()));
+                    SG_TRY(exclusive_scan_u32(susprefix.as<u32>(), susprefix.as<u32>(), n_sc, sustotal));
                     // the compaction does not need the count: it is queued behind the count's way home and runs while the host waits for it (in
                     // the rare give-up case its output is simply overwritten)
                     u32 h_sus2[2] = {0, 0};
                     {
                         ReadBack rb;
-                        SG_TRY(read_back_post(sustotal.as<u32>(), 2, nullptr, 0, &rb));
+                        SG_TRY(read_back_post(sustotal, 2, nullptr, 0, &rb));
                         hipLaunchKernelGGL(k_compact_suspects, dim3((unsigned)grid_for((n_sc + 255) / 256, 1, 1 << 16)), dim3(256), 0, st, part, susbits.as<u64>(),
                                            susprefix.as<u32>(), n_sc, spare);
                         KERNEL_CHECK();
@@ -1810,7 +1817,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     SG_TRY(mul_coeff_dev(inner, ci, Ni, outer, co, 0, No, W / 2, inner_is_left, pair_coeff.as<double>()));
                     coeff = pair_coeff.as<double>();
                 }
-                hipLaunchKernelGGL(k_pair_keys, dim3(grid_for(T)), dim3(256), 0, st, hI.as<u64>(), Ni, hO.as<u64>(), T, keys.as<u64>(), idx.as<u32>());
+                hipLaunchKernelGGL(k_pair_keys, dim3(grid_for(T)), dim3(256), 0, st, hI.as<u64>(), Ni, hO_p, T, keys.as<u64>(), idx.as<u32>());
                 KERNEL_CHECK();
             }
         } else {
@@ -1843,9 +1850,9 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             const dim3 gff((unsigned)grid_for((Tsort + 255) / 256, 4, 8192));
             const dim3 gfw((unsigned)((n_ch + 255) / 256));
             if (packed) {
-                hipLaunchKernelGGL(k_fixup_find<true>, gff, dim3(256), 0, st, ks, Tsort, 64 - fix_bits, hI.as<u64>(), hO.as<u64>(), L, inner == outer, fixlist.as<u64>(), dirty_fx);
+                hipLaunchKernelGGL(k_fixup_find<true>, gff, dim3(256), 0, st, ks, Tsort, 64 - fix_bits, hI.as<u64>(), hO_p, L, inner == outer, fixlist.as<u64>(), dirty_fx);
                 hipLaunchKernelGGL(k_fixup_work<true>, gfw, dim3(256), 0, st, ks, (u32 *)nullptr, Tsort, 64 - fix_bits, fixlist.as<u64>(), collision.as<u32>() + 1,
-                                   hI.as<u64>(), hO.as<u64>(), L, inner == outer, dirty_fx);
+                                   hI.as<u64>(), hO_p, L, inner == outer, dirty_fx);
             } else {
                 hipLaunchKernelGGL(k_fixup_find<false>, gff, dim3(256), 0, st, ks, Tsort, 64 - fix_bits, (const u64 *)nullptr, (const u64 *)nullptr, L, false, fixlist.as<u64>(), dirty_fx);
                 hipLaunchKernelGGL(k_fixup_work<false>, gfw, dim3(256), 0, st, ks, is, Tsort, 64 - fix_bits, fixlist.as<u64>(), collision.as<u32>() + 1,
@@ -1895,7 +1902,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 SG_TRY(zpart.alloc((size_t)n_zb * 16));
                 SG_TRY(zcount.alloc((size_t)n_zb * 4 + 16));
                 u32 *zl = zcount.as<u32>() + n_zb;
-                hipLaunchKernelGGL(k_zero_partial, dim3((unsigned)n_zb), dim3(256), 0, st, ks, Tsort, hI.as<u64>(), hO.as<u64>(), L, inner, W, ci,
+                hipLaunchKernelGGL(k_zero_partial, dim3((unsigned)n_zb), dim3(256), 0, st, ks, Tsort, hI.as<u64>(), hO_p, L, inner, W, ci,
                                    zpart.as<double>(), zcount.as<u32>(), collision.as<u32>(), (u32)Ni, lazy_now ? markbits.as<u32>() : (u32 *)nullptr);
                 if (diag_side) { HIP_TRY(hipStreamWaitEvent(st, ctx().ev_join, 0)); diag_side = false; }
                 hipLaunchKernelGGL(k_zero_close, dim3(1), dim3(64), 0, st, ks, zpart.as<double>(), zcount.as<u32>(), n_zb, L, (u32)Ni, thr, use_thr,
@@ -1911,7 +1918,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 SG_TRY(dirtybits.alloc((size_t)n_dw * 4 + 16));
                 HIP_TRY(hipMemsetAsync(dirtybits.p, 0, (size_t)n_dw * 4 + 16, st));
                 const dim3 gf((unsigned)grid_for((Tsort + 255) / 256, 4, 8192));
-                if (packed) hipLaunchKernelGGL(k_find_merges<true>, gf, dim3(256), 0, st, ks, Tsort, zero_len_p, L, hI.as<u64>(), hO.as<u64>(), inner == outer ? 1 : 0, dirtybits.as<u32>());
+                if (packed) hipLaunchKernelGGL(k_find_merges<true>, gf, dim3(256), 0, st, ks, Tsort, zero_len_p, L, hI.as<u64>(), hO_p, inner == outer ? 1 : 0, dirtybits.as<u32>());
                 else hipLaunchKernelGGL(k_find_merges<false>, gf, dim3(256), 0, st, ks, Tsort, zero_len_p, L, nul, nul, 0, dirtybits.as<u32>());
                 KERNEL_CHECK();
                 }
@@ -1920,7 +1927,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             }
             if (packed)
                 hipLaunchKernelGGL((k_heads_sums<true, true>), gsl, dim3(256), 0, st, ks, (const u32 *)nullptr, Tsort, nul, W, inner, (u32)Ni, outer, G, nud,
-                                   collision.as<u32>(), hI.as<u64>(), hO.as<u64>(), L, ci, co, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0,
+                                   collision.as<u32>(), hI.as<u64>(), hO_p, L, ci, co, thr, use_thr, markbits.as<u32>(), sum_of.as<double>(), cpw, squared && packed ? 1 : 0,
                                    zero_len_p, patch_p, dirty_p);
             else if (pair)
                 hipLaunchKernelGGL((k_heads_sums<true, false>), gsl, dim3(256), 0, st, ks, is, Tsort, nul, W, inner, (u32)Ni, outer, G, coeff,

@@ -368,19 +368,25 @@ static int mul_coeff_launch(const u64 *It, i64 Ipad, const double *ci, i64 Ni, c
                             const PairKeyArgs *keys = nullptr) {
     const i64 No = o_end - o_begin;
     const int W = 2 * Wq;
-    const i64 Opad = round_up(No, PO * PW);
-    SG_TRY(ot.alloc((size_t)Opad * W * sizeof(u64)));
-    SG_TRY(to_wordmajor(outer + o_begin * W, No, W, ot.as<u64>(), Opad, st));
+    // P * P in key mode: the word-major copy of the inner operand IS the outer one (its padding is the wider of the two)
+    const bool same_operand = keys && keys->squared && o_begin == 0 && No == Ni;
+    const i64 Opad = same_operand ? Ipad : round_up(No, PO * PW);
+    const u64 *Ot = It;
+    if (!same_operand) {
+        SG_TRY(ot.alloc((size_t)Opad * W * sizeof(u64)));
+        SG_TRY(to_wordmajor(outer + o_begin * W, No, W, ot.as<u64>(), Opad, st));
+        Ot = ot.as<u64>();
+    }
     // grid.x a multiple of 8: inner tile bx is then always read by XCD bx % 8, whose L2 keeps its eighth of the word-major inner
     // operand across the outer row blocks (same reasoning as in mul_rows_dev)
     const i64 gx = ((Ni + 64 * PJ - 1) / (64 * PJ) + 7) / 8 * 8;
-    const i64 gy_total = Opad / (PO * PW);
+    const i64 gy_total = round_up(No, PO * PW) / (PO * PW);
     const i64 max_gy = 65535;
     for (i64 y0 = 0; y0 < gy_total; y0 += max_gy) {
         const i64 ny = gy_total - y0 < max_gy ? gy_total - y0 : max_gy;
         const i64 ooff = y0 * PO * PW;
         dim3 grid((unsigned)gx, (unsigned)ny);
-#define LAUNCH_COEFF(L) hipLaunchKernelGGL((k_mul_coeff<L, 0>), grid, dim3(256), 0, st, It, Ipad, Ni, ci, ot.as<u64>() + ooff, Opad, \
+#define LAUNCH_COEFF(L) hipLaunchKernelGGL((k_mul_coeff<L, 0>), grid, dim3(256), 0, st, It, Ipad, Ni, ci, Ot + ooff, Opad, \
                                               No - ooff, co + 2 * (o_begin + ooff), Wq, out_coeff + 2 * ooff * Ni, PairKeyArgs())
         if (keys) {
             // key mode runs over the whole outer operand (o_begin == 0); the o field stays absolute through o_base
@@ -388,7 +394,7 @@ static int mul_coeff_launch(const u64 *It, i64 Ipad, const double *ci, i64 Ni, c
             ka.hO += ooff;
             if (!ka.squared) ka.keys += ooff * Ni;                          // dense keys: slot o*Ni + i; squared: compacted, absolute slots
             ka.o_base = ooff;
-#define LAUNCH_KEYS(L, M) hipLaunchKernelGGL((k_mul_coeff<L, M>), grid, dim3(256), 0, st, It, Ipad, Ni, (const double *)nullptr, ot.as<u64>() + ooff, Opad, \
+#define LAUNCH_KEYS(L, M) hipLaunchKernelGGL((k_mul_coeff<L, M>), grid, dim3(256), 0, st, It, Ipad, Ni, (const double *)nullptr, Ot + ooff, Opad, \
                                                 No - ooff, (const double *)nullptr, Wq, (double *)nullptr, ka)
             if (ka.squared) { LAUNCH_KEYS(true, 2); }                       // P * P: left and right are the same operand
             else if (inner_is_left) { LAUNCH_KEYS(true, 1); }
