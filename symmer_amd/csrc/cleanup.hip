@@ -292,15 +292,21 @@ __device__ __forceinline__ void tri_pair(u32 p, u32 N, u32 &o, u32 &i) {
 // histograms of the sort's first pass, which reads these very keys in this very order (one HBM pass over the keys less).
 // smallest max(|re|, |im|) over the terms of an operand (0 if a component is not a number), as the bit pattern of a non-negative double
 // (ordered like the unsigned integer): *slot starts as all ones
-__global__ __launch_bounds__(256) void k_coeff_floor(const double *__restrict__ c, i64 n, unsigned long long *__restrict__ slot, int one_block) {
+__global__ __launch_bounds__(1024) void k_coeff_floor(const double *__restrict__ c, i64 n, unsigned long long *__restrict__ slot, int one_block) {
     __shared__ unsigned long long s_min;
     if (one_block) { if (threadIdx.x == 0) s_min = ~0ULL; __syncthreads(); }
     double m = __builtin_inf();
-    for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < n; t += (i64)gridDim.x * 256) {
-        const double2 v = reinterpret_cast<const double2 *>(c)[t];
-        const double a = fabs(v.x), b = fabs(v.y);
-        const double mx = (a == a && b == b) ? (a > b ? a : b) : 0.0;
-        m = mx < m ? mx : m;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 t0 = (i64)blockIdx.x * blockDim.x + threadIdx.x; t0 < n; t0 += 4 * stride) {      // four loads in flight
+        double2 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const i64 t = t0 + k * stride; v[k] = reinterpret_cast<const double2 *>(c)[t < n ? t : n - 1]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double a = fabs(v[k].x), b = fabs(v[k].y);
+            const double mx = (a == a && b == b) ? (a > b ? a : b) : 0.0;
+            m = mx < m ? mx : m;
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(m, d); m = o < m ? o : m; }
@@ -1189,6 +1195,20 @@ __global__ __launch_bounds__(256) void k_touch(TouchMaps tm, u32 *__restrict__ s
     if (acc == 0xDEADBEEFu) *sink = acc;                           // (never true for bitmaps of a real run; keeps the loads alive)
 }
 
+// zeroes of up to two buffers in ONE launch (byte counts multiples of 4): hipMemsetAsync is a launch per buffer, two when the size is not a
+// multiple of its fill kernel's granule, 5 us each on an otherwise idle queue
+__global__ __launch_bounds__(256) void k_zero_two(u32 *__restrict__ a, i64 na, u32 *__restrict__ b, i64 nb) {
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < na; i += (i64)gridDim.x * 256) a[i] = 0u;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < nb; i += (i64)gridDim.x * 256) b[i] = 0u;
+}
+static int zero_two(void *a, size_t bytes_a, void *b, size_t bytes_b) {
+    const i64 na = (i64)(bytes_a / 4), nb = b ? (i64)(bytes_b / 4) : 0;
+    if (na + nb == 0) return SYMGPU_OK;
+    hipLaunchKernelGGL(k_zero_two, dim3(grid_for(na > nb ? na : nb, 256, 4096)), dim3(256), 0, ctx().stream, static_cast<u32 *>(a), na, static_cast<u32 *>(b), nb);
+    KERNEL_CHECK();
+    return SYMGPU_OK;
+}
+
 // T = size of the index space the kept terms are filed under (pair indices, or the slots of a squared operator: `tri`)
 // word prefix of the kept-term bitmap (the output slot of every 32 indices' first kept term) + the number of kept terms, on the device
 static int emit_prefix(const u32 *markbits_p, i64 T, Scratch &wordprefix, Scratch &total) {
@@ -1736,9 +1756,9 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     SG_TRY(cfloor.alloc(16));
                     const bool one_block = Ni <= 65536 && No <= 65536;       // a single workgroup stores its minimum: nothing to initialise
                     if (!one_block) HIP_TRY(hipMemsetAsync(cfloor.p, 0xFF, 16, st));
-                    hipLaunchKernelGGL(k_coeff_floor, dim3(one_block ? 1 : grid_for(Ni, 256, 256)), dim3(256), 0, st, ci, Ni, cfloor.as<unsigned long long>(), one_block ? 1 : 0);
+                    hipLaunchKernelGGL(k_coeff_floor, dim3(one_block ? 1 : grid_for(Ni, 256, 256)), dim3(one_block ? 1024 : 256), 0, st, ci, Ni, cfloor.as<unsigned long long>(), one_block ? 1 : 0);
                     if (co != ci || No != Ni)
-                        hipLaunchKernelGGL(k_coeff_floor, dim3(one_block ? 1 : grid_for(No, 256, 256)), dim3(256), 0, st, co, No, cfloor.as<unsigned long long>() + 1,
+                        hipLaunchKernelGGL(k_coeff_floor, dim3(one_block ? 1 : grid_for(No, 256, 256)), dim3(one_block ? 1024 : 256), 0, st, co, No, cfloor.as<unsigned long long>() + 1,
                                            one_block ? 1 : 0);
                     const double *fl_i = cfloor.as<double>(), *fl_o = (co != ci || No != Ni) ? cfloor.as<double>() + 1 : cfloor.as<double>();
                     if (getenv("SYMGPU_CLEANUP_NOFLOOR")) fl_i = fl_o = nullptr;     // tests: every coefficient looked at
@@ -1766,7 +1786,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     SG_TRY(susbits.alloc((size_t)n_sc * 8 + 16));
                     SG_TRY(susprefix.alloc((size_t)n_sc * 4));
                     u32 *sustotal = susbits.as<u32>() + 2 * n_sc;          // [0] flagged keys, [1] a run too long for the flag pass (one memset with the flags)
-                    HIP_TRY(hipMemsetAsync(susbits.p, 0, (size_t)n_sc * 8 + 16, st));
+                    SG_TRY(zero_two(susbits.p, (size_t)n_sc * 8 + 16, nullptr, 0));
                     hipLaunchKernelGGL(k_find_suspects, dim3((unsigned)((Tk + SUS_TILE - 1) / SUS_TILE)), dim3(64 * SUS_WAVES), 0, st, part, Tk, L, hI.as<u64>(),
                                        hO_p, susbits.as<u64>(), sustotal + 1);
                     hipLaunchKernelGGL(k_popc_words64, dim3(grid_for(n_sc)), dim3(256), 0, st, susbits.as<u64>(), n_sc, susprefix.as<u32>());
@@ -1834,8 +1854,8 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         if (!packed) SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), Tk, 64 - nbits, 64, &in_tmp));
         ks = ks_sorted ? ks_sorted : (in_tmp ? keys2.as<u64>() : keys.as<u64>());
         is = packed ? nullptr : (in_tmp ? idx2.as<u32>() : idx.as<u32>());
-        HIP_TRY(hipMemsetAsync(collision.p, 0, 16, st));
         bool merges_found = false;                                     // lazy: dirtybits already filled by the fix-up passes
+        if (!(fix_bits < 64 && Tsort > 0 && lazy_a)) SG_TRY(zero_two(collision.p, 16, nullptr, 0));
         if (fix_bits < 64 && Tsort > 0) {
             const i64 n_ch = (Tsort + 63) / 64;
             SG_TRY(fixlist.alloc((size_t)n_ch * 8 + 16));                         // one word of flags per 64 positions
@@ -1843,7 +1863,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             if (lazy_a) {                                                           // the chunks with merged terms are found in the same pass
                 const i64 n_dw = (n_ch + 31) / 32;
                 SG_TRY(dirtybits.alloc((size_t)n_dw * 4 + 16));
-                HIP_TRY(hipMemsetAsync(dirtybits.p, 0, (size_t)n_dw * 4 + 16, st));
+                SG_TRY(zero_two(collision.p, 16, dirtybits.p, (size_t)n_dw * 4 + 16));
                 dirty_fx = dirtybits.as<u32>();
                 merges_found = true;
             }
@@ -1862,7 +1882,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         }
         if (Tsort == 0) {
             // nothing can merge (no key has a partner): every term is a single, decided by k_mark_singles
-            HIP_TRY(hipMemsetAsync(patchbits.p, 0, (size_t)((((squared && packed) ? Tk : T) + 63) / 64) * 8, st));
+            SG_TRY(zero_two(patchbits.p, (size_t)((((squared && packed) ? Tk : T) + 63) / 64) * 8, nullptr, 0));
         } else {
             int G = 1;                                   // lanes per verified candidate: one 16-byte chunk each
             while (G < W / 2 && G < 64) G <<= 1;
@@ -1891,8 +1911,8 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 if ((i64)h_dirty * 8 > n_chunks) lazy_now = false;
             }
             lazy_final = lazy_now;
-            if (lazy_now) HIP_TRY(hipMemsetAsync(patchbits.p, 0, (size_t)((space + 63) / 64) * 8, st));
-            else HIP_TRY(hipMemsetAsync(markbits.p, 0, (size_t)((space + 31) / 32) * 4, st));
+            if (lazy_now) SG_TRY(zero_two(patchbits.p, (size_t)((space + 63) / 64) * 8, nullptr, 0));
+            else SG_TRY(zero_two(markbits.p, (size_t)((space + 31) / 32) * 4, nullptr, 0));
             u32 *patch_p = lazy_now ? patchbits.as<u32>() : nullptr;
             const u32 *zero_len_p = nullptr;
             const bool zero_on = [] { const char *e = SG_TUNE("SYMGPU_CLEANUP_ZEROSEG"); return !(e && e[0] == '0'); }();
