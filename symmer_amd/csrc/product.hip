@@ -71,40 +71,38 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
     const u64 *pox = Ot + o0, *poz = Ot + (i64)Wq * Opad + o0;
     const u64 *pix = It + ibase + lane, *piz = It + (i64)Wq * Ipad + ibase + lane;
 
-    // The words of step w + 1 are fetched before the arithmetic of step w (round 5: the loads used to be waited for right where they
-    // were issued, four wavefronts per SIMD could not cover that, and the kernel ran at half its VALU rate — 0.32 ms for the 5e7 keys
-    // of cfg3).  One parity accumulator for both halves of a word frees the registers the second set of operand words needs.
-    u64 xi[PJ], zi[PJ], xo[PO], zo[PO];
-#pragma unroll
-    for (int b = 0; b < PJ; ++b) { xi[b] = pix[64 * b]; zi[b] = piz[64 * b]; }
-#pragma unroll
-    for (int a = 0; a < PO; ++a) { xo[a] = pox[a]; zo[a] = poz[a]; }   // wave-uniform -> s_load
-    for (int w = 0; w < Wq; ++w) {
-        const int wn = w + 1 < Wq ? w + 1 : w;
-        u64 xin[PJ], zin[PJ], xon[PO], zon[PO];
+    // The words of step w + 1 are fetched before the arithmetic of step w; one parity accumulator for both halves of a word frees the
+    // registers the second set of operand words needs.
+    // Two register sets used in turn (no copies between them): the loads of step w + 1 are issued at the top of step w and first used a
+    // whole step later — the scalar loads of the outer words too, which the single-set form waited for right where it issued them.
+    struct Words { u64 xi[PJ], zi[PJ], xo[PO], zo[PO]; };
+    Words A, B;
+    auto fetch = [&](Words &d, int w) {
 #pragma unroll
         for (int b = 0; b < PJ; ++b) {
-            xin[b] = pix[(i64)wn * Ipad + 64 * b];
-            zin[b] = piz[(i64)wn * Ipad + 64 * b];
+            d.xi[b] = pix[(i64)w * Ipad + 64 * b];
+            d.zi[b] = piz[(i64)w * Ipad + 64 * b];
         }
 #pragma unroll
         for (int a = 0; a < PO; ++a) {
-            xon[a] = pox[(i64)wn * Opad + a];
-            zon[a] = poz[(i64)wn * Opad + a];
+            d.xo[a] = pox[(i64)w * Opad + a];      // wave-uniform -> s_load
+            d.zo[a] = poz[(i64)w * Opad + a];
         }
+    };
+    auto step = [&](const Words &c) {
 #pragma unroll
-        for (int b = 0; b < PJ; ++b) yi[b] += __popcll(xi[b] & zi[b]);
+        for (int b = 0; b < PJ; ++b) yi[b] += __popcll(c.xi[b] & c.zi[b]);
 #pragma unroll
-        for (int a = 0; a < PO; ++a) yo[a] += __popcll(xo[a] & zo[a]);
+        for (int a = 0; a < PO; ++a) yo[a] += __popcll(c.xo[a] & c.zo[a]);
 #pragma unroll
         for (int a = 0; a < PO; ++a) {
             // SGPR sources cost ~40 % VALU issue rate on gfx950 (tools/ubench_bitop.hip): copy the uniform words to VGPRs once
             // (the words that only feed a two-operand v_xor stay scalar: an SGPR source is free there)
-            const u32 xol = INNER_LEFT ? (u32)xo[a] : to_vgpr((u32)xo[a]), xoh = INNER_LEFT ? (u32)(xo[a] >> 32) : to_vgpr((u32)(xo[a] >> 32));
-            const u32 zol = to_vgpr((u32)zo[a]), zoh = to_vgpr((u32)(zo[a] >> 32));
+            const u32 xol = INNER_LEFT ? (u32)c.xo[a] : to_vgpr((u32)c.xo[a]), xoh = INNER_LEFT ? (u32)(c.xo[a] >> 32) : to_vgpr((u32)(c.xo[a] >> 32));
+            const u32 zol = to_vgpr((u32)c.zo[a]), zoh = to_vgpr((u32)(c.zo[a] >> 32));
 #pragma unroll
             for (int b = 0; b < PJ; ++b) {
-                const u32 xil = (u32)xi[b], xih = (u32)(xi[b] >> 32), zil = (u32)zi[b], zih = (u32)(zi[b] >> 32);
+                const u32 xil = (u32)c.xi[b], xih = (u32)(c.xi[b] >> 32), zil = (u32)c.zi[b], zih = (u32)(c.zi[b] >> 32);
                 // Y_out += |(xi^xo) & (zi^zo)|   (v_bcnt with its accumulator operand: the compiler adds two counts with a third instruction)
                 cnt[a][b] = bcnt_acc(and_xor(xil ^ xol, zil, zol), cnt[a][b]);
                 cnt[a][b] = bcnt_acc(and_xor(xih ^ xoh, zih, zoh), cnt[a][b]);
@@ -118,11 +116,16 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
                 }
             }
         }
-#pragma unroll
-        for (int b = 0; b < PJ; ++b) { xi[b] = xin[b]; zi[b] = zin[b]; }
-#pragma unroll
-        for (int a = 0; a < PO; ++a) { xo[a] = xon[a]; zo[a] = zon[a]; }
+    };
+    fetch(A, 0);
+    int w = 0;
+    for (; w + 1 < Wq; w += 2) {
+        fetch(B, w + 1);
+        step(A);
+        fetch(A, w + 2 < Wq ? w + 2 : w + 1);
+        step(B);
     }
+    if (w < Wq) step(A);
 
     // Epilogue.  The stores of a full 8-outer-term tile are issued unconditionally back to back: a conditional store per
     // pair made the compiler drain the memory counter (s_waitcnt vmcnt(0)) before every single store.
