@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_find_merges(const u64 *__restrict__ key
 // exact for dyadic coefficients, rounding-level otherwise), so the zero-key segment is reduced in parallel here, in a FIXED order
 // (per-thread ascending positions, then threads, then blocks in order: deterministic), and k_heads_sums starts behind it.
 // Members that are not diagonal pairs (duplicate rows in P, or a 64-bit collision) are verified row against row like everywhere.
-constexpr int ZB = 4096;                                              // sorted positions per block
+constexpr int ZB = 1024;                                              // sorted positions per block
 __global__ __launch_bounds__(256) void k_zero_partial(const u64 *__restrict__ keys, i64 Tk, const u64 *__restrict__ hI, const u64 *__restrict__ hO,
                                                        PackedLayout L, const u64 *__restrict__ rows, int W, const double *__restrict__ cf,
                                                        double *__restrict__ part, u32 *__restrict__ part_n, u32 *__restrict__ collision,
@@ -1606,13 +1606,14 @@ __global__ void k_popc_words64(const u64 *__restrict__ bits, i64 n_words, u32 *_
 // flagged keys, in array order, to the front of `out`
 __global__ __launch_bounds__(256) void k_compact_suspects(const u64 *__restrict__ keys, const u64 *__restrict__ suspect64, const u32 *__restrict__ prefix,
                                                            i64 n_chunks, u64 *__restrict__ out) {
-    // a lane per flag word (one coalesced load for 4,096 keys), then the few words that have a flag set one after the other with the whole
-    // wavefront (a product without repeated rows flags a few thousand of 5e7 keys: a wavefront per word spent 41 us reading zeros)
+    // sixteen flag words per wavefront (lanes 0..15 load them), then the few words that have a flag set one after the other with the whole
+    // wavefront (a product without repeated rows flags a few thousand of 5e7 keys: a wavefront per word spent 41 us reading zeros; 64 words
+    // per wavefront left the 10^4 consecutive flagged keys of a squared operator's identity segment to three wavefronts: 31 us)
     const int lane = threadIdx.x & 63;
-    for (i64 base = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; base < n_chunks; base += (i64)gridDim.x * 256) {
-        const i64 mine = base + lane;
+    for (i64 base = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; base < n_chunks; base += (i64)gridDim.x * 64) {
+        const i64 mine = base + (lane & 15);
         const u64 b = mine < n_chunks ? suspect64[mine] : 0ULL;
-        u64 nz = __ballot(b != 0ULL);
+        u64 nz = __ballot(b != 0ULL) & 0xFFFFULL;
         while (nz) {                                                             // wave-uniform
             const int l = __builtin_ctzll(nz);
             nz &= nz - 1;
@@ -1798,7 +1799,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     {
                         ReadBack rb;
                         SG_TRY(read_back_post(sustotal, 2, nullptr, 0, &rb));
-                        hipLaunchKernelGGL(k_compact_suspects, dim3((unsigned)grid_for((n_sc + 255) / 256, 1, 1 << 16)), dim3(256), 0, st, part, susbits.as<u64>(),
+                        hipLaunchKernelGGL(k_compact_suspects, dim3((unsigned)grid_for((n_sc + 63) / 64, 1, 1 << 16)), dim3(256), 0, st, part, susbits.as<u64>(),
                                            susprefix.as<u32>(), n_sc, spare);
                         KERNEL_CHECK();
                         SG_TRY(read_back_wait(&rb, h_sus2));
@@ -1819,10 +1820,13 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                             while (((i64)1 << lgs) < Tsort) ++lgs;
                             const int want_s = (lgs + 5 + 7) / 8 * 8;
                             fix_bits = want_s < hash_bits ? want_s : hash_bits;
+                            // the compaction kept the array order, i.e. the flagged keys are ordered by key bits [lo, hi) already: when the bits to
+                            // order start inside that range only the passes above it are left (LSD: stable passes on more significant bits)
+                            const int sort_from = (64 - fix_bits >= lo && 64 - fix_bits < hi) ? hi : 64 - fix_bits;
                             bool in_tmp_s = false, coop_done = false;
-                            SG_TRY(radix_sort_keys_u64_coop(spare, part, Tsort, 64 - fix_bits, 64, &in_tmp_s, &coop_done));
+                            SG_TRY(radix_sort_keys_u64_coop(spare, part, Tsort, sort_from, 64, &in_tmp_s, &coop_done));
                             sus_coop = coop_done;
-                            if (!coop_done) SG_TRY(radix_sort_keys_u64(spare, part, Tsort, 64 - fix_bits, 64, &in_tmp_s));
+                            if (!coop_done) SG_TRY(radix_sort_keys_u64(spare, part, Tsort, sort_from, 64, &in_tmp_s));
                             ks_sorted = in_tmp_s ? part : spare;
                         }
                     }
