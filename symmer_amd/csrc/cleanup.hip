@@ -1017,7 +1017,7 @@ template <bool PAIR, bool TRI, int NW, int U>
 __global__ __launch_bounds__(256) void k_emit_fused(const u64 *__restrict__ markbits64, const u32 *__restrict__ wordprefix, i64 T, const double *__restrict__ sum_of,
                                                      u32 Ni, int Wq, int wsh, const u32x4 *__restrict__ rows, const u32x4 *__restrict__ inner,
                                                      const u32x4 *__restrict__ outer, u32x4 *__restrict__ out_rows, double *__restrict__ out_coeff, LazyEmit lz,
-                                                     u64 *__restrict__ out_first) {
+                                                     u64 *__restrict__ out_first, int pfx_shift /* prefix entries per 64 indices: 1 << pfx_shift */) {
     __shared__ u32 s_i[4][64 * NW], s_o[4][64 * NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const i64 w0 = ((i64)blockIdx.x * 4 + wave) * NW;
@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(256) void k_emit_fused(const u64 *__restrict__ mark
     }
     const u32 K = off[NW];
     if (K == 0) return;                                              // wave-uniform
-    const i64 p_base = wordprefix[2 * w0];
+    const i64 p_base = wordprefix[w0 << pfx_shift];
     u32 o_min = 0xFFFFFFFFu, o_max = 0u;                             // this lane's kept terms: range of their outer indices
     // Nothing the coefficients need depends on the bitmap's CONTENT: the pair (i, o) of an index, its patch / phase-exponent bits and its
     // operands' coefficients are addressed by the index alone.  They are therefore fetched for all NW x 64 indices at once, next to the
@@ -1195,35 +1195,49 @@ __global__ __launch_bounds__(256) void k_touch(TouchMaps tm, u32 *__restrict__ s
     if (acc == 0xDEADBEEFu) *sink = acc;                           // (never true for bitmaps of a real run; keeps the loads alive)
 }
 
-// zeroes of up to two buffers in ONE launch (byte counts multiples of 4): hipMemsetAsync is a launch per buffer, two when the size is not a
+// zeroes of up to three buffers in ONE launch (byte counts multiples of 4): hipMemsetAsync is a launch per buffer, two when the size is not a
 // multiple of its fill kernel's granule, 5 us each on an otherwise idle queue
-__global__ __launch_bounds__(256) void k_zero_two(u32 *__restrict__ a, i64 na, u32 *__restrict__ b, i64 nb) {
+__global__ __launch_bounds__(256) void k_zero_two(u32 *__restrict__ a, i64 na, u32 *__restrict__ b, i64 nb, u32 *__restrict__ c, i64 nc) {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < na; i += (i64)gridDim.x * 256) a[i] = 0u;
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < nb; i += (i64)gridDim.x * 256) b[i] = 0u;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < nc; i += (i64)gridDim.x * 256) c[i] = 0u;
 }
-static int zero_two(void *a, size_t bytes_a, void *b, size_t bytes_b) {
-    const i64 na = (i64)(bytes_a / 4), nb = b ? (i64)(bytes_b / 4) : 0;
-    if (na + nb == 0) return SYMGPU_OK;
-    hipLaunchKernelGGL(k_zero_two, dim3(grid_for(na > nb ? na : nb, 256, 4096)), dim3(256), 0, ctx().stream, static_cast<u32 *>(a), na, static_cast<u32 *>(b), nb);
+static int zero_two(void *a, size_t bytes_a, void *b, size_t bytes_b, void *c = nullptr, size_t bytes_c = 0) {
+    const i64 na = (i64)(bytes_a / 4), nb = b ? (i64)(bytes_b / 4) : 0, nc = c ? (i64)(bytes_c / 4) : 0;
+    if (na + nb + nc == 0) return SYMGPU_OK;
+    i64 nmax = na > nb ? na : nb;
+    nmax = nmax > nc ? nmax : nc;
+    hipLaunchKernelGGL(k_zero_two, dim3(grid_for(nmax, 256, 4096)), dim3(256), 0, ctx().stream, static_cast<u32 *>(a), na, static_cast<u32 *>(b), nb,
+                       static_cast<u32 *>(c), nc);
     KERNEL_CHECK();
     return SYMGPU_OK;
 }
 
 // T = size of the index space the kept terms are filed under (pair indices, or the slots of a squared operator: `tri`)
 // word prefix of the kept-term bitmap (the output slot of every 32 indices' first kept term) + the number of kept terms, on the device
-static int emit_prefix(const u32 *markbits_p, i64 T, Scratch &wordprefix, Scratch &total) {
+// wide: one prefix entry per 64 indices (all the fused output stage reads) instead of per 32: half the elements to count and scan
+__global__ void k_popc_words64_tail(const u64 *__restrict__ bits, i64 n64, i64 n32, u32 *__restrict__ counts) {
+    for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < n64; w += (i64)gridDim.x * blockDim.x) {
+        u64 b = bits[w];
+        if (w == n64 - 1 && (n32 & 1)) b &= 0xFFFFFFFFULL;           // the bitmap is written in 32-bit words: the last upper half may be unwritten
+        counts[w] = (u32)__popcll(b);
+    }
+}
+static int emit_prefix(const u32 *markbits_p, i64 T, Scratch &wordprefix, Scratch &total, bool wide) {
     hipStream_t st = ctx().stream;
-    const i64 n_words = (T + 31) / 32;
-    SG_TRY(wordprefix.alloc((size_t)n_words * 4));
-    hipLaunchKernelGGL(k_popc_words, dim3(grid_for(n_words)), dim3(256), 0, st, markbits_p, n_words, wordprefix.as<u32>());
+    const i64 n_words = (T + 31) / 32, n64 = (T + 63) / 64;
+    const i64 n = wide ? n64 : n_words;
+    SG_TRY(wordprefix.alloc((size_t)n * 4));
+    if (wide) hipLaunchKernelGGL(k_popc_words64_tail, dim3(grid_for(n64)), dim3(256), 0, st, reinterpret_cast<const u64 *>(markbits_p), n64, n_words, wordprefix.as<u32>());
+    else hipLaunchKernelGGL(k_popc_words, dim3(grid_for(n_words)), dim3(256), 0, st, markbits_p, n_words, wordprefix.as<u32>());
     KERNEL_CHECK();
-    SG_TRY(total.alloc(32));                                       // [0] the count, [2] k_touch's sink, [4..5] cleanup_core's status words ride along
-    return exclusive_scan_u32(wordprefix.as<u32>(), wordprefix.as<u32>(), n_words, total.as<u32>());
+    SG_TRY(total.alloc(32));                                       // [0] the count, [2] k_touch's sink
+    return exclusive_scan_u32(wordprefix.as<u32>(), wordprefix.as<u32>(), n, total.as<u32>());
 }
 
 // pre (optional): the prefix was formed and the count read back by the caller (cleanup_core reads it with its own status words: one host
 // round trip instead of two)
-struct EmitPrefix { Scratch wordprefix, total; i64 n_out = -1; bool touched = false; };
+struct EmitPrefix { Scratch wordprefix, total; i64 n_out = -1; bool touched = false, wide = false; };
 // one launch over the bitmaps the fused output stage decodes (five launches of 2 us each sat 6 us apart behind the host's read-back)
 static bool emit_is_fused(int Wq) { return Wq <= 64 && [] { const char *e = getenv("SYMGPU_EMIT_FUSED"); return !(e && e[0] == '0'); }(); }
 static int emit_touch(const u32 *markbits_p, i64 T, const LazyEmit &lz, EmitPrefix &pre) {
@@ -1235,7 +1249,7 @@ static int emit_touch(const u32 *markbits_p, i64 T, const LazyEmit &lz, EmitPref
                            lz.mode == 1 ? (const void *)lz.e_hi : nullptr};
     for (int m = 0; m < 5; ++m) {
         tm.p[m] = reinterpret_cast<const u32x4 *>(maps[m]);
-        tm.n16[m] = maps[m] ? (m == 1 ? 2 * n16 : n16) : 0;
+        tm.n16[m] = maps[m] ? (m == 1 && !pre.wide ? 2 * n16 : n16) : 0;
     }
     hipLaunchKernelGGL(k_touch, dim3(grid_for(2 * n16)), dim3(256), 0, ctx().stream, tm, pre.total.as<u32>() + 2);
     KERNEL_CHECK();
@@ -1248,7 +1262,8 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
     EmitPrefix own;
     if (!pre || pre->n_out < 0) {
         pre = &own;
-        SG_TRY(emit_prefix(markbits_p, T, own.wordprefix, own.total));
+        own.wide = emit_is_fused(W / 2);
+        SG_TRY(emit_prefix(markbits_p, T, own.wordprefix, own.total, own.wide));
         u32 n_out32 = 0;
         SG_TRY(read_back_words(own.total.as<u32>(), 1, nullptr, 0, &n_out32));
         own.n_out = n_out32;
@@ -1281,7 +1296,7 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
             if (touch_on && !pre->touched) SG_TRY(emit_touch(markbits_p, T, lz, *pre));
             ProfScope prof(3);
 #define LAUNCH_FUSED_S(P, TR, NWV, UV) hipLaunchKernelGGL((k_emit_fused<P, TR, NWV, UV>), gfu, dim3(256), 0, st, reinterpret_cast<const u64 *>(markbits_p), wordprefix.as<u32>(), T, sum_of_p, \
-                                               (u32)(pair ? Ni : 1), Wq, wsh, reinterpret_cast<const u32x4 *>(rows), pin, pout, dst, res->coeff, lz, res->first)
+                                               (u32)(pair ? Ni : 1), Wq, wsh, reinterpret_cast<const u32x4 *>(rows), pin, pout, dst, res->coeff, lz, res->first, pre->wide ? 0 : 1)
 #define LAUNCH_FUSED_U(P, TR, NWV) do { if (Us == 8) LAUNCH_FUSED_S(P, TR, NWV, 8); else if (Us == 2) LAUNCH_FUSED_S(P, TR, NWV, 2); else LAUNCH_FUSED_S(P, TR, NWV, 4); } while (0)
 #define LAUNCH_FUSED(P, TR) do { if (NWr == 1) LAUNCH_FUSED_U(P, TR, 1); else if (NWr == 4) LAUNCH_FUSED_U(P, TR, 4); else if (NWr == 8) LAUNCH_FUSED_U(P, TR, 8); \
                                  else LAUNCH_FUSED_U(P, TR, 2); } while (0)
@@ -1858,7 +1873,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         if (!packed) SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), Tk, 64 - nbits, 64, &in_tmp));
         ks = ks_sorted ? ks_sorted : (in_tmp ? keys2.as<u64>() : keys.as<u64>());
         is = packed ? nullptr : (in_tmp ? idx2.as<u32>() : idx.as<u32>());
-        bool merges_found = false;                                     // lazy: dirtybits already filled by the fix-up passes
+        bool merges_found = false, patch_zeroed = false;               // lazy: dirtybits already filled by the fix-up passes
         if (!(fix_bits < 64 && Tsort > 0 && lazy_a)) SG_TRY(zero_two(collision.p, 16, nullptr, 0));
         if (fix_bits < 64 && Tsort > 0) {
             const i64 n_ch = (Tsort + 63) / 64;
@@ -1867,7 +1882,10 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             if (lazy_a) {                                                           // the chunks with merged terms are found in the same pass
                 const i64 n_dw = (n_ch + 31) / 32;
                 SG_TRY(dirtybits.alloc((size_t)n_dw * 4 + 16));
-                SG_TRY(zero_two(collision.p, 16, dirtybits.p, (size_t)n_dw * 4 + 16));
+                // (with the flagged keys alone in the sorted array the lazy flow is never given up below: its patch bitmap is zeroed here too)
+                patch_zeroed = sus_active && patchbits.p != nullptr;
+                SG_TRY(zero_two(collision.p, 16, dirtybits.p, (size_t)n_dw * 4 + 16, patch_zeroed ? patchbits.p : nullptr,
+                                (size_t)((((squared && packed) ? Tk : T) + 63) / 64) * 8));
                 dirty_fx = dirtybits.as<u32>();
                 merges_found = true;
             }
@@ -1915,7 +1933,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 if ((i64)h_dirty * 8 > n_chunks) lazy_now = false;
             }
             lazy_final = lazy_now;
-            if (lazy_now) SG_TRY(zero_two(patchbits.p, (size_t)((space + 63) / 64) * 8, nullptr, 0));
+            if (lazy_now) { if (!patch_zeroed) SG_TRY(zero_two(patchbits.p, (size_t)((space + 63) / 64) * 8, nullptr, 0)); }
             else SG_TRY(zero_two(markbits.p, (size_t)((space + 31) / 32) * 4, nullptr, 0));
             u32 *patch_p = lazy_now ? patchbits.as<u32>() : nullptr;
             const u32 *zero_len_p = nullptr;
@@ -1966,7 +1984,8 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         // the output stage's prefix over the kept-term bitmap is formed BEFORE this attempt's status words are read: the count of kept terms
         // comes back with them (an attempt that has to be repeated throws the prefix away)
         pre.n_out = -1;
-        SG_TRY(emit_prefix(markbits.as<u32>(), (squared && packed) ? Tk : T, pre.wordprefix, pre.total));
+        pre.wide = emit_is_fused(W / 2);
+        SG_TRY(emit_prefix(markbits.as<u32>(), (squared && packed) ? Tk : T, pre.wordprefix, pre.total, pre.wide));
         pre.touched = false;
         if (emit_is_fused(W / 2) && !SG_TUNE("SYMGPU_EMIT_TOUCH")) {      // (the output stage's bitmaps back into the cache: queued ahead of the read-back, not behind it)
             LazyEmit lzt;
