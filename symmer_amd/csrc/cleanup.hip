@@ -1383,24 +1383,24 @@ __device__ __forceinline__ u32 wave_shr1(u32 v, u32 lane0) {            // lane 
 __device__ __forceinline__ u32 sus_slot(u32 w) { return w >> 16; }
 __device__ __forceinline__ u32 sus_slot2(u32 w) { return (w >> 19) | ((w & 7u) << 13); }
 static_assert(SUS_BLOOM == 16 && SUS_RUN_BITS == 16, "sus_slot / sus_slot2 are written for these");
-__global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_find_suspects(const u64 *__restrict__ keys, i64 T, PackedLayout L, const u64 *__restrict__ hI,
+__global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_find_suspects(const u64 *__restrict__ keys, i64 T, PackedLayout L, const u64 *__restrict__ hI,
                                                                    const u64 *__restrict__ hO, u64 *__restrict__ suspect64, u32 *__restrict__ giveup) {
     constexpr int NT = 64 * SUS_WAVES;
     __shared__ u32 s_seen[1 << (SUS_BLOOM - 5)], s_dup[1 << (SUS_BLOOM - 5)];
     __shared__ __attribute__((aligned(16))) u32 s_cw[SUS_CAND];
-    __shared__ u64 s_ck[SUS_CAND];
     __shared__ u32 s_cpos[SUS_CAND];
     __shared__ u32 s_start, s_end[2], s_nc;                             // s_end by step parity: a wavefront is at most one barrier ahead
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u64 lt_mask = (1ULL << lane) - 1ULL;
     const i64 t0 = (i64)blockIdx.x * SUS_TILE;
     const u64 *kt = keys + t0;
-    const u32 n_rel = T - t0 < (i64)0x7fffffff ? (u32)(T - t0) : 0x7fffffffu;          // positions from t0 on, as far as this workgroup could ever reach
+    const u32 n_rel = T - t0 < (i64)0x0fffffff ? (u32)(T - t0) : 0x0fffffffu;          // positions from t0 on, as far as this workgroup could ever reach
     const u32 t1_rel = n_rel < (u32)SUS_TILE ? n_rel : (u32)SUS_TILE;
     const u32 rmask = (1u << SUS_RUN_BITS) - 1u;
     const int F = L.F();
     typedef unsigned long long ull;
-    auto at = [&](u32 rel) -> u64 { return kt[rel < n_rel ? rel : n_rel - 1]; };      // clamped, unconditional
+    // clamped, unconditional; a 32-bit byte offset from the workgroup's (scalar) base: one address register per load instead of two
+    auto at = [&](u32 rel) -> u64 { return *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(kt) + (size_t)((rel < n_rel ? rel : n_rel - 1) << 3)); };
     auto hash0 = [&](u64 k) -> bool { return (k >> F) == 0ULL; };                      // the identity segment
     // the tile — a wavefront holds 512 consecutive keys — and the first 1,024 keys behind it (a run of 763 keys on average ends there):
     // all loads in flight together
@@ -1410,6 +1410,8 @@ __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(
     auto rel_of = [&](int r) -> u32 { return (r < SUS_ROWS ? wrel + r * 64 : xrel + (r - SUS_ROWS) * 64) + lane; };
 #pragma unroll
     for (int r = 0; r < NK; ++r) key[r] = at(rel_of(r));
+    // only the upper half of a key (run bits + sixteen hash bits) and one bit "hash field zero" are kept from here on: ten registers less
+    u32 w[NK], zmask = 0;
     const u64 kprev = (t0 > 0 || wrel > 0) ? keys[t0 + wrel - 1] : 0ULL;
     const u64 kpe = at(xrel - 1);
     {
@@ -1422,6 +1424,8 @@ __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(
     }
     if (threadIdx.x == 0) { s_start = ~0u; s_end[0] = ~0u; s_end[1] = ~0u; s_nc = 0u; }
     __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NK; ++r) { w[r] = (u32)(key[r] >> 32); zmask |= (hash0(key[r]) ? 1u : 0u) << r; }
     // first position of the tile where a run starts, and first one behind the tile
     {
         u32 carry = (u32)(kprev >> 32) & rmask;
@@ -1429,7 +1433,7 @@ __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int r = 0; r < NK; ++r) {
             if (r == SUS_ROWS) carry = (u32)(kpe >> 32) & rmask;
-            const u32 v = (u32)(key[r] >> 32) & rmask;
+            const u32 v = w[r] & rmask;
             const u32 pv = wave_shr1(v, carry);
             carry = (u32)__builtin_amdgcn_readlane((int)v, 63);
             const u32 rel = rel_of(r);
@@ -1467,7 +1471,7 @@ __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(
         for (int r = 0; r < NK; ++r) {
             const u32 rel = rel_of(r);
             const bool own = rel >= s_rel && rel < e_rel;
-            const bool zh = own && hash0(key[r]);
+            const bool zh = own && ((zmask >> r) & 1u);
             flag_chunk(__ballot(zh), (t0 + rel - lane) / 64);
             ins |= ((own && !zh) ? 1u : 0u) << r;
         }
@@ -1478,14 +1482,14 @@ __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int q = 0; q < HB; ++q) {
                 const int r = h * HB + q;
-                const u32 w = (u32)(key[r] >> 32), slot = sus_slot(w), slot2 = sus_slot2(w), in = (ins >> r) & 1u;
+                const u32 slot = sus_slot(w[r]), slot2 = sus_slot2(w[r]), in = (ins >> r) & 1u;
                 old[q] = atomicOr(&s_seen[slot >> 5], in << (slot & 31));
                 old2[q] = atomicOr(&s_seen[slot2 >> 5], in << (slot2 & 31));
             }
 #pragma unroll
             for (int q = 0; q < HB; ++q) {
                 const int r = h * HB + q;
-                const u32 w = (u32)(key[r] >> 32), slot = sus_slot(w), slot2 = sus_slot2(w), in = (ins >> r) & 1u;
+                const u32 slot = sus_slot(w[r]), slot2 = sus_slot2(w[r]), in = (ins >> r) & 1u;
                 atomicOr(&s_dup[slot >> 5], old[q] & (in << (slot & 31)));
                 atomicOr(&s_dup[slot2 >> 5], old2[q] & (in << (slot2 & 31)));
             }
@@ -1524,7 +1528,7 @@ __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(
             const bool own = rel < e_rel;
             const bool zh = own && hash0(kq[r]);
             flag_chunk(__ballot(zh), (t0 + q0) / 64 + r);
-            const u32 w = (u32)(kq[r] >> 32), slot = sus_slot(w), slot2 = sus_slot2(w);
+            const u32 wq = (u32)(kq[r] >> 32), slot = sus_slot(wq), slot2 = sus_slot2(wq);
             const u32 bit = (own && !zh) ? 1u << (slot & 31) : 0u, bit2 = (own && !zh) ? 1u << (slot2 & 31) : 0u;
             const u32 old = atomicOr(&s_seen[slot >> 5], bit), old2 = atomicOr(&s_seen[slot2 >> 5], bit2);
             atomicOr(&s_dup[slot >> 5], old & bit);
@@ -1533,16 +1537,16 @@ __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(
     }
     __syncthreads();
     // the owned keys whose two bits were both set twice: one counter update per wavefront
-    auto listed = [&](u32 rel, u64 k) -> bool {
-        const u32 w = (u32)(k >> 32), slot = sus_slot(w), slot2 = sus_slot2(w);
-        return rel >= s_rel && rel < e_rel && ((s_dup[slot >> 5] >> (slot & 31)) & (s_dup[slot2 >> 5] >> (slot2 & 31)) & 1u) && !hash0(k);
+    auto listed = [&](u32 rel, u32 wk, bool zh) -> bool {
+        const u32 slot = sus_slot(wk), slot2 = sus_slot2(wk);
+        return rel >= s_rel && rel < e_rel && ((s_dup[slot >> 5] >> (slot & 31)) & (s_dup[slot2 >> 5] >> (slot2 & 31)) & 1u) && !zh;
     };
     {
         u64 m[NK];
         u32 total = 0;
 #pragma unroll
         for (int r = 0; r < NK; ++r) {
-            m[r] = __ballot(listed(rel_of(r), key[r]));
+            m[r] = __ballot(listed(rel_of(r), w[r], (zmask >> r) & 1u));
             total += (u32)__popcll(m[r]);
         }
         if (total) {                                                    // wave-uniform
@@ -1552,16 +1556,16 @@ __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int r = 0; r < NK; ++r) {
                 const u32 n = base + (u32)__popcll(m[r] & lt_mask);
-                if (((m[r] >> lane) & 1ULL) && n < (u32)SUS_CAND) { s_cpos[n] = rel_of(r); s_ck[n] = key[r]; s_cw[n] = (u32)(key[r] >> 32); }
+                if (((m[r] >> lane) & 1ULL) && n < (u32)SUS_CAND) { s_cpos[n] = rel_of(r); s_cw[n] = w[r]; }
                 base += (u32)__popcll(m[r]);
             }
         }
     }
     for (u32 rel = (u32)SUS_TILE + 1024u + threadIdx.x; rel < e_rel; rel += NT) {      // (the steps that were not kept in registers)
         const u64 k = kt[rel];
-        if (listed(rel, k)) {
+        if (listed(rel, (u32)(k >> 32), hash0(k))) {
             const u32 n = atomicAdd(&s_nc, 1u);
-            if (n < (u32)SUS_CAND) { s_cpos[n] = rel; s_ck[n] = k; s_cw[n] = (u32)(k >> 32); }
+            if (n < (u32)SUS_CAND) { s_cpos[n] = rel; s_cw[n] = (u32)(k >> 32); }
         }
     }
     __syncthreads();
@@ -1586,10 +1590,10 @@ __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(
         const u32 b0 = part ? half : 0u, b1 = part ? nc : (half < nc ? half : nc);
 #pragma unroll 4
         for (u32 b = b0; b < b1; b += 4) {
-            const u32x4 w = *reinterpret_cast<const u32x4 *>(&s_cw[b]);
+            const u32x4 wl = *reinterpret_cast<const u32x4 *>(&s_cw[b]);
 #pragma unroll
             for (u32 j = 0; j < 4; ++j)
-                if (live && w[j] == wa && b + j != a && b + j < b1) {
+                if (live && wl[j] == wa && b + j != a && b + j < b1) {
                     if (n_eq == 0) first = b + j;
                     last = b + j;
                     ++n_eq;
@@ -1605,7 +1609,7 @@ __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(
         }
         bool hit = n_eq > 2;                                            // (four equal 32-bit words in one run: flagged without looking)
         if (n_eq >= 1 && n_eq <= 2 && part == 0) {
-            const u64 ka = s_ck[a], kb = s_ck[first], kc = s_ck[last];
+            const u64 ka = kt[s_cpos[a]], kb = kt[s_cpos[first]], kc = kt[s_cpos[last]];      // (from the L2: the lists hold words only)
             const u64 fa = L.full_key(hI, hO, ka);
             hit = (((ka ^ kb) >> F) == 0ULL && fa == L.full_key(hI, hO, kb)) || (((ka ^ kc) >> F) == 0ULL && fa == L.full_key(hI, hO, kc));
         }
