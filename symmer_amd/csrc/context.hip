@@ -457,8 +457,8 @@ __global__ void k_mail_words(const u32 *__restrict__ a, int n_a, const u32 *__re
 }
 static bool mail_ready() {
     Context &c = ctx();
-    static const bool plain = [] { const char *e = getenv("SYMGPU_READBACK_PLAIN"); return e && e[0] == '1'; }();
-    if (plain) return false;
+    const char *plain = getenv("SYMGPU_READBACK_PLAIN");
+    if (plain && plain[0] == '1') return false;
     if (!c.mail_host && !c.mail_failed) {
         void *h = nullptr, *d = nullptr;
         if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {

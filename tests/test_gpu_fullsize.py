@@ -286,12 +286,13 @@ def test_product_cleanup_over_the_lazy_gate_against_the_c_oracle(shape):
     assert np.array_equal(R.coeff_vec, ec)
 
 
-@pytest.mark.parametrize('mode', ['default', 'full sort', 'give up', 'repeated rows'])
+@pytest.mark.parametrize('mode', ['default', 'full sort', 'give up', 'repeated rows', 'few rows'])
 def test_cleanup_flagged_key_flow_switches(mode, monkeypatch):
     """Round 4's cleanup of products (partial sort, k_find_suspects, only the flagged keys sorted completely) against the C oracle above
     the 2^22-key gate: the default, the full sort of all keys (SYMGPU_CLEANUP_SUSPECTS=0), the flow giving up after the flag pass and
     finishing the last radix pass on the whole array (forced, and reached by itself on operands full of repeated rows, where nearly
-    every key has a partner)."""
+    every key has a partner; 'few rows': 3 x 2 distinct products, runs of ~10^6 equal keys — the flag pass itself gives up on a run it cannot
+    read to its end)."""
     rng = np.random.default_rng(4404)
     n, na, nb = 100, 2600, 2100
     if mode == 'full sort': monkeypatch.setenv('SYMGPU_CLEANUP_SUSPECTS', '0')
@@ -299,6 +300,8 @@ def test_cleanup_flagged_key_flow_switches(mode, monkeypatch):
     sa = rng.random((na, 2 * n)) < 0.3; sb = rng.random((nb, 2 * n)) < 0.3
     if mode == 'repeated rows':
         sa = sa[rng.integers(0, 400, na)]; sb = sb[rng.integers(0, 300, nb)]          # 400 x 300 distinct products, each ~45 times
+    if mode == 'few rows':
+        sa = sa[rng.integers(0, 3, na)]; sb = sb[rng.integers(0, 2, nb)]
     A = PauliwordOp(sa, dyadic(rng, na)); B = PauliwordOp(sb, dyadic(rng, nb))
     for X, Y in ((A, B), (A, A)):
         R = X * Y

@@ -412,6 +412,32 @@ def test_squared_operator_path_equals_general_pair_path(n, N, monkeypatch):
     assert_op_equal(fast.symp_matrix, fast.coeff_vec, slow.symp_matrix, slow.coeff_vec, exact=False, tol=TOL * per_row)
 
 
+def test_read_backs_through_mapped_memory_equal_plain_copies(monkeypatch):
+    """Counts and status words that a call needs on the host in the middle of its work travel through mapped host memory (a one-wavefront
+    kernel + a polled sequence number, context.hip); SYMGPU_READBACK_PLAIN=1 makes every one of them a copy + stream synchronisation.
+    Product + cleanup, a rotation with duplicate rows (multi-launch path), GF(2) elimination, a projection: same results both ways."""
+    rng = np.random.default_rng(77)
+    n = 40
+    A = PauliwordOp(rng.random((700, 2 * n)) < 0.3, dyadic(rng, 700))
+    D = PauliwordOp(np.vstack([A.symp_matrix[:300], A.symp_matrix[:300]]), dyadic(rng, 600))           # duplicate rows
+    Q = PauliwordOp(rng.random((1, 2 * n)) < 0.5, [1])
+    M = rng.random((90, 300)) < 0.3
+
+    def run():
+        R = A * A
+        S = D._rotate_by_single_Pword(Q, 0.37)
+        return R.packed, R.coeff_vec, S.packed, S.coeff_vec, rref_binary(M)
+
+    fast = run()
+    monkeypatch.setenv('SYMGPU_READBACK_PLAIN', '1')
+    plain = run()
+    monkeypatch.delenv('SYMGPU_READBACK_PLAIN')
+    for x, y in zip(fast, plain):
+        assert np.array_equal(x, y)
+    from symmer_amd import _lib
+    assert all('read-back' not in d for d in _lib.degraded())
+
+
 @pytest.mark.parametrize('planted', [False, True])
 def test_singles_kept_without_looking_equals_looking(planted, monkeypatch):
     """k_mark_singles skips the coefficient arithmetic when the operands' smallest coefficients prove that every pair of non-zero weight
