@@ -165,9 +165,9 @@ def init(device=None):
     global _initialised_device
     lib = load()
     if device is None:
-        device = int(os.environ.get('SYMGPU_DEVICE', os.environ.get('LOCAL_RANK', '0')))
         if _initialised_device is not None:
             return _initialised_device
+        device = int(os.environ.get('SYMGPU_DEVICE', os.environ.get('LOCAL_RANK', '0')))
     if _initialised_device == device:
         return device
     n = device_count()
@@ -191,7 +191,8 @@ def current_device():
 
 def lib():
     """The loaded library with an initialised context."""
-    init()
+    if _initialised_device is None:
+        init()
     return _lib
 
 
