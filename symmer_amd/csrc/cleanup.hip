@@ -1361,13 +1361,14 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
 //
 // A workgroup owns the runs that START in its tile of 4,096 positions: it skips the head of the tile that continues the previous tile's
 // run and reads on past the end of the tile until its last run ends (the neighbour skips exactly those keys).  The words w = key bits
-// [lo, lo + 32) of the owned keys go through a pair of LDS bitmaps (2^17 bits each, index = multiplicative hash of w): `seen`, and `dup`
-// for a bit that was already set.  Every key whose `dup` bit is set — the keys that have a partner, plus ~4 % chance hits — is listed, the
-// listed words are compared all against all (a hundred or two per workgroup), and an equal word is followed up with the hash field and
-// then the full 64-bit keys rebuilt from the operand hash tables, exactly the test the segment machinery makes.  A list that overflows
-// flags every key the workgroup owns; a run longer than SUS_MAX_EXT extension steps raises `giveup` (the caller finishes the sort).
+// [32, 64) of the owned keys go through a pair of LDS bitmaps (2^17 bits each): `seen`, and `dup` for a bit that was already set.  Every
+// key whose `dup` bit is set — the keys that have a partner, plus ~6 % chance hits — is listed, the listed words are compared all against
+// all from LDS (two lanes per key, no memory access in the loop), and an equal word is followed up with the hash field and then the full
+// 64-bit keys rebuilt from the operand hash tables, exactly the test the segment machinery makes.  A list that overflows flags every key
+// the workgroup owns; a run longer than SUS_MAX_EXT extension steps raises `giveup` (the caller finishes the sort).  The kernel is bound
+// by its LDS atomics and the chain of dependent phases of a workgroup, not by bandwidth (the loads alone: 0.09 ms of its 0.17).
 constexpr int SUS_TILE = 4096;
-constexpr int SUS_BLOOM = 16;                                          // log2 bits per bitmap: 8 KB each
+constexpr int SUS_BLOOM = 17;                                          // log2 bits per bitmap: 16 KB each
 constexpr int SUS_CAND = 512;
 constexpr int SUS_MAX_EXT = 64;                                        // steps of 1,024 keys a workgroup reads past its tile
 constexpr int SUS_WAVES = 8;                                           // 512 threads: eight keys of the tile and two of an extension step per lane
@@ -1377,12 +1378,11 @@ __device__ __forceinline__ u32 wave_shr1(u32 v, u32 lane0) {            // lane 
     return (u32)__builtin_amdgcn_update_dpp((int)lane0, (int)v, 0x138, 0xf, 0xf, false);
 }
 // w = the upper half of a key: run bits v below, sixteen more hash bits u above.  Inside a workgroup's range v takes a handful of consecutive
-// values, so the two slots of a word are u and (u / 8, v mod 8): words that share both are equal (up to eight runs), and a key that is
-// listed without a partner needs a chance hit in each (~1 % of the keys; with one slot 7 %, and the all-against-all comparison of
-// the listed keys then costs more than everything else)
-__device__ __forceinline__ u32 sus_slot(u32 w) { return w >> 16; }
-__device__ __forceinline__ u32 sus_slot2(u32 w) { return (w >> 19) | ((w & 7u) << 13); }
-static_assert(SUS_BLOOM == 16 && SUS_RUN_BITS == 16, "sus_slot / sus_slot2 are written for these");
+// values: the slot of a word is (u, v mod 2) (one v_alignbit + one v_and).  ~6 % of the keys are listed without having a partner (another
+// run of the same parity holds their u).  A second slot (u / 8, v mod 8) in the same bitmaps brings that down to 1 %, but its two LDS
+// atomics per key cost more than the longer comparison of the listed words: 0.20 against 0.167 ms.
+__device__ __forceinline__ u32 sus_slot(u32 w) { return __builtin_amdgcn_alignbit(w, w, 16) & ((1u << SUS_BLOOM) - 1u); }
+static_assert(SUS_BLOOM == 17 && SUS_RUN_BITS == 16, "sus_slot is written for these");
 __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_find_suspects(const u64 *__restrict__ keys, i64 T, PackedLayout L, const u64 *__restrict__ hI,
                                                                    const u64 *__restrict__ hO, u64 *__restrict__ suspect64, u32 *__restrict__ giveup) {
     constexpr int NT = 64 * SUS_WAVES;
@@ -1478,20 +1478,18 @@ __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                                   // five keys at a time: ten atomics with return in flight
             constexpr int HB = NK / 2;
-            u32 old[HB], old2[HB];
+            u32 old[HB];
 #pragma unroll
             for (int q = 0; q < HB; ++q) {
                 const int r = h * HB + q;
-                const u32 slot = sus_slot(w[r]), slot2 = sus_slot2(w[r]), in = (ins >> r) & 1u;
+                const u32 slot = sus_slot(w[r]), in = (ins >> r) & 1u;
                 old[q] = atomicOr(&s_seen[slot >> 5], in << (slot & 31));
-                old2[q] = atomicOr(&s_seen[slot2 >> 5], in << (slot2 & 31));
             }
 #pragma unroll
             for (int q = 0; q < HB; ++q) {
                 const int r = h * HB + q;
-                const u32 slot = sus_slot(w[r]), slot2 = sus_slot2(w[r]), in = (ins >> r) & 1u;
+                const u32 slot = sus_slot(w[r]), in = (ins >> r) & 1u;
                 atomicOr(&s_dup[slot >> 5], old[q] & (in << (slot & 31)));
-                atomicOr(&s_dup[slot2 >> 5], old2[q] & (in << (slot2 & 31)));
             }
         }
     }
@@ -1528,18 +1526,17 @@ __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(
             const bool own = rel < e_rel;
             const bool zh = own && hash0(kq[r]);
             flag_chunk(__ballot(zh), (t0 + q0) / 64 + r);
-            const u32 wq = (u32)(kq[r] >> 32), slot = sus_slot(wq), slot2 = sus_slot2(wq);
-            const u32 bit = (own && !zh) ? 1u << (slot & 31) : 0u, bit2 = (own && !zh) ? 1u << (slot2 & 31) : 0u;
-            const u32 old = atomicOr(&s_seen[slot >> 5], bit), old2 = atomicOr(&s_seen[slot2 >> 5], bit2);
+            const u32 wq = (u32)(kq[r] >> 32), slot = sus_slot(wq);
+            const u32 bit = (own && !zh) ? 1u << (slot & 31) : 0u;
+            const u32 old = atomicOr(&s_seen[slot >> 5], bit);
             atomicOr(&s_dup[slot >> 5], old & bit);
-            atomicOr(&s_dup[slot2 >> 5], old2 & bit2);
         }
     }
     __syncthreads();
-    // the owned keys whose two bits were both set twice: one counter update per wavefront
+    // the owned keys whose bit was set twice: one counter update per wavefront
     auto listed = [&](u32 rel, u32 wk, bool zh) -> bool {
-        const u32 slot = sus_slot(wk), slot2 = sus_slot2(wk);
-        return rel >= s_rel && rel < e_rel && ((s_dup[slot >> 5] >> (slot & 31)) & (s_dup[slot2 >> 5] >> (slot2 & 31)) & 1u) && !zh;
+        const u32 slot = sus_slot(wk);
+        return rel >= s_rel && rel < e_rel && ((s_dup[slot >> 5] >> (slot & 31)) & 1u) && !zh;
     };
     {
         u64 m[NK];
