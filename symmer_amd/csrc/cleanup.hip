@@ -1568,8 +1568,14 @@ __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(
     __syncthreads();
     const u32 nc = s_nc;
     if (nc > (u32)SUS_CAND) {                                           // (repeated rows all over: the caller gives the partial sort up anyway)
-        for (u32 rel = s_rel + threadIdx.x; rel < e_rel; rel += NT)
-            atomicOr(reinterpret_cast<ull *>(suspect64 + ((t0 + rel) >> 6)), 1ULL << ((t0 + rel) & 63));
+        // whole flag words (a bit at a time this path took 1.5 ms on the hash-partitioned products, where every key has its twin)
+        const i64 g0 = t0 + s_rel, g1 = t0 + e_rel - 1;                // first and last owned position
+        for (i64 wd = (g0 >> 6) + threadIdx.x; wd <= (g1 >> 6); wd += NT) {
+            u64 m = ~0ULL;
+            if (wd == (g0 >> 6)) m &= ~0ULL << (g0 & 63);
+            if (wd == (g1 >> 6)) m &= ~0ULL >> (63 - (g1 & 63));
+            atomicOr(reinterpret_cast<ull *>(suspect64 + wd), (ull)m);
+        }
         return;
     }
     // listed keys all against all by their words (a broadcast 16-byte read serves four) — no memory access in the loop: a lane that
