@@ -1412,7 +1412,7 @@ __global__ __launch_bounds__(64 * SUS_WAVES) __attribute__((amdgpu_waves_per_eu(
     for (int r = 0; r < NK; ++r) key[r] = at(rel_of(r));
     // only the upper half of a key (run bits + sixteen hash bits) and one bit "hash field zero" are kept from here on: ten registers less
     u32 w[NK], zmask = 0;
-    const u64 kprev = (t0 > 0 || wrel > 0) ? keys[t0 + wrel - 1] : 0ULL;
+    const u64 kprev = wrel > 0 ? at(wrel - 1) : (t0 > 0 ? keys[t0 - 1] : 0ULL);      // (clamped: a wavefront's segment may lie behind the end)
     const u64 kpe = at(xrel - 1);
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
