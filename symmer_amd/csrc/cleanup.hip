@@ -1369,7 +1369,7 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
 // by its LDS atomics and the chain of dependent phases of a workgroup, not by bandwidth (the loads alone: 0.09 ms of its 0.17).
 constexpr int SUS_TILE = 4096;
 constexpr int SUS_BLOOM = 17;                                          // log2 bits per bitmap: 16 KB each
-constexpr int SUS_CAND = 512;
+constexpr int SUS_CAND = 960;                                          // (four workgroups' LDS per CU: 4 x 40.4 KB)
 constexpr int SUS_MAX_EXT = 64;                                        // steps of 1,024 keys a workgroup reads past its tile
 constexpr int SUS_WAVES = 8;                                           // 512 threads: eight keys of the tile and two of an extension step per lane
 constexpr int SUS_ROWS = SUS_TILE / (64 * SUS_WAVES), SUS_XROWS = 1024 / (64 * SUS_WAVES);
@@ -1795,9 +1795,9 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 // SYMGPU_CLEANUP_SUSPECTS: 0 = complete sort of all keys; 2 = tests: behave as if most keys were flagged (the remaining passes are finished on the whole array)
                 const bool sus_env = [] { const char *e = getenv("SYMGPU_CLEANUP_SUSPECTS"); return !(e && e[0] == '0'); }();
                 const bool sus_giveup = [] { const char *e = getenv("SYMGPU_CLEANUP_SUSPECTS"); return e && e[0] == '2'; }();
-                // two passes before the flag pass, on key bits [32, 48): a run then holds <= 1,024 keys on average
+                // two passes before the flag pass, on key bits [32, 48): a run then holds <= 2,048 keys on average (products of up to 2^27 keys)
                 const int sus_pass = SUS_RUN_BITS / 8;
-                const bool sus_try = lazy_a && sus_env && nbits == 32 && (Tk >> SUS_RUN_BITS) <= 1024 && !(inner == outer && !squared);
+                const bool sus_try = lazy_a && sus_env && nbits == 32 && (Tk >> SUS_RUN_BITS) <= 2048 && !(inner == outer && !squared);
                 if (!sus_try) {
                     SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp, first_hist));
                 } else {

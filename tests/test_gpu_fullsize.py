@@ -309,6 +309,25 @@ def test_cleanup_flagged_key_flow_switches(mode, monkeypatch):
         assert np.array_equal(R.packed, er) and np.array_equal(R.coeff_vec, ec), mode
 
 
+def test_squared_product_with_runs_of_more_than_a_thousand_keys(monkeypatch):
+    """The flag pass of the cleanup (k_find_suspects) works on runs of keys that agree in 16 sorted hash bits: 763 keys on average at
+    cfg3, up to 2,048 (products of 2^27 keys) before the library sorts completely instead.  12,000 terms squared = 7.2e7 keys, runs of
+    ~1,100 keys that mostly need a second extension step: same rows, order and coefficients as the complete sort of all keys
+    (SYMGPU_CLEANUP_SUSPECTS=0), and the count of kept terms is 1 + the commuting pairs (dyadic coefficients, nothing cancels by chance)."""
+    rng = np.random.default_rng(8128)
+    n, N = 100, 12000
+    c = dyadic(rng, N); c[c == 0] = 0.5
+    A = PauliwordOp(rng.random((N, 2 * n)) < 0.3, c)
+    fast = A * A
+    monkeypatch.setenv('SYMGPU_CLEANUP_SUSPECTS', '0')
+    full = A * A
+    monkeypatch.delenv('SYMGPU_CLEANUP_SUSPECTS')
+    assert fast.n_terms == full.n_terms > 3.5e7
+    assert np.array_equal(fast.packed, full.packed) and np.array_equal(fast.coeff_vec, full.coeff_vec)
+    adj = A.adjacency_matrix
+    assert fast.n_terms == 1 + (int(adj.sum()) - N) // 2
+
+
 @pytest.mark.parametrize('coeffs', ['gaussian', 'dyadic'])
 def test_cfg3_full_size_against_the_oracle(coeffs):
     """BASELINE cfg3 at full size — a 10,000-term, 1,000-qubit operator squared (10^8 pairs) + cleanup — against the reference's
