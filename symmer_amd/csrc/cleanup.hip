@@ -1749,8 +1749,10 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
     bool lazy_final = false;
     EmitPrefix pre;
     for (int attempt = 0; attempt < 6 && !ok; ++attempt) {
-        // the lazy flow pays off on big key sets (its passes are fixed costs, the scatter it avoids only hurts at scale)
-        const bool lazy_a = lazy && (lazy_env == 1 || Tk >= ((i64)1 << 22));
+        // the lazy flow pays off on big key sets (its passes are fixed costs, the scatter it avoids only hurts at scale): from 2^18 keys for
+        // general products (2.5e5 keys: 0.178 -> 0.164 ms, 1.5e6: 0.32 -> 0.25, 4e6: 0.60 -> 0.42), from 2^20 for squared operators (5e5 keys:
+        // 0.222 against 0.231 lazy; 1.1e6: 0.31 -> 0.30, 3.1e6: 0.42 -> 0.37) — round 4's gate was 2^22 for both
+        const bool lazy_a = lazy && (lazy_env == 1 || Tk >= ((i64)1 << (squared ? 20 : 18)));
         lazy_final = lazy_a;
         SG_TRY(ensure_hash_tables(seed));
         const int hash_bits = packed ? 64 - L.F() : 64;       // a packed key carries 64 - F >= 30 hash bits

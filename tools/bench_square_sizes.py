@@ -1,9 +1,10 @@
 import sys, time
 sys.path.insert(0, '/root/repo')
-import ctypes
+import ctypes   # squared product + cleanup, 1,000 qubits, device resident: python tools/bench_square_sizes.py [N1,N2,...]
 from symmer_amd import kernels, _lib
 from symmer_amd.kernels import DeviceOp
-for N in (8000, 10000, 11000, 11500, 12000, 14000):
+Ns = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (8000, 10000, 11000, 11500, 12000, 14000)
+for N in Ns:
     A = DeviceOp.random(N, 1000, 0.3, seed=5)
     ts = []
     for rep in range(4):
