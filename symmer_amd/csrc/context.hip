@@ -96,7 +96,7 @@ DeviceScope::~DeviceScope() { if (active) t_cur_dev = saved; }
 // every later pass costs (round 2 needed a warm-up pass in the bench for that).  Carved blocks are never returned to the runtime
 // one by one; a chunk is released as a whole when none of its blocks is in use (dev_cache_release).
 static std::mutex g_alloc_mu;
-struct LiveBlock { size_t cls; int chunk; int dev; };   // chunk: index into the device's chunks, -1 = its own hipMalloc
+struct LiveBlock { size_t cls; int chunk; int dev; size_t req = 0; };   // req: requested bytes (canary mode only)   // chunk: index into the device's chunks, -1 = its own hipMalloc
 static std::map<void *, LiveBlock> g_live;        // block in use -> class / origin (device pointers are unique across the devices)
 struct Chunk { char *base; size_t size, used; i64 live; };
 struct DevAlloc {                                 // the allocator's state of ONE device
@@ -156,8 +156,29 @@ static void *arena_carve(size_t c, int *chunk) {
     return nullptr;
 }
 
+// Debug aid (tuning build, SYMGPU_ALLOC_CANARY=1): every block gets 256 bytes of 0xA5 behind the bytes that were asked for, checked when
+// the block is freed — a kernel that writes past the end of a buffer is reported on stderr with the block's size (size classes round up, so
+// such a write otherwise lands in padding and goes unnoticed).  Reads past the end cannot be caught this way.
+constexpr size_t CANARY = 256;
+static bool canary_on() { static const bool on = [] { const char *e = SG_TUNE("SYMGPU_ALLOC_CANARY"); return e && e[0] == '1'; }(); return on; }
+static void canary_set(void *p, size_t bytes) {
+    (void)hipMemsetAsync(static_cast<char *>(p) + bytes, 0xA5, CANARY, ctx().stream);
+}
+static void canary_check(void *p, size_t bytes) {
+    unsigned char h[CANARY];
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(h, static_cast<char *>(p) + bytes, CANARY, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (size_t k = 0; k < CANARY; ++k)
+        if (h[k] != 0xA5) {
+            fprintf(stderr, "symgpu CANARY: block of %zu bytes overwritten at +%zu behind its end (value 0x%02x)\n", bytes, k, h[k]);
+            ++g_counters[11];
+            return;
+        }
+}
 int dev_alloc(size_t bytes, void **ptr) {
     SG_TRY(require_ctx());
+    const size_t req = bytes;
+    if (canary_on()) bytes += CANARY;
     size_t c = size_class(bytes);
     {
         std::lock_guard<std::mutex> lk(g_alloc_mu);
@@ -169,13 +190,15 @@ int dev_alloc(size_t bytes, void **ptr) {
             int chunk = -1;
             auto pc = g_parked_chunk.find(*ptr);
             if (pc != g_parked_chunk.end()) { chunk = pc->second; g_parked_chunk.erase(pc); ++g_chunks[chunk].live; }
-            g_live[*ptr] = LiveBlock{c, chunk, cur_index()};
+            g_live[*ptr] = LiveBlock{c, chunk, cur_index(), req};
+            if (canary_on()) canary_set(*ptr, req);
             return SYMGPU_OK;
         }
         int chunk = -1;
         if (void *p = arena_carve(c, &chunk)) {
             *ptr = p;
-            g_live[p] = LiveBlock{c, chunk, cur_index()};
+            g_live[p] = LiveBlock{c, chunk, cur_index(), req};
+            if (canary_on()) canary_set(p, req);
             return SYMGPU_OK;
         }
     }
@@ -199,7 +222,8 @@ int dev_alloc(size_t bytes, void **ptr) {
                 int chunk = -1;
                 auto pc = g_parked_chunk.find(*ptr);
                 if (pc != g_parked_chunk.end()) { chunk = pc->second; g_parked_chunk.erase(pc); ++g_chunks[chunk].live; }
-                g_live[*ptr] = LiveBlock{cls, chunk, cur_index()};
+                g_live[*ptr] = LiveBlock{cls, chunk, cur_index(), req};
+                if (canary_on()) canary_set(*ptr, req);
                 return SYMGPU_OK;
             }
             set_error("device allocation of %zu bytes failed: %s", c, hipGetErrorString(e));
@@ -209,7 +233,8 @@ int dev_alloc(size_t bytes, void **ptr) {
     }
     std::lock_guard<std::mutex> lk(g_alloc_mu);
     ++g_counters[3];
-    g_live[*ptr] = LiveBlock{c, -1, cur_index()};
+    g_live[*ptr] = LiveBlock{c, -1, cur_index(), req};
+    if (canary_on()) canary_set(*ptr, req);
     return SYMGPU_OK;
 }
 
@@ -223,6 +248,7 @@ int dev_free(void *ptr) {
     }
     const LiveBlock blk = it->second;
     g_live.erase(it);
+    if (canary_on()) canary_check(ptr, blk.req);
     DevAlloc &A = g_alloc[blk.dev];                    // the OWNING device's lists (a handle may be dropped while another device is current)
     if (blk.chunk >= 0) {                              // arena block: parked, whatever the limit says (it cannot go back on its own)
         --A.chunks[blk.chunk].live;
