@@ -341,7 +341,11 @@ __device__ __forceinline__ void tri_pair(u32 p, u32 N, u32 &o, u32 &i) {
 // histograms of the sort's first pass, which reads these very keys in this very order (one HBM pass over the keys less).
 // smallest max(|re|, |im|) over the terms of an operand (0 if a component is not a number), as the bit pattern of a non-negative double
 // (ordered like the unsigned integer): *slot starts as all ones
-__global__ __launch_bounds__(1024) void k_coeff_floor(const double *__restrict__ c, i64 n, unsigned long long *__restrict__ slot, int one_block) {
+__global__ __launch_bounds__(1024) void k_coeff_floor(const double *__restrict__ c0, i64 n0, const double *__restrict__ c1, i64 n1,
+                                                      unsigned long long *__restrict__ slot0, int one_block) {
+    const double *__restrict__ c = blockIdx.y ? c1 : c0;           // one_block: grid (1, 2) = operand 0 / operand 1 -> slot0[0] / slot0[1]
+    const i64 n = blockIdx.y ? n1 : n0;
+    unsigned long long *slot = slot0 + blockIdx.y;
     __shared__ unsigned long long s_min;
     if (one_block) { if (threadIdx.x == 0) s_min = ~0ULL; __syncthreads(); }
     double m = __builtin_inf();
@@ -1294,10 +1298,11 @@ static int emit_prefix(const u32 *markbits_p, i64 T, Scratch &wordprefix, Scratc
     const i64 n_words = (T + 31) / 32, n64 = (T + 63) / 64;
     const i64 n = wide ? n64 : n_words;
     SG_TRY(wordprefix.alloc((size_t)n * 4));
+    SG_TRY(total.alloc(32));                                       // [0] the count, [2] k_touch's sink
+    if (wide && n64 <= POPC_SCAN_SMALL_MAX) return popc_scan_small(reinterpret_cast<const u64 *>(markbits_p), n64, n_words, wordprefix.as<u32>(), total.as<u32>());
     if (wide) hipLaunchKernelGGL(k_popc_words64_tail, dim3(grid_for(n64)), dim3(256), 0, st, reinterpret_cast<const u64 *>(markbits_p), n64, n_words, wordprefix.as<u32>());
     else hipLaunchKernelGGL(k_popc_words, dim3(grid_for(n_words)), dim3(256), 0, st, markbits_p, n_words, wordprefix.as<u32>());
     KERNEL_CHECK();
-    SG_TRY(total.alloc(32));                                       // [0] the count, [2] k_touch's sink
     return exclusive_scan_u32(wordprefix.as<u32>(), wordprefix.as<u32>(), n, total.as<u32>());
 }
 
@@ -1309,7 +1314,7 @@ static bool emit_is_fused(int Wq) { return Wq <= 64 && [] { const char *e = gete
 static int emit_touch(const u32 *markbits_p, i64 T, const LazyEmit &lz, EmitPrefix &pre) {
     const i64 n16 = (T + 63) / 64 / 2;                              // whole 16-byte chunks of a T-bit map
     pre.touched = true;
-    if (n16 <= 0) return SYMGPU_OK;
+    if (n16 <= 0 || T < ((i64)1 << 23)) return SYMGPU_OK;           // (five maps of < 1 MiB each: still cached from the kernels that wrote them)
     TouchMaps tm;
     const void *maps[5] = {markbits_p, pre.wordprefix.p, lz.mode ? (const void *)lz.patchbits : nullptr, lz.mode == 1 ? (const void *)lz.e_lo : nullptr,
                            lz.mode == 1 ? (const void *)lz.e_hi : nullptr};
@@ -1847,10 +1852,14 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     SG_TRY(cfloor.alloc(16));
                     const bool one_block = Ni <= 65536 && No <= 65536;       // a single workgroup stores its minimum: nothing to initialise
                     if (!one_block) HIP_TRY(hipMemsetAsync(cfloor.p, 0xFF, 16, st));
-                    hipLaunchKernelGGL(k_coeff_floor, dim3(one_block ? 1 : grid_for(Ni, 256, 256)), dim3(one_block ? 1024 : 256), 0, st, ci, Ni, cfloor.as<unsigned long long>(), one_block ? 1 : 0);
-                    if (co != ci || No != Ni)
-                        hipLaunchKernelGGL(k_coeff_floor, dim3(one_block ? 1 : grid_for(No, 256, 256)), dim3(one_block ? 1024 : 256), 0, st, co, No, cfloor.as<unsigned long long>() + 1,
-                                           one_block ? 1 : 0);
+                    const bool two_ops = co != ci || No != Ni;
+                    if (one_block)                                         // (blockIdx.y selects the operand: one launch for both)
+                        hipLaunchKernelGGL(k_coeff_floor, dim3(1, two_ops ? 2 : 1), dim3(1024), 0, st, ci, Ni, co, No, cfloor.as<unsigned long long>(), 1);
+                    else {
+                        hipLaunchKernelGGL(k_coeff_floor, dim3(grid_for(Ni, 256, 256)), dim3(256), 0, st, ci, Ni, ci, Ni, cfloor.as<unsigned long long>(), 0);
+                        if (two_ops)
+                            hipLaunchKernelGGL(k_coeff_floor, dim3(grid_for(No, 256, 256)), dim3(256), 0, st, co, No, co, No, cfloor.as<unsigned long long>() + 1, 0);
+                    }
                     const double *fl_i = cfloor.as<double>(), *fl_o = (co != ci || No != Ni) ? cfloor.as<double>() + 1 : cfloor.as<double>();
                     if (getenv("SYMGPU_CLEANUP_NOFLOOR")) fl_i = fl_o = nullptr;     // tests: every coefficient looked at
                     hipLaunchKernelGGL(k_mark_singles<true>, dim3((unsigned)n_tiles), dim3(256), 0, st, keys.as<u64>(), (const double *)nullptr, Tk, L, ci, co,
@@ -1880,9 +1889,12 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     SG_TRY(zero_two(susbits.p, (size_t)n_sc * 8 + 16, nullptr, 0));
                     hipLaunchKernelGGL(k_find_suspects, dim3((unsigned)((Tk + SUS_TILE - 1) / SUS_TILE)), dim3(64 * SUS_WAVES), 0, st, part, Tk, L, hI.as<u64>(),
                                        hO_p, susbits.as<u64>(), sustotal + 1);
-                    hipLaunchKernelGGL(k_popc_words64, dim3(grid_for(n_sc)), dim3(256), 0, st, susbits.as<u64>(), n_sc, susprefix.as<u32>());
-                    KERNEL_CHECK();
-                    SG_TRY(exclusive_scan_u32(susprefix.as<u32>(), susprefix.as<u32>(), n_sc, sustotal));
+                    if (n_sc <= POPC_SCAN_SMALL_MAX) SG_TRY(popc_scan_small(susbits.as<u64>(), n_sc, -1, susprefix.as<u32>(), sustotal));
+                    else {
+                        hipLaunchKernelGGL(k_popc_words64, dim3(grid_for(n_sc)), dim3(256), 0, st, susbits.as<u64>(), n_sc, susprefix.as<u32>());
+                        KERNEL_CHECK();
+                        SG_TRY(exclusive_scan_u32(susprefix.as<u32>(), susprefix.as<u32>(), n_sc, sustotal));
+                    }
                     // the compaction does not need the count: it is queued behind the count's way home and runs while the host waits for it (in
                     // the rare give-up case its output is simply overwritten)
                     u32 h_sus2[2] = {0, 0};
@@ -1949,7 +1961,9 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         ks = ks_sorted ? ks_sorted : (in_tmp ? keys2.as<u64>() : keys.as<u64>());
         is = packed ? nullptr : (in_tmp ? idx2.as<u32>() : idx.as<u32>());
         bool merges_found = false, patch_zeroed = false;               // lazy: dirtybits already filled by the fix-up passes
-        if (!(fix_bits < 64 && Tsort > 0 && lazy_a)) SG_TRY(zero_two(collision.p, 16, nullptr, 0));
+        // (no key has a partner — Tsort == 0 —: every term is a single, decided by k_mark_singles; the patch bitmap is zeroed in the same launch)
+        if (!(fix_bits < 64 && Tsort > 0 && lazy_a))
+            SG_TRY(zero_two(collision.p, 16, Tsort == 0 ? patchbits.p : nullptr, (size_t)((((squared && packed) ? Tk : T) + 63) / 64) * 8));
         if (fix_bits < 64 && Tsort > 0) {
             const i64 n_ch = (Tsort + 63) / 64;
             SG_TRY(fixlist.alloc((size_t)n_ch * 8 + 16));                         // one word of flags per 64 positions
@@ -1978,8 +1992,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             KERNEL_CHECK();
         }
         if (Tsort == 0) {
-            // nothing can merge (no key has a partner): every term is a single, decided by k_mark_singles
-            SG_TRY(zero_two(patchbits.p, (size_t)((((squared && packed) ? Tk : T) + 63) / 64) * 8, nullptr, 0));
+            // nothing can merge (no key has a partner): every term is a single, decided by k_mark_singles (patch bitmap zeroed above)
         } else {
             int G = 1;                                   // lanes per verified candidate: one 16-byte chunk each
             while (G < W / 2 && G < 64) G <<= 1;

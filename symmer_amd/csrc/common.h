@@ -199,6 +199,9 @@ int read_back_wait(ReadBack *rb, u32 *host_out);
 
 // sort.hip
 int exclusive_scan_u32(const u32 *in, u32 *out, i64 n, u32 *total_dev /* may be null: device u32 */);
+// bitmaps of up to POPC_SCAN_SMALL_MAX 64-bit words: out[w] = set bits in the words before w, *total_dev = all of them, one launch (n32: see sort.hip)
+constexpr i64 POPC_SCAN_SMALL_MAX = (i64)1 << 13;
+int popc_scan_small(const u64 *bits, i64 n, i64 n32, u32 *out, u32 *total_dev);
 // first_hist (optional, device, 256 * ceil(n / SORT_TILE) u32): the TILE-major ([tile][256]) tile histograms of the FIRST pass
 // (hist[tile * 256 + digit] = keys of tile `tile` whose bits [begin_bit, begin_bit + 8) equal `digit`), formed by a kernel of the
 // caller's that reads the keys anyway; the buffer then serves the later passes

@@ -140,6 +140,47 @@ __global__ __launch_bounds__(256) void k_scan_final(const u32 *__restrict__ in, 
     }
 }
 
+// Population counts of the 64-bit words of a bitmap and their exclusive prefix in ONE launch, for bitmaps of up to 2^13 words (512K bits):
+// the count kernel + the two scan kernels are 5 us each on an idle queue, which is most of a small product's prefix.  One workgroup of
+// 1,024 lanes, a lane takes up to eight consecutive words (loaded together).  n32 >= 0: the bitmap was written in 32-bit words, the upper
+// half of the last 64-bit word is unwritten when n32 is odd.
+__global__ __launch_bounds__(1024) void k_popc_scan_small(const u64 *__restrict__ bits, i64 n, i64 n32, u32 *__restrict__ out, u32 *__restrict__ total) {
+    __shared__ u32 s_wave[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 b0 = (i64)threadIdx.x * 8;
+    u32 cnt[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const i64 w = b0 + k;
+        u64 b = w < n ? bits[w] : 0ULL;
+        if (n32 >= 0 && w == n - 1 && (n32 & 1)) b &= 0xFFFFFFFFULL;
+        cnt[k] = (u32)__popcll(b);
+        sum += cnt[k];
+    }
+    const u32 incl = wave_incl_scan(sum, lane);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    u32 off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const u32 sv = s_wave[k];
+        if (k < wave) off += sv;
+        tot += sv;
+    }
+    u32 run = off + incl - sum;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (b0 + k < n) out[b0 + k] = run;
+        run += cnt[k];
+    }
+    if (threadIdx.x == 0 && total) *total = tot;
+}
+int popc_scan_small(const u64 *bits, i64 n, i64 n32, u32 *out, u32 *total_dev) {
+    hipLaunchKernelGGL(k_popc_scan_small, dim3(1), dim3(1024), 0, ctx().stream, bits, n, n32, out, total_dev);
+    KERNEL_CHECK();
+    return SYMGPU_OK;
+}
+
 // out may alias in.  total_dev (optional, device) receives the sum of all n inputs.
 int exclusive_scan_u32(const u32 *in, u32 *out, i64 n, u32 *total_dev) {
     Context &c = ctx();
