@@ -174,29 +174,36 @@ __device__ __forceinline__ u64 mix_word(u64 x, u32 w, u64 seed) {
     return ((u64)b << 32) | a;
 }
 __global__ __launch_bounds__(256) void k_hash_rows_mix(const u64 *__restrict__ rows, i64 T, int W, int G, u64 seed, u64 keep_mask, u64 *__restrict__ out1) {
+    // G lanes per row, a lane takes 16-byte chunks g, g + G, ... (W = 2 Wq is even: a row is a whole number of chunks)
     const int rows_per_block = 256 / G;
     const int g = threadIdx.x % G, rsub = threadIdx.x / G;
+    const int C = W / 2;                                             // chunks per row
+    const u32x4 *rows16 = reinterpret_cast<const u32x4 *>(rows);
     constexpr int HU = 4;                                           // row groups in flight per step
     for (i64 t0 = (i64)blockIdx.x * rows_per_block * HU; t0 < T; t0 += (i64)gridDim.x * rows_per_block * HU) {
         u64 h[HU];
 #pragma unroll
         for (int u = 0; u < HU; ++u) h[u] = 0;
-        for (int w0 = 0; w0 < W; w0 += 2 * G) {                      // two words per lane and step (rows of up to 128 words: one step)
-            u64 x[2][HU];
+        for (int c0 = 0; c0 < C; c0 += 2 * G) {                      // two chunks per lane and step (rows of up to 256 words: one step)
+            u32x4 x[2][HU];
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
                 for (int u = 0; u < HU; ++u) {
                     const i64 t = t0 + (i64)u * rows_per_block + rsub;
-                    const int w = w0 + k * G + g;
-                    x[k][u] = (t < T && w < W) ? rows[t * W + w] : 0ULL;
+                    const int c = c0 + k * G + g;
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    x[k][u] = (t < T && c < C) ? rows16[t * C + c] : z;
                 }
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
                 for (int u = 0; u < HU; ++u) {
-                    const int w = w0 + k * G + g;
-                    if (w < W) h[u] ^= mix_word(x[k][u], (u32)w, seed);
+                    const int c = c0 + k * G + g;
+                    if (c < C) {
+                        h[u] ^= mix_word(((u64)x[k][u].y << 32) | x[k][u].x, (u32)(2 * c), seed);
+                        h[u] ^= mix_word(((u64)x[k][u].w << 32) | x[k][u].z, (u32)(2 * c + 1), seed);
+                    }
                 }
         }
 #pragma unroll
@@ -1222,7 +1229,7 @@ int hash_rows_any(const u64 *rows, i64 T, int W, u64 seed, u64 *out1) {
     u64 keep = ~0ULL;
     if (const char *e = getenv("SYMGPU_HASH_WEAK_ODD"))             // the tables' test hook: an odd seed keeps 4 bits, so rows collide in bulk
         if (e[0] == '1' && (seed & 1)) keep = 0xF000000000000000ULL;
-    const int G = pow2_group(W);
+    const int G = pow2_group(W / 2);                                // lanes per row: one 16-byte chunk each (rows of up to 128 words)
     const int rpb = 4 * (256 / G);
     i64 g = (T + rpb - 1) / rpb;
     if (g > 4096) g = 4096;
