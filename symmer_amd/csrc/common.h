@@ -85,6 +85,8 @@ struct Context {
     u32 *sort_state = nullptr;     // one-launch radix sort (sort.hip): barrier counter, time-out flag, tile histograms
     u32 sort_bar_base = 0;
     bool sort_coop_disabled = false;
+    u32 *m7_flags = nullptr;       // stream-K commutation kernel (commute_m4r7.hip): per-workgroup words compared with the launch's epoch
+    u32 m7_epoch = 0;
     u32 *sort_scan_ticket = nullptr;   // radix sort: "last workgroup finishes the scan" ticket, zero between launches
     bool res_disabled = false;     // a barrier timed out once (workgroups not co-resident): the process keeps to the multi-launch paths
     u32 res_finished_base = 0, res_host_tag = 0;   // one-launch rotation: arrival counter base of the next launch, tag of its report

@@ -9,7 +9,8 @@
 // XOR-combinations of the group's bit-rows of the (bit-transposed, X/Z-swapped) right operand in LDS, and a row of A then needs ONE
 // ds_read_b128 per lane and group (a wave instruction serves 4 rows x 2048 columns) — 1/13 of the VALU work per pair.
 // Rounds 2-4 used one 256-entry table (8 bits, 64 KiB) per step: 40.1 ms for the 200,000^2 adjacency matrix of cfg5, its look-up stream
-// VALU bound at 5 instructions per read.  Round 5 (commute_m4r7.hip): two 128-entry tables per step folded with v_bitop3, 36.1 ms.
+// VALU bound at 5 instructions per read.  Round 5 (commute_m4r7.hip): two 128-entry tables per step folded with v_bitop3, 36.1 ms; round 6:
+// persistent workgroups over the (tile, step) space, 31.2 ms.
 //
 //   BT[c][jw]   bit c of B rows 64jw..64jw+63 (bit-major copy, cached on the operator); row c of the contraction pairs A bit c with B bit
 //               c +- 64Wq (x with z', z with x'), which is just a row offset into BT.
@@ -76,8 +77,9 @@ __global__ __launch_bounds__(256) void k_bits_to_bytes(const u64 *__restrict__ b
 
 static i64 round_up_i64(i64 x, i64 m) { return (x + m - 1) / m * m; }
 
-// tile heights: R rows per 16-lane slot -> 32 R rows per workgroup.  Taller tiles amortise the tables over more rows (200,000^2 terms at
-// n = 2000: R = 16 / 24 / 40 / 48 -> 60.0 / 50.8 / 38.1 / 36.1 ms) but need enough workgroups for 256 CUs.  SYMGPU_M4R_R forces one (tests).
+// tile heights: R rows per 16-lane slot -> 32 R rows per workgroup.  Taller tiles amortise the tables over more rows (round 5, 200,000^2
+// terms at n = 2000: R = 16 / 24 / 48 -> 60.0 / 50.8 / 36.1 ms); the stream-K launch (commute_m4r7.hip) balances any tile count over the
+// CUs, so the tallest height with at least one tile per CU is taken.  SYMGPU_M4R_R forces one (tests).
 static i64 m4r_workgroups(i64 N, i64 M, int R) {
     const i64 Mw = (M + 63) / 64;
     return ((N + 32 * R - 1) / (32 * R)) * ((Mw + MK_TILE_W - 1) / MK_TILE_W);
@@ -85,11 +87,11 @@ static i64 m4r_workgroups(i64 N, i64 M, int R) {
 static int m4r_pick(i64 N, i64 M) {
     if (const char *e = getenv("SYMGPU_M4R_R")) {
         const int r = atoi(e);
-        if (r == 16 || r == 24 || r == 40 || r == 48) return r;
+        if (r == 16 || r == 24 || r == 48) return r;
     }
-    const int cand[3] = {48, 40, 24};
+    const int cand[2] = {48, 24};
     for (int R : cand)
-        if (m4r_workgroups(N, M, R) >= 3 * ctx().num_cu) return R;
+        if (m4r_workgroups(N, M, R) >= ctx().num_cu) return R;
     return 16;
 }
 // enough 512 x 2048 tiles to occupy most of the chip (below that the register-tile kernel wins: 1024 x 16384 at n = 2000 takes

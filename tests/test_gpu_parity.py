@@ -1040,17 +1040,58 @@ def test_commutes_both_kernels(n, N, M, dens, force, monkeypatch):
 
 
 @pytest.mark.parametrize('M', [4208, 4200])
-@pytest.mark.parametrize('r', ['16', '24', '40', '48'])
+@pytest.mark.parametrize('r', ['16', '24', '48'])
 def test_commutes_m4r_tile_heights(r, M, monkeypatch):
     """Every instantiation of the Four-Russians kernel (rows per 16-lane slot; two 7-bit tables per step, csrc/commute_m4r7.hip) on a shape that
-    leaves partial row and column tiles; M = 4208 takes the fused byte-expanding epilogue (16-byte stores), M = 4200 the
-    bit-packed rows + separate expansion."""
+    leaves partial row and column tiles (fewer tiles than compute units: one tile per workgroup); M = 4208 takes the fused byte-expanding
+    epilogue (16-byte stores), M = 4200 the bit-packed rows + separate expansion."""
     monkeypatch.setenv('SYMGPU_COMMUTE_M4R', '1'); monkeypatch.setenv('SYMGPU_M4R_R', r)
     rng = np.random.default_rng(77)
     n, N = 200, 1500
     a = packing.pack_rows(rng.random((N, 2 * n)) < 0.3); b = packing.pack_rows(rng.random((M, 2 * n)) < 0.3)
     expect = oc.commutes(a, b)
     assert np.array_equal(kernels.commutes(a, b), expect)
+
+
+_STREAMK_EXPECT = {}
+
+
+@pytest.mark.parametrize('mode', ['stream', 'fixup', 'one_tile_per_workgroup'])
+@pytest.mark.parametrize('M', [32752, 32750])
+@pytest.mark.parametrize('r', ['16', '24', '48'])
+def test_commutes_m4r_stream_k(r, M, mode, monkeypatch):
+    """The stream-K launch of the Four-Russians kernel (csrc/commute_m4r7.hip): 17 row tiles x 16 column tiles = 272 tiles for the 256
+    persistent workgroups, so every workgroup's range starts and ends inside a tile; ragged last row and column tiles; M = 32752 the
+    byte epilogue, M = 32750 bit-packed rows + expansion.  `stream`: a split tile is finished by the owner of its first steps from
+    the neighbour's published part; `fixup` (SYMGPU_M4R_FIXUP=1): both parts go to scratch and k_m7_fixup writes the tile — the path
+    of a neighbour that has not run yet; `one_tile_per_workgroup` (SYMGPU_M4R_STREAM=0): what fewer tiles than CUs take."""
+    monkeypatch.setenv('SYMGPU_COMMUTE_M4R', '1'); monkeypatch.setenv('SYMGPU_M4R_R', r)
+    if mode == 'fixup':
+        monkeypatch.setenv('SYMGPU_M4R_FIXUP', '1')
+    if mode == 'one_tile_per_workgroup':
+        monkeypatch.setenv('SYMGPU_M4R_STREAM', '0')
+    n = 100
+    N = 32 * int(r) * 17 - 37
+    key = (N, M)
+    if key not in _STREAMK_EXPECT:
+        _STREAMK_EXPECT.clear()                                       # one table at a time: up to 0.85 GB each
+        rng = np.random.default_rng(78)
+        a = packing.pack_rows(rng.random((N, 2 * n)) < 0.3); b = packing.pack_rows(rng.random((M, 2 * n)) < 0.3)
+        a[5] = 0                                                      # an identity row
+        _STREAMK_EXPECT[key] = (a, b, oc.commutes(a, b))
+    a, b, expect = _STREAMK_EXPECT[key]
+    got = kernels.commutes(a, b)
+    assert got.shape == expect.shape and np.array_equal(got, expect)
+
+
+def test_commutes_m4r_all_identity_left_operand(monkeypatch):
+    """An all-identity left operand has no non-zero 7-bit group: the kernel runs one step on the zero group and everything commutes."""
+    monkeypatch.setenv('SYMGPU_COMMUTE_M4R', '1')
+    rng = np.random.default_rng(79)
+    a = np.zeros((8704, 4), dtype='<u8'); b = packing.pack_rows(rng.random((32768, 200)) < 0.3)
+    assert kernels.commutes(a, b).all()
+    monkeypatch.setenv('SYMGPU_M4R_R', '16')
+    assert kernels.commutes(a[:600], b[:4096]).all()
 
 
 @pytest.mark.parametrize('case', family('jordan'))
