@@ -43,7 +43,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-PROFILE_TAG = 'r05'                     # profiles/<tag>_*: the round whose rocprofv3 summaries belong to this bench.py
+API_LEGEND = ('api objects: first_call = fresh host arrays in (upload included); a = operands resident, result object out (left on the GPU); '
+              'b = a + result host arrays out; c_abi = the device-resident C-ABI step of the same line')
+PROFILE_TAG = 'r06'                     # profiles/<tag>_*: the round whose rocprofv3 summaries belong to this bench.py
 TRAFFIC_PROFILE = f'{PROFILE_TAG}_traffic.json'   # written by tools/pmc_product.sh from the rocprofv3 --pmc passes of this bench
 
 
@@ -70,6 +72,8 @@ def parse():
     ap.add_argument('--no-api', action='store_true', help='skip the `api` objects (the reference\'s call spelling timed on the drop-in classes)')
     ap.add_argument('--cpu-full', action='store_true', help='gf2: time the CPU restatement on the full 4000 x 54000 matrix (~70 s) instead of citing the cached run')
     args = ap.parse_args()
+    if os.environ.get('BENCH_CPU_FULL', '0') == '1':
+        args.cpu_full = True                                      # the driver passes no flags: the environment switches the full-size CPU leg on
     # a millisecond-scale step needs more than three of them for a stable figure (clocks, allocator): mul_cleanup 20 + 3, gf2 10 + 2
     d_steps, d_warm = {'mul_cleanup': (20, 3), 'gf2': (10, 2)}.get(args.workload, (3, 1))
     if args.steps is None: args.steps = d_steps
@@ -87,7 +91,7 @@ def main():
     if world == 1 and (args.single_process or (args.gpus > 1 and 'WORLD_SIZE' not in os.environ)):
         # no launcher: ONE process drives all devices — same workload, same contract line
         out = single_process_product(args)
-        print(json.dumps(out))
+        emit(out)
         return
 
     from symmer_amd import _lib, kernels
@@ -106,7 +110,7 @@ def main():
         comm.close()
         if rank == 0:
             out['degraded_kernels'] = _lib.degraded()     # fast paths that gave up in this process (in-kernel wait timed out): [] on a healthy box
-            print(json.dumps(out))
+            emit(out)
         comm.hard_exit_if_hung()
         return
 
@@ -262,7 +266,7 @@ def main():
     comm.close()
     if rank == 0:
         out['degraded_kernels'] = _lib.degraded()         # fast paths that gave up in this process (in-kernel wait timed out): [] on a healthy box
-        print(json.dumps(out))
+        emit(out)
     comm.hard_exit_if_hung()
 
 
@@ -347,6 +351,79 @@ def single_process_product(args):
         except Exception as exc:                                      # noqa: BLE001
             out['cpu_baseline'] = {'error': f'{type(exc).__name__}: {exc}'}
     return out
+
+
+def _sig(x, digits=4):
+    """A number with `digits` significant figures (the summary has to stay short), None as it is."""
+    if x is None or isinstance(x, (str, bool)):
+        return x
+    try:
+        return float(f'{float(x):.{digits}g}')
+    except (TypeError, ValueError):
+        return None
+
+
+def _roof(r):
+    return [r.get('kernel'), _sig(r.get('frac'), 3)] if isinstance(r, dict) else None
+
+
+def _api(a):
+    return [_sig(a.get('a_result_object_seconds')), _sig(a.get('b_host_arrays_out_seconds'))] if isinstance(a, dict) and 'a_result_object_seconds' in a else None
+
+
+def summary_of(out):
+    """Every config's figure in one compact object, printed LAST in the line: the driver keeps the tail of stdout, and the line is > 8 KB.
+    Per entry: v = value, u = unit, s = seconds per step (C ABI, operands resident), k = [dominant kernel, roofline fraction], api = [a, b]
+    seconds (see `api_legend`), cpu = the CPU baseline's value in the same unit."""
+    ex = out.get('extras') if isinstance(out.get('extras'), dict) else {}
+    cpu = out.get('cpu_baseline') if isinstance(out.get('cpu_baseline'), dict) else {}
+    oc_ = cpu.get('other_configs', {}) if isinstance(cpu.get('other_configs'), dict) else {}
+    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    sm = {'legend': 'v value, u unit, s seconds/step, k [kernel, roofline frac], api [a, b] seconds, cpu = CPU baseline in u'}
+    if out.get('config', {}).get('workload') == 'allpairs_product':
+        sm['product_1e5x1e5'] = {'v': _sig(out.get('value')), 'u': 'pairs/s', 's': _sig(out.get('ms_per_step', 0) * 1e-3), 'k': _roof(out.get('roofline')),
+                                 'cpu': _sig(cpu.get('value'))}
+    else:
+        sm[out.get('config', {}).get('workload', 'workload')] = {'v': _sig(out.get('value')), 'u': out.get('unit'), 's': _sig(out.get('ms_per_step', 0) * 1e-3),
+                                                                  'k': _roof(out.get('roofline')), 'api': _api(out.get('api')) or _api(g(out, 'api', 'full')),
+                                                                  'cpu': _sig(g(out, 'cpu_baseline', 'value'))}
+        if g(out, 'roofline', 'lds', 'frac') is not None:
+            sm[out['config']['workload']]['lds_frac'] = _sig(g(out, 'roofline', 'lds', 'frac'), 3)
+    c1, c2, c3, c4, c5, ss = (ex.get(k) for k in ('cfg1_api_mul', 'cfg2_rotation', 'cfg3_mul_cleanup', 'cfg4_symmetry_kernel', 'cfg5_adjacency', 'strong_scaling_shard'))
+    if isinstance(c1, dict) and 'error' not in c1:
+        sm['cfg1_mul_500t_100q'] = {'v': _sig(c1.get('pairs_per_s')), 'u': 'pairs/s', 's': _sig(c1.get('seconds')), 'api': _api(c1.get('api')),
+                                    'cpu': _sig(g(oc_, 'cfg1_mul_cleanup', 'pairs_per_s'))}
+    if isinstance(c2, dict) and 'error' not in c2:
+        sm['cfg2_rotation'] = {'v': _sig(c2.get('term_pairs_per_s')), 'u': 'term-pairs/s', 's': _sig(c2.get('seconds_per_rotation')), 'k': _roof(c2.get('roofline')),
+                               'api': _api(c2.get('api')), 'cpu': _sig(g(oc_, 'cfg2_rotation', 'term_pairs_per_s')),
+                               'clifford_s': _sig(g(c2, 'clifford', 'seconds_per_rotation')), 'saturated_chain_s': _sig(g(c2, 'saturated_chain', 'seconds_per_rotation'))}
+    if isinstance(c3, dict) and 'error' not in c3:
+        sm['cfg3_mul_cleanup'] = {'v': _sig(c3.get('pairs_per_s')), 'u': 'pairs/s', 's': _sig(c3.get('seconds')), 'k': _roof(c3.get('roofline')),
+                                  'api': _api(c3.get('api')), 'cpu': _sig(g(oc_, 'cfg3_sample_mul_cleanup', 'pairs_per_s'))}
+    if isinstance(c4, dict) and 'error' not in c4:
+        sm['cfg4_gf2'] = {'v': _sig(c4.get('row_xors_per_s')), 'u': 'row-XORs/s', 's': _sig(c4.get('seconds')), 'k': _roof(c4.get('roofline')),
+                          'api': _api(c4.get('api')), 'cpu': _sig(g(oc_, 'cfg4_full_size_cached', 'row_xors_per_s') or g(oc_, 'cfg4_sample_rref', 'row_xors_per_s'))}
+    if isinstance(c5, dict) and 'error' not in c5:
+        rs = c5.get('rank_share_25000_rows') or {}
+        sm['cfg5_adjacency'] = {'v': _sig(c5.get('pairs_per_s')), 'u': 'pairs/s', 's': _sig(c5.get('seconds')), 'k': _roof(c5.get('roofline')),
+                                'lds_frac': _sig(g(c5, 'roofline', 'lds', 'frac'), 3), 'api_full': _api(g(c5, 'api', 'full')), 'api_share': _api(g(c5, 'api', 'rank_share')),
+                                'cpu': _sig(g(oc_, 'cfg5_sample_commutation', 'pairs_per_s')),
+                                'rank_share_s': _sig(rs.get('seconds')), 'predicted_8gpu_x': _sig(rs.get('predicted_8gpu_strong_speedup_before_allgather'), 3)}
+    if isinstance(ss, dict) and 'error' not in ss:
+        sm['strong_scaling_shard'] = {'s': _sig(ss.get('ms_per_step', 0) * 1e-3), 'k': _roof(ss.get('roofline')),
+                                      'predicted_8gpu_x': _sig(ss.get('predicted_8gpu_strong_speedup_before_allgather'), 3)}
+    errs = [k for k, v in ex.items() if isinstance(v, dict) and 'error' in v]
+    if errs:
+        sm['failed_sections'] = errs
+    return sm
+
+
+def emit(out):
+    """The ONE JSON line: `api_legend` once, `summary` last (the last 4 KB of stdout carry every config's figure)."""
+    out.pop('summary', None)
+    out['api_legend'] = API_LEGEND
+    out['summary'] = summary_of(out)
+    print(json.dumps(out))
 
 
 def collective_hang(exc, args, rank, world):
@@ -447,7 +524,7 @@ def wl_mul_cleanup(args, comm, rank, world, _lib, DeviceOp, parallel):
             'frac': launch_bytes / kt / 1e9 / HBM_PEAK_GBS if kt else None, 'traffic': None, 'launches': nl, 'avg_launch_ms': kt * 1e3,
             'algorithmic_bytes_per_launch': launch_bytes,
             'note': 'output stage of the cleanup in one launch: 16*Wq + 16 bytes per kept row, written once (non-temporal stores), rows '
-                    'gathered from the L2-resident operand; the other kernels of the step are key generation, the partial radix sort (3 of 4 '
+                    'gathered from the L2-resident operand; the other kernels of the step are key generation, the partial radix sort (2 of 4 '
                     f'8-bit passes), the marking of single keys and the suspect search — profiles/{PROFILE_TAG}_cfg3_kernel_trace.txt',
             'whole_step': {'survey_8d_algorithmic_bytes': algo_step, 'algorithmic_GBps': algo_step / (dt / args.steps) / 1e9,
                            'physical_write_floor_ms': n_out[0] * (row_bytes + 16) / (HBM_PEAK_GBS * 1e9) * 1e3,
@@ -550,6 +627,37 @@ def wl_rotation(args, comm, rank, world, _lib, DeviceOp, parallel):
             Pc.free()
             return res
         out['clifford'] = guarded(clifford)
+
+        def saturated_chain():
+            # SURVEY 8d cfg2 asks for the per-rotation time over a CHAIN of >= 100 rotations.  A chain of non-Clifford rotations by random
+            # Paulis grows the operator 1.5x per step; the realistic chain (Trotter circuits, symmer/evolution/exponentiation.py:26-38) cycles
+            # through a fixed set of generators, under which the term set saturates: 400 seed terms x the 2^8 products of 8 generators.
+            # Every rotation then MERGES (each anticommuting term's partner P.Q is already there): the term count stays constant.
+            seed_op = DeviceOp.random(400, n, 0.3, seed=4242)
+            cur, counts = seed_op, []
+            for k in range(8 * 14):                                  # to the fixed point (the count stops growing after a few cycles)
+                nxt = kernels.rotate_single_dev(cur, qs[k % 8], 0.3)[0]
+                cur.free(); cur = nxt
+                counts.append(cur.n_terms)
+                if k % 8 == 7 and len(counts) > 8 and counts[-1] == counts[-9]:
+                    break
+            sat_terms, cycles = cur.n_terms, len(counts) // 8
+            reps = 104
+            for k in range(16):                                       # warm: allocator classes, join tables of this size
+                nxt = kernels.rotate_single_dev(cur, qs[k % 8], 0.3)[0]; cur.free(); cur = nxt
+            kernels.sync()
+            t0 = time.perf_counter()
+            for k in range(reps):
+                nxt = kernels.rotate_single_dev(cur, qs[k % 8], 0.3)[0]; cur.free(); cur = nxt
+            kernels.sync()
+            t = (time.perf_counter() - t0) / reps
+            end_terms = cur.n_terms
+            cur.free()
+            return {'generators': 8, 'seed_terms': 400, 'saturated_terms': sat_terms, 'cycles_to_saturation': cycles, 'timed_rotations': reps, 'terms_after': end_terms,
+                    'seconds_per_rotation': t, 'term_pairs_per_s': sat_terms / t, 'angle': 0.3,
+                    'call': 'cur = rotate(cur, Q_{k mod 8}, 0.3) 104 times on the saturated operator (kernels.rotate_single_dev: one C-ABI call per rotation, '
+                            'device resident; every rotation merges rows, the term count is constant)'}
+        out['saturated_chain'] = guarded(saturated_chain)
     P.free()
     if rank == 0 and not getattr(args, 'no_api', False):
         from symmer_amd import PauliwordOp
@@ -682,9 +790,7 @@ def api_block(spelling, make, call, fetch, reps, c_abi_seconds, note=None):
         del r
     med = lambda v: sorted(v)[len(v) // 2]
     out = {'call': spelling, 'first_call_seconds': first, 'a_result_object_seconds': med(ta), 'b_host_arrays_out_seconds': med(tb),
-           'c_abi_seconds': c_abi_seconds, 'a_over_c_abi': med(ta) / c_abi_seconds if c_abi_seconds else None, 'reps': reps,
-           'legend': 'first_call: fresh host arrays in (upload included); a: operands resident, result object out (left on the GPU); '
-                     'b: a + result host arrays out; c_abi: the device-resident C-ABI step of this line'}
+           'c_abi_seconds': c_abi_seconds, 'a_over_c_abi': med(ta) / c_abi_seconds if c_abi_seconds else None, 'reps': reps}   # (legend: top-level `api_legend`)
     if note:
         out['note'] = note
     return out
@@ -799,11 +905,12 @@ def adjacency(args, comm, rank, world, _lib, DeviceOp, parallel):
                       'parallelism': (f'left-axis shard x{world}, all-gather of right rows ({comm.data_plane})' if world > 1 else 'single GPU')},
            # the contract's roofline object is HBM-side (1 B/pair np.bool_ output); the kernel itself is bound by the LDS table
            # reads of the Four-Russians product, reported next to it
-           'roofline': {'bound': 'hbm', 'kernel': 'k_commutes_m4r', 'achieved': launch_rows * T / kt / 1e9 if kt else None, 'peak': HBM_PEAK_GBS,
+           'roofline': {'bound': 'hbm', 'kernel': 'k_commutes_m4r7s', 'achieved': launch_rows * T / kt / 1e9 if kt else None, 'peak': HBM_PEAK_GBS,
                         'unit': 'GB/s', 'frac': launch_rows * T / kt / 1e9 / HBM_PEAK_GBS if kt else None, 'traffic': None,
                         'launches': nl.value, 'avg_launch_ms': kt * 1e3,
                         'note': 'not HBM-bound: Four-Russians GF(2) product, one 256-byte LDS table entry per row, 7-bit group and 2048-column tile; two '
-                                'tables per step folded with v_bitop3 (csrc/commute_m4r7.hip)',
+                                'tables per step folded with v_bitop3, persistent workgroups over the (tile, step) space (csrc/commute_m4r7.hip); '
+                                'the events cover the main launch and the (usually empty) fix-up launch behind it',
                         'lds': {'achieved_GBps': lds_bytes / kt / 1e9 if kt else None, 'peak_GBps': 157286.4,
                                 'frac': lds_bytes / kt / 1e9 / 157286.4 if kt else None,
                                 'peak_source': '256 CUs x 256 B/clk (ds_read_b128) x 2.4 GHz, MI355X_MICROARCH.md LDS table'}}}
@@ -993,7 +1100,8 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
         P.free()
         ex['cfg2_rotation'] = {'terms_in': 100000, 'seconds_per_rotation': line['seconds_per_rotation'], 'term_pairs_per_s': line['value'],
                                'first_rotation_seconds': t1, 'first_rotation_note': 'through kernels.rotate_single_dev (Python wrapper + handle free per call), 20 calls back to back',
-                               'roofline': line['roofline'], 'api': line.get('api'), 'api_perform_rotations': line.get('api_perform_rotations'), 'chain4_seconds': t_chain, 'chain_terms': terms, 'clifford': line.get('clifford')}
+                               'roofline': line['roofline'], 'api': line.get('api'), 'api_perform_rotations': line.get('api_perform_rotations'), 'chain4_seconds': t_chain, 'chain_terms': terms, 'clifford': line.get('clifford'),
+                               'saturated_chain': line.get('saturated_chain')}
         # README claim 1 (a depth-2,000 Clifford circuit on 1,000 qubits "in one second"): 2,000 Clifford rotations of a 64-term,
         # 1,000-qubit observable through perform_rotations — one single-workgroup launch for the whole run (rotate.hip)
         rng_c = np.random.default_rng(1240)
@@ -1025,7 +1133,7 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
         lds_bytes = nrow * n_kblocks * col_tiles * 256.0
         full_s = line['ms_per_step'] * 1e-3
         ex['cfg5_adjacency'] = {'pairs': 200000 ** 2, 'seconds': full_s, 'pairs_per_s': line['value'], 'roofline': line['roofline'], 'api': line.get('api'),
-                                'rank_share_25000_rows': {'pairs': pairs, 'seconds': t, 'pairs_per_s': pairs / t, 'kernel': 'k_commutes_m4r', 'kernel_seconds': kt,
+                                'rank_share_25000_rows': {'pairs': pairs, 'seconds': t, 'pairs_per_s': pairs / t, 'kernel': 'k_commutes_m4r7s', 'kernel_seconds': kt,
                                                           'hbm_GBps_at_1B_per_pair': pairs / kt / 1e9 if kt else None,
                                                           'lds_read_frac_of_157TBps': lds_bytes / kt / 157.3e12 if kt else None,
                                                           'predicted_8gpu_strong_speedup_before_allgather': full_s / t}}

@@ -169,7 +169,6 @@ struct symgpu_op_s {
     // for free (h(P ^ Q) = h(P) ^ h(Q)), so a chain of rotations hashes the operator once.  Dropped by op_invalidate.
     u64 *hash = nullptr;
     u64 hash_seed = 0;
-    std::vector<u64> host_hash_tab;  // host copy of hash_tab (to hash single rows, e.g. a rotation's Q, with the SAME device's tables)
     // cached bit-major copy of rows[0..T) for the Four-Russians commutation kernel (commute_m4r.hip): bt[c][jw], bt_pad words per
     // bit-row; valid while bt_T == T.  An adjacency matrix computed slab by slab transposes its right operand once.
     u64 *bt = nullptr;

@@ -442,28 +442,71 @@ __global__ __launch_bounds__(256) void k_probe_copy(const u32x4p *in, u32x4p *ou
 // Large device -> host copies into FRESH pageable memory (np.empty) are bound by first-touch page faults taken inside the
 // runtime's pinning path: 9-18 GB/s, against 43-55 GB/s once the pages exist (tools/ubench_d2h.hip, MI355X box).  Touch the
 // destination pages first, from a few threads; the copy overwrites the whole range anyway.
+static void touch_pages(char *base, size_t lo, size_t hi) {
+    for (size_t o = lo; o < hi; o += 4096) reinterpret_cast<volatile char *>(base)[o] = 0;
+    if (hi > lo) reinterpret_cast<volatile char *>(base)[hi - 1] = 0;
+}
+
+static int prefault_threads() {
+    const unsigned hw = std::thread::hardware_concurrency();
+    return hw >= 16 ? 8 : (hw >= 4 ? 4 : 1);
+}
+
+// first touch of [lo, hi) of a large D2H destination from several threads (the runtime's own pinning path takes the first-touch faults
+// at 9-18 GB/s, tools/ubench_d2h.hip); the workers are returned running, the caller joins them
+static std::vector<std::thread> prefault_start(char *base, size_t lo, size_t hi) {
+    std::vector<std::thread> workers;
+    const size_t page = 4096;
+    const int n_threads = prefault_threads();
+    const size_t chunk = ((hi - lo) / n_threads + page - 1) / page * page;
+    for (int k = 0; k < n_threads && chunk; ++k) {
+        const size_t a = lo + (size_t)k * chunk, b = a + chunk < hi ? a + chunk : hi;
+        if (a >= b) break;
+        workers.emplace_back(touch_pages, base, a, b);
+    }
+    return workers;
+}
+
+static void ask_for_huge_pages(void *dst, size_t bytes) {
+    // transparent huge pages on the page-aligned interior (honoured where THP is 'always' or 'madvise'): 512x fewer faults
+    const size_t page = 4096;
+    const uintptr_t a = (reinterpret_cast<uintptr_t>(dst) + page - 1) & ~(uintptr_t)(page - 1);
+    const uintptr_t b = (reinterpret_cast<uintptr_t>(dst) + bytes) & ~(uintptr_t)(page - 1);
+    if (b > a) (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_HUGEPAGE);
+}
+
 void prefault_host(void *dst, size_t bytes) {
     if (!dst || bytes < ((size_t)64 << 20)) return;
-    const size_t page = 4096;
-    {   // ask for transparent huge pages on the page-aligned interior (honoured where THP is 'always' or 'madvise'): 512x fewer faults
-        const uintptr_t a = (reinterpret_cast<uintptr_t>(dst) + page - 1) & ~(uintptr_t)(page - 1);
-        const uintptr_t b = (reinterpret_cast<uintptr_t>(dst) + bytes) & ~(uintptr_t)(page - 1);
-        if (b > a) (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_HUGEPAGE);
+    ask_for_huge_pages(dst, bytes);
+    for (auto &w : prefault_start(static_cast<char *>(dst), 0, bytes)) w.join();
+}
+
+// A large device-to-host copy into pageable memory, in pieces: while piece k travels (the copy call blocks its thread) the pages of
+// piece k + 1 are touched by the worker threads, so the first-touch faults of a fresh destination (a 40 GB commutation table: ~0.2 s) hide
+// behind the PCIe transfer; the first piece is touched while the kernels queued ahead of the copy are still running.
+static int download_pipelined(const char *dev, char *host, size_t bytes) {
+    const size_t piece = (size_t)1 << 30;
+    ask_for_huge_pages(host, bytes);
+    for (auto &w : prefault_start(host, 0, piece < bytes ? piece : bytes)) w.join();
+    for (size_t off = 0; off < bytes; off += piece) {
+        const size_t n = bytes - off < piece ? bytes - off : piece;
+        std::vector<std::thread> next;
+        if (off + piece < bytes) next = prefault_start(host, off + piece, off + 2 * piece < bytes ? off + 2 * piece : bytes);
+        const hipError_t e1 = hipMemcpyAsync(host + off, dev + off, n, hipMemcpyDeviceToHost, ctx().stream);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamSynchronize(ctx().stream) : e1;
+        for (auto &w : next) w.join();
+        HIP_TRY(e2);
     }
-    unsigned hw = std::thread::hardware_concurrency();
-    const int n_threads = hw >= 16 ? 8 : (hw >= 4 ? 4 : 1);
-    char *base = static_cast<char *>(dst);
-    const size_t chunk = (bytes / n_threads + page - 1) / page * page;
-    std::vector<std::thread> workers;
-    for (int k = 0; k < n_threads; ++k) {
-        const size_t lo = (size_t)k * chunk, hi = lo + chunk < bytes ? lo + chunk : bytes;
-        if (lo >= hi) break;
-        workers.emplace_back([base, lo, hi] {
-            for (size_t o = lo; o < hi; o += 4096) reinterpret_cast<volatile char *>(base)[o] = 0;
-            reinterpret_cast<volatile char *>(base)[hi - 1] = 0;
-        });
-    }
-    for (auto &w : workers) w.join();
+    return SYMGPU_OK;
+}
+
+// device -> pageable host memory, any size: small copies as one call, large ones pipelined (see above); returns with the data on the host
+static int download_any(const void *dev, void *host, size_t bytes) {
+    if (bytes >= ((size_t)2 << 30)) return download_pipelined(static_cast<const char *>(dev), static_cast<char *>(host), bytes);
+    prefault_host(host, bytes);
+    HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx().stream));
+    HIP_TRY(hipStreamSynchronize(ctx().stream));
+    return SYMGPU_OK;
 }
 
 // ---- a few words back to the host in the middle of a call ---------------------------------------------------------------------------
@@ -817,9 +860,7 @@ int symgpu_dev_free(void *ptr) { return dev_free(ptr); }
 int symgpu_dev_download(const void *dev, void *host, int64_t bytes) {
     SG_TRY(require_ctx());
     SG_REQUIRE(dev && host && bytes >= 0, "dev_download");
-    prefault_host(host, (size_t)bytes);
-    HIP_TRY(hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx().stream));
-    HIP_TRY(hipStreamSynchronize(ctx().stream));
+    SG_TRY(download_any(dev, host, (size_t)bytes));
     count_d2h((size_t)bytes);
     return SYMGPU_OK;
 }
@@ -966,8 +1007,7 @@ int symgpu_op_download(symgpu_op_t op, uint64_t *rows, double *coeff, int64_t ca
     }
     if (op->T > 0) {
         if (rows) {
-            prefault_host(rows, (size_t)op->T * 2 * op->Wq * sizeof(u64));
-            HIP_TRY(hipMemcpyAsync(rows, op->rows, (size_t)op->T * 2 * op->Wq * sizeof(u64), hipMemcpyDeviceToHost, ctx().stream));
+            SG_TRY(download_any(op->rows, rows, (size_t)op->T * 2 * op->Wq * sizeof(u64)));
             count_d2h((size_t)op->T * 2 * op->Wq * sizeof(u64));
         }
         if (coeff) {
@@ -1085,9 +1125,7 @@ int symgpu_op_download_bool(symgpu_op_t op, int n_qubits, uint8_t *symp_out, int
     const unsigned grid = (unsigned)((n_words + 3) / 4 < 65536 * 16 ? (n_words + 3) / 4 : 65536 * 16);
     hipLaunchKernelGGL(k_unpack_bool, dim3(grid), dim3(256), 0, ctx().stream, op->rows, op->T, n_qubits, op->Wq, stage.as<uint8_t>());
     KERNEL_CHECK();
-    prefault_host(symp_out, nb);
-    HIP_TRY(hipMemcpyAsync(symp_out, stage.p, nb, hipMemcpyDeviceToHost, ctx().stream));
-    HIP_TRY(hipStreamSynchronize(ctx().stream));
+    SG_TRY(download_any(stage.p, symp_out, nb));
     count_d2h(nb);
     ++g_counters[10];
     return SYMGPU_OK;

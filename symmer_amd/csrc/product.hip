@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
 // RCT = 16-byte chunks per lane, NT = non-temporal stores, rto = outer rows per block (runtime).
 template <int RCT, bool NT>
 __global__ __launch_bounds__(1024) void k_mul_rows(const u32x4 *__restrict__ inner, i64 n_chunks, const u32x4 *__restrict__ outer,
-                                                    int Wq, i64 o_count, u32x4 *__restrict__ out, int rto) {
+                                                    int Wq, i64 o_count, u32x4 *__restrict__ out, int rto, i64 out_stride) {
     const int BT = blockDim.x;                                      // 256 (default) .. 1024 threads: BT * 16 contiguous bytes per row
     const i64 c0 = (i64)blockIdx.x * (BT * RCT) + threadIdx.x;
     u32x4 v[RCT];
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(1024) void k_mul_rows(const u32x4 *__restrict__ inn
     const i64 oe = ob + rto < o_count ? ob + rto : o_count;
     for (i64 o = ob; o < oe; ++o) {
         const u32x4 *orow = outer + o * Wq;
-        u32x4 *dst = out + o * n_chunks + c0;
+        u32x4 *dst = out + o * out_stride + c0;
 #pragma unroll
         for (int k = 0; k < RCT; ++k) {
             if (ok[k]) {
@@ -265,7 +265,7 @@ template <int WQ> __device__ __forceinline__ u32 half_row_sum(u32 s) {
 // bytes of neighbouring blocks interleaved from 8 different L2s cost partial-line write-backs.
 template <int WQ, bool INNER_LEFT>
 __global__ __launch_bounds__(256) void k_mul_rows_e(const u32x4 *__restrict__ inner, i64 n_chunks, const u32x4 *__restrict__ outer,
-                                                     u32x4 *__restrict__ out, unsigned char *__restrict__ eb) {
+                                                     u32x4 *__restrict__ out, unsigned char *__restrict__ eb, i64 out_stride) {
     constexpr int R = 256 / WQ;
     __shared__ __attribute__((aligned(16))) unsigned char sb[R];
     const i64 cb = (i64)blockIdx.x * 256;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_mul_rows_e(const u32x4 *__restrict__ in
     const i64 o = blockIdx.y;
     const u32x4 r = outer[o * WQ + (threadIdx.x & (WQ - 1))];
     const u32x4 x = v ^ r;
-    if (ok) __builtin_nontemporal_store(x, out + o * n_chunks + c0);
+    if (ok) __builtin_nontemporal_store(x, out + o * out_stride + c0);
     u32 s;
     if constexpr (WQ == 1) {                                         // the chunk is the whole row: x word, z word
         const u32 cy = __popc(x.x & x.z) + __popc(x.y & x.w);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_mul_rows_e(const u32x4 *__restrict__ in
 constexpr int EO = 4;
 __global__ __launch_bounds__(256) void k_mul_coeff_expand(const unsigned char *__restrict__ eb, i64 gx, int rshift, const int *__restrict__ yi,
                                                            const int *__restrict__ yo, const double *__restrict__ ci, const double *__restrict__ co,
-                                                           i64 Ni, i64 No, double *__restrict__ out) {
+                                                           i64 Ni, i64 No, double *__restrict__ out, i64 out_stride) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= Ni) return;
     const i64 R = 1LL << rshift, bx = i >> rshift;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void k_mul_coeff_expand(const unsigned char *_
             double re, im;
             pair_coefficient(ar, ai, co[2 * o], co[2 * o + 1], e, re, im);
             const f64x2 w = {re, im};
-            __builtin_nontemporal_store(w, dst + o * Ni);
+            __builtin_nontemporal_store(w, dst + o * out_stride);
         }
     } else {
         for (i64 o = ob; o < No; ++o) {
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_mul_coeff_expand(const unsigned char *_
             double re, im;
             pair_coefficient(ar, ai, co[2 * o], co[2 * o + 1], e, re, im);
             const f64x2 w = {re, im};
-            __builtin_nontemporal_store(w, dst + o * Ni);
+            __builtin_nontemporal_store(w, dst + o * out_stride);
         }
     }
 }
@@ -434,37 +434,60 @@ int mul_keys_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 No, int Wq, int
     return mul_coeff_launch(it.as<u64>(), Ipad, nullptr, Ni, outer, nullptr, 0, No, Wq, inner_is_left, nullptr, ctx().stream, ot, &ka);
 }
 
+// Chunks (16 B) of the inner operand per launch of a row stream: all of it while an eighth fits an XCD's L2 with room to spare (3.5 MiB of
+// 4), else equal tiles of at most 3 MiB per XCD — whole rows, whole 256-chunk blocks, gx a multiple of 8.  SYMGPU_PRODUCT_TILE_MB (tests)
+// sets the tile size in MiB of inner operand.
+static i64 inner_tile_chunks(i64 n_chunks, int Wq) {
+    i64 budget = (i64)24 << 20, whole = (i64)28 << 20;
+    if (const char *e = getenv("SYMGPU_PRODUCT_TILE_MB")) {
+        const double mb = atof(e);
+        if (mb > 0) budget = whole = (i64)(mb * 1048576.0);
+    }
+    if (n_chunks * 16 <= whole) return n_chunks;
+    const i64 n_tiles = (n_chunks * 16 + budget - 1) / budget;
+    i64 unit = 2048;                                                // 8 blocks of 256 chunks ...
+    while (unit % Wq) unit += 2048;                                 // ... and whole rows (a power-of-two Wq <= 64 divides 2048)
+    const i64 per = (n_chunks + n_tiles - 1) / n_tiles;
+    return (per + unit - 1) / unit * unit;
+}
+
 // rows of the slab: out_rows[((o-o_begin)*Ni + i)*W + w]
 int mul_rows_dev(const u64 *inner, i64 Ni, const u64 *outer, i64 o_begin, i64 o_end, int Wq, u64 *out_rows) {
     const i64 No = o_end - o_begin;
     if (Ni == 0 || No <= 0) return SYMGPU_OK;
     const i64 n_chunks = Ni * Wq;
     const RowsVariant &rv = rows_variant();
-    i64 gx = (n_chunks + (i64)rv.threads * rv.rc - 1) / ((i64)rv.threads * rv.rc);
     // Workgroups go to the 8 XCDs round-robin by linear id (= by * gx + bx): with gx a multiple of 8 the inner chunk bx is ALWAYS
     // read by XCD bx % 8, so each XCD's 4 MB L2 only ever sees its own eighth of the inner operand (3.2 MB of 25.6 MB at the
     // benchmark size) and keeps it.  The re-reads of the inner operand then stop at the L2 instead of crossing the fabric, which
     // makes ONE output row per block affordable — and that is the sequential write pattern the HBM likes (tools/ubench_rows.hip:
     // 12 rows per block 6.27 TB/s either way; 1 row per block 3.76 TB/s unpadded, 7.14 TB/s padded).  The surplus blocks exit.
-    if (rv.pad8) gx = (gx + 7) / 8 * 8;
+    // An inner operand whose eighth does NOT fit (round 6 sweep: 10^5 terms of 2,000 qubits = 6.4 MB per XCD, 0.47 of the HBM peak
+    // against 0.8 for 10^4 terms) is cut into tiles that do (inner_tiles): every tile is a launch over all outer rows.
     const i64 max_gy = 65535;
     const i64 gy_total = (No + rv.rto - 1) / rv.rto;
-    for (i64 y0 = 0; y0 < gy_total; y0 += max_gy) {
-        const i64 ny = gy_total - y0 < max_gy ? gy_total - y0 : max_gy;
-        const i64 ooff = y0 * rv.rto;
-        dim3 grid((unsigned)gx, (unsigned)ny);
-        const u32x4 *pi = reinterpret_cast<const u32x4 *>(inner);
-        const u32x4 *po = reinterpret_cast<const u32x4 *>(outer + (o_begin + ooff) * 2 * Wq);
-        u32x4 *pd = reinterpret_cast<u32x4 *>(out_rows) + ooff * n_chunks;
-        ProfScope prof(0);
-#define LAUNCH_ROWS(RCV, NTV) hipLaunchKernelGGL((k_mul_rows<RCV, NTV>), grid, dim3(rv.threads), 0, ctx().stream, pi, n_chunks, po, Wq, No - ooff, pd, rv.rto)
-        if (rv.nt) {
-            if (rv.rc == 1) LAUNCH_ROWS(1, true); else if (rv.rc == 2) LAUNCH_ROWS(2, true); else if (rv.rc == 8) LAUNCH_ROWS(8, true); else LAUNCH_ROWS(4, true);
-        } else {
-            if (rv.rc == 1) LAUNCH_ROWS(1, false); else if (rv.rc == 2) LAUNCH_ROWS(2, false); else if (rv.rc == 8) LAUNCH_ROWS(8, false); else LAUNCH_ROWS(4, false);
-        }
+    const i64 tile = inner_tile_chunks(n_chunks, Wq);
+    for (i64 c_lo = 0; c_lo < n_chunks; c_lo += tile) {
+        const i64 nc = n_chunks - c_lo < tile ? n_chunks - c_lo : tile;
+        i64 gx = (nc + (i64)rv.threads * rv.rc - 1) / ((i64)rv.threads * rv.rc);
+        if (rv.pad8) gx = (gx + 7) / 8 * 8;
+        for (i64 y0 = 0; y0 < gy_total; y0 += max_gy) {
+            const i64 ny = gy_total - y0 < max_gy ? gy_total - y0 : max_gy;
+            const i64 ooff = y0 * rv.rto;
+            dim3 grid((unsigned)gx, (unsigned)ny);
+            const u32x4 *pi = reinterpret_cast<const u32x4 *>(inner) + c_lo;
+            const u32x4 *po = reinterpret_cast<const u32x4 *>(outer + (o_begin + ooff) * 2 * Wq);
+            u32x4 *pd = reinterpret_cast<u32x4 *>(out_rows) + ooff * n_chunks + c_lo;
+            ProfScope prof(0);
+#define LAUNCH_ROWS(RCV, NTV) hipLaunchKernelGGL((k_mul_rows<RCV, NTV>), grid, dim3(rv.threads), 0, ctx().stream, pi, nc, po, Wq, No - ooff, pd, rv.rto, n_chunks)
+            if (rv.nt) {
+                if (rv.rc == 1) LAUNCH_ROWS(1, true); else if (rv.rc == 2) LAUNCH_ROWS(2, true); else if (rv.rc == 8) LAUNCH_ROWS(8, true); else LAUNCH_ROWS(4, true);
+            } else {
+                if (rv.rc == 1) LAUNCH_ROWS(1, false); else if (rv.rc == 2) LAUNCH_ROWS(2, false); else if (rv.rc == 8) LAUNCH_ROWS(8, false); else LAUNCH_ROWS(4, false);
+            }
 #undef LAUNCH_ROWS
-        KERNEL_CHECK();
+            KERNEL_CHECK();
+        }
     }
     return SYMGPU_OK;
 }
@@ -479,40 +502,46 @@ static int mul_rows_coeff_fused(symgpu_op_s *inner, symgpu_op_s *outer, i64 o_be
     const int *yi = nullptr, *yo = nullptr;
     SG_TRY(op_ycount(inner, &yi));
     SG_TRY(op_ycount(outer, &yo));
-    const i64 gx = ((n_chunks + 255) / 256 + 7) / 8 * 8;               // a multiple of 8: see mul_rows_dev
     const i64 R = 256 / Wq;
     int rshift = 0;
     while ((1LL << rshift) < R) ++rshift;
     hipStream_t st = ctx().stream;
     const i64 max_gy = 65535 / EO * EO;
+    const i64 tile = inner_tile_chunks(n_chunks, Wq);                  // see mul_rows_dev: an inner operand beyond the L2s goes tile by tile
+    const i64 gx_max = (((tile < n_chunks ? tile : n_chunks) + 255) / 256 + 7) / 8 * 8;
     Scratch eb;
-    SG_TRY(eb.alloc((size_t)(No < max_gy ? No : max_gy) * gx * R));
-    for (i64 y0 = 0; y0 < No; y0 += max_gy) {
-        const i64 ny = No - y0 < max_gy ? No - y0 : max_gy;
-        const u32x4 *pi = reinterpret_cast<const u32x4 *>(inner->rows);
-        const u32x4 *po = reinterpret_cast<const u32x4 *>(outer->rows + (o_begin + y0) * 2 * Wq);
-        u32x4 *pd = reinterpret_cast<u32x4 *>(out->rows) + y0 * n_chunks;
-        dim3 grid((unsigned)gx, (unsigned)ny);
-        {
-            ProfScope prof(0);
-#define LAUNCH_E(W) do { if (inner_is_left) hipLaunchKernelGGL((k_mul_rows_e<W, true>), grid, dim3(256), 0, st, pi, n_chunks, po, pd, eb.as<unsigned char>()); \
-                         else hipLaunchKernelGGL((k_mul_rows_e<W, false>), grid, dim3(256), 0, st, pi, n_chunks, po, pd, eb.as<unsigned char>()); } while (0)
-            switch (Wq) {
-                case 1: LAUNCH_E(1); break;
-                case 2: LAUNCH_E(2); break;
-                case 4: LAUNCH_E(4); break;
-                case 8: LAUNCH_E(8); break;
-                case 16: LAUNCH_E(16); break;
-                case 32: LAUNCH_E(32); break;
-                default: LAUNCH_E(64); break;
-            }
+    SG_TRY(eb.alloc((size_t)(No < max_gy ? No : max_gy) * gx_max * R));
+    for (i64 c_lo = 0; c_lo < n_chunks; c_lo += tile) {
+        const i64 nc = n_chunks - c_lo < tile ? n_chunks - c_lo : tile;
+        const i64 i_lo = c_lo / Wq, ni = nc / Wq;
+        const i64 gx = ((nc + 255) / 256 + 7) / 8 * 8;                 // a multiple of 8: see mul_rows_dev
+        for (i64 y0 = 0; y0 < No; y0 += max_gy) {
+            const i64 ny = No - y0 < max_gy ? No - y0 : max_gy;
+            const u32x4 *pi = reinterpret_cast<const u32x4 *>(inner->rows) + c_lo;
+            const u32x4 *po = reinterpret_cast<const u32x4 *>(outer->rows + (o_begin + y0) * 2 * Wq);
+            u32x4 *pd = reinterpret_cast<u32x4 *>(out->rows) + y0 * n_chunks + c_lo;
+            dim3 grid((unsigned)gx, (unsigned)ny);
+            {
+                ProfScope prof(0);
+#define LAUNCH_E(W) do { if (inner_is_left) hipLaunchKernelGGL((k_mul_rows_e<W, true>), grid, dim3(256), 0, st, pi, nc, po, pd, eb.as<unsigned char>(), n_chunks); \
+                         else hipLaunchKernelGGL((k_mul_rows_e<W, false>), grid, dim3(256), 0, st, pi, nc, po, pd, eb.as<unsigned char>(), n_chunks); } while (0)
+                switch (Wq) {
+                    case 1: LAUNCH_E(1); break;
+                    case 2: LAUNCH_E(2); break;
+                    case 4: LAUNCH_E(4); break;
+                    case 8: LAUNCH_E(8); break;
+                    case 16: LAUNCH_E(16); break;
+                    case 32: LAUNCH_E(32); break;
+                    default: LAUNCH_E(64); break;
+                }
 #undef LAUNCH_E
+                KERNEL_CHECK();
+            }
+            dim3 ge((unsigned)((ni + 255) / 256), (unsigned)((ny + EO - 1) / EO));
+            hipLaunchKernelGGL(k_mul_coeff_expand, ge, dim3(256), 0, st, eb.as<unsigned char>(), gx, rshift, yi + i_lo, yo + o_begin + y0, inner->coeff + 2 * i_lo,
+                               outer->coeff + 2 * (o_begin + y0), ni, ny, out->coeff + 2 * (y0 * Ni + i_lo), Ni);
             KERNEL_CHECK();
         }
-        dim3 ge((unsigned)((Ni + 255) / 256), (unsigned)((ny + EO - 1) / EO));
-        hipLaunchKernelGGL(k_mul_coeff_expand, ge, dim3(256), 0, st, eb.as<unsigned char>(), gx, rshift, yi, yo + o_begin + y0, inner->coeff,
-                           outer->coeff + 2 * (o_begin + y0), Ni, ny, out->coeff + 2 * y0 * Ni);
-        KERNEL_CHECK();
     }
     return SYMGPU_OK;
 }

@@ -37,6 +37,10 @@ class DeviceOp:
         self.shared = True
         return self
 
+    def __reduce__(self):
+        raise TypeError('a DeviceOp is a pointer into this process\'s GPU memory and cannot be pickled: pickle the PauliwordOp that owns it '
+                        '(it is brought to the host), or download() the rows')
+
     @classmethod
     def upload(cls, rows, coeff=None):
         rows = _rows(rows)
@@ -180,6 +184,20 @@ def ycount(rows):
     out = np.zeros(rows.shape[0], dtype=np.int64)
     check(_lib.lib().symgpu_ycount(addr(rows), rows.shape[0], rows.shape[1] // 2, addr(out)))
     return out
+
+
+_device_memory = {}
+
+
+def device_memory_bytes():
+    """Total memory of the calling thread's current device (cached per device)."""
+    d = _lib.current_device() if _lib._initialised_device is not None else -1
+    if d not in _device_memory:
+        free_b, total_b = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(_lib.lib().symgpu_mem_info(ctypes.addressof(free_b), ctypes.addressof(total_b)))
+        _device_memory[_lib.current_device()] = int(total_b.value)
+        d = _lib.current_device()
+    return _device_memory[d]
 
 
 def commutes(a_rows, b_rows):
@@ -422,6 +440,24 @@ def generator_reconstruction_dev(gens, op, n_qubits):
 
 
 # ---- f3 / f4: projection, noncontextuality test, state inner product -------------------------------------------------
+def sector_signs(eigenvalues):
+    """Stabiliser eigenvalues as ints in {-1, 0, +1}.  The reference multiplies by the eigenvalue itself (projection/base.py:68-71); the
+    sign-mask form of the device kernel is that product only for these three values, so anything else is refused — with an exception, not
+    an assert (`python -O`), and before anything has consumed the values; entries within 1e-12 of an allowed value (a sector that went
+    through floating point) are rounded as the reference's own `IndependentOp` would store them."""
+    ev = np.asarray(eigenvalues).ravel()
+    if ev.size == 0:
+        return np.zeros(0, dtype=np.int64)
+    if np.iscomplexobj(ev):
+        if np.any(np.abs(ev.imag) > 1e-12):
+            raise ValueError(f'stabiliser eigenvalues must be -1, 0 or +1, got {ev}')
+        ev = ev.real
+    rounded = np.rint(np.asarray(ev, dtype=float))
+    if np.any(np.abs(ev - rounded) > 1e-12) or not np.all(np.isin(rounded, (-1.0, 0.0, 1.0))):
+        raise ValueError(f'stabiliser eigenvalues must be -1, 0 or +1, got {ev}')
+    return rounded.astype(np.int64)
+
+
 def project_dev(op, stab_rows, eigenvalues, keep_qubits, n_qubits, zero_threshold=1e-15):
     """``S3Projection._perform_projection`` (projection/base.py:44-84) on a device operator: ``stab_rows`` uint64[k, 2*Wq] the fixed
     single-qubit stabilisers, ``eigenvalues`` int[k] their sector, ``keep_qubits`` the ascending indices of the qubits that stay.
@@ -430,10 +466,7 @@ def project_dev(op, stab_rows, eigenvalues, keep_qubits, n_qubits, zero_threshol
     k = stab_rows.shape[0]
     wq = op.info()[1]
     neg = np.zeros(2 * wq, dtype='<u8')
-    eigenvalues = np.asarray(eigenvalues).ravel()
-    # the reference multiplies by the eigenvalue itself (projection/base.py:68-71); the sign-mask form below is that product only for
-    # eigenvalues in {-1, 0, +1} — anything else (a sector entry like -1.0000000000000002) must not be read as +1 in silence
-    assert np.all(np.isin(eigenvalues, (-1, 0, 1))), f'stabiliser eigenvalues must be -1, 0 or +1, got {eigenvalues}'
+    eigenvalues = sector_signs(eigenvalues)
     for row, ev in zip(stab_rows, eigenvalues):
         if ev == -1:
             neg |= row                                             # (projection/base.py:69: the column index list has one entry per stabiliser)

@@ -52,6 +52,10 @@ class HipBackend:
     def use(self, d):
         _lib.check(self.lib.symgpu_set_device(int(d)))
 
+    def current(self):
+        """The calling thread's current device (DeviceGroup restores it when a sharded call returns)."""
+        return _lib.current_device()
+
     def sync(self, d):
         self.use(d)
         _lib.check(self.lib.symgpu_sync())
@@ -195,9 +199,21 @@ class DeviceGroup:
             b.free(s)
         return fulls
 
+    def _home(self):
+        """The caller's current device: a sharded call visits every device and must leave the thread where it found it (an operator
+        created afterwards would otherwise land on the last device visited and refuse to meet the caller's older operators)."""
+        return self.b.current()
+
     def commutes(self, a, b_src=None):
         """bool[N, M]: ``a`` against ``b_src`` (None: against itself — the all-gather that assembles the right operand is then also the
-        distribution of the left blocks)."""
+        distribution of the left blocks).  The thread's current device is the same before and after."""
+        home = self._home()
+        try:
+            return self._commutes(a, b_src)
+        finally:
+            self.b.use(home)
+
+    def _commutes(self, a, b_src):
         be, G = self.b, self.n
         same = b_src is None
         fulls = self._replicate(a if same else b_src, with_coeff=False)
@@ -220,8 +236,15 @@ class DeviceGroup:
         return out.view(np.bool_)
 
     def mul_cleanup(self, inner, outer, inner_is_left=True, zero_threshold=1e-15, same=False):
-        """Fused product + cleanup with the OUTER index in contiguous blocks over the devices; the result is an operator on device 0.
-        ``same``: both factors are one operand (``P * P``)."""
+        """Fused product + cleanup with the OUTER index in contiguous blocks over the devices; the result is an operator on the CALLER's
+        current device, which is also the thread's current device afterwards.  ``same``: both factors are one operand (``P * P``)."""
+        home = self._home()
+        try:
+            return self._mul_cleanup(inner, outer, inner_is_left, zero_threshold, same, home)
+        finally:
+            self.b.use(home)
+
+    def _mul_cleanup(self, inner, outer, inner_is_left, zero_threshold, same, home):
         be, G = self.b, self.n
         inner_fulls = self._replicate(inner, with_coeff=True)
         no = be.n_source_rows(inner if same else outer)
@@ -242,9 +265,9 @@ class DeviceGroup:
             res = parts[0]
         else:
             for d in range(G):
-                be.sync(d)                                          # the parts are complete before device 0 copies them
-            cat = be.concat_on(0, parts)
-            res = be.cleanup(0, cat, zero_threshold)
+                be.sync(d)                                          # the parts are complete before the home device copies them
+            cat = be.concat_on(home, parts)
+            res = be.cleanup(home, cat, zero_threshold)
             be.free(cat)
             for p in parts:
                 be.free(p)
@@ -266,17 +289,45 @@ def n_devices_wanted():
     return max(1, min(have, int(want))) if want else have
 
 
+def under_launcher(environ=None):
+    """One process per GPU (torchrun / bench.py --gpus N): every rank owns ONE device (``symmer_amd.parallel``); a rank must not bring up
+    contexts and an RCCL clique over all eight behind its launcher's back."""
+    env = os.environ if environ is None else environ
+    return int(env.get('WORLD_SIZE', '1') or 1) > 1 or 'RANK' in env
+
+
 def group():
-    """The process-wide :class:`DeviceGroup` over the visible devices, or None when there is only one (or ``SYMGPU_DEVICES=1``)."""
+    """The process-wide :class:`DeviceGroup` over the visible devices, or None when there is only one, ``SYMGPU_DEVICES=1``, or the
+    process is one rank of a launcher.  Creating it leaves the thread's current device where it was."""
     global _group, _group_tried
     if not _group_tried:
         _group_tried = True
+        if under_launcher():
+            return None
         n = n_devices_wanted()
         if n > 1:
             _lib.init()
-            _group = DeviceGroup(HipBackend(n))
-            _lib.check(_lib.load().symgpu_set_device(0))
+            home = _lib.current_device()
+            try:
+                _group = DeviceGroup(HipBackend(n))
+            finally:
+                _lib.set_device(home)
     return _group
+
+
+def product_uses_devices(n_pairs, row_bytes, device_bytes, environ=None):
+    """Does ``A * B`` go to the device group?  The sharded product + cleanup computes per-device GENERAL sub-products (the squared-operator
+    half-pairs path is lost), copies every cleaned part to one device and cleans the concatenation there: measured on one MI355X
+    (tools/bench_devices_product.py) it is slower than the single-device call wherever that call can run.  So it is taken
+    only on request (``SYMGPU_DEVICES_PRODUCT=1``, above MIN_PAIRS_PRODUCT pairs) or when one device cannot hold the product:
+    ``n_pairs`` result rows of ``row_bytes`` (packed row + coefficient) plus 16 bytes of sort keys and indices per pair against half of
+    the device's memory.  ``commutes_termwise`` is different: its blocks are independent and come back over eight PCIe links."""
+    env = os.environ if environ is None else environ
+    if n_pairs < MIN_PAIRS_PRODUCT:
+        return False
+    if env.get('SYMGPU_DEVICES_PRODUCT', '0') == '1':
+        return True
+    return n_pairs * (row_bytes + 16) > device_bytes // 2
 
 
 def reset():

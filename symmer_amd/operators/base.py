@@ -5,7 +5,6 @@ routines.  The data-parallel work runs in hand-written HIP kernels (``libsymgpu.
 glue only.  Out of scope (not on the path): ``from_matrix``, ``to_sparse_matrix``, graph colouring,
 openfermion/qiskit converters, ``QuantumState``.
 """
-import sys
 import warnings
 from copy import deepcopy
 from functools import reduce, cached_property
@@ -47,7 +46,8 @@ class PauliwordOp:
         assert len(symp_matrix.shape) == 2, 'symplectic matrix must be 2 dimensional only'
         self._symp = symp_matrix
         self.n_qubits = symp_matrix.shape[1] // 2
-        self._coeff = np.asarray(coeff_vec, dtype=complex)
+        self._coeff = np.array(coeff_vec, dtype=complex)          # OUR copy (the reference aliases a complex ndarray argument): see the note below
+        self._coeff_private = True       # nobody outside this object has been handed the host coefficient array
         self.n_terms = symp_matrix.shape[0]
         assert self.n_terms == len(self._coeff), 'coeff list and Pauliwords not same length'
         self._packed_cache = None
@@ -58,9 +58,11 @@ class PauliwordOp:
     # Results of device kernels STAY on the device (`_dev`) and come to the host when somebody asks for `symp_matrix`, `packed` or
     # `coeff_vec`; operands are uploaded once and the handle is kept, so a multi-step caller (rotate -> project -> cleanup,
     # symmer/projection/base.py:44-124) moves its operator over PCIe once in and once out.  `symp_matrix` is treated as immutable, as
-    # in the reference; `coeff_vec` is not (`op.coeff_vec *= -1`, `op.coeff_vec[i] = x` are reference idioms, and the constructor
-    # aliases the caller's array as the reference's np.asarray does): while anybody outside holds the host array — seen from its
-    # reference count — the device copy of the coefficients is refreshed (16 bytes per term) before every device call.
+    # in the reference; `coeff_vec` is not (`op.coeff_vec *= -1`, `op.coeff_vec[i] = x` are reference idioms).  Ownership is explicit
+    # (`_coeff_private`): the constructor COPIES its coefficient argument (a deliberate divergence — the reference's np.asarray aliases
+    # a complex ndarray, so a caller who later writes into the array he passed changes the reference's operator; here mutations reach
+    # the operator through `op.coeff_vec` only), and from the moment `coeff_vec` has been handed out or assigned the device copy of
+    # the coefficients is refreshed (16 bytes per term) before every device call that reads them.
     @property
     def symp_matrix(self) -> np.ndarray:
         """bool[T, 2n] = [X | Z] as in the reference; expanded to one byte per bit only when somebody asks (a 2.5e7-term, 1000-qubit
@@ -97,24 +99,21 @@ class PauliwordOp:
         """complex128[T] (whatever was assigned, for subclasses that keep ints).  Handing the array out ends our knowledge of its
         contents: see the note above."""
         self._dev_coeff_valid = False
-        return self._c()
+        c = self._c()
+        self._coeff_private = False
+        return c
 
     @coeff_vec.setter
     def coeff_vec(self, value) -> None:
         self._coeff = value if isinstance(value, np.ndarray) else np.asarray(value)
+        self._coeff_private = False                               # the caller may keep (and write through) what he assigned
         self._dev_coeff_valid = False
-
-    def _coeff_is_private(self) -> bool:
-        """Nobody but this object can reach the host coefficient array: it owns its memory and the only references to it are our
-        attribute, the local below and getrefcount's argument (every view, memoryview or alias a caller may write through holds a
-        reference to the owning array).  CPython reference counting; a False negative only costs a 16 B/term upload."""
-        c = self._coeff
-        return isinstance(c, np.ndarray) and c.base is None and sys.getrefcount(c) <= 3
 
     def _c(self) -> np.ndarray:
         """The coefficients for READING inside this package (never mutated, never passed on by reference)."""
         if self._coeff is None:
             self._coeff = self._dev.download_coeff()
+            self._coeff_private = True
         return self._coeff
 
     _UPLOAD_BOOL_MIN_BYTES = 1 << 20
@@ -129,13 +128,12 @@ class PauliwordOp:
                 self._dev = kernels.DeviceOp.upload_bool(self._symp, coeff)       # packed by a ballot kernel: 10x np.packbits
             else:
                 self._dev = kernels.DeviceOp.upload(self.packed, coeff)
-            del coeff                                             # (a second reference to the array would read as "somebody holds it")
-            self._dev_coeff_valid = self._coeff_is_private()
+            self._dev_coeff_valid = self._coeff_private
         elif not rows_only and not self._dev_coeff_valid and self._coeff is not None:
             if self._dev.shared:
                 self._dev = self._dev.clone()
             self._dev.set_coeff(np.asarray(self._coeff, dtype=complex))
-            self._dev_coeff_valid = self._coeff_is_private()
+            self._dev_coeff_valid = self._coeff_private
         return self._dev
 
     def _multi_source(self, with_coeff: bool = True):
@@ -150,6 +148,7 @@ class PauliwordOp:
         """A kernel's result, left where it is."""
         op = cls.__new__(cls)
         op._symp = op._packed_cache = op._coeff = None
+        op._coeff_private = True
         op._dev, op._dev_coeff_valid = dev, True
         op.n_qubits = n_qubits
         op.n_terms = dev.n_terms
@@ -164,7 +163,8 @@ class PauliwordOp:
         op._packed_cache = packed
         op.n_qubits = n_qubits
         op.n_terms = packed.shape[0]
-        op._coeff = np.asarray(coeff_vec, dtype=complex)
+        op._coeff = np.array(coeff_vec, dtype=complex)
+        op._coeff_private = True
         op._dev, op._dev_coeff_valid = None, False
         assert op.n_terms == len(op._coeff), 'coeff list and Pauliwords not same length'
         return op
@@ -187,6 +187,7 @@ class PauliwordOp:
         coeff = self._c() if coeff_vec is None else coeff_vec
         op._coeff = np.array(coeff if index is None or coeff_vec is not None else coeff[index], dtype=complex)   # a copy: never an alias of ours
         op.n_terms = len(op._coeff)
+        op._coeff_private = True
         op._dev, op._dev_coeff_valid = None, False
         if index is None and self._dev is not None:
             op._dev = self._dev                                   # same rows: the handle is shared, its coefficients are not ours
@@ -243,6 +244,32 @@ class PauliwordOp:
 
     def copy(self) -> "PauliwordOp":
         return deepcopy(self)
+
+    def __deepcopy__(self, memo):
+        # member by member (a device handle is shared, kernels.DeviceOp.__deepcopy__) — NOT through __getstate__ below, which brings the
+        # operator to the host
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for key, value in self.__dict__.items():
+            new.__dict__[key] = deepcopy(value, memo)
+        return new
+
+    # The reference's objects are plain NumPy and are pickled by its process pool (symmer/process_handler.py) and by users who save
+    # results; a device handle is a pointer into THIS process.  Pickling brings the operator to the host (packed rows + coefficients,
+    # 1/8 of the bool matrix) and the copy starts life without a handle.
+    def __getstate__(self):
+        state = {k: v for k, v in self.__dict__.items() if k not in ('_dev', '_dev_coeff_valid', '_symp', '_packed_cache', '_coeff')}
+        if self.n_qubits > 0:
+            state['_packed_cache'] = self.packed
+            state['_symp'] = None
+        else:
+            state['_packed_cache'], state['_symp'] = None, self.symp_matrix
+        state['_coeff'] = np.array(self._c())
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._dev, self._dev_coeff_valid, self._coeff_private = None, False, True
 
     def _xz_score(self, wx: int, wz: int) -> np.ndarray:
         """Per term: wx * (number of X bits) + wz * (number of Z bits)."""
@@ -397,8 +424,12 @@ class PauliwordOp:
         are the fast index of the reference's pair order (base.py:783-792)."""
         if self.n_terms == 0 or other.n_terms == 0:
             return PauliwordOp._from_packed(np.empty((0, 2 * packing.words_per_block(self.n_qubits)), dtype='<u8'), self.n_qubits, [])
-        if self.n_terms * other.n_terms >= multi.MIN_PAIRS_PRODUCT and multi.group() is not None:
-            # more than one MI355X in this process: the outer index in contiguous blocks over the devices (symmer_amd/multi.py)
+        n_pairs = self.n_terms * other.n_terms
+        if (n_pairs >= multi.MIN_PAIRS_PRODUCT
+                and multi.product_uses_devices(n_pairs, 16 * packing.words_per_block(self.n_qubits) + 16, kernels.device_memory_bytes())
+                and multi.group() is not None):
+            # on request (SYMGPU_DEVICES_PRODUCT=1) or when one MI355X cannot hold the product: the outer index in contiguous blocks over the
+            # devices of this process (symmer_amd/multi.py)
             inner, outer = (self, other) if self_is_inner else (other, self)
             res = multi.group().mul_cleanup(inner._multi_source(), None if other is self else outer._multi_source(), self_is_inner, zero_threshold,
                                             same=other is self)

@@ -28,10 +28,9 @@ class S3Projection:
             # every qubit stabilised: a scalar (projection/base.py:83-84) — the surviving weights times their signs, from the packed rows
             survives = np.all(operator.commutes_termwise(fixed), axis=1)
             neg = np.zeros(operator.packed.shape[1], dtype='<u8')
-            for row, ev in zip(fixed.packed, np.asarray(fixed.coeff_vec)):
+            for row, ev in zip(fixed.packed, kernels.sector_signs(fixed.coeff_vec)):      # (ValueError for anything but -1, 0, +1, before use)
                 if ev == -1:
                     neg |= row
-            assert np.all(np.isin(np.asarray(fixed.coeff_vec), (-1, 0, 1))), 'stabiliser eigenvalues must be -1, 0 or +1'
             odd = (packing.popcount_rows(operator.packed[survives] & neg) & 1).astype(bool)
             weights = np.where(odd, -operator._c()[survives], operator._c()[survives])
             return PauliwordOp(np.zeros((1, 0), dtype=bool), [np.sum(weights)])

@@ -420,6 +420,11 @@ def test_bench_line_schema_small_workload():
     for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert key in r, key
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    # the line ENDS with a compact `summary` (the driver keeps the tail of stdout), the api legend appears once
+    assert list(d)[-1] == 'summary' and list(d)[-2] == 'api_legend' and lines[0].count('first_call = fresh host arrays') == 1
+    sm = d['summary']
+    assert sm['product_1e5x1e5']['k'][0] == r['kernel'] and abs(sm['product_1e5x1e5']['k'][1] - r['frac']) < 5e-3
+    assert len(json.dumps(sm)) < 1500
 
 
 def test_bench_adjacency_workload_schema():

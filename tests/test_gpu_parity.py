@@ -168,6 +168,33 @@ def test_rotation_chain_from_operator_with_duplicates():
     assert_op_equal(R.symp_matrix, R.coeff_vec, er, ec, exact=False, tol=TOL)
 
 
+def test_saturating_nonclifford_chain_vs_oracle():
+    """VERDICT r5 item 7 / SURVEY 8d cfg2: a chain of > 100 NON-Clifford rotations that cycles through 8 fixed generators (a Trotter circuit,
+    symmer/evolution/exponentiation.py:26-38).  The term set saturates at (seed terms) x 2^8 products — 2,048 here, 10^5 in bench.py — and
+    from then on every rotation merges rows instead of adding them.  Step by step on the device against the step-by-step oracle: the term
+    count and the ROW ORDER at saturation, the coefficients within 1e-12 after 120 rotations."""
+    rng = np.random.default_rng(97)
+    n, seed_terms = 40, 8
+    symp = rng.random((seed_terms, 2 * n)) < 0.3
+    c = rng.standard_normal(seed_terms) + 1j * rng.standard_normal(seed_terms)
+    gens = [rng.random(2 * n) < 0.5 for _ in range(8)]
+    angles = [0.3, -1.1, 0.7, 2.0, 0.3, 0.45, -0.2, 1.3]
+    rots = [(gens[k % 8], angles[k % 8]) for k in range(120)]
+    P = PauliwordOp(symp, c)
+    cur, counts = P, []
+    es, ec = symp, c
+    for q, a in rots:
+        cur = cur._rotate_by_single_Pword(PauliwordOp(q.reshape(1, -1), [1]), a)
+        es, ec = onp.rotate_by_single_pword(es, ec, q, a)
+        counts.append(cur.n_terms)
+        assert cur.n_terms == es.shape[0]
+    assert counts[-1] == counts[-9] == counts[40] and 500 <= counts[-1] <= seed_terms * 256, counts[::8]       # saturated long before the end
+    assert_op_equal(cur.symp_matrix, cur.coeff_vec, es, ec, exact=False, tol=TOL)
+    chained = P.perform_rotations([(PauliwordOp(q.reshape(1, -1), [1]), a) for q, a in rots])
+    er, erc = onp.perform_rotations(symp, c, rots)
+    assert_op_equal(chained.symp_matrix, chained.coeff_vec, er, erc, exact=False, tol=TOL)
+
+
 @pytest.mark.parametrize('n,T,K', [(1000, 1, 300), (70, 37, 200), (5, 60, 120), (130, 1500, 60), (64, 128, 30), (64, 129, 12), (64, 448, 30), (64, 1537, 12), (100, 4096, 9), (100, 4097, 7), (1000, 3000, 11), (2000, 700, 9), (4096, 300, 9), (1, 4, 50),
                                    (4096, 60, 15), (2000, 128, 10), (2048, 127, 10), (1000, 128, 12), (1, 128, 20),       # the LDS-resident kernel at its limits
                                    (200, 20000, 25)])
@@ -366,6 +393,22 @@ def test_mul_allpairs_vs_oracle(n, Ni, No, left, fused, monkeypatch):
     _, coeff = kernels.mul_allpairs(a, cg, b, cbg, left)
     _, ecoeff = oc.mul_allpairs(a, cg, b, cbg, left)
     assert np.array_equal(coeff, ecoeff)        # both sides are the un-fused IEEE expression: bit-exact even for Gaussian input
+
+
+@pytest.mark.parametrize('fused', ['1', '0'])
+@pytest.mark.parametrize('n,Ni,No,left', [(1000, 5000, 9, True), (2000, 3001, 5, False), (3000, 2100, 4, True), (100, 70000, 3, False), (20, 200001, 2, True)])
+def test_mul_allpairs_inner_operand_in_tiles(n, Ni, No, left, fused, monkeypatch):
+    """An inner operand whose eighth does not fit an XCD's L2 is streamed tile by tile (product.hip inner_tile_chunks: 10^5 terms of 2,000
+    qubits ran at 0.47 of the HBM peak untiled).  SYMGPU_PRODUCT_TILE_MB forces small tiles here: several tiles, a ragged last one, both
+    row streams (phase-byte stream and plain stream + word-major coefficients), rows whose chunk count is not a power of two."""
+    monkeypatch.setenv('SYMGPU_PRODUCT_FUSED', fused)
+    monkeypatch.setenv('SYMGPU_PRODUCT_TILE_MB', '0.3')
+    rng = np.random.default_rng(210 + n + Ni)
+    a = packing.pack_rows(rng.random((Ni, 2 * n)) < 0.3); b = packing.pack_rows(rng.random((No, 2 * n)) < 0.3)
+    ca, cb = dyadic(rng, Ni), dyadic(rng, No)
+    rows, coeff = kernels.mul_allpairs(a, ca, b, cb, left)
+    erows, ecoeff = oc.mul_allpairs(a, ca, b, cb, left)
+    assert np.array_equal(rows, erows) and np.array_equal(coeff, ecoeff)
 
 
 @pytest.mark.parametrize('n,N,M', [(100, 500, 500), (1000, 300, 200), (3, 700, 700), (65, 64, 900), (5000, 90, 60), (10, 70000, 3),

@@ -57,9 +57,13 @@ def test_square_then_multiply_moves_every_operand_once():
     with Traffic() as t:                                                  # the operands are resident now: nothing goes up again but P's and
         R2 = P * Q                                                        # Q's coefficients (their host arrays were handed out two lines above)
     assert t.h2d == 16 * (P.n_terms + Q.n_terms) and t.d2h == 0
-    with Traffic() as t:                                                  # nobody holds those arrays any more (reference counts): nothing moves
-        R3 = P * Q
-    assert t.h2d == 0 and t.d2h == 0
+    with Traffic() as t:                                                  # ownership is an explicit flag, not a reference count: arrays that have
+        R3 = P * Q                                                        # been handed out once are refreshed before every call (16 B per term)
+    assert t.h2d == 16 * (P.n_terms + Q.n_terms) and t.d2h == 0
+    P2 = PauliwordOp(P.symp_matrix, dyadic(rng, 300))                     # an operator whose coefficients nobody has seen: rows + coefficients go up once
+    with Traffic() as t:
+        P2 * Q; P2 * Q
+    assert t.uploads == 3 and t.h2d == op_bytes(P2) + 2 * 16 * Q.n_terms, (t.uploads, t.h2d)     # P2 once + two refreshes of Q's coefficients
     er, ec = oc.mul(P.packed, P.coeff_vec, Q.packed, Q.coeff_vec)
     for R in (R2, R3):
         assert np.array_equal(R.packed, er) and np.array_equal(R.coeff_vec, ec)
@@ -169,6 +173,42 @@ def test_coefficients_changed_on_the_host_are_seen_by_the_next_call():
     check(P, Q)
     S = P + twin
     assert S.n_terms == 0
+    # an alias held across device calls (invisible to any reference count on CPython 3.14 / PyPy): ownership is an explicit flag
+    held = P.coeff_vec
+    check(P, Q)                                                            # a device call with the alias outstanding
+    held *= 3                                                              # ... then a write through it
+    check(P, Q)
+    held[5] = -7j
+    check(P, Q)
+    # the constructor copies its coefficient argument: the operator does not change behind `coeff_vec`'s back
+    mine = dyadic(rng, 9)
+    Q2 = PauliwordOp(Q.symp_matrix, mine)
+    before = (P * Q2).coeff_vec.copy()
+    mine *= 5
+    assert np.array_equal((P * Q2).coeff_vec, before) and not np.shares_memory(Q2._coeff, mine)
+
+
+def test_operators_pickle_from_the_device():
+    """the reference's objects are plain NumPy and are pickled by its process pool and by users; a device-resident
+    result comes to the host when it is pickled and the copy starts without a handle.  A bare DeviceOp refuses with a clear message."""
+    import pickle
+    from symmer_amd import IndependentOp
+    rng = np.random.default_rng(511)
+    n = 70
+    P = PauliwordOp(rng.random((150, 2 * n)) < 0.3, dyadic(rng, 150))
+    R = P * P
+    assert is_device_only(R)
+    back = pickle.loads(pickle.dumps(R))
+    assert back._dev is None and np.array_equal(back.packed, R.packed) and np.array_equal(back.coeff_vec, R.coeff_vec)
+    assert back == R and np.array_equal((back * P).packed, (R * P).packed)
+    host_only = PauliwordOp(rng.random((7, 2 * n)) < 0.3, dyadic(rng, 7))
+    again = pickle.loads(pickle.dumps(host_only))
+    assert np.array_equal(again.symp_matrix, host_only.symp_matrix) and np.array_equal(again.coeff_vec, host_only.coeff_vec)
+    G = IndependentOp.from_list(['ZI', 'IZ'])
+    G2 = pickle.loads(pickle.dumps(G))
+    assert type(G2) is IndependentOp and np.array_equal(G2.symp_matrix, G.symp_matrix) and list(G2.coeff_vec) == list(G.coeff_vec)
+    with pytest.raises(TypeError, match='cannot be pickled'):
+        pickle.dumps(R._dev)
 
 
 def test_scaling_dagger_indexing_and_sums_stay_on_the_device():
@@ -245,6 +285,16 @@ def test_device_group_on_one_device_runs_the_grouped_rccl_path(monkeypatch):
     res = grp.mul_cleanup(dA, None, True, 1e-15, same=True)
     er, ec = oc.mul(A, a, A, a)
     rows, coeff = res.download()
+    assert np.array_equal(rows, er) and np.array_equal(coeff, ec)
+    # the thread's current device survives a sharded call, and an operator created afterwards meets the older ones
+    home = _lib.current_device()
+    grp.commutes(dA, dB)
+    assert _lib.current_device() == home
+    fresh = kernels.DeviceOp.upload(B, b)
+    prod = kernels.mul_cleanup_handles(dA, fresh, True, 1e-15)
+    pr, pc = oc.mul_allpairs(A, a, B, b, True)
+    er, ec = oc.cleanup(pr, pc, 1e-15)
+    rows, coeff = prod.download()
     assert np.array_equal(rows, er) and np.array_equal(coeff, ec)
     _lib.check(_lib.load().symgpu_comm_destroy())
 

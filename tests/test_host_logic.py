@@ -238,3 +238,57 @@ def test_hash_partition_classes_are_linear_and_shares_partition_the_product():
             assert np.unique(g).size == g.size
             assert np.array_equal(np.concatenate([s[0] for s in shares], axis=0)[order], er)
             assert np.array_equal(np.concatenate([s[1] for s in shares])[order], ec)
+
+
+def test_host_operators_pickle_and_constructor_owns_its_coefficients():
+    """A host-only operator pickles as plain arrays (the reference's objects are NumPy and travel through its process pool); the
+    constructor copies the coefficient array it is given (mutations reach an operator through `op.coeff_vec` only)."""
+    import pickle
+    c = np.array([1 + 2j, -0.5, 3j])
+    P = PauliwordOp.from_list(['XZ', 'YI', 'ZZ'], c)
+    c[0] = 99
+    assert P.coeff_vec[0] == 1 + 2j
+    Q = pickle.loads(pickle.dumps(P))
+    assert np.array_equal(Q.symp_matrix, P.symp_matrix) and np.array_equal(Q.coeff_vec, P.coeff_vec) and Q.n_qubits == 2 and Q._dev is None
+    Z = pickle.loads(pickle.dumps(PauliwordOp(np.zeros((1, 0), dtype=bool), [2.5])))          # a 0-qubit scalar has no packed rows
+    assert Z.n_qubits == 0 and Z.coeff_vec[0] == 2.5
+
+
+def test_sector_values_are_checked_with_an_exception():
+    """anything but -1, 0, +1 as a stabiliser eigenvalue is a ValueError (not an assert that `python -O` removes),
+    raised before the values are used; float noise within 1e-12 is rounded."""
+    from symmer_amd import kernels
+    assert list(kernels.sector_signs([1, -1, 0, 1.0000000000000002, -0.9999999999999999 + 0j])) == [1, -1, 0, 1, -1]
+    for bad in ([2], [0.5], [1j], [1 + 1e-6]):
+        with pytest.raises(ValueError, match='eigenvalues'):
+            kernels.sector_signs(bad)
+
+
+def test_bench_summary_carries_every_config():
+    """`summary_of` on a line shaped like the full default run: cfg1-cfg5 + the strong-scaling shard within 1.5 KB, in the last 4 KB."""
+    import json, sys, importlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    roof = {'kernel': 'k_some_kernel_name', 'frac': 0.812345, 'lds': {'frac': 0.6012}}
+    api = {'a_result_object_seconds': 0.0023456, 'b_host_arrays_out_seconds': 0.165432}
+    line = {'metric': 'pauli_term_pairs_per_sec', 'value': 2.52e10, 'unit': 'pairs/s', 'ms_per_step': 396.5, 'config': {'workload': 'allpairs_product'},
+            'roofline': roof, 'cpu_baseline': {'value': 1.1e6, 'other_configs': {'cfg1_mul_cleanup': {'pairs_per_s': 3e5}, 'cfg2_rotation': {'term_pairs_per_s': 2e4},
+                                                                                 'cfg3_sample_mul_cleanup': {'pairs_per_s': 1e5}, 'cfg4_sample_rref': {'row_xors_per_s': 1e4},
+                                                                                 'cfg5_sample_commutation': {'pairs_per_s': 5e6}}},
+            'extras': {'cfg1_api_mul': {'pairs_per_s': 1.4e8, 'seconds': 1.8e-3, 'api': api},
+                       'cfg2_rotation': {'term_pairs_per_s': 3.5e9, 'seconds_per_rotation': 2.8e-5, 'roofline': roof, 'api': api, 'clifford': {'seconds_per_rotation': 5e-6},
+                                         'saturated_chain': {'seconds_per_rotation': 3e-5}},
+                       'cfg3_mul_cleanup': {'pairs_per_s': 4.2e10, 'seconds': 2.36e-3, 'roofline': roof, 'api': api},
+                       'cfg4_symmetry_kernel': {'row_xors_per_s': 4.1e9, 'seconds': 1.95e-3, 'roofline': roof, 'api': api},
+                       'cfg5_adjacency': {'pairs_per_s': 1.28e12, 'seconds': 0.0312, 'roofline': roof, 'api': {'full': api, 'rank_share': api},
+                                          'rank_share_25000_rows': {'seconds': 4.2e-3, 'predicted_8gpu_strong_speedup_before_allgather': 7.43}},
+                       'strong_scaling_shard': {'ms_per_step': 49.9, 'roofline': roof, 'predicted_8gpu_strong_speedup_before_allgather': 7.95},
+                       'broken_section': {'error': 'X'}}}
+    sm = bench.summary_of(line)
+    text = json.dumps(sm)
+    assert len(text) <= 1500, len(text)
+    for key in ('product_1e5x1e5', 'cfg1_mul_500t_100q', 'cfg2_rotation', 'cfg3_mul_cleanup', 'cfg4_gf2', 'cfg5_adjacency', 'strong_scaling_shard'):
+        assert key in sm, key
+    assert sm['cfg5_adjacency']['predicted_8gpu_x'] == 7.43 and sm['cfg3_mul_cleanup']['api'] == [0.002346, 0.1654] and sm['failed_sections'] == ['broken_section']

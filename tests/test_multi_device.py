@@ -20,10 +20,17 @@ class OracleBackend:
     """G pretend devices; every cross-device rule the real backend enforces is asserted here (an operator is only ever used on its device)."""
     degraded = None
 
-    def __init__(self, n):
+    def __init__(self, n, home=0):
         self.n = n
         self.live = 0
         self.gathers = 0
+        self.cur = home                                                # the calling thread's current device
+
+    def use(self, d):
+        self.cur = d
+
+    def current(self):
+        return self.cur
 
     def _src(self, source):
         return (source.rows[:source.T], None if source.coeff is None else source.coeff[:source.T]) if isinstance(source, FakeOp) else source
@@ -38,6 +45,7 @@ class OracleBackend:
         pass
 
     def shard_from(self, d, source, r0, r1, capacity, with_coeff):
+        self.use(d)                                                    # (as HipBackend: every call moves the thread to the device it works on)
         rows, coeff = self._src(source)
         op = FakeOp(d, max(1, capacity), rows.shape[1], with_coeff)
         op.rows[:r1 - r0] = rows[r0:r1]
@@ -48,6 +56,7 @@ class OracleBackend:
         return op
 
     def alloc(self, d, capacity, wq, with_coeff):
+        self.use(d)
         self.live += 1
         return FakeOp(d, max(1, capacity), 2 * wq, with_coeff)
 
@@ -66,6 +75,7 @@ class OracleBackend:
             f.T = n_rows_total
 
     def commutes_block(self, d, a, a0, a1, b):
+        self.use(d)
         assert a.device == d and b.device == d
         return oc.commutes(a.rows[a0:a1], b.rows[:b.T]).astype(np.uint8) if a1 > a0 and b.T else np.zeros((a1 - a0, b.T), dtype=np.uint8)
 
@@ -74,6 +84,7 @@ class OracleBackend:
             out[b0:b1] = bufs[d]
 
     def mul_cleanup(self, d, inner, outer, inner_is_left, zero_threshold):
+        self.use(d)
         assert inner.device == d and outer.device == d
         rows, coeff = oc.mul_allpairs(inner.rows[:inner.T], inner.coeff[:inner.T], outer.rows[:outer.T], outer.coeff[:outer.T], inner_is_left)
         r, c = oc.cleanup(rows, coeff, zero_threshold)
@@ -83,6 +94,7 @@ class OracleBackend:
         return op
 
     def concat_on(self, d, parts):
+        self.use(d)
         total = sum(p.T for p in parts)
         op = FakeOp(d, max(1, total), parts[0].rows.shape[1], True)
         at = 0
@@ -94,6 +106,7 @@ class OracleBackend:
         return op
 
     def cleanup(self, d, op, zero_threshold):
+        self.use(d)
         assert op.device == d
         r, c = oc.cleanup(op.rows[:op.T], op.coeff[:op.T], zero_threshold)
         out = FakeOp(d, max(1, r.shape[0]), op.rows.shape[1], True)
@@ -154,3 +167,42 @@ def test_block_bounds_of_the_north_star_configuration():
     assert ts == 25000 and bounds[0] == (0, 25000) and bounds[7] == (175000, 200000)
     ts, bounds = shard_bounds(10, 8)                                   # fewer rows than devices: tail devices are empty
     assert ts == 2 and bounds[5] == (10, 10) and bounds[4] == (8, 10)
+
+
+@pytest.mark.parametrize('home', [0, 2])
+def test_sharded_calls_leave_the_current_device_alone(home):
+    """a sharded call visits every device; the thread's current device — where the caller's next operator will be
+    created — must be what it was, and the product lands on the caller's device, not on device 0."""
+    rng = np.random.default_rng(5)
+    n, N = 64, 90
+    a = onp.pack_rows(rng.random((N, 2 * n)) < 0.3)
+    c = dyadic(rng, N)
+    be = OracleBackend(3, home=home)
+    grp = DeviceGroup(be)
+    grp.commutes((a, None))
+    assert be.current() == home
+    grp.commutes((a, None), (a[:7], None))
+    assert be.current() == home
+    res = grp.mul_cleanup((a, c), None, True, 1e-15, same=True)
+    assert be.current() == home and res.device == home, 'the result lives where the caller works'
+    be.free(res)
+    assert be.live == 0
+
+
+def test_launcher_ranks_do_not_build_a_device_group():
+    from symmer_amd import multi
+    assert multi.under_launcher({'WORLD_SIZE': '8', 'RANK': '3'}) and multi.under_launcher({'RANK': '0'})
+    assert not multi.under_launcher({}) and not multi.under_launcher({'WORLD_SIZE': '1'})
+
+
+def test_product_goes_to_the_device_group_only_on_request_or_for_size():
+    """`A * B` stays on one device unless SYMGPU_DEVICES_PRODUCT=1 or one device cannot hold the product (rows +
+    coefficients + 16 B of keys per pair against half of the device's memory); commutes_termwise keeps its own gate."""
+    from symmer_amd import multi
+    hbm = 288 << 30
+    row = 256 + 16                                                     # 1,000 qubits
+    assert not multi.product_uses_devices(10 ** 8, row, hbm, {})       # cfg3: 29 GB
+    assert not multi.product_uses_devices(4 * 10 ** 8, row, hbm, {})   # 2 x 10^4 terms squared: 115 GB < 144 GB
+    assert multi.product_uses_devices(6 * 10 ** 8, row, hbm, {})       # does not fit one MI355X
+    assert multi.product_uses_devices(4 * 10 ** 8, row, hbm, {'SYMGPU_DEVICES_PRODUCT': '1'})
+    assert not multi.product_uses_devices(1 << 20, row, hbm, {'SYMGPU_DEVICES_PRODUCT': '1'})      # below MIN_PAIRS_PRODUCT: never

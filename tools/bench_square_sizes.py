@@ -1,5 +1,5 @@
-import sys, time
-sys.path.insert(0, '/root/repo')
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes   # squared product + cleanup, 1,000 qubits, device resident: python tools/bench_square_sizes.py [N1,N2,...]
 from symmer_amd import kernels, _lib
 from symmer_amd.kernels import DeviceOp
