@@ -754,7 +754,8 @@ int symgpu_device_name(char *buf, int len) {
     if (!buf || len <= 0) return SYMGPU_E_INVALID;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ctx().device));
-    snprintf(buf, (size_t)len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    // (some driver stacks leave the marketing name empty: say so instead of printing nothing)
+    snprintf(buf, (size_t)len, "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD GPU, name not reported by the driver", prop.gcnArchName, prop.multiProcessorCount);
     return SYMGPU_OK;
 }
 

@@ -1,7 +1,7 @@
 # Everything under profiles/ for one round (run on the GPU box): bash tools/prof_all.sh r04
 # -> gpurun_out/<tag>_profiles/: bench lines (un-profiled) of all five workloads, rocprofv3 kernel traces, PMC passes, traffic JSONs
 export TMPDIR=/tmp
-tag=${1:-r05}
+tag=${1:-r06}
 dst=gpurun_out/${tag}_profiles; rm -rf $dst; mkdir -p $dst
 # 2. product: PMC + kernel trace (+ traffic JSON tied to product.hip)
 bash tools/pmc_product.sh $tag > $dst/pmc_product.log 2>&1
@@ -18,7 +18,7 @@ python3 profiles/summarize_rocpd.py $dst/adj/t_results.db | head -14 > $dst/${ta
 timeout 600 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU -d $dst/adjpmc -o p -- python3 bench.py --workload adjacency --steps 1 --warmup 0 --no-api --no-cpu > /dev/null 2> $dst/adjpmc.log
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_BUSY_CYCLES -d $dst/adjpmc2 -o p -- python3 bench.py --workload adjacency --steps 1 --warmup 0 --no-api --no-cpu > /dev/null 2> $dst/adjpmc2.log
 python3 profiles/summarize_rocpd.py --pmc $dst/adjpmc/p_results.db --pmc $dst/adjpmc2/p_results.db | grep -E "counter|k_commutes_m4r" > $dst/${tag}_adjacency_lds_pmc.txt
-timeout 600 rocprofv3 --kernel-trace --stats -d $dst/chain -o t -- python3 tools/bench_chain3.py > $dst/chain.out 2> $dst/chain.log
+timeout 600 rocprofv3 --kernel-trace --stats -d $dst/chain -o t -- python3 tools/bench_clifford_run.py > $dst/chain.out 2> $dst/chain.log
 { grep chain $dst/chain.out; python3 profiles/summarize_rocpd.py $dst/chain/t_results.db | grep -E "calls|cchain_reg|rs_coop|permute|cchain_flags|cchain_move" ; } > $dst/${tag}_clifford_run_kernel_trace.txt
 rm -rf $dst/adj $dst/adjpmc $dst/adjpmc2 $dst/chain
 # the traffic JSONs of THIS source go where bench.py looks for them (on the box's copy of the tree), then:
