@@ -396,7 +396,7 @@ def summary_of(out):
     if isinstance(c2, dict) and 'error' not in c2:
         sm['cfg2_rotation'] = {'v': _sig(c2.get('term_pairs_per_s')), 'u': 'term-pairs/s', 's': _sig(c2.get('seconds_per_rotation')), 'k': _roof(c2.get('roofline')),
                                'api': _api(c2.get('api')), 'cpu': _sig(g(oc_, 'cfg2_rotation', 'term_pairs_per_s')),
-                               'clifford_s': _sig(g(c2, 'clifford', 'seconds_per_rotation')), 'saturated_chain_s': _sig(g(c2, 'saturated_chain', 'seconds_per_rotation'))}
+                               'clifford_s': _sig(g(c2, 'clifford', 'run_of_200_seconds_per_rotation')), 'saturated_chain_s': _sig(g(c2, 'saturated_chain', 'seconds_per_rotation'))}
     if isinstance(c3, dict) and 'error' not in c3:
         sm['cfg3_mul_cleanup'] = {'v': _sig(c3.get('pairs_per_s')), 'u': 'pairs/s', 's': _sig(c3.get('seconds')), 'k': _roof(c3.get('roofline')),
                                   'api': _api(c3.get('api')), 'cpu': _sig(g(oc_, 'cfg3_sample_mul_cleanup', 'pairs_per_s'))}
@@ -1121,9 +1121,16 @@ def extras(_lib, kernels, DeviceOp, comm, parallel, args, headline):
         nrow = 25000
         buf = ctypes.c_void_p()
         _lib.check(lib.symgpu_dev_alloc(nrow * 200000, ctypes.byref(buf)))
-        _lib.check(lib.symgpu_commutes_dev(C.handle, 0, nrow, C.handle, buf)); kernels.sync()
+        # a 4 ms call is timed at the clocks of a busy GPU, as inside the 8-GPU step: the API legs above left the chip idle for seconds (the
+        # first calls after that run 10 % slower, `tools/bench_adj_rows.py`), so ~60 ms of the same launches first, then the median of 10
+        for _ in range(14):
+            _lib.check(lib.symgpu_commutes_dev(C.handle, 0, nrow, C.handle, buf))
+        kernels.sync()
         _lib.check(lib.symgpu_prof_enable(1, 1))
-        t = timed(lambda: _lib.check(lib.symgpu_commutes_dev(C.handle, 0, nrow, C.handle, buf)), 3)
+        ts = []
+        for _ in range(10):
+            t0 = time.perf_counter(); _lib.check(lib.symgpu_commutes_dev(C.handle, 0, nrow, C.handle, buf)); kernels.sync(); ts.append(time.perf_counter() - t0)
+        t = sorted(ts)[len(ts) // 2]
         _lib.check(lib.symgpu_prof_enable(1, 0))
         nl, ms = prof_read(_lib, 1)
         kt = ms / max(1, nl) * 1e-3

@@ -188,6 +188,10 @@ int symgpu_rotate_single(const uint64_t *rows, const double *coeff, int64_t N, i
                          uint64_t *out_rows, double *out_coeff, int64_t capacity, int64_t *n_out, int *all_commute);
 int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double cos_t, double sin_t, int clifford_k,
                              double thr, symgpu_op_t *out, int *all_commute);
+/* The same call, also returning the result's term count (0 when *out == NULL): the drop-in class needs it for every rotation
+ * (base.py:1159-1161: a rotation that leaves no term returns 0 * I) and saves a symgpu_op_info round trip per call. */
+int symgpu_rotate_single_dev_n(symgpu_op_t in, const uint64_t *q_row_host, double cos_t, double sin_t, int clifford_k,
+                               double thr, symgpu_op_t *out, int *all_commute, int64_t *n_out);
 
 /* A run of K Clifford rotations (perform_rotations, base.py:1163-1186, on pi/2-multiples; CircuitSymmerlator) of a CLEAN
  * operator: `in` must come from a cleanup (no duplicate rows, every |c| > 1e-15) — then every step is a stable partition

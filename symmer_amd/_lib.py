@@ -89,6 +89,7 @@ SIGNATURES = {
     'symgpu_merge_indexed_dev': [P, c_int, c_int, c_int, c_dbl, c_int, PP],
     'symgpu_rotate_single': [P, P, c_i64, c_int, P, c_dbl, c_dbl, c_int, c_dbl, P, P, c_i64, P, P],
     'symgpu_rotate_single_dev': [P, P, c_dbl, c_dbl, c_int, c_dbl, PP, P],
+    'symgpu_rotate_single_dev_n': [P, P, c_dbl, c_dbl, c_int, c_dbl, PP, P, P],
     'symgpu_rotate_clifford_chain_dev': [P, P, P, c_i64, PP],
     'symgpu_perform_rotations_dev': [P, P, P, P, P, c_i64, c_dbl, c_int, PP, P, P, P],
     'symgpu_rref': [P, c_i64, c_i64, P, P],

@@ -1069,6 +1069,15 @@ using namespace symgpu;
 
 extern "C" {
 
+int symgpu_rotate_single_dev_n(symgpu_op_t in, const uint64_t *q_row_host, double cos_t, double sin_t, int clifford_k, double thr,
+                               symgpu_op_t *out, int *all_commute, int64_t *n_out) {
+    SG_REQUIRE(n_out, "rotate_single_dev_n: null argument");
+    *n_out = 0;
+    SG_TRY(symgpu_rotate_single_dev(in, q_row_host, cos_t, sin_t, clifford_k, thr, out, all_commute));
+    if (*out) *n_out = (*out)->T;
+    return SYMGPU_OK;
+}
+
 int symgpu_rotate_single_dev(symgpu_op_t in, const uint64_t *q_row_host, double cos_t, double sin_t, int clifford_k, double thr,
                              symgpu_op_t *out, int *all_commute) {
     SG_ENTER(in);

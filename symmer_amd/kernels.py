@@ -315,6 +315,11 @@ def mul_cleanup(inner, ci, outer, co, inner_is_left=True, zero_threshold=1e-15, 
             b.free()
 
 
+import functools
+import math
+
+
+@functools.lru_cache(maxsize=256)
 def rotation_args(angle, threshold=1e-18):
     """(cos, sin, clifford_k) for ``_rotate_by_single_Pword`` (base.py:1146-1156): clifford_k = round(2*angle/pi) if the
     angle is a multiple of pi/2 to within ``threshold``, else -1.  Negative multiples keep the reference's behaviour
@@ -324,8 +329,24 @@ def rotation_args(angle, threshold=1e-18):
     k = round(multiple)
     if abs(k - multiple) <= threshold:
         ck = k if k in (2, 3) else (k % 2)
-        return 0.0, 0.0, int(ck)             # the Clifford branch never uses cos / sin (base.py:1139-1154): not computed (2 us each)
+        return 0.0, 0.0, int(ck)             # the Clifford branch never uses cos / sin (base.py:1139-1154): not computed
+    # (np.cos / np.sin of a Python float and math.cos / math.sin are the same libm call; the results are cached per angle: a Trotter circuit
+    # repeats a handful of angles thousands of times)
     return float(np.cos(angle)), float(np.sin(angle)), -1
+
+
+def rotate_single_resident(op, q_addr, angle, zero_threshold=1e-15, clifford_threshold=1e-18):
+    """``rotate_single_dev`` for the drop-in class, without its per-call conveniences (the API call cost 1.6x the C-ABI
+    step): the generator's packed row comes as an address the caller keeps, cos / sin come from the cache, and the result's term count is
+    read once and returned.  -> (DeviceOp or None, all_commute, n_terms)."""
+    cos_t, sin_t, k = rotation_args(angle, clifford_threshold)
+    out = ctypes.c_void_p()
+    allc, t = c_int(0), c_i64(0)
+    check(_lib.lib().symgpu_rotate_single_dev_n(op.handle, q_addr, cos_t, sin_t, k, zero_threshold, ctypes.byref(out), ctypes.addressof(allc),
+                                                ctypes.addressof(t)))
+    if allc.value:
+        return None, True, 0
+    return DeviceOp(out), False, t.value
 
 
 def rotate_single_dev(op, q_row, angle, zero_threshold=1e-15, clifford_threshold=1e-18):

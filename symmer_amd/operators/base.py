@@ -144,14 +144,14 @@ class PauliwordOp:
         return (self.packed, np.asarray(self._c(), dtype=complex) if with_coeff else None)
 
     @classmethod
-    def _from_device(cls, dev: "kernels.DeviceOp", n_qubits: int) -> "PauliwordOp":
-        """A kernel's result, left where it is."""
+    def _from_device(cls, dev: "kernels.DeviceOp", n_qubits: int, n_terms: int = None) -> "PauliwordOp":
+        """A kernel's result, left where it is (``n_terms``: the caller knows it already)."""
         op = cls.__new__(cls)
         op._symp = op._packed_cache = op._coeff = None
         op._coeff_private = True
         op._dev, op._dev_coeff_valid = dev, True
         op.n_qubits = n_qubits
-        op.n_terms = dev.n_terms
+        op.n_terms = dev.n_terms if n_terms is None else n_terms
         return op
 
     @classmethod
@@ -251,14 +251,15 @@ class PauliwordOp:
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for key, value in self.__dict__.items():
-            new.__dict__[key] = deepcopy(value, memo)
+            if key != '_row_addr':                                # (an address into THIS object's packed rows)
+                new.__dict__[key] = deepcopy(value, memo)
         return new
 
     # The reference's objects are plain NumPy and are pickled by its process pool (symmer/process_handler.py) and by users who save
     # results; a device handle is a pointer into THIS process.  Pickling brings the operator to the host (packed rows + coefficients,
     # 1/8 of the bool matrix) and the copy starts life without a handle.
     def __getstate__(self):
-        state = {k: v for k, v in self.__dict__.items() if k not in ('_dev', '_dev_coeff_valid', '_symp', '_packed_cache', '_coeff')}
+        state = {k: v for k, v in self.__dict__.items() if k not in ('_dev', '_dev_coeff_valid', '_symp', '_packed_cache', '_coeff', '_row_addr')}
         if self.n_qubits > 0:
             state['_packed_cache'] = self.packed
             state['_symp'] = None
@@ -626,15 +627,19 @@ class PauliwordOp:
             warnings.warn(f'Pword coefficient {Pword._c()[0]: .8f} has been set to 1')
         if self.n_terms == 0:
             return self
-        res, all_commute = kernels.rotate_single_dev(self._device(), Pword.packed[0], angle, clifford_threshold=threshold)
+        q_addr = Pword.__dict__.get('_row_addr')                # the generator's packed row, pinned by its owner: a Trotter circuit reuses its generators
+        if q_addr is None:
+            q_addr = Pword.__dict__['_row_addr'] = Pword.packed.ctypes.data
+        res, all_commute, n_out = kernels.rotate_single_resident(self._device(), q_addr, angle, 1e-15, threshold)
         if all_commute:
             return self                                         # identity action: the SAME object (base.py:1131-1133)
-        _warn_large_angle(angle, threshold)                     # only on the non-Clifford, non-commuting branch (base.py:1156-1157)
-        if res.n_terms == 0 and kernels.rotation_args(angle, threshold)[2] < 0 and not np.any(self.commutes_termwise(Pword)):
+        if abs(angle) > 1e6:
+            _warn_large_angle(angle, threshold)                 # only on the non-Clifford, non-commuting branch (base.py:1156-1157)
+        if n_out == 0 and kernels.rotation_args(angle, threshold)[2] < 0 and not np.any(self.commutes_termwise(Pword)):
             # non-Clifford and nothing left: the reference returns `commute_self + anticom_part` (base.py:1159-1161), and the sum of
             # two operators without terms is 0 * I (append, then cleanup(): base.py:631-632)
             return PauliwordOp(np.zeros((1, 2 * self.n_qubits), dtype=bool), [0])
-        return PauliwordOp._from_device(res, self.n_qubits)     # the result stays on the device until somebody reads it
+        return PauliwordOp._from_device(res, self.n_qubits, n_out)     # the result stays on the device until somebody reads it
 
     def perform_rotations(self, rotations: List[Tuple["PauliwordOp", float]]) -> "PauliwordOp":
         """base.py:1163-1186: rotations applied left to right, each followed by ``cleanup()``; the operator stays

@@ -278,7 +278,7 @@ def test_bench_summary_carries_every_config():
                                                                                  'cfg3_sample_mul_cleanup': {'pairs_per_s': 1e5}, 'cfg4_sample_rref': {'row_xors_per_s': 1e4},
                                                                                  'cfg5_sample_commutation': {'pairs_per_s': 5e6}}},
             'extras': {'cfg1_api_mul': {'pairs_per_s': 1.4e8, 'seconds': 1.8e-3, 'api': api},
-                       'cfg2_rotation': {'term_pairs_per_s': 3.5e9, 'seconds_per_rotation': 2.8e-5, 'roofline': roof, 'api': api, 'clifford': {'seconds_per_rotation': 5e-6},
+                       'cfg2_rotation': {'term_pairs_per_s': 3.5e9, 'seconds_per_rotation': 2.8e-5, 'roofline': roof, 'api': api, 'clifford': {'run_of_200_seconds_per_rotation': 5e-6},
                                          'saturated_chain': {'seconds_per_rotation': 3e-5}},
                        'cfg3_mul_cleanup': {'pairs_per_s': 4.2e10, 'seconds': 2.36e-3, 'roofline': roof, 'api': api},
                        'cfg4_symmetry_kernel': {'row_xors_per_s': 4.1e9, 'seconds': 1.95e-3, 'roofline': roof, 'api': api},
