@@ -1077,13 +1077,16 @@ template <bool PAIR, bool TRI, int NW, int U>
 __global__ __launch_bounds__(256) void k_emit_fused(const u64 *__restrict__ markbits64, const u32 *__restrict__ wordprefix, i64 T, const double *__restrict__ sum_of,
                                                      u32 Ni, int Wq, int wsh, const u32x4 *__restrict__ rows, const u32x4 *__restrict__ inner,
                                                      const u32x4 *__restrict__ outer, u32x4 *__restrict__ out_rows, double *__restrict__ out_coeff, LazyEmit lz,
-                                                     u64 *__restrict__ out_first, int pfx_shift /* prefix entries per 64 indices: 1 << pfx_shift */) {
+                                                     u64 *__restrict__ out_first, int pfx_shift /* prefix entries per 64 indices: 1 << pfx_shift */,
+                                                     int interleaved) {
     __shared__ u32 s_i[4][64 * NW], s_o[4][64 * NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // XCD-aware order: workgroups go round-robin over the 8 XCDs; every XCD takes a CONTIGUOUS eighth of the bitmap (and of the output) in
-    // order instead of every eighth 64 KB piece — 1.13-1.18 -> 1.04 ms at cfg3 (the output stage's write stream reaches 6.5 TB/s)
+    // order instead of every eighth 64 KB piece — 1.13-1.18 -> 1.04 ms at cfg3 (the output stage's write stream reaches 6.5 TB/s) on the
+    // arenas that like it and 1.20 ms on those that do not (round 5: the mode follows the memory the driver hands out).  `interleaved`
+    // is the plain order (1.10-1.19 ms everywhere); emit_order() measures both on the buffer at hand and keeps the faster.
     const i64 per_xcd = ((i64)gridDim.x + 7) / 8;
-    const i64 blk = (i64)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const i64 blk = interleaved ? (i64)blockIdx.x : (i64)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const i64 w0 = (blk * 4 + wave) * NW;
     if (w0 * 64 >= T) return;
     u64 bits[NW];
@@ -1321,6 +1324,44 @@ static int emit_prefix(const u32 *markbits_p, i64 T, Scratch &wordprefix, Scratc
 // round trip instead of two)
 struct EmitPrefix { Scratch wordprefix, total; i64 n_out = -1; bool touched = false, wide = false; };
 // one launch over the bitmaps the fused output stage decodes (five launches of 2 us each sat 6 us apart behind the host's read-back)
+// Which block order the fused output stage takes on THIS output buffer (the XCD-contiguous order is 15 % faster or 3 %
+// slower than the plain one depending on the memory behind the buffer, which a process cannot choose).  A large output (>= 512 MB) is
+// written into blocks the allocator hands out again and again (a loop of calls alternates between two of them): per block, the first four
+// calls alternate the two orders under a pair of events, from the fifth on the block is written in the order whose faster sample won.
+// Both orders write the same bytes.  SYMGPU_EMIT_ORDER=0 / 1 pins the contiguous / plain order (tests).
+struct EmitOrder { int interleaved = 0; EmitProbe *probe = nullptr; };
+static int emit_order_begin(const void *dst, size_t bytes, EmitOrder &eo) {
+    Context &c = ctx();
+    if (const char *e = getenv("SYMGPU_EMIT_ORDER")) { eo.interleaved = e[0] == '1'; return SYMGPU_OK; }
+    if (bytes < ((size_t)512 << 20)) return SYMGPU_OK;
+    EmitProbe *p = nullptr, *oldest = &c.emit_probe[0];
+    for (auto &q : c.emit_probe) {
+        if (q.key == dst) { p = &q; break; }
+        if (q.stamp < oldest->stamp) oldest = &q;
+    }
+    if (!p) { p = oldest; p->key = dst; p->phase = 0; p->best[0] = p->best[1] = 1e30f; }
+    p->stamp = ++c.emit_stamp;
+    if (p->phase > 0 && p->phase <= 4) {                          // the sample of this block's previous call (two or more calls ago: complete)
+        float ms = 0;
+        if (hipEventSynchronize(p->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, p->ev[0], p->ev[1]) == hipSuccess) {
+            const int o = (p->phase - 1) & 1;
+            if (ms < p->best[o]) p->best[o] = ms;
+        } else (void)hipGetLastError();
+        if (p->phase == 4) { p->choice = p->best[1] < p->best[0] ? 1 : 0; p->phase = 5; }
+    }
+    if (p->phase >= 5) { eo.interleaved = p->choice; return SYMGPU_OK; }
+    if (!p->ev[0]) { HIP_TRY(hipEventCreate(&p->ev[0])); HIP_TRY(hipEventCreate(&p->ev[1])); }
+    eo.interleaved = p->phase & 1;                                // 0, 1, 0, 1
+    eo.probe = p;
+    HIP_TRY(hipEventRecord(p->ev[0], c.stream));
+    return SYMGPU_OK;
+}
+static void emit_order_end(const EmitOrder &eo) {
+    if (!eo.probe) return;
+    (void)hipEventRecord(eo.probe->ev[1], ctx().stream);
+    ++eo.probe->phase;
+}
+
 static bool emit_is_fused(int Wq) { return Wq <= 64 && [] { const char *e = getenv("SYMGPU_EMIT_FUSED"); return !(e && e[0] == '0'); }(); }
 static int emit_touch(const u32 *markbits_p, i64 T, const LazyEmit &lz, EmitPrefix &pre) {
     const i64 n16 = (T + 63) / 64 / 2;                              // whole 16-byte chunks of a T-bit map
@@ -1376,13 +1417,16 @@ int cleanup_finish(u32 *markbits_p, const double *sum_of_p, i64 T, bool pair, co
             const dim3 gfu((unsigned)(((n_w64 + 4 * NWr - 1) / (4 * NWr) + 7) / 8 * 8));     // a multiple of 8: the kernel's XCD-aware order is a bijection then
             static const bool touch_on = [] { const char *e = SG_TUNE("SYMGPU_EMIT_TOUCH"); return !(e && e[0] == '0'); }();
             if (touch_on && !pre->touched) SG_TRY(emit_touch(markbits_p, T, lz, *pre));
+            EmitOrder eo;
+            SG_TRY(emit_order_begin(dst, (size_t)n_out * (size_t)(16 * Wq + 16), eo));
             ProfScope prof(3);
 #define LAUNCH_FUSED_S(P, TR, NWV, UV) hipLaunchKernelGGL((k_emit_fused<P, TR, NWV, UV>), gfu, dim3(256), 0, st, reinterpret_cast<const u64 *>(markbits_p), wordprefix.as<u32>(), T, sum_of_p, \
-                                               (u32)(pair ? Ni : 1), Wq, wsh, reinterpret_cast<const u32x4 *>(rows), pin, pout, dst, res->coeff, lz, res->first, pre->wide ? 0 : 1)
+                                               (u32)(pair ? Ni : 1), Wq, wsh, reinterpret_cast<const u32x4 *>(rows), pin, pout, dst, res->coeff, lz, res->first, pre->wide ? 0 : 1, eo.interleaved)
 #define LAUNCH_FUSED_U(P, TR, NWV) do { if (Us == 8) LAUNCH_FUSED_S(P, TR, NWV, 8); else if (Us == 2) LAUNCH_FUSED_S(P, TR, NWV, 2); else LAUNCH_FUSED_S(P, TR, NWV, 4); } while (0)
 #define LAUNCH_FUSED(P, TR) do { if (NWr == 1) LAUNCH_FUSED_U(P, TR, 1); else if (NWr == 4) LAUNCH_FUSED_U(P, TR, 4); else if (NWr == 8) LAUNCH_FUSED_U(P, TR, 8); \
                                  else LAUNCH_FUSED_U(P, TR, 2); } while (0)
             if (pair && tri) LAUNCH_FUSED(true, true); else if (pair) LAUNCH_FUSED(true, false); else LAUNCH_FUSED(false, false);
+            emit_order_end(eo);
 #undef LAUNCH_FUSED_S
 #undef LAUNCH_FUSED_U
 #undef LAUNCH_FUSED

@@ -50,6 +50,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 #endif
 
 // ---- context ---------------------------------------------------------------------------------
+struct EmitProbe { const void *key = nullptr; int phase = 0, choice = 0; u64 stamp = 0; float best[2] = {1e30f, 1e30f}; hipEvent_t ev[2] = {nullptr, nullptr}; };
 struct Context {
     bool ready = false;
     int device = -1;
@@ -85,6 +86,8 @@ struct Context {
     u32 *sort_state = nullptr;     // one-launch radix sort (sort.hip): barrier counter, time-out flag, tile histograms
     u32 sort_bar_base = 0;
     bool sort_coop_disabled = false;
+    EmitProbe emit_probe[8];          // fused output stage of the cleanup: the output blocks whose block order is being / has been measured (cleanup.hip emit_order_begin)
+    u64 emit_stamp = 0;
     u32 *m7_flags = nullptr;       // stream-K commutation kernel (commute_m4r7.hip): per-workgroup words compared with the launch's epoch
     u32 m7_epoch = 0;
     u32 *sort_scan_ticket = nullptr;   // radix sort: "last workgroup finishes the scan" ticket, zero between launches

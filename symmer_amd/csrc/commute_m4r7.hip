@@ -30,7 +30,9 @@
 // Measured and dropped (round 5): look-ups and the next table's build as one interleaved instruction stream; a staggered start of every
 // CU's first workgroup; the index dwords in a rolling window of their own through LDS.  Round 6: uneven build shares between the two wave
 // groups (200,000^2: 31.9 ms even; 33.1 / 34.2 / 36.0 ms with the early builders at 3 : 5 / 2 : 6 / 1 : 7 of a table, 33.0 / 33.5 / 34.9 ms
-// the other way round); all waves building after their look-ups (31.5 against 31.3 ms).
+// the other way round); all waves building after their look-ups (31.5 against 31.3 ms); the tables written four entries at a time with
+// ds_write_b128 (eight stores per wave and step instead of 32: 34.0 against 30.4 ms — the wide stores and the 16-byte reads of the bit rows
+// keep the pipe from the look-ups: builds 960-1,200 cycles against ~800, look-ups 3,100-3,560 against 2,900-3,200).
 //
 // Layouts prepared per call:
 //   A7[g][i]   bits [7g, 7g + 7) of packed row i (values 0..127), group-major, i zero padded to Npad; one more all-zero group at index

@@ -714,6 +714,10 @@ static void shutdown_device(int device) {
     if (c.sort_state) { (void)hipFree(c.sort_state); c.sort_state = nullptr; c.sort_bar_base = 0; }
     if (c.sort_scan_ticket) { (void)hipFree(c.sort_scan_ticket); c.sort_scan_ticket = nullptr; }
     if (c.m7_flags) { (void)hipFree(c.m7_flags); c.m7_flags = nullptr; }
+    for (auto &q : c.emit_probe) {
+        for (auto &ev : q.ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+        q = EmitProbe();
+    }
     if (c.res_table) { (void)hipFree(c.res_table); c.res_table = nullptr; c.res_table_cap = 0; }
     if (c.res_state) { (void)hipFree(c.res_state); c.res_state = nullptr; c.res_epoch = 0; }
     if (c.rot_host_cnt) { (void)hipHostFree(c.rot_host_cnt); c.rot_host_cnt = nullptr; c.rot_host_cnt_dev = nullptr; }

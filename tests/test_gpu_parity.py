@@ -395,6 +395,20 @@ def test_mul_allpairs_vs_oracle(n, Ni, No, left, fused, monkeypatch):
     assert np.array_equal(coeff, ecoeff)        # both sides are the un-fused IEEE expression: bit-exact even for Gaussian input
 
 
+@pytest.mark.parametrize('order', ['0', '1'])
+def test_fused_output_stage_block_orders(order, monkeypatch):
+    """The fused output stage of the cleanup writes its rows in one of two block orders (every XCD a contiguous eighth of the output, or
+    the plain interleaved order) and keeps whichever it measured faster on the buffer at hand (cleanup.hip emit_order_begin);
+    SYMGPU_EMIT_ORDER pins one.  1,500 terms squared is above the 2^20-key gate of the lazy path that ends in that stage."""
+    monkeypatch.setenv('SYMGPU_EMIT_ORDER', order)
+    rng = np.random.default_rng(611)
+    n, N = 100, 1500
+    A = PauliwordOp(rng.random((N, 2 * n)) < 0.3, dyadic(rng, N))
+    R = A * A
+    erows, ecoeff = oc.mul(A.packed, A.coeff_vec, A.packed, A.coeff_vec)
+    assert np.array_equal(R.packed, erows) and np.array_equal(R.coeff_vec, ecoeff)
+
+
 @pytest.mark.parametrize('fused', ['1', '0'])
 @pytest.mark.parametrize('n,Ni,No,left', [(1000, 5000, 9, True), (2000, 3001, 5, False), (3000, 2100, 4, True), (100, 70000, 3, False), (20, 200001, 2, True)])
 def test_mul_allpairs_inner_operand_in_tiles(n, Ni, No, left, fused, monkeypatch):
