@@ -631,9 +631,9 @@ def wl_rotation(args, comm, rank, world, _lib, DeviceOp, parallel):
         def saturated_chain():
             # SURVEY 8d cfg2 asks for the per-rotation time over a CHAIN of >= 100 rotations.  A chain of non-Clifford rotations by random
             # Paulis grows the operator 1.5x per step; the realistic chain (Trotter circuits, symmer/evolution/exponentiation.py:26-38) cycles
-            # through a fixed set of generators, under which the term set saturates: 400 seed terms x the 2^8 products of 8 generators.
+            # through a fixed set of generators, under which the term set saturates: 800 seed terms x the products of 8 generators they reach (~10^5 terms).
             # Every rotation then MERGES (each anticommuting term's partner P.Q is already there): the term count stays constant.
-            seed_op = DeviceOp.random(400, n, 0.3, seed=4242)
+            seed_op = DeviceOp.random(800, n, 0.3, seed=4242)
             cur, counts = seed_op, []
             for k in range(8 * 14):                                  # to the fixed point (the count stops growing after a few cycles)
                 nxt = kernels.rotate_single_dev(cur, qs[k % 8], 0.3)[0]
@@ -653,7 +653,7 @@ def wl_rotation(args, comm, rank, world, _lib, DeviceOp, parallel):
             t = (time.perf_counter() - t0) / reps
             end_terms = cur.n_terms
             cur.free()
-            return {'generators': 8, 'seed_terms': 400, 'saturated_terms': sat_terms, 'cycles_to_saturation': cycles, 'timed_rotations': reps, 'terms_after': end_terms,
+            return {'generators': 8, 'seed_terms': 800, 'saturated_terms': sat_terms, 'cycles_to_saturation': cycles, 'timed_rotations': reps, 'terms_after': end_terms,
                     'seconds_per_rotation': t, 'term_pairs_per_s': sat_terms / t, 'angle': 0.3,
                     'call': 'cur = rotate(cur, Q_{k mod 8}, 0.3) 104 times on the saturated operator (kernels.rotate_single_dev: one C-ABI call per rotation, '
                             'device resident; every rotation merges rows, the term count is constant)'}
