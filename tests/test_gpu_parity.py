@@ -1110,10 +1110,10 @@ def test_commutes_m4r_tile_heights(r, M, monkeypatch):
     assert np.array_equal(kernels.commutes(a, b), expect)
 
 
-_STREAMK_EXPECT = {}
+_STREAMK_REF = {}
 
 
-@pytest.mark.parametrize('mode', ['stream', 'fixup', 'one_tile_per_workgroup'])
+@pytest.mark.parametrize('mode', ['stream', 'fixup'])
 @pytest.mark.parametrize('M', [32752, 32750])
 @pytest.mark.parametrize('r', ['16', '24', '48'])
 def test_commutes_m4r_stream_k(r, M, mode, monkeypatch):
@@ -1121,24 +1121,32 @@ def test_commutes_m4r_stream_k(r, M, mode, monkeypatch):
     persistent workgroups, so every workgroup's range starts and ends inside a tile; ragged last row and column tiles; M = 32752 the
     byte epilogue, M = 32750 bit-packed rows + expansion.  `stream`: a split tile is finished by the owner of its first steps from
     the neighbour's published part; `fixup` (SYMGPU_M4R_FIXUP=1): both parts go to scratch and k_m7_fixup writes the tile — the path
-    of a neighbour that has not run yet; `one_tile_per_workgroup` (SYMGPU_M4R_STREAM=0): what fewer tiles than CUs take."""
+    of a neighbour that has not run yet.  Both must equal, byte for byte, the table of the one-tile-per-workgroup launch
+    (SYMGPU_M4R_STREAM=0: what fewer tiles than CUs take), which is checked against the C oracle on 48 random 256 x 256 blocks and on
+    the ragged last rows and columns (the whole 0.85 GB table through the oracle takes a minute per shape)."""
     monkeypatch.setenv('SYMGPU_COMMUTE_M4R', '1'); monkeypatch.setenv('SYMGPU_M4R_R', r)
-    if mode == 'fixup':
-        monkeypatch.setenv('SYMGPU_M4R_FIXUP', '1')
-    if mode == 'one_tile_per_workgroup':
-        monkeypatch.setenv('SYMGPU_M4R_STREAM', '0')
     n = 100
     N = 32 * int(r) * 17 - 37
     key = (N, M)
-    if key not in _STREAMK_EXPECT:
-        _STREAMK_EXPECT.clear()                                       # one table at a time: up to 0.85 GB each
+    if key not in _STREAMK_REF:
+        _STREAMK_REF.clear()                                          # one table at a time: up to 0.85 GB each
         rng = np.random.default_rng(78)
         a = packing.pack_rows(rng.random((N, 2 * n)) < 0.3); b = packing.pack_rows(rng.random((M, 2 * n)) < 0.3)
         a[5] = 0                                                      # an identity row
-        _STREAMK_EXPECT[key] = (a, b, oc.commutes(a, b))
-    a, b, expect = _STREAMK_EXPECT[key]
+        monkeypatch.setenv('SYMGPU_M4R_STREAM', '0')
+        ref = kernels.commutes(a, b)
+        monkeypatch.delenv('SYMGPU_M4R_STREAM')
+        for _ in range(48):
+            r0, c0 = int(rng.integers(0, N - 256)), int(rng.integers(0, M - 256))
+            assert np.array_equal(ref[r0:r0 + 256, c0:c0 + 256], oc.commutes(a[r0:r0 + 256], b[c0:c0 + 256]))
+        assert np.array_equal(ref[N - 300:], oc.commutes(a[N - 300:], b)) and np.array_equal(ref[:, M - 300:], oc.commutes(a, b[M - 300:]))
+        assert ref[5].all()
+        _STREAMK_REF[key] = (a, b, ref)
+    a, b, ref = _STREAMK_REF[key]
+    if mode == 'fixup':
+        monkeypatch.setenv('SYMGPU_M4R_FIXUP', '1')
     got = kernels.commutes(a, b)
-    assert got.shape == expect.shape and np.array_equal(got, expect)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
 
 
 def test_commutes_m4r_all_identity_left_operand(monkeypatch):
