@@ -226,6 +226,7 @@ int ycount_dev(const u64 *rows, i64 T, int Wq, int *out);
 // commute_m4r.hip — the same contract on the Four-Russians kernel (LDS tables)
 int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *out, u64 *out_bits, symgpu_op_s *b_owner = nullptr);
 bool commutes_m4r_worthwhile(i64 N, i64 M);
+int bits_to_bytes_dev(const u64 *bits, i64 stride_words, i64 N, i64 M, uint8_t *out);   // bit-packed rows -> np.bool_ [N][M], any M, any alignment
 // commute_m4r7.hip — the same product with two 7-bit tables per step (called by commutes_m4r_dev, which owns the operand preparation of B)
 int commutes_m4r7_launch(const u64 *A, i64 N, i64 M, int Wq, const u64 *bt_p, i64 Mw_pad, int R, bool bytes, void *dst, i64 stride);
 

@@ -50,29 +50,72 @@ __global__ __launch_bounds__(256) void k_m4r_bt(const u64 *__restrict__ rows, i6
     for (int g = 0; g < 8; ++g) dst[g] = mine[g];
 }
 
-// bit-packed rows -> np.bool_ bytes: one thread per 16 columns
-template <bool VEC>
-__global__ __launch_bounds__(256) void k_bits_to_bytes(const u64 *__restrict__ bits, i64 stride_words, i64 N, i64 M, uint8_t *__restrict__ out) {
-    const i64 n16 = (M + 15) / 16;
-    const i64 total = N * n16;
-    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
-        const i64 i = idx / n16, c = idx - i * n16;
-        const u32 b16 = (u32)(bits[i * stride_words + (c >> 2)] >> (16 * (c & 3))) & 0xFFFFu;
+// bit-packed rows -> np.bool_ bytes for ANY row length and base alignment: the output [N][M] is treated as one flat run of N * M bytes and
+// written in aligned 16-byte chunks (non-temporal), a chunk taking its 16 bits from one row or — across a row boundary — from two or
+// more.  (Rounds 2-5 wrote rows whose length is not a multiple of 16 byte by byte: 13 ms for a 100,008^2 table against 2.6 ms for
+// 100,000^2 — and 15 of 16 term counts are not multiples of 16.)  A block owns a contiguous span; row and column of its first byte
+// come from one 64-bit division, the chunks inside from 32-bit ones.
+constexpr int B2B_CHUNKS_PER_THREAD = 8;
+__device__ __forceinline__ u32 b2b_bits16(const u64 *__restrict__ row, i64 j) {          // bits [j, j + 16) of a bit-packed row
+    const i64 w = j >> 6;
+    const int sh = (int)(j & 63);
+    u64 v = row[w] >> sh;
+    if (sh > 48) v |= row[w + 1] << (64 - sh);
+    return (u32)v & 0xFFFFu;
+}
+__global__ __launch_bounds__(256) void k_bits_to_bytes_flat(const u64 *__restrict__ bits, i64 stride_words, i64 N, i64 M, uint8_t *__restrict__ out) {
+    const i64 total = N * M;
+    const i64 head = (i64)((16 - (reinterpret_cast<uintptr_t>(out) & 15)) & 15) < total ? (i64)((16 - (reinterpret_cast<uintptr_t>(out) & 15)) & 15) : total;
+    const i64 n_chunks = (total - head) >> 4;
+    const i64 span = (i64)256 * B2B_CHUNKS_PER_THREAD;                 // chunks per block
+    const i64 c_block = (i64)blockIdx.x * span;
+    auto bit_at = [&](i64 f) -> u32 { const i64 i = f / M, j = f - i * M; return (u32)(bits[i * stride_words + (j >> 6)] >> (j & 63)) & 1u; };
+    if (blockIdx.x == 0) {                                             // the unaligned head and tail: a few bytes, one at a time
+        for (i64 f = threadIdx.x; f < head; f += 256) out[f] = (uint8_t)bit_at(f);
+        for (i64 f = head + (n_chunks << 4) + threadIdx.x; f < total; f += 256) out[f] = (uint8_t)bit_at(f);
+    }
+    if (c_block >= n_chunks) return;
+    const i64 f_block = head + (c_block << 4);
+    const i64 i_block = f_block / M, j_block = f_block - i_block * M;  // uniform
+    u32x4 *dst = reinterpret_cast<u32x4 *>(out + head) + c_block;
+#pragma unroll
+    for (int k = 0; k < B2B_CHUNKS_PER_THREAD; ++k) {
+        const i64 c = (i64)k * 256 + threadIdx.x;                      // chunk inside the span: consecutive lanes, consecutive chunks
+        if (c_block + c >= n_chunks) break;
+        const i64 d = j_block + (c << 4);                              // column of the chunk's first byte, counted from row i_block
+        i64 i, j;
+        if (d < ((i64)1 << 31) && M < ((i64)1 << 31)) { const u32 q = (u32)d / (u32)M; i = i_block + q; j = d - (i64)q * M; }
+        else { const i64 q = d / M; i = i_block + q; j = d - q * M; }
+        u32 b16;
+        if (j + 16 <= M) {
+            b16 = b2b_bits16(bits + i * stride_words, j);
+        } else {                                                       // the chunk runs over the end of row i (rows shorter than 16: of several rows)
+            b16 = 0;
+            i64 ii = i, jj = j;
+            for (int t = 0; t < 16; ++t) {
+                if (ii < N) b16 |= ((u32)(bits[ii * stride_words + (jj >> 6)] >> (jj & 63)) & 1u) << t;
+                if (++jj == M) { jj = 0; ++ii; }
+            }
+        }
         u32x4 v;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const u32 x = (b16 >> (4 * q)) & 0xFu;
             v[q] = (x | (x << 7) | (x << 14) | (x << 21)) & 0x01010101u;
         }
-        uint8_t *dst = out + i * M + 16 * c;
-        if (VEC) {
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst));
-        } else {
-#pragma unroll
-            for (int b = 0; b < 16; ++b)
-                if (16 * c + b < M) dst[b] = (uint8_t)(v[b / 4] >> (8 * (b % 4)));
-        }
+        __builtin_nontemporal_store(v, dst + c);
     }
+}
+
+int bits_to_bytes_dev(const u64 *bits, i64 stride_words, i64 N, i64 M, uint8_t *out) {
+    if (N <= 0 || M <= 0) return SYMGPU_OK;
+    const i64 n_chunks = (N * M) / 16 + 1;
+    const i64 span = (i64)256 * B2B_CHUNKS_PER_THREAD;
+    const i64 g = (n_chunks + span - 1) / span;
+    SG_REQUIRE(g < ((i64)1 << 31), "bits_to_bytes: table too large for one launch");
+    hipLaunchKernelGGL(k_bits_to_bytes_flat, dim3((unsigned)g), dim3(256), 0, ctx().stream, bits, stride_words, N, M, out);
+    KERNEL_CHECK();
+    return SYMGPU_OK;
 }
 
 static i64 round_up_i64(i64 x, i64 m) { return (x + m - 1) / m * m; }
@@ -126,9 +169,10 @@ int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *
         KERNEL_CHECK();
         bt_p = bt.p ? bt.as<u64>() : nullptr;
     }
-    // np.bool_ output: expanded by the kernel's own epilogue when rows can be written with aligned 16-byte stores, otherwise
-    // bit-packed rows to scratch + a separate expansion with byte stores
-    const bool fused_bytes = out && (M % 16 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    // np.bool_ output: expanded by the kernel's own epilogue, rows of any length at any base (unaligned 16-byte stores where they have to be).
+    // SYMGPU_M4R_UNFUSED=1: bit-packed rows to scratch + the flat expansion kernel (a second pass: 2.8 against 2.3 ms at 100,000^2 terms of 20
+    // qubits, but 0.30 against 0.36 ms at 30,000^2) — kept as the tested alternative.
+    const bool fused_bytes = out && !getenv("SYMGPU_M4R_UNFUSED");
     void *dst = out_bits;
     i64 stride = Mw;
     if (fused_bytes) {
@@ -139,15 +183,7 @@ int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *
         dst = bits.p;
     }
     SG_TRY(commutes_m4r7_launch(A, N, M, Wq, bt_p, Mw_pad, R, fused_bytes, dst, stride));
-    if (out && !fused_bytes) {
-        const i64 total = N * ((M + 15) / 16);
-        i64 g = (total + 255) / 256;
-        if (g > 65536) g = 65536;
-        const bool vec = (M % 16 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-        if (vec) hipLaunchKernelGGL(k_bits_to_bytes<true>, dim3((unsigned)g), dim3(256), 0, st, bits.as<u64>(), stride, N, M, out);
-        else hipLaunchKernelGGL(k_bits_to_bytes<false>, dim3((unsigned)g), dim3(256), 0, st, bits.as<u64>(), stride, N, M, out);
-        KERNEL_CHECK();
-    }
+    if (out && !fused_bytes) SG_TRY(bits_to_bytes_dev(bits.as<u64>(), stride, N, M, out));
     return SYMGPU_OK;
 }
 

@@ -157,6 +157,17 @@ __device__ __forceinline__ void m7_read2(u32x4 &a, u32x4 &c, u32 addr_a, u32 add
     asm volatile("ds_read_b128 %0, %1 offset:32768" : "=v"(c) : "v"(addr_b));
 }
 __device__ __forceinline__ void m7_pin(u32x4 &x) { asm volatile("" : "+v"(x)); }
+// 16 np.bool_ bytes of a row: one non-temporal 16-byte store wherever the row length and the base put it (an unaligned store costs a second
+// transaction where it straddles a cache line, not correctness), the columns past the end of the row byte by byte.  Round 6: rows that
+// are not a multiple of 16 bytes used to leave the kernel bit-packed for a second, byte-by-byte pass (100,008^2: 13 ms against 2.6 ms).
+__device__ __forceinline__ void m7_store16(uint8_t *dst, u32x4 v, i64 cols_left) {
+    typedef u32x4 u32x4_any __attribute__((aligned(1)));
+    if (cols_left >= 16) {
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4_any *>(dst));
+    } else {
+        for (int b = 0; b < (int)cols_left; ++b) dst[b] = (uint8_t)(v[b >> 2] >> (8 * (b & 3)));
+    }
+}
 // a lane index the optimiser cannot see through: what is computed from it stays where it is used (the epilogues' per-lane constants would
 // otherwise be hoisted out of the job loop and held in registers through the look-up stream, which has none to spare)
 __device__ __forceinline__ int m7_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
@@ -467,7 +478,7 @@ __global__ __launch_bounds__(64 * M7_WAVES) void k_commutes_m4r7s(const uint8_t 
                 for (int q = 0; q < 4 * rows_here * 2; ++q) {
                     const int half = q & 1, rl = q >> 1, s = rl / rows_here, jj = rl - s * rows_here;
                     const i64 i = wave_row0 + s * R + p0 + jj;
-                    const i64 col = (tile_w0 << 6) + half * 1024 + lane_e * 16;           // m_cols % 16 == 0: whole chunks in or out
+                    const i64 col = (tile_w0 << 6) + half * 1024 + lane_e * 16;
                     if (i < N && col < m_cols) {
                         const u32 b16 = *reinterpret_cast<const uint16_t *>(region + (s * RO + jj) * M7_ENTRY_BYTES + half * 128 + lane_e * 2);
                         u32x4 v;
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(64 * M7_WAVES) void k_commutes_m4r7s(const uint8_t 
                             const u32 x = (b16 >> (4 * k)) & 0xFu;
                             v[k] = (x | (x << 7) | (x << 14) | (x << 21)) & 0x01010101u;
                         }
-                        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out + i * out_stride + col));
+                        m7_store16(out + i * out_stride + col, v, m_cols - col);
                     }
                 }
                 __syncthreads();
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(256) void k_m7_fixup(const u64 *__restrict__ part, 
                 const u32 x = (b16 >> (4 * k)) & 0xFu;
                 v[k] = (x | (x << 7) | (x << 14) | (x << 21)) & 0x01010101u;
             }
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out + i * out_stride + col));
+            m7_store16(out + i * out_stride + col, v, m_cols - col);
         }
     } else {
         u64 *const out_bits = reinterpret_cast<u64 *>(out_v);

@@ -1110,6 +1110,35 @@ def test_commutes_m4r_tile_heights(r, M, monkeypatch):
     assert np.array_equal(kernels.commutes(a, b), expect)
 
 
+@pytest.mark.parametrize('force', ['1', '0'])
+@pytest.mark.parametrize('N,M,off', [(700, 2500, 3), (513, 1001, 8), (300, 15, 13), (64, 7, 1), (1100, 4099, 0), (5, 3, 5)])
+def test_commutes_any_row_length_any_alignment(N, M, off, force, monkeypatch):
+    """np.bool_ tables whose rows are not multiples of 16 (8) bytes, or whose base is not aligned, are computed as bit-packed rows and
+    written by the flat 16-byte expansion (commute_m4r.hip k_bits_to_bytes_flat: chunks that run over a row end, rows shorter than a
+    chunk, unaligned head and tail) — both commutation kernels, output at `off` bytes into a device buffer whose other bytes must
+    stay untouched."""
+    import ctypes
+    from symmer_amd import _lib
+    from symmer_amd.kernels import DeviceOp
+    monkeypatch.setenv('SYMGPU_COMMUTE_M4R', force)
+    rng = np.random.default_rng(400 + N + M)
+    n = 130
+    a = packing.pack_rows(rng.random((N, 2 * n)) < 0.3); b = packing.pack_rows(rng.random((M, 2 * n)) < 0.3)
+    A, B = DeviceOp.upload(a), DeviceOp.upload(b)
+    lib = _lib.lib()
+    total = N * M + 64
+    buf = ctypes.c_void_p()
+    _lib.check(lib.symgpu_dev_alloc(total, ctypes.byref(buf)))
+    junk = np.full(total, 0xEE, dtype=np.uint8)
+    _lib.check(lib.symgpu_dev_upload(buf, junk.ctypes.data, total))
+    _lib.check(lib.symgpu_commutes_dev(A.handle, 0, N, B.handle, ctypes.c_void_p(buf.value + off)))
+    got = np.empty(total, dtype=np.uint8)
+    _lib.check(lib.symgpu_dev_download(buf, got.ctypes.data, total))
+    assert np.array_equal(got[off:off + N * M].reshape(N, M).astype(bool), oc.commutes(a, b))
+    assert np.all(got[:off] == 0xEE) and np.all(got[off + N * M:] == 0xEE), 'bytes outside the table were written'
+    _lib.check(lib.symgpu_dev_free(buf)); A.free(); B.free()
+
+
 _STREAMK_REF = {}
 
 
@@ -1118,8 +1147,8 @@ _STREAMK_REF = {}
 @pytest.mark.parametrize('r', ['16', '24', '48'])
 def test_commutes_m4r_stream_k(r, M, mode, monkeypatch):
     """The stream-K launch of the Four-Russians kernel (csrc/commute_m4r7.hip): 17 row tiles x 16 column tiles = 272 tiles for the 256
-    persistent workgroups, so every workgroup's range starts and ends inside a tile; ragged last row and column tiles; M = 32752 the
-    byte epilogue, M = 32750 bit-packed rows + expansion.  `stream`: a split tile is finished by the owner of its first steps from
+    persistent workgroups, so every workgroup's range starts and ends inside a tile; ragged last row and column tiles; M = 32752 rows of
+    whole 16-byte chunks, M = 32750 a byte-wise row end and unaligned row starts.  `stream`: a split tile is finished by the owner of its first steps from
     the neighbour's published part; `fixup` (SYMGPU_M4R_FIXUP=1): both parts go to scratch and k_m7_fixup writes the tile — the path
     of a neighbour that has not run yet.  Both must equal, byte for byte, the table of the one-tile-per-workgroup launch
     (SYMGPU_M4R_STREAM=0: what fewer tiles than CUs take), which is checked against the C oracle on 48 random 256 x 256 blocks and on
