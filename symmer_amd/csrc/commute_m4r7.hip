@@ -21,7 +21,7 @@
 //   * waves 4..7 (one per SIMD) build the next tables BEFORE their look-ups, waves 0..3 after: a step no longer starts with all eight waves
 //     waiting for their first table entries at the same moment.
 //   * tables are written with ds_write_addtid_b32 (a wave stores one 256-byte entry per instruction, no address register).
-//   * every scalar of a step (index offsets, BT row offsets) comes from a table computed once (k_m7_steptab) and is fetched one step
+//   * every scalar of a step (index offsets, BT row offsets) comes from a table computed once (k_m7_klist) and is fetched one step
 //     ahead; the step's global requests are issued before the barrier that precedes it.  (Round 5 recomputed them at the top of every
 //     step behind four scalar loads: ~800 cycles of a 6,000-cycle step.)
 // What a step still costs beyond its 3,072 cycles of table reads: the builds (a wave's 32 entries take ~800 cycles whatever the chain
@@ -40,7 +40,7 @@
 //   BT[c][jw]  bit c of B rows 64jw..64jw+63 (the bit-major copy of commute_m4r.hip, cached on the operator); contraction bit c of A pairs
 //              with row c + 64Wq (c in the X half) or c - 64Wq (Z half).
 //   klist      the groups in which A has any non-zero value, ascending, padded to an even count with the zero group.
-//   steptab    per pair of groups: index offsets and BT row offsets (k_m7_steptab).
+//   steptab    per pair of groups: index offsets and BT row offsets (second half of k_m7_klist).
 #include "common.h"
 #include <stdlib.h>
 #include <stdio.h>
@@ -93,8 +93,12 @@ __global__ __launch_bounds__(256) void k_m7_a7(const u64 *__restrict__ rows, i64
     if (blockIdx.y == 0) A7[(i64)ng7 * Npad + i0 + r] = 0;            // the padding group
 }
 
-// compact the flagged groups (single wave; ascending) and pad to an even count with the zero group
-__global__ __launch_bounds__(64) void k_m7_klist(const u32 *__restrict__ flags, int ng7, u32 *__restrict__ klist, u32 *__restrict__ n_pairs) {
+// compact the flagged groups (single wave; ascending) and pad to an even count with the zero group; then the per-step scalars of the
+// stream-K kernel, computed once: entry p (16 u64) = { byte offset of group ga's index bytes in A7, same for gb, then for w = 0..6 the word
+// offsets of the BT rows that bit w of ga / of gb pairs with }.  Two entries behind the last pair point at the zero group / row 0, so the
+// kernel fetches entries t + 1 and t + 2 without asking whether they exist.
+__global__ __launch_bounds__(64) void k_m7_klist(const u32 *__restrict__ flags, int ng7, u32 *__restrict__ klist, u32 *__restrict__ n_pairs, int max_pairs, i64 Npad,
+                                                 i64 Mw_pad, int Wq, u64 *__restrict__ tab) {
     const int lane = threadIdx.x;
     u32 count = 0;
     for (int base = 0; base < ng7; base += 64) {
@@ -109,28 +113,24 @@ __global__ __launch_bounds__(64) void k_m7_klist(const u32 *__restrict__ flags, 
         if (count == 0) { klist[0] = klist[1] = (u32)ng7; count = 1; }   // an all-identity left operand: one step on the zero group (every workgroup owns >= 1 step)
         *n_pairs = (count + 1) / 2;
     }
-}
-
-// Per-step scalars of the stream-K kernel, computed once: entry p (16 u64) = { byte offset of group ga's index bytes in A7, same for gb,
-// then for w = 0..6 the word offsets of the BT rows that bit w of ga / of gb pairs with }.  Two entries behind the last pair point at
-// the zero group / row 0, so the kernel fetches entries t + 1 and t + 2 without asking whether they exist.
-__global__ __launch_bounds__(64) void k_m7_steptab(const u32 *__restrict__ klist, const u32 *__restrict__ n_pairs, int ng7, int max_pairs, i64 Npad, i64 Mw_pad, int Wq,
-                                                   u64 *__restrict__ tab) {
-    const int p = blockIdx.x * 64 + threadIdx.x;
-    if (p >= max_pairs + 2) return;
-    const bool live = (u32)p < *n_pairs;
-    const u32 ga = live ? klist[2 * p] : (u32)ng7, gb = live ? klist[2 * p + 1] : (u32)ng7;
+    __threadfence_block();
+    __syncthreads();                                                  // (one wave: orders the klist stores above before the loads below)
+    const u32 np = (count + 1) / 2 + (count == 0 ? 1u : 0u);
     const i64 half_bits = (i64)64 * Wq;
     auto bt_row = [&](u32 g, int r) -> i64 {                          // BT row that contraction bit 7g + r of A pairs with
         const i64 c = 7 * (i64)g + r;
         return c < half_bits ? c + half_bits : (c < 2 * half_bits ? c - half_bits : 0);   // (padding bits of the last group: A has zeros there)
     };
-    u64 *e = tab + (i64)p * 16;
-    e[0] = (u64)ga * (u64)Npad;
-    e[1] = (u64)gb * (u64)Npad;
-    for (int w = 0; w < 7; ++w) {
-        e[2 + 2 * w] = (u64)(bt_row(ga, w) * Mw_pad);
-        e[3 + 2 * w] = (u64)(bt_row(gb, w) * Mw_pad);
+    for (int p = lane; p < max_pairs + 2; p += 64) {
+        const bool live = (u32)p < np;
+        const u32 ga = live ? klist[2 * p] : (u32)ng7, gb = live ? klist[2 * p + 1] : (u32)ng7;
+        u64 *e = tab + (i64)p * 16;
+        e[0] = (u64)ga * (u64)Npad;
+        e[1] = (u64)gb * (u64)Npad;
+        for (int w = 0; w < 7; ++w) {
+            e[2 + 2 * w] = (u64)(bt_row(ga, w) * Mw_pad);
+            e[3 + 2 * w] = (u64)(bt_row(gb, w) * Mw_pad);
+        }
     }
 }
 
@@ -619,18 +619,17 @@ int commutes_m4r7_launch(const u64 *A, i64 N, i64 M, int Wq, const u64 *bt_p, i6
     const i64 Npad = (N + (i64)4 * M7_WAVES * R - 1) / ((i64)4 * M7_WAVES * R) * ((i64)4 * M7_WAVES * R);   // multiples of 256
     Scratch a7, flags, klist;
     SG_TRY(a7.alloc((size_t)(ng7 + 1) * Npad));
-    SG_TRY(flags.alloc((size_t)(ng7 + 1) * 4));
+    const size_t flag_bytes = ((size_t)(ng7 + 1) * 4 + 255) / 256 * 256;   // (a whole number of 256-byte pieces: one fill kernel, not a body and a tail)
+    SG_TRY(flags.alloc(flag_bytes));
     SG_TRY(klist.alloc((size_t)(ng7 + 2) * 4));
-    HIP_TRY(hipMemsetAsync(flags.p, 0, (size_t)(ng7 + 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(flags.p, 0, flag_bytes, st));
     hipLaunchKernelGGL(k_m7_a7, dim3((unsigned)(Npad / 256), (unsigned)((W + A7_CW - 1) / A7_CW)), dim3(256), 0, st, A, N, W, ng7, a7.as<uint8_t>(), Npad, flags.as<u32>());
     KERNEL_CHECK();
     u32 *np = flags.as<u32>() + ng7;
-    hipLaunchKernelGGL(k_m7_klist, dim3(1), dim3(64), 0, st, flags.as<u32>(), ng7, klist.as<u32>(), np);
-    KERNEL_CHECK();
     Scratch steptab;
     const int max_pairs = (ng7 + 1) / 2;
     SG_TRY(steptab.alloc((size_t)(max_pairs + 2) * 16 * 8));
-    hipLaunchKernelGGL(k_m7_steptab, dim3((unsigned)((max_pairs + 2 + 63) / 64)), dim3(64), 0, st, klist.as<u32>(), np, ng7, max_pairs, Npad, Mw_pad, Wq, steptab.as<u64>());
+    hipLaunchKernelGGL(k_m7_klist, dim3(1), dim3(64), 0, st, flags.as<u32>(), ng7, klist.as<u32>(), np, max_pairs, Npad, Mw_pad, Wq, steptab.as<u64>());
     KERNEL_CHECK();
     ProfScope prof(1);
 #define M7S_ARGS a7.as<uint8_t>(), Npad, N, bt_p, Mw_pad, steptab.as<u64>(), np, dst, stride, M, bytes
