@@ -121,20 +121,25 @@ int bits_to_bytes_dev(const u64 *bits, i64 stride_words, i64 N, i64 M, uint8_t *
 static i64 round_up_i64(i64 x, i64 m) { return (x + m - 1) / m * m; }
 
 // tile heights: R rows per 16-lane slot -> 32 R rows per workgroup.  Taller tiles amortise the tables over more rows (round 5, 200,000^2
-// terms at n = 2000: R = 16 / 24 / 48 -> 60.0 / 50.8 / 36.1 ms); the stream-K launch (commute_m4r7.hip) balances any tile count over the
-// CUs, so the tallest height with at least one tile per CU is taken.  SYMGPU_M4R_R forces one (tests).
+// terms at n = 2000: R = 16 / 24 / 48 -> 60.0 / 50.8 / 36.1 ms), but a workgroup finishes a tile with a store phase no other work on its CU
+// hides, so a launch wants several tiles per CU for the stores of one workgroup to fall under the lookups of the others — the more, the
+// shorter the tile's lookup phase is.  Measured (round 6, profiles/r06_m4r_pick.txt, n in 20..2000 x N in 20,000..100,000): the tallest
+// height with  tiles x steps-per-tile >= 200 x CUs  is within 5 % of the best of the three everywhere; below 32 steps (n <= 192: rows of at
+// most three words a half) the table is bound by its own bytes and R = 16 is never beaten.  SYMGPU_M4R_R forces one (tests).
 static i64 m4r_workgroups(i64 N, i64 M, int R) {
     const i64 Mw = (M + 63) / 64;
     return ((N + 32 * R - 1) / (32 * R)) * ((Mw + MK_TILE_W - 1) / MK_TILE_W);
 }
-static int m4r_pick(i64 N, i64 M) {
+static int m4r_pick(i64 N, i64 M, int Wq) {
     if (const char *e = getenv("SYMGPU_M4R_R")) {
         const int r = atoi(e);
         if (r == 16 || r == 24 || r == 48) return r;
     }
+    const i64 steps = ((128 * (i64)Wq + 6) / 7 + 1) / 2;
+    if (steps < 32) return 16;
     const int cand[2] = {48, 24};
     for (int R : cand)
-        if (m4r_workgroups(N, M, R) >= ctx().num_cu) return R;
+        if (m4r_workgroups(N, M, R) * steps >= (i64)200 * ctx().num_cu) return R;
     return 16;
 }
 // enough 512 x 2048 tiles to occupy most of the chip (below that the register-tile kernel wins: 1024 x 16384 at n = 2000 takes
@@ -148,7 +153,7 @@ int commutes_m4r_dev(const u64 *A, i64 N, const u64 *B, i64 M, int Wq, uint8_t *
     if (N == 0 || M == 0) return SYMGPU_OK;
     hipStream_t st = ctx().stream;
     const int W = 2 * Wq;
-    const int R = m4r_pick(N, M);
+    const int R = m4r_pick(N, M, Wq);
     const i64 Mw = (M + 63) / 64, Mw_pad = round_up_i64(Mw, MK_TILE_W);
     Scratch bt, bits;
     // the bit-major copy of B is cached on its operator (an adjacency matrix computed slab by slab transposes B once)

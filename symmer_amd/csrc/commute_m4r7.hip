@@ -54,6 +54,8 @@ typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int M7_TILE_W = 32;                          // 64-bit words per column tile: 2048 columns
 constexpr int M7_ENTRY_BYTES = M7_TILE_W * 8;          // 256
+constexpr int M7_STREAM_MIN_WORK = 125;                // tile-steps per persistent workgroup from which it pays
+constexpr int M7_STREAM_MIN_STEPS = 32;                // steps a tile (pairs of 7-bit groups of the padded row: 28 at n <= 192, 37 above) from which the stream-K launch pays
 constexpr int M7_TABLE_BYTES = 128 * M7_ENTRY_BYTES;   // 32 KiB: one 7-bit group
 constexpr int M7_BUF_BYTES = 2 * M7_TABLE_BYTES;       // the two tables of a step
 constexpr int M7_LDS = 2 * M7_BUF_BYTES;               // double buffered: 128 KiB
@@ -565,17 +567,20 @@ __global__ __launch_bounds__(256) void k_m7_fixup(const u64 *__restrict__ part, 
 }
 
 template <int R, int LOOKP, int CH, int NS>
-static int launch_m7s(const uint8_t *A7, i64 Npad, i64 N, const u64 *BT, i64 Mw_pad, const u64 *steptab, const u32 *np, void *out, i64 stride, i64 M, bool bytes) {
+static int launch_m7s(const uint8_t *A7, i64 Npad, i64 N, const u64 *BT, i64 Mw_pad, const u64 *steptab, const u32 *np, void *out, i64 stride, i64 M, bool bytes, int max_steps) {
     const bool attr = SG_DEVICE_ONCE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_commutes_m4r7s<R, LOOKP, CH, NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                          M7S_LDS) == hipSuccess);
     if (!attr) { set_error("commutes_m4r7: %d bytes of LDS refused", M7S_LDS); return SYMGPU_E_HIP; }
     constexpr i64 WG_ROWS = 4 * M7_WAVES * R;
     const i64 n_rt = Npad / WG_ROWS, n_ct = Mw_pad / M7_TILE_W, n_tiles = n_rt * n_ct;
     const int P = ctx().num_cu;
-    // runtime switches ("Environment switches"): both force a path the kernel takes by itself — fewer tiles than compute units; a
-    // neighbour whose part is not published yet
-    bool stream = n_tiles >= P;
-    if (const char *e = getenv("SYMGPU_M4R_STREAM")) stream = stream && atoi(e) != 0;
+    // one tile per workgroup where the persistent launch's published parts only cost: short operators (below M7_STREAM_MIN_STEPS steps a
+    // tile the table is bound by its own bytes — 30,000^2 terms of 20 / 100 / 150 qubits, R = 16: 0.339 / 0.370 / 0.372 ms streamed against
+    // 0.284 / 0.307 / 0.339 ms tile by tile), launches of little work (20,000^2 terms of 200 / 300 / 400 qubits: 0.220 / 0.238 / 0.259 against
+    // 0.189 / 0.219 / 0.254 ms; the streamed launch wins from about 125 tile-steps per workgroup) and fewer tiles than compute units
+    // (profiles/r06_m4r_pick.txt).  Runtime switches ("Environment switches"): both force a path the kernel takes by itself.
+    bool stream = n_tiles >= P && max_steps >= M7_STREAM_MIN_STEPS && n_tiles * max_steps >= (i64)M7_STREAM_MIN_WORK * P;
+    if (const char *e = getenv("SYMGPU_M4R_STREAM")) stream = n_tiles >= P && atoi(e) != 0;
     const int force_fixup = getenv("SYMGPU_M4R_FIXUP") ? 1 : 0;
     Scratch part, dbgbuf;
     Context &c = ctx();
@@ -632,7 +637,7 @@ int commutes_m4r7_launch(const u64 *A, i64 N, i64 M, int Wq, const u64 *bt_p, i6
     hipLaunchKernelGGL(k_m7_klist, dim3(1), dim3(64), 0, st, flags.as<u32>(), ng7, klist.as<u32>(), np, max_pairs, Npad, Mw_pad, Wq, steptab.as<u64>());
     KERNEL_CHECK();
     ProfScope prof(1);
-#define M7S_ARGS a7.as<uint8_t>(), Npad, N, bt_p, Mw_pad, steptab.as<u64>(), np, dst, stride, M, bytes
+#define M7S_ARGS a7.as<uint8_t>(), Npad, N, bt_p, Mw_pad, steptab.as<u64>(), np, dst, stride, M, bytes, max_pairs
     if (R == 48) SG_TRY((launch_m7s<48, 3, 8, 3>(M7S_ARGS)));
     else if (R == 24) SG_TRY((launch_m7s<24, 4, 8, 3>(M7S_ARGS)));
     else SG_TRY((launch_m7s<16, 4, 4, 4>(M7S_ARGS)));

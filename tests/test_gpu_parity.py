@@ -1164,7 +1164,6 @@ def test_commutes_m4r_stream_k(r, M, mode, monkeypatch):
         a[5] = 0                                                      # an identity row
         monkeypatch.setenv('SYMGPU_M4R_STREAM', '0')
         ref = kernels.commutes(a, b)
-        monkeypatch.delenv('SYMGPU_M4R_STREAM')
         for _ in range(48):
             r0, c0 = int(rng.integers(0, N - 256)), int(rng.integers(0, M - 256))
             assert np.array_equal(ref[r0:r0 + 256, c0:c0 + 256], oc.commutes(a[r0:r0 + 256], b[c0:c0 + 256]))
@@ -1172,6 +1171,7 @@ def test_commutes_m4r_stream_k(r, M, mode, monkeypatch):
         assert ref[5].all()
         _STREAMK_REF[key] = (a, b, ref)
     a, b, ref = _STREAMK_REF[key]
+    monkeypatch.setenv('SYMGPU_M4R_STREAM', '1')                      # (operators this short take one tile per workgroup by themselves)
     if mode == 'fixup':
         monkeypatch.setenv('SYMGPU_M4R_FIXUP', '1')
     got = kernels.commutes(a, b)
@@ -1180,7 +1180,7 @@ def test_commutes_m4r_stream_k(r, M, mode, monkeypatch):
 
 def test_commutes_m4r_all_identity_left_operand(monkeypatch):
     """An all-identity left operand has no non-zero 7-bit group: the kernel runs one step on the zero group and everything commutes."""
-    monkeypatch.setenv('SYMGPU_COMMUTE_M4R', '1')
+    monkeypatch.setenv('SYMGPU_COMMUTE_M4R', '1'); monkeypatch.setenv('SYMGPU_M4R_STREAM', '1')
     rng = np.random.default_rng(79)
     a = np.zeros((8704, 4), dtype='<u8'); b = packing.pack_rows(rng.random((32768, 200)) < 0.3)
     assert kernels.commutes(a, b).all()
