@@ -1934,16 +1934,23 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp, first_hist));
                 } else {
                     const int lo = 64 - nbits, hi = lo + 8 * sus_pass;
-                    SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, lo, hi, &in_tmp, first_hist));
-                    u64 *part = in_tmp ? keys2.as<u64>() : keys.as<u64>(), *spare = in_tmp ? keys.as<u64>() : keys2.as<u64>();
                     const i64 n_sc = (Tk + 63) / 64;
                     Scratch susbits, susprefix;
                     SG_TRY(susbits.alloc((size_t)n_sc * 8 + 16));
                     SG_TRY(susprefix.alloc((size_t)n_sc * 4));
-                    u32 *sustotal = susbits.as<u32>() + 2 * n_sc;          // [0] flagged keys, [1] a run too long for the flag pass (one memset with the flags)
+                    u32 *sustotal = susbits.as<u32>() + 2 * n_sc;          // [0] flagged keys, [1] the flag pass gave up (one memset with the flags)
                     SG_TRY(zero_two(susbits.p, (size_t)n_sc * 8 + 16, nullptr, 0));
-                    hipLaunchKernelGGL(k_find_suspects, dim3((unsigned)((Tk + SUS_TILE - 1) / SUS_TILE)), dim3(64 * SUS_WAVES), 0, st, part, Tk, L, hI.as<u64>(),
-                                       hO_p, susbits.as<u64>(), sustotal + 1);
+                    // round 6: operands whose bucketed hash words fit a workgroup's LDS — the flags come from the operand hash tables, the
+                    // keys are never sorted (pair_dups.hip); they stay in index order and the flags are indexed likewise
+                    bool direct = false;
+                    SG_TRY(pair_dups_dev(hI.as<u64>(), Ni, hO_p, No, squared, Tk, susbits.as<u64>(), sustotal + 1, &direct));
+                    u64 *part = keys.as<u64>(), *spare = keys2.as<u64>();
+                    if (!direct) {
+                        SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, lo, hi, &in_tmp, first_hist));
+                        part = in_tmp ? keys2.as<u64>() : keys.as<u64>(); spare = in_tmp ? keys.as<u64>() : keys2.as<u64>();
+                        hipLaunchKernelGGL(k_find_suspects, dim3((unsigned)((Tk + SUS_TILE - 1) / SUS_TILE)), dim3(64 * SUS_WAVES), 0, st, part, Tk, L, hI.as<u64>(),
+                                           hO_p, susbits.as<u64>(), sustotal + 1);
+                    }
                     if (n_sc <= POPC_SCAN_SMALL_MAX) SG_TRY(popc_scan_small(susbits.as<u64>(), n_sc, -1, susprefix.as<u32>(), sustotal));
                     else {
                         hipLaunchKernelGGL(k_popc_words64, dim3(grid_for(n_sc)), dim3(256), 0, st, susbits.as<u64>(), n_sc, susprefix.as<u32>());
@@ -1963,9 +1970,10 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     }
                     const u32 h_sus = h_sus2[0];
                     if ((i64)h_sus * 16 > Tk || sus_giveup || h_sus2[1]) {
-                        // repeated rows all over: the last pass on the whole array after all (LSD: the order so far is its first passes)
+                        // repeated rows all over: the last pass on the whole array after all (LSD: the order so far is its first passes; the
+                        // direct flag pass left the keys in index order: all passes)
                         bool in_tmp2 = false;
-                        SG_TRY(radix_sort_keys_u64(part, spare, Tk, hi, 64, &in_tmp2));
+                        SG_TRY(radix_sort_keys_u64(part, spare, Tk, direct ? lo : hi, 64, &in_tmp2, direct ? first_hist : nullptr));
                         if (in_tmp2) in_tmp = !in_tmp;
                     } else {
                         sus_active = true;
@@ -1979,7 +1987,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                             fix_bits = want_s < hash_bits ? want_s : hash_bits;
                             // the compaction kept the array order, i.e. the flagged keys are ordered by key bits [lo, hi) already: when the bits to
                             // order start inside that range only the passes above it are left (LSD: stable passes on more significant bits)
-                            const int sort_from = (64 - fix_bits >= lo && 64 - fix_bits < hi) ? hi : 64 - fix_bits;
+                            const int sort_from = (!direct && 64 - fix_bits >= lo && 64 - fix_bits < hi) ? hi : 64 - fix_bits;
                             bool in_tmp_s = false, coop_done = false;
                             SG_TRY(radix_sort_keys_u64_coop(spare, part, Tsort, sort_from, 64, &in_tmp_s, &coop_done));
                             sus_coop = coop_done;

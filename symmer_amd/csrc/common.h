@@ -282,6 +282,9 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W,          //
                  const double *ci = nullptr, const double *co = nullptr, int inner_is_left = 1,    // pair mode: operand coefficients
                  bool want_first = false);                                                          // the result carries symgpu_op_s::first
 
+// pair_dups.hip — the pairs of a product whose 64-bit key another pair shares, found without sorting the keys
+int pair_dups_dev(const u64 *hI, i64 Ni, const u64 *hO, i64 No, bool squared, i64 Tk, u64 *flags, u32 *giveup, bool *applies);
+
 // gf2.hip
 int rref_dev(u64 *rows, i64 R, i64 Wc, i64 *xor_count, i64 *pivots_host);
 

@@ -285,13 +285,22 @@ class PauliwordOp:
     # NumPy sorts on the same score vectors as the reference, so ties fall the same way.
     _ORDERINGS = {
         'magnitude': lambda P: np.argsort(-abs(P._c())),
-        'lex': lambda P: np.lexsort(P.symp_matrix.T) if P.n_terms else np.zeros(0, dtype=int),    # last column = primary key
+        'lex': lambda P: P._lex_order(),
         'weight': lambda P: np.argsort(-P.symp_matrix.sum(axis=1, dtype=int)),
         'support': lambda P: P._support_order(),
         'Z': lambda P: np.argsort(P._xz_score(P.n_qubits + 1, 1)),
         'X': lambda P: np.argsort(P._xz_score(1, P.n_qubits + 1)),
         'Y': lambda P: np.argsort(np.abs(P.X_block.astype(int) - P.Z_block.astype(int)).sum(axis=1)),
     }
+
+    def _lex_order(self) -> np.ndarray:
+        """``np.lexsort(symp_matrix.T)`` (last column = primary key) from the packed rows: column j is bit j % 64 of word j // 64 of its
+        half, so the 2 Wq words taken as sort keys in storage order (last word primary) order the rows exactly as the 2n columns do."""
+        if not self.n_terms:
+            return np.zeros(0, dtype=int)
+        if not self.n_qubits:
+            return np.lexsort(self.symp_matrix.T)
+        return np.lexsort(self.packed.T)
 
     def sort(self, by: str = 'magnitude', key: str = 'decreasing') -> "PauliwordOp":
         """Terms re-ordered by one of ``_ORDERINGS`` (``__eq__`` relies on ``'lex'``); same names and errors as base.py:455-492."""
@@ -374,14 +383,18 @@ class PauliwordOp:
 
     def __eq__(self, Pword: "PauliwordOp") -> bool:
         """base.py:640-662: cleanup + lexicographic sort on both sides, exact rows, ``np.allclose`` coefficients."""
-        check_1 = self.cleanup().sort('lex')
-        check_2 = Pword.cleanup().sort('lex')
+        check_1 = self.cleanup()
+        check_2 = Pword.cleanup()
         if check_1.n_qubits != check_2.n_qubits:
             raise ValueError('Operators defined over differing numbers of qubits.')
         if check_1.n_terms != check_2.n_terms:
             return False
-        return bool(not np.sum(np.logical_xor(check_1.symp_matrix, check_2.symp_matrix)) and
-                    np.allclose(check_1._c(), check_2._c()))
+        if not check_1.n_qubits:
+            return bool(np.allclose(check_1._c(), check_2._c()))
+        # both sides in lexicographic order, compared on the packed rows (the bool matrices are never formed)
+        order_1, order_2 = check_1._lex_order(), check_2._lex_order()
+        return bool(np.array_equal(check_1.packed[order_1], check_2.packed[order_2]) and
+                    np.allclose(check_1._c()[order_1], check_2._c()[order_2]))
 
     def __hash__(self) -> int:
         return hash(tuple(self.to_dictionary.items()))
