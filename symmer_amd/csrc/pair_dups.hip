@@ -11,7 +11,7 @@
 // all a.  A persistent workgroup takes the product buckets beta one after the other, with the bucketed hash words of the operands in its LDS:
 //   tiles   per a: the size of tile (a, a ^ beta); a block scan gives every tile its first pair number (P * P: only the tiles a < a ^ beta —
 //           the tile (a ^ beta, a) holds the same pairs; beta = 0, pairs inside one bucket, takes a loop of its own);
-//   count   every lane takes q = ceil(P / 1024) consecutive pair numbers: finds its first tile by bisection and walks on from there — one
+//   count   every lane takes q = ceil(P / 1024) consecutive pair numbers: the tile's owner has left it its first tile and place, it walks on from there — one
 //           LDS read, one XOR and one returning LDS add on a 4-bit counter per pair, the key words stay in registers;
 //   list    a pair whose counter had been hit before, or reads >= 2 now, is listed (4 % of them: chance hits included);
 //   match   the listed words are chained by a 2,048-way LDS hash; a listed pair walks its chain, an equal word is followed up with the 64-bit
@@ -30,7 +30,7 @@ constexpr int PD_THREADS = 1024;
 constexpr int PD_QUOTA = 16;                        // pairs per lane and product bucket: 16,384 pairs per bucket at most
 constexpr int PD_TARGET = 12288;                    // pairs per product bucket the bucket width is chosen for
 constexpr int PD_SLOT_BITS = 17;                    // 4-bit counters: 64 KiB
-constexpr int PD_CAND = 2048, PD_CHAIN = 2048;
+constexpr int PD_CAND = 1536, PD_CHAIN = 1024;
 constexpr int PD_MAX_B = 13;
 constexpr int PD_MAX_BUCKET = 255;                  // terms per operand bucket (longer: the hashes are not spread — repeated rows)
 constexpr size_t PD_LDS_MAX = 160 * 1024 - 256;
@@ -98,52 +98,97 @@ __device__ __forceinline__ u64 pd_hash(const PairDupArgs &a, u32 xy) {
     return a.tab_h[xy & 0xFFFFu] ^ a.tab_h[(a.squared ? 0u : (u32)a.nI) + (xy >> 16)];
 }
 
+// LDS of k_pair_dups, in this order (pd_lds_bytes is the host's copy of the sum)
+//   s_w      [nI + nO] u32   hash words, bucket order: inner table, then the outer one
+//   s_cnt    64 KiB          4-bit counters, eight per word
+//   s_tiles  [cap] 2 x u32   non-empty tiles: {first inner position | end << 16, first outer position | end << 16}
+//   s_lw, s_lxy, s_next [PD_CAND] u32, s_head [PD_CHAIN] u32      listed pairs: word, positions, chain link; chain heads
+//   s_lane   [1024] u32      where a lane's first pair lies: tile << 16 | pair number inside the tile
+//   s_sI, s_sO [nb + 4] u16  bucket starts of the two tables (P * P: one)
+__host__ __device__ inline size_t pd_tile_cap(int nb, int squared) { return squared ? (size_t)nb / 2 + 4 : (size_t)nb; }
+__host__ __device__ inline size_t pd_lds_bytes(int nTab, int nb, int squared) {
+    return (size_t)((nTab + 3) & ~3) * 4 + ((size_t)1 << (PD_SLOT_BITS - 3)) * 4 + pd_tile_cap(nb, squared) * 8 + (size_t)PD_CAND * 12 + (size_t)PD_CHAIN * 4 +
+           (size_t)PD_THREADS * 4 + (size_t)(squared ? 1 : 2) * (nb + 4) * 2;
+}
+
+#ifdef SYMGPU_PD_STAMPS
+__device__ u64 g_pd_stamps[8];
+#define PD_STAMP(i) do { const u64 tn_ = __builtin_readcyclecounter(); acc_[i] += tn_ - ts_; ts_ = tn_; } while (0)
+#else
+#define PD_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = PD_THREADS;
     const int nb = 1 << a.B, nTab = a.nI + a.nO;
-    u32 *s_w = reinterpret_cast<u32 *>(smem);                                  // [nTab]: inner table, then the outer one
-    u32 *s_cnt = s_w + ((nTab + 3) & ~3);                                      // 4-bit counters, eight per word
-    u32 *s_tiles = s_cnt + (1 << (PD_SLOT_BITS - 3));                          // [nb]: first pair number << 13 | a
-    u32 *s_lw = s_tiles + nb;                                                  // listed pairs: word, positions, chain link
+    u32 *s_w = reinterpret_cast<u32 *>(smem);
+    u32 *s_cnt = s_w + ((nTab + 3) & ~3);
+    uint2 *s_tiles = reinterpret_cast<uint2 *>(s_cnt + (1 << (PD_SLOT_BITS - 3)));
+    u32 *s_lw = reinterpret_cast<u32 *>(s_tiles + pd_tile_cap(nb, a.squared));
     u32 *s_lxy = s_lw + PD_CAND;
     u32 *s_next = s_lxy + PD_CAND;
-    u32 *s_head = s_next + PD_CAND;                                            // [PD_CHAIN]
-    unsigned short *s_sI = reinterpret_cast<unsigned short *>(s_head + PD_CHAIN);   // [nb + 1] bucket starts of the inner table
-    unsigned short *s_sO = a.squared ? s_sI : s_sI + (nb + 2);                 // ... and of the outer one
-    __shared__ u32 s_wsum[16], s_wtil[16], s_nc, s_total, s_ntiles, s_over;
+    u32 *s_head = s_next + PD_CAND;
+    u32 *s_lane = s_head + PD_CHAIN;
+    unsigned short *s_sI = reinterpret_cast<unsigned short *>(s_lane + NT);
+    unsigned short *s_sO = a.squared ? s_sI : s_sI + (nb + 4);
+    __shared__ u32 s_wsum[16], s_wtil[16], s_nc, s_over;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (*a.giveup & 8u) return;                                                 // a bucket longer than the positions below can address: not for this path
     const u32 *s_wO = a.squared ? s_w : s_w + a.nI;
     for (int i = tid; i < nTab; i += NT) s_w[i] = a.tab_w[i];
-    for (int i = tid; i <= nb; i += NT) { s_sI[i] = a.start[i]; if (!a.squared) s_sO[i] = a.start[nb + 1 + i]; }
+    for (int i = tid; i < nb + 4; i += NT) {                                    // (padded with the table's length: the groups of four below read one start past theirs)
+        s_sI[i] = i <= nb ? a.start[i] : (unsigned short)a.nI;
+        if (!a.squared) s_sO[i] = i <= nb ? a.start[nb + 1 + i] : (unsigned short)a.nO;
+    }
     __syncthreads();
     // P * P: the diagonal (the identity, N pairs) is flagged as it is
     if (a.squared)
         for (int x = blockIdx.x * NT + tid; x < a.nI; x += gridDim.x * NT) pd_flag(a, (u32)x, (u32)x);
+    const int n_grp = nb >= 4 * NT ? nb / (4 * NT) : 1;                         // groups of four buckets per lane (nb = 8192: two)
+#ifdef SYMGPU_PD_STAMPS
+    u64 acc_[6] = {0, 0, 0, 0, 0, 0}, ts_ = __builtin_readcyclecounter();
+#endif
     for (int beta = blockIdx.x; beta < nb; beta += gridDim.x) {
+        PD_STAMP(5);
         {
             const u32x4 z = {0u, 0u, 0u, 0u};
             for (int i = tid; i < (1 << (PD_SLOT_BITS - 5)); i += NT) reinterpret_cast<u32x4 *>(s_cnt)[i] = z;
         }
         for (int i = tid; i < PD_CHAIN; i += NT) s_head[i] = 0xFFFFFFFFu;
+        s_lane[tid] = 0u;
         if (tid == 0) { s_nc = 0; s_over = 0; }
         const bool inside = a.squared && beta == 0;                             // pairs inside one bucket: no tiles, a loop per bucket
-        u32 P = 0, ntl = 0;
-        u32 hw[PD_QUOTA], xy[PD_QUOTA], old[PD_QUOTA];
-        u32 rem = 0;
+        u32 hw[PD_QUOTA], xy[PD_QUOTA];
+        u32 rem = 0, sat = 0;
         if (!inside) {
-            // ---- tiles of this product bucket: sizes, scan, list of the non-empty ones
-            const int per = (nb + NT - 1) / NT;
-            u32 mysum = 0, mytiles = 0;
-            for (int k = 0; k < per; ++k) {
-                const int av = tid * per + k;
-                if (av < nb) {
-                    const int b = av ^ beta;
-                    const u32 ca = s_sI[av + 1] - s_sI[av], cb = s_sO[b + 1] - s_sO[b];
-                    const u32 c = (!a.squared || av < b) ? ca * cb : 0u;
-                    mysum += c; mytiles += c ? 1u : 0u;
+            // ---- tiles of this product bucket: sizes (a lane: groups of four consecutive buckets a — their partners a ^ beta are a group of
+            //      four as well), scan, list of the non-empty ones with the lanes whose first pair lies in them
+            // (a group's twelve values are formed twice, before and behind the scan, rather than kept: registers)
+            auto group = [&](int g, u32 (&tsz)[4], u32 (&tax)[4], u32 (&tby)[4]) {
+                const int a0 = 4 * (tid + g * NT);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { tsz[j] = 0; tax[j] = 0; tby[j] = 0; }
+                if (a0 < nb) {
+                    const int b0 = a0 ^ (beta & ~3), bj = beta & 3;
+                    const uint2 ia = *reinterpret_cast<const uint2 *>(s_sI + a0), ib = *reinterpret_cast<const uint2 *>(s_sO + b0);
+                    const u32 sa[5] = {ia.x & 0xFFFFu, ia.x >> 16, ia.y & 0xFFFFu, ia.y >> 16, (u32)s_sI[a0 + 4]};
+                    const u32 sbv[5] = {ib.x & 0xFFFFu, ib.x >> 16, ib.y & 0xFFFFu, ib.y >> 16, (u32)s_sO[b0 + 4]};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int jb = j ^ bj;
+                        u32 lo_b = sbv[0], hi_b = sbv[1];
+                        if (jb == 1) { lo_b = sbv[1]; hi_b = sbv[2]; } else if (jb == 2) { lo_b = sbv[2]; hi_b = sbv[3]; } else if (jb == 3) { lo_b = sbv[3]; hi_b = sbv[4]; }
+                        tsz[j] = (!a.squared || (a0 + j) < (b0 + jb)) ? (sa[j + 1] - sa[j]) * (hi_b - lo_b) : 0u;
+                        tax[j] = sa[j] | (sa[j + 1] << 16); tby[j] = lo_b | (hi_b << 16);
+                    }
                 }
+            };
+            u32 mysum = 0, mytiles = 0;
+            for (int g = 0; g < n_grp; ++g) {
+                u32 tsz[4], tax[4], tby[4];
+                group(g, tsz, tax, tby);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { mysum += tsz[j]; mytiles += tsz[j] ? 1u : 0u; }
             }
             u32 inc_s = mysum, inc_t = mytiles;                                 // (two sums: a tile holds up to 255 x 255 pairs)
             for (int off = 1; off < 64; off <<= 1) {
@@ -152,65 +197,75 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
             }
             if (lane == 63) { s_wsum[wave] = inc_s; s_wtil[wave] = inc_t; }
             __syncthreads();
-            u32 base_s = 0, base_t = 0;
-            for (int w2 = 0; w2 < wave; ++w2) { base_s += s_wsum[w2]; base_t += s_wtil[w2]; }
-            if (tid == NT - 1) { s_total = base_s + inc_s; s_ntiles = base_t + inc_t; }
-            {
-                u32 off = base_s + inc_s - mysum, tix = base_t + inc_t - mytiles;
-                for (int k = 0; k < per; ++k) {
-                    const int av = tid * per + k;
-                    if (av < nb) {
-                        const int b = av ^ beta;
-                        const u32 ca = s_sI[av + 1] - s_sI[av], cb = s_sO[b + 1] - s_sO[b];
-                        const u32 c = (!a.squared || av < b) ? ca * cb : 0u;
-                        if (c) { if (off < (1u << 19)) s_tiles[tix] = (off << 13) | (u32)av; ++tix; off += c; }
-                    }
-                }
-            }
-            __syncthreads();
-            P = s_total; ntl = s_ntiles;
+            u32 base_s = 0, base_t = 0, P = 0, ntl = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NT / 64; ++w2) { const u32 vs = s_wsum[w2], vt = s_wtil[w2]; P += vs; ntl += vt; if (w2 < wave) { base_s += vs; base_t += vt; } }
             if (P > (u32)(PD_QUOTA * NT)) {                                     // (block-uniform)
                 if (tid == 0) atomicOr(a.giveup, 1u);
                 __syncthreads();
                 continue;
             }
             if (P == 0) { __syncthreads(); continue; }
-            // ---- count: a lane takes q consecutive pairs; words, positions and counter answers stay in registers
-            const u32 q = (u32)__builtin_amdgcn_readfirstlane((int)((P + NT - 1) / NT));   // block-uniform
+            const u32 q = (u32)__builtin_amdgcn_readfirstlane((int)((P + NT - 1) / NT));   // pairs per lane, block-uniform
+            const u32 qinv = ((1u << 20) + q - 1) / q;                         // x / q = (x * qinv) >> 20 for x < 2^15, q <= 32
+            {
+                u32 off = base_s + inc_s - mysum, tix = base_t + inc_t - mytiles;
+                for (int g = 0; g < n_grp; ++g) {
+                    u32 tsz[4], tax[4], tby[4];
+                    group(g, tsz, tax, tby);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const u32 c = tsz[j];
+                        if (c) {
+                            s_tiles[tix] = uint2{tax[j], tby[j]};
+                            for (u32 L = ((off + q - 1) * qinv) >> 20; L * q < off + c; ++L) s_lane[L] = (tix << 16) | (L * q - off);
+                            ++tix; off += c;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            PD_STAMP(0);
+            // ---- count: a lane takes q consecutive pairs.  First the words and positions of all of them (reads only), then the returning adds
+            //      back to back: LDS answers come back in order, a read behind an add would wait for it
             const u32 p0 = tid * q;
             rem = p0 < P ? (P - p0 < q ? P - p0 : q) : 0u;
             {
-                int lo = 0, hi = (int)ntl - 1;                                  // last tile that starts at or before p0
-                const u32 ps = p0 < P ? p0 : 0u;
-                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((s_tiles[mid] >> 13) <= ps) lo = mid; else hi = mid - 1; }
-                u32 t = (u32)lo;
-                u32 td = s_tiles[t];
-                u32 av = td & 0x1FFFu, b = av ^ (u32)beta;
-                u32 sb = s_sO[b];
-                const u32 cb = s_sO[b + 1] - sb;
-                const u32 r = ps - (td >> 13);
-                const u32 x0 = r / cb, y0 = r - x0 * cb;
-                u32 ax = s_sI[av] + x0, ax_end = s_sI[av + 1], ay = sb + y0, ay_end = sb + cb;
+                const u32 e = s_lane[tid];
+                u32 t = e >> 16;
+                uint2 d = s_tiles[t];
+                u32 ax_end = d.x >> 16, sb = d.y & 0xFFFFu, ay_end = d.y >> 16;
+                const u32 cb = ay_end - sb, r = e & 0xFFFFu;
+                const u32 x0 = (u32)__fdividef((float)r + 0.5f, (float)cb);
+                u32 ax = (d.x & 0xFFFFu) + x0, ay = sb + (r - x0 * cb);
                 u32 wI = s_w[ax];
 #pragma unroll
                 for (int k = 0; k < PD_QUOTA; ++k) {
                     if ((u32)k < q) {                                            // (scalar)
-                        const u32 v = wI ^ s_wO[ay];
-                        hw[k] = v; xy[k] = ax | (ay << 16);
-                        const u32 incr = (u32)k < rem ? 1u << pd_cnt_shift(v) : 0u;
-                        old[k] = atomicAdd(&s_cnt[pd_cnt_word(v)], incr);
+                        hw[k] = wI ^ s_wO[ay]; xy[k] = ax | (ay << 16);
                         ++ay;
                         if (ay == ay_end) {
                             ++ax;
                             if (ax == ax_end) {
                                 t = t + 1 < ntl ? t + 1 : t;                      // (behind the last tile the lane has no pairs left: it walks the last tile again, adding zeros)
-                                td = s_tiles[t]; av = td & 0x1FFFu; b = av ^ (u32)beta;
-                                ax = s_sI[av]; ax_end = s_sI[av + 1]; sb = s_sO[b]; ay_end = s_sO[b + 1];
+                                d = s_tiles[t];
+                                ax = d.x & 0xFFFFu; ax_end = d.x >> 16; sb = d.y & 0xFFFFu; ay_end = d.y >> 16;
                             }
                             ay = sb;
                             wI = s_w[ax];
                         }
                     }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {                                   // eight returning adds in flight
+                    constexpr int HQ = PD_QUOTA / 2;
+                    u32 old[HQ];
+#pragma unroll
+                    for (int k = 0; k < HQ; ++k)
+                        if ((u32)(h * HQ + k) < q) old[k] = atomicAdd(&s_cnt[pd_cnt_word(hw[h * HQ + k])], (u32)(h * HQ + k) < rem ? 1u << pd_cnt_shift(hw[h * HQ + k]) : 0u);
+#pragma unroll
+                    for (int k = 0; k < HQ; ++k)
+                        if ((u32)(h * HQ + k) < q) sat |= ((old[k] >> pd_cnt_shift(hw[h * HQ + k])) & 15u) == 15u ? 1u : 0u;
                 }
             }
         } else {
@@ -222,43 +277,35 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
                     for (u32 y = s0; y < x; ++y) {
                         const u32 v = s_w[x] ^ s_w[y];
                         const u32 o = (atomicAdd(&s_cnt[pd_cnt_word(v)], 1u << pd_cnt_shift(v)) >> pd_cnt_shift(v)) & 15u;
-                        if (o == 15u) s_over = 1;
+                        sat |= o == 15u ? 1u : 0u;
                     }
             }
         }
-        u32 live = 0, later = 0;
-        if (!inside) {
-#pragma unroll
-            for (int k = 0; k < PD_QUOTA; ++k) {
-                if ((u32)k < rem) {
-                    const u32 v = hw[k];
-                    live |= 1u << k;
-                    const u32 o = (old[k] >> pd_cnt_shift(v)) & 15u;
-                    if (o == 15u) s_over = 1;
-                    if (o || v == 0u) later |= 1u << k;                          // (a zero word: listed whatever its count — the identity is decided on the list)
-                }
-            }
-        }
+        if (sat) s_over = 1;
         __syncthreads();
+        PD_STAMP(1);
         if (s_over) {                                                           // a counter saturated: rows repeated all over
             if (tid == 0) atomicOr(a.giveup, 2u);
             __syncthreads();
             continue;
         }
-        // ---- list: pairs whose counter was hit before them or reads >= 2 now
+        // ---- list: pairs whose counter reads >= 2 now (4 % of them), and zero words whatever their count (the identity is decided on the list)
         if (!inside) {
+            u32 lm = 0;
 #pragma unroll
-            for (int k = 0; k < PD_QUOTA; ++k) {
-                bool li = false;
-                if ((live >> k) & 1u) li = ((later >> k) & 1u) || ((s_cnt[pd_cnt_word(hw[k])] >> pd_cnt_shift(hw[k])) & 15u) >= 2u;
-                const u64 m = __ballot(li);
-                if (m) {
-                    u32 base = 0;
-                    if (lane == 0) base = atomicAdd(&s_nc, (u32)__popcll(m));
-                    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-                    const u32 n = base + (u32)__popcll(m & ((1ULL << lane) - 1ULL));
-                    if (li && n < (u32)PD_CAND) { s_lw[n] = hw[k]; s_lxy[n] = xy[k]; }
-                }
+            for (int k = 0; k < PD_QUOTA; ++k)
+                if ((u32)k < rem && (hw[k] == 0u || ((s_cnt[pd_cnt_word(hw[k])] >> pd_cnt_shift(hw[k])) & 15u) >= 2u)) lm |= 1u << k;
+            const u32 mine = (u32)__popc(lm);
+            u32 inc = mine;
+            for (int off = 1; off < 64; off <<= 1) { const u32 t = (u32)__shfl_up((int)inc, off); if (lane >= off) inc += t; }
+            const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+            if (total) {                                                        // (wave-uniform)
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(&s_nc, total);
+                u32 n = (u32)__builtin_amdgcn_readfirstlane((int)base) + inc - mine;
+#pragma unroll
+                for (int k = 0; k < PD_QUOTA; ++k)
+                    if ((lm >> k) & 1u) { if (n < (u32)PD_CAND) { s_lw[n] = hw[k]; s_lxy[n] = xy[k]; } ++n; }
             }
         } else {
             for (int av = tid; av < nb; av += NT) {
@@ -274,6 +321,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
             }
         }
         __syncthreads();
+        PD_STAMP(2);
         const u32 nc = s_nc;
         if (nc > (u32)PD_CAND) {
             if (tid == 0) atomicOr(a.giveup, 4u);
@@ -282,12 +330,12 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
         }
         // ---- match: chains by word, every listed pair walks its chain; an equal word is decided by the 64-bit hashes
         for (u32 c = tid; c < nc; c += NT) {
-            const u32 hsh = (s_lw[c] * 2654435761u) >> 21;
+            const u32 hsh = (s_lw[c] * 2654435761u) >> 22;
             s_next[c] = atomicExch(&s_head[hsh], c);
         }
         __syncthreads();
         for (u32 c = tid; c < nc; c += NT) {
-            const u32 wc = s_lw[c], hsh = (wc * 2654435761u) >> 21, xyc = s_lxy[c];
+            const u32 wc = s_lw[c], hsh = (wc * 2654435761u) >> 22, xyc = s_lxy[c];
             u64 Hc = 0;
             bool have = false;
             if (wc == 0u) { Hc = pd_hash(a, xyc); have = true; }
@@ -301,9 +349,13 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
             if (hit) pd_flag(a, xyc & 0xFFFFu, xyc >> 16);
         }
         __syncthreads();
+        PD_STAMP(3);
     }
+#ifdef SYMGPU_PD_STAMPS
+    if (tid == 0 && blockIdx.x == 7) for (int i = 0; i < 6; ++i) g_pd_stamps[i] = acc_[i];
+#endif
 }
-static_assert(PD_CHAIN == 2048, "the chain hash keeps 11 bits");
+static_assert(PD_CHAIN == 1024, "the chain hash keeps 10 bits");
 
 // The flag bitmap `flags` (one bit per pair, indexed like the key array in index order; zeroed by the caller) gets the bit of every pair
 // whose 64-bit key equals another pair's, and of every pair whose key is zero.  *applies = false: the operands do not fit this path (nothing
@@ -317,8 +369,7 @@ int pair_dups_dev(const u64 *hI, i64 Ni, const u64 *hO, i64 No, bool squared, i6
     while (B < PD_MAX_B && (Tk >> B) > PD_TARGET) ++B;
     if ((Tk >> B) > PD_TARGET) return SYMGPU_OK;
     const int nb = 1 << B;
-    const size_t lds = (size_t)((nI + nO + 3) & ~3) * 4 + ((size_t)1 << (PD_SLOT_BITS - 3)) * 4 + (size_t)nb * 4 + (size_t)PD_CAND * 12 + (size_t)PD_CHAIN * 4 +
-                       (size_t)(squared ? 1 : 2) * (nb + 2) * 2 + 16;
+    const size_t lds = pd_lds_bytes((int)(nI + nO), nb, squared ? 1 : 0);
     if (lds > PD_LDS_MAX) return SYMGPU_OK;
     const bool attr = SG_DEVICE_ONCE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair_dups), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PD_LDS_MAX) == hipSuccess);
     if (!attr) return SYMGPU_OK;
@@ -339,6 +390,16 @@ int pair_dups_dev(const u64 *hI, i64 Ni, const u64 *hO, i64 No, bool squared, i6
     const int P = ctx().num_cu < nb ? ctx().num_cu : nb;
     hipLaunchKernelGGL(k_pair_dups, dim3((unsigned)P), dim3(PD_THREADS), lds, st, a);
     KERNEL_CHECK();
+#ifdef SYMGPU_PD_STAMPS
+    if (getenv("SYMGPU_PD_STAMPS")) {
+        u64 h[8];
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pd_stamps), sizeof h));
+        const double nbeta = (double)((nb - 7 + P - 1) / P);
+        fprintf(stderr, "pair_dups workgroup 7, cycles per product bucket: tiles %.0f count %.0f list %.0f match %.0f (loop top %.0f)\n", h[0] / nbeta, h[1] / nbeta, h[2] / nbeta,
+                h[3] / nbeta, h[5] / nbeta);
+    }
+#endif
     *applies = true;
     return SYMGPU_OK;       // (`tab` goes back to the stream-ordered allocator: the kernel above is queued ahead of any reuse)
 }

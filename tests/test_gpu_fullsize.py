@@ -286,18 +286,29 @@ def test_product_cleanup_over_the_lazy_gate_against_the_c_oracle(shape):
     assert np.array_equal(R.coeff_vec, ec)
 
 
-@pytest.mark.parametrize('mode', ['default', 'full sort', 'give up', 'repeated rows', 'few rows'])
+@pytest.mark.parametrize('mode', ['default', 'sorted flag pass', 'full sort', 'give up', 'repeated rows', 'few rows', 'planted'])
 def test_cleanup_flagged_key_flow_switches(mode, monkeypatch):
-    """Round 4's cleanup of products (partial sort, k_find_suspects, only the flagged keys sorted completely) against the C oracle above
+    """The cleanup of products — the pairs that share a key found from the bucketed operand hash tables (round 6, pair_dups.hip) or, with
+    SYMGPU_CLEANUP_DIRECT=0 ('sorted flag pass') and for operands that do not fit a workgroup's LDS, behind a partial sort (round 4-5,
+    k_find_suspects), only the flagged keys sorted completely — against the C oracle above
     the 2^22-key gate: the default, the full sort of all keys (SYMGPU_CLEANUP_SUSPECTS=0), the flow giving up after the flag pass and
     finishing the last radix pass on the whole array (forced, and reached by itself on operands full of repeated rows, where nearly
     every key has a partner; 'few rows': 3 x 2 distinct products, runs of ~10^6 equal keys — the flag pass itself gives up on a run it cannot
-    read to its end)."""
+    read to its end; 'planted': rows that are products of two other rows, so that a few hundred product rows occur two or three times)."""
     rng = np.random.default_rng(4404)
     n, na, nb = 100, 2600, 2100
     if mode == 'full sort': monkeypatch.setenv('SYMGPU_CLEANUP_SUSPECTS', '0')
     if mode == 'give up': monkeypatch.setenv('SYMGPU_CLEANUP_SUSPECTS', '2')
+    if mode == 'sorted flag pass': monkeypatch.setenv('SYMGPU_CLEANUP_DIRECT', '0')
     sa = rng.random((na, 2 * n)) < 0.3; sb = rng.random((nb, 2 * n)) < 0.3
+    if mode == 'planted':                          # a few hundred products that occur twice or three times: rows that are products of two others
+        for k in range(150):
+            i, j, l = rng.integers(0, na, 3)
+            sa[l] = sa[i] ^ sa[j]
+            i, j, l = rng.integers(0, nb, 3)
+            sb[l] = sb[i] ^ sb[j]
+        sa = np.unique(sa, axis=0); sb = np.unique(sb, axis=0)
+        na, nb = sa.shape[0], sb.shape[0]
     if mode == 'repeated rows':
         sa = sa[rng.integers(0, 400, na)]; sb = sb[rng.integers(0, 300, nb)]          # 400 x 300 distinct products, each ~45 times
     if mode == 'few rows':
