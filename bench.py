@@ -524,8 +524,8 @@ def wl_mul_cleanup(args, comm, rank, world, _lib, DeviceOp, parallel):
             'frac': launch_bytes / kt / 1e9 / HBM_PEAK_GBS if kt else None, 'traffic': None, 'launches': nl, 'avg_launch_ms': kt * 1e3,
             'algorithmic_bytes_per_launch': launch_bytes,
             'note': 'output stage of the cleanup in one launch: 16*Wq + 16 bytes per kept row, written once (non-temporal stores), rows '
-                    'gathered from the L2-resident operand; the other kernels of the step are key generation, the partial radix sort (2 of 4 '
-                    f'8-bit passes), the marking of single keys and the suspect search — profiles/{PROFILE_TAG}_cfg3_kernel_trace.txt',
+                    'gathered from the L2-resident operand; the other kernels of the step are key generation, the marking of single keys and the '
+                    f'search for the pairs that share a product row (pair_dups.hip: operand hash tables in LDS, no sort) — profiles/{PROFILE_TAG}_cfg3_kernel_trace.txt',
             'whole_step': {'survey_8d_algorithmic_bytes': algo_step, 'algorithmic_GBps': algo_step / (dt / args.steps) / 1e9,
                            'physical_write_floor_ms': n_out[0] * (row_bytes + 16) / (HBM_PEAK_GBS * 1e9) * 1e3,
                            'note': 'SURVEY 8d counts T (16Wq+16) B read + U_kept (16Wq+16) B written; the T product rows and pair coefficients '
