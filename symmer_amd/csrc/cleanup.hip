@@ -1941,7 +1941,11 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     u32 *sustotal = susbits.as<u32>() + 2 * n_sc;          // [0] flagged keys, [1] the flag pass gave up (one memset with the flags)
                     SG_TRY(zero_two(susbits.p, (size_t)n_sc * 8 + 16, nullptr, 0));
                     // round 6: operands whose bucketed hash words fit a workgroup's LDS — the flags come from the operand hash tables, the
-                    // keys are never sorted (pair_dups.hip); they stay in index order and the flags are indexed likewise
+                    // keys are never sorted (pair_dups.hip); they stay in index order and the flags are indexed likewise.
+                    // (Measured and dropped: the marking pass folded into the key kernel — three bitmaps ORed from its epilogue, an atomic per
+                    // 64 indices, or per 256 with the inner words stored: the conditional memory operations of the epilogue drain the kernel's
+                    // memory counter one by one, 0.28 -> 0.48 / 0.58 ms for the 0.14 ms pass it would replace; and the marking pass without the
+                    // first-pass histograms, which only the fall-back needs: 0.139 -> 0.141 ms, it is bound by reading the keys.)
                     bool direct = false;
                     SG_TRY(pair_dups_dev(hI.as<u64>(), Ni, hO_p, No, squared, Tk, susbits.as<u64>(), sustotal + 1, &direct));
                     u64 *part = keys.as<u64>(), *spare = keys2.as<u64>();

@@ -391,18 +391,27 @@ static_assert(PD_CHAIN == 1024, "the chain hash keeps 10 bits");
 // The flag bitmap `flags` (one bit per pair, indexed like the key array in index order; zeroed by the caller) gets the bit of every pair
 // whose 64-bit key equals another pair's, and of every pair whose key is zero.  *applies = false: the operands do not fit this path (nothing
 // was launched).  giveup (device word, zeroed by the caller) != 0 afterwards: the flags are incomplete, take the sorted path.
-int pair_dups_dev(const u64 *hI, i64 Ni, const u64 *hO, i64 No, bool squared, i64 Tk, u64 *flags, u32 *giveup, bool *applies) {
-    *applies = false;
-    if (getenv("SYMGPU_CLEANUP_DIRECT") && getenv("SYMGPU_CLEANUP_DIRECT")[0] == '0') return SYMGPU_OK;
+// pair_dups_fits: does this path take the product?  (host-side: sizes only; *B_out: the bucket width)
+bool pair_dups_fits(i64 Ni, i64 No, bool squared, i64 Tk, int *B_out) {
+    if (getenv("SYMGPU_CLEANUP_DIRECT") && getenv("SYMGPU_CLEANUP_DIRECT")[0] == '0') return false;
     const i64 nI = Ni, nO = squared ? 0 : No;
-    if (nI + nO > 65535 || nI < 2 || (!squared && nO < 1)) return SYMGPU_OK;
+    if (nI + nO > 65535 || nI < 2 || (!squared && nO < 1)) return false;
     int B = 2;
     while (B < PD_MAX_B && (Tk >> B) > PD_TARGET) ++B;
-    if ((Tk >> B) > PD_TARGET) return SYMGPU_OK;
-    if (B < PD_MIN_B) return SYMGPU_OK;              // (below ~1.6e6 keys the sorted flag pass is as fast: P * P of 1,500 terms 0.29 against 0.30 ms)
+    if ((Tk >> B) > PD_TARGET) return false;
+    if (B < PD_MIN_B) return false;                  // (below ~1.6e6 keys the sorted flag pass is as fast: P * P of 1,500 terms 0.29 against 0.30 ms)
+    if (pd_lds_bytes((int)(nI + nO), 1 << B, squared ? 1 : 0) > PD_LDS_MAX) return false;
+    if (B_out) *B_out = B;
+    return true;
+}
+
+int pair_dups_dev(const u64 *hI, i64 Ni, const u64 *hO, i64 No, bool squared, i64 Tk, u64 *flags, u32 *giveup, bool *applies) {
+    *applies = false;
+    int B = 0;
+    if (!pair_dups_fits(Ni, No, squared, Tk, &B)) return SYMGPU_OK;
+    const i64 nI = Ni, nO = squared ? 0 : No;
     const int nb = 1 << B;
     const size_t lds = pd_lds_bytes((int)(nI + nO), nb, squared ? 1 : 0);
-    if (lds > PD_LDS_MAX) return SYMGPU_OK;
     const bool attr = SG_DEVICE_ONCE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair_dups), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PD_LDS_MAX) == hipSuccess);
     if (!attr) return SYMGPU_OK;
     hipStream_t st = ctx().stream;
