@@ -457,6 +457,85 @@ __global__ __launch_bounds__(256) void k_mark_singles(const u64 *__restrict__ ke
     }
 }
 
+// Round 6: the same marking from ONE BYTE per pair (PairKeyArgs::ebytes: e | (i == o) << 2, written by the key kernel in index order in
+// place of the keys) — where the pairs that share a key are found from the operand hash tables (pair_dups.hip) the marking was the only
+// reader of the 400 MB of keys (0.14 ms at cfg3: bound by the latency of its 8-byte loads).  A lane takes 16 consecutive indices (one 16-byte
+// load), forms its 16 bits of the three bitmaps with byte-parallel arithmetic and stores them as 2 bytes each (a wavefront: 128 contiguous
+// bytes per bitmap): 50 MB in, 19 MB out.  When the operands' coefficient floors do not settle the decision (all_kept false) the sixteen
+// pairs are decided one by one from the operand tables like k_mark_singles does.
+// index -> (i, o) of a pair: general o * Ni + i; squared operator: the compacted slot of PairKeyArgs
+__device__ __forceinline__ void pair_of_index(i64 pos, i64 Ni, int squared, i64 &i, i64 &o) {
+    if (!squared) { o = pos / Ni; i = pos - o * Ni; return; }
+    // row o starts at s(o) = o (2 Ni - o + 1) / 2: the largest o with s(o) <= pos
+    const double b = 2.0 * (double)Ni + 1.0;
+    i64 oo = (i64)((b - sqrt(b * b - 8.0 * (double)pos)) * 0.5);
+    if (oo < 0) oo = 0;
+    if (oo >= Ni) oo = Ni - 1;
+    while (oo > 0 && oo * (2 * Ni - oo + 1) / 2 > pos) --oo;
+    while (oo + 1 < Ni && (oo + 1) * (2 * Ni - oo) / 2 <= pos) ++oo;
+    o = oo;
+    i = pos - oo * (2 * Ni - oo + 1) / 2 + oo;
+}
+__device__ __forceinline__ u32 pack_bit0_of_bytes(u32 w) { return ((w & 0x01010101u) * 0x01020408u) >> 24 & 0xFu; }   // bit 0 of the four bytes -> four bits
+__global__ __launch_bounds__(256) void k_mark_bytes(const u32x4 *__restrict__ eb, i64 space, i64 n_groups, i64 Ni, const double *__restrict__ ci,
+                                                     const double *__restrict__ co, int squared, double thr, int use_thr, unsigned short *__restrict__ mark16,
+                                                     unsigned short *__restrict__ lo16, unsigned short *__restrict__ hi16, const double *__restrict__ floor_i,
+                                                     const double *__restrict__ floor_o) {
+    const bool all_kept = !use_thr || (floor_i && floor_o && 0.5 * floor_i[0] * floor_o[0] > thr);     // uniform
+    const bool drop_rule = use_thr && squared && !(0.0 > thr);           // the anticommuting off-diagonal pairs of a squared operator are exact zeros
+    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (i64)gridDim.x * blockDim.x) {
+        const i64 p0 = g * 16;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (p0 < space) v = __builtin_nontemporal_load(eb + g);
+        u32 valid = 0xFFFFu;
+        if (p0 + 16 > space) valid = p0 < space ? (1u << (int)(space - p0)) - 1u : 0u;
+        u32 lo = 0, hi = 0, drop = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 w = v[q];
+            lo |= pack_bit0_of_bytes(w) << (4 * q);
+            hi |= pack_bit0_of_bytes(w >> 1) << (4 * q);
+            drop |= pack_bit0_of_bytes(w & ~(w >> 2)) << (4 * q);        // e odd and not the diagonal
+        }
+        lo &= valid; hi &= valid;
+        u32 keep;
+        if (all_kept) keep = valid & (drop_rule ? ~drop : 0xFFFFu);
+        else {
+            keep = 0;
+            for (int k = 0; k < 16; ++k) {
+                if (!((valid >> k) & 1u)) continue;
+                i64 i, o;
+                pair_of_index(p0 + k, Ni, squared, i, o);
+                const int e = (int)(((lo >> k) & 1u) | (((hi >> k) & 1u) << 1));
+                double cx, cy;
+                pair_coefficient(ci[2 * i], ci[2 * i + 1], co[2 * o], co[2 * o + 1], e, cx, cy);
+                if (squared && i != o) {
+                    if (e & 1) { cx = 0.0; cy = 0.0; }
+                    else { cx = __dadd_rn(cx, cx); cy = __dadd_rn(cy, cy); }
+                }
+                const bool zero = cx == 0.0 && cy == 0.0;
+                const bool kp = !use_thr || (zero ? 0.0 > thr : (fabs(cx) > thr || fabs(cy) > thr || hypot(__dadd_rn(0.0, cx), __dadd_rn(0.0, cy)) > thr));
+                keep |= (kp ? 1u : 0u) << k;
+            }
+        }
+        mark16[g] = (unsigned short)keep; lo16[g] = (unsigned short)lo; hi16[g] = (unsigned short)hi;
+    }
+}
+// the flagged pairs' packed keys rebuilt in place from their indices (k_compact_suspects with keys == null leaves those), the byte and the
+// operand hash tables; *n_flagged is the device-side count (the host does not know it yet)
+__global__ __launch_bounds__(256) void k_keys_of_indices(u64 *__restrict__ out, const u32 *__restrict__ n_flagged, const unsigned char *__restrict__ eb, i64 Ni, int squared,
+                                                          PackedLayout L, const u64 *__restrict__ hI, const u64 *__restrict__ hO) {
+    const u64 hmask = ~((1ULL << L.F()) - 1ULL);
+    const i64 n = n_flagged[0];
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+        const i64 pos = (i64)out[t];
+        i64 i, o;
+        pair_of_index(pos, Ni, squared, i, o);
+        const u64 e = eb[pos] & 3u;
+        out[t] = ((hI[i] ^ hO[o]) & hmask) | (e << (L.bi + L.bo)) | ((u64)o << L.bi) | (u64)i;
+    }
+}
+
 // lazy mode, after the sort: which 64-position chunks of the sorted keys hold a member of a segment with more than one element?
 // A position that equals its predecessor (the test k_heads_sums makes: prefix, then P * P twins, then the full keys rebuilt from the
 // operand hash tables) marks its own chunk and its predecessor's.  Four chunks per wavefront and step, all loads of a step in flight.
@@ -1767,7 +1846,7 @@ __global__ __launch_bounds__(256) void k_compact_suspects(const u64 *__restrict_
             nz &= nz - 1;
             const u64 bb = __shfl(b, l);
             const i64 c = base + l;
-            if ((bb >> lane) & 1ULL) out[(i64)prefix[c] + __popcll(bb & ((1ULL << lane) - 1ULL))] = keys[c * 64 + lane];
+            if ((bb >> lane) & 1ULL) out[(i64)prefix[c] + __popcll(bb & ((1ULL << lane) - 1ULL))] = keys ? keys[c * 64 + lane] : (u64)(c * 64 + lane);   // (no keys: the index)
         }
     }
 }
@@ -1897,13 +1976,28 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 PairKeyArgs ka;
                 ka.hI = hI.as<u64>(); ka.hO = hO_p; ka.keys = keys.as<u64>(); ka.bi = L.bi; ka.bo = L.bo; ka.o_base = 0;
                 ka.squared = squared ? 1 : 0;
+                // products whose keys mostly merge with nothing: stop the sort one pass early and sort only the keys that have a partner
+                // (k_find_suspects).  Applies when a run of the partial order is short (<= 8 keys on average) and the operands are not
+                // one array used twice without the squared-operator compaction (then EVERY key has its twin).
+                // SYMGPU_CLEANUP_SUSPECTS: 0 = complete sort of all keys; 2 = tests: behave as if most keys were flagged (the remaining passes are finished on the whole array)
+                const bool sus_env = [] { const char *e = getenv("SYMGPU_CLEANUP_SUSPECTS"); return !(e && e[0] == '0'); }();
+                const bool sus_giveup = [] { const char *e = getenv("SYMGPU_CLEANUP_SUSPECTS"); return e && e[0] == '2'; }();
+                // two passes before the flag pass, on key bits [32, 48): a run then holds <= 2,048 keys on average (products of up to 2^27 keys)
+                const int sus_pass = SUS_RUN_BITS / 8;
+                const bool sus_try = lazy_a && sus_env && nbits == 32 && (Tk >> SUS_RUN_BITS) <= 2048 && !(inner == outer && !squared);
+                // round 6: where the flag pass works from the operand hash tables (pair_dups.hip) nobody reads the keys but the marking of
+                // the single terms, and all it reads of them is the phase exponent and "is the diagonal": the key kernel then writes ONE BYTE
+                // per pair (into the key buffer) and k_mark_bytes marks from those; the few flagged keys are rebuilt at their compaction.
+                // Should the flag pass give up, the keys are generated after all.  SYMGPU_CLEANUP_KEYBYTES=0: 8-byte keys + k_mark_singles.
+                const bool key_bytes = sus_try && pair_dups_fits(Ni, No, squared, Tk, nullptr) && !wide_pairs_worthwhile(Ni, No, W / 2) &&
+                                       !(getenv("SYMGPU_CLEANUP_KEYBYTES") && getenv("SYMGPU_CLEANUP_KEYBYTES")[0] == '0');
+                if (key_bytes) ka.ebytes = keys.as<unsigned char>();
                 SG_TRY(mul_keys_dev(inner, Ni, outer, No, W / 2, inner_is_left, ka));
+                ka.ebytes = nullptr;
                 u32 *first_hist = nullptr;
                 if (lazy_a) {                                          // the keys are still in index order
                     const i64 n_tiles = (Tk + SORT_TILE - 1) / SORT_TILE;
-                    SG_TRY(sort_hist.alloc((size_t)n_tiles * 256 * sizeof(u32)));
-                    first_hist = sort_hist.as<u32>();
-                    // how small the operands' coefficients get: decides whether k_mark_singles has to look at them at all
+                    // how small the operands' coefficients get: decides whether the marking has to look at them at all
                     SG_TRY(cfloor.alloc(16));
                     const bool one_block = Ni <= 65536 && No <= 65536;       // a single workgroup stores its minimum: nothing to initialise
                     if (!one_block) HIP_TRY(hipMemsetAsync(cfloor.p, 0xFF, 16, st));
@@ -1917,19 +2011,18 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     }
                     const double *fl_i = cfloor.as<double>(), *fl_o = (co != ci || No != Ni) ? cfloor.as<double>() + 1 : cfloor.as<double>();
                     if (getenv("SYMGPU_CLEANUP_NOFLOOR")) fl_i = fl_o = nullptr;     // tests: every coefficient looked at
-                    hipLaunchKernelGGL(k_mark_singles<true>, dim3((unsigned)n_tiles), dim3(256), 0, st, keys.as<u64>(), (const double *)nullptr, Tk, L, ci, co,
-                                       squared ? 1 : 0, thr, use_thr, markbits.as<u64>(), e_lo.as<u64>(), e_hi.as<u64>(), first_hist, 64 - nbits, n_tiles, fl_i, fl_o);
+                    if (key_bytes) {
+                        const i64 n_groups = (Tk + 63) / 64 * 4;           // whole 64-bit words of the bitmaps
+                        hipLaunchKernelGGL(k_mark_bytes, dim3((unsigned)grid_for(n_groups, 256, 1 << 16)), dim3(256), 0, st, keys.as<u32x4>(), Tk, n_groups, Ni, ci, co,
+                                           squared ? 1 : 0, thr, use_thr, markbits.as<unsigned short>(), e_lo.as<unsigned short>(), e_hi.as<unsigned short>(), fl_i, fl_o);
+                    } else {
+                        SG_TRY(sort_hist.alloc((size_t)n_tiles * 256 * sizeof(u32)));
+                        first_hist = sort_hist.as<u32>();
+                        hipLaunchKernelGGL(k_mark_singles<true>, dim3((unsigned)n_tiles), dim3(256), 0, st, keys.as<u64>(), (const double *)nullptr, Tk, L, ci, co,
+                                           squared ? 1 : 0, thr, use_thr, markbits.as<u64>(), e_lo.as<u64>(), e_hi.as<u64>(), first_hist, 64 - nbits, n_tiles, fl_i, fl_o);
+                    }
                     KERNEL_CHECK();
                 }
-                // products whose keys mostly merge with nothing: stop the sort one pass early and sort only the keys that have a partner
-                // (k_find_suspects).  Applies when a run of the partial order is short (<= 8 keys on average) and the operands are not
-                // one array used twice without the squared-operator compaction (then EVERY key has its twin).
-                // SYMGPU_CLEANUP_SUSPECTS: 0 = complete sort of all keys; 2 = tests: behave as if most keys were flagged (the remaining passes are finished on the whole array)
-                const bool sus_env = [] { const char *e = getenv("SYMGPU_CLEANUP_SUSPECTS"); return !(e && e[0] == '0'); }();
-                const bool sus_giveup = [] { const char *e = getenv("SYMGPU_CLEANUP_SUSPECTS"); return e && e[0] == '2'; }();
-                // two passes before the flag pass, on key bits [32, 48): a run then holds <= 2,048 keys on average (products of up to 2^27 keys)
-                const int sus_pass = SUS_RUN_BITS / 8;
-                const bool sus_try = lazy_a && sus_env && nbits == 32 && (Tk >> SUS_RUN_BITS) <= 2048 && !(inner == outer && !squared);
                 if (!sus_try) {
                     SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp, first_hist));
                 } else {
@@ -1950,6 +2043,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     SG_TRY(pair_dups_dev(hI.as<u64>(), Ni, hO_p, No, squared, Tk, susbits.as<u64>(), sustotal + 1, &direct));
                     u64 *part = keys.as<u64>(), *spare = keys2.as<u64>();
                     if (!direct) {
+                        if (key_bytes) SG_TRY(mul_keys_dev(inner, Ni, outer, No, W / 2, inner_is_left, ka));     // (the flag pass was refused: keys after all)
                         SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, lo, hi, &in_tmp, first_hist));
                         part = in_tmp ? keys2.as<u64>() : keys.as<u64>(); spare = in_tmp ? keys.as<u64>() : keys2.as<u64>();
                         hipLaunchKernelGGL(k_find_suspects, dim3((unsigned)((Tk + SUS_TILE - 1) / SUS_TILE)), dim3(64 * SUS_WAVES), 0, st, part, Tk, L, hI.as<u64>(),
@@ -1967,8 +2061,11 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     {
                         ReadBack rb;
                         SG_TRY(read_back_post(sustotal, 2, nullptr, 0, &rb));
-                        hipLaunchKernelGGL(k_compact_suspects, dim3((unsigned)grid_for((n_sc + 63) / 64, 1, 1 << 16)), dim3(256), 0, st, part, susbits.as<u64>(),
-                                           susprefix.as<u32>(), n_sc, spare);
+                        const bool from_bytes = key_bytes && direct;       // only bytes in the key buffer: the indices are compacted, the keys rebuilt from them
+                        hipLaunchKernelGGL(k_compact_suspects, dim3((unsigned)grid_for((n_sc + 63) / 64, 1, 1 << 16)), dim3(256), 0, st, from_bytes ? (const u64 *)nullptr : part,
+                                           susbits.as<u64>(), susprefix.as<u32>(), n_sc, spare);
+                        if (from_bytes)
+                            hipLaunchKernelGGL(k_keys_of_indices, dim3(64), dim3(256), 0, st, spare, sustotal, keys.as<unsigned char>(), Ni, squared ? 1 : 0, L, hI.as<u64>(), hO_p);
                         KERNEL_CHECK();
                         SG_TRY(read_back_wait(&rb, h_sus2));
                     }
@@ -1977,6 +2074,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                         // repeated rows all over: the last pass on the whole array after all (LSD: the order so far is its first passes; the
                         // direct flag pass left the keys in index order: all passes)
                         bool in_tmp2 = false;
+                        if (key_bytes && direct) SG_TRY(mul_keys_dev(inner, Ni, outer, No, W / 2, inner_is_left, ka));   // (only bytes so far: the keys after all)
                         SG_TRY(radix_sort_keys_u64(part, spare, Tk, direct ? lo : hi, 64, &in_tmp2, direct ? first_hist : nullptr));
                         if (in_tmp2) in_tmp = !in_tmp;
                     } else {

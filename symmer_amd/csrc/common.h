@@ -257,6 +257,9 @@ struct PairKeyArgs {
     // squared mode (P * P, cleanup.hip): only the pairs with i >= o get a key (the twin (o, i) of an off-diagonal pair is the
     // same row with the same or the opposite coefficient), compacted in pair-index order: slot(o, i) = o*Ni - o(o-1)/2 + (i - o)
     int squared = 0;
+    // round 6, ebytes != null: instead of the 8-byte key ONE byte per pair at the key's index, e | (i == o) << 2 — all that the marking of
+    // the single terms reads when the pairs that share a key are found from the operand hash tables (pair_dups.hip); `keys` is not written
+    unsigned char *ebytes = nullptr;
 };
 
 int mul_coeff_dev(const u64 *inner, const double *ci, i64 Ni, const u64 *outer, const double *co, i64 o_begin, i64 o_end,

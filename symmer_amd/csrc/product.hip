@@ -150,7 +150,10 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
             for (int b = 0; b < PJ; ++b) {
                 const i64 i = ibase + 64 * b + lane;
                 const u64 e = (3u * (yi[b] + (u32)yo[a]) + cnt[a][b] + 2u * (__popc(flip[a][b]) & 1u)) & 3u;
-                if (i < Ni && i >= o) dst[i] = ((ka.hI[i] ^ ho[a]) & hmask) | (e << (ka.bi + ka.bo)) | ((u64)o << ka.bi) | (u64)i;
+                if (i < Ni && i >= o) {
+                    if (ka.ebytes) ka.ebytes[(o * Ni - o * (o - 1) / 2 - o) + i] = (unsigned char)(e | (i == o ? 4u : 0u));      // (uniform choice)
+                    else dst[i] = ((ka.hI[i] ^ ho[a]) & hmask) | (e << (ka.bi + ka.bo)) | ((u64)o << ka.bi) | (u64)i;
+                }
             }
         }
         return;
@@ -168,6 +171,18 @@ __global__ __launch_bounds__(256) void k_mul_coeff(const u64 *__restrict__ It, i
             for (int a = 0; a < PO; ++a) {
                 const u64 e = (3u * (yi[b] + (u32)yo[a]) + cnt[a][b] + 2u * (__popc(flip[a][b]) & 1u)) & 3u;
                 key[a] = ((hi ^ ho[a]) & hmask) | (e << (ka.bi + ka.bo)) | ((u64)(o0 + a + ka.o_base) << ka.bi) | (u64)i;
+            }
+            if (ka.ebytes) {                                                // (uniform) one byte per pair: the phase exponent
+                unsigned char *db = ka.ebytes + o0 * Ni + i;
+                if (full_o) {
+#pragma unroll
+                    for (int a = 0; a < PO; ++a) db[(i64)a * Ni] = (unsigned char)((key[a] >> (ka.bi + ka.bo)) & 3u);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < PO; ++a)
+                        if (o0 + a < No) db[(i64)a * Ni] = (unsigned char)((key[a] >> (ka.bi + ka.bo)) & 3u);
+                }
+                continue;
             }
             u64 *dst = ka.keys + o0 * Ni + i;
             if (full_o) {

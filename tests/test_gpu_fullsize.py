@@ -320,6 +320,48 @@ def test_cleanup_flagged_key_flow_switches(mode, monkeypatch):
         assert np.array_equal(R.packed, er) and np.array_equal(R.coeff_vec, ec), mode
 
 
+@pytest.mark.parametrize('planted', [False, True])
+@pytest.mark.parametrize('shape', ['squared 2300', 'general 1900x1500'])
+def test_marking_from_bytes_equals_marking_from_keys(shape, planted, monkeypatch):
+    """Where the flag pass works from the operand hash tables the key kernel writes one byte per pair and k_mark_bytes marks the single terms
+    from those (round 6): the same rows, order and coefficient bits as the 8-byte keys + k_mark_singles (SYMGPU_CLEANUP_KEYBYTES=0), as the
+    sorted flag pass (SYMGPU_CLEANUP_DIRECT=0), and with every coefficient looked at (SYMGPU_CLEANUP_NOFLOOR=1: the per-pair decisions of
+    k_mark_bytes) — O(1) Gaussian coefficients, and planted tiny ones whose products fall under the threshold; against the C oracle with the
+    Gaussian rule of the parity tests."""
+    rng = np.random.default_rng(515 + planted + len(shape))
+    n = 64
+    N, M = (2300, 2300) if shape.startswith('squared') else (1900, 1500)
+    ca = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    if planted:
+        ca[rng.integers(0, N, 60)] *= 1e-9
+    sa = rng.random((N, 2 * n)) < 0.3
+    for k in range(40):                                       # product rows that occur twice
+        i, j, l = rng.integers(0, N, 3)
+        sa[l] = sa[i] ^ sa[j]
+    sa = np.unique(sa, axis=0); N = sa.shape[0]; ca = ca[:N]
+    A = PauliwordOp(sa, ca)
+    if shape.startswith('squared'):
+        B = A
+    else:
+        cb = rng.standard_normal(M) + 1j * rng.standard_normal(M)
+        if planted:
+            cb[rng.integers(0, M, 60)] *= 1e-9
+        B = PauliwordOp(rng.random((M, 2 * n)) < 0.3, cb)
+    for thr in (1e-15, 1e-12):
+        ref = kernels.mul_cleanup(A.packed, A.coeff_vec, B.packed, B.coeff_vec, True, thr)
+        for env in ({'SYMGPU_CLEANUP_KEYBYTES': '0'}, {'SYMGPU_CLEANUP_DIRECT': '0'}, {'SYMGPU_CLEANUP_NOFLOOR': '1'}, {'SYMGPU_CLEANUP_NOFLOOR': '1', 'SYMGPU_CLEANUP_KEYBYTES': '0'}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got = kernels.mul_cleanup(A.packed, A.coeff_vec, B.packed, B.coeff_vec, True, thr)
+            for k in env:
+                monkeypatch.delenv(k)
+            assert got[0].shape == ref[0].shape and np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint64), ref[1].view(np.uint64)), (env, thr)
+    er, ec = oc.mul(A.packed, A.coeff_vec, B.packed, B.coeff_vec)
+    R = A * B
+    k1 = np.abs(R.coeff_vec) > 1e-12; k2 = np.abs(ec) > 1e-12
+    assert np.array_equal(R.packed[k1], er[k2]) and np.allclose(R.coeff_vec[k1], ec[k2], rtol=0, atol=1e-12)
+
+
 def test_squared_product_with_runs_of_more_than_a_thousand_keys(monkeypatch):
     """The flag pass of the cleanup (k_find_suspects) works on runs of keys that agree in 16 sorted hash bits: 763 keys on average at
     cfg3, up to 2,048 (products of 2^27 keys) before the library sorts completely instead.  12,000 terms squared = 7.2e7 keys, runs of
