@@ -981,6 +981,9 @@ __global__ __launch_bounds__(256) void k_fixup_work(u64 *__restrict__ keys, u32 
         const u64 k = keys[sp];
         const bool with_prev = sp > 0 && (keys[sp - 1] >> shift) == (k >> shift);
         if (!with_prev) {                                                     // the start of a run
+            // (a run longer than FIX_MAX is judged by its members below: the keys are ordered by the prefix, so one look at the key FIX_MAX
+            // positions on says so — the 10^4-key identity segment of a squared operator cost its first thread 48 dependent loads, 20 us)
+            if (sp + FIX_MAX < T && (keys[sp + FIX_MAX] >> shift) == (k >> shift)) continue;
             i64 e = sp + 1;
             bool mixed = false;
             while (e < T && e - sp <= FIX_MAX && (keys[e] >> shift) == (k >> shift)) { mixed |= fixup_differ<PACKED>(keys[e], keys[e - 1], hI, hO, L, same_operand); ++e; }
