@@ -893,14 +893,15 @@ __global__ __launch_bounds__(256) void k_heads_sums(const u64 *__restrict__ keys
 // run holds more than one distinct key it is re-ordered here by (full key, input order) with a stable insertion sort.
 // Runs longer than FIX_MAX that are not uniform raise `fallback`: the caller then redoes a full 64-bit sort.
 constexpr int FIX_MAX = 48;
-// Round 3: the keys that need a look at all — a run's first key, and a key inside a run that differs from its predecessor: 0.6 % of
-// the positions, but one in every other wavefront — are flagged by a streaming pass (k_fixup_find: four chunks per wavefront and step,
+// Round 3: the keys that need a look at all — a key inside a run that differs from its predecessor (round 6: no longer every run's first
+// key as well: an input full of repeated rows has a run start at every third position, and walking all those uniform runs was a quarter of a
+// plain cleanup, 60 of 237 us at 10^5 rows) — are flagged by a streaming pass (k_fixup_find: four chunks per wavefront and step,
 // one 64-bit word of flags per chunk, plain stores: appending to ONE list counter instead serialises 4e5 returning atomics on one
-// address, 2.8 ms) and worked off by wavefronts that expand the flags of 4,096 positions into a dense list (k_fixup_work): the thread of a run's START
-// walks it (<= FIX_MAX elements) and sorts it if it holds more than one distinct key; a differing key inside a run measures the run and
-// raises `fallback` if it is longer than FIX_MAX (a long UNIFORM run — the identity segment of a squared operator — costs nothing).
-// Threads of one run may read keys while its start thread reorders them: all of them share the prefix, which is all the others look
-// at.  (The two launches this replaces walked the runs from inside the streaming pass: 0.33 ms at cfg3, now 0.11.)
+// address, 2.8 ms) and worked off by wavefronts that expand the flags of 4,096 positions into a dense list (k_fixup_work): the thread
+// of a flagged key measures its run by the prefixes, raises `fallback` if it is longer than FIX_MAX (a long UNIFORM run — the identity
+// segment of a squared operator — has no flagged key and costs nothing) and, if no earlier member of the run is flagged, sorts it.
+// Threads of one run may read keys while its first flagged member reorders them: all of them share the prefix, which is all the others
+// look at (who is first is read from the flags, which nobody writes here).  (The two launches this replaces walked the runs from inside the streaming pass: 0.33 ms at cfg3, now 0.11.)
 // PACKED: keys are packed pair keys (full key recomputed from the (i, o) fields), there is no separate idx array.
 template <bool PACKED>
 __device__ __forceinline__ bool fixup_differ(u64 k, u64 kp, const u64 *__restrict__ hI, const u64 *__restrict__ hO, const PackedLayout &L, bool same_operand) {
@@ -935,8 +936,8 @@ __global__ __launch_bounds__(256) void k_fixup_find(const u64 *__restrict__ keys
             const bool valid = sp < T;
             const bool with_prev = valid && sp > 0 && (kp >> shift) == (k[j] >> shift);
             const bool with_next = valid && sp + 1 < T && (kn >> shift) == (k[j] >> shift);
-            bool rare = !with_prev && with_next;
-            if (with_prev) rare = fixup_differ<PACKED>(k[j], kp, hI, hO, L, same_operand);
+            (void)with_next;
+            const bool rare = with_prev && fixup_differ<PACKED>(k[j], kp, hI, hO, L, same_operand);
             const u64 b = __ballot(rare);
             if (lane == 0 && base + 64 * j < T) rarebits[base / 64 + j] = b;
             if (dirtybits) {
@@ -978,44 +979,38 @@ __global__ __launch_bounds__(256) void k_fixup_work(u64 *__restrict__ keys, u32 
     const i64 wbase = ((i64)blockIdx.x * 4 + wave) * 4096;
     for (u32 it = lane; it < n; it += 64) {
         const i64 sp = wbase + list[it];
-        const u64 k = keys[sp];
-        const bool with_prev = sp > 0 && (keys[sp - 1] >> shift) == (k >> shift);
-        if (!with_prev) {                                                     // the start of a run
-            // (a run longer than FIX_MAX is judged by its members below: the keys are ordered by the prefix, so one look at the key FIX_MAX
-            // positions on says so — the 10^4-key identity segment of a squared operator cost its first thread 48 dependent loads, 20 us)
-            if (sp + FIX_MAX < T && (keys[sp + FIX_MAX] >> shift) == (k >> shift)) continue;
-            i64 e = sp + 1;
-            bool mixed = false;
-            while (e < T && e - sp <= FIX_MAX && (keys[e] >> shift) == (k >> shift)) { mixed |= fixup_differ<PACKED>(keys[e], keys[e - 1], hI, hO, L, same_operand); ++e; }
-            if (e - sp > FIX_MAX || !mixed) continue;                         // long: judged by its members below; uniform: nothing to do
-            for (i64 a = sp + 1; a < e; ++a) {                                // stable insertion sort by full key
-                const u64 ka = keys[a];
-                if (PACKED) {
-                    const u64 fa = L.full_key(hI, hO, ka);
-                    i64 c = a - 1;
-                    while (c >= sp && L.full_key(hI, hO, keys[c]) > fa) { keys[c + 1] = keys[c]; --c; }
-                    keys[c + 1] = ka;
-                } else {
-                    const u32 ia = idx[a];
-                    i64 c = a - 1;
-                    while (c >= sp && keys[c] > ka) { keys[c + 1] = keys[c]; idx[c + 1] = idx[c]; --c; }
-                    keys[c + 1] = ka;
-                    idx[c + 1] = ia;
-                }
+        const u64 k = keys[sp];                                               // (only its prefix is used: the run's first flagged member may be moving keys)
+        // the run's start and end (prefixes do not change under the reordering)
+        i64 b = sp, e = sp + 1;
+        while (b > 0 && sp - b <= FIX_MAX && (keys[b - 1] >> shift) == (k >> shift)) --b;
+        while (e < T && e - b <= FIX_MAX && (keys[e] >> shift) == (k >> shift)) ++e;
+        if (e - b > FIX_MAX) { atomicOr(fallback, 1u); continue; }           // a long run that is not uniform: the caller sorts completely
+        bool first = true;                                                    // the run's FIRST flagged member reorders it (the flags are not written here)
+        for (i64 j = b + 1; j < sp; ++j)
+            if ((rarebits[j >> 6] >> (j & 63)) & 1ULL) { first = false; break; }
+        if (!first) continue;
+        for (i64 a = b + 1; a < e; ++a) {                                     // stable insertion sort by full key
+            const u64 ka = keys[a];
+            if (PACKED) {
+                const u64 fa = L.full_key(hI, hO, ka);
+                i64 c = a - 1;
+                while (c >= b && L.full_key(hI, hO, keys[c]) > fa) { keys[c + 1] = keys[c]; --c; }
+                keys[c + 1] = ka;
+            } else {
+                const u32 ia = idx[a];
+                i64 c = a - 1;
+                while (c >= b && keys[c] > ka) { keys[c + 1] = keys[c]; idx[c + 1] = idx[c]; --c; }
+                keys[c + 1] = ka;
+                idx[c + 1] = ia;
             }
-            if (dirtybits)                                                    // the merged terms of the reordered run, where they are now
-                for (i64 a = sp + 1; a < e; ++a)
-                    if (!fixup_differ<PACKED>(keys[a], keys[a - 1], hI, hO, L, same_operand)) {
-                        const i64 ca = a / 64, cb = (a - 1) / 64;
-                        atomicOr(&dirtybits[ca >> 5], 1u << (ca & 31));
-                        if (cb != ca) atomicOr(&dirtybits[cb >> 5], 1u << (cb & 31));
-                    }
-        } else {                                                              // a differing key inside a run: is the run too long?
-            i64 b = sp - 1, e = sp + 1;
-            while (b > 0 && sp - b <= FIX_MAX && (keys[b - 1] >> shift) == (k >> shift)) --b;
-            while (e < T && e - b <= FIX_MAX && (keys[e] >> shift) == (k >> shift)) ++e;
-            if (e - b > FIX_MAX) atomicOr(fallback, 1u);
         }
+        if (dirtybits)                                                        // the merged terms of the reordered run, where they are now
+            for (i64 a = b + 1; a < e; ++a)
+                if (!fixup_differ<PACKED>(keys[a], keys[a - 1], hI, hO, L, same_operand)) {
+                    const i64 ca = a / 64, cb = (a - 1) / 64;
+                    atomicOr(&dirtybits[ca >> 5], 1u << (ca & 31));
+                    if (cb != ca) atomicOr(&dirtybits[cb >> 5], 1u << (cb & 31));
+                }
     }
 }
 
@@ -2125,7 +2120,13 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                                (const double *)nullptr);
             KERNEL_CHECK();
         }
-        if (!packed) SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), Tk, 64 - nbits, 64, &in_tmp));
+        if (!packed) {
+            // (plain cleanups of up to 5e5 rows: the index sort in ONE launch — its three passes were nine launches, launch bound)
+            bool coop_done = false;
+            SG_TRY(radix_sort_pairs_u64_u32_coop(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), Tk, 64 - nbits, 64, &in_tmp, &coop_done));
+            if (coop_done) sus_coop = true;
+            else SG_TRY(radix_sort_pairs_u64_u32(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), Tk, 64 - nbits, 64, &in_tmp));
+        }
         ks = ks_sorted ? ks_sorted : (in_tmp ? keys2.as<u64>() : keys.as<u64>());
         is = packed ? nullptr : (in_tmp ? idx2.as<u32>() : idx.as<u32>());
         bool merges_found = false, patch_zeroed = false;               // lazy: dirtybits already filled by the fix-up passes

@@ -498,9 +498,13 @@ __device__ __forceinline__ bool coop_barrier(u32 *bar, u32 target, int G, u32 *s
     return G == 1 || *s_flag != 0;
 }
 
-__global__ __launch_bounds__(256) void k_rs_coop(u64 *__restrict__ buf_a, u64 *__restrict__ buf_b, i64 n, int begin_bit, int n_passes,
-                                                  u32 *__restrict__ tile_hist /* [256][G] */, u32 *__restrict__ bar, u32 bar_base) {
+// HAS_VALS: a 32-bit value travels with every key (round 6: the index sort of a plain cleanup — `A + B`, `cleanup()` — of up to 5e5 rows:
+// three passes were nine launches, launch bound)
+template <bool HAS_VALS>
+__global__ __launch_bounds__(256) void k_rs_coop(u64 *__restrict__ buf_a, u64 *__restrict__ buf_b, u32 *__restrict__ val_a, u32 *__restrict__ val_b, i64 n, int begin_bit,
+                                                  int n_passes, u32 *__restrict__ tile_hist /* [256][G] */, u32 *__restrict__ bar, u32 bar_base) {
     __shared__ u64 s_key[RS_TILE];
+    __shared__ u32 s_val[HAS_VALS ? RS_TILE : 1];
     __shared__ u32 s_cnt[4][256];                           // see k_rs_scatter: plain LDS accesses ordered by wavefront-scope fences
     __shared__ u32 s_dig_off[256];
     __shared__ u32 s_gbase[256];
@@ -515,15 +519,18 @@ __global__ __launch_bounds__(256) void k_rs_coop(u64 *__restrict__ buf_a, u64 *_
         const int shift = begin_bit + 8 * p;
         const u64 *src = (p & 1) ? buf_b : buf_a;
         u64 *dst = (p & 1) ? buf_a : buf_b;
+        const u32 *vsrc = (p & 1) ? val_b : val_a;
+        u32 *vdst = (p & 1) ? val_a : val_b;
 #pragma unroll
         for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
         __syncthreads();
         u64 key[RS_ITEMS];
-        u32 pos[RS_ITEMS];
+        u32 pos[RS_ITEMS], val[HAS_VALS ? RS_ITEMS : 1];
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r) {                                   // all sixteen loads in flight before the first one is used
             const i64 idx = tile_base + (i64)wave * RS_WSEG + r * 64 + lane;
             key[r] = idx < n ? __hip_atomic_load(src + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ULL;
+            if (HAS_VALS) val[r] = idx < n ? __hip_atomic_load(vsrc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         }
         asm volatile("" : "+v"(key[0]), "+v"(key[1]), "+v"(key[2]), "+v"(key[3]), "+v"(key[4]), "+v"(key[5]), "+v"(key[6]), "+v"(key[7]));
         asm volatile("" : "+v"(key[8]), "+v"(key[9]), "+v"(key[10]), "+v"(key[11]), "+v"(key[12]), "+v"(key[13]), "+v"(key[14]), "+v"(key[15]));
@@ -583,6 +590,7 @@ __global__ __launch_bounds__(256) void k_rs_coop(u64 *__restrict__ buf_a, u64 *_
             if (idx < n) {
                 const u32 d = (u32)(key[r] >> shift) & 255u;
                 s_key[s_dig_off[d] + s_cnt[wave][d] + pos[r]] = key[r];
+                if (HAS_VALS) s_val[s_dig_off[d] + s_cnt[wave][d] + pos[r]] = val[r];
             }
         }
         __syncthreads();
@@ -594,6 +602,7 @@ __global__ __launch_bounds__(256) void k_rs_coop(u64 *__restrict__ buf_a, u64 *_
                 const u64 kk = s_key[sidx];
                 const u32 d = (u32)(kk >> shift) & 255u;
                 __hip_atomic_store(dst + ((i64)s_gbase[d] + (sidx - (int)s_dig_off[d])), kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (HAS_VALS) __hip_atomic_store(vdst + ((i64)s_gbase[d] + (sidx - (int)s_dig_off[d])), s_val[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (!coop_barrier(bar, bar_base + (u32)G * (++n_bar), G, &s_ok)) return;
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(256) void k_rs_coop(u64 *__restrict__ buf_a, u64 *_
 }
 
 // returns SYMGPU_OK with *done = false if the array is too large for the one-launch form
-int radix_sort_keys_u64_coop(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done) {
+static int radix_sort_coop_launch(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done) {
     *done = false;
     *result_in_tmp = false;
     if (n <= 1) { *done = true; return SYMGPU_OK; }
@@ -623,13 +632,24 @@ int radix_sort_keys_u64_coop(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int
         HIP_TRY(hipMemsetAsync(c.sort_state, 0, 64 * sizeof(u32), st));
         c.sort_bar_base = 0;
     }
-    hipLaunchKernelGGL(k_rs_coop, dim3((unsigned)n_tiles), dim3(256), 0, st, keys, keys_tmp, n, begin_bit, n_passes, c.sort_state + 64, c.sort_state,
-                       c.sort_bar_base);
+    if (vals)
+        hipLaunchKernelGGL((k_rs_coop<true>), dim3((unsigned)n_tiles), dim3(256), 0, st, keys, keys_tmp, vals, vals_tmp, n, begin_bit, n_passes, c.sort_state + 64, c.sort_state,
+                           c.sort_bar_base);
+    else
+        hipLaunchKernelGGL((k_rs_coop<false>), dim3((unsigned)n_tiles), dim3(256), 0, st, keys, keys_tmp, (u32 *)nullptr, (u32 *)nullptr, n, begin_bit, n_passes, c.sort_state + 64,
+                           c.sort_state, c.sort_bar_base);
     KERNEL_CHECK();
     c.sort_bar_base += n_tiles > 1 ? arrivals : 0u;
     *result_in_tmp = (n_passes & 1) != 0;
     *done = true;
     return SYMGPU_OK;
+}
+int radix_sort_keys_u64_coop(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done) {
+    return radix_sort_coop_launch(keys, nullptr, keys_tmp, nullptr, n, begin_bit, end_bit, result_in_tmp, done);
+}
+// the same with a 32-bit value per key (plain cleanups of up to COOP_MAX_TILES tiles)
+int radix_sort_pairs_u64_u32_coop(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done) {
+    return radix_sort_coop_launch(keys, vals, keys_tmp, vals_tmp, n, begin_bit, end_bit, result_in_tmp, done);
 }
 
 // After the stream has been synchronised: did a one-launch sort since the last check give up at a barrier?  Then its output is garbage;
