@@ -173,7 +173,8 @@ __device__ __forceinline__ u64 mix_word(u64 x, u32 w, u64 seed) {
     b = fmix32(b ^ a);
     return ((u64)b << 32) | a;
 }
-__global__ __launch_bounds__(256) void k_hash_rows_mix(const u64 *__restrict__ rows, i64 T, int W, int G, u64 seed, u64 keep_mask, u64 *__restrict__ out1) {
+__global__ __launch_bounds__(256) void k_hash_rows_mix(const u64 *__restrict__ rows, i64 T, int W, int G, u64 seed, u64 keep_mask, u64 *__restrict__ out1,
+                                                        u32 *__restrict__ iota /* null, or [T]: iota[t] = t (the index array the sort carries) */) {
     // G lanes per row, a lane takes 16-byte chunks g, g + G, ... (W = 2 Wq is even: a row is a whole number of chunks)
     const int rows_per_block = 256 / G;
     const int g = threadIdx.x % G, rsub = threadIdx.x / G;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void k_hash_rows_mix(const u64 *__restrict__ r
         for (int u = 0; u < HU; ++u) {
             for (int off = G >> 1; off > 0; off >>= 1) h[u] ^= __shfl_xor(h[u], off);
             const i64 t = t0 + (i64)u * rows_per_block + rsub;
-            if (g == 0 && t < T) out1[t] = h[u] & keep_mask;
+            if (g == 0 && t < T) { out1[t] = h[u] & keep_mask; if (iota) iota[t] = (u32)t; }
         }
     }
 }
@@ -1305,9 +1306,12 @@ static int pow2_group(int W) {
 }
 
 // rows that are only compared with each other (see k_hash_rows_mix); `seed` as for the tables: a reseed changes the function
-int hash_rows_any(const u64 *rows, i64 T, int W, u64 seed, u64 *out1) {
+int hash_rows_any(const u64 *rows, i64 T, int W, u64 seed, u64 *out1, u32 *iota) {
     if (T == 0) return SYMGPU_OK;
-    if (W >= 64 * 128) return hash_rows(rows, T, W, out1);         // very long rows: the segmented kernel of the linear hash
+    if (W >= 64 * 128) {                                            // very long rows: the segmented kernel of the linear hash
+        if (iota) { hipLaunchKernelGGL(k_iota_keys_plain, dim3(grid_for(T)), dim3(256), 0, ctx().stream, iota, T); KERNEL_CHECK(); }
+        return hash_rows(rows, T, W, out1);
+    }
     u64 s = seed * 0x9E3779B97F4A7C15ULL + 0xD1B54A32D192ED03ULL;
     s ^= s >> 29; s *= 0xBF58476D1CE4E5B9ULL; s ^= s >> 32;
     u64 keep = ~0ULL;
@@ -1317,7 +1321,7 @@ int hash_rows_any(const u64 *rows, i64 T, int W, u64 seed, u64 *out1) {
     const int rpb = 4 * (256 / G);
     i64 g = (T + rpb - 1) / rpb;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_hash_rows_mix, dim3((unsigned)g), dim3(256), 0, ctx().stream, rows, T, W, G, s, keep, out1);
+    hipLaunchKernelGGL(k_hash_rows_mix, dim3((unsigned)g), dim3(256), 0, ctx().stream, rows, T, W, G, s, keep, out1, iota);
     KERNEL_CHECK();
     return SYMGPU_OK;
 }
@@ -2110,9 +2114,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                 KERNEL_CHECK();
             }
         } else {
-            SG_TRY(hash_rows_any(rows, T, W, seed, keys.as<u64>()));
-            hipLaunchKernelGGL(k_iota_keys_plain, dim3(grid_for(T)), dim3(256), 0, st, idx.as<u32>(), T);
-            KERNEL_CHECK();
+            SG_TRY(hash_rows_any(rows, T, W, seed, keys.as<u64>(), idx.as<u32>()));      // (and idx[t] = t, the array the sort carries)
         }
         if (!packed && lazy_a) {
             hipLaunchKernelGGL(k_mark_singles<false>, dim3((unsigned)((T + SORT_TILE - 1) / SORT_TILE)), dim3(256), 0, st, (const u64 *)nullptr, coeff, T, L, (const double *)nullptr,
@@ -2131,8 +2133,11 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
         is = packed ? nullptr : (in_tmp ? idx2.as<u32>() : idx.as<u32>());
         bool merges_found = false, patch_zeroed = false;               // lazy: dirtybits already filled by the fix-up passes
         // (no key has a partner — Tsort == 0 —: every term is a single, decided by k_mark_singles; the patch bitmap is zeroed in the same launch)
+        // (and without the lazy flow the kept-term bitmap, which the segment sums then fill: one launch for both)
+        const size_t space_now = (size_t)((squared && packed) ? Tk : T);
+        const bool mark_zeroed = !lazy_a && Tsort > 0;
         if (!(fix_bits < 64 && Tsort > 0 && lazy_a))
-            SG_TRY(zero_two(collision.p, 16, Tsort == 0 ? patchbits.p : nullptr, (size_t)((((squared && packed) ? Tk : T) + 63) / 64) * 8));
+            SG_TRY(zero_two(collision.p, 16, Tsort == 0 ? patchbits.p : nullptr, (space_now + 63) / 64 * 8, mark_zeroed ? markbits.p : nullptr, (space_now + 31) / 32 * 4));
         if (fix_bits < 64 && Tsort > 0) {
             const i64 n_ch = (Tsort + 63) / 64;
             SG_TRY(fixlist.alloc((size_t)n_ch * 8 + 16));                         // one word of flags per 64 positions
@@ -2191,7 +2196,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             }
             lazy_final = lazy_now;
             if (lazy_now) { if (!patch_zeroed) SG_TRY(zero_two(patchbits.p, (size_t)((space + 63) / 64) * 8, nullptr, 0)); }
-            else SG_TRY(zero_two(markbits.p, (size_t)((space + 31) / 32) * 4, nullptr, 0));
+            else if (!mark_zeroed) SG_TRY(zero_two(markbits.p, (size_t)((space + 31) / 32) * 4, nullptr, 0));
             u32 *patch_p = lazy_now ? patchbits.as<u32>() : nullptr;
             const u32 *zero_len_p = nullptr;
             const bool zero_on = [] { const char *e = SG_TUNE("SYMGPU_CLEANUP_ZEROSEG"); return !(e && e[0] == '0'); }();
