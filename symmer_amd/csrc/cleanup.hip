@@ -2026,7 +2026,11 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     KERNEL_CHECK();
                 }
                 if (!sus_try) {
-                    SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp, first_hist));
+                    // (small products — up to 5e5 keys, no first-pass histograms at hand —: the sort in ONE launch; its passes were three launches each)
+                    bool coop_done = false;
+                    if (!first_hist) SG_TRY(radix_sort_keys_u64_coop(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp, &coop_done));
+                    if (coop_done) sus_coop = true;
+                    else SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp, first_hist));
                 } else {
                     const int lo = 64 - nbits, hi = lo + 8 * sus_pass;
                     const i64 n_sc = (Tk + 63) / 64;
