@@ -2026,9 +2026,9 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
                     KERNEL_CHECK();
                 }
                 if (!sus_try) {
-                    // (small products — up to 5e5 keys, no first-pass histograms at hand —: the sort in ONE launch; its passes were three launches each)
+                    // (small products — up to 2e5 keys, no first-pass histograms at hand —: the sort in ONE launch; its passes were three launches each)
                     bool coop_done = false;
-                    if (!first_hist) SG_TRY(radix_sort_keys_u64_coop(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp, &coop_done));
+                    if (!first_hist) SG_TRY(radix_sort_keys_u64_small(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp, &coop_done));
                     if (coop_done) sus_coop = true;
                     else SG_TRY(radix_sort_keys_u64(keys.as<u64>(), keys2.as<u64>(), Tk, 64 - nbits, 64, &in_tmp, first_hist));
                 } else {
@@ -2127,7 +2127,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W, const u64 *
             KERNEL_CHECK();
         }
         if (!packed) {
-            // (plain cleanups of up to 5e5 rows: the index sort in ONE launch — its three passes were nine launches, launch bound)
+            // (plain cleanups of up to 1.3e5 rows: the index sort in ONE launch — its three passes were nine launches, launch bound)
             bool coop_done = false;
             SG_TRY(radix_sort_pairs_u64_u32_coop(keys.as<u64>(), idx.as<u32>(), keys2.as<u64>(), idx2.as<u32>(), Tk, 64 - nbits, 64, &in_tmp, &coop_done));
             if (coop_done) sus_coop = true;

@@ -215,6 +215,7 @@ int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp,
 int radix_sort_keys_u64(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, u32 *first_hist = nullptr);
 // the same as one persistent launch (up to 2^19 keys); *done = false: not applicable, use the multi-launch form
 int radix_sort_keys_u64_coop(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done);
+int radix_sort_keys_u64_small(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done);   // the one launch where it pays (<= ~2e5 keys)
 int radix_sort_pairs_u64_u32_coop(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done);
 const u32 *radix_sort_coop_flag();
 void radix_sort_coop_note(u32 flag, bool *timed_out);

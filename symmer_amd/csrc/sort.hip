@@ -479,6 +479,9 @@ int radix_sort_pairs_u64_u32(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp,
 // The workgroups must be co-resident: <= COOP_MAX_TILES blocks of 256 threads and 35 KB of LDS.
 // ------------------------------------------------------------------------------------------------
 constexpr int COOP_MAX_TILES = 128;
+// where the one launch beats a launch per step (round 6, P * P and plain cleanups of 100 qubits): keys alone up to ~2e5 (245,350 keys: 182
+// against 178 us; 125,250: 158 against 184), keys with values up to ~1.3e5 (100,000 rows: 116 against 121 us; 200,000: 140 against 127)
+constexpr int COOP_TILES_KEYS = 48, COOP_TILES_PAIRS = 32;
 
 // returns false if the other workgroups did not arrive within ~2^22 polls (not co-resident): the caller's kernel gives up, bar[1] says so
 __device__ __forceinline__ bool coop_barrier(u32 *bar, u32 target, int G, u32 *s_flag) {
@@ -610,12 +613,12 @@ __global__ __launch_bounds__(256) void k_rs_coop(u64 *__restrict__ buf_a, u64 *_
 }
 
 // returns SYMGPU_OK with *done = false if the array is too large for the one-launch form
-static int radix_sort_coop_launch(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done) {
+static int radix_sort_coop_launch(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done, bool auto_size) {
     *done = false;
     *result_in_tmp = false;
     if (n <= 1) { *done = true; return SYMGPU_OK; }
     const i64 n_tiles = (n + RS_TILE - 1) / RS_TILE;
-    if (n_tiles > COOP_MAX_TILES) return SYMGPU_OK;
+    if (n_tiles > COOP_MAX_TILES || (auto_size && n_tiles > (vals ? COOP_TILES_PAIRS : COOP_TILES_KEYS))) return SYMGPU_OK;
     if (const char *e = SG_TUNE("SYMGPU_SORT_COOP")) if (e[0] == '0') return SYMGPU_OK;
     Context &c = ctx();
     if (c.sort_coop_disabled) return SYMGPU_OK;
@@ -645,11 +648,15 @@ static int radix_sort_coop_launch(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals
     return SYMGPU_OK;
 }
 int radix_sort_keys_u64_coop(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done) {
-    return radix_sort_coop_launch(keys, nullptr, keys_tmp, nullptr, n, begin_bit, end_bit, result_in_tmp, done);
+    return radix_sort_coop_launch(keys, nullptr, keys_tmp, nullptr, n, begin_bit, end_bit, result_in_tmp, done, false);
+}
+// ... only where it beats the launches per step (small products: the caller has no better use for the answer than "sort these keys")
+int radix_sort_keys_u64_small(u64 *keys, u64 *keys_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done) {
+    return radix_sort_coop_launch(keys, nullptr, keys_tmp, nullptr, n, begin_bit, end_bit, result_in_tmp, done, true);
 }
 // the same with a 32-bit value per key (plain cleanups of up to COOP_MAX_TILES tiles)
 int radix_sort_pairs_u64_u32_coop(u64 *keys, u32 *vals, u64 *keys_tmp, u32 *vals_tmp, i64 n, int begin_bit, int end_bit, bool *result_in_tmp, bool *done) {
-    return radix_sort_coop_launch(keys, vals, keys_tmp, vals_tmp, n, begin_bit, end_bit, result_in_tmp, done);
+    return radix_sort_coop_launch(keys, vals, keys_tmp, vals_tmp, n, begin_bit, end_bit, result_in_tmp, done, true);
 }
 
 // After the stream has been synchronised: did a one-launch sort since the last check give up at a barrier?  Then its output is garbage;
