@@ -292,3 +292,17 @@ def test_bench_summary_carries_every_config():
     for key in ('product_1e5x1e5', 'cfg1_mul_500t_100q', 'cfg2_rotation', 'cfg3_mul_cleanup', 'cfg4_gf2', 'cfg5_adjacency', 'strong_scaling_shard'):
         assert key in sm, key
     assert sm['cfg5_adjacency']['predicted_8gpu_x'] == 7.43 and sm['cfg3_mul_cleanup']['api'] == [0.002346, 0.1654] and sm['failed_sections'] == ['broken_section']
+
+
+def test_lexicographic_order_from_packed_rows_equals_numpy_lexsort_of_the_columns():
+    """``sort('lex')`` and ``==`` (base.py:455-492, 640-662) order the rows by ``np.lexsort(symp_matrix.T)`` (last column = primary key); the
+    drop-in takes the order from the packed rows — 2 Wq sort keys instead of 2n — which must be the SAME permutation, ties included."""
+    rng = np.random.default_rng(321)
+    for n in (1, 5, 63, 64, 65, 130):
+        m = rng.random((300, 2 * n)) < 0.5
+        m[10] = m[3]; m[200] = m[3]                               # equal rows: a stable sort keeps their order
+        P = PauliwordOp(m, np.arange(300, dtype=complex))
+        assert np.array_equal(P._lex_order(), np.lexsort(m.T)), n
+        Q = P.sort('lex')
+        assert np.array_equal(Q.symp_matrix, m[np.lexsort(m.T)]) and np.array_equal(Q.coeff_vec, np.lexsort(m.T).astype(complex))
+    assert PauliwordOp(np.zeros((0, 6), dtype=bool), [])._lex_order().size == 0
