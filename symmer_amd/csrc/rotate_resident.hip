@@ -54,10 +54,12 @@ enum { CL_C = 1, CL_A = 2, CL_N = 4, CL_MATCHED = 8, CL_CLAIMED = 16, CL_SECOND 
 // coefficient (16), one word that is first the row's join state (claimed slot / partner / occupant) and later its rank (4), the rank
 // of its new row (4), info and class bytes.  Hashes are read from HBM where they are needed (twice, coalesced).
 struct ResLayout { int rows, coef, ps, posn, info, cls, q, wtot, misc, total, lds_chunks; };
-__host__ __device__ inline ResLayout res_layout(int R, int Wq, int nreg) {
+// hbm: the rows are NOT kept on the chip (round 6: operators beyond the 38 MB of LDS + registers): only the 26 bytes per row stay in LDS, the
+// rows are read a second time — from the Infinity Cache, mostly — when they are written out
+__host__ __device__ inline ResLayout res_layout(int R, int Wq, int nreg, int hbm = 0) {
     ResLayout L;
     int o = 0;
-    L.lds_chunks = R * Wq - nreg * 1024;
+    L.lds_chunks = hbm ? 0 : R * Wq - nreg * 1024;
     if (L.lds_chunks < 0) L.lds_chunks = 0;
     L.rows = o; o += L.lds_chunks * 16;
     L.coef = o; o += R * 16;
@@ -76,6 +78,7 @@ __host__ __device__ inline ResLayout res_layout(int R, int Wq, int nreg) {
 struct ResArgs {
     const u32x4 *rows; const double *coeff; const u64 *hin;
     i64 T; int Wq, R, GA, nreg; u32 yq;          // nreg: 1,024-chunk rounds of the row load that stay in registers (0 or 2)
+    int hbm;                                      // 1: rows are not kept on the chip (res_layout)
     u32x4 *out_rows; double *out_coeff; u64 *out_hash;
     double cos_t, sin_t, thr; int k;
     u64 hq;
@@ -187,7 +190,8 @@ template <int MODE, int WQ>
 __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nreg = WQ > 0 ? a.nreg : 0;                                      // (rows of a generic length are analysed from LDS: all of them live there)
-    const ResLayout L = res_layout(a.R, a.Wq, nreg);
+    const bool hbm = WQ > 0 && a.hbm != 0;                                     // (block-uniform) rows read again from memory where they are needed
+    const ResLayout L = res_layout(a.R, a.Wq, nreg, hbm ? 1 : 0);
     u32x4 *s_rows = reinterpret_cast<u32x4 *>(smem + L.rows);
     f64x2 *s_coef = reinterpret_cast<f64x2 *>(smem + L.coef);
     u32 *s_ps = reinterpret_cast<u32 *>(smem + L.ps);                          // join state, later: rank of the row in its class
@@ -217,7 +221,8 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
     const u32x4 *sq4 = reinterpret_cast<const u32x4 *>(s_q);
     u32x4 keep0 = (u32x4)(0u), keep1 = (u32x4)(0u);
     // chunk `it * 1024 + tid` of the block, from the registers or from LDS
-#define RES_CHUNK(it, i) (((it) < nreg) ? ((it) == 0 ? keep0 : keep1) : s_rows[(i) - reg_chunks])
+    const u32x4 *const rows_blk = a.rows + row0 * Wq;
+#define RES_CHUNK(it, i) (hbm ? rows_blk[(i)] : (((it) < nreg) ? ((it) == 0 ? keep0 : keep1) : s_rows[(i) - reg_chunks]))
     // ---- A1: the block's rows and coefficients: HBM -> registers / LDS, read once; flags and phase exponents on the way ---------
     {
         const u32x4 *src = a.rows + row0 * Wq;
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
 #pragma unroll
             for (int j = 0; j < RES_LD_UNROLL; ++j) {
                 const int i = i0 + j * RES_THREADS + tid;
-                v[j] = i < nchunk ? __builtin_nontemporal_load(src + i) : (u32x4)(0u);
+                v[j] = i < nchunk ? (hbm ? src[i] : __builtin_nontemporal_load(src + i)) : (u32x4)(0u);   // (hbm: the rows are read again: no streaming hint)
             }
             if (i0 == 0)
                 for (int r = tid; r < Rw; r += RES_THREADS) s_coef[r] = coeff2[row0 + r];
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
             for (int j = 0; j < RES_LD_UNROLL; ++j) {
                 const int i = i0 + j * RES_THREADS + tid;
                 if (i0 == 0 && j < 2 && j < nreg) { if (j == 0) keep0 = v[j]; else keep1 = v[j]; }
-                else if (i < nchunk) s_rows[i - reg_chunks] = v[j];
+                else if (i < nchunk && !hbm) s_rows[i - reg_chunks] = v[j];
             }
             if constexpr (WQ > 0 && MODE == 0) {
                 // What the first probes found (only now: the empty statement keeps the compiler from testing each answer right behind
@@ -672,9 +677,12 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     // the rows of the block in LDS; if they do not fit, the first two 1,024-chunk rounds of the load stay in registers (+32 KB per CU:
     // 1.46e5 -> 1.76e5 terms of 1,000 qubits — the operator a repeated rotation of 1e5 terms grows into, 1.5e5, is resident)
     const bool pow2 = Wq <= 32 && (Wq & (Wq - 1)) == 0;
-    int nreg = 0;
+    int nreg = 0, hbm = 0;
     ResLayout L = res_layout((int)R, Wq, 0);
     if ((size_t)L.total > RES_LDS_MAX && pow2) { nreg = 2; L = res_layout((int)R, Wq, nreg); }
+    // beyond that (round 6; rows of a power-of-two number of chunks): only the 26 bytes per row stay on the chip, the rows are read a second
+    // time when they are written out — 1e5 terms of 2,000 qubits (51 MB): 73 us on the multi-launch path, see DESIGN 3.4.  SYMGPU_ROT_HBM=0: off
+    if ((size_t)L.total > RES_LDS_MAX && pow2 && !(getenv("SYMGPU_ROT_HBM") && getenv("SYMGPU_ROT_HBM")[0] == '0')) { nreg = 0; hbm = 1; L = res_layout((int)R, Wq, 0, 1); }
     if ((size_t)L.total > RES_LDS_MAX) return SYMGPU_OK;
     const bool attr_ok = SG_DEVICE_ONCE(([] {
         for (int m = 0; m < 2; ++m)
@@ -716,6 +724,7 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     while (GA < Wq && GA < 64) GA <<= 1;
     a.GA = GA;
     a.nreg = nreg;
+    a.hbm = hbm;
     a.yq = 0;
     for (int ww = 0; ww < Wq; ++ww) a.yq += (u32)__builtin_popcountll(q_host[ww] & q_host[Wq + ww]);
     a.cos_t = cos_t; a.sin_t = sin_t; a.thr = thr; a.k = clifford_k;

@@ -266,6 +266,54 @@ def test_cfg2_full_size_rotations_against_the_oracle():
     assert np.array_equal(R.packed, packing.pack_rows(er1)) and np.allclose(R.coeff_vec, ec1, rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize('n,N', [(2000, 100000), (1000, 400000)])
+def test_one_launch_rotation_with_the_rows_left_in_memory(n, N, monkeypatch):
+    """Operators beyond the 38 MB of LDS + registers the one-launch rotation kernel holds (round 6: 1e5 terms of 2,000 qubits, 4e5 terms of
+    1,000 qubits): only the per-row state stays on the chip, the rows are read again when they are written.  A non-Clifford and a Clifford
+    rotation, then a non-Clifford rotation of the grown result: the one-launch kernel takes them (debug counter), rows / order / coefficients
+    equal the NumPy oracle of base.py:1090-1161 and, bit for bit, the multi-launch path (SYMGPU_ROT_HBM=0)."""
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(2026 + n)
+    P = DeviceOp.random(N, n, 0.3, seed=77 + n)
+    clean = kernels.cleanup_dev(P)
+    P.free()
+    rows0, c0 = clean.download()
+    symp0 = packing.unpack_rows(rows0, n)
+    cnt = ctypes.c_int64(0)
+
+    def one_launch_count():
+        _lib.check(_lib.lib().symgpu_debug_counter(1, ctypes.addressof(cnt)))
+        return cnt.value
+
+    q1 = rng.random(2 * n) < 0.3; q2 = rng.random(2 * n) < 0.3
+    for q, ang, exact in ((q1, 0.3, False), (q2, np.pi / 2, True)):
+        qpk = packing.pack_rows(q.reshape(1, -1))[0]
+        before = one_launch_count()
+        res, allc = kernels.rotate_single_dev(clean, qpk, ang)
+        assert not allc and one_launch_count() - before == 1, 'the one-launch kernel did not take the operator'
+        r, c = res.download()
+        monkeypatch.setenv('SYMGPU_ROT_HBM', '0')
+        res_m, _ = kernels.rotate_single_dev(clean, qpk, ang)
+        monkeypatch.delenv('SYMGPU_ROT_HBM')
+        rm, cm = res_m.download()
+        res_m.free()
+        assert np.array_equal(r, rm) and np.array_equal(c.view(np.uint64), cm.view(np.uint64)), 'differs from the multi-launch path'
+        er, ec = onp.rotate_by_single_pword(symp0, c0, q, ang)
+        assert np.array_equal(r, packing.pack_rows(er)), 'rows / row order differ from the oracle'
+        assert np.array_equal(c, ec) if exact else np.allclose(c, ec, rtol=0, atol=1e-12)
+        if not exact:                                             # the grown operator (hashes handed on by the kernel) once more
+            q3 = rng.random(2 * n) < 0.3
+            before = one_launch_count()
+            res2, _ = kernels.rotate_single_dev(res, packing.pack_rows(q3.reshape(1, -1))[0], -0.7)
+            assert one_launch_count() - before == 1
+            r2, c2 = res2.download()
+            er2, ec2 = onp.rotate_by_single_pword(er, ec, q3, -0.7)
+            assert np.array_equal(r2, packing.pack_rows(er2)) and np.allclose(c2, ec2, rtol=0, atol=1e-12)
+            res2.free()
+        res.free()
+    clean.free()
+
+
 @pytest.mark.parametrize('shape', ['squared 3000', 'general 2500x2000', 'general 2000x2500'])
 def test_product_cleanup_over_the_lazy_gate_against_the_c_oracle(shape):
     """Product + cleanup with more than 2^22 keys on the DEFAULT path (the lazy flow of cleanup.hip switches on there by itself;
