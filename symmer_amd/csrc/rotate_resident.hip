@@ -26,7 +26,8 @@
 // the partner's row in HBM); a mismatch, a third row under one canonical key, or an all-gather that does not complete (workgroups
 // not co-resident) makes the call report failure and the caller takes the multi-launch path.
 // Preconditions (else *done = 0): the operator is known to be duplicate free (symgpu_op_s::dup_free), carries its row hashes
-// (non-Clifford), has rows of <= 64 words, and its block of rows fits the LDS.
+// (non-Clifford), has rows of <= 128 words (4,096 qubits), and the per-row state of its block fits the LDS (the rows themselves may stay
+// in memory: res_layout's hbm form).
 #include "common.h"
 #include "rotate_common.h"
 #include <time.h>
@@ -54,6 +55,8 @@ enum { CL_C = 1, CL_A = 2, CL_N = 4, CL_MATCHED = 8, CL_CLAIMED = 16, CL_SECOND 
 // coefficient (16), one word that is first the row's join state (claimed slot / partner / occupant) and later its rank (4), the rank
 // of its new row (4), info and class bytes.  Hashes are read from HBM where they are needed (twice, coalesced).
 struct ResLayout { int rows, coef, ps, posn, info, cls, q, wtot, misc, total, lds_chunks; };
+constexpr int RES_MAX_W = 128;                   // words per row (4,096 qubits; round 5: 64)
+struct QArgW { u64 w[RES_MAX_W]; };
 // hbm: the rows are NOT kept on the chip (round 6: operators beyond the 38 MB of LDS + registers): only the 26 bytes per row stay in LDS, the
 // rows are read a second time — from the Infinity Cache, mostly — when they are written out
 __host__ __device__ inline ResLayout res_layout(int R, int Wq, int nreg, int hbm = 0) {
@@ -68,7 +71,7 @@ __host__ __device__ inline ResLayout res_layout(int R, int Wq, int nreg, int hbm
     L.info = o; o += R;
     L.cls = o; o += R;
     o = (o + 15) & ~15;
-    L.q = o; o += 64 * 8;
+    L.q = o; o += RES_MAX_W * 8;
     L.wtot = o; o += 256 * 8;
     L.misc = o; o += 32 * 4;
     L.total = o;
@@ -89,7 +92,7 @@ struct ResArgs {
     u64 *trace;                                   // [G][16] wall-clock stamps of the phases (SYMGPU_RES_TRACE=1), else null
     int inject;                                   // tests: the last workgroup leaves at once without a word (SYMGPU_RES_INJECT=1)
     u64 *host_words; u32 *host_late; u32 host_tag; u32 *published;   // pinned host memory: the report (res_report) and the late-failure word
-    QArg q;
+    QArgW q;
 };
 
 enum { M_OK = 1, M_FAIL = 2, M_NC = 3, M_NA = 4, M_NN = 5, M_NANTI = 6, M_PREF_C = 8, M_TOT_C = 9, M_PREF_A = 10, M_TOT_A = 11, M_PREF_N = 12,
@@ -190,7 +193,7 @@ template <int MODE, int WQ>
 __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nreg = WQ > 0 ? a.nreg : 0;                                      // (rows of a generic length are analysed from LDS: all of them live there)
-    const bool hbm = WQ > 0 && a.hbm != 0;                                     // (block-uniform) rows read again from memory where they are needed
+    const bool hbm = a.hbm != 0;                                               // (block-uniform) rows read again from memory where they are needed
     const ResLayout L = res_layout(a.R, a.Wq, nreg, hbm ? 1 : 0);
     u32x4 *s_rows = reinterpret_cast<u32x4 *>(smem + L.rows);
     f64x2 *s_coef = reinterpret_cast<f64x2 *>(smem + L.coef);
@@ -226,7 +229,9 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
     // ---- A1: the block's rows and coefficients: HBM -> registers / LDS, read once; flags and phase exponents on the way ---------
     {
         const u32x4 *src = a.rows + row0 * Wq;
-        for (int i0 = 0; i0 < nchunk; i0 += RES_LD_UNROLL * RES_THREADS) {
+        if (WQ == 0 && hbm)                                                    // (nothing to do with the rows here: A2 analyses them from memory)
+            for (int r = tid; r < Rw; r += RES_THREADS) s_coef[r] = coeff2[row0 + r];
+        for (int i0 = 0; i0 < ((WQ == 0 && hbm) ? 0 : nchunk); i0 += RES_LD_UNROLL * RES_THREADS) {
             u32x4 v[RES_LD_UNROLL];
 #pragma unroll
             for (int j = 0; j < RES_LD_UNROLL; ++j) {
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rot_resident(const ResArgs a) {
     if constexpr (WQ == 0) {
         // ---- A2: flags and phase exponents from LDS, GA lanes per row (row lengths that are not a power-of-two number of chunks) ---
         const int GA = a.GA, g = tid & (GA - 1), rsub = tid / GA, rpp = RES_THREADS / GA;
-        const u64 *rows64 = reinterpret_cast<const u64 *>(s_rows);
+        const u64 *rows64 = hbm ? reinterpret_cast<const u64 *>(rows_blk) : reinterpret_cast<const u64 *>(s_rows);
         for (int r0 = 0; r0 < Rw; r0 += rpp) {
             const int r = r0 + rsub;
             u32 pf = 0, yy = 0;                     // pf: parity of |x & zq| + |z & xq| (bit 0) and of |x & zq| (bit 1); yy: Y_P | Y_out << 16
@@ -663,7 +668,7 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     if (c.res_disabled) return SYMGPU_OK;
     const i64 T = in->T;
     const int Wq = in->Wq, W = 2 * Wq;
-    if (T < 1 || W > 64 || T >= ((i64)1 << 22) - 1) return SYMGPU_OK;
+    if (T < 1 || W > RES_MAX_W || T >= ((i64)1 << 22) - 1) return SYMGPU_OK;
     const bool clifford = clifford_k >= 0;
     if ((!clifford || (clifford_k & 1)) && !in->dup_free) return SYMGPU_OK;      // merges possible: the multi-launch paths check / handle them
     bool have_hash = in->hash && c.hash_tab && in->hash_seed == c.hash_seed;
@@ -680,9 +685,9 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     int nreg = 0, hbm = 0;
     ResLayout L = res_layout((int)R, Wq, 0);
     if ((size_t)L.total > RES_LDS_MAX && pow2) { nreg = 2; L = res_layout((int)R, Wq, nreg); }
-    // beyond that (round 6; rows of a power-of-two number of chunks): only the 26 bytes per row stay on the chip, the rows are read a second
+    // beyond that (round 6): only the 26 bytes per row stay on the chip, the rows are read a second
     // time when they are written out — 1e5 terms of 2,000 qubits (51 MB): 73 us on the multi-launch path, see DESIGN 3.4.  SYMGPU_ROT_HBM=0: off
-    if ((size_t)L.total > RES_LDS_MAX && pow2 && !(getenv("SYMGPU_ROT_HBM") && getenv("SYMGPU_ROT_HBM")[0] == '0')) { nreg = 0; hbm = 1; L = res_layout((int)R, Wq, 0, 1); }
+    if ((size_t)L.total > RES_LDS_MAX && !(getenv("SYMGPU_ROT_HBM") && getenv("SYMGPU_ROT_HBM")[0] == '0')) { nreg = 0; hbm = 1; L = res_layout((int)R, Wq, 0, 1); }
     if ((size_t)L.total > RES_LDS_MAX) return SYMGPU_OK;
     const bool attr_ok = SG_DEVICE_ONCE(([] {
         for (int m = 0; m < 2; ++m)
@@ -785,7 +790,7 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     host_tag = host_tag >= 65535 ? 1 : host_tag + 1;
     a.host_late = reinterpret_cast<u32 *>(hcnt_dev) + 8; a.host_words = reinterpret_cast<u64 *>(hcnt_dev) + 5; a.host_tag = host_tag;
     a.published = a.fail + 3;
-    for (int ww = 0; ww < 64; ++ww) a.q.w[ww] = ww < W ? q_host[ww] : 0ULL;
+    for (int ww = 0; ww < RES_MAX_W; ++ww) a.q.w[ww] = ww < W ? q_host[ww] : 0ULL;
     symgpu_op_t res = nullptr;
     SG_TRY(symgpu_op_alloc(clifford ? T : 2 * T, Wq, 1, &res));                   // upper bound: no host round trip before the rows are written
     if (have_hash) {

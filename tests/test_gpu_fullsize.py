@@ -266,12 +266,13 @@ def test_cfg2_full_size_rotations_against_the_oracle():
     assert np.array_equal(R.packed, packing.pack_rows(er1)) and np.allclose(R.coeff_vec, ec1, rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize('n,N', [(2000, 100000), (1000, 400000)])
+@pytest.mark.parametrize('n,N', [(2000, 100000), (1000, 400000), (3000, 100000), (3000, 8000)])
 def test_one_launch_rotation_with_the_rows_left_in_memory(n, N, monkeypatch):
     """Operators beyond the 38 MB of LDS + registers the one-launch rotation kernel holds (round 6: 1e5 terms of 2,000 qubits, 4e5 terms of
-    1,000 qubits): only the per-row state stays on the chip, the rows are read again when they are written.  A non-Clifford and a Clifford
+    1,000 qubits; 3,000 qubits: rows of 94 words, not a power-of-two number of chunks — analysed from memory — and, at 8,000 terms, rows of
+    more than 64 words resident in LDS): only the per-row state stays on the chip, the rows are read again when they are written.  A non-Clifford and a Clifford
     rotation, then a non-Clifford rotation of the grown result: the one-launch kernel takes them (debug counter), rows / order / coefficients
-    equal the NumPy oracle of base.py:1090-1161 and, bit for bit, the multi-launch path (SYMGPU_ROT_HBM=0)."""
+    equal the NumPy oracle of base.py:1090-1161 and, bit for bit, the multi-launch path (SYMGPU_ROT_RESIDENT=0)."""
     from oracle import oracle_np as onp
     rng = np.random.default_rng(2026 + n)
     P = DeviceOp.random(N, n, 0.3, seed=77 + n)
@@ -292,9 +293,9 @@ def test_one_launch_rotation_with_the_rows_left_in_memory(n, N, monkeypatch):
         res, allc = kernels.rotate_single_dev(clean, qpk, ang)
         assert not allc and one_launch_count() - before == 1, 'the one-launch kernel did not take the operator'
         r, c = res.download()
-        monkeypatch.setenv('SYMGPU_ROT_HBM', '0')
+        monkeypatch.setenv('SYMGPU_ROT_RESIDENT', '0')
         res_m, _ = kernels.rotate_single_dev(clean, qpk, ang)
-        monkeypatch.delenv('SYMGPU_ROT_HBM')
+        monkeypatch.delenv('SYMGPU_ROT_RESIDENT')
         rm, cm = res_m.download()
         res_m.free()
         assert np.array_equal(r, rm) and np.array_equal(c.view(np.uint64), cm.view(np.uint64)), 'differs from the multi-launch path'
