@@ -686,8 +686,9 @@ int rotate_resident_try(symgpu_op_t in, const u64 *q_host, double cos_t, double 
     ResLayout L = res_layout((int)R, Wq, 0);
     if ((size_t)L.total > RES_LDS_MAX && pow2) { nreg = 2; L = res_layout((int)R, Wq, nreg); }
     // beyond that (round 6): only the 26 bytes per row stay on the chip, the rows are read a second
-    // time when they are written out — 1e5 terms of 2,000 qubits (51 MB): 73 us on the multi-launch path, see DESIGN 3.4.  SYMGPU_ROT_HBM=0: off
-    if ((size_t)L.total > RES_LDS_MAX && !(getenv("SYMGPU_ROT_HBM") && getenv("SYMGPU_ROT_HBM")[0] == '0')) { nreg = 0; hbm = 1; L = res_layout((int)R, Wq, 0, 1); }
+    // time when they are written out — 1e5 terms of 2,000 qubits (51 MB): 73 us on the multi-launch path, see DESIGN 3.4
+    const char *hbm_env = getenv("SYMGPU_ROT_HBM");                                  // 0: off; 2 (tests): also for operators that would fit the chip
+    if (((size_t)L.total > RES_LDS_MAX && !(hbm_env && hbm_env[0] == '0')) || (hbm_env && hbm_env[0] == '2')) { nreg = 0; hbm = 1; L = res_layout((int)R, Wq, 0, 1); }
     if ((size_t)L.total > RES_LDS_MAX) return SYMGPU_OK;
     const bool attr_ok = SG_DEVICE_ONCE(([] {
         for (int m = 0; m < 2; ++m)

@@ -1210,6 +1210,14 @@ def test_jordan_and_reindex_golden(case):
 
 
 @pytest.mark.parametrize('case', family('rotate')[::3])
+def test_rotate_golden_rows_left_in_memory(case, monkeypatch):
+    """SYMGPU_ROT_HBM=2 makes the one-launch rotation kernel leave the rows in memory (the form operators beyond the chip's LDS take,
+    csrc/rotate_resident.hip) whatever the operator's size: the reference-generated cases, every row length among them."""
+    monkeypatch.setenv('SYMGPU_ROT_HBM', '2')
+    test_rotate_golden(case)
+
+
+@pytest.mark.parametrize('case', family('rotate')[::3])
 def test_rotate_golden_general_path(case, monkeypatch):
     """SYMGPU_ROTATE_GENERAL=1 disables the hash-join (non-Clifford) and fused (Clifford) fast paths: the stacked-operator +
     cleanup path that serves inputs with duplicate rows and very large operators must give the same answers."""
