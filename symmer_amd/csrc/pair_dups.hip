@@ -38,7 +38,7 @@ constexpr int PD_THREADS = 1024;
 constexpr int PD_QUOTA = 16;                        // pairs per lane and product bucket: 16,384 pairs per bucket at most
 constexpr int PD_TARGET = 12288;                    // pairs per product bucket the bucket width is chosen for
 constexpr int PD_SLOT_BITS = 17;                    // 4-bit counters: 64 KiB (two 1-bit maps, `seen` and `dup`, were measured: 6 % slower)
-constexpr int PD_CAND = 1536, PD_CHAIN = 1024;
+constexpr int PD_CAND = 1792, PD_CHAIN = 1024;         // (cfg3 lists 1,140 +- 50 pairs per product bucket, 1,269 at most over its 4,096 buckets)
 constexpr int PD_MIN_B = 8;
 constexpr int PD_MAX_B = 12;                        // 4,096 buckets: four per lane
 constexpr int PD_MAX_BUCKET = 255;                  // terms per operand bucket (longer: the hashes are not spread — repeated rows)
