@@ -288,7 +288,7 @@ int cleanup_core(const u64 *rows, const double *coeff, i64 T, int W,          //
                  bool want_first = false);                                                          // the result carries symgpu_op_s::first
 
 // pair_dups.hip — the pairs of a product whose 64-bit key another pair shares, found without sorting the keys
-bool pair_dups_fits(i64 Ni, i64 No, bool squared, i64 Tk, int *B_out);      // host-side: would pair_dups_dev take this product?
+bool pair_dups_fits(i64 Ni, i64 No, bool squared, i64 Tk, int *B_out, int *sb_out = nullptr);      // host-side: would pair_dups_dev take this product?
 int pair_dups_dev(const u64 *hI, i64 Ni, const u64 *hO, i64 No, bool squared, i64 Tk, u64 *flags, u32 *giveup, bool *applies);
 
 // gf2.hip

@@ -8,7 +8,8 @@
 //
 // Here the keys are never moved.  The terms of each operand are bucketed by the top B bits of their hash (k_pd_bucket: 10^4 terms, one
 // workgroup); the pairs whose key starts with beta are then exactly the TILES (bucket a of one operand) x (bucket a ^ beta of the other), for
-// all a.  A persistent workgroup takes the product buckets beta one after the other, with the bucketed hash words of the operands in its LDS:
+// all a.  A persistent workgroup takes the product buckets beta one after the other, with the bucketed hash words of the operands in its LDS
+// (4,096 buckets of up to 12,288 pairs — 10,030 terms squared —, or, for squared operators, 8,192 of up to 9,216 with half the counters):
 //   tiles   per a: the size of tile (a, a ^ beta); a block scan gives every tile its first pair number (P * P: only the tiles a < a ^ beta —
 //           the tile (a ^ beta, a) holds the same pairs; beta = 0, pairs inside one bucket, takes a loop of its own);
 //   count   every lane takes q = ceil(P / 1024) consecutive pair numbers: the tile's owner has left it its first tile and place, it walks on from there — one
@@ -40,9 +41,10 @@ constexpr int PD_TARGET = 12288;                    // pairs per product bucket 
 constexpr int PD_SLOT_BITS = 17;                    // 4-bit counters: 64 KiB (two 1-bit maps, `seen` and `dup`, were measured: 6 % slower)
 constexpr int PD_CAND = 1792, PD_CHAIN = 1024;         // (cfg3 lists 1,140 +- 50 pairs per product bucket, 1,269 at most over its 4,096 buckets)
 constexpr int PD_MIN_B = 8;
-constexpr int PD_MAX_B = 12;                        // 4,096 buckets: four per lane
+constexpr int PD_MAX_B = 13;                        // 8,192 buckets: eight per lane (two groups of four); up to 12: 4,096, one group
+constexpr int PD_TARGET_16 = 9216;                  // pairs per product bucket with the 32 KiB counter table of the 8,192-bucket form
 constexpr int PD_MAX_BUCKET = 255;                  // terms per operand bucket (longer: the hashes are not spread — repeated rows)
-constexpr size_t PD_LDS_MAX = 160 * 1024 - 256;
+constexpr size_t PD_LDS_MAX = 160 * 1024 - 512;     // (the kernel's static LDS — wavefront sums, two counters — comes on top)
 
 // inclusive prefix sum over the wavefront: four row_shr steps inside the rows of 16 lanes, then lane 15 of rows 0 and 2 into rows 1 and 3
 // (row_bcast:15) and lane 31 into the upper half (row_bcast:31) — DPP modifiers, no LDS round trips (__shfl_up is a ds_bpermute each)
@@ -56,8 +58,9 @@ __device__ __forceinline__ u32 pd_wave_scan(u32 x) {
     return x;
 }
 // the 4-bit counter of a word: index of its 32-bit word, shift of its field
-__device__ __forceinline__ u32 pd_cnt_word(u32 v) { return v >> (32 - PD_SLOT_BITS + 3); }
-__device__ __forceinline__ u32 pd_cnt_shift(u32 v) { return ((v >> (32 - PD_SLOT_BITS)) << 2) & 28u; }
+// (sb = log2 of the counters: 17, 64 KiB — or 16 with 8,192 buckets, whose tile list and bucket starts need the other 32 KiB)
+__device__ __forceinline__ u32 pd_cnt_word(u32 v, int sb) { return v >> (32 - sb + 3); }
+__device__ __forceinline__ u32 pd_cnt_shift(u32 v, int sb) { return ((v >> (32 - sb)) << 2) & 28u; }
 
 // one workgroup per operand: terms in bucket order (unordered inside a bucket) — hash word behind the bucket bits, full hash, term index
 __global__ __launch_bounds__(1024) void k_pd_bucket(const u64 *__restrict__ hI, int nI, const u64 *__restrict__ hO, int nO, int B, u32 *__restrict__ tab_w,
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(1024) void k_pd_bucket(const u64 *__restrict__ hI, 
 struct PairDupArgs {
     const u32 *tab_w; const u64 *tab_h; const u32 *tab_idx; const unsigned short *start;
     int nI, nO, B, squared;                          // squared: ONE table (nO = 0), pairs i >= o
+    int sb;                                          // log2 of the 4-bit counters (17 or 16)
     i64 Ni;                                          // terms of the inner operand (index of a pair: o * Ni + i; squared: PairKeyArgs' compacted slot)
     u64 *flags; u32 *giveup;
 };
@@ -135,8 +139,8 @@ __device__ __forceinline__ u64 pd_hash(const PairDupArgs &a, u32 xy) {
 //   s_lane   [1024] u32      where a lane's first pair lies: tile << 16 | pair number inside the tile
 //   s_sI, s_sO [nb + 4] u16  bucket starts of the two tables (P * P: one)
 __host__ __device__ inline size_t pd_tile_cap(int nb, int squared) { return squared ? (size_t)nb / 2 + 4 : (size_t)nb; }
-__host__ __device__ inline size_t pd_lds_bytes(int nTab, int nb, int squared) {
-    return (size_t)((nTab + 3) & ~3) * 4 + ((size_t)1 << (PD_SLOT_BITS - 3)) * 4 + pd_tile_cap(nb, squared) * 8 + (size_t)PD_CAND * 12 + (size_t)PD_CHAIN * 4 +
+__host__ __device__ inline size_t pd_lds_bytes(int nTab, int nb, int squared, int sb) {
+    return (size_t)((nTab + 3) & ~3) * 4 + ((size_t)1 << (sb - 3)) * 4 + pd_tile_cap(nb, squared) * 8 + (size_t)PD_CAND * 12 + (size_t)PD_CHAIN * 4 +
            (size_t)PD_THREADS * 4 + (size_t)(squared ? 1 : 2) * (nb + 4) * 2;
 }
 
@@ -152,7 +156,8 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
     const int nb = 1 << a.B, nTab = a.nI + a.nO;
     u32 *s_w = reinterpret_cast<u32 *>(smem);
     u32 *s_cnt = s_w + ((nTab + 3) & ~3);
-    uint2 *s_tiles = reinterpret_cast<uint2 *>(s_cnt + (1 << (PD_SLOT_BITS - 3)));
+    const int cbits = a.sb;                                                    // log2 of the counters
+    uint2 *s_tiles = reinterpret_cast<uint2 *>(s_cnt + (1 << (cbits - 3)));
     u32 *s_lw = reinterpret_cast<u32 *>(s_tiles + pd_tile_cap(nb, a.squared));
     u32 *s_lxy = s_lw + PD_CAND;
     u32 *s_next = s_lxy + PD_CAND;
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
     u32 *s_lane = s_head + PD_CHAIN;
     unsigned short *s_sI = reinterpret_cast<unsigned short *>(s_lane + NT);
     unsigned short *s_sO = a.squared ? s_sI : s_sI + (nb + 4);
-    __shared__ __attribute__((aligned(16))) u32 s_wsum[32];                     // inclusive sums per wavefront: pairs, then tiles
+    __shared__ __attribute__((aligned(16))) u32 s_wsum[64];                     // inclusive sums per wavefront: pairs, tiles (and the same of the second groups)
     __shared__ u32 s_nc, s_over;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (*a.giveup & 8u) return;                                                 // a bucket longer than the positions below can address: not for this path
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
         PD_STAMP(5);
         {
             const u32x4 z = {0u, 0u, 0u, 0u};
-            for (int i = tid; i < (1 << (PD_SLOT_BITS - 5)); i += NT) reinterpret_cast<u32x4 *>(s_cnt)[i] = z;
+            for (int i = tid; i < (1 << (cbits - 5)); i += NT) reinterpret_cast<u32x4 *>(s_cnt)[i] = z;
         }
         for (int i = tid; i < PD_CHAIN; i += NT) s_head[i] = 0xFFFFFFFFu;
         s_lane[tid] = 0u;
@@ -193,9 +198,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
         if (!inside) {
             // ---- tiles of this product bucket: sizes (a lane: groups of four consecutive buckets a — their partners a ^ beta are a group of
             //      four as well), scan, list of the non-empty ones with the lanes whose first pair lies in them
-            u32 tsz[4], tax[4], tby[4];
-            {
-                const int a0 = 4 * tid;
+            auto group = [&](int a0, u32 (&tsz)[4], u32 (&tax)[4], u32 (&tby)[4]) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { tsz[j] = 0; tax[j] = 0; tby[j] = 0; }
                 if (a0 < nb) {
@@ -212,16 +215,34 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
                         tax[j] = sa[j] | (sa[j + 1] << 16); tby[j] = lo_b | (hi_b << 16);
                     }
                 }
-            }
+            };
+            // (the lane's first four buckets stay in registers across the scan; with 8,192 buckets its second four, a = 4,096 + 4 tid ..., are
+            // formed again behind it)
+            const bool two_groups = nb > 4 * NT;
+            u32 tsz[4], tax[4], tby[4];
+            group(4 * tid, tsz, tax, tby);
             PD_STAMP(7);
             u32 mysum = 0, mytiles = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { mysum += tsz[j]; mytiles += tsz[j] ? 1u : 0u; }
+            // tile order = pair order: all first groups (a < 4,096) come before all second groups, so the two are scanned one after the other
+            u32 mysum2 = 0, mytiles2 = 0;
+            if (two_groups) {
+                u32 t2[4], x2[4], y2[4];
+                group(4 * (tid + NT), t2, x2, y2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { mysum2 += t2[j]; mytiles2 += t2[j] ? 1u : 0u; }
+            }
             const u32 inc_s = pd_wave_scan(mysum), inc_t = pd_wave_scan(mytiles);     // (two sums: a tile holds up to 255 x 255 pairs)
-            if (lane == 63) { s_wsum[wave] = inc_s; s_wsum[16 + wave] = inc_t; }
+            u32 inc_s2 = 0, inc_t2 = 0;
+            if (two_groups) { inc_s2 = pd_wave_scan(mysum2); inc_t2 = pd_wave_scan(mytiles2); }
+            if (lane == 63) {
+                s_wsum[wave] = inc_s; s_wsum[16 + wave] = inc_t;
+                if (two_groups) { s_wsum[32 + wave] = inc_s2; s_wsum[48 + wave] = inc_t2; }
+            }
             __syncthreads();
             PD_STAMP(8);
-            u32 base_s = 0, base_t = 0, P = 0, ntl = 0;
+            u32 base_s = 0, base_t = 0, P = 0, ntl = 0, base_s2 = 0, base_t2 = 0, P2 = 0, ntl2 = 0;
             {
                 const u32x4 *ws4 = reinterpret_cast<const u32x4 *>(s_wsum);
 #pragma unroll
@@ -233,7 +254,20 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
                         base_s += (w4 * 4 + j) < wave ? vs[j] : 0u; base_t += (w4 * 4 + j) < wave ? vt[j] : 0u;
                     }
                 }
+                if (two_groups) {
+#pragma unroll
+                    for (int w4 = 0; w4 < 4; ++w4) {
+                        const u32x4 vs = ws4[8 + w4], vt = ws4[12 + w4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            P2 += vs[j]; ntl2 += vt[j];
+                            base_s2 += (w4 * 4 + j) < wave ? vs[j] : 0u; base_t2 += (w4 * 4 + j) < wave ? vt[j] : 0u;
+                        }
+                    }
+                }
             }
+            const u32 P1 = P, ntl1 = ntl;
+            P += P2; ntl += ntl2;
             if (P > (u32)(PD_QUOTA * NT)) {                                     // (block-uniform)
                 if (tid == 0) atomicOr(a.giveup, 1u);
                 __syncthreads();
@@ -243,15 +277,22 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
             const u32 q = (u32)__builtin_amdgcn_readfirstlane((int)((P + NT - 1) / NT));   // pairs per lane, block-uniform
             const u32 qinv = ((1u << 20) + q - 1) / q;                         // x / q = (x * qinv) >> 20 for x < 2^15, q <= 32
             {
-                u32 off = base_s + inc_s - mysum, tix = base_t + inc_t - mytiles;
+                auto file = [&](u32 off, u32 tix, const u32 (&tsz_)[4], const u32 (&tax_)[4], const u32 (&tby_)[4]) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const u32 c = tsz[j];
-                    if (c) {
-                        s_tiles[tix] = uint2{tax[j], tby[j]};
-                        for (u32 L = ((off + q - 1) * qinv) >> 20; L * q < off + c; ++L) s_lane[L] = (tix << 16) | (L * q - off);
-                        ++tix; off += c;
+                    for (int j = 0; j < 4; ++j) {
+                        const u32 c = tsz_[j];
+                        if (c) {
+                            s_tiles[tix] = uint2{tax_[j], tby_[j]};
+                            for (u32 L = ((off + q - 1) * qinv) >> 20; L * q < off + c; ++L) s_lane[L] = (tix << 16) | (L * q - off);
+                            ++tix; off += c;
+                        }
                     }
+                };
+                file(base_s + inc_s - mysum, base_t + inc_t - mytiles, tsz, tax, tby);
+                if (two_groups) {
+                    u32 t2[4], x2[4], y2[4];
+                    group(4 * (tid + NT), t2, x2, y2);
+                    file(P1 + base_s2 + inc_s2 - mysum2, ntl1 + base_t2 + inc_t2 - mytiles2, t2, x2, y2);
                 }
             }
             __syncthreads();
@@ -293,10 +334,10 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
                     u32 old[HQ];
 #pragma unroll
                     for (int k = 0; k < HQ; ++k)
-                        if ((u32)(h * HQ + k) < q) old[k] = atomicAdd(&s_cnt[pd_cnt_word(hw[h * HQ + k])], (u32)(h * HQ + k) < rem ? 1u << pd_cnt_shift(hw[h * HQ + k]) : 0u);
+                        if ((u32)(h * HQ + k) < q) old[k] = atomicAdd(&s_cnt[pd_cnt_word(hw[h * HQ + k], cbits)], (u32)(h * HQ + k) < rem ? 1u << pd_cnt_shift(hw[h * HQ + k], cbits) : 0u);
 #pragma unroll
                     for (int k = 0; k < HQ; ++k)
-                        if ((u32)(h * HQ + k) < q) sat |= ((old[k] >> pd_cnt_shift(hw[h * HQ + k])) & 15u) == 15u ? 1u : 0u;
+                        if ((u32)(h * HQ + k) < q) sat |= ((old[k] >> pd_cnt_shift(hw[h * HQ + k], cbits)) & 15u) == 15u ? 1u : 0u;
                 }
             }
         } else {
@@ -307,7 +348,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
                 for (u32 x = s0 + 1; x < s1; ++x)
                     for (u32 y = s0; y < x; ++y) {
                         const u32 v = s_w[x] ^ s_w[y];
-                        const u32 o = (atomicAdd(&s_cnt[pd_cnt_word(v)], 1u << pd_cnt_shift(v)) >> pd_cnt_shift(v)) & 15u;
+                        const u32 o = (atomicAdd(&s_cnt[pd_cnt_word(v, cbits)], 1u << pd_cnt_shift(v, cbits)) >> pd_cnt_shift(v, cbits)) & 15u;
                         sat |= o == 15u ? 1u : 0u;
                     }
             }
@@ -325,7 +366,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
             u32 lm = 0;
 #pragma unroll
             for (int k = 0; k < PD_QUOTA; ++k)
-                if ((u32)k < rem && (hw[k] == 0u || ((s_cnt[pd_cnt_word(hw[k])] >> pd_cnt_shift(hw[k])) & 15u) >= 2u)) lm |= 1u << k;
+                if ((u32)k < rem && (hw[k] == 0u || ((s_cnt[pd_cnt_word(hw[k], cbits)] >> pd_cnt_shift(hw[k], cbits)) & 15u) >= 2u)) lm |= 1u << k;
             const u32 mine = (u32)__popc(lm);
             const u32 inc = pd_wave_scan(mine);
             const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
@@ -343,7 +384,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
                 for (u32 x = s0 + 1; x < s1; ++x)
                     for (u32 y = s0; y < x; ++y) {
                         const u32 v = s_w[x] ^ s_w[y];
-                        if (v == 0u || ((s_cnt[pd_cnt_word(v)] >> pd_cnt_shift(v)) & 15u) >= 2u) {
+                        if (v == 0u || ((s_cnt[pd_cnt_word(v, cbits)] >> pd_cnt_shift(v, cbits)) & 15u) >= 2u) {
                             const u32 n = atomicAdd(&s_nc, 1u);
                             if (n < (u32)PD_CAND) { s_lw[n] = v; s_lxy[n] = x | (y << 16); }
                         }
@@ -392,28 +433,33 @@ static_assert(PD_CHAIN == 1024, "the chain hash keeps 10 bits");
 // whose 64-bit key equals another pair's, and of every pair whose key is zero.  *applies = false: the operands do not fit this path (nothing
 // was launched).  giveup (device word, zeroed by the caller) != 0 afterwards: the flags are incomplete, take the sorted path.
 // pair_dups_fits: does this path take the product?  (host-side: sizes only; *B_out: the bucket width)
-bool pair_dups_fits(i64 Ni, i64 No, bool squared, i64 Tk, int *B_out) {
+bool pair_dups_fits(i64 Ni, i64 No, bool squared, i64 Tk, int *B_out, int *sb_out) {
     if (getenv("SYMGPU_CLEANUP_DIRECT") && getenv("SYMGPU_CLEANUP_DIRECT")[0] == '0') return false;
     const i64 nI = Ni, nO = squared ? 0 : No;
     if (nI + nO > 65535 || nI < 2 || (!squared && nO < 1)) return false;
-    int B = 2;
-    while (B < PD_MAX_B && (Tk >> B) > PD_TARGET) ++B;
-    if ((Tk >> B) > PD_TARGET) return false;
+    int B = 2, sb = PD_SLOT_BITS;
+    while (B < 12 && (Tk >> B) > PD_TARGET) ++B;
+    if ((Tk >> B) > PD_TARGET) {
+        // 8,192 buckets: their tile list and bucket starts take 24 KiB more, which the counters give up — fewer pairs per bucket for the smaller table
+        B = 13; sb = 16;
+        if ((Tk >> B) > PD_TARGET_16) return false;
+    }
     if (B < PD_MIN_B) return false;                  // (below ~1.6e6 keys the sorted flag pass is as fast: P * P of 1,500 terms 0.29 against 0.30 ms)
-    if (pd_lds_bytes((int)(nI + nO), 1 << B, squared ? 1 : 0) > PD_LDS_MAX) return false;
+    if (pd_lds_bytes((int)(nI + nO), 1 << B, squared ? 1 : 0, sb) > PD_LDS_MAX) return false;
     if (B_out) *B_out = B;
+    if (sb_out) *sb_out = sb;
     return true;
 }
 
 int pair_dups_dev(const u64 *hI, i64 Ni, const u64 *hO, i64 No, bool squared, i64 Tk, u64 *flags, u32 *giveup, bool *applies) {
     *applies = false;
-    int B = 0;
-    if (!pair_dups_fits(Ni, No, squared, Tk, &B)) return SYMGPU_OK;
+    int B = 0, sb = PD_SLOT_BITS;
+    if (!pair_dups_fits(Ni, No, squared, Tk, &B, &sb)) return SYMGPU_OK;
     const i64 nI = Ni, nO = squared ? 0 : No;
     const int nb = 1 << B;
-    const size_t lds = pd_lds_bytes((int)(nI + nO), nb, squared ? 1 : 0);
+    const size_t lds = pd_lds_bytes((int)(nI + nO), nb, squared ? 1 : 0, sb);
     const bool attr = SG_DEVICE_ONCE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair_dups), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PD_LDS_MAX) == hipSuccess);
-    if (!attr) return SYMGPU_OK;
+    if (!attr) { (void)hipGetLastError(); return SYMGPU_OK; }
     hipStream_t st = ctx().stream;
     Scratch tab;
     const size_t n = (size_t)(nI + nO);
@@ -427,7 +473,7 @@ int pair_dups_dev(const u64 *hI, i64 Ni, const u64 *hO, i64 No, bool squared, i6
     KERNEL_CHECK();
     PairDupArgs a;
     a.tab_w = tab_w; a.tab_h = tab_h; a.tab_idx = tab_idx; a.start = start;
-    a.nI = (int)nI; a.nO = (int)nO; a.B = B; a.squared = squared ? 1 : 0; a.Ni = Ni; a.flags = flags; a.giveup = giveup;
+    a.nI = (int)nI; a.nO = (int)nO; a.B = B; a.sb = sb; a.squared = squared ? 1 : 0; a.Ni = Ni; a.flags = flags; a.giveup = giveup;
     const int P = ctx().num_cu < nb ? ctx().num_cu : nb;
     hipLaunchKernelGGL(k_pair_dups, dim3((unsigned)P), dim3(PD_THREADS), lds, st, a);
     KERNEL_CHECK();

@@ -27,7 +27,7 @@ for case in range(n_cases):
     n = int(rng.choice([14, 20, 33, 64, 100, 130]))
     squared = rng.random() < 0.5
     if squared:
-        N = int(rng.choice([1800, 2500, 4000, 6000, 8000, 10200, 10300])); M = N
+        N = int(rng.choice([1800, 2500, 4000, 6000, 8000, 10000, 10100, 11000, 12200, 12400])); M = N   # (from 10,031 terms: 8,192 buckets; 12,300: beyond the path)
     else:
         N, M = [(1300, 1300), (2000, 1700), (4000, 3000), (6000, 900), (9000, 700), (5000, 5000), (12000, 600), (16000, 300)][int(rng.integers(0, 8))]
     A = rng.random((N, 2 * n)) < 0.3
