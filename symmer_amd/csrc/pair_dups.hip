@@ -412,7 +412,8 @@ __global__ __launch_bounds__(PD_THREADS) void k_pair_dups(const PairDupArgs a) {
             bool have = false;
             if (wc == 0u) { Hc = pd_hash(a, xyc); have = true; }
             bool hit = have && Hc == 0ULL;                                      // the identity
-            for (u32 j = hit ? 0xFFFFFFFFu : s_head[hsh]; j != 0xFFFFFFFFu; j = s_next[j]) {
+            u32 steps = 0;                                                     // (a chain holds at most nc pairs: the walk ends whatever the links say)
+            for (u32 j = hit ? 0xFFFFFFFFu : s_head[hsh]; j < nc && steps < nc; j = s_next[j], ++steps) {
                 if (j != c && s_lw[j] == wc) {
                     if (!have) { Hc = pd_hash(a, xyc); have = true; }
                     if (pd_hash(a, s_lxy[j]) == Hc) { hit = true; break; }
